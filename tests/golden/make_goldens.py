@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the UNMODIFIED reference files (authoring container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+Puts ``oracle/shims`` (stand-ins for torch_geometric / GCL / lightning / torchmetrics /
+omegaconf, built on the oracle's restatements) and ``/root/reference`` on ``sys.path``, imports
+the reference's own ``biomedkg`` package, runs it on CPU over small seeded inputs, and records
+inputs + state_dict + the tape of random draws + outputs (loss, embeddings, scores, grads) into
+``tests/golden/*.pt``.  Only these data files are committed; no reference source or bytecode is.
+
+What this pins: the reference's own arithmetic (decoders, fusion modules) and its composition /
+loss wiring (GRACE/GGD/DGI forward, encoder stacking, KGE training_step).  What it cannot pin:
+the arithmetic inside torch_geometric / PyGCL (restated in ``oracle/pyg_ops.py`` /
+``oracle/pygcl_ops.py`` -- parity unpinned, see ``oracle/__init__.py``).
+"""
+import importlib.util
+import os
+import random
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path[:0] = [os.path.join(ROOT, "oracle", "shims"), ROOT, REF]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import pyg_ops, rand as orand  # noqa: E402
+
+
+class Batch:
+    pass
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+class patched_rng:
+    """Route the torch RNG entry points the reference calls directly through the oracle provider."""
+
+    def __enter__(self):
+        self.saved = (torch.rand, torch.randperm, F.dropout)
+        torch.rand = lambda *a, **k: orand.current().coin() if a == (1,) else self.saved[0](*a, **k)
+        torch.randperm = lambda n, **k: orand.current().perm(n)
+        F.dropout = lambda x, p=0.5, training=True, inplace=False: pyg_ops.dropout(x, p, training)
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randperm, F.dropout = self.saved
+        return False
+
+
+def graph(n, e, seed, with_self_loops=True):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if with_self_loops:  # exercise add_remaining_self_loops: a couple of (duplicate) self loops
+        ei[:, 0] = torch.tensor([3, 3])
+        ei[:, 1] = torch.tensor([3, 3])
+        ei[:, 2] = torch.tensor([5, 5])
+    return ei
+
+
+def lm_features(n, m, d, seed):
+    """[n, m, d] features normalised across the modality axis (reference biomedkg/data/node.py:116-117)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, m, d, generator=g)
+    return x / x.norm(dim=1, keepdim=True)
+
+
+def grads_of(module):
+    return {k: p.grad.clone() for k, p in module.named_parameters() if p.grad is not None}
+
+
+def save(name, obj):
+    path = os.path.join(HERE, name + ".pt")
+    torch.save(obj, path)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------- decoders (direct)
+def gen_decoders():
+    from biomedkg.model.decoder import DistMult, TransE
+
+    out = {}
+    for name, cls in (("dismult", DistMult), ("transe", TransE)):
+        seed_all(1)
+        n, d, r, t = 37, 24, 5, 150
+        dec = cls(num_relations=r, hidden_channels=d)
+        z = torch.randn(n, d, requires_grad=True)
+        with torch.no_grad():
+            z[4].zero_()  # TransE eps path: an all-zero row
+        ei = torch.randint(0, n, (2, t))
+        ei[0, 0] = 4
+        et = torch.randint(0, r, (t,))
+        score = dec(z, ei, et)
+        gout = torch.randn(t)
+        score.backward(gout)
+        out[name] = dict(z=z.detach().clone(), edge_index=ei, edge_type=et, rel_emb=dec.rel_emb.detach().clone(),
+                         score=score.detach().clone(), grad_out=gout, grad_z=z.grad.clone(),
+                         grad_rel=dec.rel_emb.grad.clone())
+    save("decoders", out)
+
+
+# --------------------------------------------------------------------------- fusion (direct)
+def gen_fusion():
+    from biomedkg.utils.fusion import AttentionFusion, ReDAF
+
+    out = {}
+    seed_all(2)
+    n, d = 29, 48
+    x = lm_features(n, 2, d, 3)
+    att = AttentionFusion(embed_dim=d)
+    out["attention"] = dict(x=x, state=att.state_dict(), y=att(x).detach().clone())
+    red = ReDAF(embed_dim=d)
+    with torch.no_grad():
+        red.modal_weights.uniform_(0.5, 1.5)
+    red.eval()
+    out["redaf_eval"] = dict(x=x, state=red.state_dict(), y=red(x).detach().clone())
+    red.train()
+    tape = orand.TapeRand()
+    saved = red.dropout.forward
+    red.dropout.forward = lambda t: pyg_ops.dropout(t, 0.1, True)
+    with orand.use(tape):
+        y = red(x)
+    red.dropout.forward = saved
+    out["redaf_train"] = dict(x=x, state=red.state_dict(), y=y.detach().clone(), tape=tape.tape)
+    save("fusion", out)
+
+
+# --------------------------------------------------------------------------- GCL modules
+def gen_gcl():
+    from biomedkg.gcl_module import DGIModule, GGDModule, GRACEModule
+
+    out = {}
+    n, e, d_in, h = 48, 220, 32, 16
+    cases = [
+        ("grace_attention", GRACEModule, "attention", 11),
+        ("grace_none", GRACEModule, "none", 12),
+        ("ggd_redaf", GGDModule, "redaf", 13),
+        ("ggd_none_a", GGDModule, "none", 14),
+        ("ggd_none_b", GGDModule, "none", 15),
+        ("dgi_attention", DGIModule, "attention", 16),
+        ("dgi_none", DGIModule, "none", 17),
+    ]
+    coins = set()
+    for name, cls, fuse, seed in cases:
+        seed_all(seed)
+        mod = cls(in_dim=d_in, hidden_dim=h, out_dim=h, num_hidden_layers=2, fuse_method=fuse)
+        mod.train()
+        if fuse == "redaf":  # route nn.Dropout through the tape as well
+            drop = mod.modality_transform.dropout
+            drop.forward = lambda t, drop=drop: pyg_ops.dropout(t, 0.1, drop.training)
+        for p in mod.model.encoder.graph_layers:  # non-zero biases so the +bias term is exercised
+            with torch.no_grad():
+                p.bias.uniform_(-0.1, 0.1)
+        b = Batch()
+        b.x = lm_features(n, 2, d_in, seed)
+        b.edge_index = graph(n, e, seed)
+        tape = orand.TapeRand()
+        with patched_rng(), orand.use(tape):
+            loss = mod.training_step(b)
+        loss.backward()
+        with torch.no_grad():
+            mod.eval()
+            z_eval = mod(b.x, b.edge_index)  # BaseGCL.forward (gcl_module.py:55-58), dropout off
+            mod.train()
+        if name.startswith("ggd"):
+            coins.add(bool(tape.tape[1 if fuse == "redaf" else 0][1].item() < 0.5))
+        out[name] = dict(kind=cls.__name__, fuse_method=fuse, hparams=dict(in_dim=d_in, hidden_dim=h, out_dim=h,
+                         num_hidden_layers=2), x=b.x, edge_index=b.edge_index,
+                         state=mod.state_dict(), tape=tape.tape, loss=loss.detach().clone(),
+                         grads=grads_of(mod.model), z_eval=z_eval)
+    assert coins == {True, False}, f"GGD cases must cover both coin outcomes, got {coins}"
+    save("gcl_steps", out)
+
+
+# --------------------------------------------------------------------------- KGE module
+def gen_kge():
+    from biomedkg.kge_module import KGEModule
+
+    out = {}
+    n, e, r, h = 40, 180, 4, 16
+    cases = [
+        ("rgcn_dismult_random", "dismult", "random", "none", 32, 1, None, 21),
+        ("rgcn_dismult_neg3", "dismult", "random", "none", 32, 3, None, 22),
+        ("rgcn_transe_lm_attention", "transe", "lm", "attention", 32, 2, None, 23),
+        ("rgcn_transe_gcl_fixid", "transe", "gcl", "none", 16, 2, 1, 24),
+    ]
+    for name, dec, init, fuse, d_in, neg_ratio, fix_id, seed in cases:
+        seed_all(seed)
+        mod = KGEModule(encoder_name="rgcn", decoder_name=dec, in_dim=d_in, hidden_dim=h, out_dim=h,
+                        num_hidden_layers=2, num_relation=r, num_heads=2, scheduler_type="cosine",
+                        learning_rate=1e-3, warm_up_ratio=0.2, fuse_method=fuse, neg_ratio=neg_ratio,
+                        node_init_method=init)
+        mod.train()
+        for p in mod.model.encoder.graph_layers:
+            with torch.no_grad():
+                p.bias.uniform_(-0.1, 0.1)
+        if fix_id is not None:
+            mod.fix_edge_id = fix_id
+        b = Batch()
+        if init == "lm":
+            b.x = lm_features(n, 2, d_in, seed)
+        elif init == "gcl":
+            b.x = torch.randn(n, 1, d_in)
+        else:
+            b.x = torch.randn(n, d_in)
+        b.edge_index = graph(n, e, seed)
+        b.edge_type = torch.randint(0, r, (e,))
+        b.edge_type[b.edge_type == 2] = 3  # relation 2 is empty: mean over nothing -> 0
+        edge_type_in = b.edge_type.clone()
+        rec = {}
+        enc, dec_fn = mod.model.encode, mod.model.decode
+
+        def encode(*a):
+            rec["z"] = enc(*a)
+            rec["z"].retain_grad()
+            return rec["z"]
+
+        def decode(*a):
+            rec.setdefault("pred", []).append(dec_fn(*a))
+            return rec["pred"][-1]
+
+        mod.model.encode, mod.model.decode = encode, decode
+        tape = orand.TapeRand()
+        with patched_rng(), orand.use(tape):
+            loss = mod.training_step(b)
+        loss.backward()
+        mod.model.encode, mod.model.decode = enc, dec_fn
+        out[name] = dict(hparams=dict(encoder_name="rgcn", decoder_name=dec, in_dim=d_in, hidden_dim=h, out_dim=h,
+                         num_hidden_layers=2, num_relation=r, num_heads=2, scheduler_type="cosine",
+                         learning_rate=1e-3, warm_up_ratio=0.2, fuse_method=fuse, neg_ratio=neg_ratio,
+                         node_init_method=init), fix_edge_id=fix_id, x=b.x, edge_index=b.edge_index,
+                         edge_type=edge_type_in, state={k: v for k, v in mod.state_dict().items()},
+                         tape=tape.tape, loss=loss.detach().clone(), z=rec["z"].detach().clone(),
+                         grad_z=rec["z"].grad.clone(), pos_pred=rec["pred"][0].detach().clone(),
+                         neg_pred=rec["pred"][1].detach().clone(), grads=grads_of(mod.model))
+    save("kge_steps", out)
+
+
+# --------------------------------------------------------------------------- metric
+def gen_metric():
+    from biomedkg.utils.metrics import EdgeWisePrecision
+
+    seed_all(5)
+    mapping = {0: "a_b", 1: "b_c", 2: "c_d"}
+    m = EdgeWisePrecision(class_mapping=mapping)
+    preds = torch.randn(200) + 0.5
+    target = torch.randint(0, 2, (200,))  # class 2 never appears -> 0.0
+    m.update(preds[:120], target[:120])
+    m.update(preds[120:], target[120:])
+    save("edge_wise_precision", dict(mapping=mapping, preds=preds, target=target, result=m.compute()))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        raise SystemExit("the reference is only mounted in the authoring container")
+    gen_decoders()
+    gen_fusion()
+    gen_gcl()
+    gen_kge()
+    gen_metric()
+    # the reference tree must stay clean
+    assert not any("__pycache__" in d for d, _, _ in os.walk(REF)), "left bytecode in /root/reference"
