@@ -1,0 +1,86 @@
+"""ctypes binding of ``libbiomedkg_hip.so`` -- the C-ABI boundary declared in
+``include/biomedkg_hip.h``.  There is no fallback: if the library is missing, or a call returns
+non-zero, this raises.  torch only supplies device memory (``tensor.data_ptr()``) and the stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbiomedkg_hip.so")
+
+P = c_void_p
+I32, I64, U32, U64, F32 = c_int32, c_int64, c_uint32, c_uint64, c_float
+
+# name -> (restype, argtypes); mirrors include/biomedkg_hip.h one to one.
+SIGNATURES = {
+    "bkg_abi_version": (c_int32, []),
+    "bkg_last_error": (ctypes.c_char_p, []),
+    # graph.hip
+    "bkg_sort_workspace_bytes": (I64, [I64]),
+    "bkg_sort_edges": (I32, [P, P, I64, I64, I64, P, P, P, P, P, I64, P]),
+    "bkg_lower_bound_u32": (I32, [P, I64, I64, U32, P, P]),
+    "bkg_gather_i64_to_i32": (I32, [P, P, P, I64, P]),
+    "bkg_gather_i32": (I32, [P, P, P, I64, P]),
+    "bkg_gather_f32": (I32, [P, P, P, I64, P]),
+    "bkg_gcn_norm": (I32, [P, P, P, P, P, P, I64, I64, P, P, P, P]),
+    "bkg_rgcn_segments": (I32, [P, I64, I64, P, P, P, P, P, P, P, P, P, I64, P]),
+    # spmm.hip
+    "bkg_spmm_csr_f32": (I32, [P, P, P, P, I64, P, I64, I64, I32, P, P, I64, P, I32, P, F32, U64, U32, P]),
+    # gemm_f32.hip
+    "bkg_gemm_f32": (I32, [I32, I32, I64, I64, I64, F32, P, I64, P, I64, F32, P, I64, P, I32, P, I64, F32, P]),
+    "bkg_gemm_grouped_rows_f32": (I32, [I32, I64, I64, I64, P, I64, P, I64, I64, P, I64, P, I32, P, I64, F32, P]),
+    "bkg_gemm_grouped_k_f32": (I32, [I64, I64, I64, P, I64, P, I64, P, I64, I64, P, I32, P]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(biomedkg_amd has no CPU / eager fallback)"
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise HipLibraryError(f"{name} failed ({rc}): {lib().bkg_last_error().decode()}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipLibraryError(
+                "biomedkg_amd runs on MI355X only: got a CPU tensor (there is no CPU fallback; "
+                "the CPU restatement lives in oracle/ and is test infrastructure)"
+            )

@@ -1,0 +1,63 @@
+// Shared device/host helpers for the biomedkg HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BKG_WAVE 64
+
+namespace bkg {
+
+// Last error text for bkg_last_error(); set by the launch wrappers.
+void set_error(const char* what, hipError_t e);
+void set_error_msg(const char* what);
+
+static inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(what, e);
+    return (int)e;
+  }
+  return 0;
+}
+
+#define BKG_ARG(cond, msg)          \
+  do {                              \
+    if (!(cond)) {                  \
+      bkg::set_error_msg(msg);      \
+      return -1;                    \
+    }                               \
+  } while (0)
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- Philox4x32-7 (counter RNG)
+// Used for dropout / feature-mask / edge-mask keep decisions generated inside kernels so that
+// the forward and the backward pass can regenerate the same decision from (seed, element id)
+// without a mask ever touching HBM.
+__device__ __forceinline__ uint4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+// keep decision for 4 consecutive elements starting at (4-aligned) linear element id `e`:
+// element kept iff u32 >= thresh, thresh = p * 2^32.
+__device__ __forceinline__ uint4 philox_keep4(uint64_t seed, uint64_t e, uint32_t stream_id) {
+  uint64_t q = e >> 2;
+  return philox4x32((uint32_t)q, (uint32_t)(q >> 32), stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace bkg

@@ -1,0 +1,299 @@
+// Exact-fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate,
+// bit-for-bit a k-ordered fmaf chain), with the epilogues the GCL / KGE hot path needs fused in:
+//   C = epi(alpha * op(A) @ op(B))      epi: + bias[col], ReLU / ELU, * gate(aux), + beta * C_old
+// Used for GCNConv.lin (encoder.py:155,160 -> PyG Linear), the GRACE / GGD / DGI projection heads
+// (gcl.py:19-21,49-51,86-90), the fusion projections (fusion.py:17-20,70) and, in its grouped
+// forms, RGCNConv's per-relation weight products.
+//
+// Layout: op(A) is [M,K], op(B) is [K,N], C is [M,N] row-major.  TA: A is stored [K,M]; TB: B is
+// stored [N,K] (a torch Linear weight).  Block = 256 threads = 4 waves in a 2x2 grid, each wave
+// owning a (BM/2)x(BN/2) patch as 32x32 MFMA tiles.  Operand tiles are staged through LDS
+// K-major ([BK][BM+4]) so that both fragments are conflict-free ds_read_b32 (lane -> consecutive
+// address) regardless of the global orientation; global loads are 16 B/lane where alignment
+// allows.  The next K-tile's global loads are issued before the MFMAs of the current one.
+//
+// Grouped forms (RGCNConv): rows of A / C are partitioned into G groups by a device-side
+// group_ptr; group g multiplies by its own B_g.  `grouped rows` (C_g = A_g B_g) and `grouped K`
+// (C_g += A_g^T B_g, split-K over row chunks, f32 atomics into a zeroed C) need no host sync.
+#include "common.h"
+
+namespace bkg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmEpilogue {
+  float alpha;
+  float beta;         // C = ... + beta * C_old (0 -> C_old never read)
+  const float* bias;  // [N] or null
+  int act;            // 0 none, 1 relu, 2 elu(alpha=1)
+  const float* gate;  // [M, ldg] or null: C *= (gate > 0 ? gate_scale : 0)   (ReLU+dropout backward)
+  int64_t ldg;
+  float gate_scale;
+  int atomic;         // 1: atomicAdd into C (split-K)
+};
+
+constexpr int BK = 16;
+constexpr int PAD = 4;
+
+// Load 4 consecutive elements along the contiguous dimension with bounds / alignment guards.
+__device__ __forceinline__ float4 load4(const float* __restrict__ base, int64_t ld, int r, int c, int R, int C,
+                                        bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < R) {
+    const float* p = base + (int64_t)r * ld + c;
+    if (vec && c + 3 < C) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else {
+      if (c < C) v.x = p[0];
+      if (c + 1 < C) v.y = p[1];
+      if (c + 2 < C) v.z = p[2];
+      if (c + 3 < C) v.w = p[3];
+    }
+  }
+  return v;
+}
+
+// Stage one operand tile.  `contig_is_k`: the stored matrix is [rows = tile dim (M or N), cols = K].
+// Otherwise it is [rows = K, cols = tile dim].  LDS image is always [BK][BT+PAD].
+template <int BT, bool CONTIG_IS_K>
+struct Stager {
+  static constexpr int NV = (BT * BK / 4) / 256;  // float4 per thread
+  float4 reg[NV];
+
+  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int t0, int k0, int T, int K,
+                                       bool vec) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = threadIdx.x + i * 256;
+      if (CONTIG_IS_K) {
+        int r = f / (BK / 4), kc = f % (BK / 4);
+        reg[i] = load4(base, ld, t0 + r, k0 + kc * 4, T, K, vec);
+      } else {
+        int kr = f / (BT / 4), tc = f % (BT / 4);
+        reg[i] = load4(base, ld, k0 + kr, t0 + tc * 4, K, T, vec);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float (*lds)[BT + PAD]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int f = threadIdx.x + i * 256;
+      if (CONTIG_IS_K) {
+        int r = f / (BK / 4), kc = f % (BK / 4);
+        lds[kc * 4 + 0][r] = reg[i].x;
+        lds[kc * 4 + 1][r] = reg[i].y;
+        lds[kc * 4 + 2][r] = reg[i].z;
+        lds[kc * 4 + 3][r] = reg[i].w;
+      } else {
+        int kr = f / (BT / 4), tc = f % (BT / 4);
+        *reinterpret_cast<float4*>(&lds[kr][tc * 4]) = reg[i];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                          int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                          int m0, int n0, int kbeg, int kend, const GemmEpilogue& ep, bool vecA,
+                                          bool vecB) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  __shared__ float As[BK][BM + PAD];
+  __shared__ float Bs[BK][BN + PAD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Stager<BM, !TA> sa;  // A stored [M,K] (K contiguous) unless TA
+  Stager<BN, TB> sb;   // B stored [K,N] (N contiguous) unless TB
+  sa.load(A, lda, m0, kbeg, M, kend, vecA);
+  sb.load(B, ldb, n0, kbeg, N, kend, vecB);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();
+    sa.store(As);
+    sb.store(Bs);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      sa.load(A, lda, m0, k0 + BK, M, kend, vecA);
+      sb.load(B, ldb, n0, k0 + BK, N, kend, vecB);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kk + lh][wm0 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kk + lh][wn0 + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + j * 32 + l31;
+      if (col >= N) continue;
+      const float bias = ep.bias ? ep.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= M) continue;
+        float v = ep.alpha * acc[i][j][r] + bias;
+        if (ep.act == 1) v = fmaxf(v, 0.f);
+        else if (ep.act == 2) v = v > 0.f ? v : expm1f(v);
+        if (ep.gate) v = ep.gate[(int64_t)row * ep.ldg + col] > 0.f ? v * ep.gate_scale : 0.f;
+        float* dst = C + (int64_t)row * ldc + col;
+        if (ep.atomic) atomicAdd(dst, v);
+        else {
+          if (ep.beta != 0.f) v = fmaf(ep.beta, *dst, v);
+          *dst = v;
+        }
+      }
+    }
+}
+
+__device__ __forceinline__ bool vec_ok(const float* p, int64_t ld) {
+  return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0);
+}
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ B, int64_t ldb,
+                                                       float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                       GemmEpilogue ep) {
+  // blockIdx.x walks N tiles fastest so that blocks sharing an A row-panel are dispatched together.
+  const int n_tiles = (N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
+  gemm_tile<BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, 0, K, ep, vec_ok(A, lda), vec_ok(B, ldb));
+}
+
+// C_g[rows of group g, :] = A_g @ op(B_g);  B_g = B + g * strideB.  Tiles never straddle groups.
+template <int BM, int BN, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_grouped_rows_kernel(const float* __restrict__ A, int64_t lda,
+                                                                    const float* __restrict__ B, int64_t ldb,
+                                                                    int64_t strideB, float* __restrict__ C,
+                                                                    int64_t ldc, const int32_t* __restrict__ group_ptr,
+                                                                    int G, int N, int K, GemmEpilogue ep) {
+  __shared__ int s_g, s_m0;
+  const int n_tiles = (N + BN - 1) / BN;
+  if (threadIdx.x == 0) {
+    int t = blockIdx.x / n_tiles, g = 0, found = -1, m0 = 0;
+    for (; g < G; ++g) {
+      int rows = group_ptr[g + 1] - group_ptr[g];
+      int nt = (rows + BM - 1) / BM;
+      if (t < nt) { found = g; m0 = group_ptr[g] + t * BM; break; }
+      t -= nt;
+    }
+    s_g = found; s_m0 = m0;
+  }
+  __syncthreads();
+  const int g = s_g;
+  if (g < 0) return;
+  const int m0 = s_m0, mend = group_ptr[g + 1];
+  const float* Bg = B + (int64_t)g * strideB;
+  gemm_tile<BM, BN, false, TB>(A, lda, Bg, ldb, C, ldc, mend, N, K, m0, (blockIdx.x % n_tiles) * BN, 0, K, ep,
+                               vec_ok(A, lda), vec_ok(Bg, ldb));
+}
+
+// C_g += A_g^T @ B_g over the rows of group g (K dimension = rows), split into chunks of KCHUNK
+// rows; C_g = C + g * strideC is [M = colsA, N = colsB] and must be zeroed by the caller.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const float* __restrict__ A, int64_t lda,
+                                                                 const float* __restrict__ B, int64_t ldb,
+                                                                 float* __restrict__ C, int64_t ldc, int64_t strideC,
+                                                                 const int32_t* __restrict__ group_ptr, int G, int M,
+                                                                 int N, int kchunk, GemmEpilogue ep) {
+  __shared__ int s_g, s_k0;
+  const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
+  const int tiles = m_tiles * n_tiles;
+  if (threadIdx.x == 0) {
+    int t = blockIdx.x / tiles, g = 0, found = -1, k0 = 0;
+    for (; g < G; ++g) {
+      int rows = group_ptr[g + 1] - group_ptr[g];
+      int nc = (rows + kchunk - 1) / kchunk;
+      if (t < nc) { found = g; k0 = group_ptr[g] + t * kchunk; break; }
+      t -= nc;
+    }
+    s_g = found; s_k0 = k0;
+  }
+  __syncthreads();
+  const int g = s_g;
+  if (g < 0) return;
+  const int k0 = s_k0;
+  const int kend = min(k0 + kchunk, group_ptr[g + 1]);
+  const int tile = blockIdx.x % tiles;
+  float* Cg = C + (int64_t)g * strideC;
+  // op(A) = A^T: stored [K(rows), M] ; op(B) = B stored [K(rows), N]
+  gemm_tile<BM, BN, true, false>(A, lda, B, ldb, Cg, ldc, M, N, kend, (tile / n_tiles) * BM, (tile % n_tiles) * BN, k0,
+                                 kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
+}
+
+template <int BM, int BN>
+static void launch_gemm(bool ta, bool tb, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                        int64_t ldc, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
+  dim3 grid(ceil_div(M, BM) * ceil_div(N, BN)), block(256);
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
+}
+
+}  // namespace bkg
+
+using namespace bkg;
+
+extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, float alpha,
+                            const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
+                            int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg,
+                            float gate_scale, void* stream) {
+  BKG_ARG(M >= 0 && N >= 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "bkg_gemm_f32: bad shape");
+  BKG_ARG(act >= 0 && act <= 2, "bkg_gemm_f32: bad act");
+  if (M == 0 || N == 0) return 0;
+  GemmEpilogue ep{alpha, beta, bias, act, gate, ldg, gate_scale, 0};
+  hipStream_t s = (hipStream_t)stream;
+  // big tiles once they fill the chip, small tiles otherwise
+  if ((M / 128) * ((N + 127) / 128) >= 256) launch_gemm<128, 128>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);
+  else launch_gemm<64, 64>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);
+  return check_launch("bkg_gemm_f32");
+}
+
+extern "C" int bkg_gemm_grouped_rows_f32(int32_t trans_b, int64_t M_total, int64_t N, int64_t K, const float* A,
+                                         int64_t lda, const float* B, int64_t ldb, int64_t strideB, float* C,
+                                         int64_t ldc, const int32_t* group_ptr, int32_t G, const float* gate,
+                                         int64_t ldg, float gate_scale, void* stream) {
+  BKG_ARG(M_total >= 0 && N > 0 && K > 0 && G > 0, "bkg_gemm_grouped_rows_f32: bad shape");
+  if (M_total == 0) return 0;
+  GemmEpilogue ep{1.f, 0.f, nullptr, 0, gate, ldg, gate_scale, 0};
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int BM = 128, BN = 128;
+  dim3 grid((ceil_div(M_total, BM) + G) * ceil_div(N, BN)), block(256);
+  if (trans_b) hipLaunchKernelGGL((gemm_f32_grouped_rows_kernel<BM, BN, true>), grid, block, 0, s, A, lda, B, ldb, strideB, C, ldc, group_ptr, G, (int)N, (int)K, ep);
+  else hipLaunchKernelGGL((gemm_f32_grouped_rows_kernel<BM, BN, false>), grid, block, 0, s, A, lda, B, ldb, strideB, C, ldc, group_ptr, G, (int)N, (int)K, ep);
+  return check_launch("bkg_gemm_grouped_rows_f32");
+}
+
+extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, const float* A, int64_t lda,
+                                      const float* B, int64_t ldb, float* C, int64_t ldc, int64_t strideC,
+                                      const int32_t* group_ptr, int32_t G, void* stream) {
+  BKG_ARG(rows_total >= 0 && M > 0 && N > 0 && G > 0, "bkg_gemm_grouped_k_f32: bad shape");
+  if (rows_total == 0) return 0;
+  GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int BM = 128, BN = 128, KCHUNK = 2048;
+  dim3 grid((ceil_div(rows_total, KCHUNK) + G) * ceil_div(M, BM) * ceil_div(N, BN)), block(256);
+  hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
+  return check_launch("bkg_gemm_grouped_k_f32");
+}

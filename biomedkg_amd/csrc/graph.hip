@@ -1,0 +1,207 @@
+// Graph preparation on device: COO (int64 edge_index, as handed over by the reference's batch
+// contract -- SURVEY.md 8b) -> destination-sorted int32 CSR pieces, GCN normalisation weights
+// (PyG gcn_norm / add_remaining_self_loops semantics) and R-GCN (relation, destination) segments.
+// Stable LSD radix sort (rocPRIM) keeps equal-key edges in input order, so every segment sum that
+// follows has a fixed, input-determined order (bitwise reproducible; no atomics anywhere here).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace bkg {
+
+__global__ void make_keys_kernel(const int64_t* __restrict__ lo, const int64_t* __restrict__ hi, int64_t n_lo,
+                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ iota, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t k = lo[i] + (hi ? hi[i] * n_lo : 0);
+  keys[i] = (uint32_t)k;
+  iota[i] = (uint32_t)i;
+}
+
+// out[s] = first position p in sorted[0..n) with sorted[p] >= s * stride   (s in [0, n_q))
+__global__ void lower_bound_kernel(const uint32_t* __restrict__ sorted, int64_t n, int64_t n_q, uint32_t stride,
+                                   int32_t* __restrict__ out) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_q) return;
+  uint64_t q = (uint64_t)s * stride;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((uint64_t)sorted[mid] < q) lo = mid + 1; else hi = mid;
+  }
+  out[s] = (int32_t)lo;
+}
+
+__global__ void gather_i64_to_i32_kernel(const int64_t* __restrict__ src, const uint32_t* __restrict__ idx,
+                                         int32_t* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)src[idx[i]];
+}
+
+__global__ void gather_i32_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ idx,
+                                  int32_t* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+
+__global__ void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                  float* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+
+// ---- GCN normalisation (PyG gcn_norm) over the dst-sorted CSR.
+// deg[i] = 1 (the one unit self loop) + #{in-edges k of i : src != i and kept}.
+__global__ void gcn_degree_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                  const int32_t* __restrict__ perm, const uint8_t* __restrict__ keep, int n,
+                                  float* __restrict__ dis, float* __restrict__ self_w) {
+  const int lane = threadIdx.x & 63;
+  int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= n) return;
+  int cnt = 0;
+  for (int k = rowptr[row] + lane; k < rowptr[row + 1]; k += 64)
+    cnt += (col[k] != row) && (!keep || keep[perm[k]]);
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane == 0) {
+    float d = 1.0f / sqrtf((float)(cnt + 1));
+    dis[row] = d;
+    self_w[row] = d * d;
+  }
+}
+
+// w_edge[e] (original edge order) = kept && src != dst ? dis[src] * dis[dst] : 0
+__global__ void gcn_edge_weight_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                       const uint8_t* __restrict__ keep, const float* __restrict__ dis, int64_t n,
+                                       float* __restrict__ w_edge) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  int64_t s = src[e], d = dst[e];
+  w_edge[e] = (s != d && (!keep || keep[e])) ? dis[s] * dis[d] : 0.f;
+}
+
+// ---- R-GCN (relation, dst) segments over edges sorted by key = rel * N + dst.
+__global__ void segment_flags_kernel(const uint32_t* __restrict__ sorted, int64_t n, int32_t* __restrict__ flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
+}
+
+// seg_of[k] = inclusive_scan(flag)[k] - 1 ; at each segment head record start + key.
+__global__ void segment_fill_kernel(const uint32_t* __restrict__ sorted, const int32_t* __restrict__ scan, int64_t n,
+                                    uint32_t n_lo, int32_t* __restrict__ seg_of, int32_t* __restrict__ seg_ptr,
+                                    int32_t* __restrict__ seg_dst, int32_t* __restrict__ seg_rel,
+                                    int32_t* __restrict__ n_seg_out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int s = scan[i] - 1;
+  seg_of[i] = s;
+  if (i == 0 || sorted[i] != sorted[i - 1]) {
+    seg_ptr[s] = (int32_t)i;
+    seg_dst[s] = (int32_t)(sorted[i] % n_lo);
+    seg_rel[s] = (int32_t)(sorted[i] / n_lo);
+  }
+  if (i == n - 1) {
+    seg_ptr[s + 1] = (int32_t)n;
+    *n_seg_out = s + 1;
+  }
+}
+
+// per sorted edge: w[k] = 1 / (size of its segment)
+__global__ void segment_inv_count_kernel(const int32_t* __restrict__ seg_of, const int32_t* __restrict__ seg_ptr,
+                                         int64_t n, float* __restrict__ w) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int s = seg_of[i];
+  w[i] = 1.0f / (float)(seg_ptr[s + 1] - seg_ptr[s]);
+}
+
+static inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+
+}  // namespace bkg
+
+using namespace bkg;
+
+// ----------------------------------------------------------------------------- sort
+extern "C" int64_t bkg_sort_workspace_bytes(int64_t n) {
+  size_t bytes = 0;
+  uint32_t* p = nullptr;
+  rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)n, 0, 32, (hipStream_t)0);
+  size_t scan_bytes = 0;
+  int32_t* q = nullptr;
+  rocprim::inclusive_scan(nullptr, scan_bytes, q, q, (size_t)n, rocprim::plus<int32_t>(), (hipStream_t)0);
+  return (int64_t)(bytes > scan_bytes ? bytes : scan_bytes) + 256;
+}
+
+// keys = lo[i] + hi[i] * n_lo (hi nullable); stable sort; outputs sorted keys + permutation.
+extern "C" int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n,
+                              uint32_t* keys_tmp, uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+  BKG_ARG(n >= 0 && n_lo > 0 && n_hi > 0, "bkg_sort_edges: bad sizes");
+  BKG_ARG((double)n_lo * (double)n_hi < 4294967296.0, "bkg_sort_edges: key space exceeds 32 bits");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(make_keys_kernel, grid1(n), dim3(256), 0, s, lo, hi, n_lo, keys_tmp, iota_tmp, n);
+  uint64_t space = (uint64_t)n_lo * (uint64_t)n_hi;
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < space) ++bits;
+  size_t bytes = (size_t)workspace_bytes;
+  hipError_t e = rocprim::radix_sort_pairs(workspace, bytes, keys_tmp, sorted_keys, iota_tmp, perm, (size_t)n, 0, bits, s);
+  if (e != hipSuccess) { set_error("bkg_sort_edges: radix_sort_pairs", e); return (int)e; }
+  return check_launch("bkg_sort_edges");
+}
+
+extern "C" int bkg_lower_bound_u32(const uint32_t* sorted, int64_t n, int64_t n_queries, uint32_t stride,
+                                   int32_t* out, void* stream) {
+  if (n_queries == 0) return 0;
+  hipLaunchKernelGGL(lower_bound_kernel, grid1(n_queries), dim3(256), 0, (hipStream_t)stream, sorted, n, n_queries, stride, out);
+  return check_launch("bkg_lower_bound_u32");
+}
+
+extern "C" int bkg_gather_i64_to_i32(const int64_t* src, const uint32_t* idx, int32_t* out, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gather_i64_to_i32_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, src, idx, out, n);
+  return check_launch("bkg_gather_i64_to_i32");
+}
+
+extern "C" int bkg_gather_i32(const int32_t* src, const int32_t* idx, int32_t* out, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gather_i32_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, src, idx, out, n);
+  return check_launch("bkg_gather_i32");
+}
+
+extern "C" int bkg_gather_f32(const float* src, const int32_t* idx, float* out, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gather_f32_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, src, idx, out, n);
+  return check_launch("bkg_gather_f32");
+}
+
+// ----------------------------------------------------------------------------- GCN norm
+extern "C" int bkg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int64_t* src,
+                            const int64_t* dst, const uint8_t* keep, int64_t n_nodes, int64_t n_edges, float* dis,
+                            float* self_w, float* w_edge, void* stream) {
+  BKG_ARG(n_nodes >= 0 && n_edges >= 0, "bkg_gcn_norm: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (n_nodes) hipLaunchKernelGGL(gcn_degree_kernel, grid1(n_nodes * 64), dim3(256), 0, s, rowptr, col, perm, keep, (int)n_nodes, dis, self_w);
+  if (n_edges) hipLaunchKernelGGL(gcn_edge_weight_kernel, grid1(n_edges), dim3(256), 0, s, src, dst, keep, dis, n_edges, w_edge);
+  return check_launch("bkg_gcn_norm");
+}
+
+// ----------------------------------------------------------------------------- R-GCN segments
+// sorted: edge keys (rel * N + dst) ascending.  Outputs: seg_of[E], seg_ptr[<=E+1], seg_dst/seg_rel[<=E],
+// inv_cnt[E] (per sorted edge), n_seg (device int32).  flag_tmp/scan_tmp: int32[E] scratch.
+extern "C" int bkg_rgcn_segments(const uint32_t* sorted, int64_t n, int64_t n_nodes, int32_t* flag_tmp,
+                                 int32_t* scan_tmp, int32_t* seg_of, int32_t* seg_ptr, int32_t* seg_dst,
+                                 int32_t* seg_rel, float* inv_cnt, int32_t* n_seg, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) { hipMemsetAsync(n_seg, 0, sizeof(int32_t), s); return 0; }
+  hipLaunchKernelGGL(segment_flags_kernel, grid1(n), dim3(256), 0, s, sorted, n, flag_tmp);
+  size_t bytes = (size_t)workspace_bytes;
+  hipError_t e = rocprim::inclusive_scan(workspace, bytes, flag_tmp, scan_tmp, (size_t)n, rocprim::plus<int32_t>(), s);
+  if (e != hipSuccess) { set_error("bkg_rgcn_segments: inclusive_scan", e); return (int)e; }
+  hipLaunchKernelGGL(segment_fill_kernel, grid1(n), dim3(256), 0, s, sorted, scan_tmp, n, (uint32_t)n_nodes, seg_of, seg_ptr, seg_dst, seg_rel, n_seg);
+  hipLaunchKernelGGL(segment_inv_count_kernel, grid1(n), dim3(256), 0, s, seg_of, seg_ptr, n, inv_cnt);
+  return check_launch("bkg_rgcn_segments");
+}

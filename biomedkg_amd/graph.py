@@ -1,0 +1,166 @@
+"""Device-side graph structures behind GCNConv / RGCNConv / the KGE scorer backward.
+
+The reference hands over ``edge_index [2,E] int64`` (row 0 = source, row 1 = target) and
+``edge_type [E] int64`` per batch (SURVEY.md 8b batch contract).  Internally the HIP kernels want
+destination-sorted int32 CSR (forward) and source-sorted CSR (backward), built once per distinct
+edge set and cached on the ``edge_index`` tensor object itself (invalidated by ``_version``).
+All index work runs in ``csrc/graph.hip``; this file only owns the buffers.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _i32(n, device):
+    return torch.empty(max(int(n), 0), dtype=torch.int32, device=device)
+
+
+class _Sorter:
+    """Stable radix sort of 32-bit keys ``lo + hi * n_lo`` carrying the original positions."""
+
+    @staticmethod
+    def sort(lo, hi, n_lo, n_hi):
+        L.require_cuda(lo, hi)
+        n = lo.numel()
+        dev = lo.device
+        ws_bytes = L.lib().bkg_sort_workspace_bytes(max(n, 1))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        keys_tmp, iota_tmp, sorted_keys, perm = (_i32(n, dev) for _ in range(4))
+        L.call("bkg_sort_edges", L.ptr(lo), L.ptr(hi), n_lo, n_hi, n, L.ptr(keys_tmp), L.ptr(iota_tmp),
+               L.ptr(sorted_keys), L.ptr(perm), L.ptr(ws), ws_bytes, L.stream())
+        return sorted_keys, perm, ws
+
+
+class CSR:
+    """``rowptr [n_rows+1]``, ``col [nnz]`` (the other endpoint), ``perm [nnz]`` (original position)."""
+
+    def __init__(self, key, other, n_rows):
+        key = key.contiguous()
+        other = other.contiguous()
+        dev = key.device
+        self.n_rows, self.nnz = int(n_rows), key.numel()
+        self.sorted_keys, self.perm, _ = _Sorter.sort(key, None, n_rows, 1)
+        self.rowptr = _i32(n_rows + 1, dev)
+        L.call("bkg_lower_bound_u32", L.ptr(self.sorted_keys), self.nnz, n_rows + 1, 1, L.ptr(self.rowptr), L.stream())
+        self.col = _i32(self.nnz, dev)
+        L.call("bkg_gather_i64_to_i32", L.ptr(other), L.ptr(self.perm), L.ptr(self.col), self.nnz, L.stream())
+
+    def permute_f32(self, v_edge):
+        """Values given in original edge order -> this CSR's order."""
+        out = torch.empty(self.nnz, dtype=torch.float32, device=v_edge.device)
+        L.call("bkg_gather_f32", L.ptr(v_edge), L.ptr(self.perm), L.ptr(out), self.nnz, L.stream())
+        return out
+
+
+class GcnWeights:
+    """gcn_norm result for one (graph, keep mask): weights in both CSR orders + self-loop weight."""
+
+    __slots__ = ("w_dst", "w_src", "self_w")
+
+    def __init__(self, w_dst, w_src, self_w):
+        self.w_dst, self.w_src, self.self_w = w_dst, w_src, self_w
+
+
+class Graph:
+    """Homogeneous message-passing graph (GCNConv).  ``num_nodes`` = rows of x."""
+
+    def __init__(self, edge_index, num_nodes):
+        L.require_cuda(edge_index)
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError("edge_index must be int64 [2, E]")
+        self.edge_index = edge_index.contiguous()
+        self.num_nodes, self.num_edges = int(num_nodes), edge_index.size(1)
+        self.src, self.dst = self.edge_index[0], self.edge_index[1]
+        self.by_dst = CSR(self.dst, self.src, num_nodes)   # rows = targets, col = sources  (forward)
+        self.by_src = CSR(self.src, self.dst, num_nodes)   # rows = sources, col = targets  (backward)
+        self._plain = None
+
+    def gcn_weights(self, keep=None) -> GcnWeights:
+        """``keep``: optional uint8/bool ``[E]`` dropout_edge mask in original edge order."""
+        if keep is None and self._plain is not None:
+            return self._plain
+        dev = self.edge_index.device
+        if keep is not None:
+            keep = keep.to(torch.uint8).contiguous()
+        dis = torch.empty(self.num_nodes, dtype=torch.float32, device=dev)
+        self_w = torch.empty_like(dis)
+        w_edge = torch.empty(self.num_edges, dtype=torch.float32, device=dev)
+        c = self.by_dst
+        L.call("bkg_gcn_norm", L.ptr(c.rowptr), L.ptr(c.col), L.ptr(c.perm), L.ptr(self.src), L.ptr(self.dst),
+               L.ptr(keep), self.num_nodes, self.num_edges, L.ptr(dis), L.ptr(self_w), L.ptr(w_edge), L.stream())
+        out = GcnWeights(self.by_dst.permute_f32(w_edge), self.by_src.permute_f32(w_edge), self_w)
+        if keep is None:
+            self._plain = out
+        return out
+
+
+class RelGraph:
+    """Relational graph (RGCNConv, aggr="mean"): edges grouped into (relation, target) segments.
+
+    Forward:  H[s] = mean_{e in s} x[src_e]  (spmm over ``seg_ptr``) -> per-relation GEMM -> sum of the
+    segment rows of each target (spmm over ``dst_csr``).  Backward uses ``src_csr`` whose entries
+    point at segments with weight 1/|segment|.
+    """
+
+    def __init__(self, edge_index, edge_type, num_nodes, num_relations):
+        L.require_cuda(edge_index, edge_type)
+        self.edge_index = edge_index.contiguous()
+        self.edge_type = edge_type.contiguous()
+        dev = edge_index.device
+        self.num_nodes, self.num_edges, self.num_relations = int(num_nodes), edge_index.size(1), int(num_relations)
+        n, e, r = self.num_nodes, self.num_edges, self.num_relations
+        src, dst = self.edge_index[0], self.edge_index[1]
+        sorted_keys, perm, ws = _Sorter.sort(dst, self.edge_type, n, r)
+        self.perm = perm
+        self.src_sorted = _i32(e, dev)
+        L.call("bkg_gather_i64_to_i32", L.ptr(src), L.ptr(perm), L.ptr(self.src_sorted), e, L.stream())
+        flag, scan = _i32(e, dev), _i32(e, dev)
+        self.seg_of = _i32(e, dev)              # sorted edge -> segment
+        seg_ptr, seg_dst, seg_rel = _i32(e + 1, dev), _i32(e, dev), _i32(e, dev)
+        self.inv_cnt = torch.empty(e, dtype=torch.float32, device=dev)   # per sorted edge
+        n_seg = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.call("bkg_rgcn_segments", L.ptr(sorted_keys), e, n, L.ptr(flag), L.ptr(scan), L.ptr(self.seg_of),
+               L.ptr(seg_ptr), L.ptr(seg_dst), L.ptr(seg_rel), L.ptr(self.inv_cnt), L.ptr(n_seg), L.ptr(ws),
+               ws.numel(), L.stream())
+        self.num_segments = int(n_seg.item())   # one host sync per distinct graph (sizes H)
+        s = self.num_segments
+        self.seg_ptr, self.seg_dst, self.seg_rel = seg_ptr[: s + 1], seg_dst[:s], seg_rel[:s]
+        # segment ranges per relation (segments are sorted by (rel, dst))
+        self.rel_ptr = _i32(r + 1, dev)
+        seg_rel_u = self.seg_rel.contiguous()
+        L.call("bkg_lower_bound_u32", L.ptr(seg_rel_u), s, r + 1, 1, L.ptr(self.rel_ptr), L.stream())
+        # target -> its segments
+        self.dst_csr = CSR(self.seg_dst.to(torch.int64), torch.arange(s, device=dev), n)
+        # source -> (segment, 1/|segment|) of each out-edge
+        seg_of_edge = torch.empty(e, dtype=torch.int64, device=dev)
+        seg_of_edge[perm.long()] = self.seg_of.long()
+        w_edge = torch.empty(e, dtype=torch.float32, device=dev)
+        w_edge[perm.long()] = self.inv_cnt
+        self.src_csr = CSR(src, seg_of_edge, n)
+        self.src_w = self.src_csr.permute_f32(w_edge)
+        self.seg_iota_ptr = torch.arange(s + 1, dtype=torch.int32, device=dev)
+
+
+def _cached(t, slot, key, build):
+    """One cached object per slot on the tensor object; rebuilt when key or ``_version`` changes."""
+    tag = getattr(t, "_bkg_cache", None)
+    if tag is None:
+        tag = {}
+        t._bkg_cache = tag
+    key = (t._version,) + key
+    hit = tag.get(slot)
+    if hit is None or hit[0] != key:
+        hit = (key, build())
+        tag[slot] = hit
+    return hit[1]
+
+
+def graph_of(edge_index, num_nodes) -> Graph:
+    return _cached(edge_index, "gcn", (int(num_nodes),), lambda: Graph(edge_index, num_nodes))
+
+
+def rel_graph_of(edge_index, edge_type, num_nodes, num_relations) -> RelGraph:
+    key = (int(num_nodes), int(num_relations), edge_type.data_ptr(), edge_type._version)
+    return _cached(edge_index, "rgcn", key, lambda: RelGraph(edge_index, edge_type, num_nodes, num_relations))

@@ -1,0 +1,204 @@
+"""Host-side wrappers (autograd glue) over the C-ABI kernels.  No CPU path: every function
+requires CUDA (HIP) tensors and raises otherwise.  fp32 throughout in this file.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .graph import CSR, Graph, GcnWeights, RelGraph
+
+ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- raw kernels
+def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, gate=None,
+         gate_scale=1.0):
+    """``out = epi(alpha * op(a) @ op(b))``; a/b 2-D row-major fp32 (exact-fp32 MFMA kernel)."""
+    L.require_cuda(a, b, out, bias, gate)
+    a, b = _f32c(a), _f32c(b)
+    m, k = (a.size(1), a.size(0)) if trans_a else (a.size(0), a.size(1))
+    k2, n = (b.size(1), b.size(0)) if trans_b else (b.size(0), b.size(1))
+    if k != k2:
+        raise ValueError(f"gemm shape mismatch: {tuple(a.shape)} x {tuple(b.shape)} (ta={trans_a}, tb={trans_b})")
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    L.call("bkg_gemm_f32", int(trans_a), int(trans_b), m, n, k, alpha, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0),
+           beta, L.ptr(out), out.stride(0), L.ptr(bias), act, L.ptr(gate), gate.stride(0) if gate is not None else 0,
+           gate_scale, L.stream())
+    return out
+
+
+def gemm_grouped_rows(a, b, group_ptr, trans_b=False):
+    """``out[rows of g] = a[rows of g] @ op(b[g])``; ``b`` is ``[G, k, n]`` (or ``[G, n, k]`` if trans_b)."""
+    L.require_cuda(a, b, group_ptr)
+    a, b = _f32c(a), _f32c(b)
+    g = b.size(0)
+    k, n = (b.size(2), b.size(1)) if trans_b else (b.size(1), b.size(2))
+    out = torch.empty(a.size(0), n, dtype=torch.float32, device=a.device)
+    L.call("bkg_gemm_grouped_rows_f32", int(trans_b), a.size(0), n, k, L.ptr(a), a.stride(0), L.ptr(b), b.stride(1),
+           b.stride(0), L.ptr(out), out.stride(0), L.ptr(group_ptr), g, None, 0, 1.0, L.stream())
+    return out
+
+
+def gemm_grouped_k(a, b, group_ptr, num_groups):
+    """``out[g] = a[rows of g]^T @ b[rows of g]`` -> ``[G, a.cols, b.cols]`` (split-K, f32 atomics)."""
+    L.require_cuda(a, b, group_ptr)
+    a, b = _f32c(a), _f32c(b)
+    m, n = a.size(1), b.size(1)
+    out = torch.zeros(num_groups, m, n, dtype=torch.float32, device=a.device)
+    L.call("bkg_gemm_grouped_k_f32", a.size(0), m, n, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), n,
+           m * n, L.ptr(group_ptr), num_groups, L.stream())
+    return out
+
+
+class Dropout:
+    """Dropout request for a kernel epilogue: explicit keep mask (replay) or in-kernel Philox."""
+
+    __slots__ = ("p", "keep", "seed", "stream_id")
+
+    def __init__(self, p, keep=None, seed=0, stream_id=0):
+        self.p, self.keep, self.seed, self.stream_id = float(p), keep, int(seed), int(stream_id)
+
+
+def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=False, drop: Dropout = None):
+    """``out[i] = epi(sum_k w[k] x[col[k]] (+ self_w[i] x[i]) (+ addend[i]))`` (csrc/spmm.hip)."""
+    L.require_cuda(rowptr, col, w, x, self_w, addend, bias)
+    x = _f32c(x)
+    d = x.size(1)
+    out = torch.empty(n_rows, d, dtype=torch.float32, device=x.device)
+    keep, p, seed, sid = None, 0.0, 0, 0
+    if drop is not None and drop.p > 0.0:
+        p, seed, sid = drop.p, drop.seed, drop.stream_id
+        if drop.keep is not None:
+            keep = drop.keep.to(torch.uint8).contiguous()
+            if keep.shape != out.shape:
+                raise ValueError("dropout keep mask shape mismatch")
+    if addend is not None:
+        addend = _f32c(addend)
+    L.call("bkg_spmm_csr_f32", L.ptr(rowptr), L.ptr(col), L.ptr(w), L.ptr(x), x.stride(0), L.ptr(out), out.stride(0),
+           n_rows, d, L.ptr(self_w), L.ptr(addend), addend.stride(0) if addend is not None else 0, L.ptr(bias),
+           int(relu), L.ptr(keep), p, seed, sid, L.stream())
+    return out
+
+
+def _gate(dout, out, scale):
+    """Backward of ``dropout(relu(.))`` from the saved OUTPUT: ``out > 0`` iff pre > 0 and kept."""
+    return torch.where(out > 0, dout * scale, torch.zeros((), dtype=dout.dtype, device=dout.device))
+
+
+# ----------------------------------------------------------------------------- Linear
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        out = gemm(x, weight, trans_b=True, bias=bias, act=act)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, out = ctx.saved_tensors
+        dout = _f32c(dout)
+        if ctx.act == ACT_RELU:
+            dout = _gate(dout, out, 1.0)
+        elif ctx.act == ACT_ELU:  # elu'(pre) = 1 (pre > 0) else elu(pre) + 1
+            dout = torch.where(out > 0, dout, dout * (out + 1.0))
+        dx = gemm(dout, weight) if ctx.needs_input_grad[0] else None
+        dw = gemm(dout, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        db = dout.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE):
+    """``act(x @ weight^T + bias)`` with ``weight [out, in]`` (torch.nn.Linear layout)."""
+    lead = x.shape[:-1]
+    y = _Linear.apply(x.reshape(-1, x.size(-1)), weight, bias, act)
+    return y.reshape(*lead, weight.size(0))
+
+
+# ----------------------------------------------------------------------------- GCNConv
+class _GcnConv(torch.autograd.Function):
+    """``dropout(relu(A_hat (x W^T) + b))`` -- PyG GCNConv + the encoder's ReLU/dropout
+    (reference biomedkg/model/encoder.py:153-162) fused into the aggregation epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, graph: Graph, gw: GcnWeights, relu, drop):
+        xw = gemm(x, weight, trans_b=True)
+        c = graph.by_dst
+        out = spmm(c.rowptr, c.col, gw.w_dst, xw, graph.num_nodes, self_w=gw.self_w, bias=bias, relu=relu, drop=drop)
+        ctx.graph, ctx.gw, ctx.relu = graph, gw, relu
+        ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
+        ctx.gated = relu or ctx.scale != 1.0
+        ctx.save_for_backward(x, weight, out if ctx.gated else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, out = ctx.saved_tensors
+        g, gw = ctx.graph, ctx.gw
+        dout = _f32c(dout)
+        if ctx.gated:
+            dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
+        c = g.by_src
+        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, g.num_nodes, self_w=gw.self_w)
+        dx = gemm(dxw, weight) if ctx.needs_input_grad[0] else None
+        dw = gemm(dxw, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        db = dout.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None, None, None
+
+
+def gcn_conv(x, weight, bias, graph, gw, relu=False, drop=None):
+    L.require_cuda(x, weight, bias)
+    return _GcnConv.apply(_f32c(x), weight, bias, graph, gw, relu, drop)
+
+
+# ----------------------------------------------------------------------------- RGCNConv
+class _RgcnConv(torch.autograd.Function):
+    """``dropout(relu(sum_r mean_{N_r(i)}(x_j) W_r + x_i W_root + b))`` -- PyG RGCNConv
+    + the encoder's ReLU/dropout (reference biomedkg/model/encoder.py:50-59)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop):
+        n = rg.num_nodes
+        h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, x, rg.num_segments)          # [S, in]  segment means
+        y = gemm_grouped_rows(h, weight, rg.rel_ptr)                                  # [S, out] per-relation W_r
+        xr = gemm(x, root)                                                            # [N, out] root term
+        c = rg.dst_csr
+        out = spmm(c.rowptr, c.col, None, y, n, addend=xr, bias=bias, relu=relu, drop=drop)
+        ctx.rg, ctx.relu = rg, relu
+        ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
+        ctx.gated = relu or ctx.scale != 1.0
+        ctx.save_for_backward(x, weight, root, h, out if ctx.gated else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, root, h, out = ctx.saved_tensors
+        rg = ctx.rg
+        dout = _f32c(dout)
+        if ctx.gated:
+            dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
+        dy = spmm(rg.seg_iota_ptr, rg.seg_dst, None, dout, rg.num_segments)          # dY[s] = dOut[dst_s]
+        dweight = gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations) if ctx.needs_input_grad[1] else None
+        droot = gemm(x, dout, trans_a=True) if ctx.needs_input_grad[2] else None
+        db = dout.sum(0) if ctx.needs_input_grad[3] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dh = gemm_grouped_rows(dy, weight, rg.rel_ptr, trans_b=True)              # [S, in]
+            dx_root = gemm(dout, root, trans_b=True)                                  # [N, in]
+            c = rg.src_csr
+            dx = spmm(c.rowptr, c.col, rg.src_w, dh, rg.num_nodes, addend=dx_root)
+        return dx, dweight, droot, db, None, None, None
+
+
+def rgcn_conv(x, weight, root, bias, rg, relu=False, drop=None):
+    L.require_cuda(x, weight, root, bias)
+    return _RgcnConv.apply(_f32c(x), weight, root, bias, rg, relu, drop)

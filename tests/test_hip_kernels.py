@@ -1,0 +1,155 @@
+"""HIP kernels (through the C-ABI) vs. the CPU oracle / fp64 algebra.  Needs an MI355X."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _graph(n, e, seed, self_loops=True):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if self_loops and e >= 3:
+        ei[:, 0] = torch.tensor([3, 3]); ei[:, 1] = torch.tensor([3, 3]); ei[:, 2] = torch.tensor([5, 5])
+    return ei
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(77, 45, 33), (256, 128, 768), (1000, 16, 24), (5, 300, 130), (640, 256, 256)])
+def test_gemm_f32(ta, tb, m, n, k):
+    from biomedkg_amd import ops
+    torch.manual_seed(0)
+    a = torch.randn((k, m) if ta else (m, k), device=DEV)
+    b = torch.randn((n, k) if tb else (k, n), device=DEV)
+    ref = ((a.t() if ta else a).double() @ (b.t() if tb else b).double())
+    out = ops.gemm(a, b, trans_a=ta, trans_b=tb)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_epilogues():
+    from biomedkg_amd import ops
+    torch.manual_seed(1)
+    m, n, k = 300, 70, 50
+    a, b = torch.randn(m, k, device=DEV), torch.randn(n, k, device=DEV)
+    bias, c0, gate = torch.randn(n, device=DEV), torch.randn(m, n, device=DEV), torch.randn(m, n, device=DEV)
+    pre = 0.5 * (a.double() @ b.double().t()) + bias.double()
+    torch.testing.assert_close(ops.gemm(a, b, trans_b=True, alpha=0.5, bias=bias, act=ops.ACT_RELU).double(),
+                               pre.relu(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ops.gemm(a, b, trans_b=True, alpha=0.5, bias=bias, act=ops.ACT_ELU).double(),
+                               torch.nn.functional.elu(pre), rtol=1e-5, atol=1e-5)
+    out = c0.clone()
+    ops.gemm(a, b, trans_b=True, alpha=0.5, bias=bias, beta=2.0, out=out)
+    torch.testing.assert_close(out.double(), pre + 2.0 * c0.double(), rtol=1e-5, atol=1e-5)
+    out = ops.gemm(a, b, trans_b=True, alpha=0.5, bias=bias, gate=gate, gate_scale=1.25)
+    torch.testing.assert_close(out.double(), torch.where(gate > 0, pre * 1.25, 0.0), rtol=1e-5, atol=1e-5)
+
+
+def test_gemm_grouped():
+    from biomedkg_amd import ops
+    torch.manual_seed(2)
+    sizes = [0, 130, 1, 0, 257, 64]
+    gptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=DEV)
+    s, k, n, g = sum(sizes), 40, 24, len(sizes)
+    a, w = torch.randn(s, k, device=DEV), torch.randn(g, k, n, device=DEV)
+    y = ops.gemm_grouped_rows(a, w, gptr)
+    dy = torch.randn(s, n, device=DEV)
+    dh = ops.gemm_grouped_rows(dy, w, gptr, trans_b=True)
+    dw = ops.gemm_grouped_k(a, dy, gptr, g)
+    o = 0
+    for i, sz in enumerate(sizes):
+        sl = slice(o, o + sz)
+        torch.testing.assert_close(y[sl].double(), a[sl].double() @ w[i].double(), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(dh[sl].double(), dy[sl].double() @ w[i].double().t(), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(dw[i].double(), a[sl].double().t() @ dy[sl].double(), rtol=1e-5, atol=1e-4)
+        o += sz
+
+
+@pytest.mark.parametrize("d", [16, 24, 64, 128, 256, 768])
+def test_spmm_and_gcn_norm(d):
+    from biomedkg_amd import graph as G, ops
+    from oracle import pyg_ops as P
+    n, e = 200, 3000
+    ei = _graph(n, e, 3)
+    torch.manual_seed(3)
+    x = torch.randn(n, d)
+    keep = torch.rand(e) >= 0.4
+    gr = G.Graph(ei.to(DEV), n)
+    for kp in (None, keep):
+        gw = gr.gcn_weights(None if kp is None else kp.to(DEV))
+        ei_k = ei if kp is None else ei[:, kp]
+        e2, w = P.gcn_norm(ei_k, n)
+        ref = torch.zeros(n, d, dtype=torch.float64).index_add_(0, e2[1], x.double()[e2[0]] * w.double()[:, None])
+        out = ops.spmm(gr.by_dst.rowptr, gr.by_dst.col, gw.w_dst, x.to(DEV), n, self_w=gw.self_w)
+        torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+        refT = torch.zeros(n, d, dtype=torch.float64).index_add_(0, e2[0], x.double()[e2[1]] * w.double()[:, None])
+        outT = ops.spmm(gr.by_src.rowptr, gr.by_src.col, gw.w_src, x.to(DEV), n, self_w=gw.self_w)
+        torch.testing.assert_close(outT.cpu().double(), refT, rtol=1e-5, atol=1e-5)
+
+
+def test_spmm_epilogue_and_philox():
+    from biomedkg_amd import graph as G, ops
+    n, e, d = 300, 2000, 128
+    ei = _graph(n, e, 4)
+    torch.manual_seed(4)
+    x, bias, add = torch.randn(n, d, device=DEV), torch.randn(d, device=DEV), torch.randn(n, d, device=DEV)
+    keep = (torch.rand(n, d, device=DEV) >= 0.2)
+    gr = G.Graph(ei.to(DEV), n)
+    c = gr.by_dst
+    base = ops.spmm(c.rowptr, c.col, None, x, n)
+    out = ops.spmm(c.rowptr, c.col, None, x, n, addend=add, bias=bias, relu=True, drop=ops.Dropout(0.2, keep=keep))
+    ref = (base + add + bias).relu() * keep * 1.25
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+    # in-kernel Philox: deterministic per (seed, stream), keep rate ~ 0.8, values scaled 1.25
+    o1 = ops.spmm(c.rowptr, c.col, None, x, n, drop=ops.Dropout(0.2, seed=7, stream_id=1))
+    o2 = ops.spmm(c.rowptr, c.col, None, x, n, drop=ops.Dropout(0.2, seed=7, stream_id=1))
+    o3 = ops.spmm(c.rowptr, c.col, None, x, n, drop=ops.Dropout(0.2, seed=8, stream_id=1))
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    nz = base != 0
+    kept = (o1 != 0) & nz
+    assert abs(kept.sum().item() / nz.sum().item() - 0.8) < 0.02
+    torch.testing.assert_close(o1[kept], base[kept] * 1.25)
+
+
+def test_gcn_conv_fwd_bwd_vs_oracle():
+    from biomedkg_amd import graph as G, ops
+    from oracle import pyg_ops as P
+    n, e, din, dout = 150, 1200, 48, 32
+    ei = _graph(n, e, 5)
+    torch.manual_seed(5)
+    x, w, b = torch.randn(n, din), torch.randn(dout, din) * 0.2, torch.randn(dout) * 0.1
+    keep = torch.rand(n, dout) >= 0.2
+    xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = torch.relu(P.gcn_conv(xo, ei, wo, bo)) * keep * 1.25
+    gout = torch.randn(n, dout)
+    ref.backward(gout)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    gr = G.Graph(ei.to(DEV), n)
+    out = ops.gcn_conv(xd, wd, bd, gr, gr.gcn_weights(), relu=True, drop=ops.Dropout(0.2, keep=keep.to(DEV)))
+    out.backward(gout.to(DEV))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    for got, exp in ((xd, xo), (wd, wo), (bd, bo)):
+        torch.testing.assert_close(got.grad.cpu(), exp.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_rgcn_conv_fwd_bwd_vs_oracle():
+    from biomedkg_amd import graph as G, ops
+    from oracle import pyg_ops as P
+    n, e, r, din, dout = 120, 1500, 5, 40, 32
+    ei = _graph(n, e, 6)
+    torch.manual_seed(6)
+    et = torch.randint(0, r, (e,))
+    et[et == 2] = 3  # an empty relation
+    x, w = torch.randn(n, din), torch.randn(r, din, dout) * 0.2
+    root, b = torch.randn(din, dout) * 0.2, torch.randn(dout) * 0.1
+    xo, wo, ro, bo = (t.clone().requires_grad_(True) for t in (x, w, root, b))
+    ref = torch.relu(P.rgcn_conv(xo, ei, et, wo, ro, bo))
+    gout = torch.randn(n, dout)
+    ref.backward(gout)
+    xd, wd, rd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, root, b))
+    rg = G.RelGraph(ei.to(DEV), et.to(DEV), n, r)
+    out = ops.rgcn_conv(xd, wd, rd, bd, rg, relu=True)
+    out.backward(gout.to(DEV))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    for got, exp in ((xd, xo), (wd, wo), (rd, ro), (bd, bo)):
+        torch.testing.assert_close(got.grad.cpu(), exp.grad, rtol=1e-4, atol=1e-5)
