@@ -35,6 +35,17 @@ SIGNATURES = {
     "bkg_gemm_f32": (I32, [I32, I32, I64, I64, I64, F32, P, I64, P, I64, F32, P, I64, P, I32, P, I64, F32, P]),
     "bkg_gemm_grouped_rows_f32": (I32, [I32, I64, I64, I64, P, I64, P, I64, I64, P, I64, P, I32, P, I64, F32, P]),
     "bkg_gemm_grouped_k_f32": (I32, [I64, I64, I64, P, I64, P, I64, P, I64, I64, P, I32, P]),
+    # kge.hip
+    "bkg_kge_score_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, P]),
+    "bkg_row_l1norm_f32": (I32, [P, I64, I64, I32, P, P]),
+    "bkg_kge_bwd_nodes_f32": (I32, [I32, P, I64, I64, I32, P, P, P, I64, P, I64, P, P, P, P, P, I64, P]),
+    "bkg_kge_bwd_rel_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, I32, P, I64, P]),
+    # ntxent.hip
+    "bkg_ntxent_rowsum_f32": (I32, [P, I64, I64, I32, F32, I32, P, P]),
+    "bkg_ntxent_bwd_f32": (I32, [P, I64, I64, I32, F32, P, I32, P, P]),
+    # fusion.hip
+    "bkg_attn_fuse_f32": (I32, [P, I64, I64, I32, I32, P, I64, P]),
+    "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, P, I64, P]),
 }
 
 _lib = None

@@ -1,0 +1,97 @@
+"""GCL wrappers behind the reference's class names (``biomedkg/model/gcl.py``)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import ops
+from .. import rand as _rand
+
+
+class DGI(torch.nn.Module):
+    """reference gcl.py:8-27."""
+
+    def __init__(self, encoder, hidden_dim):
+        super().__init__()
+        self.encoder = encoder
+        self.project = torch.nn.Linear(hidden_dim, hidden_dim)
+        bound = 1.0 / math.sqrt(hidden_dim)  # PyG inits.uniform(size, weight)
+        with torch.no_grad():
+            self.project.weight.uniform_(-bound, bound)
+
+    @staticmethod
+    def corruption(x, edge_index):
+        return x[_rand.current().perm(x.size(0), x.device)], edge_index
+
+    @staticmethod
+    def summary(z):
+        return torch.sigmoid(z.mean(dim=0, keepdim=True))
+
+    def forward(self, x, edge_index):
+        z = self.encoder(x, edge_index)
+        g = ops.linear(self.summary(z), self.project.weight, self.project.bias)
+        zn = self.encoder(*self.corruption(x, edge_index))
+        return z, g, zn
+
+
+class GRACE(torch.nn.Module):
+    """reference gcl.py:31-51.  ``forward`` keeps the reference's three encoder passes (the first is
+    unused by the loss); ``views`` computes only the two the loss consumes."""
+
+    def __init__(self, encoder, hidden_dim, proj_dim):
+        super().__init__()
+        self.encoder = encoder
+        self.fc1 = torch.nn.Linear(hidden_dim, proj_dim)
+        self.fc2 = torch.nn.Linear(proj_dim, hidden_dim)
+
+    def _augment(self, x, edge_index):
+        r = _rand.current()
+        k1, k2 = r.feat_keep(x, 0.4), r.feat_keep(x, 0.4)
+        e1 = r.edge_keep(edge_index.size(1), 0.4, x.device)
+        e2 = r.edge_keep(edge_index.size(1), 0.4, x.device)
+        return (x * k1, e1), (x * k2, e2)
+
+    def forward(self, x, edge_index):
+        (x1, e1), (x2, e2) = self._augment(x, edge_index)
+        z = self.encoder(x, edge_index)
+        return z, self.encoder(x1, edge_index, edge_keep=e1), self.encoder(x2, edge_index, edge_keep=e2)
+
+    def views(self, x, edge_index):
+        (x1, e1), (x2, e2) = self._augment(x, edge_index)
+        if self.encoder.training and self.encoder.drop_out:
+            _rand.current().skip(len(self.encoder.graph_layers) - 1)  # the unused pass's dropout draws
+        return self.encoder(x1, edge_index, edge_keep=e1), self.encoder(x2, edge_index, edge_keep=e2)
+
+    def project(self, z):
+        return ops.linear(ops.linear(z, self.fc1.weight, self.fc1.bias, act=ops.ACT_ELU), self.fc2.weight, self.fc2.bias)
+
+
+class GGD(torch.nn.Module):
+    """reference gcl.py:54-93 (https://arxiv.org/abs/2206.01535)."""
+
+    def __init__(self, encoder, hidden_dim, n_proj, aug_p):
+        super().__init__()
+        self.encoder = encoder
+        self.p = aug_p
+        self.mlp = torch.nn.ModuleList(torch.nn.Linear(hidden_dim, hidden_dim) for _ in range(n_proj))
+
+    @staticmethod
+    def corruption(x, edge_index):
+        return x[_rand.current().perm(x.size(0), x.device)], edge_index
+
+    def forward(self, x, edge_index):
+        r = _rand.current()
+        edge_keep = None
+        if r.coin() < self.p:
+            x = x * r.feat_keep(x, 0.4)
+            edge_keep = r.edge_keep(edge_index.size(1), 0.4, x.device)
+        pos_h = self.encoder(x, edge_index, edge_keep=edge_keep)
+        # the reference corrupts over the (possibly edge-dropped) graph of the positive pass
+        neg_h = self.encoder(self.corruption(x, edge_index)[0], edge_index, edge_keep=edge_keep)
+        for layer in self.mlp[:-1]:
+            pos_h = ops.linear(pos_h, layer.weight, layer.bias, act=ops.ACT_RELU)
+            neg_h = ops.linear(neg_h, layer.weight, layer.bias, act=ops.ACT_RELU)
+        pos_h = ops.linear(pos_h, self.mlp[-1].weight, self.mlp[-1].bias)
+        neg_h = ops.linear(neg_h, self.mlp[-1].weight, self.mlp[-1].bias)
+        return pos_h.sum(1), neg_h.sum(1)

@@ -202,3 +202,146 @@ class _RgcnConv(torch.autograd.Function):
 def rgcn_conv(x, weight, root, bias, rg, relu=False, drop=None):
     L.require_cuda(x, weight, root, bias)
     return _RgcnConv.apply(_f32c(x), weight, root, bias, rg, relu, drop)
+
+
+# ----------------------------------------------------------------------------- KGE scorer
+KGE_DISTMULT, KGE_TRANSE = 0, 1
+
+
+class Incidence:
+    """Node -> incident (triplet, role) lists for the non-atomic scorer backward: the 2T entries
+    ``cat(head, tail)`` sorted by node.  Entry e < T: the node is the head of triplet e."""
+
+    def __init__(self, edge_index, num_nodes):
+        from .graph import _Sorter, _i32
+        ei = edge_index.contiguous()
+        flat = ei.view(-1)                       # == cat(head, tail)
+        sorted_keys, self.perm, _ = _Sorter.sort(flat, None, num_nodes, 1)
+        self.rowptr = _i32(num_nodes + 1, ei.device)
+        L.call("bkg_lower_bound_u32", L.ptr(sorted_keys), flat.numel(), num_nodes + 1, 1, L.ptr(self.rowptr), L.stream())
+
+
+def incidence_of(edge_index, num_nodes) -> Incidence:
+    from .graph import _cached
+    return _cached(edge_index, "incidence", (int(num_nodes),), lambda: Incidence(edge_index, num_nodes))
+
+
+class _KgeScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, rel_emb, edge_index, edge_type, kind):
+        t = edge_index.size(1)
+        score = torch.empty(t, dtype=torch.float32, device=z.device)
+        L.call("bkg_kge_score_f32", kind, L.ptr(z), z.stride(0), z.size(1), L.ptr(edge_index[0]), L.ptr(edge_index[1]),
+               L.ptr(edge_type), t, L.ptr(rel_emb), rel_emb.stride(0), L.ptr(score), L.stream())
+        ctx.kind = kind
+        ctx.edge_index, ctx.edge_type = edge_index, edge_type
+        ctx.save_for_backward(z, rel_emb)
+        return score
+
+    @staticmethod
+    def backward(ctx, gscore):
+        z, rel_emb = ctx.saved_tensors
+        ei, et, kind = ctx.edge_index, ctx.edge_type, ctx.kind
+        gscore = _f32c(gscore)
+        n, d, t = z.size(0), z.size(1), ei.size(1)
+        dz = drel = None
+        if ctx.needs_input_grad[0]:
+            inc = incidence_of(ei, n)
+            l1 = None
+            if kind == KGE_TRANSE:
+                l1 = torch.empty(n, dtype=torch.float32, device=z.device)
+                L.call("bkg_row_l1norm_f32", L.ptr(z), z.stride(0), n, d, L.ptr(l1), L.stream())
+            dz = torch.empty_like(z)
+            L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
+                   L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), L.ptr(l1), L.ptr(inc.rowptr), L.ptr(inc.perm),
+                   L.ptr(dz), dz.stride(0), L.stream())
+        if ctx.needs_input_grad[1]:
+            drel = torch.zeros_like(rel_emb)
+            L.call("bkg_kge_bwd_rel_f32", kind, L.ptr(z), z.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
+                   L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), rel_emb.size(0), L.ptr(drel), drel.stride(0),
+                   L.stream())
+        return dz, drel, None, None, None
+
+
+def kge_score(z, rel_emb, edge_index, edge_type, kind):
+    """DistMult / TransE logits of the triplets ``(edge_index[0], edge_type, edge_index[1])``."""
+    L.require_cuda(z, rel_emb, edge_index, edge_type)
+    if edge_index.dtype != torch.int64 or edge_type.dtype != torch.int64:
+        raise TypeError("edge_index / edge_type must be int64")
+    return _KgeScore.apply(_f32c(z), _f32c(rel_emb), edge_index.contiguous(), edge_type.contiguous(), kind)
+
+
+# ----------------------------------------------------------------------------- NT-Xent
+def _ntxent_splits(m):
+    n_i = (m + 63) // 64
+    return max(1, min(16, 1024 // n_i))
+
+
+class _NtXent(torch.autograd.Function):
+    """GRACE loss: DualBranchContrast(InfoNCE(tau), L2L, intraview_negs=True)(h1, h2)."""
+
+    @staticmethod
+    def forward(ctx, h1, h2, tau):
+        n, h = h1.shape
+        m = 2 * n
+        z = torch.cat([h1, h2], dim=0)
+        norm = z.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        zn = (z / norm).contiguous()
+        splits = _ntxent_splits(m)
+        part = torch.empty(splits, m, dtype=torch.float32, device=z.device)
+        L.call("bkg_ntxent_rowsum_f32", L.ptr(zn), zn.stride(0), m, h, tau, splits, L.ptr(part), L.stream())
+        den = part.sum(0)
+        pos = (zn[:n] * zn[n:]).sum(1).double().sum() / tau
+        loss = (torch.log(den.double()).sum() - 2.0 * pos) / m
+        ctx.tau, ctx.n = tau, n
+        ctx.save_for_backward(zn, norm, den)
+        return loss.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        zn, norm, den = ctx.saved_tensors
+        n, tau = ctx.n, ctx.tau
+        m, h = zn.shape
+        rden = (1.0 / den).contiguous()
+        splits = _ntxent_splits(m)
+        part = torch.empty(splits, m, h, dtype=torch.float32, device=zn.device)
+        L.call("bkg_ntxent_bwd_f32", L.ptr(zn), zn.stride(0), m, h, tau, L.ptr(rden), splits, L.ptr(part), L.stream())
+        dzn = part.sum(0) - 2.0 * torch.roll(zn, n, dims=0)
+        dzn = dzn * (g / (m * tau))
+        dz = (dzn - zn * (zn * dzn).sum(1, keepdim=True)) / norm
+        return dz[:n], dz[n:], None
+
+
+def ntxent_loss(h1, h2, tau=0.2):
+    L.require_cuda(h1, h2)
+    return _NtXent.apply(_f32c(h1), _f32c(h2), float(tau))
+
+
+# ----------------------------------------------------------------------------- modality fusion
+def attention_fusion(x, w_qkv, b_qkv):
+    """AttentionFusion.forward (reference fusion.py:17-31): one QKV GEMM + fused MxM attention/mean.
+    ``x [n, M, D]``, ``w_qkv [3D, D]``, ``b_qkv [3D]`` -> ``[n, D]``.  Forward only (the reference never
+    trains the fuser: its parameters are outside every optimizer)."""
+    L.require_cuda(x, w_qkv, b_qkv)
+    n, m, d = x.shape
+    qkv = gemm(_f32c(x).view(n * m, d), w_qkv, trans_b=True, bias=b_qkv)
+    out = torch.empty(n, d, dtype=torch.float32, device=x.device)
+    L.call("bkg_attn_fuse_f32", L.ptr(qkv), qkv.stride(0), n, m, d, L.ptr(out), out.stride(0), L.stream())
+    return out
+
+
+def redaf_fusion(x, w_t, b_t, scale, drop: Dropout = None):
+    """ReDAF.forward (reference fusion.py:49-90): relu(Linear_T(x)) in the GEMM epilogue, then
+    mean_m relu(dropout(t * scale[m])) with ``scale = modal_weights * zeta`` ``[M, D]``."""
+    L.require_cuda(x, w_t, b_t, scale)
+    n, m, d = x.shape
+    t = gemm(_f32c(x).view(n * m, d), w_t, trans_b=True, bias=b_t, act=ACT_RELU)
+    out = torch.empty(n, d, dtype=torch.float32, device=x.device)
+    keep, p, seed = None, 0.0, 0
+    if drop is not None and drop.p > 0:
+        p, seed = drop.p, drop.seed
+        if drop.keep is not None:
+            keep = drop.keep.to(torch.uint8).contiguous()
+    L.call("bkg_redaf_combine_f32", L.ptr(t), t.stride(0), n, m, d, L.ptr(_f32c(scale)), L.ptr(keep), p, seed,
+           L.ptr(out), out.stride(0), L.stream())
+    return out

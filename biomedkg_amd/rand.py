@@ -1,0 +1,111 @@
+"""Randomness providers for the stochastic steps of the hot path.
+
+The reference draws every mask / permutation with torch (on whatever device ``x`` lives on) and the
+negative samples with python ``random`` (reference ``biomedkg/model/gcl.py:40-43,75-76``,
+``biomedkg/kge_module.py:86-102``, PyG ``negative_sampling``).  RNG streams cannot be matched
+across devices, so every draw goes through a provider:
+
+* ``DeviceRand`` (default): draws on the GPU -- torch's device generator for feature / edge masks
+  and permutations, an in-kernel Philox stream for layer dropout (no mask ever touches HBM), and
+  the device rejection sampler for negatives.
+* ``ReplayRand``: replays a tape of draws recorded by a CPU run (tape format:
+  ``[(kind, tensor), ...]`` with kinds feat_keep / edge_keep / drop_keep / perm / coin / neg_edges)
+  -- this is how the parity tests feed identical randomness to the HIP path and to the checker.
+"""
+from __future__ import annotations
+
+import torch
+
+from .ops import Dropout
+
+
+class DeviceRand:
+    def __init__(self, seed=None):
+        self.seed = int(torch.initial_seed() if seed is None else seed) & ((1 << 63) - 1)
+        self.counter = 0
+
+    def feat_keep(self, x, p):
+        return torch.rand_like(x) >= p
+
+    def edge_keep(self, num_edges, p, device):
+        return torch.rand(num_edges, device=device) >= p
+
+    def dropout(self, shape, p, device) -> Dropout:
+        self.counter += 1
+        return Dropout(p, keep=None, seed=self.seed, stream_id=self.counter & 0xFFFFFFFF)
+
+    def perm(self, n, device):
+        return torch.randperm(n, device=device)
+
+    def coin(self) -> float:
+        return float(torch.rand(1).item())
+
+    def neg_edges(self, edge_index, num_neg_samples):
+        from .sampling import negative_sampling
+        return negative_sampling(edge_index, num_neg_samples=num_neg_samples)
+
+    def skip(self, count):
+        pass
+
+
+class ReplayRand:
+    def __init__(self, tape, device="cuda"):
+        self.tape, self.pos, self.device = list(tape), 0, device
+
+    def _next(self, kind):
+        k, t = self.tape[self.pos]
+        if k != kind:
+            raise RuntimeError(f"tape mismatch at {self.pos}: have {k!r}, asked {kind!r}")
+        self.pos += 1
+        return t.to(self.device)
+
+    def feat_keep(self, x, p):
+        return self._next("feat_keep")
+
+    def edge_keep(self, num_edges, p, device):
+        return self._next("edge_keep")
+
+    def dropout(self, shape, p, device) -> Dropout:
+        keep = self._next("drop_keep")
+        return Dropout(p, keep=keep.reshape(shape))
+
+    def perm(self, n, device):
+        return self._next("perm")
+
+    def coin(self) -> float:
+        return float(self._next("coin").item())
+
+    def neg_edges(self, edge_index, num_neg_samples):
+        return self._next("neg_edges")
+
+    def skip(self, count):
+        """Discard draws the HIP path does not need (e.g. GRACE's unused third encoder pass)."""
+        self.pos += count
+
+    def exhausted(self):
+        return self.pos == len(self.tape)
+
+
+_current = None
+
+
+def current():
+    global _current
+    if _current is None:
+        _current = DeviceRand()
+    return _current
+
+
+class use:
+    def __init__(self, provider):
+        self.provider = provider
+
+    def __enter__(self):
+        global _current
+        self.prev, _current = _current, self.provider
+        return self.provider
+
+    def __exit__(self, *exc):
+        global _current
+        _current = self.prev
+        return False

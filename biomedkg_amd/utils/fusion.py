@@ -1,0 +1,60 @@
+"""Modality fusion ``[n, M, D] -> [n, D]`` behind the reference's class names
+(``biomedkg/utils/fusion.py``).  Parameter names match the reference for checkpoint loading.
+
+Forward only: in the reference the fuser's parameters are never handed to an optimizer
+(``gcl_module.py:81``, ``kge_module.py:211`` optimise ``self.model.parameters()`` only; SURVEY.md
+0.3-1), so the task modules call the fuser under ``torch.no_grad()``.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from .. import rand as _rand
+
+
+class AttentionFusion(torch.nn.Module):
+    """reference fusion.py:10-31: q/k/v Linear -> single-head SDPA over the M modality tokens -> mean."""
+
+    def __init__(self, embed_dim: int):
+        super().__init__()
+        self.q_proj = torch.nn.Linear(embed_dim, embed_dim)
+        self.k_proj = torch.nn.Linear(embed_dim, embed_dim)
+        self.v_proj = torch.nn.Linear(embed_dim, embed_dim)
+
+    def forward(self, x):
+        if x.dim() != 3:
+            raise ValueError("AttentionFusion expects [n, modalities, embed_dim]")
+        w = torch.cat([self.q_proj.weight, self.k_proj.weight, self.v_proj.weight], dim=0)
+        b = torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias], dim=0)
+        with torch.no_grad():
+            return ops.attention_fusion(x, w, b)
+
+
+class ReDAF(torch.nn.Module):
+    """reference fusion.py:34-90 with ``sub_type_ids=None`` (the only way the reference calls it)."""
+
+    def __init__(self, embed_dim: int, num_modalities: int = 2):
+        super().__init__()
+        self.embed_dim, self.num_modalities = embed_dim, num_modalities
+        self.modal_weights = torch.nn.Parameter(torch.ones(num_modalities, 1, embed_dim))
+        self.sub_type_embeddings = torch.nn.Embedding(num_modalities, embed_dim)  # unused by the reference too
+        self.transform_layer = torch.nn.Linear(embed_dim, embed_dim)
+        self.relational_context_layer = torch.nn.Linear(embed_dim, embed_dim)
+        self.dropout = torch.nn.Dropout(0.1)
+        self.activation = torch.nn.ReLU()
+
+    def forward(self, x, relational_context=0.2, sub_type_ids=None):
+        if sub_type_ids is not None:
+            raise NotImplementedError("sub_type_ids is never passed by the reference (fusion.py:63-68)")
+        if x.dim() != 3:
+            raise ValueError("ReDAF expects [n, modalities, embed_dim]")
+        with torch.no_grad():
+            ctx = torch.full((1, self.embed_dim), relational_context, dtype=x.dtype, device=x.device)
+            rl = self.relational_context_layer
+            zeta = torch.sigmoid(ops.linear(ctx, rl.weight, rl.bias))                     # [1, D]
+            scale = (self.modal_weights[:, 0, :] * zeta).contiguous()                     # [M, D]
+            drop = None
+            if self.training:
+                drop = _rand.current().dropout((x.size(0) * x.size(1), self.embed_dim), 0.1, x.device)
+            return ops.redaf_fusion(x, self.transform_layer.weight, self.transform_layer.bias, scale, drop)
