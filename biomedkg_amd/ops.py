@@ -67,7 +67,18 @@ class Dropout:
         self.p, self.keep, self.seed, self.stream_id = float(p), keep, int(seed), int(stream_id)
 
 
-def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=False, drop: Dropout = None):
+# bench.py sets this to a dict to time tagged launches with HIP events on the launch stream:
+# tag -> {"events": [(start, end), ...], "bytes": algorithmic bytes of one launch}
+KERNEL_TIMERS = None
+
+
+def _spmm_bytes(nnz, n_rows, d, has_w):
+    """Algorithmic bytes of one launch: gathered row + int32 index (+ fp32 weight) per
+    entry, stored row + int32 rowptr per output row."""
+    return nnz * (d * 4 + 4 + (4 if has_w else 0)) + n_rows * (d * 4 + 4)
+
+
+def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=False, drop: Dropout = None, tag=None):
     """``out[i] = epi(sum_k w[k] x[col[k]] (+ self_w[i] x[i]) (+ addend[i]))`` (csrc/spmm.hip)."""
     L.require_cuda(rowptr, col, w, x, self_w, addend, bias)
     x = _f32c(x)
@@ -82,9 +93,17 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
                 raise ValueError("dropout keep mask shape mismatch")
     if addend is not None:
         addend = _f32c(addend)
+    timing = KERNEL_TIMERS is not None and tag is not None
+    if timing:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     L.call("bkg_spmm_csr_f32", L.ptr(rowptr), L.ptr(col), L.ptr(w), L.ptr(x), x.stride(0), L.ptr(out), out.stride(0),
            n_rows, d, L.ptr(self_w), L.ptr(addend), addend.stride(0) if addend is not None else 0, L.ptr(bias),
            int(relu), L.ptr(keep), p, seed, sid, L.stream())
+    if timing:
+        ev1.record()
+        rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None)})
+        rec["events"].append((ev0, ev1))
     return out
 
 
@@ -133,7 +152,8 @@ class _GcnConv(torch.autograd.Function):
     def forward(ctx, x, weight, bias, graph: Graph, gw: GcnWeights, relu, drop):
         xw = gemm(x, weight, trans_b=True)
         c = graph.by_dst
-        out = spmm(c.rowptr, c.col, gw.w_dst, xw, graph.num_nodes, self_w=gw.self_w, bias=bias, relu=relu, drop=drop)
+        out = spmm(c.rowptr, c.col, gw.w_dst, xw, graph.num_nodes, self_w=gw.self_w, bias=bias, relu=relu, drop=drop,
+                   tag="gcn_propagate")
         ctx.graph, ctx.gw, ctx.relu = graph, gw, relu
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
@@ -168,7 +188,7 @@ class _RgcnConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop):
         n = rg.num_nodes
-        h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, x, rg.num_segments)          # [S, in]  segment means
+        h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, x, rg.num_segments, tag="rgcn_segment_mean")   # [S, in]
         y = gemm_grouped_rows(h, weight, rg.rel_ptr)                                  # [S, out] per-relation W_r
         xr = gemm(x, root)                                                            # [N, out] root term
         c = rg.dst_csr
