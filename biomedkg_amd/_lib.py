@@ -16,6 +16,13 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libbiomedkg_hip.so")
 P = c_void_p
 I32, I64, U32, U64, F32 = c_int32, c_int64, c_uint32, c_uint64, c_float
 
+class RowSplitStruct(ctypes.Structure):
+    """``bkg_rowsplit`` of include/biomedkg_hip.h (device pointers + upper-bound sizes)."""
+    _fields_ = [(n, c_void_p) for n in ("item_row", "item_beg", "item_end", "item_slot", "long_row", "long_slot0",
+                                        "long_cnt", "totals")] + [(n, c_int64) for n in
+                                                                  ("n_items_max", "n_slots_max", "n_long_max")]
+
+
 # name -> (restype, argtypes); mirrors include/biomedkg_hip.h one to one.
 SIGNATURES = {
     "bkg_abi_version": (c_int32, []),
@@ -30,7 +37,8 @@ SIGNATURES = {
     "bkg_gcn_norm": (I32, [P, P, P, P, P, P, I64, I64, P, P, P, P]),
     "bkg_rgcn_segments": (I32, [P, I64, I64, P, P, P, P, P, P, P, P, P, I64, P]),
     # spmm.hip
-    "bkg_spmm_csr_f32": (I32, [P, P, P, P, I64, P, I64, I64, I32, P, P, I64, P, I32, P, F32, U64, U32, P]),
+    "bkg_rowsplit_build": (I32, [P, I64, I64, I32, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
+    "bkg_spmm_csr_f32": (I32, [P, P, P, P, I64, P, I64, I64, I32, P, P, I64, P, I32, P, F32, U64, U32, P, P, P]),
     # gemm_f32.hip
     "bkg_gemm_f32": (I32, [I32, I32, I64, I64, I64, F32, P, I64, P, I64, F32, P, I64, P, I32, P, I64, F32, P]),
     "bkg_gemm_grouped_rows_f32": (I32, [I32, I64, I64, I64, P, I64, P, I64, I64, P, I64, P, I32, P, I64, F32, P]),
@@ -38,8 +46,8 @@ SIGNATURES = {
     # kge.hip
     "bkg_kge_score_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, P]),
     "bkg_row_l1norm_f32": (I32, [P, I64, I64, I32, P, P]),
-    "bkg_kge_bwd_nodes_f32": (I32, [I32, P, I64, I64, I32, P, P, P, I64, P, I64, P, P, P, P, P, I64, P]),
-    "bkg_kge_bwd_rel_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, I32, P, I64, P]),
+    "bkg_kge_bwd_nodes_f32": (I32, [I32, P, I64, I64, I32, P, P, P, I64, P, I64, P, P, P, P, P, I64, P, P, P]),
+    "bkg_kge_bwd_rel_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, I32, P, I64, P, P, P]),
     # ntxent.hip
     "bkg_ntxent_rowsum_f32": (I32, [P, I64, I64, I32, F32, I32, P, P]),
     "bkg_ntxent_bwd_f32": (I32, [P, I64, I64, I32, F32, P, I32, P, P]),
@@ -76,6 +84,11 @@ def ptr(t):
     if t is None:
         return None
     return t.data_ptr()
+
+
+def sref(struct):
+    """Host pointer to a ctypes struct (None -> NULL)."""
+    return None if struct is None else ctypes.cast(ctypes.byref(struct), c_void_p)
 
 
 def stream():

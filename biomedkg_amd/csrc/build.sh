@@ -8,7 +8,7 @@ mkdir -p obj
 pids=()
 for f in *.hip; do
   o=obj/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/biomedkg_hip.h -nt "$o" ]; then
     ( hipcc $FLAGS -c "$f" -o "$o" ) &
     pids+=($!)
     if [ ${#pids[@]} -ge $JOBS ]; then wait "${pids[0]}"; pids=("${pids[@]:1}"); fi

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/biomedkg_hip.h"
+
 #define BKG_WAVE 64
 
 namespace bkg {

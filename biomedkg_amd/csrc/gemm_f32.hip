@@ -180,6 +180,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   gemm_tile<BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, 0, K, ep, vec_ok(A, lda), vec_ok(B, ldb));
 }
 
+// Split-K: blockIdx.y owns K range [y*kchunk, (y+1)*kchunk) and adds its tile into a zeroed C with
+// f32 atomics.  For the weight-gradient products dW = dY^T X (K = number of nodes, M x N = a few tiles).
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb,
+                                                              float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                              int kchunk, GemmEpilogue ep) {
+  const int n_tiles = (N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
+  const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, K);
+  if (kbeg >= kend) return;
+  gemm_tile<BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, kbeg, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
+}
+
 // C_g[rows of group g, :] = A_g @ op(B_g);  B_g = B + g * strideB.  Tiles never straddle groups.
 template <int BM, int BN, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_rows_kernel(const float* __restrict__ A, int64_t lda,
@@ -264,6 +278,31 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
   if (M == 0 || N == 0) return 0;
   GemmEpilogue ep{alpha, beta, bias, act, gate, ldg, gate_scale, 0};
   hipStream_t s = (hipStream_t)stream;
+  // Deep-K plain products with few output tiles (weight gradients): split K over the grid.
+  const bool plain = !bias && act == 0 && !gate && beta == 0.f;
+  const int64_t tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
+  if (plain && K >= 4096 && tiles64 <= 256) {
+    const bool big = tiles64 >= 64;  // 128x128 tiles once there are enough of them
+    const int64_t tiles = big ? ((M + 127) / 128) * ((N + 127) / 128) : tiles64;
+    int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 2048 / tiles));
+    int kchunk = (int)(((K + nsplit - 1) / nsplit + 15) / 16 * 16);
+    nsplit = (K + kchunk - 1) / kchunk;
+    hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
+    if (e != hipSuccess) { set_error("bkg_gemm_f32: memset", e); return (int)e; }
+    ep.atomic = 1;
+    dim3 grid((unsigned)tiles, (unsigned)nsplit), block(256);
+#define BKG_SPLITK(BMN, TA_, TB_) \
+  hipLaunchKernelGGL((gemm_f32_splitk_kernel<BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep)
+#define BKG_SPLITK_T(BMN)                                 \
+  if (!trans_a && !trans_b) { BKG_SPLITK(BMN, false, false); } \
+  else if (!trans_a && trans_b) { BKG_SPLITK(BMN, false, true); } \
+  else if (trans_a && !trans_b) { BKG_SPLITK(BMN, true, false); } \
+  else { BKG_SPLITK(BMN, true, true); }
+    if (big) { BKG_SPLITK_T(128) } else { BKG_SPLITK_T(64) }
+#undef BKG_SPLITK_T
+#undef BKG_SPLITK
+    return check_launch("bkg_gemm_f32(split-K)");
+  }
   // big tiles once they fill the chip, small tiles otherwise
   if ((M / 128) * ((N + 127) / 128) >= 256) launch_gemm<128, 128>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);
   else launch_gemm<64, 64>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);

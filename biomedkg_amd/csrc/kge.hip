@@ -107,21 +107,110 @@ __global__ __launch_bounds__(256) void row_l1_kernel(const float* __restrict__ z
 
 // ------------------------------------------------------------------------------------ backward: dz
 // inc_perm[k] in [0, 2T): entry e < T -> node is the HEAD of triplet e; e >= T -> TAIL of e - T.
+// TransE: acc = Q = d loss / d z^_i.  Through z^ = z / max(||z||_1, eps):
+//   ||z||_1 > eps : dz = (Q - sign(z) (z^ . Q)) / ||z||_1     else : dz = Q / eps
 template <int KIND, int LPR, int VPL>
+__device__ __forceinline__ void kge_nodes_finish(float4 (&acc)[VPL], const float4 (&self)[VPL], float inv_self,
+                                                 bool above_eps, int node, int lig, float* __restrict__ dz,
+                                                 int64_t lddz) {
+  if (KIND == KGE_TRANSE) {
+    float dot = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+      dot += self[v].x * acc[v].x + self[v].y * acc[v].y + self[v].z * acc[v].z + self[v].w * acc[v].w;
+    dot = group_sum<LPR>(dot);
+    if (!above_eps) dot = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      acc[v].x = (acc[v].x - sgn(self[v].x) * dot) * inv_self; acc[v].y = (acc[v].y - sgn(self[v].y) * dot) * inv_self;
+      acc[v].z = (acc[v].z - sgn(self[v].z) * dot) * inv_self; acc[v].w = (acc[v].w - sgn(self[v].w) * dot) * inv_self;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) *reinterpret_cast<float4*>(dz + (int64_t)node * lddz + 4 * (lig + v * LPR)) = acc[v];
+}
+
+// long incidence lists: add the node's partial slots in chunk order, then the TransE epilogue
+template <int KIND, int LPR, int VPL>
+__global__ __launch_bounds__(256) void kge_bwd_nodes_fixup_kernel(bkg_rowsplit rs, const float* __restrict__ z,
+                                                                  int64_t ldz, const float* __restrict__ l1,
+                                                                  const float* __restrict__ partials,
+                                                                  float* __restrict__ dz, int64_t lddz) {
+  constexpr int G = 64 / LPR, d = 4 * LPR * VPL;
+  const int lane = threadIdx.x & 63;
+  const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR;
+  const bool live = l < rs.totals[2];
+  const int lig = lane % LPR;
+  const int node = live ? rs.long_row[l] : 0, s0 = live ? rs.long_slot0[l] : 0, n = live ? rs.long_cnt[l] : 0;
+  float4 acc[VPL], self[VPL];
+  float inv_self = 0.f;
+  bool above = false;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (KIND == KGE_TRANSE) {
+    const float nrm = l1[node];
+    inv_self = 1.0f / fmaxf(nrm, L1_EPS);
+    above = nrm > L1_EPS;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const float4 a = ld4(z + (int64_t)node * ldz + 4 * (lig + v * LPR));
+      self[v] = make_float4(a.x * inv_self, a.y * inv_self, a.z * inv_self, a.w * inv_self);
+    }
+  }
+  for (int c = 0; c < n; ++c) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const float4 t = ld4(partials + (int64_t)(s0 + c) * d + 4 * (lig + v * LPR));
+      acc[v].x += t.x; acc[v].y += t.y; acc[v].z += t.z; acc[v].w += t.w;
+    }
+  }
+  if (KIND == KGE_TRANSE) {  // the in-group reduction below needs every lane of the group
+    float dot = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+      dot += self[v].x * acc[v].x + self[v].y * acc[v].y + self[v].z * acc[v].z + self[v].w * acc[v].w;
+    dot = group_sum<LPR>(dot);
+    if (!above) dot = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      acc[v].x = (acc[v].x - sgn(self[v].x) * dot) * inv_self; acc[v].y = (acc[v].y - sgn(self[v].y) * dot) * inv_self;
+      acc[v].z = (acc[v].z - sgn(self[v].z) * dot) * inv_self; acc[v].w = (acc[v].w - sgn(self[v].w) * dot) * inv_self;
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) *reinterpret_cast<float4*>(dz + (int64_t)node * lddz + 4 * (lig + v * LPR)) = acc[v];
+  }
+}
+
+// SPLIT: one wave per row-split item (rowsplit.hip) instead of one wave per node
+template <int KIND, int LPR, int VPL, bool SPLIT>
 __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const float* __restrict__ z, int64_t ldz, int n_nodes,
                                                             Triplets tr, const float* __restrict__ rel_emb,
                                                             int64_t ldr, const float* __restrict__ gscore,
                                                             const float* __restrict__ l1,
                                                             const int32_t* __restrict__ inc_rowptr,
                                                             const int32_t* __restrict__ inc_perm,
-                                                            float* __restrict__ dz, int64_t lddz) {
+                                                            float* __restrict__ dz, int64_t lddz, bkg_rowsplit rs,
+                                                            float* __restrict__ partials) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
-  int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (node >= n_nodes) return;
-  node = __builtin_amdgcn_readfirstlane(node);
-  const int start = __builtin_amdgcn_readfirstlane(inc_rowptr[node]);
-  const int end = __builtin_amdgcn_readfirstlane(inc_rowptr[node + 1]);
+  int node, start, end, slot = -1;
+  if (SPLIT) {
+    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= rs.totals[0]) return;
+    item = __builtin_amdgcn_readfirstlane(item);
+    node = __builtin_amdgcn_readfirstlane(rs.item_row[item]);
+    start = __builtin_amdgcn_readfirstlane(rs.item_beg[item]);
+    end = __builtin_amdgcn_readfirstlane(rs.item_end[item]);
+    slot = __builtin_amdgcn_readfirstlane(rs.item_slot[item]);
+  } else {
+    node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= n_nodes) return;
+    node = __builtin_amdgcn_readfirstlane(node);
+    start = __builtin_amdgcn_readfirstlane(inc_rowptr[node]);
+    end = __builtin_amdgcn_readfirstlane(inc_rowptr[node + 1]);
+  }
 
   float4 self[VPL], acc[VPL];
   float inv_self = 0.f;
@@ -176,26 +265,16 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const float* __restr
         acc[v].z += __shfl_xor(acc[v].z, o, 64); acc[v].w += __shfl_xor(acc[v].w, o, 64);
       }
   }
-  if (KIND == KGE_TRANSE) {
-    // acc = Q = d loss / d z^_i.  Through z^ = z / max(||z||_1, eps):
-    //   ||z||_1 > eps : dz = (Q - sign(z) (z^ . Q)) / ||z||_1     else : dz = Q / eps
-    float dot = 0.f;
+  if (grp != 0) return;  // after the cross-group combine every group holds the full sum
+  if (SPLIT && slot >= 0) {
+    constexpr int d = 4 * LPR * VPL;
 #pragma unroll
     for (int v = 0; v < VPL; ++v)
-      dot += self[v].x * acc[v].x + self[v].y * acc[v].y + self[v].z * acc[v].z + self[v].w * acc[v].w;
-    dot = group_sum<LPR>(dot);
-    if (!(l1[node] > L1_EPS)) dot = 0.f;
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      acc[v].x = (acc[v].x - sgn(self[v].x) * dot) * inv_self; acc[v].y = (acc[v].y - sgn(self[v].y) * dot) * inv_self;
-      acc[v].z = (acc[v].z - sgn(self[v].z) * dot) * inv_self; acc[v].w = (acc[v].w - sgn(self[v].w) * dot) * inv_self;
-    }
+      *reinterpret_cast<float4*>(partials + (int64_t)slot * d + 4 * (lig + v * LPR)) = acc[v];
+    return;
   }
-  if (grp == 0) {
-#pragma unroll
-    for (int v = 0; v < VPL; ++v)
-      *reinterpret_cast<float4*>(dz + (int64_t)node * lddz + 4 * (lig + v * LPR)) = acc[v];
-  }
+  kge_nodes_finish<KIND, LPR, VPL>(acc, self, inv_self, KIND == KGE_TRANSE ? (l1[node] > L1_EPS) : true, node, lig, dz,
+                                   lddz);
 }
 
 // ------------------------------------------------------------------------------------ backward: drel
@@ -261,20 +340,99 @@ __global__ __launch_bounds__(256) void kge_bwd_rel_kernel(const float* __restric
   }
 }
 
+// Relation-sorted variant: order[] lists triplet ids grouped by relation (rel_ptr[r] .. rel_ptr[r+1]).
+// One wave owns a <= CH-triplet slice of ONE relation, accumulates it in registers and flushes once
+// with 16 B/lane-shaped float atomics (T/CH flushes of d floats: far below the atomic budget).
+template <int KIND, int LPR, int VPL>
+__global__ __launch_bounds__(256) void kge_bwd_rel_sorted_kernel(const float* __restrict__ z, int64_t ldz, Triplets tr,
+                                                                 const float* __restrict__ rel_emb, int64_t ldr,
+                                                                 const float* __restrict__ gscore, int n_rel,
+                                                                 float* __restrict__ drel, int64_t lddr,
+                                                                 const int32_t* __restrict__ order,
+                                                                 const int32_t* __restrict__ rel_ptr, int chunk) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
+  int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  w = __builtin_amdgcn_readfirstlane(w);
+  int r = 0, beg = 0, end = 0;
+  for (; r < n_rel; ++r) {  // wave-uniform scan of <= n_rel scalars
+    const int a = rel_ptr[r], b = rel_ptr[r + 1];
+    const int nc = (b - a + chunk - 1) / chunk;
+    if (w < nc) { beg = a + w * chunk; end = min(beg + chunk, b); break; }
+    w -= nc;
+  }
+  if (r >= n_rel) return;
+  float4 acc[VPL], rr[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rr[v] = ld4(rel_emb + (int64_t)r * ldr + 4 * (lig + v * LPR));
+  }
+  for (int k0 = beg; k0 < end; k0 += G) {
+    const int k = k0 + grp;
+    const bool live = k < end;
+    const int64_t t = live ? order[k] : order[beg];
+    const int64_t hi = tr.head[t], ti = tr.tail[t];
+    const float g = live ? gscore[t] : 0.f;
+    float4 h[VPL], tl[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = 4 * (lig + v * LPR);
+      h[v] = ld4(z + hi * ldz + c);
+      tl[v] = ld4(z + ti * ldz + c);
+    }
+    if (KIND == KGE_DISTMULT) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        acc[v].x = fmaf(g * h[v].x, tl[v].x, acc[v].x); acc[v].y = fmaf(g * h[v].y, tl[v].y, acc[v].y);
+        acc[v].z = fmaf(g * h[v].z, tl[v].z, acc[v].z); acc[v].w = fmaf(g * h[v].w, tl[v].w, acc[v].w);
+      }
+    } else {
+      float nh = 0.f, nt = 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        nh += fabsf(h[v].x) + fabsf(h[v].y) + fabsf(h[v].z) + fabsf(h[v].w);
+        nt += fabsf(tl[v].x) + fabsf(tl[v].y) + fabsf(tl[v].z) + fabsf(tl[v].w);
+      }
+      const float ih = 1.0f / fmaxf(group_sum<LPR>(nh), L1_EPS), it = 1.0f / fmaxf(group_sum<LPR>(nt), L1_EPS);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        acc[v].x -= g * sgn(h[v].x * ih + rr[v].x - tl[v].x * it); acc[v].y -= g * sgn(h[v].y * ih + rr[v].y - tl[v].y * it);
+        acc[v].z -= g * sgn(h[v].z * ih + rr[v].z - tl[v].z * it); acc[v].w -= g * sgn(h[v].w * ih + rr[v].w - tl[v].w * it);
+      }
+    }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        acc[v].x += __shfl_xor(acc[v].x, o, 64); acc[v].y += __shfl_xor(acc[v].y, o, 64);
+        acc[v].z += __shfl_xor(acc[v].z, o, 64); acc[v].w += __shfl_xor(acc[v].w, o, 64);
+      }
+  }
+  if (grp != 0) return;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    float* dst = drel + (int64_t)r * lddr + 4 * (lig + v * LPR);
+    atomicAdd(dst + 0, acc[v].x); atomicAdd(dst + 1, acc[v].y); atomicAdd(dst + 2, acc[v].z); atomicAdd(dst + 3, acc[v].w);
+  }
+}
+
 // ------------------------------------------------------------------------------------ launchers
-#define BKG_KGE_DISPATCH(D, CALL)                                   \
+#define BKG_KGE_DISPATCH(D, ...)                                    \
   switch (D) {                                                      \
-    case 8: { constexpr int LPR = 2, VPL = 1; CALL; } break;        \
-    case 16: { constexpr int LPR = 4, VPL = 1; CALL; } break;       \
-    case 24: { constexpr int LPR = 2, VPL = 3; CALL; } break;       \
-    case 48: { constexpr int LPR = 4, VPL = 3; CALL; } break;       \
-    case 96: { constexpr int LPR = 8, VPL = 3; CALL; } break;       \
-    case 32: { constexpr int LPR = 8, VPL = 1; CALL; } break;       \
-    case 64: { constexpr int LPR = 16, VPL = 1; CALL; } break;      \
-    case 128: { constexpr int LPR = 32, VPL = 1; CALL; } break;     \
-    case 256: { constexpr int LPR = 64, VPL = 1; CALL; } break;     \
-    case 512: { constexpr int LPR = 64, VPL = 2; CALL; } break;     \
-    case 768: { constexpr int LPR = 64, VPL = 3; CALL; } break;     \
+    case 8: { constexpr int LPR = 2, VPL = 1; __VA_ARGS__; } break;        \
+    case 16: { constexpr int LPR = 4, VPL = 1; __VA_ARGS__; } break;       \
+    case 24: { constexpr int LPR = 2, VPL = 3; __VA_ARGS__; } break;       \
+    case 48: { constexpr int LPR = 4, VPL = 3; __VA_ARGS__; } break;       \
+    case 96: { constexpr int LPR = 8, VPL = 3; __VA_ARGS__; } break;       \
+    case 32: { constexpr int LPR = 8, VPL = 1; __VA_ARGS__; } break;       \
+    case 64: { constexpr int LPR = 16, VPL = 1; __VA_ARGS__; } break;      \
+    case 128: { constexpr int LPR = 32, VPL = 1; __VA_ARGS__; } break;     \
+    case 256: { constexpr int LPR = 64, VPL = 1; __VA_ARGS__; } break;     \
+    case 512: { constexpr int LPR = 64, VPL = 2; __VA_ARGS__; } break;     \
+    case 768: { constexpr int LPR = 64, VPL = 3; __VA_ARGS__; } break;     \
     default: bkg::set_error_msg("kge: embedding width must be one of 8,16,24,32,48,64,96,128,256,512,768"); return -1; \
   }
 
@@ -316,17 +474,32 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const float* z, int64_t ldz, 
                                      const int64_t* head, const int64_t* tail, const int64_t* rel, int64_t T,
                                      const float* rel_emb, int64_t ldr, const float* gscore, const float* l1,
                                      const int32_t* inc_rowptr, const int32_t* inc_perm, float* dz, int64_t lddz,
-                                     void* stream) {
+                                     const bkg_rowsplit* split, float* partials, void* stream) {
   BKG_ARG(kind == KGE_DISTMULT || kind == KGE_TRANSE, "bkg_kge_bwd_nodes_f32: bad kind");
   BKG_ARG(kind == KGE_DISTMULT || l1 != nullptr, "bkg_kge_bwd_nodes_f32: TransE needs the row L1 norms");
   BKG_ARG(aligned16(z, ldz) && aligned16(rel_emb, ldr) && aligned16(dz, lddz), "bkg_kge_bwd_nodes_f32: alignment");
+  BKG_ARG(!split || (partials && ((uintptr_t)partials % 16 == 0)), "bkg_kge_bwd_nodes_f32: splitting needs partials");
   if (n_nodes == 0) return 0;
   Triplets tr{head, tail, rel, T};
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(ceil_div(n_nodes, 4)), block(256);
+  dim3 block(256);
+  bkg_rowsplit none{};
   BKG_KGE_DISPATCH(d, {
-    if (kind == KGE_DISTMULT) hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_DISTMULT, LPR, VPL>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz);
-    else hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_TRANSE, LPR, VPL>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz);
+    if (split) {
+      constexpr int G = 64 / LPR;
+      dim3 grid(ceil_div(split->n_items_max, 4)), fgrid(ceil_div(split->n_long_max, 4 * G));
+      if (kind == KGE_DISTMULT) {
+        hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_DISTMULT, LPR, VPL, true>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, *split, partials);
+        hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<KGE_DISTMULT, LPR, VPL>), fgrid, block, 0, s, *split, z, ldz, l1, partials, dz, lddz);
+      } else {
+        hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_TRANSE, LPR, VPL, true>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, *split, partials);
+        hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<KGE_TRANSE, LPR, VPL>), fgrid, block, 0, s, *split, z, ldz, l1, partials, dz, lddz);
+      }
+    } else {
+      dim3 grid(ceil_div(n_nodes, 4));
+      if (kind == KGE_DISTMULT) hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_DISTMULT, LPR, VPL, false>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, none, partials);
+      else hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_TRANSE, LPR, VPL, false>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, none, partials);
+    }
   })
   return check_launch("bkg_kge_bwd_nodes_f32");
 }
@@ -334,12 +507,22 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const float* z, int64_t ldz, 
 extern "C" int bkg_kge_bwd_rel_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, const int64_t* head,
                                    const int64_t* tail, const int64_t* rel, int64_t T, const float* rel_emb,
                                    int64_t ldr, const float* gscore, int32_t n_rel, float* drel, int64_t lddr,
-                                   void* stream) {
+                                   const int32_t* order, const int32_t* rel_ptr, void* stream) {
   BKG_ARG(kind == KGE_DISTMULT || kind == KGE_TRANSE, "bkg_kge_bwd_rel_f32: bad kind");
   BKG_ARG(aligned16(z, ldz) && aligned16(rel_emb, ldr), "bkg_kge_bwd_rel_f32: alignment");
+  BKG_ARG((order == nullptr) == (rel_ptr == nullptr), "bkg_kge_bwd_rel_f32: order and rel_ptr come together");
   if (T == 0) return 0;
   Triplets tr{head, tail, rel, T};
   hipStream_t s = (hipStream_t)stream;
+  if (order) {
+    constexpr int CH = 256;
+    dim3 grid(ceil_div(ceil_div(T, CH) + n_rel, 4)), block(256);
+    BKG_KGE_DISPATCH(d, {
+      if (kind == KGE_DISTMULT) hipLaunchKernelGGL((kge_bwd_rel_sorted_kernel<KGE_DISTMULT, LPR, VPL>), grid, block, 0, s, z, ldz, tr, rel_emb, ldr, gscore, n_rel, drel, lddr, order, rel_ptr, CH);
+      else hipLaunchKernelGGL((kge_bwd_rel_sorted_kernel<KGE_TRANSE, LPR, VPL>), grid, block, 0, s, z, ldz, tr, rel_emb, ldr, gscore, n_rel, drel, lddr, order, rel_ptr, CH);
+    })
+    return check_launch("bkg_kge_bwd_rel_f32");
+  }
   size_t lds = (size_t)n_rel * d * sizeof(float);
   int use_lds = lds <= 64 * 1024;
   BKG_KGE_DISPATCH(d, {

@@ -1,0 +1,87 @@
+// Long-row splitting for the CSR segment-reduce kernels (spmm.hip, kge.hip).
+//
+// PrimeKG-like graphs are heavily skewed (a handful of rows with 10^4-10^5 entries against a median
+// of tens): with one wave per row the launch runs as long as its longest row.  Following
+// cdna_hip_programming.md Appendix B "Scatter / gather / embedding", rows longer than `chunk` entries
+// are cut into chunks summed by separate waves into a partials buffer, and a second pass adds each
+// row's partials in chunk order (fixed order => bitwise reproducible).  The item table is built on the
+// device with three exclusive scans; array sizes are upper bounds so no host sync is needed.
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace bkg {
+
+// cnt[0][r] = items of row r (>= 1), cnt[1][r] = partial slots (0 for short rows), cnt[2][r] = is long
+__global__ void rowsplit_count_kernel(const int32_t* __restrict__ rowptr, int n_rows, int chunk,
+                                      int32_t* __restrict__ cnt) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_rows) return;
+  int items = 0, slots = 0, lng = 0;
+  if (r < n_rows) {
+    int len = rowptr[r + 1] - rowptr[r];
+    items = len <= chunk ? 1 : (len + chunk - 1) / chunk;
+    if (items > 1) { slots = items; lng = 1; }
+  }
+  const int stride = n_rows + 1;
+  cnt[r] = items;
+  cnt[stride + r] = slots;
+  cnt[2 * stride + r] = lng;
+}
+
+__global__ void rowsplit_fill_kernel(const int32_t* __restrict__ rowptr, int n_rows, int chunk,
+                                     const int32_t* __restrict__ scan, int32_t* __restrict__ item_row,
+                                     int32_t* __restrict__ item_beg, int32_t* __restrict__ item_end,
+                                     int32_t* __restrict__ item_slot, int32_t* __restrict__ long_row,
+                                     int32_t* __restrict__ long_slot0, int32_t* __restrict__ long_cnt,
+                                     int32_t* __restrict__ totals) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = n_rows + 1;
+  if (r == n_rows) {
+    totals[0] = scan[n_rows];
+    totals[1] = scan[stride + n_rows];
+    totals[2] = scan[2 * stride + n_rows];
+  }
+  if (r >= n_rows) return;
+  const int beg = rowptr[r], end = rowptr[r + 1], len = end - beg;
+  const int i0 = scan[r];
+  if (len <= chunk) {
+    item_row[i0] = r; item_beg[i0] = beg; item_end[i0] = end; item_slot[i0] = -1;
+    return;
+  }
+  const int n = (len + chunk - 1) / chunk, s0 = scan[stride + r], l = scan[2 * stride + r];
+  long_row[l] = r; long_slot0[l] = s0; long_cnt[l] = n;
+  for (int c = 0; c < n; ++c) {
+    item_row[i0 + c] = r;
+    item_beg[i0 + c] = beg + c * chunk;
+    item_end[i0 + c] = min(beg + (c + 1) * chunk, end);
+    item_slot[i0 + c] = s0 + c;
+  }
+}
+
+}  // namespace bkg
+
+using namespace bkg;
+
+extern "C" int bkg_rowsplit_build(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int32_t chunk, int32_t* cnt_tmp,
+                                  int32_t* scan_tmp, int32_t* item_row, int32_t* item_beg, int32_t* item_end,
+                                  int32_t* item_slot, int32_t* long_row, int32_t* long_slot0, int32_t* long_cnt,
+                                  int32_t* totals, void* workspace, int64_t workspace_bytes, void* stream) {
+  BKG_ARG(n_rows >= 0 && nnz >= 0 && chunk >= 16, "bkg_rowsplit_build: bad sizes (chunk >= 16)");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = (int)n_rows;
+  dim3 grid(ceil_div(n_rows + 1, 256)), block(256);
+  hipLaunchKernelGGL(rowsplit_count_kernel, grid, block, 0, s, rowptr, n, chunk, cnt_tmp);
+  const size_t stride = (size_t)n_rows + 1;
+  for (int k = 0; k < 3; ++k) {
+    size_t bytes = (size_t)workspace_bytes;
+    hipError_t e = rocprim::exclusive_scan(workspace, bytes, cnt_tmp + k * stride, scan_tmp + k * stride, (int32_t)0,
+                                           stride, rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) { set_error("bkg_rowsplit_build: exclusive_scan", e); return (int)e; }
+  }
+  hipLaunchKernelGGL(rowsplit_fill_kernel, grid, block, 0, s, rowptr, n, chunk, scan_tmp, item_row, item_beg, item_end,
+                     item_slot, long_row, long_slot0, long_cnt, totals);
+  return check_launch("bkg_rowsplit_build");
+}

@@ -33,8 +33,46 @@ class _Sorter:
         return sorted_keys, perm, ws
 
 
+SPLIT_CHUNK = 256        # entries per work item of a long row (csrc/rowsplit.hip)
+SPLIT_MIN_NNZ = 1 << 15  # below this one wave per row is fine and the table is not worth building
+
+
+class RowSplit:
+    """Device work-item table cutting rows longer than ``SPLIT_CHUNK`` entries (``bkg_rowsplit``)."""
+
+    def __init__(self, rowptr, n_rows, nnz, chunk=SPLIT_CHUNK):
+        dev = rowptr.device
+        self.n_items_max = n_rows + nnz // chunk
+        self.n_slots_max = 2 * (nnz // chunk) + 2
+        self.n_long_max = nnz // chunk + 1
+        cnt, scan = _i32(3 * (n_rows + 1), dev), _i32(3 * (n_rows + 1), dev)
+        self.bufs = [_i32(self.n_items_max, dev) for _ in range(4)] + [_i32(self.n_long_max, dev) for _ in range(3)]
+        self.totals = torch.zeros(3, dtype=torch.int32, device=dev)
+        ws_bytes = L.lib().bkg_sort_workspace_bytes(max(n_rows + 1, 1))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.call("bkg_rowsplit_build", L.ptr(rowptr), n_rows, nnz, chunk, L.ptr(cnt), L.ptr(scan),
+               *[L.ptr(b) for b in self.bufs], L.ptr(self.totals), L.ptr(ws), ws_bytes, L.stream())
+        self.c = L.RowSplitStruct(*[b.data_ptr() for b in self.bufs], self.totals.data_ptr(), self.n_items_max,
+                                  self.n_slots_max, self.n_long_max)
+
+    def partials(self, d, device):
+        return torch.empty(self.n_slots_max, d, dtype=torch.float32, device=device)
+
+
+def rowsplit_for(rowptr, n_rows, nnz):
+    return RowSplit(rowptr, n_rows, nnz) if nnz >= SPLIT_MIN_NNZ else None
+
+
 class CSR:
     """``rowptr [n_rows+1]``, ``col [nnz]`` (the other endpoint), ``perm [nnz]`` (original position)."""
+
+    _split = False
+
+    @property
+    def split(self):
+        if self._split is False:
+            self._split = rowsplit_for(self.rowptr, self.n_rows, self.nnz)
+        return self._split
 
     def __init__(self, key, other, n_rows):
         key = key.contiguous()
@@ -141,6 +179,7 @@ class RelGraph:
         self.src_csr = CSR(src, seg_of_edge, n)
         self.src_w = self.src_csr.permute_f32(w_edge)
         self.seg_iota_ptr = torch.arange(s + 1, dtype=torch.int32, device=dev)
+        self.seg_split = rowsplit_for(self.seg_ptr, s, e)
 
 
 def _cached(t, slot, key, build):

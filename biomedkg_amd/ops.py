@@ -78,7 +78,8 @@ def _spmm_bytes(nnz, n_rows, d, has_w):
     return nnz * (d * 4 + 4 + (4 if has_w else 0)) + n_rows * (d * 4 + 4)
 
 
-def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=False, drop: Dropout = None, tag=None):
+def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=False, drop: Dropout = None, tag=None,
+         split=None):
     """``out[i] = epi(sum_k w[k] x[col[k]] (+ self_w[i] x[i]) (+ addend[i]))`` (csrc/spmm.hip)."""
     L.require_cuda(rowptr, col, w, x, self_w, addend, bias)
     x = _f32c(x)
@@ -97,9 +98,11 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
     if timing:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+    partials = split.partials(d, x.device) if split is not None else None
     L.call("bkg_spmm_csr_f32", L.ptr(rowptr), L.ptr(col), L.ptr(w), L.ptr(x), x.stride(0), L.ptr(out), out.stride(0),
            n_rows, d, L.ptr(self_w), L.ptr(addend), addend.stride(0) if addend is not None else 0, L.ptr(bias),
-           int(relu), L.ptr(keep), p, seed, sid, L.stream())
+           int(relu), L.ptr(keep), p, seed, sid, L.sref(split.c if split is not None else None), L.ptr(partials),
+           L.stream())
     if timing:
         ev1.record()
         rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None)})
@@ -153,7 +156,7 @@ class _GcnConv(torch.autograd.Function):
         xw = gemm(x, weight, trans_b=True)
         c = graph.by_dst
         out = spmm(c.rowptr, c.col, gw.w_dst, xw, graph.num_nodes, self_w=gw.self_w, bias=bias, relu=relu, drop=drop,
-                   tag="gcn_propagate")
+                   tag="gcn_propagate", split=c.split)
         ctx.graph, ctx.gw, ctx.relu = graph, gw, relu
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
@@ -168,7 +171,7 @@ class _GcnConv(torch.autograd.Function):
         if ctx.gated:
             dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
         c = g.by_src
-        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, g.num_nodes, self_w=gw.self_w)
+        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, g.num_nodes, self_w=gw.self_w, split=c.split)
         dx = gemm(dxw, weight) if ctx.needs_input_grad[0] else None
         dw = gemm(dxw, x, trans_a=True) if ctx.needs_input_grad[1] else None
         db = dout.sum(0) if ctx.needs_input_grad[2] else None
@@ -188,11 +191,12 @@ class _RgcnConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop):
         n = rg.num_nodes
-        h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, x, rg.num_segments, tag="rgcn_segment_mean")   # [S, in]
+        h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, x, rg.num_segments, tag="rgcn_segment_mean",
+                 split=rg.seg_split)                                                  # [S, in]  segment means
         y = gemm_grouped_rows(h, weight, rg.rel_ptr)                                  # [S, out] per-relation W_r
         xr = gemm(x, root)                                                            # [N, out] root term
         c = rg.dst_csr
-        out = spmm(c.rowptr, c.col, None, y, n, addend=xr, bias=bias, relu=relu, drop=drop)
+        out = spmm(c.rowptr, c.col, None, y, n, addend=xr, bias=bias, relu=relu, drop=drop, split=c.split)
         ctx.rg, ctx.relu = rg, relu
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
@@ -215,7 +219,7 @@ class _RgcnConv(torch.autograd.Function):
             dh = gemm_grouped_rows(dy, weight, rg.rel_ptr, trans_b=True)              # [S, in]
             dx_root = gemm(dout, root, trans_b=True)                                  # [N, in]
             c = rg.src_csr
-            dx = spmm(c.rowptr, c.col, rg.src_w, dh, rg.num_nodes, addend=dx_root)
+            dx = spmm(c.rowptr, c.col, rg.src_w, dh, rg.num_nodes, addend=dx_root, split=c.split)
         return dx, dweight, droot, db, None, None, None
 
 
@@ -239,11 +243,26 @@ class Incidence:
         sorted_keys, self.perm, _ = _Sorter.sort(flat, None, num_nodes, 1)
         self.rowptr = _i32(num_nodes + 1, ei.device)
         L.call("bkg_lower_bound_u32", L.ptr(sorted_keys), flat.numel(), num_nodes + 1, 1, L.ptr(self.rowptr), L.stream())
+        from .graph import rowsplit_for
+        self.split = rowsplit_for(self.rowptr, num_nodes, flat.numel())
 
 
 def incidence_of(edge_index, num_nodes) -> Incidence:
     from .graph import _cached
     return _cached(edge_index, "incidence", (int(num_nodes),), lambda: Incidence(edge_index, num_nodes))
+
+
+def relation_order_of(edge_type, num_relations):
+    """Triplet ids grouped by relation (stable) + per-relation offsets, cached on ``edge_type``."""
+    from .graph import _cached, _Sorter, _i32
+
+    def build():
+        sorted_keys, perm, _ = _Sorter.sort(edge_type, None, num_relations, 1)
+        rel_ptr = _i32(num_relations + 1, edge_type.device)
+        L.call("bkg_lower_bound_u32", L.ptr(sorted_keys), edge_type.numel(), num_relations + 1, 1, L.ptr(rel_ptr),
+               L.stream())
+        return perm, rel_ptr
+    return _cached(edge_type, "rel_order", (int(num_relations),), build)
 
 
 class _KgeScore(torch.autograd.Function):
@@ -272,14 +291,17 @@ class _KgeScore(torch.autograd.Function):
                 l1 = torch.empty(n, dtype=torch.float32, device=z.device)
                 L.call("bkg_row_l1norm_f32", L.ptr(z), z.stride(0), n, d, L.ptr(l1), L.stream())
             dz = torch.empty_like(z)
+            sp = inc.split
+            partials = sp.partials(d, z.device) if sp is not None else None
             L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
                    L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), L.ptr(l1), L.ptr(inc.rowptr), L.ptr(inc.perm),
-                   L.ptr(dz), dz.stride(0), L.stream())
+                   L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None), L.ptr(partials), L.stream())
         if ctx.needs_input_grad[1]:
             drel = torch.zeros_like(rel_emb)
+            order, rel_ptr = relation_order_of(et, rel_emb.size(0)) if t >= (1 << 15) else (None, None)
             L.call("bkg_kge_bwd_rel_f32", kind, L.ptr(z), z.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
                    L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), rel_emb.size(0), L.ptr(drel), drel.stride(0),
-                   L.stream())
+                   L.ptr(order), L.ptr(rel_ptr), L.stream())
         return dz, drel, None, None, None
 
 

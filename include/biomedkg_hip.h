@@ -1,0 +1,126 @@
+/* C-ABI of libbiomedkg_hip.so -- the drop-in boundary of the MI355X-native BioMedKG hot path.
+ *
+ * The reference (HySonLab/BioMedKG) is pure Python: it has no FFI of its own.  The boundary a
+ * maintainer binds is therefore the set of third-party / in-repo operator calls its hot path makes;
+ * every entry point below names the reference call site it replaces (paths relative to the reference
+ * root) and INTEGRATION.md shows the ctypes stub.  All pointers are DEVICE pointers unless marked
+ * (host); matrices are row-major with an explicit leading dimension in ELEMENTS; `stream` is a
+ * hipStream_t.  Every function returns 0 on success, a hipError_t (> 0) or -1 (bad argument)
+ * otherwise, with text available from bkg_last_error().  fp32 = IEEE binary32 throughout.
+ */
+#ifndef BIOMEDKG_HIP_H
+#define BIOMEDKG_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int bkg_abi_version(void);
+const char* bkg_last_error(void); /* (host) thread-local text of the last failure */
+
+/* ---- graph preparation (replaces PyG's COO bookkeeping inside GCNConv / RGCNConv /
+ *      negative_sampling: biomedkg/model/encoder.py:52,57,155,160; biomedkg/kge_module.py:93) */
+int64_t bkg_sort_workspace_bytes(int64_t n);
+/* stable radix sort of keys lo[i] + hi[i]*n_lo (hi may be NULL); outputs sorted keys + source positions */
+int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n, uint32_t* keys_tmp,
+                   uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+/* out[s] = lower_bound(sorted, s*stride), s in [0, n_queries) -- CSR row pointers from sorted keys */
+int bkg_lower_bound_u32(const uint32_t* sorted, int64_t n, int64_t n_queries, uint32_t stride, int32_t* out,
+                        void* stream);
+int bkg_gather_i64_to_i32(const int64_t* src, const uint32_t* idx, int32_t* out, int64_t n, void* stream);
+int bkg_gather_i32(const int32_t* src, const int32_t* idx, int32_t* out, int64_t n, void* stream);
+int bkg_gather_f32(const float* src, const int32_t* idx, float* out, int64_t n, void* stream);
+/* PyG gcn_norm (add_remaining_self_loops + deg^-1/2 by target) over the dst-sorted CSR; keep = optional
+ * dropout_edge mask [E] in edge order (biomedkg/model/gcl.py:42-43,76).  Outputs dis[N], self_w[N], w_edge[E]. */
+int bkg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int64_t* src,
+                 const int64_t* dst, const uint8_t* keep, int64_t n_nodes, int64_t n_edges, float* dis, float* self_w,
+                 float* w_edge, void* stream);
+/* RGCNConv(aggr="mean") (relation, target) segments over edges sorted by rel*N + dst */
+int bkg_rgcn_segments(const uint32_t* sorted, int64_t n, int64_t n_nodes, int32_t* flag_tmp, int32_t* scan_tmp,
+                      int32_t* seg_of, int32_t* seg_ptr, int32_t* seg_dst, int32_t* seg_rel, float* inv_cnt,
+                      int32_t* n_seg, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Long-row splitting of a CSR for the segment-reduce kernels: rows longer than `chunk` entries are cut
+ * into chunks summed by separate waves (partials added in chunk order by a second pass).  All arrays are
+ * sized by the upper bounds n_items_max = n_rows + nnz/chunk, n_slots_max = 2*(nnz/chunk) + 2,
+ * n_long_max = nnz/chunk + 1; totals[3] = {n_items, n_slots, n_long} stays on the device (no host sync). */
+typedef struct bkg_rowsplit {
+  const int32_t* item_row;   /* [n_items_max] */
+  const int32_t* item_beg;   /* [n_items_max] entry range of the item */
+  const int32_t* item_end;
+  const int32_t* item_slot;  /* [n_items_max] partial slot, or -1: the item is a whole row */
+  const int32_t* long_row;   /* [n_long_max] */
+  const int32_t* long_slot0; /* [n_long_max] first slot of the row */
+  const int32_t* long_cnt;   /* [n_long_max] number of slots */
+  const int32_t* totals;     /* [3] device */
+  int64_t n_items_max, n_slots_max, n_long_max;
+} bkg_rowsplit;
+int bkg_rowsplit_build(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int32_t chunk, int32_t* cnt_tmp /*[3*(n_rows+1)]*/,
+                       int32_t* scan_tmp /*[3*(n_rows+1)]*/, int32_t* item_row, int32_t* item_beg, int32_t* item_end,
+                       int32_t* item_slot, int32_t* long_row, int32_t* long_slot0, int32_t* long_cnt, int32_t* totals,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- message passing: out[i,:] = epi(sum_k w[k] x[col[k],:] (+ self_w[i] x[i,:]) (+ addend[i,:]))
+ *      epi = dropout(relu(. + bias)).  Replaces MessagePassing.propagate + scatter of GCNConv / RGCNConv and
+ *      the ReLU + F.dropout(0.2) that follow (biomedkg/model/encoder.py:50-59,153-162).  Dropout keep decisions:
+ *      explicit uint8 mask `keep` [n_rows,d], or in-kernel Philox(seed, stream_id) when keep == NULL and drop_p > 0.
+ *      split (host, nullable) + partials [n_slots_max, d] enable long-row splitting. */
+int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x, int64_t ldx,
+                     float* out, int64_t ldo, int64_t n_rows, int32_t d, const float* self_w, const float* addend,
+                     int64_t ld_add, const float* bias, int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
+                     uint32_t stream_id, const bkg_rowsplit* split, float* partials, void* stream);
+
+/* ---- exact-fp32 MFMA GEMM: C = epi(alpha op(A) op(B)), epi = (+bias[col]) -> act (0 none, 1 relu, 2 elu) ->
+ *      (* gate>0 ? gate_scale : 0) -> (+ beta C).  Replaces torch Linear inside GCNConv.lin, the GRACE/GGD/DGI heads
+ *      (biomedkg/model/gcl.py:19-21,49-51,86-90), fusion projections (biomedkg/utils/fusion.py:17-20,70).
+ *      Large-K plain products (weight gradients) run split-K with f32 atomics into a zeroed C. */
+int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                 int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias,
+                 int32_t act, const float* gate, int64_t ldg, float gate_scale, void* stream);
+/* RGCNConv per-relation products: rows grouped by device-side group_ptr[G+1]; group g uses B + g*strideB */
+int bkg_gemm_grouped_rows_f32(int32_t trans_b, int64_t M_total, int64_t N, int64_t K, const float* A, int64_t lda,
+                              const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                              const int32_t* group_ptr, int32_t G, const float* gate, int64_t ldg, float gate_scale,
+                              void* stream);
+/* C[g] += A[rows g]^T B[rows g] (C zeroed by the caller; split over row chunks, f32 atomics) */
+int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, const float* A, int64_t lda, const float* B,
+                           int64_t ldb, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int32_t G,
+                           void* stream);
+
+/* ---- KGE triplet scorer: kind 0 = DistMult (biomedkg/model/decoder.py:45-49), 1 = TransE (:31-38).
+ *      head/tail/rel are int64 [T] (the rows of edge_index / edge_type as the reference hands them over). */
+int bkg_kge_score_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, const int64_t* head, const int64_t* tail,
+                      const int64_t* rel, int64_t T, const float* rel_emb, int64_t ldr, float* score, void* stream);
+int bkg_row_l1norm_f32(const float* z, int64_t ldz, int64_t n, int32_t d, float* l1, void* stream);
+/* dz[i] = sum over the incidences of node i (inc_rowptr/inc_perm: the 2T entries cat(head,tail) sorted by node;
+ * entry e < T: i is the head of triplet e) -- segment reduce, plain stores, no atomics */
+int bkg_kge_bwd_nodes_f32(int32_t kind, const float* z, int64_t ldz, int64_t n_nodes, int32_t d, const int64_t* head,
+                          const int64_t* tail, const int64_t* rel, int64_t T, const float* rel_emb, int64_t ldr,
+                          const float* gscore, const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm,
+                          float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials, void* stream);
+/* drel[r] += sum_t ... (drel zeroed by the caller); order/rel_ptr (nullable together) = triplet ids sorted by
+ * relation and the [n_rel+1] offsets of each relation in that order */
+int bkg_kge_bwd_rel_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, const int64_t* head, const int64_t* tail,
+                        const int64_t* rel, int64_t T, const float* rel_emb, int64_t ldr, const float* gscore,
+                        int32_t n_rel, float* drel, int64_t lddr, const int32_t* order, const int32_t* rel_ptr,
+                        void* stream);
+
+/* ---- NT-Xent (PyGCL DualBranchContrast(InfoNCE(tau), "L2L", intraview_negs=True): biomedkg/gcl_module.py:171-173,189)
+ *      over zn = [normalize(h1); normalize(h2)] (M = 2N rows, h <= 256): partial row sums of exp(z_i.z_j/tau), j != i,
+ *      and the flash-style backward sum_j exp(.)(1/D_i + 1/D_j) zn_j; `splits` column ranges, summed by the caller. */
+int bkg_ntxent_rowsum_f32(const float* zn, int64_t ld, int64_t M, int32_t h, float tau, int32_t splits,
+                          float* rowsum_partial, void* stream);
+int bkg_ntxent_bwd_f32(const float* zn, int64_t ld, int64_t M, int32_t h, float tau, const float* rden, int32_t splits,
+                       float* dz_partial, void* stream);
+
+/* ---- modality fusion epilogues (biomedkg/utils/fusion.py:17-31 AttentionFusion, :49-90 ReDAF) */
+int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_t D, float* out, int64_t ldo,
+                      void* stream);
+int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int32_t M, int32_t D, const float* scale,
+                          const uint8_t* keep, float drop_p, uint64_t seed, float* out, int64_t ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
