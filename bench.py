@@ -52,28 +52,17 @@ def parse():
     return ap.parse_args()
 
 
-def allreduce_grads(params, world):
-    if world == 1:
-        return
-    grads = [p.grad for p in params if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])      # one bucket: <= 49 MB for R-GCN-768
-    torch.distributed.all_reduce(flat)
-    flat.div_(world)
-    off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
-
-
 def make_step(module, batch, world):
+    from biomedkg_amd.distributed import GradBucket
     params = [p for p in module.model.parameters()]
     opt = torch.optim.Adam(params, lr=1e-3)
+    bucket = GradBucket(params, world)   # one flat RCCL all-reduce per sub-step (<= 49 MB)
 
     def step():
         opt.zero_grad(set_to_none=True)
         loss = module.training_step(batch)
         loss.backward()
-        allreduce_grads(params, world)
+        bucket.all_reduce()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
         return loss

@@ -1,0 +1,80 @@
+"""Multi-GPU glue: one process per GPU, ``torch.distributed`` over RCCL (backend "nccl" on ROCm).
+
+The reference's only multi-GPU mode is Lightning's implicit DDP over mini-batches
+(``configs/{gcl,kge,dpi}.yaml:11``, ``train_gcl.py:63-68``): every rank steps on its own
+batch / graph and the gradients of ``self.model`` are averaged.  That is what this module provides,
+sized for xGMI: the R-GCN (R=30, d=256) gradient is 32.5 MB and the GCN+head 1.8 MB, so ALL gradients
+go out as ONE flat bucket per step (a ring all-reduce over 7 x ~153 GB/s links is per-link bound:
+2*(7/8)*32.5 MB / 153 GB/s ~ 0.37 ms; splitting it would only add launch latency).  No collective is on
+the data path of a single-GPU step.  Node-partitioned full-graph training (all-gather of boundary
+embeddings per layer) is the next multi-GPU row and is not built yet.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*.
+    Returns (rank, world, local_rank).  No-op for WORLD_SIZE == 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+class GradBucket:
+    """Averages the gradients of ``params`` across ranks with one flat all-reduce per call."""
+
+    def __init__(self, params, world=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self._flat = None
+
+    def all_reduce(self):
+        if self.world == 1:
+            return
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        n = sum(g.numel() for g in grads)
+        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
+            self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
+        off = 0
+        for g in grads:
+            self._flat[off:off + g.numel()].copy_(g.reshape(-1))
+            off += g.numel()
+        dist.all_reduce(self._flat)
+        self._flat.div_(self.world)
+        off = 0
+        for p, g in zip(self.params, grads):
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(self._flat[off:off + g.numel()].view_as(p))
+            off += g.numel()
+
+
+def broadcast_parameters(module, src=0):
+    """Make every rank start from rank ``src``'s weights (what DDP does at construction)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,78 @@
+"""Host-side logic that needs no GPU: synthetic graph shapes, the LightningModule stand-in
+(hyper-parameters, checkpoint round trip, reference key layout), module construction."""
+import os
+
+import torch
+
+
+def test_primekg_like_shape_and_skew():
+    from biomedkg_amd import synthetic
+    g = synthetic.primekg_like(13_000, 400_000, 30, seed=1)
+    ei, et = g["edge_index"], g["edge_type"]
+    assert ei.shape == (2, 400_000) and et.shape == (400_000,) and ei.dtype == torch.int64
+    assert int(ei.max()) < 13_000 and int(et.max()) == g["num_relations"] - 1 == 29
+    share = torch.bincount(et, minlength=30).float() / et.numel()
+    assert 0.30 < share[0] < 0.45 and 0.25 < share[1] < 0.40 and share[-1] < 1e-3      # skewed relation histogram
+    indeg = torch.bincount(ei[1], minlength=13_000)
+    assert indeg.max() > 50 * indeg.float().median().clamp(min=1)                       # hubs
+    g2 = synthetic.primekg_like(13_000, 400_000, 30, seed=1)
+    assert torch.equal(g2["edge_index"], ei)                                            # seeded
+
+
+def test_gcl_small_graph():
+    from biomedkg_amd import synthetic
+    ei = synthetic.gcl_small(500, 5_000, seed=2)
+    assert ei.shape == (2, 5_000) and (ei[0] != ei[1]).all()
+    assert torch.unique(ei[0] * 500 + ei[1]).numel() == 5_000
+    x = synthetic.lm_features(10, 2, 16)
+    torch.testing.assert_close(x.norm(dim=1), torch.ones(10, 16))
+
+
+def test_module_key_layout_matches_reference(golden):
+    """state_dict keys of the modules == the keys recorded from the reference's own modules."""
+    from biomedkg_amd import gcl_module as M
+    from biomedkg_amd.kge_module import KGEModule
+    for name, g in golden("gcl_steps").items():
+        mod = getattr(M, g["kind"])(**g["hparams"], fuse_method=g["fuse_method"])
+        assert set(mod.state_dict()) == set(g["state"]), name
+    for name, g in golden("kge_steps").items():
+        assert set(KGEModule(**g["hparams"]).state_dict()) == set(g["state"]), name
+
+
+def test_hparams_and_checkpoint_round_trip(tmp_path):
+    from biomedkg_amd.gcl_module import GGDModule
+    from biomedkg_amd.kge_module import KGEModule
+    m = GGDModule(in_dim=32, hidden_dim=16, out_dim=16, num_hidden_layers=2, fuse_method="redaf")
+    hp = dict(m.hparams)
+    assert hp["in_dim"] == 32 and hp["fuse_method"] == "redaf" and hp["embed_dim"] == 32 and "model" not in hp
+    path = os.path.join(tmp_path, "m.ckpt")
+    keep = {k: v for k, v in hp.items() if not isinstance(v, torch.nn.Module)}
+    torch.save({"state_dict": m.state_dict(), "hyper_parameters": keep}, path)
+    m2 = GGDModule.load_from_checkpoint(path)
+    for k, v in m.state_dict().items():
+        assert torch.equal(m2.state_dict()[k], v)
+    k = KGEModule("rgcn", "transe", 32, 16, 16, 2, 5, 2, "cosine", 1e-3, 0.2, "attention", 3, "lm")
+    assert k.modality_transform is not None and k.neg_ratio == 3 and k.fix_edge_id is None
+    k.fix_edge_id = 1
+    k.edge_mapping = {0: "a", 1: "b"}
+    assert k.fix_edge_id == 1 and hasattr(k, "edge_wise_pre_valid") and k.edge_mapping[1] == "b"
+    assert torch.allclose(k.model.decoder.rel_emb.norm(dim=1), torch.ones(5))      # TransE init: row-normalised
+
+
+def test_factory_names():
+    from biomedkg_amd.factory import FusionFactory, KGEModelFactory
+    assert FusionFactory.create_fuser("none", 8) is None
+    assert type(FusionFactory.create_fuser("attention", 8)).__name__ == "AttentionFusion"
+    model = KGEModelFactory.get_model("rgcn", "dismult", 8, 8, 8, 1, 3, 2)
+    assert type(model.decoder).__name__ == "DistMult" and len(model.encoder.graph_layers) == 3
+    assert KGEModelFactory._get_decoder("nope", 3, 8) is None     # reference returns None silently
+
+
+def test_metrics_small_known_answers():
+    from biomedkg_amd.utils.metrics import AUROC, AveragePrecision, F1Score
+    p = torch.tensor([0.9, 0.8, 0.7, 0.6, 0.55, 0.4])
+    t = torch.tensor([1, 1, 0, 1, 0, 0])
+    for cls, exp in ((AUROC, 8 / 9), (AveragePrecision, (1 + 1 + 0.75) / 3), (F1Score, 2 * 3 / (2 * 3 + 2 + 0))):
+        m = cls(task="binary")
+        m.update(p[:3], t[:3]); m.update(p[3:], t[3:])
+        assert abs(float(m.compute()) - exp) < 1e-6, cls.__name__
