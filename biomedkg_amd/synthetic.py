@@ -49,8 +49,10 @@ def primekg_like(num_nodes=130_000, num_edges=4_000_000, num_relations=30, seed=
     """-> dict(edge_index int64 [2,E], edge_type int64 [E], num_nodes, num_relations, node_type)."""
     rng = np.random.default_rng(seed)
     total = sum(s for _, s in NODE_TYPES)
-    sizes = [max(8, int(round(s * num_nodes / total))) for _, s in NODE_TYPES]
-    sizes[-1] += num_nodes - sum(sizes)
+    sizes = [max(2, int(round(s * num_nodes / total))) for _, s in NODE_TYPES]
+    sizes[int(np.argmax(sizes))] += num_nodes - sum(sizes)   # rounding slack goes to the largest type
+    if min(sizes) < 1:
+        raise ValueError("num_nodes too small for the 10 PrimeKG node types")
     offs = np.concatenate([[0], np.cumsum(sizes)])
     rels = RELATIONS[:num_relations]
     share = np.array([r[3] for r in rels])

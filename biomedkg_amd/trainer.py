@@ -1,0 +1,184 @@
+"""Minimal stand-in for the Lightning ``Trainer`` behaviours the reference's entry points rely on
+(``train_gcl.py:63-122``, ``train_kge.py:44-98``; SURVEY.md 8b "Trainer behaviours to reproduce"):
+``seed_everything``, ``max_epochs``, ``check_val_every_n_epoch``, ``gradient_clip_val`` (global L2
+norm over the optimiser's parameters), ``fast_dev_run``, ``ModelCheckpoint(monitor, mode, save_top_k,
+save_last)``, ``EarlyStopping(monitor, patience)``, ``estimated_stepping_batches``, the per-EPOCH
+``lr_scheduler.step()`` Lightning applies to a bare scheduler, ``test(ckpt_path="best")``
+and -- for ``devices`` > 1 under torch.distributed.run -- DDP-style gradient averaging over RCCL.
+Used only when ``lightning`` is not importable.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import distributed as D
+
+
+def seed_everything(seed: int):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    os.environ["PL_GLOBAL_SEED"] = str(seed)
+    return seed
+
+
+class ModelCheckpoint:
+    def __init__(self, dirpath, monitor="val_loss", save_top_k=1, mode="min", save_last=False):
+        self.dirpath, self.monitor, self.save_top_k, self.mode, self.save_last = dirpath, monitor, save_top_k, mode, save_last
+        self.best = []            # [(score, path)]
+        self.best_model_path = ""
+
+    def _better(self, a, b):
+        return a < b if self.mode == "min" else a > b
+
+    def on_validation_end(self, trainer, module, metrics):
+        if self.monitor not in metrics or trainer.fast_dev_run:
+            return
+        score = float(metrics[self.monitor])
+        os.makedirs(self.dirpath, exist_ok=True)
+        path = os.path.join(self.dirpath, f"epoch={trainer.current_epoch}-step={trainer.global_step}.ckpt")
+        self.best.append((score, path))
+        self.best.sort(key=lambda t: t[0], reverse=self.mode != "min")
+        trainer.save_checkpoint(module, path)
+        for _, old in self.best[self.save_top_k:]:
+            if os.path.exists(old):
+                os.remove(old)
+        self.best = self.best[: self.save_top_k]
+        self.best_model_path = self.best[0][1]
+        if self.save_last:
+            trainer.save_checkpoint(module, os.path.join(self.dirpath, "last.ckpt"))
+
+
+class EarlyStopping:
+    def __init__(self, monitor="val_loss", mode="min", patience=3):
+        self.monitor, self.mode, self.patience = monitor, mode, patience
+        self.best, self.wait = None, 0
+
+    def on_validation_end(self, trainer, module, metrics):
+        if self.monitor not in metrics:
+            return
+        score = float(metrics[self.monitor])
+        if self.best is None or (score < self.best if self.mode == "min" else score > self.best):
+            self.best, self.wait = score, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                trainer.should_stop = True
+
+
+class Trainer:
+    def __init__(self, max_epochs=1, check_val_every_n_epoch=1, gradient_clip_val=None, fast_dev_run=False,
+                 callbacks=None, devices=None, accelerator="auto", log_every_n_steps=10, deterministic=False,
+                 enable_checkpointing=True, default_root_dir=None, logger=None, **unused):
+        self.max_epochs, self.val_every = max_epochs, check_val_every_n_epoch
+        self.clip, self.fast_dev_run = gradient_clip_val, fast_dev_run
+        self.callbacks = list(callbacks or [])
+        self.log_every, self.root = log_every_n_steps, default_root_dir
+        self.rank, self.world, self.local = D.init_from_env()
+        self.device = torch.device("cuda", self.local) if torch.cuda.is_available() else torch.device("cpu")
+        self.current_epoch = self.global_step = 0
+        self.should_stop = False
+        self.estimated_stepping_batches = 0
+        self.callback_metrics = {}
+        self._epoch_logs = {}
+        self.history = []
+
+    # ---- logging hook used by compat.LightningModule.log
+    def _log(self, name, value, **kw):
+        v = float(value.item() if isinstance(value, torch.Tensor) else value)
+        self._epoch_logs.setdefault(name, []).append(v)
+
+    def _flush_logs(self):
+        out = {k: sum(v) / len(v) for k, v in self._epoch_logs.items()}
+        self._epoch_logs = {}
+        self.callback_metrics.update(out)
+        return out
+
+    def save_checkpoint(self, module, path):
+        if self.rank != 0:
+            return
+        hp = {k: v for k, v in dict(getattr(module, "hparams", {})).items() if not isinstance(v, torch.nn.Module)}
+        torch.save({"state_dict": module.state_dict(), "hyper_parameters": hp, "epoch": self.current_epoch,
+                    "global_step": self.global_step}, path)
+
+    def _move(self, batch):
+        return batch.to(self.device) if hasattr(batch, "to") else batch
+
+    def _limit(self, loader):
+        for i, batch in enumerate(loader):
+            if self.fast_dev_run and i >= 1:
+                break
+            yield i, self._move(batch)
+
+    def fit(self, model, train_dataloaders=None, val_dataloaders=None):
+        model.trainer = self
+        model.to(self.device)
+        D.broadcast_parameters(model)
+        steps_per_epoch = len(train_dataloaders) if hasattr(train_dataloaders, "__len__") else 1
+        epochs = 1 if self.fast_dev_run else self.max_epochs
+        self.estimated_stepping_batches = 1 if self.fast_dev_run else steps_per_epoch * epochs
+        conf = model.configure_optimizers()
+        opt, sched = conf["optimizer"], conf.get("lr_scheduler")
+        params = [p for g in opt.param_groups for p in g["params"]]
+        bucket = D.GradBucket(params, self.world)
+        for epoch in range(epochs):
+            self.current_epoch = epoch
+            model.train()
+            t0 = time.time()
+            for i, batch in self._limit(train_dataloaders):
+                opt.zero_grad(set_to_none=True)
+                loss = model.training_step(batch)
+                loss.backward()
+                bucket.all_reduce()
+                if self.clip:
+                    torch.nn.utils.clip_grad_norm_(params, self.clip)
+                opt.step()
+                self.global_step += 1
+            if sched is not None:
+                sched.step()                      # Lightning's default interval for a bare scheduler: "epoch"
+            logs = self._flush_logs()
+            logs.update(epoch=epoch, seconds=time.time() - t0)
+            if val_dataloaders is not None and (self.fast_dev_run or (epoch + 1) % self.val_every == 0):
+                logs.update(self.validate(model, val_dataloaders))
+                for cb in self.callbacks:
+                    cb.on_validation_end(self, model, self.callback_metrics)
+            self.history.append(logs)
+            if self.rank == 0:
+                print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in logs.items()}), flush=True)
+            if self.should_stop:
+                break
+        return self
+
+    @torch.no_grad()
+    def validate(self, model, loader):
+        model.eval()
+        for i, batch in self._limit(loader):
+            model.validation_step(batch, i)
+        if hasattr(model, "on_validation_epoch_end"):
+            model.on_validation_epoch_end()
+        model.train()
+        return self._flush_logs()
+
+    @torch.no_grad()
+    def test(self, model=None, dataloaders=None, ckpt_path=None):
+        model.trainer = self
+        model.to(self.device)
+        if ckpt_path == "best":
+            best = next((cb.best_model_path for cb in self.callbacks if isinstance(cb, ModelCheckpoint)), "")
+            if best and os.path.exists(best):
+                model.load_state_dict(torch.load(best, map_location=self.device, weights_only=False)["state_dict"])
+        model.eval()
+        for i, batch in self._limit(dataloaders):
+            model.test_step(batch, i)
+        if hasattr(model, "on_test_epoch_end"):
+            model.on_test_epoch_end()
+        out = self._flush_logs()
+        if self.rank == 0:
+            print(json.dumps({"test": {k: round(v, 6) for k, v in out.items()}}), flush=True)
+        return [out]
