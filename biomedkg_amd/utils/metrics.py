@@ -117,7 +117,8 @@ class BootStrapper(Metric):
 
 class MetricCollection(torch.nn.ModuleDict):
     def __init__(self, metrics, prefix=""):
-        super().__init__(metrics)
+        super().__init__()
+        torch.nn.ModuleDict.update(self, metrics)   # `update` below is the METRIC update, not dict.update
         self.prefix = prefix
 
     def clone(self, prefix=""):
