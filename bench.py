@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--relations", type=int, default=30)
     ap.add_argument("--neg-ratio", type=int, default=1)
     ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                    help="matrix-core operand precision (BASELINE configs[2] is the bf16 config; fp32 = exact mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=int, default=16, help="CPU baseline runs on a 1/scale graph")
     return ap.parse_args()
@@ -145,6 +147,7 @@ def main():
     from biomedkg_amd.gcl_module import GGDModule
     from biomedkg_amd.kge_module import KGEModule
 
+    ops.set_matmul_precision(args.precision)
     g = synthetic.primekg_like(args.nodes, args.edges, args.relations, seed=42 + rank)
     torch.manual_seed(42 + rank)
     n, e, r, h = g["num_nodes"], g["edge_index"].size(1), g["num_relations"], args.hidden
@@ -216,11 +219,15 @@ def main():
             "metric": "edges/sec, GCL (GGD) step + KGE (R-GCN+DistMult) step, PrimeKG++ scale",
             "value": world * e / (ms * 1e-3), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
+            "dtype_note": ("matrix-core operands bf16 (rounded while staged into LDS), fp32 accumulate; activations, "
+                           "aggregation, scorer and optimizer state fp32" if args.precision == "bf16"
+                           else "exact fp32 everywhere (fp32-input MFMA)"),
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] shape: synthetic PrimeKG++-like graph per GPU, "
                                    f"N={n} E={e} R={r}; GGD/GCN 768->{h} (4 conv layers) step + R-GCN d={h} "
-                                   f"(4 conv layers) + DistMult, neg_ratio={args.neg_ratio}, step; fp32; "
-                                   "fwd+bwd+clip+Adam", "parallelism": f"dp{world}"},
+                                   f"(4 conv layers) + DistMult, neg_ratio={args.neg_ratio}, step; "
+                                   f"{args.precision} matmuls; fwd+bwd+clip+Adam", "parallelism": f"dp{world}"},
             "triplets_per_sec_kge_step": world * (e + n_neg) / (ms_k * 1e-3),
             "edges_per_sec_gcl_step": world * e / (ms_g * 1e-3),
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k,

@@ -40,9 +40,9 @@ SIGNATURES = {
     "bkg_rowsplit_build": (I32, [P, I64, I64, I32, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
     "bkg_spmm_csr_f32": (I32, [P, P, P, P, I64, P, I64, I64, I32, P, P, I64, P, I32, P, F32, U64, U32, P, P, P]),
     # gemm_f32.hip
-    "bkg_gemm_f32": (I32, [I32, I32, I64, I64, I64, F32, P, I64, P, I64, F32, P, I64, P, I32, P, I64, F32, P]),
-    "bkg_gemm_grouped_rows_f32": (I32, [I32, I64, I64, I64, P, I64, P, I64, I64, P, I64, P, I32, P, I64, F32, P]),
-    "bkg_gemm_grouped_k_f32": (I32, [I64, I64, I64, P, I64, P, I64, P, I64, I64, P, I32, P]),
+    "bkg_gemm_f32": (I32, [I32, I32, I64, I64, I64, F32, P, I64, P, I64, F32, P, I64, P, I32, P, I64, F32, I32, P]),
+    "bkg_gemm_grouped_rows_f32": (I32, [I32, I64, I64, I64, P, I64, P, I64, I64, P, I64, P, I32, P, I64, F32, I32, P]),
+    "bkg_gemm_grouped_k_f32": (I32, [I64, I64, I64, P, I64, P, I64, P, I64, I64, P, I32, I32, P]),
     # kge.hip
     "bkg_kge_score_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, P]),
     "bkg_row_l1norm_f32": (I32, [P, I64, I64, I32, P, P]),

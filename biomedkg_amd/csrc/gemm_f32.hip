@@ -16,21 +16,12 @@
 // group_ptr; group g multiplies by its own B_g.  `grouped rows` (C_g = A_g B_g) and `grouped K`
 // (C_g += A_g^T B_g, split-K over row chunks, f32 atomics into a zeroed C) need no host sync.
 #include "common.h"
+#include "gemm_epilogue.h"
+#include "gemm_tile_bf16.h"
 
 namespace bkg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GemmEpilogue {
-  float alpha;
-  float beta;         // C = ... + beta * C_old (0 -> C_old never read)
-  const float* bias;  // [N] or null
-  int act;            // 0 none, 1 relu, 2 elu(alpha=1)
-  const float* gate;  // [M, ldg] or null: C *= (gate > 0 ? gate_scale : 0)   (ReLU+dropout backward)
-  int64_t ldg;
-  float gate_scale;
-  int atomic;         // 1: atomicAdd into C (split-K)
-};
 
 constexpr int BK = 16;
 constexpr int PAD = 4;
@@ -140,36 +131,25 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, int64_t l
     }
   }
 
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn0 + j * 32 + l31;
-      if (col >= N) continue;
-      const float bias = ep.bias ? ep.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= M) continue;
-        float v = ep.alpha * acc[i][j][r] + bias;
-        if (ep.act == 1) v = fmaxf(v, 0.f);
-        else if (ep.act == 2) v = v > 0.f ? v : expm1f(v);
-        if (ep.gate) v = ep.gate[(int64_t)row * ep.ldg + col] > 0.f ? v * ep.gate_scale : 0.f;
-        float* dst = C + (int64_t)row * ldc + col;
-        if (ep.atomic) atomicAdd(dst, v);
-        else {
-          if (ep.beta != 0.f) v = fmaf(ep.beta, *dst, v);
-          *dst = v;
-        }
-      }
-    }
+  __shared__ __attribute__((aligned(16))) float patch[4][16 * (WN + 4)];
+  store_acc_tile<TM, TN>(acc, C, ldc, M, N, m0 + wm0, n0 + wn0, ep, patch[wave]);
+}
+
+// PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32); PREC 1: bf16 operands, fp32 accumulate (gemm_tile_bf16.h)
+template <int PREC, int BM, int BN, bool TA, bool TB>
+__device__ __forceinline__ void gemm_tile_any(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                              int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                              int m0, int n0, int kbeg, int kend, const GemmEpilogue& ep, bool vecA,
+                                              bool vecB) {
+  if constexpr (PREC == 0) gemm_tile<BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, kbeg, kend, ep, vecA, vecB);
+  else gemm_tile_bf16<BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, m0, n0, kbeg, kend, ep, vecA, vecB);
 }
 
 __device__ __forceinline__ bool vec_ok(const float* p, int64_t ld) {
   return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0);
 }
 
-template <int BM, int BN, bool TA, bool TB>
+template <int PREC, int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ B, int64_t ldb,
                                                        float* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -177,12 +157,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   // blockIdx.x walks N tiles fastest so that blocks sharing an A row-panel are dispatched together.
   const int n_tiles = (N + BN - 1) / BN;
   const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
-  gemm_tile<BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, 0, K, ep, vec_ok(A, lda), vec_ok(B, ldb));
+  gemm_tile_any<PREC, BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, 0, K, ep, vec_ok(A, lda), vec_ok(B, ldb));
 }
 
 // Split-K: blockIdx.y owns K range [y*kchunk, (y+1)*kchunk) and adds its tile into a zeroed C with
 // f32 atomics.  For the weight-gradient products dW = dY^T X (K = number of nodes, M x N = a few tiles).
-template <int BM, int BN, bool TA, bool TB>
+template <int PREC, int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const float* __restrict__ A, int64_t lda,
                                                               const float* __restrict__ B, int64_t ldb,
                                                               float* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -191,11 +171,11 @@ __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const float* __res
   const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
   const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, K);
   if (kbeg >= kend) return;
-  gemm_tile<BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, kbeg, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
+  gemm_tile_any<PREC, BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, kbeg, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
 }
 
 // C_g[rows of group g, :] = A_g @ op(B_g);  B_g = B + g * strideB.  Tiles never straddle groups.
-template <int BM, int BN, bool TB>
+template <int PREC, int BM, int BN, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_rows_kernel(const float* __restrict__ A, int64_t lda,
                                                                     const float* __restrict__ B, int64_t ldb,
                                                                     int64_t strideB, float* __restrict__ C,
@@ -218,13 +198,13 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_rows_kernel(const float*
   if (g < 0) return;
   const int m0 = s_m0, mend = group_ptr[g + 1];
   const float* Bg = B + (int64_t)g * strideB;
-  gemm_tile<BM, BN, false, TB>(A, lda, Bg, ldb, C, ldc, mend, N, K, m0, (blockIdx.x % n_tiles) * BN, 0, K, ep,
-                               vec_ok(A, lda), vec_ok(Bg, ldb));
+  gemm_tile_any<PREC, BM, BN, false, TB>(A, lda, Bg, ldb, C, ldc, mend, N, K, m0, (blockIdx.x % n_tiles) * BN, 0, K, ep,
+                                         vec_ok(A, lda), vec_ok(Bg, ldb));
 }
 
 // C_g += A_g^T @ B_g over the rows of group g (K dimension = rows), split into chunks of KCHUNK
 // rows; C_g = C + g * strideC is [M = colsA, N = colsB] and must be zeroed by the caller.
-template <int BM, int BN>
+template <int PREC, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const float* __restrict__ A, int64_t lda,
                                                                  const float* __restrict__ B, int64_t ldb,
                                                                  float* __restrict__ C, int64_t ldc, int64_t strideC,
@@ -251,18 +231,18 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const float* __
   const int tile = blockIdx.x % tiles;
   float* Cg = C + (int64_t)g * strideC;
   // op(A) = A^T: stored [K(rows), M] ; op(B) = B stored [K(rows), N]
-  gemm_tile<BM, BN, true, false>(A, lda, B, ldb, Cg, ldc, M, N, kend, (tile / n_tiles) * BM, (tile % n_tiles) * BN, k0,
-                                 kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
+  gemm_tile_any<PREC, BM, BN, true, false>(A, lda, B, ldb, Cg, ldc, M, N, kend, (tile / n_tiles) * BM,
+                                           (tile % n_tiles) * BN, k0, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
 }
 
-template <int BM, int BN>
+template <int PREC, int BM, int BN>
 static void launch_gemm(bool ta, bool tb, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                         int64_t ldc, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
   dim3 grid(ceil_div(M, BM) * ceil_div(N, BN)), block(256);
-  if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
-  else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
-  else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<PREC, BM, BN, false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<PREC, BM, BN, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<PREC, BM, BN, true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
+  else hipLaunchKernelGGL((gemm_f32_kernel<PREC, BM, BN, true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
 }
 
 }  // namespace bkg
@@ -272,9 +252,10 @@ using namespace bkg;
 extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, float alpha,
                             const float* A, int64_t lda, const float* B, int64_t ldb, float beta, float* C,
                             int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg,
-                            float gate_scale, void* stream) {
+                            float gate_scale, int32_t precision, void* stream) {
   BKG_ARG(M >= 0 && N >= 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "bkg_gemm_f32: bad shape");
   BKG_ARG(act >= 0 && act <= 2, "bkg_gemm_f32: bad act");
+  BKG_ARG(precision == 0 || precision == 1, "bkg_gemm_f32: precision is 0 (fp32) or 1 (bf16 operands)");
   if (M == 0 || N == 0) return 0;
   GemmEpilogue ep{alpha, beta, bias, act, gate, ldg, gate_scale, 0};
   hipStream_t s = (hipStream_t)stream;
@@ -291,8 +272,9 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     if (e != hipSuccess) { set_error("bkg_gemm_f32: memset", e); return (int)e; }
     ep.atomic = 1;
     dim3 grid((unsigned)tiles, (unsigned)nsplit), block(256);
-#define BKG_SPLITK(BMN, TA_, TB_) \
-  hipLaunchKernelGGL((gemm_f32_splitk_kernel<BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep)
+#define BKG_SPLITK(BMN, TA_, TB_)                                                                                      \
+  if (precision) hipLaunchKernelGGL((gemm_f32_splitk_kernel<1, BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep); \
+  else hipLaunchKernelGGL((gemm_f32_splitk_kernel<0, BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep)
 #define BKG_SPLITK_T(BMN)                                 \
   if (!trans_a && !trans_b) { BKG_SPLITK(BMN, false, false); } \
   else if (!trans_a && trans_b) { BKG_SPLITK(BMN, false, true); } \
@@ -304,35 +286,46 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     return check_launch("bkg_gemm_f32(split-K)");
   }
   // big tiles once they fill the chip, small tiles otherwise
-  if ((M / 128) * ((N + 127) / 128) >= 256) launch_gemm<128, 128>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);
-  else launch_gemm<64, 64>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);
+  const bool big_tiles = (M / 128) * ((N + 127) / 128) >= 256;
+  if (precision) {
+    if (big_tiles) launch_gemm<1, 128, 128>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);
+    else launch_gemm<1, 64, 64>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);
+  } else {
+    if (big_tiles) launch_gemm<0, 128, 128>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);
+    else launch_gemm<0, 64, 64>(trans_a, trans_b, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, ep, s);
+  }
   return check_launch("bkg_gemm_f32");
 }
 
 extern "C" int bkg_gemm_grouped_rows_f32(int32_t trans_b, int64_t M_total, int64_t N, int64_t K, const float* A,
                                          int64_t lda, const float* B, int64_t ldb, int64_t strideB, float* C,
                                          int64_t ldc, const int32_t* group_ptr, int32_t G, const float* gate,
-                                         int64_t ldg, float gate_scale, void* stream) {
+                                         int64_t ldg, float gate_scale, int32_t precision, void* stream) {
   BKG_ARG(M_total >= 0 && N > 0 && K > 0 && G > 0, "bkg_gemm_grouped_rows_f32: bad shape");
+  BKG_ARG(precision == 0 || precision == 1, "bkg_gemm_grouped_rows_f32: precision is 0 or 1");
   if (M_total == 0) return 0;
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, gate, ldg, gate_scale, 0};
   hipStream_t s = (hipStream_t)stream;
   constexpr int BM = 128, BN = 128;
   dim3 grid((ceil_div(M_total, BM) + G) * ceil_div(N, BN)), block(256);
-  if (trans_b) hipLaunchKernelGGL((gemm_f32_grouped_rows_kernel<BM, BN, true>), grid, block, 0, s, A, lda, B, ldb, strideB, C, ldc, group_ptr, G, (int)N, (int)K, ep);
-  else hipLaunchKernelGGL((gemm_f32_grouped_rows_kernel<BM, BN, false>), grid, block, 0, s, A, lda, B, ldb, strideB, C, ldc, group_ptr, G, (int)N, (int)K, ep);
+#define BKG_GROWS(P, TB_) hipLaunchKernelGGL((gemm_f32_grouped_rows_kernel<P, BM, BN, TB_>), grid, block, 0, s, A, lda, B, ldb, strideB, C, ldc, group_ptr, G, (int)N, (int)K, ep)
+  if (precision) { if (trans_b) BKG_GROWS(1, true); else BKG_GROWS(1, false); }
+  else { if (trans_b) BKG_GROWS(0, true); else BKG_GROWS(0, false); }
+#undef BKG_GROWS
   return check_launch("bkg_gemm_grouped_rows_f32");
 }
 
 extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, const float* A, int64_t lda,
                                       const float* B, int64_t ldb, float* C, int64_t ldc, int64_t strideC,
-                                      const int32_t* group_ptr, int32_t G, void* stream) {
+                                      const int32_t* group_ptr, int32_t G, int32_t precision, void* stream) {
   BKG_ARG(rows_total >= 0 && M > 0 && N > 0 && G > 0, "bkg_gemm_grouped_k_f32: bad shape");
+  BKG_ARG(precision == 0 || precision == 1, "bkg_gemm_grouped_k_f32: precision is 0 or 1");
   if (rows_total == 0) return 0;
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   hipStream_t s = (hipStream_t)stream;
   constexpr int BM = 128, BN = 128, KCHUNK = 2048;
   dim3 grid((ceil_div(rows_total, KCHUNK) + G) * ceil_div(M, BM) * ceil_div(N, BN)), block(256);
-  hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
+  if (precision) hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
+  else hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<0, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
   return check_launch("bkg_gemm_grouped_k_f32");
 }

@@ -57,12 +57,32 @@ __global__ void gather_f32_kernel(const float* __restrict__ src, const int32_t* 
 // deg[i] = 1 (the one unit self loop) + #{in-edges k of i : src != i and kept}.
 // Edge-parallel with integer atomics (exact, order-independent): a row-parallel count would run as
 // long as the largest in-degree (10^4-10^5 on PrimeKG-like graphs).  `cnt` aliases the dis buffer.
-__global__ void gcn_degree_count_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
-                                        const uint8_t* __restrict__ keep, int64_t n, int32_t* __restrict__ cnt) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const int64_t s = src[e], d = dst[e];
-  if (s != d && (!keep || keep[e])) atomicAdd(&cnt[d], 1);
+// One thread per DST-SORTED entry: equal targets are adjacent, so each wave first adds up its runs with
+// a segmented shuffle scan and only the last lane of a run issues an atomic (a 4*10^4-in-edge hub costs
+// ~700 atomics instead of 4*10^4 serialised ones).
+__global__ void gcn_degree_count_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                        const int32_t* __restrict__ perm, const uint8_t* __restrict__ keep,
+                                        int n_nodes, int64_t nnz, int32_t* __restrict__ cnt) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool valid = k < nnz;
+  int row = -1, v = 0;
+  if (valid) {
+    int lo = 0, hi = n_nodes;  // largest row with rowptr[row] <= k
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rowptr[mid] <= k) lo = mid; else hi = mid;
+    }
+    row = lo;
+    v = (col[k] != row && (!keep || keep[perm[k]])) ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(v, off, 64), rr = __shfl_up(row, off, 64);
+    if (lane >= off && rr == row) v += t;
+  }
+  const int next = __shfl_down(row, 1, 64);
+  if (valid && v && (lane == 63 || next != row)) atomicAdd(&cnt[row], v);
 }
 
 __global__ void gcn_degree_finish_kernel(int n, float* __restrict__ dis, float* __restrict__ self_w) {
@@ -185,11 +205,10 @@ extern "C" int bkg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int
                             float* self_w, float* w_edge, void* stream) {
   BKG_ARG(n_nodes >= 0 && n_edges >= 0, "bkg_gcn_norm: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  (void)rowptr; (void)col; (void)perm;  // the CSR is not needed for the count any more (kept in the ABI)
   if (n_nodes) {
     hipError_t e = hipMemsetAsync(dis, 0, (size_t)n_nodes * sizeof(float), s);
     if (e != hipSuccess) { set_error("bkg_gcn_norm: memset", e); return (int)e; }
-    if (n_edges) hipLaunchKernelGGL(gcn_degree_count_kernel, grid1(n_edges), dim3(256), 0, s, src, dst, keep, n_edges, reinterpret_cast<int32_t*>(dis));
+    if (n_edges) hipLaunchKernelGGL(gcn_degree_count_kernel, grid1(n_edges), dim3(256), 0, s, rowptr, col, perm, keep, (int)n_nodes, n_edges, reinterpret_cast<int32_t*>(dis));
     hipLaunchKernelGGL(gcn_degree_finish_kernel, grid1(n_nodes), dim3(256), 0, s, (int)n_nodes, dis, self_w);
   }
   if (n_edges) hipLaunchKernelGGL(gcn_edge_weight_kernel, grid1(n_edges), dim3(256), 0, s, src, dst, keep, dis, n_edges, w_edge);

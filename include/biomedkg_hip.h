@@ -75,18 +75,20 @@ int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, 
  *      (* gate>0 ? gate_scale : 0) -> (+ beta C).  Replaces torch Linear inside GCNConv.lin, the GRACE/GGD/DGI heads
  *      (biomedkg/model/gcl.py:19-21,49-51,86-90), fusion projections (biomedkg/utils/fusion.py:17-20,70).
  *      Large-K plain products (weight gradients) run split-K with f32 atomics into a zeroed C. */
+/*      precision: 0 = exact fp32 (v_mfma_f32_32x32x2_f32, the parity default); 1 = operands rounded to bf16 while
+ *      staged into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate and fp32 C (BASELINE configs[2] "bf16" runs). */
 int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                  int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias,
-                 int32_t act, const float* gate, int64_t ldg, float gate_scale, void* stream);
+                 int32_t act, const float* gate, int64_t ldg, float gate_scale, int32_t precision, void* stream);
 /* RGCNConv per-relation products: rows grouped by device-side group_ptr[G+1]; group g uses B + g*strideB */
 int bkg_gemm_grouped_rows_f32(int32_t trans_b, int64_t M_total, int64_t N, int64_t K, const float* A, int64_t lda,
                               const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                               const int32_t* group_ptr, int32_t G, const float* gate, int64_t ldg, float gate_scale,
-                              void* stream);
+                              int32_t precision, void* stream);
 /* C[g] += A[rows g]^T B[rows g] (C zeroed by the caller; split over row chunks, f32 atomics) */
 int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, const float* A, int64_t lda, const float* B,
                            int64_t ldb, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int32_t G,
-                           void* stream);
+                           int32_t precision, void* stream);
 
 /* ---- KGE triplet scorer: kind 0 = DistMult (biomedkg/model/decoder.py:45-49), 1 = TransE (:31-38).
  *      head/tail/rel are int64 [T] (the rows of edge_index / edge_type as the reference hands them over). */

@@ -1,0 +1,75 @@
+"""bf16-operand matrix-core mode (BASELINE config 3): operands rounded to bf16 (8 significant bits) while
+staged, fp32 accumulate.  Tolerances follow from that rounding: products carry ~2^-9 relative error per
+operand, so GEMMs are checked to 1e-2 of the output scale and step losses to 5e-3.  Needs an MI355X."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def bf16_mode():
+    from biomedkg_amd import ops
+    ops.set_matmul_precision("bf16")
+    yield
+    ops.set_matmul_precision("fp32")
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(77, 45, 33), (300, 256, 768), (640, 256, 256), (256, 256, 20_000)])
+def test_gemm_bf16_operands(ta, tb, m, n, k):
+    from biomedkg_amd import ops
+    torch.manual_seed(0)
+    a = torch.randn((k, m) if ta else (m, k), device=DEV)
+    b = torch.randn((n, k) if tb else (k, n), device=DEV)
+    # exact reference of what the kernel computes: bf16-rounded operands, wide accumulate
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    ref = (ar.t() if ta else ar) @ (br.t() if tb else br)
+    out = ops.gemm(a, b, trans_a=ta, trans_b=tb)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-4, atol=1e-3 * k ** 0.5)
+    full = (a.t() if ta else a).double() @ (b.t() if tb else b).double()
+    assert (out.double() - full).abs().max() < 1e-2 * full.abs().max()
+
+
+def test_grouped_gemm_bf16_operands():
+    from biomedkg_amd import ops
+    torch.manual_seed(1)
+    sizes = [0, 130, 1, 257, 64]
+    gptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=DEV)
+    s, k, n, g = sum(sizes), 40, 24, len(sizes)
+    a, w, dy = torch.randn(s, k, device=DEV), torch.randn(g, k, n, device=DEV), torch.randn(s, n, device=DEV)
+    y, dh, dw = ops.gemm_grouped_rows(a, w, gptr), ops.gemm_grouped_rows(dy, w, gptr, trans_b=True), ops.gemm_grouped_k(a, dy, gptr, g)
+    ab, wb, dyb = a.bfloat16().double(), w.bfloat16().double(), dy.bfloat16().double()
+    o = 0
+    for i, sz in enumerate(sizes):
+        sl = slice(o, o + sz)
+        torch.testing.assert_close(y[sl].double(), ab[sl] @ wb[i], rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(dh[sl].double(), dyb[sl] @ wb[i].t(), rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(dw[i].double(), ab[sl].t() @ dyb[sl], rtol=1e-4, atol=2e-3)
+        o += sz
+
+
+@pytest.mark.parametrize("name", ["rgcn_dismult_random", "rgcn_transe_lm_attention"])
+def test_kge_step_bf16_mode_close_to_reference(golden, name):
+    from biomedkg_amd import rand as R
+    from biomedkg_amd.kge_module import KGEModule
+    g = golden("kge_steps")[name]
+    mod = KGEModule(**g["hparams"]).to(DEV)
+    mod.load_state_dict(g["state"], strict=True)
+    mod.train()
+
+    class B:
+        pass
+    b = B()
+    b.x, b.edge_index, b.edge_type = g["x"].to(DEV), g["edge_index"].to(DEV), g["edge_type"].to(DEV)
+    with R.use(R.ReplayRand(g["tape"], DEV)):
+        loss = mod.training_step(b)
+    loss.backward()
+    # four bf16-operand R-GCN layers feeding a cubic (DistMult) score: ~1e-2 relative on loss and gradients
+    rel = abs(loss.item() - g["loss"].item()) / max(1.0, abs(g["loss"].item()))
+    assert rel < 2e-2, (loss.item(), g["loss"].item())
+    params = dict(mod.model.named_parameters())
+    for k, v in g["grads"].items():
+        err = (params[k].grad.cpu() - v).norm() / v.norm().clamp_min(1e-6)
+        assert err < 1e-1, (k, float(err))

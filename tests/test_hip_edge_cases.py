@@ -1,0 +1,122 @@
+"""Edge cases of the hot path on the HIP side, each against the CPU oracle: empty and ragged inputs,
+isolated nodes, duplicate edges and duplicate self loops, sizes that are not multiples of any tile,
+embedding widths that take the generic kernels, an all-empty relation set, zero negatives.  Needs an MI355X."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = dict(rtol=1e-4, atol=1e-5)
+
+
+def _gcn_both(x, ei, w, b):
+    from biomedkg_amd import graph as G, ops
+    from oracle import pyg_ops as P
+    n = x.size(0)
+    xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = P.gcn_conv(xo, ei, wo, bo)
+    ref.sum().backward()
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    gr = G.Graph(ei.to(DEV), n)
+    out = ops.gcn_conv(xd, wd, bd, gr, gr.gcn_weights())
+    out.sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), **TOL)
+    for got, exp in ((xd, xo), (wd, wo), (bd, bo)):
+        torch.testing.assert_close(got.grad.cpu(), exp.grad, **TOL)
+
+
+def test_gcn_empty_edge_set_and_single_node():
+    torch.manual_seed(0)
+    _gcn_both(torch.randn(7, 12), torch.zeros(2, 0, dtype=torch.long), torch.randn(5, 12), torch.randn(5))
+    _gcn_both(torch.randn(1, 8), torch.zeros(2, 0, dtype=torch.long), torch.randn(4, 8), torch.randn(4))
+    _gcn_both(torch.randn(1, 8), torch.tensor([[0, 0], [0, 0]]), torch.randn(4, 8), torch.randn(4))   # only self loops
+
+
+def test_gcn_duplicates_isolated_and_odd_sizes():
+    torch.manual_seed(1)
+    n = 67                                   # not a multiple of 4 / 64
+    ei = torch.randint(0, 40, (2, 333))      # nodes 40..66 isolated
+    ei = torch.cat([ei, ei[:, :50], torch.tensor([[3, 3, 9], [3, 3, 9]])], dim=1)   # duplicate edges + duplicate loops
+    _gcn_both(torch.randn(n, 19), ei, torch.randn(13, 19), torch.randn(13))         # odd widths: generic spmm path
+
+
+@pytest.mark.parametrize("n,e,r,din,dout", [(50, 0, 3, 8, 8), (33, 200, 1, 20, 12), (40, 300, 6, 16, 24)])
+def test_rgcn_edge_cases(n, e, r, din, dout):
+    from biomedkg_amd import graph as G, ops
+    from oracle import pyg_ops as P
+    torch.manual_seed(2)
+    ei = torch.randint(0, max(n - 5, 1), (2, e))
+    et = torch.randint(0, r, (e,))
+    if r > 2:
+        et[et == 1] = 0                      # an empty relation in the middle
+    x, w = torch.randn(n, din), torch.randn(r, din, dout) * 0.3
+    root, b = torch.randn(din, dout) * 0.3, torch.randn(dout)
+    xo, wo, ro, bo = (t.clone().requires_grad_(True) for t in (x, w, root, b))
+    ref = P.rgcn_conv(xo, ei, et, wo, ro, bo)
+    ref.pow(2).sum().backward()
+    xd, wd, rd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, root, b))
+    rg = G.RelGraph(ei.to(DEV), et.to(DEV), n, r)
+    out = ops.rgcn_conv(xd, wd, rd, bd, rg)
+    out.pow(2).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), **TOL)
+    for got, exp in ((xd, xo), (wd, wo), (rd, ro), (bd, bo)):
+        torch.testing.assert_close(got.grad.cpu(), exp.grad, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["dismult", "transe"])
+def test_scorer_empty_and_repeated_triplets(kind):
+    from biomedkg_amd import ops
+    from oracle import ref_modules as R
+    torch.manual_seed(3)
+    z, rel = torch.randn(9, 16), torch.randn(2, 16)
+    k = ops.KGE_DISTMULT if kind == "dismult" else ops.KGE_TRANSE
+    s = ops.kge_score(z.to(DEV), rel.to(DEV), torch.zeros(2, 0, dtype=torch.long, device=DEV),
+                      torch.zeros(0, dtype=torch.long, device=DEV), k)
+    assert s.shape == (0,)
+    ei = torch.tensor([[0, 0, 0, 4, 4], [0, 0, 1, 4, 2]])     # h == t pairs and exact repeats
+    et = torch.tensor([0, 0, 1, 1, 0])
+    zo, ro = z.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    fn = R.distmult_score if kind == "dismult" else R.transe_score
+    so = fn(zo, ei, et, ro)
+    so.sum().backward()
+    zd, rd = z.to(DEV).requires_grad_(True), rel.to(DEV).requires_grad_(True)
+    sd = ops.kge_score(zd, rd, ei.to(DEV), et.to(DEV), k)
+    sd.sum().backward()
+    torch.testing.assert_close(sd.detach().cpu(), so.detach(), **TOL)
+    torch.testing.assert_close(zd.grad.cpu(), zo.grad, **TOL)
+    torch.testing.assert_close(rd.grad.cpu(), ro.grad, **TOL)
+
+
+def test_ntxent_ragged_sizes():
+    from biomedkg_amd import ops
+    from oracle import pygcl_ops as G
+    for n, h in ((1, 4), (3, 5), (65, 33), (130, 96)):
+        torch.manual_seed(n)
+        a, b = torch.randn(n, h), torch.randn(n, h)
+        ao, bo = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        if n == 1:
+            continue   # a single pair has no negatives: log(0) in the reference as well
+        ref = G.dual_branch_l2l_intraview(ao, bo, 0.2)
+        ref.backward()
+        ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        loss = ops.ntxent_loss(ad, bd, 0.2)
+        loss.backward()
+        torch.testing.assert_close(loss.detach().cpu(), ref.detach(), rtol=0, atol=1e-5)
+        torch.testing.assert_close(ad.grad.cpu(), ao.grad, rtol=1e-3, atol=1e-6)
+
+
+def test_kge_module_step_with_saturated_graph_returns_no_negatives():
+    """negative_sampling on a complete graph yields zero negatives; the step must still run."""
+    from biomedkg_amd.kge_module import KGEModule
+    n = 6
+    ei = torch.cartesian_prod(torch.arange(n), torch.arange(n)).t().contiguous()
+    mod = KGEModule("rgcn", "dismult", 8, 8, 8, 1, 2, 2, "cosine", 1e-3, 0.2, "none", 1, "random").to(DEV).train()
+
+    class B:
+        pass
+    b = B()
+    b.x, b.edge_index, b.edge_type = torch.randn(n, 8, device=DEV), ei.to(DEV), torch.randint(0, 2, (n * n,), device=DEV)
+    neg_ei, neg_et = mod.sample_neg_edges(b.edge_index, b.edge_type)
+    assert neg_ei.shape == (2, 0)
+    z = mod(b.x, b.edge_index, b.edge_type)
+    assert torch.isfinite(z).all()
