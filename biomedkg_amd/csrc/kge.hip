@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void row_l1_kernel(const float* __restrict__ z
 template <int KIND, int LPR, int VPL>
 __device__ __forceinline__ void kge_nodes_finish(float4 (&acc)[VPL], const float4 (&self)[VPL], float inv_self,
                                                  bool above_eps, int node, int lig, float* __restrict__ dz,
-                                                 int64_t lddz) {
+                                                 int64_t lddz, int accumulate = 0) {
   if (KIND == KGE_TRANSE) {
     float dot = 0.f;
 #pragma unroll
@@ -127,7 +127,14 @@ __device__ __forceinline__ void kge_nodes_finish(float4 (&acc)[VPL], const float
     }
   }
 #pragma unroll
-  for (int v = 0; v < VPL; ++v) *reinterpret_cast<float4*>(dz + (int64_t)node * lddz + 4 * (lig + v * LPR)) = acc[v];
+  for (int v = 0; v < VPL; ++v) {
+    float4* dst = reinterpret_cast<float4*>(dz + (int64_t)node * lddz + 4 * (lig + v * LPR));
+    if (accumulate) {
+      const float4 o = *dst;
+      acc[v].x += o.x; acc[v].y += o.y; acc[v].z += o.z; acc[v].w += o.w;
+    }
+    *dst = acc[v];
+  }
 }
 
 // long incidence lists: add the node's partial slots in chunk order, then the TransE epilogue
@@ -135,7 +142,8 @@ template <int KIND, int LPR, int VPL>
 __global__ __launch_bounds__(256) void kge_bwd_nodes_fixup_kernel(bkg_rowsplit rs, const float* __restrict__ z,
                                                                   int64_t ldz, const float* __restrict__ l1,
                                                                   const float* __restrict__ partials,
-                                                                  float* __restrict__ dz, int64_t lddz) {
+                                                                  float* __restrict__ dz, int64_t lddz,
+                                                                  int accumulate) {
   constexpr int G = 64 / LPR, d = 4 * LPR * VPL;
   const int lane = threadIdx.x & 63;
   const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR;
@@ -179,7 +187,14 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_fixup_kernel(bkg_rowsplit r
   }
   if (live) {
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) *reinterpret_cast<float4*>(dz + (int64_t)node * lddz + 4 * (lig + v * LPR)) = acc[v];
+    for (int v = 0; v < VPL; ++v) {
+      float4* dst = reinterpret_cast<float4*>(dz + (int64_t)node * lddz + 4 * (lig + v * LPR));
+      if (accumulate) {
+        const float4 o = *dst;
+        acc[v].x += o.x; acc[v].y += o.y; acc[v].z += o.z; acc[v].w += o.w;
+      }
+      *dst = acc[v];
+    }
   }
 }
 
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const float* __restr
                                                             const int32_t* __restrict__ inc_rowptr,
                                                             const int32_t* __restrict__ inc_perm,
                                                             float* __restrict__ dz, int64_t lddz, bkg_rowsplit rs,
-                                                            float* __restrict__ partials) {
+                                                            float* __restrict__ partials, int accumulate) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
   int node, start, end, slot = -1;
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const float* __restr
     return;
   }
   kge_nodes_finish<KIND, LPR, VPL>(acc, self, inv_self, KIND == KGE_TRANSE ? (l1[node] > L1_EPS) : true, node, lig, dz,
-                                   lddz);
+                                   lddz, accumulate);
 }
 
 // ------------------------------------------------------------------------------------ backward: drel
@@ -474,7 +489,7 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const float* z, int64_t ldz, 
                                      const int64_t* head, const int64_t* tail, const int64_t* rel, int64_t T,
                                      const float* rel_emb, int64_t ldr, const float* gscore, const float* l1,
                                      const int32_t* inc_rowptr, const int32_t* inc_perm, float* dz, int64_t lddz,
-                                     const bkg_rowsplit* split, float* partials, void* stream) {
+                                     const bkg_rowsplit* split, float* partials, int32_t accumulate, void* stream) {
   BKG_ARG(kind == KGE_DISTMULT || kind == KGE_TRANSE, "bkg_kge_bwd_nodes_f32: bad kind");
   BKG_ARG(kind == KGE_DISTMULT || l1 != nullptr, "bkg_kge_bwd_nodes_f32: TransE needs the row L1 norms");
   BKG_ARG(aligned16(z, ldz) && aligned16(rel_emb, ldr) && aligned16(dz, lddz), "bkg_kge_bwd_nodes_f32: alignment");
@@ -489,16 +504,16 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const float* z, int64_t ldz, 
       constexpr int G = 64 / LPR;
       dim3 grid(ceil_div(split->n_items_max, 4)), fgrid(ceil_div(split->n_long_max, 4 * G));
       if (kind == KGE_DISTMULT) {
-        hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_DISTMULT, LPR, VPL, true>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, *split, partials);
-        hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<KGE_DISTMULT, LPR, VPL>), fgrid, block, 0, s, *split, z, ldz, l1, partials, dz, lddz);
+        hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_DISTMULT, LPR, VPL, true>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, *split, partials, accumulate);
+        hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<KGE_DISTMULT, LPR, VPL>), fgrid, block, 0, s, *split, z, ldz, l1, partials, dz, lddz, accumulate);
       } else {
-        hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_TRANSE, LPR, VPL, true>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, *split, partials);
-        hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<KGE_TRANSE, LPR, VPL>), fgrid, block, 0, s, *split, z, ldz, l1, partials, dz, lddz);
+        hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_TRANSE, LPR, VPL, true>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, *split, partials, accumulate);
+        hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<KGE_TRANSE, LPR, VPL>), fgrid, block, 0, s, *split, z, ldz, l1, partials, dz, lddz, accumulate);
       }
     } else {
       dim3 grid(ceil_div(n_nodes, 4));
-      if (kind == KGE_DISTMULT) hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_DISTMULT, LPR, VPL, false>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, none, partials);
-      else hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_TRANSE, LPR, VPL, false>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, none, partials);
+      if (kind == KGE_DISTMULT) hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_DISTMULT, LPR, VPL, false>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, none, partials, accumulate);
+      else hipLaunchKernelGGL((kge_bwd_nodes_kernel<KGE_TRANSE, LPR, VPL, false>), grid, block, 0, s, z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz, none, partials, accumulate);
     }
   })
   return check_launch("bkg_kge_bwd_nodes_f32");

@@ -83,9 +83,28 @@ class KGEModule(LightningModule):
         reg_loss = z.pow(2).mean() + self.model.decoder.rel_emb.pow(2).mean()
         return cross_entropy_loss + 1e-2 * reg_loss
 
+    def _fused_training_loss(self, batch):
+        """training_step's arithmetic (reference kge_module.py:110-129) with decode(pos) + decode(neg) + BCE
+        fused into one op (``ops.kge_bce_loss``); same loss value and gradients as ``_score_step`` + ``_loss``."""
+        from . import ops
+        x = self.fusion_fn(x=batch.x)
+        if self._fix_edge_id is not None:
+            batch.edge_type = torch.full_like(batch.edge_type, self._fix_edge_id)
+        z = self.model.encode(x, batch.edge_index, batch.edge_type)
+        neg_edge_index, neg_edge_type = self.sample_neg_edges(batch.edge_index, batch.edge_type)
+        dec = self.model.decoder
+        ce, pos_pred, neg_pred = ops.kge_bce_loss(z, dec.rel_emb, batch.edge_index, batch.edge_type, neg_edge_index,
+                                                  neg_edge_type, dec.kind)
+        self._last_scores = (z, pos_pred, neg_pred)
+        reg_loss = z.pow(2).mean() + dec.rel_emb.pow(2).mean()
+        return ce + 1e-2 * reg_loss
+
     def training_step(self, batch, batch_idx=None):
-        z, _, _, pred, gt = self._score_step(batch)
-        loss = self._loss(z, pred, gt)
+        if getattr(self.model.decoder, "kind", None) is not None:
+            loss = self._fused_training_loss(batch)
+        else:
+            z, _, _, pred, gt = self._score_step(batch)
+            loss = self._loss(z, pred, gt)
         self.log("train_loss", loss, on_epoch=True, on_step=True, prog_bar=True)
         return loss
 

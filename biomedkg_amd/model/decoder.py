@@ -26,6 +26,8 @@ class Decoder(torch.nn.Module):
 
 
 class TransE(Decoder):
+    kind = ops.KGE_TRANSE
+
     def reset_parameters(self):
         """U(-6/sqrt(d), 6/sqrt(d)) then row L2-normalise (reference decoder.py:25-29)."""
         bound = 6.0 / math.sqrt(self.hidden_channels)
@@ -38,6 +40,8 @@ class TransE(Decoder):
 
 
 class DistMult(Decoder):
+    kind = ops.KGE_DISTMULT
+
     def forward(self, z, edge_index, edge_type):
         return ops.kge_score(z, self.rel_emb, edge_index, edge_type, ops.KGE_DISTMULT)
 

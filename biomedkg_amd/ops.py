@@ -312,7 +312,7 @@ class _KgeScore(torch.autograd.Function):
             partials = sp.partials(d, z.device) if sp is not None else None
             L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
                    L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), L.ptr(l1), L.ptr(inc.rowptr), L.ptr(inc.perm),
-                   L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None), L.ptr(partials), L.stream())
+                   L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None), L.ptr(partials), 0, L.stream())
         if ctx.needs_input_grad[1]:
             drel = torch.zeros_like(rel_emb)
             order, rel_ptr = relation_order_of(et, rel_emb.size(0)) if t >= (1 << 15) else (None, None)
@@ -328,6 +328,77 @@ def kge_score(z, rel_emb, edge_index, edge_type, kind):
     if edge_index.dtype != torch.int64 or edge_type.dtype != torch.int64:
         raise TypeError("edge_index / edge_type must be int64")
     return _KgeScore.apply(_f32c(z), _f32c(rel_emb), edge_index.contiguous(), edge_type.contiguous(), kind)
+
+
+class _KgeBceLoss(torch.autograd.Function):
+    """``binary_cross_entropy_with_logits(cat(decode(pos), decode(neg)), cat(1, 0))`` of the reference's
+    ``KGEModule.training_step`` (kge_module.py:121-127) as ONE op: the forward sweeps each triplet set once
+    (scores, loss terms, d loss / d score, d rel_emb -- csrc/kge_fused.hip), the backward is the per-node
+    segment reduce for dz.  Returns ``(loss, pos_pred, neg_pred)``; the preds are detached outputs."""
+
+    @staticmethod
+    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind):
+        n, d, r = z.size(0), z.size(1), rel_emb.size(0)
+        t_pos, t_neg = pos_ei.size(1), neg_ei.size(1)
+        total = t_pos + t_neg
+        dev = z.device
+        drel = torch.zeros_like(rel_emb)
+        scores, grads, loss = [], [], torch.zeros((), dtype=torch.float64, device=dev)
+        for ei, et, label in ((pos_ei, pos_et, 1.0), (neg_ei, neg_et, 0.0)):
+            t = ei.size(1)
+            s = torch.empty(t, dtype=torch.float32, device=dev)
+            g = torch.empty(t, dtype=torch.float32, device=dev)
+            if t:
+                order, rel_ptr = relation_order_of(et, r)
+                waves = L.lib().bkg_kge_fused_bce_waves(t, r)
+                part = torch.empty(waves, dtype=torch.float32, device=dev)
+                L.call("bkg_kge_fused_bce_f32", kind, L.ptr(z), z.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]), t, label,
+                       1.0 / total, L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order), L.ptr(rel_ptr), L.ptr(s), L.ptr(g),
+                       L.ptr(part), L.ptr(drel), drel.stride(0), L.stream())
+                loss = loss + part.double().sum()
+            scores.append(s)
+            grads.append(g)
+        ctx.kind = kind
+        ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
+        ctx.save_for_backward(z, rel_emb, grads[0], grads[1], drel)
+        ctx.mark_non_differentiable(scores[0], scores[1])
+        return (loss / total).float(), scores[0], scores[1]
+
+    @staticmethod
+    def backward(ctx, gloss, _gp, _gn):
+        z, rel_emb, g_pos, g_neg, drel = ctx.saved_tensors
+        pos_ei, pos_et, neg_ei, neg_et = ctx.graphs
+        kind = ctx.kind
+        n, d = z.size(0), z.size(1)
+        dz = None
+        if ctx.needs_input_grad[0]:
+            l1 = None
+            if kind == KGE_TRANSE:
+                l1 = torch.empty(n, dtype=torch.float32, device=z.device)
+                L.call("bkg_row_l1norm_f32", L.ptr(z), z.stride(0), n, d, L.ptr(l1), L.stream())
+            dz = torch.empty_like(z)
+            first = True
+            for ei, et, g in ((pos_ei, pos_et, g_pos), (neg_ei, neg_et, g_neg)):
+                if ei.size(1) == 0:
+                    continue
+                inc = incidence_of(ei, n)
+                sp = inc.split
+                partials = sp.partials(d, z.device) if sp is not None else None
+                L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et),
+                       ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), L.ptr(g), L.ptr(l1), L.ptr(inc.rowptr),
+                       L.ptr(inc.perm), L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None),
+                       L.ptr(partials), 0 if first else 1, L.stream())
+                first = False
+            if first:
+                dz.zero_()
+            dz = dz * gloss
+        return dz, (drel * gloss if ctx.needs_input_grad[1] else None), None, None, None, None, None
+
+
+def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind):
+    L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type)
+    return _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
+                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind)
 
 
 # ----------------------------------------------------------------------------- NT-Xent

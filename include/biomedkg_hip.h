@@ -100,7 +100,17 @@ int bkg_row_l1norm_f32(const float* z, int64_t ldz, int64_t n, int32_t d, float*
 int bkg_kge_bwd_nodes_f32(int32_t kind, const float* z, int64_t ldz, int64_t n_nodes, int32_t d, const int64_t* head,
                           const int64_t* tail, const int64_t* rel, int64_t T, const float* rel_emb, int64_t ldr,
                           const float* gscore, const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm,
-                          float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials, void* stream);
+                          float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
+                          void* stream);
+/* Fused training pass for one label (1 = positives, 0 = negatives): score[T], g[T] = (sigmoid(s) - label) *
+ * inv_total, per-wave BCE-with-logits partial sums loss_part[bkg_kge_fused_bce_waves(T, n_rel)] and drel += the
+ * relation-side gradient, in one sweep over the triplets' rows visited in relation-sorted order (order / rel_ptr).
+ * Replaces decode + cat + binary_cross_entropy_with_logits of biomedkg/kge_module.py:121-127 and their autograd. */
+int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel);
+int bkg_kge_fused_bce_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, const int64_t* head,
+                          const int64_t* tail, int64_t T, float label, float inv_total, const float* rel_emb,
+                          int64_t ldr, int32_t n_rel, const int32_t* order, const int32_t* rel_ptr, float* score,
+                          float* g, float* loss_part, float* drel, int64_t lddr, void* stream);
 /* drel[r] += sum_t ... (drel zeroed by the caller); order/rel_ptr (nullable together) = triplet ids sorted by
  * relation and the [n_rel+1] offsets of each relation in that order */
 int bkg_kge_bwd_rel_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, const int64_t* head, const int64_t* tail,

@@ -94,28 +94,31 @@ def test_kge_training_step_vs_reference(golden, name):
     b = Batch()
     b.x, b.edge_index, b.edge_type = _dev(g["x"]), _dev(g["edge_index"]), _dev(g["edge_type"])
     rec = {}
-    enc, dec = mod.model.encode, mod.model.decode
+    enc = mod.model.encode
 
     def encode(*a):
         rec["z"] = enc(*a)
         rec["z"].retain_grad()
         return rec["z"]
 
-    def decode(*a):
-        rec.setdefault("pred", []).append(dec(*a))
-        return rec["pred"][-1]
-
-    mod.model.encode, mod.model.decode = encode, decode
+    mod.model.encode = encode
     rp = R.ReplayRand(g["tape"], DEV)
     with R.use(rp):
-        loss = mod.training_step(b)
+        loss = mod.training_step(b)        # fused score + BCE path
     assert rp.exhausted()
+    _, pos_pred, neg_pred = mod._last_scores
     torch.testing.assert_close(loss.detach().cpu(), g["loss"], **LOSS_TOL)
     torch.testing.assert_close(rec["z"].detach().cpu(), g["z"], **VEC_TOL)
-    torch.testing.assert_close(rec["pred"][0].detach().cpu(), g["pos_pred"], **VEC_TOL)
-    torch.testing.assert_close(rec["pred"][1].detach().cpu(), g["neg_pred"], **VEC_TOL)
+    torch.testing.assert_close(pos_pred.cpu(), g["pos_pred"], **VEC_TOL)
+    torch.testing.assert_close(neg_pred.cpu(), g["neg_pred"], **VEC_TOL)
     loss.backward()
     torch.testing.assert_close(rec["z"].grad.cpu(), g["grad_z"], **VEC_TOL)
+    # the unfused route (decode + BCE, what validation_step uses) gives the same numbers
+    with R.use(R.ReplayRand(g["tape"], DEV)):
+        z2, p2, n2, pred, gt = mod._score_step(b)
+        loss2 = mod._loss(z2, pred, gt)
+    torch.testing.assert_close(loss2.detach().cpu(), g["loss"], **LOSS_TOL)
+    torch.testing.assert_close(p2.detach().cpu(), g["pos_pred"], **VEC_TOL)
     params = dict(mod.model.named_parameters())
     for k, v in g["grads"].items():
         torch.testing.assert_close(params[k].grad.cpu(), v, **VEC_TOL, msg=lambda m, k=k: f"{k}: {m}")
