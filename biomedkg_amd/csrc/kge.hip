@@ -239,34 +239,60 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const float* __restr
       self[v] = make_float4(a.x * inv_self, a.y * inv_self, a.z * inv_self, a.w * inv_self);  // z^_i
     }
   }
-  for (int k0 = start; k0 < end; k0 += G) {
-    const int k = k0 + grp;
-    if (k < end) {
-      const int64_t e = inc_perm[k];
-      const bool is_head = e < tr.T;
-      const int64_t t = is_head ? e : e - tr.T;
-      const int64_t other = is_head ? tr.tail[t] : tr.head[t];
-      const int64_t ri = tr.rel[t];
-      const float g = gscore[t];
-      const float inv_o = (KIND == KGE_TRANSE) ? 1.0f / fmaxf(l1[other], L1_EPS) : 0.f;
+  // Batches of U incidences per lane group with the three dependent load stages (entry id -> triplet fields
+  // -> rows) each issued for the whole batch, so a batch pays the latency chain once instead of per entry.
+  // Slots past the end are clamped to a valid entry and masked out of the accumulation.
+  constexpr int U = (VPL == 1) ? 4 : 2;
+  for (int k0 = start; k0 < end; k0 += U * G) {
+    int64_t e[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * G + grp;
+      ok[u] = k < end;
+      e[u] = inc_perm[min(k, end - 1)];
+    }
+    int64_t other[U], ri[U];
+    float g[U], inv_o[U];
+    bool is_head[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      is_head[u] = e[u] < tr.T;
+      const int64_t t = is_head[u] ? e[u] : e[u] - tr.T;
+      other[u] = is_head[u] ? tr.tail[t] : tr.head[t];
+      ri[u] = tr.rel[t];
+      g[u] = gscore[t];
+    }
+    float4 o[U][VPL], r[U][VPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      inv_o[u] = (KIND == KGE_TRANSE) ? 1.0f / fmaxf(l1[other[u]], L1_EPS) : 0.f;
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int c = 4 * (lig + v * LPR);
-        const float4 o = ld4(z + other * ldz + c);
-        const float4 r = ld4(rel_emb + ri * ldr + c);
+        o[u][v] = ld4(z + other[u] * ldz + c);
+        r[u][v] = ld4(rel_emb + ri[u] * ldr + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
         if (KIND == KGE_DISTMULT) {
-          acc[v].x = fmaf(g * r.x, o.x, acc[v].x); acc[v].y = fmaf(g * r.y, o.y, acc[v].y);
-          acc[v].z = fmaf(g * r.z, o.z, acc[v].z); acc[v].w = fmaf(g * r.w, o.w, acc[v].w);
+          acc[v].x = fmaf(g[u] * r[u][v].x, o[u][v].x, acc[v].x); acc[v].y = fmaf(g[u] * r[u][v].y, o[u][v].y, acc[v].y);
+          acc[v].z = fmaf(g[u] * r[u][v].z, o[u][v].z, acc[v].z); acc[v].w = fmaf(g[u] * r[u][v].w, o[u][v].w, acc[v].w);
         } else {
           // u = h^ + r - t^ ;  d score / d h^ = -sign(u), d score / d t^ = +sign(u)
-          const float sg = is_head ? -g : g;
-          float4 u;
-          if (is_head) u = make_float4(self[v].x + r.x - o.x * inv_o, self[v].y + r.y - o.y * inv_o,
-                                       self[v].z + r.z - o.z * inv_o, self[v].w + r.w - o.w * inv_o);
-          else u = make_float4(o.x * inv_o + r.x - self[v].x, o.y * inv_o + r.y - self[v].y,
-                               o.z * inv_o + r.z - self[v].z, o.w * inv_o + r.w - self[v].w);
-          acc[v].x = fmaf(sg, sgn(u.x), acc[v].x); acc[v].y = fmaf(sg, sgn(u.y), acc[v].y);
-          acc[v].z = fmaf(sg, sgn(u.z), acc[v].z); acc[v].w = fmaf(sg, sgn(u.w), acc[v].w);
+          const float sg = is_head[u] ? -g[u] : g[u];
+          const float io = inv_o[u];
+          float4 d4;
+          if (is_head[u]) d4 = make_float4(self[v].x + r[u][v].x - o[u][v].x * io, self[v].y + r[u][v].y - o[u][v].y * io,
+                                           self[v].z + r[u][v].z - o[u][v].z * io, self[v].w + r[u][v].w - o[u][v].w * io);
+          else d4 = make_float4(o[u][v].x * io + r[u][v].x - self[v].x, o[u][v].y * io + r[u][v].y - self[v].y,
+                                o[u][v].z * io + r[u][v].z - self[v].z, o[u][v].w * io + r[u][v].w - self[v].w);
+          acc[v].x = fmaf(sg, sgn(d4.x), acc[v].x); acc[v].y = fmaf(sg, sgn(d4.y), acc[v].y);
+          acc[v].z = fmaf(sg, sgn(d4.z), acc[v].z); acc[v].w = fmaf(sg, sgn(d4.w), acc[v].w);
         }
       }
     }

@@ -59,18 +59,35 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const float* __restr
       acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
       rr[v] = kf_ld4(rel_emb + (int64_t)r * ldr + 4 * (lig + v * LPR));
     }
-    for (int k0 = beg; k0 < end; k0 += G) {
-      const int k = k0 + grp;
-      const bool live = k < end;
-      const int64_t t = order[live ? k : beg];
-      const int64_t hi = head[t], ti = tail[t];
-      float4 h[VPL], tl[VPL];
+    // batches of U triplets per lane group: triplet ids, then endpoints, then rows are each loaded for the
+    // whole batch so the three-deep dependent-load chain is paid once per batch, not once per triplet
+    constexpr int U = (VPL == 1) ? 4 : 2;
+    for (int k0 = beg; k0 < end; k0 += U * G) {
+      int64_t tt[U], hh[U], ta[U];
+      bool lv[U];
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const int c = 4 * (lig + v * LPR);
-        h[v] = kf_ld4(z + hi * ldz + c);
-        tl[v] = kf_ld4(z + ti * ldz + c);
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * G + grp;
+        lv[u] = k < end;
+        tt[u] = order[min(k, end - 1)];
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { hh[u] = head[tt[u]]; ta[u] = tail[tt[u]]; }
+      float4 hb[U][VPL], tb[U][VPL];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int c = 4 * (lig + v * LPR);
+          hb[u][v] = kf_ld4(z + hh[u] * ldz + c);
+          tb[u][v] = kf_ld4(z + ta[u] * ldz + c);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+      const bool live = lv[u];
+      const int64_t t = tt[u];
+      const float4* h = hb[u];
+      const float4* tl = tb[u];
       float s = 0.f, ih = 0.f, it = 0.f;
       if (KIND == KF_DISTMULT) {
 #pragma unroll
@@ -115,6 +132,7 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const float* __restr
           acc[v].z -= g * kf_sgn(h[v].z * ih + rr[v].z - tl[v].z * it); acc[v].w -= g * kf_sgn(h[v].w * ih + rr[v].w - tl[v].w * it);
         }
       }
+      }  // u
     }
     if (G > 1) {
 #pragma unroll

@@ -7,11 +7,16 @@
 //
 // One wavefront (64 lanes) owns one work item = one destination row, or one <= chunk-entry slice of
 // a long row (rowsplit.hip; partials are added in chunk order by spmm_fixup_kernel).  A row of d
-// floats is covered by LPR lanes x VPL float4 each (d = 4*LPR*VPL); when LPR < 64 the 64/LPR lane
-// groups take alternating entries of the same item and are combined by shuffles, so the wave never
-// diverges on degree.  Item bookkeeping lives in SGPRs (readfirstlane) so the index/weight reads
-// are scalar loads and every gathered row is one coalesced 16 B/lane wave-instruction; U entries per
-// lane group are kept in flight.
+// values is covered by LPR lanes x VPL 16-byte loads each; when LPR < 64 the 64/LPR lane groups take
+// alternating entries of the same item and are combined by shuffles, so the wave never diverges on
+// degree.  Item bookkeeping lives in SGPRs (readfirstlane) so the index/weight reads are scalar loads
+// and every gathered row is one coalesced 16 B/lane wave-instruction; U entries per lane group are
+// kept in flight.
+//
+// The gathered table x is fp32 (exact mode) or bf16 (BASELINE config 3: "bf16 storage / fp32
+// accumulate"): a 16-byte load then carries 8 columns, the row is half the bytes and the launch -- which
+// is bound by the bytes leaving L2 (profiles/r01_pmc_traffic.json) -- moves half the traffic.
+// Accumulation, epilogue and the output are fp32 in both cases.
 //
 // Replaces (functionally) torch_geometric MessagePassing.propagate + scatter for the call sites
 // /root/reference/biomedkg/model/encoder.py:52,57,155,160.
@@ -35,12 +40,69 @@ __device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
   a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
 }
 
-// acc += sum over entries [beg, end) of this item (all lane groups, then combined across groups)
-template <int LPR, int VPL>
-__device__ __forceinline__ void spmm_accumulate(float4 (&acc)[VPL], int beg, int end, const int32_t* __restrict__ col,
-                                                const float* __restrict__ w, const float* __restrict__ x, int64_t ldx,
+// One 16-byte piece of a table row: Q float4 of accumulators (Q = 1 for fp32, 2 for bf16).
+template <typename T> struct Piece;
+template <> struct Piece<float> {
+  static constexpr int Q = 1, EPL = 4;
+  float4 v;
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void fma(float4* acc, float w) const { fma4(acc[0], w, v); }
+};
+template <> struct Piece<__bf16> {
+  static constexpr int Q = 2, EPL = 8;
+  uint4 v;
+  __device__ __forceinline__ void load(const __bf16* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void fma(float4* acc, float w) const {
+    // bf16 -> fp32 is a 16-bit shift: element 2i is the low half of word i
+    const float4 lo = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                  __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    const float4 hi = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
+                                  __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
+    fma4(acc[0], w, lo);
+    fma4(acc[1], w, hi);
+  }
+};
+
+// One predicated batch of UT entries per lane group starting at e (entries >= end get weight 0 and a clamped,
+// valid index so that the batch's loads are unconditional).
+template <typename T, int LPR, int VPL, int UT>
+__device__ __forceinline__ void spmm_tail(float4* acc, int e, int end, const int32_t* __restrict__ col,
+                                          const float* __restrict__ w, const T* __restrict__ x, int64_t ldx, int grp,
+                                          int lig) {
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL;
+  int idx[UT];
+  float wt[UT];
+  bool ok[UT];
+#pragma unroll
+  for (int u = 0; u < UT; ++u) {
+    const int k = e + u * G + grp;
+    const int kc = min(k, end - 1);
+    ok[u] = k < end;
+    idx[u] = col[kc];
+    wt[u] = w ? w[kc] : 1.0f;
+  }
+  Piece<T> val[UT][VPL];
+#pragma unroll
+  for (int u = 0; u < UT; ++u) {
+    const T* src = x + (int64_t)idx[u] * ldx + EPL * lig;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) val[u][v].load(src + EPL * v * LPR);
+  }
+#pragma unroll
+  for (int u = 0; u < UT; ++u)
+    if (ok[u]) {  // a padded slot contributes nothing, whatever the clamped row holds
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) val[u][v].fma(acc + v * Q, wt[u]);
+    }
+}
+
+// acc += sum over entries [beg, end) of this item (all lane groups, then combined across groups).
+// acc has VPL * Q float4: piece v of lane `lig` covers columns EPL * (lig + v * LPR) + [0, EPL).
+template <typename T, int LPR, int VPL>
+__device__ __forceinline__ void spmm_accumulate(float4* acc, int beg, int end, const int32_t* __restrict__ col,
+                                                const float* __restrict__ w, const T* __restrict__ x, int64_t ldx,
                                                 int grp, int lig) {
-  constexpr int G = 64 / LPR;
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL;
   constexpr int U = (VPL == 1) ? 8 : 4;  // entries in flight per lane group
   int e = beg;
   for (; e + U * G <= end; e += U * G) {
@@ -51,33 +113,33 @@ __device__ __forceinline__ void spmm_accumulate(float4 (&acc)[VPL], int beg, int
       idx[u] = col[e + u * G + grp];
       wt[u] = w ? w[e + u * G + grp] : 1.0f;
     }
-    float4 val[U][VPL];
+    Piece<T> val[U][VPL];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float4* src = reinterpret_cast<const float4*>(x + (int64_t)idx[u] * ldx) + lig;
+      const T* src = x + (int64_t)idx[u] * ldx + EPL * lig;
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) val[u][v] = src[v * LPR];
+      for (int v = 0; v < VPL; ++v) val[u][v].load(src + EPL * v * LPR);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) fma4(acc[v], wt[u], val[u][v]);
+      for (int v = 0; v < VPL; ++v) val[u][v].fma(acc + v * Q, wt[u]);
   }
-  for (; e < end; e += G) {
-    const int k = e + grp;
-    if (k < end) {
-      const int idx = col[k];
-      const float wt = w ? w[k] : 1.0f;
-      const float4* src = reinterpret_cast<const float4*>(x + (int64_t)idx * ldx) + lig;
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) fma4(acc[v], wt, src[v * LPR]);
-    }
+  // Remainder (the common case: most rows are shorter than one full batch).  One PREDICATED batch sized to
+  // the wave-uniform remainder keeps all its index loads, then all its row loads, in flight together; a
+  // one-entry-per-iteration tail would pay the index -> row latency chain once per entry.
+  const int rem = end - e;  // wave-uniform, < U * G
+  if (rem > 0) {
+    if (rem > 4 * G) spmm_tail<T, LPR, VPL, (U > 4 ? U : 4)>(acc, e, end, col, w, x, ldx, grp, lig);
+    else if (rem > 2 * G) spmm_tail<T, LPR, VPL, 4>(acc, e, end, col, w, x, ldx, grp, lig);
+    else if (rem > G) spmm_tail<T, LPR, VPL, 2>(acc, e, end, col, w, x, ldx, grp, lig);
+    else spmm_tail<T, LPR, VPL, 1>(acc, e, end, col, w, x, ldx, grp, lig);
   }
   if (G > 1) {
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
+      for (int v = 0; v < VPL * Q; ++v) {
         acc[v].x += __shfl_xor(acc[v].x, o, 64); acc[v].y += __shfl_xor(acc[v].y, o, 64);
         acc[v].z += __shfl_xor(acc[v].z, o, 64); acc[v].w += __shfl_xor(acc[v].w, o, 64);
       }
@@ -85,55 +147,64 @@ __device__ __forceinline__ void spmm_accumulate(float4 (&acc)[VPL], int beg, int
 }
 
 // self-loop term, addend, bias, ReLU, dropout, store (lane group 0 only)
-template <int LPR, int VPL>
-__device__ __forceinline__ void spmm_finish(float4 (&acc)[VPL], int row, int lig, const float* __restrict__ x,
-                                            int64_t ldx, float* __restrict__ out, int64_t ldo,
-                                            const SpmmEpilogue& ep) {
+template <typename T, int LPR, int VPL>
+__device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const T* __restrict__ x, int64_t ldx,
+                                            float* __restrict__ out, int64_t ldo, const SpmmEpilogue& ep) {
+  constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL, d = EPL * LPR * VPL;
   if (ep.self_w) {
     const float sw = ep.self_w[row];
-    const float4* src = reinterpret_cast<const float4*>(x + (int64_t)row * ldx) + lig;
+    const T* src = x + (int64_t)row * ldx + EPL * lig;
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) fma4(acc[v], sw, src[v * LPR]);
+    for (int v = 0; v < VPL; ++v) {
+      Piece<T> p;
+      p.load(src + EPL * v * LPR);
+      p.fma(acc + v * Q, sw);
+    }
   }
-  constexpr int d = 4 * LPR * VPL;
   const float scale = (ep.keep || ep.drop_p > 0.f) ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
   const uint32_t thresh = (uint32_t)fminf(ep.drop_p * 4294967296.0f, 4294967295.0f);
 #pragma unroll
-  for (int v = 0; v < VPL; ++v) {
-    const int c = 4 * (lig + v * LPR);
-    float4 a = acc[v];
-    if (ep.addend) {
-      const float4 t = *reinterpret_cast<const float4*>(ep.addend + (int64_t)row * ep.ld_add + c);
-      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+  for (int v = 0; v < VPL; ++v)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int c = EPL * (lig + v * LPR) + 4 * q;
+      float4 a = acc[v * Q + q];
+      if (ep.addend) {
+        const float4 t = *reinterpret_cast<const float4*>(ep.addend + (int64_t)row * ep.ld_add + c);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      if (ep.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(ep.bias + c);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      if (ep.relu) {
+        a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+      }
+      if (ep.keep) {
+        const uchar4 k = *reinterpret_cast<const uchar4*>(ep.keep + (int64_t)row * d + c);
+        a.x = k.x ? a.x * scale : 0.f; a.y = k.y ? a.y * scale : 0.f;
+        a.z = k.z ? a.z * scale : 0.f; a.w = k.w ? a.w * scale : 0.f;
+      } else if (ep.drop_p > 0.f) {
+        const uint4 r = philox_keep4(ep.seed, (uint64_t)row * d + c, ep.stream_id);
+        a.x = r.x >= thresh ? a.x * scale : 0.f; a.y = r.y >= thresh ? a.y * scale : 0.f;
+        a.z = r.z >= thresh ? a.z * scale : 0.f; a.w = r.w >= thresh ? a.w * scale : 0.f;
+      }
+      *reinterpret_cast<float4*>(out + (int64_t)row * ldo + c) = a;
     }
-    if (ep.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(ep.bias + c);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    if (ep.relu) {
-      a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-    }
-    if (ep.keep) {
-      const uchar4 k = *reinterpret_cast<const uchar4*>(ep.keep + (int64_t)row * d + c);
-      a.x = k.x ? a.x * scale : 0.f; a.y = k.y ? a.y * scale : 0.f;
-      a.z = k.z ? a.z * scale : 0.f; a.w = k.w ? a.w * scale : 0.f;
-    } else if (ep.drop_p > 0.f) {
-      const uint4 r = philox_keep4(ep.seed, (uint64_t)row * d + c, ep.stream_id);
-      a.x = r.x >= thresh ? a.x * scale : 0.f; a.y = r.y >= thresh ? a.y * scale : 0.f;
-      a.z = r.z >= thresh ? a.z * scale : 0.f; a.w = r.w >= thresh ? a.w * scale : 0.f;
-    }
-    *(reinterpret_cast<float4*>(out + (int64_t)row * ldo) + lig + v * LPR) = a;
-  }
+}
+
+template <int N>
+__device__ __forceinline__ void zero4(float4 (&acc)[N]) {
+#pragma unroll
+  for (int v = 0; v < N; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // one wave per row (no splitting): small or unskewed inputs
-template <int LPR, int VPL>
-__global__ __launch_bounds__(256) void spmm_csr_f32_kernel(const int32_t* __restrict__ rowptr,
-                                                           const int32_t* __restrict__ col,
-                                                           const float* __restrict__ w,
-                                                           const float* __restrict__ x, int64_t ldx,
-                                                           float* __restrict__ out, int64_t ldo, int n_rows,
-                                                           SpmmEpilogue ep) {
+template <typename T, int LPR, int VPL>
+__global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, const float* __restrict__ w,
+                                                       const T* __restrict__ x, int64_t ldx, float* __restrict__ out,
+                                                       int64_t ldo, int n_rows, SpmmEpilogue ep) {
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
@@ -141,20 +212,19 @@ __global__ __launch_bounds__(256) void spmm_csr_f32_kernel(const int32_t* __rest
   const int grp = lane / LPR, lig = lane % LPR;
   const int beg = __builtin_amdgcn_readfirstlane(rowptr[row]);
   const int end = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
-  float4 acc[VPL];
-#pragma unroll
-  for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  spmm_accumulate<LPR, VPL>(acc, beg, end, col, w, x, ldx, grp, lig);
-  if (grp == 0) spmm_finish<LPR, VPL>(acc, row, lig, x, ldx, out, ldo, ep);
+  float4 acc[VPL * Piece<T>::Q];
+  zero4(acc);
+  spmm_accumulate<T, LPR, VPL>(acc, beg, end, col, w, x, ldx, grp, lig);
+  if (grp == 0) spmm_finish<T, LPR, VPL>(acc, row, lig, x, ldx, out, ldo, ep);
 }
 
 // one wave per work item of the row-split table
-template <int LPR, int VPL>
-__global__ __launch_bounds__(256) void spmm_items_f32_kernel(bkg_rowsplit rs, const int32_t* __restrict__ col,
-                                                             const float* __restrict__ w,
-                                                             const float* __restrict__ x, int64_t ldx,
-                                                             float* __restrict__ out, int64_t ldo,
-                                                             float* __restrict__ partials, SpmmEpilogue ep) {
+template <typename T, int LPR, int VPL>
+__global__ __launch_bounds__(256) void spmm_items_kernel(bkg_rowsplit rs, const int32_t* __restrict__ col,
+                                                         const float* __restrict__ w, const T* __restrict__ x,
+                                                         int64_t ldx, float* __restrict__ out, int64_t ldo,
+                                                         float* __restrict__ partials, SpmmEpilogue ep) {
+  constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL;
   const int lane = threadIdx.x & 63;
   int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= rs.totals[0]) return;
@@ -164,46 +234,49 @@ __global__ __launch_bounds__(256) void spmm_items_f32_kernel(bkg_rowsplit rs, co
   const int beg = __builtin_amdgcn_readfirstlane(rs.item_beg[item]);
   const int end = __builtin_amdgcn_readfirstlane(rs.item_end[item]);
   const int slot = __builtin_amdgcn_readfirstlane(rs.item_slot[item]);
-  float4 acc[VPL];
-#pragma unroll
-  for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  spmm_accumulate<LPR, VPL>(acc, beg, end, col, w, x, ldx, grp, lig);
+  float4 acc[VPL * Q];
+  zero4(acc);
+  spmm_accumulate<T, LPR, VPL>(acc, beg, end, col, w, x, ldx, grp, lig);
   if (grp != 0) return;
   if (slot < 0) {
-    spmm_finish<LPR, VPL>(acc, row, lig, x, ldx, out, ldo, ep);
+    spmm_finish<T, LPR, VPL>(acc, row, lig, x, ldx, out, ldo, ep);
   } else {
-    constexpr int d = 4 * LPR * VPL;
+    constexpr int d = EPL * LPR * VPL;
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) *(reinterpret_cast<float4*>(partials + (int64_t)slot * d) + lig + v * LPR) = acc[v];
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        *reinterpret_cast<float4*>(partials + (int64_t)slot * d + EPL * (lig + v * LPR) + 4 * q) = acc[v * Q + q];
   }
 }
 
 // long rows: add the row's partial slots in chunk order, then the epilogue
-template <int LPR, int VPL>
-__global__ __launch_bounds__(256) void spmm_fixup_f32_kernel(bkg_rowsplit rs, const float* __restrict__ x, int64_t ldx,
-                                                             float* __restrict__ out, int64_t ldo,
-                                                             const float* __restrict__ partials, SpmmEpilogue ep) {
-  constexpr int G = 64 / LPR, d = 4 * LPR * VPL;
+template <typename T, int LPR, int VPL>
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(bkg_rowsplit rs, const T* __restrict__ x, int64_t ldx,
+                                                         float* __restrict__ out, int64_t ldo,
+                                                         const float* __restrict__ partials, SpmmEpilogue ep) {
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, d = EPL * LPR * VPL;
   const int lane = threadIdx.x & 63;
   const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR;  // one lane group per long row
   if (l >= rs.totals[2]) return;
   const int lig = lane % LPR;
   const int row = rs.long_row[l], s0 = rs.long_slot0[l], n = rs.long_cnt[l];
-  float4 acc[VPL];
-#pragma unroll
-  for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc[VPL * Q];
+  zero4(acc);
   for (int c = 0; c < n; ++c) {
-    const float4* src = reinterpret_cast<const float4*>(partials + (int64_t)(s0 + c) * d) + lig;
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      const float4 t = src[v * LPR];
-      acc[v].x += t.x; acc[v].y += t.y; acc[v].z += t.z; acc[v].w += t.w;
-    }
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(partials + (int64_t)(s0 + c) * d + EPL * (lig + v * LPR) + 4 * q);
+        float4& a = acc[v * Q + q];
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
   }
-  spmm_finish<LPR, VPL>(acc, row, lig, x, ldx, out, ldo, ep);
+  spmm_finish<T, LPR, VPL>(acc, row, lig, x, ldx, out, ldo, ep);
 }
 
-// Any d (not a multiple of 4 / not a supported width): lanes stride over the columns.
+// Any d (not a multiple of 4 / not a supported width), fp32 table only: lanes stride over the columns.
 __global__ __launch_bounds__(256) void spmm_csr_f32_generic_kernel(const int32_t* __restrict__ rowptr,
                                                                    const int32_t* __restrict__ col,
                                                                    const float* __restrict__ w,
@@ -235,29 +308,48 @@ __global__ __launch_bounds__(256) void spmm_csr_f32_generic_kernel(const int32_t
   }
 }
 
+template <typename T>
 struct SpmmArgs {
-  const int32_t* rowptr; const int32_t* col; const float* w; const float* x; int64_t ldx; float* out; int64_t ldo;
+  const int32_t* rowptr; const int32_t* col; const float* w; const T* x; int64_t ldx; float* out; int64_t ldo;
   int n_rows; const bkg_rowsplit* split; float* partials; SpmmEpilogue ep; hipStream_t s;
 };
 
-template <int LPR, int VPL>
-static void launch_spmm(const SpmmArgs& a) {
+template <typename T, int LPR, int VPL>
+static void launch_spmm(const SpmmArgs<T>& a) {
   if (a.split) {
     constexpr int G = 64 / LPR;
-    hipLaunchKernelGGL((spmm_items_f32_kernel<LPR, VPL>), dim3(ceil_div(a.split->n_items_max, 4)), dim3(256), 0, a.s,
+    hipLaunchKernelGGL((spmm_items_kernel<T, LPR, VPL>), dim3(ceil_div(a.split->n_items_max, 4)), dim3(256), 0, a.s,
                        *a.split, a.col, a.w, a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
-    hipLaunchKernelGGL((spmm_fixup_f32_kernel<LPR, VPL>), dim3(ceil_div(a.split->n_long_max, 4 * G)), dim3(256), 0,
-                       a.s, *a.split, a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
+    hipLaunchKernelGGL((spmm_fixup_kernel<T, LPR, VPL>), dim3(ceil_div(a.split->n_long_max, 4 * G)), dim3(256), 0, a.s,
+                       *a.split, a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
   } else {
-    hipLaunchKernelGGL((spmm_csr_f32_kernel<LPR, VPL>), dim3(ceil_div(a.n_rows, 4)), dim3(256), 0, a.s, a.rowptr,
-                       a.col, a.w, a.x, a.ldx, a.out, a.ldo, a.n_rows, a.ep);
+    hipLaunchKernelGGL((spmm_csr_kernel<T, LPR, VPL>), dim3(ceil_div(a.n_rows, 4)), dim3(256), 0, a.s, a.rowptr, a.col,
+                       a.w, a.x, a.ldx, a.out, a.ldo, a.n_rows, a.ep);
+  }
+}
+
+// d -> (LPR, VPL) for 16-byte pieces of EPL columns
+template <typename T>
+static bool dispatch_spmm(int d, const SpmmArgs<T>& a) {
+  constexpr int EPL = Piece<T>::EPL;
+  switch (d / EPL) {  // pieces per row
+    case 4: launch_spmm<T, 4, 1>(a); return true;
+    case 8: launch_spmm<T, 8, 1>(a); return true;
+    case 16: launch_spmm<T, 16, 1>(a); return true;
+    case 32: launch_spmm<T, 32, 1>(a); return true;
+    case 64: launch_spmm<T, 64, 1>(a); return true;
+    case 96: launch_spmm<T, 32, 3>(a); return true;
+    case 128: launch_spmm<T, 64, 2>(a); return true;
+    case 192: launch_spmm<T, 64, 3>(a); return true;
+    case 256: launch_spmm<T, 64, 4>(a); return true;
+    default: return false;
   }
 }
 
 }  // namespace bkg
 
-extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x,
-                                int64_t ldx, float* out, int64_t ldo, int64_t n_rows, int32_t d,
+extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const void* x,
+                                int32_t x_is_bf16, int64_t ldx, float* out, int64_t ldo, int64_t n_rows, int32_t d,
                                 const float* self_w, const float* addend, int64_t ld_add, const float* bias,
                                 int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
                                 uint32_t stream_id, const bkg_rowsplit* split, float* partials, void* stream) {
@@ -267,21 +359,59 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   BKG_ARG(!split || partials, "bkg_spmm_csr_f32: row splitting needs a partials buffer");
   if (n_rows == 0) return 0;
   SpmmEpilogue ep{self_w, bias, addend, ld_add, relu, keep, drop_p, seed, stream_id};
-  const bool vec_ok = (d % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % 16 == 0) &&
+  const int epl = x_is_bf16 ? 8 : 4;
+  const bool vec_ok = (d % epl == 0) && (ldx % epl == 0) && (ldo % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % 16 == 0) &&
                       (!bias || ((uintptr_t)bias % 16 == 0)) && (!keep || ((uintptr_t)keep % 4 == 0)) &&
                       (!addend || (((uintptr_t)addend % 16 == 0) && (ld_add % 4 == 0))) &&
                       (!partials || ((uintptr_t)partials % 16 == 0));
-  SpmmArgs a{rowptr, col, w, x, ldx, out, ldo, (int)n_rows, split, partials, ep, (hipStream_t)stream};
-  if (vec_ok && d == 16) launch_spmm<4, 1>(a);
-  else if (vec_ok && d == 32) launch_spmm<8, 1>(a);
-  else if (vec_ok && d == 64) launch_spmm<16, 1>(a);
-  else if (vec_ok && d == 128) launch_spmm<32, 1>(a);
-  else if (vec_ok && d == 256) launch_spmm<64, 1>(a);
-  else if (vec_ok && d == 512) launch_spmm<64, 2>(a);
-  else if (vec_ok && d == 768) launch_spmm<64, 3>(a);
-  else if (vec_ok && d == 1024) launch_spmm<64, 4>(a);
-  else
-    hipLaunchKernelGGL(spmm_csr_f32_generic_kernel, dim3(ceil_div(n_rows, 4)), dim3(256), 0, a.s, rowptr, col, w, x, ldx,
-                       out, ldo, (int)n_rows, d, ep);
+  hipStream_t s = (hipStream_t)stream;
+  bool done = false;
+  if (x_is_bf16) {
+    BKG_ARG(vec_ok, "bkg_spmm_csr_f32: a bf16 table needs d % 8 == 0 and 16-byte aligned rows");
+    SpmmArgs<__bf16> a{rowptr, col, w, (const __bf16*)x, ldx, out, ldo, (int)n_rows, split, partials, ep, s};
+    done = dispatch_spmm<__bf16>(d, a);
+    BKG_ARG(done, "bkg_spmm_csr_f32: unsupported width for a bf16 table (d/8 in {4,8,16,32,64,96,128,192,256})");
+  } else {
+    SpmmArgs<float> a{rowptr, col, w, (const float*)x, ldx, out, ldo, (int)n_rows, split, partials, ep, s};
+    if (vec_ok) done = dispatch_spmm<float>(d, a);
+    if (!done)
+      hipLaunchKernelGGL(spmm_csr_f32_generic_kernel, dim3(ceil_div(n_rows, 4)), dim3(256), 0, s, rowptr, col, w,
+                         (const float*)x, ldx, out, ldo, (int)n_rows, d, ep);
+  }
   return check_launch("bkg_spmm_csr_f32");
+}
+
+// ---- fp32 -> bf16 (RNE) copy of a gather table, optionally through the ReLU/dropout backward gate:
+//      dst = bf16( gate ? (gate > 0 ? src * scale : 0) : src )
+namespace bkg {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, const float* __restrict__ gate,
+                                                        float scale, __bf16* __restrict__ dst, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+  if (gate) {
+    const float4 ga = reinterpret_cast<const float4*>(gate)[2 * i], gb = reinterpret_cast<const float4*>(gate)[2 * i + 1];
+    a.x = ga.x > 0.f ? a.x * scale : 0.f; a.y = ga.y > 0.f ? a.y * scale : 0.f;
+    a.z = ga.z > 0.f ? a.z * scale : 0.f; a.w = ga.w > 0.f ? a.w * scale : 0.f;
+    b.x = gb.x > 0.f ? b.x * scale : 0.f; b.y = gb.y > 0.f ? b.y * scale : 0.f;
+    b.z = gb.z > 0.f ? b.z * scale : 0.f; b.w = gb.w > 0.f ? b.w * scale : 0.f;
+  }
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  bf16x8 o;
+  o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+  o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+  reinterpret_cast<bf16x8*>(dst)[i] = o;
+}
+}  // namespace bkg
+
+extern "C" int bkg_cast_f32_bf16(const float* src, const float* gate, float gate_scale, void* dst, int64_t n,
+                                 void* stream) {
+  using namespace bkg;
+  BKG_ARG(n >= 0 && n % 8 == 0, "bkg_cast_f32_bf16: element count must be a multiple of 8");
+  BKG_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && (!gate || (uintptr_t)gate % 16 == 0),
+          "bkg_cast_f32_bf16: 16-byte alignment");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(ceil_div(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, gate,
+                     gate_scale, (__bf16*)dst, n / 8);
+  return check_launch("bkg_cast_f32_bf16");
 }

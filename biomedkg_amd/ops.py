@@ -89,17 +89,40 @@ class Dropout:
 KERNEL_TIMERS = None
 
 
-def _spmm_bytes(nnz, n_rows, d, has_w):
-    """Algorithmic bytes of one launch: gathered row + int32 index (+ fp32 weight) per
-    entry, stored row + int32 rowptr per output row."""
-    return nnz * (d * 4 + 4 + (4 if has_w else 0)) + n_rows * (d * 4 + 4)
+def _spmm_bytes(nnz, n_rows, d, has_w, elem=4):
+    """Algorithmic bytes of one launch: gathered row (fp32 or bf16 table) + int32 index
+    (+ fp32 weight) per entry, stored fp32 row + int32 rowptr per output row."""
+    return nnz * (d * elem + 4 + (4 if has_w else 0)) + n_rows * (d * 4 + 4)
+
+
+def to_bf16(x, gate=None, gate_scale=1.0):
+    """bf16 gather table of ``x`` (csrc/spmm.hip ``bkg_cast_f32_bf16``), optionally through the
+    ReLU/dropout backward gate ``gate > 0 ? x * gate_scale : 0``."""
+    L.require_cuda(x, gate)
+    x = _f32c(x)
+    if x.numel() % 8:
+        raise ValueError("to_bf16 needs a multiple of 8 elements")
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.call("bkg_cast_f32_bf16", L.ptr(x), L.ptr(_f32c(gate) if gate is not None else None), gate_scale, L.ptr(out),
+           x.numel(), L.stream())
+    return out
+
+
+def bf16_storage() -> bool:
+    """bf16 mode also keeps the tables the gather kernels read in bf16 (fp32 accumulate)."""
+    return _PRECISION == 1
 
 
 def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=False, drop: Dropout = None, tag=None,
          split=None):
-    """``out[i] = epi(sum_k w[k] x[col[k]] (+ self_w[i] x[i]) (+ addend[i]))`` (csrc/spmm.hip)."""
+    """``out[i] = epi(sum_k w[k] x[col[k]] (+ self_w[i] x[i]) (+ addend[i]))`` (csrc/spmm.hip).
+    ``x`` is an fp32 or a bf16 table; the result is fp32."""
     L.require_cuda(rowptr, col, w, x, self_w, addend, bias)
-    x = _f32c(x)
+    if x.dtype == torch.bfloat16:
+        x = x if x.is_contiguous() else x.contiguous()
+    else:
+        x = _f32c(x)
+    is_bf16 = int(x.dtype == torch.bfloat16)
     d = x.size(1)
     out = torch.empty(n_rows, d, dtype=torch.float32, device=x.device)
     keep, p, seed, sid = None, 0.0, 0, 0
@@ -116,15 +139,28 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     partials = split.partials(d, x.device) if split is not None else None
-    L.call("bkg_spmm_csr_f32", L.ptr(rowptr), L.ptr(col), L.ptr(w), L.ptr(x), x.stride(0), L.ptr(out), out.stride(0),
-           n_rows, d, L.ptr(self_w), L.ptr(addend), addend.stride(0) if addend is not None else 0, L.ptr(bias),
-           int(relu), L.ptr(keep), p, seed, sid, L.sref(split.c if split is not None else None), L.ptr(partials),
-           L.stream())
+    L.call("bkg_spmm_csr_f32", L.ptr(rowptr), L.ptr(col), L.ptr(w), L.ptr(x), is_bf16, x.stride(0), L.ptr(out),
+           out.stride(0), n_rows, d, L.ptr(self_w), L.ptr(addend), addend.stride(0) if addend is not None else 0,
+           L.ptr(bias), int(relu), L.ptr(keep), p, seed, sid, L.sref(split.c if split is not None else None),
+           L.ptr(partials), L.stream())
     if timing:
         ev1.record()
-        rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None)})
+        rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None,
+                                                                             2 if is_bf16 else 4)})
         rec["events"].append((ev0, ev1))
     return out
+
+
+def _table(x):
+    """The table a gather kernel reads: a bf16 copy in bf16 mode (when the shape allows 16-byte pieces)."""
+    if bf16_storage() and x.dtype == torch.float32 and x.dim() == 2 and _bf16_ok(x.size(1)):
+        return to_bf16(x)
+    return x
+
+
+def _bf16_ok(d):
+    """Row widths the bf16-table SpMM kernels are instantiated for (d / 8 sixteen-byte pieces per row)."""
+    return d % 8 == 0 and (d // 8) in (4, 8, 16, 32, 64, 96, 128, 192, 256)
 
 
 def _gate(dout, out, scale):
@@ -170,7 +206,7 @@ class _GcnConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, graph: Graph, gw: GcnWeights, relu, drop):
-        xw = gemm(x, weight, trans_b=True)
+        xw = _table(gemm(x, weight, trans_b=True))
         c = graph.by_dst
         out = spmm(c.rowptr, c.col, gw.w_dst, xw, graph.num_nodes, self_w=gw.self_w, bias=bias, relu=relu, drop=drop,
                    tag="gcn_propagate", split=c.split)
@@ -185,13 +221,16 @@ class _GcnConv(torch.autograd.Function):
         x, weight, out = ctx.saved_tensors
         g, gw = ctx.graph, ctx.gw
         dout = _f32c(dout)
-        if ctx.gated:
+        if bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(dout.size(1)):
+            # gate + bf16 gather table in one pass over dOut (no fp32 gated copy is ever written)
+            dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
+        elif ctx.gated:
             dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
         c = g.by_src
         dxw = spmm(c.rowptr, c.col, gw.w_src, dout, g.num_nodes, self_w=gw.self_w, split=c.split)
         dx = gemm(dxw, weight) if ctx.needs_input_grad[0] else None
         dw = gemm(dxw, x, trans_a=True) if ctx.needs_input_grad[1] else None
-        db = dout.sum(0) if ctx.needs_input_grad[2] else None
+        db = dout.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None, None, None
 
 
@@ -208,7 +247,7 @@ class _RgcnConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop):
         n = rg.num_nodes
-        h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, x, rg.num_segments, tag="rgcn_segment_mean",
+        h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, _table(x), rg.num_segments, tag="rgcn_segment_mean",
                  split=rg.seg_split)                                                  # [S, in]  segment means
         y = gemm_grouped_rows(h, weight, rg.rel_ptr)                                  # [S, out] per-relation W_r
         xr = gemm(x, root)                                                            # [N, out] root term
@@ -236,7 +275,7 @@ class _RgcnConv(torch.autograd.Function):
             dh = gemm_grouped_rows(dy, weight, rg.rel_ptr, trans_b=True)              # [S, in]
             dx_root = gemm(dout, root, trans_b=True)                                  # [N, in]
             c = rg.src_csr
-            dx = spmm(c.rowptr, c.col, rg.src_w, dh, rg.num_nodes, addend=dx_root, split=c.split)
+            dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), rg.num_nodes, addend=dx_root, split=c.split)
         return dx, dweight, droot, db, None, None, None
 
 

@@ -65,9 +65,13 @@ int bkg_rowsplit_build(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int32
  *      epi = dropout(relu(. + bias)).  Replaces MessagePassing.propagate + scatter of GCNConv / RGCNConv and
  *      the ReLU + F.dropout(0.2) that follow (biomedkg/model/encoder.py:50-59,153-162).  Dropout keep decisions:
  *      explicit uint8 mask `keep` [n_rows,d], or in-kernel Philox(seed, stream_id) when keep == NULL and drop_p > 0.
- *      split (host, nullable) + partials [n_slots_max, d] enable long-row splitting. */
-int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const float* x, int64_t ldx,
-                     float* out, int64_t ldo, int64_t n_rows, int32_t d, const float* self_w, const float* addend,
+ *      split (host, nullable) + partials [n_slots_max, d] enable long-row splitting.
+ *      x is the gathered table: fp32 [*, ldx] (x_is_bf16 = 0) or bf16 [*, ldx] (x_is_bf16 = 1, "bf16 storage / fp32
+ *      accumulate" of BASELINE configs[2]); out, the partial sums and every epilogue operand are fp32.
+ *      bkg_cast_f32_bf16 makes such a table: dst = bf16(gate ? (gate > 0 ? src * gate_scale : 0) : src), n % 8 == 0. */
+int bkg_cast_f32_bf16(const float* src, const float* gate, float gate_scale, void* dst, int64_t n, void* stream);
+int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const void* x, int32_t x_is_bf16,
+                     int64_t ldx, float* out, int64_t ldo, int64_t n_rows, int32_t d, const float* self_w, const float* addend,
                      int64_t ld_add, const float* bias, int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
                      uint32_t stream_id, const bkg_rowsplit* split, float* partials, void* stream);
 

@@ -32,6 +32,31 @@ def test_gemm_bf16_operands(ta, tb, m, n, k):
     assert (out.double() - full).abs().max() < 1e-2 * full.abs().max()
 
 
+@pytest.mark.parametrize("d", [32, 128, 256, 768])
+def test_spmm_bf16_table_matches_rounded_reference(d):
+    """SpMM over a bf16 gather table == fp64 algebra on the bf16-rounded table (fp32 accumulate)."""
+    from biomedkg_amd import graph as G, ops
+    n, e = 2500, 120_000
+    g = torch.Generator().manual_seed(9)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[1, : e // 4] = 5                                # one long row -> the split path
+    x = torch.randn(n, d, generator=g)
+    gr = G.Graph(ei.to(DEV), n)
+    gw = gr.gcn_weights()
+    xb = ops.to_bf16(x.to(DEV))
+    assert xb.dtype == torch.bfloat16 and torch.equal(xb.cpu(), x.bfloat16())          # RNE, same as torch
+    c = gr.by_dst
+    out = ops.spmm(c.rowptr, c.col, gw.w_dst, xb, n, self_w=gw.self_w, relu=True, split=c.split)
+    from oracle import pyg_ops as P
+    e2, w = P.gcn_norm(ei, n)
+    xr = x.bfloat16().double()
+    ref = torch.zeros(n, d, dtype=torch.float64).index_add_(0, e2[1], xr[e2[0]] * w.double()[:, None]).relu()
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-4, atol=1e-4)
+    gate = torch.randn(n, d, device=DEV)
+    gb = ops.to_bf16(x.to(DEV), gate=gate, gate_scale=1.25)
+    torch.testing.assert_close(gb.float().cpu(), torch.where(gate.cpu() > 0, x * 1.25, 0.0).bfloat16().float())
+
+
 def test_grouped_gemm_bf16_operands():
     from biomedkg_amd import ops
     torch.manual_seed(1)
