@@ -49,30 +49,61 @@ struct StagerH {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = threadIdx.x + i * 256;
-      if (CONTIG_IS_K) {
-        const int r = f / (BKH / 4), kc = f % (BKH / 4);
-        reg[i] = load4h(base, ld, t0 + r, k0 + kc * 4, T, K, vec);
-      } else {
-        const int kr = f / (BT / 4), tc = f % (BT / 4);
-        reg[i] = load4h(base, ld, k0 + kr, t0 + tc * 4, K, T, vec);
-      }
+      const int r = f / (BKH / 4), kc = f % (BKH / 4);
+      reg[i] = load4h(base, ld, t0 + r, k0 + kc * 4, T, K, vec);
     }
   }
   __device__ __forceinline__ void store(__bf16 (*lds)[LDH]) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = threadIdx.x + i * 256;
-      if (CONTIG_IS_K) {
-        const int r = f / (BKH / 4), kc = f % (BKH / 4);
-        bf16x4_t h;
-        h[0] = (__bf16)reg[i].x; h[1] = (__bf16)reg[i].y; h[2] = (__bf16)reg[i].z; h[3] = (__bf16)reg[i].w;
-        *reinterpret_cast<bf16x4_t*>(&lds[r][kc * 4]) = h;
-      } else {
-        const int kr = f / (BT / 4), tc = f % (BT / 4);
-        lds[tc * 4 + 0][kr] = (__bf16)reg[i].x;
-        lds[tc * 4 + 1][kr] = (__bf16)reg[i].y;
-        lds[tc * 4 + 2][kr] = (__bf16)reg[i].z;
-        lds[tc * 4 + 3][kr] = (__bf16)reg[i].w;
+      const int r = f / (BKH / 4), kc = f % (BKH / 4);
+      bf16x4_t h;
+      h[0] = (__bf16)reg[i].x; h[1] = (__bf16)reg[i].y; h[2] = (__bf16)reg[i].z; h[3] = (__bf16)reg[i].w;
+      *reinterpret_cast<bf16x4_t*>(&lds[r][kc * 4]) = h;
+    }
+  }
+};
+
+// Transposing form: the operand is stored [K, tile rows] (tile dim contiguous).  A task = a 4(k) x 4(rows)
+// patch: four 16-byte loads along the rows (one per k), transposed in registers into four 8-byte LDS stores
+// {k..k+3} (one per row) -- 4x fewer LDS store instructions than element stores.  Lanes run over the 8 k-quads
+// fastest: a wave's ds_write_b64 then covers 16 banks x 2 half-rows at the 80-byte row stride, i.e. the
+// 4-cycle minimum of a 512-byte store, with no extra conflict.
+template <int BT>
+struct StagerH<BT, false> {
+  static constexpr int TASKS = (BT / 4) * (BKH / 4);         // 256 for BT = 128, 128 for BT = 64
+  static constexpr int NT = (TASKS + 255) / 256;
+  float4 reg[NT][4];
+
+  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int t0, int k0, int T, int K,
+                                       bool vec) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int f = threadIdx.x + i * 256;
+      const int kq = f % (BKH / 4), tc = f / (BKH / 4);
+      if (TASKS % 256 == 0 || f < TASKS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) reg[i][j] = load4h(base, ld, k0 + kq * 4 + j, t0 + tc * 4, K, T, vec);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(__bf16 (*lds)[LDH]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int f = threadIdx.x + i * 256;
+      const int kq = f % (BKH / 4), tc = f / (BKH / 4);
+      if (TASKS % 256 == 0 || f < TASKS) {
+        const float* r0 = reinterpret_cast<const float*>(&reg[i][0]);
+        const float* r1 = reinterpret_cast<const float*>(&reg[i][1]);
+        const float* r2 = reinterpret_cast<const float*>(&reg[i][2]);
+        const float* r3 = reinterpret_cast<const float*>(&reg[i][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bf16x4_t h;
+          h[0] = (__bf16)r0[e]; h[1] = (__bf16)r1[e]; h[2] = (__bf16)r2[e]; h[3] = (__bf16)r3[e];
+          *reinterpret_cast<bf16x4_t*>(&lds[tc * 4 + e][kq * 4]) = h;
+        }
       }
     }
   }

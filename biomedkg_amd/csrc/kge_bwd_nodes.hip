@@ -1,0 +1,279 @@
+// KGE scorer backward, node side: dz[i] = sum over the triplets incident to node i of the contribution of
+// the OTHER endpoint.  NOT a scatter-add: the caller sorts the 2T (node, role) incidences by node once
+// (graph.hip radix sort; entry e < T: i is the head of triplet e, else the tail of e - T) and this kernel
+// does a per-node segment reduce with plain stores -- bitwise reproducible, and several times the
+// float-atomic rate on gfx950.  Long incidence lists are split into <= 256-entry work items (rowsplit.hip).
+//
+//   DistMult (reference decoder.py:45-49):  dz_i += g_t * rel[r_t] (*) z[other]
+//   TransE   (reference decoder.py:31-38):  with z^ = z / max(||z||_1, eps), u = h^ + r - t^,
+//            Q_i = sum_t (-/+) g_t sign(u_t)  (head / tail role), then through the L1 normalisation ONCE per
+//            node:  dz_i = (Q_i - sign(z_i) (z^_i . Q_i)) / ||z_i||_1   (Q_i / eps when ||z_i||_1 <= eps).
+//
+// The gathered node table z is fp32 or bf16 (rowpiece.h); g, rel_emb, l1 and dz are fp32.
+#include "common.h"
+#include "rowpiece.h"
+
+namespace bkg {
+
+enum { KN_DISTMULT = 0, KN_TRANSE = 1 };
+constexpr float KN_EPS = 1e-12f;
+
+__device__ __forceinline__ float kn_sgn(float v) { return (v > 0.f) - (v < 0.f); }
+__device__ __forceinline__ float4 kn_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int LPR>
+__device__ __forceinline__ float kn_group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct KnTriplets {
+  const int64_t* head;
+  const int64_t* tail;
+  const int64_t* rel;
+  int64_t T;
+};
+
+// z^_i (TransE) of lane `lig`'s columns
+template <typename T, int LPR, int VPL>
+__device__ __forceinline__ void kn_load_self(const T* __restrict__ z, int64_t ldz, int node, int lig, float inv_self,
+                                             float4* self) {
+  constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    Piece<T> p;
+    p.load(z + (int64_t)node * ldz + EPL * (lig + v * LPR));
+    p.expand(self + v * Q);
+  }
+#pragma unroll
+  for (int q = 0; q < VPL * Q; ++q) {
+    self[q].x *= inv_self; self[q].y *= inv_self; self[q].z *= inv_self; self[q].w *= inv_self;
+  }
+}
+
+// TransE normalisation backward (needs every lane of the group), then store / accumulate
+template <typename T, int KIND, int LPR, int VPL>
+__device__ __forceinline__ void kn_finish(float4* acc, const float4* self, float inv_self, bool above_eps, int node,
+                                          int lig, float* __restrict__ dz, int64_t lddz, int accumulate, bool store) {
+  constexpr int VQ = VPL * Piece<T>::Q;
+  if (KIND == KN_TRANSE) {
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < VQ; ++q)
+      dot += self[q].x * acc[q].x + self[q].y * acc[q].y + self[q].z * acc[q].z + self[q].w * acc[q].w;
+    dot = kn_group_sum<LPR>(dot);
+    if (!above_eps) dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < VQ; ++q) {
+      acc[q].x = (acc[q].x - kn_sgn(self[q].x) * dot) * inv_self; acc[q].y = (acc[q].y - kn_sgn(self[q].y) * dot) * inv_self;
+      acc[q].z = (acc[q].z - kn_sgn(self[q].z) * dot) * inv_self; acc[q].w = (acc[q].w - kn_sgn(self[q].w) * dot) * inv_self;
+    }
+  }
+  if (!store) return;
+#pragma unroll
+  for (int q = 0; q < VQ; ++q) {
+    float4* dst = reinterpret_cast<float4*>(dz + (int64_t)node * lddz + piece_col<T, LPR>(lig, q));
+    if (accumulate) {
+      const float4 o = *dst;
+      acc[q].x += o.x; acc[q].y += o.y; acc[q].z += o.z; acc[q].w += o.w;
+    }
+    *dst = acc[q];
+  }
+}
+
+// SPLIT: one wave per row-split item instead of one wave per node
+template <typename T, int KIND, int LPR, int VPL, bool SPLIT>
+__global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict__ z, int64_t ldz, int n_nodes,
+                                                            KnTriplets tr, const float* __restrict__ rel_emb,
+                                                            int64_t ldr, const float* __restrict__ gscore,
+                                                            const float* __restrict__ l1,
+                                                            const int32_t* __restrict__ inc_rowptr,
+                                                            const int32_t* __restrict__ inc_perm,
+                                                            float* __restrict__ dz, int64_t lddz, bkg_rowsplit rs,
+                                                            float* __restrict__ partials, int accumulate) {
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q;
+  const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
+  int node, start, end, slot = -1;
+  if (SPLIT) {
+    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= rs.totals[0]) return;
+    item = __builtin_amdgcn_readfirstlane(item);
+    node = __builtin_amdgcn_readfirstlane(rs.item_row[item]);
+    start = __builtin_amdgcn_readfirstlane(rs.item_beg[item]);
+    end = __builtin_amdgcn_readfirstlane(rs.item_end[item]);
+    slot = __builtin_amdgcn_readfirstlane(rs.item_slot[item]);
+  } else {
+    node = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= n_nodes) return;
+    node = __builtin_amdgcn_readfirstlane(node);
+    start = __builtin_amdgcn_readfirstlane(inc_rowptr[node]);
+    end = __builtin_amdgcn_readfirstlane(inc_rowptr[node + 1]);
+  }
+  float4 self[VQ], acc[VQ];
+  float inv_self = 0.f;
+  zero4(acc);
+  if (KIND == KN_TRANSE) {
+    inv_self = 1.0f / fmaxf(l1[node], KN_EPS);
+    kn_load_self<T, LPR, VPL>(z, ldz, node, lig, inv_self, self);
+  }
+  // Batches of U incidences per lane group with the three dependent load stages (entry id -> triplet fields
+  // -> rows) each issued for the whole batch.  Slots past the end are clamped and masked out.
+  constexpr int U = (VQ == 1) ? 4 : 2;
+  for (int k0 = start; k0 < end; k0 += U * G) {
+    int64_t e[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * G + grp;
+      ok[u] = k < end;
+      e[u] = inc_perm[min(k, end - 1)];
+    }
+    int64_t other[U], ri[U];
+    float g[U], inv_o[U];
+    bool is_head[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      is_head[u] = e[u] < tr.T;
+      const int64_t t = is_head[u] ? e[u] : e[u] - tr.T;
+      other[u] = is_head[u] ? tr.tail[t] : tr.head[t];
+      ri[u] = tr.rel[t];
+      g[u] = gscore[t];
+    }
+    Piece<T> ob[U][VPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      inv_o[u] = (KIND == KN_TRANSE) ? 1.0f / fmaxf(l1[other[u]], KN_EPS) : 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) ob[u][v].load(z + other[u] * ldz + EPL * (lig + v * LPR));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      float4 o[VQ];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) ob[u][v].expand(o + v * Q);
+      const float sg = is_head[u] ? -g[u] : g[u], io = inv_o[u];
+#pragma unroll
+      for (int q = 0; q < VQ; ++q) {
+        const float4 r = kn_ld4(rel_emb + ri[u] * ldr + piece_col<T, LPR>(lig, q));  // <= R rows: cache resident
+        if (KIND == KN_DISTMULT) {
+          acc[q].x = fmaf(g[u] * r.x, o[q].x, acc[q].x); acc[q].y = fmaf(g[u] * r.y, o[q].y, acc[q].y);
+          acc[q].z = fmaf(g[u] * r.z, o[q].z, acc[q].z); acc[q].w = fmaf(g[u] * r.w, o[q].w, acc[q].w);
+        } else {
+          float4 d4;  // u = h^ + r - t^ ;  d score / d h^ = -sign(u), d score / d t^ = +sign(u)
+          if (is_head[u]) d4 = make_float4(self[q].x + r.x - o[q].x * io, self[q].y + r.y - o[q].y * io,
+                                           self[q].z + r.z - o[q].z * io, self[q].w + r.w - o[q].w * io);
+          else d4 = make_float4(o[q].x * io + r.x - self[q].x, o[q].y * io + r.y - self[q].y,
+                                o[q].z * io + r.z - self[q].z, o[q].w * io + r.w - self[q].w);
+          acc[q].x = fmaf(sg, kn_sgn(d4.x), acc[q].x); acc[q].y = fmaf(sg, kn_sgn(d4.y), acc[q].y);
+          acc[q].z = fmaf(sg, kn_sgn(d4.z), acc[q].z); acc[q].w = fmaf(sg, kn_sgn(d4.w), acc[q].w);
+        }
+      }
+    }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int q = 0; q < VQ; ++q) {
+        acc[q].x += __shfl_xor(acc[q].x, o, 64); acc[q].y += __shfl_xor(acc[q].y, o, 64);
+        acc[q].z += __shfl_xor(acc[q].z, o, 64); acc[q].w += __shfl_xor(acc[q].w, o, 64);
+      }
+  }
+  if (grp != 0) return;  // after the cross-group combine every group holds the full sum
+  if (SPLIT && slot >= 0) {
+    constexpr int d = EPL * LPR * VPL;
+#pragma unroll
+    for (int q = 0; q < VQ; ++q)
+      *reinterpret_cast<float4*>(partials + (int64_t)slot * d + piece_col<T, LPR>(lig, q)) = acc[q];
+    return;
+  }
+  kn_finish<T, KIND, LPR, VPL>(acc, self, inv_self, KIND == KN_TRANSE ? (l1[node] > KN_EPS) : true, node, lig, dz, lddz,
+                               accumulate, true);
+}
+
+// long incidence lists: add the node's partial slots in chunk order, then the TransE epilogue
+template <typename T, int KIND, int LPR, int VPL>
+__global__ __launch_bounds__(256) void kge_bwd_nodes_fixup_kernel(bkg_rowsplit rs, const T* __restrict__ z, int64_t ldz,
+                                                                  const float* __restrict__ l1,
+                                                                  const float* __restrict__ partials,
+                                                                  float* __restrict__ dz, int64_t lddz,
+                                                                  int accumulate) {
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, d = EPL * LPR * VPL;
+  const int lane = threadIdx.x & 63;
+  const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR;
+  const bool live = l < rs.totals[2];
+  const int lig = lane % LPR;
+  const int node = live ? rs.long_row[l] : 0, s0 = live ? rs.long_slot0[l] : 0, n = live ? rs.long_cnt[l] : 0;
+  float4 acc[VQ], self[VQ];
+  float inv_self = 0.f;
+  bool above = false;
+  zero4(acc);
+  if (KIND == KN_TRANSE) {
+    const float nrm = l1[node];
+    inv_self = 1.0f / fmaxf(nrm, KN_EPS);
+    above = nrm > KN_EPS;
+    kn_load_self<T, LPR, VPL>(z, ldz, node, lig, inv_self, self);
+  }
+  constexpr int UF = 8;  // partial slots in flight (a hub node has hundreds); still added in chunk order
+  for (int c0 = 0; c0 < n; c0 += UF) {
+    float4 t[UF][VQ];
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      const int c = min(c0 + u, n - 1);
+#pragma unroll
+      for (int q = 0; q < VQ; ++q) t[u][q] = kn_ld4(partials + (int64_t)(s0 + c) * d + piece_col<T, LPR>(lig, q));
+    }
+#pragma unroll
+    for (int u = 0; u < UF; ++u)
+      if (c0 + u < n) {
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) {
+          acc[q].x += t[u][q].x; acc[q].y += t[u][q].y; acc[q].z += t[u][q].z; acc[q].w += t[u][q].w;
+        }
+      }
+  }
+  kn_finish<T, KIND, LPR, VPL>(acc, self, inv_self, above, node, lig, dz, lddz, accumulate, live);
+}
+
+}  // namespace bkg
+
+using namespace bkg;
+
+extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes,
+                                     int32_t d, const int64_t* head, const int64_t* tail, const int64_t* rel,
+                                     int64_t T, const float* rel_emb, int64_t ldr, const float* gscore,
+                                     const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm, float* dz,
+                                     int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
+                                     void* stream) {
+  BKG_ARG(kind == KN_DISTMULT || kind == KN_TRANSE, "bkg_kge_bwd_nodes_f32: bad kind");
+  BKG_ARG(kind == KN_DISTMULT || l1 != nullptr, "bkg_kge_bwd_nodes_f32: TransE needs the row L1 norms");
+  const int epl = z_is_bf16 ? 8 : 4;
+  BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) &&
+              (ldr % 4 == 0) && ((uintptr_t)dz % 16 == 0) && (lddz % 4 == 0), "bkg_kge_bwd_nodes_f32: alignment");
+  BKG_ARG(!split || (partials && ((uintptr_t)partials % 16 == 0)), "bkg_kge_bwd_nodes_f32: splitting needs partials");
+  if (n_nodes == 0) return 0;
+  KnTriplets tr{head, tail, rel, T};
+  hipStream_t s = (hipStream_t)stream;
+  dim3 block(256);
+  bkg_rowsplit none{};
+#define KN_LAUNCH(TT, K)                                                                                               \
+  if (split) {                                                                                                         \
+    hipLaunchKernelGGL((kge_bwd_nodes_kernel<TT, K, LPR, VPL, true>), dim3(ceil_div(split->n_items_max, 4)), block, 0, \
+                       s, (const TT*)z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz,    \
+                       lddz, *split, partials, accumulate);                                                            \
+    hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, K, LPR, VPL>), dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), \
+                       block, 0, s, *split, (const TT*)z, ldz, l1, partials, dz, lddz, accumulate);                    \
+  } else {                                                                                                             \
+    hipLaunchKernelGGL((kge_bwd_nodes_kernel<TT, K, LPR, VPL, false>), dim3(ceil_div(n_nodes, 4)), block, 0, s,        \
+                       (const TT*)z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz,  \
+                       none, partials, accumulate);                                                                    \
+  }
+  BKG_PIECE_DISPATCH(d / epl, {
+    if (z_is_bf16) { if (kind == KN_DISTMULT) { KN_LAUNCH(__bf16, KN_DISTMULT) } else { KN_LAUNCH(__bf16, KN_TRANSE) } }
+    else { if (kind == KN_DISTMULT) { KN_LAUNCH(float, KN_DISTMULT) } else { KN_LAUNCH(float, KN_TRANSE) } }
+  })
+#undef KN_LAUNCH
+  return check_launch("bkg_kge_bwd_nodes_f32");
+}

@@ -5,15 +5,19 @@
 // decode(pos), decode(neg), cat, ones/zeros, binary_cross_entropy_with_logits -- and autograd then walks
 // the [T,d] gathers again.  Unfused, this build needs three passes over the 2T rows (score, node-side
 // gradient, relation-side gradient); because BCE's gradient g = sigmoid(s) - y only needs the score and
-// the label (triplet id < n_pos), the relation-side gradient can be accumulated in the scoring pass
-// itself, leaving one more pass for the node side (kge.hip kge_bwd_nodes_kernel, fed with the g written
-// here).  Triplets are visited in relation-sorted order so that a wave owns a slice of ONE relation and
-// keeps its d rel_emb partial in registers (one 1-KiB atomic flush per <= 256 triplets).
+// the label, the relation-side gradient can be accumulated in the scoring pass itself, leaving one more
+// pass for the node side (kge_bwd_nodes.hip, fed with the g written here).  Triplets are visited in
+// relation-sorted order so that a wave owns a slice of ONE relation and keeps its d rel_emb partial in
+// registers (one 1-KiB atomic flush per <= 256 triplets).
 //
+// The node table z is fp32 or bf16 (rowpiece.h); rel_emb, scores and all gradients are fp32.
 // One launch per label (positives y = 1, negatives y = 0).  Outputs: score[T] (original triplet order),
-// g[T] = (sigmoid(s) - y) * inv_total, loss_part[n_waves] (sum it, multiply by inv_total),
-// drel[R,d] (zeroed by the caller).  The caller multiplies by the upstream gradient of the loss.
+// g[T] = (sigmoid(s) - y) * inv_total, loss_part[n_waves] (sum it, multiply by inv_total) and
+// drel_part[n_waves, d]: wave w's partial of d rel_emb[r(w)], where relation r owns the consecutive waves
+// [sum_{q<r} ceil(cnt_q / 64), ...) -- rows of waves without work are left unwritten and are never read.
+// The caller reduces drel_part per relation and multiplies by the upstream gradient of the loss.
 #include "common.h"
+#include "rowpiece.h"
 
 namespace bkg {
 
@@ -22,6 +26,7 @@ constexpr float KF_EPS = 1e-12f;
 
 __device__ __forceinline__ float kf_sgn(float v) { return (v > 0.f) - (v < 0.f); }
 __device__ __forceinline__ float4 kf_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float kf_abs4(const float4& a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w); }
 
 template <int LPR>
 __device__ __forceinline__ float kf_group_sum(float v) {
@@ -30,22 +35,22 @@ __device__ __forceinline__ float kf_group_sum(float v) {
   return v;
 }
 
-template <int KIND, int LPR, int VPL>
-__global__ __launch_bounds__(256) void kge_fused_bce_kernel(const float* __restrict__ z, int64_t ldz,
+template <typename T, int KIND, int LPR, int VPL>
+__global__ __launch_bounds__(256) void kge_fused_bce_kernel(const T* __restrict__ z, int64_t ldz,
                                                             const int64_t* __restrict__ head,
-                                                            const int64_t* __restrict__ tail, int64_t T, float label, float inv_t,
-                                                            const float* __restrict__ rel_emb, int64_t ldr, int n_rel,
-                                                            const int32_t* __restrict__ order,
+                                                            const int64_t* __restrict__ tail, int64_t T_, float label,
+                                                            float inv_t, const float* __restrict__ rel_emb,
+                                                            int64_t ldr, int n_rel, const int32_t* __restrict__ order,
                                                             const int32_t* __restrict__ rel_ptr, int chunk,
                                                             float* __restrict__ score, float* __restrict__ g_out,
                                                             float* __restrict__ loss_part, float* __restrict__ drel,
                                                             int64_t lddr) {
-  constexpr int G = 64 / LPR;
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q;
   const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
   int w = __builtin_amdgcn_readfirstlane(wave_id);
   int r = 0, beg = 0, end = 0;
-  for (; r < n_rel; ++r) {
+  for (; r < n_rel; ++r) {  // wave-uniform scan of <= n_rel scalars
     const int a = rel_ptr[r], b = rel_ptr[r + 1];
     const int nc = (b - a + chunk - 1) / chunk;
     if (w < nc) { beg = a + w * chunk; end = min(beg + chunk, b); break; }
@@ -53,15 +58,13 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const float* __restr
   }
   float loss_acc = 0.f;
   if (r < n_rel) {
-    float4 acc[VPL], rr[VPL];
+    float4 acc[VQ], rr[VQ];
+    zero4(acc);
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      rr[v] = kf_ld4(rel_emb + (int64_t)r * ldr + 4 * (lig + v * LPR));
-    }
+    for (int q = 0; q < VQ; ++q) rr[q] = kf_ld4(rel_emb + (int64_t)r * ldr + piece_col<T, LPR>(lig, q));
     // batches of U triplets per lane group: triplet ids, then endpoints, then rows are each loaded for the
     // whole batch so the three-deep dependent-load chain is paid once per batch, not once per triplet
-    constexpr int U = (VPL == 1) ? 4 : 2;
+    constexpr int U = (VQ == 1) ? 4 : 2;  // keeps the batch at <= 8 float4 per operand (VGPRs -> occupancy)
     for (int k0 = beg; k0 < end; k0 += U * G) {
       int64_t tt[U], hh[U], ta[U];
       bool lv[U];
@@ -73,82 +76,78 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const float* __restr
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) { hh[u] = head[tt[u]]; ta[u] = tail[tt[u]]; }
-      float4 hb[U][VPL], tb[U][VPL];
+      Piece<T> hb[U][VPL], tb[U][VPL];
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
-          const int c = 4 * (lig + v * LPR);
-          hb[u][v] = kf_ld4(z + hh[u] * ldz + c);
-          tb[u][v] = kf_ld4(z + ta[u] * ldz + c);
+          hb[u][v].load(z + hh[u] * ldz + EPL * (lig + v * LPR));
+          tb[u][v].load(z + ta[u] * ldz + EPL * (lig + v * LPR));
         }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-      const bool live = lv[u];
-      const int64_t t = tt[u];
-      const float4* h = hb[u];
-      const float4* tl = tb[u];
-      float s = 0.f, ih = 0.f, it = 0.f;
-      if (KIND == KF_DISTMULT) {
+        float4 h[VQ], tl[VQ];
 #pragma unroll
-        for (int v = 0; v < VPL; ++v)
-          s += h[v].x * rr[v].x * tl[v].x + h[v].y * rr[v].y * tl[v].y + h[v].z * rr[v].z * tl[v].z + h[v].w * rr[v].w * tl[v].w;
-        s = kf_group_sum<LPR>(s);
-      } else {
-        float nh = 0.f, nt = 0.f;
+        for (int v = 0; v < VPL; ++v) { hb[u][v].expand(h + v * Q); tb[u][v].expand(tl + v * Q); }
+        float s = 0.f, ih = 0.f, it = 0.f;
+        if (KIND == KF_DISTMULT) {
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          nh += fabsf(h[v].x) + fabsf(h[v].y) + fabsf(h[v].z) + fabsf(h[v].w);
-          nt += fabsf(tl[v].x) + fabsf(tl[v].y) + fabsf(tl[v].z) + fabsf(tl[v].w);
+          for (int q = 0; q < VQ; ++q)
+            s += h[q].x * rr[q].x * tl[q].x + h[q].y * rr[q].y * tl[q].y + h[q].z * rr[q].z * tl[q].z + h[q].w * rr[q].w * tl[q].w;
+          s = kf_group_sum<LPR>(s);
+        } else {
+          float nh = 0.f, nt = 0.f;
+#pragma unroll
+          for (int q = 0; q < VQ; ++q) { nh += kf_abs4(h[q]); nt += kf_abs4(tl[q]); }
+          ih = 1.0f / fmaxf(kf_group_sum<LPR>(nh), KF_EPS);
+          it = 1.0f / fmaxf(kf_group_sum<LPR>(nt), KF_EPS);
+#pragma unroll
+          for (int q = 0; q < VQ; ++q)
+            s += fabsf(h[q].x * ih + rr[q].x - tl[q].x * it) + fabsf(h[q].y * ih + rr[q].y - tl[q].y * it) +
+                 fabsf(h[q].z * ih + rr[q].z - tl[q].z * it) + fabsf(h[q].w * ih + rr[q].w - tl[q].w * it);
+          s = -kf_group_sum<LPR>(s);
         }
-        ih = 1.0f / fmaxf(kf_group_sum<LPR>(nh), KF_EPS);
-        it = 1.0f / fmaxf(kf_group_sum<LPR>(nt), KF_EPS);
-#pragma unroll
-        for (int v = 0; v < VPL; ++v)
-          s += fabsf(h[v].x * ih + rr[v].x - tl[v].x * it) + fabsf(h[v].y * ih + rr[v].y - tl[v].y * it) +
-               fabsf(h[v].z * ih + rr[v].z - tl[v].z * it) + fabsf(h[v].w * ih + rr[v].w - tl[v].w * it);
-        s = -kf_group_sum<LPR>(s);
-      }
-      // BCE with logits (torch formula): max(s,0) - s*y + log1p(exp(-|s|));  d/ds = sigmoid(s) - y
-      const float y = label;
-      const float e = expf(-fabsf(s));
-      const float sig = s >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-      const float g = live ? (sig - y) * inv_t : 0.f;
-      if (live && lig == 0) {
-        score[t] = s;
-        g_out[t] = g;
-        loss_acc += fmaxf(s, 0.f) - s * y + log1pf(e);
-      }
-      if (KIND == KF_DISTMULT) {
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          acc[v].x = fmaf(g * h[v].x, tl[v].x, acc[v].x); acc[v].y = fmaf(g * h[v].y, tl[v].y, acc[v].y);
-          acc[v].z = fmaf(g * h[v].z, tl[v].z, acc[v].z); acc[v].w = fmaf(g * h[v].w, tl[v].w, acc[v].w);
+        // BCE with logits (torch formula): max(s,0) - s*y + log1p(exp(-|s|));  d/ds = sigmoid(s) - y
+        const float e = expf(-fabsf(s));
+        const float sig = s >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+        const float g = lv[u] ? (sig - label) * inv_t : 0.f;
+        if (lv[u] && lig == 0) {
+          score[tt[u]] = s;
+          g_out[tt[u]] = g;
+          loss_acc += fmaxf(s, 0.f) - s * label + log1pf(e);
         }
-      } else {
+        if (KIND == KF_DISTMULT) {
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          acc[v].x -= g * kf_sgn(h[v].x * ih + rr[v].x - tl[v].x * it); acc[v].y -= g * kf_sgn(h[v].y * ih + rr[v].y - tl[v].y * it);
-          acc[v].z -= g * kf_sgn(h[v].z * ih + rr[v].z - tl[v].z * it); acc[v].w -= g * kf_sgn(h[v].w * ih + rr[v].w - tl[v].w * it);
+          for (int q = 0; q < VQ; ++q) {
+            acc[q].x = fmaf(g * h[q].x, tl[q].x, acc[q].x); acc[q].y = fmaf(g * h[q].y, tl[q].y, acc[q].y);
+            acc[q].z = fmaf(g * h[q].z, tl[q].z, acc[q].z); acc[q].w = fmaf(g * h[q].w, tl[q].w, acc[q].w);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < VQ; ++q) {
+            acc[q].x -= g * kf_sgn(h[q].x * ih + rr[q].x - tl[q].x * it); acc[q].y -= g * kf_sgn(h[q].y * ih + rr[q].y - tl[q].y * it);
+            acc[q].z -= g * kf_sgn(h[q].z * ih + rr[q].z - tl[q].z * it); acc[q].w -= g * kf_sgn(h[q].w * ih + rr[q].w - tl[q].w * it);
+          }
         }
       }
-      }  // u
     }
     if (G > 1) {
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          acc[v].x += __shfl_xor(acc[v].x, o, 64); acc[v].y += __shfl_xor(acc[v].y, o, 64);
-          acc[v].z += __shfl_xor(acc[v].z, o, 64); acc[v].w += __shfl_xor(acc[v].w, o, 64);
+        for (int q = 0; q < VQ; ++q) {
+          acc[q].x += __shfl_xor(acc[q].x, o, 64); acc[q].y += __shfl_xor(acc[q].y, o, 64);
+          acc[q].z += __shfl_xor(acc[q].z, o, 64); acc[q].w += __shfl_xor(acc[q].w, o, 64);
         }
     }
+    // Per-wave partial row, plain store.  (Float atomics into the R rows of drel were the first version: with
+    // ~70 % of the triplets in two relations every wave hammers the same two 1-KiB rows, the 14x-slower
+    // "everyone on one row" case of MI355X_MICROARCH.md "Global float atomics": 6.9 ms per launch.)  The
+    // waves of one relation are consecutive, so the caller finishes with one segment reduce over wave rows.
     if (grp == 0) {
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        float* dst = drel + (int64_t)r * lddr + 4 * (lig + v * LPR);
-        atomicAdd(dst + 0, acc[v].x); atomicAdd(dst + 1, acc[v].y); atomicAdd(dst + 2, acc[v].z); atomicAdd(dst + 3, acc[v].w);
-      }
+      for (int q = 0; q < VQ; ++q)
+        *reinterpret_cast<float4*>(drel + (int64_t)wave_id * lddr + piece_col<T, LPR>(lig, q)) = acc[q];
     }
   }
   // per-wave loss partial (fixed-order sum by the caller): only lig == 0 lanes hold terms
@@ -157,44 +156,36 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const float* __restr
   if (lane == 0) loss_part[wave_id] = loss_acc;
 }
 
-static bool kf_aligned16(const void* p, int64_t ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
-
 }  // namespace bkg
 
 using namespace bkg;
 
 extern "C" int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel) {
-  return ((T + 255) / 256 + n_rel + 3) / 4 * 4;
+  return ((T + 63) / 64 + n_rel + 3) / 4 * 4;
 }
 
-extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, const int64_t* head,
-                                     const int64_t* tail, int64_t T, float label, float inv_total, const float* rel_emb,
-                                     int64_t ldr,
-                                     int32_t n_rel, const int32_t* order, const int32_t* rel_ptr, float* score,
-                                     float* g, float* loss_part, float* drel, int64_t lddr, void* stream) {
+extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const void* z, int32_t z_is_bf16, int64_t ldz, int32_t d,
+                                     const int64_t* head, const int64_t* tail, int64_t T, float label,
+                                     float inv_total, const float* rel_emb, int64_t ldr, int32_t n_rel,
+                                     const int32_t* order, const int32_t* rel_ptr, float* score, float* g,
+                                     float* loss_part, float* drel, int64_t lddr, void* stream) {
   BKG_ARG(kind == KF_DISTMULT || kind == KF_TRANSE, "bkg_kge_fused_bce_f32: bad kind");
-  BKG_ARG(kf_aligned16(z, ldz) && kf_aligned16(rel_emb, ldr) && kf_aligned16(drel, lddr), "bkg_kge_fused_bce_f32: alignment");
+  const int epl = z_is_bf16 ? 8 : 4;
+  BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) &&
+              (ldr % 4 == 0) && ((uintptr_t)drel % 16 == 0) && (lddr % 4 == 0), "bkg_kge_fused_bce_f32: alignment");
   BKG_ARG(T > 0 && n_rel > 0 && (label == 0.f || label == 1.f), "bkg_kge_fused_bce_f32: bad sizes / label");
   hipStream_t s = (hipStream_t)stream;
-  constexpr int CH = 256;
+  // triplets per wave: small enough that T / CH waves oversubscribe the chip several times (each wave walks its
+  // slice serially through a 3-deep dependent-load chain), large enough that the 1-KiB atomic flush stays rare
+  constexpr int CH = 64;
   dim3 grid((unsigned)(bkg_kge_fused_bce_waves(T, n_rel) / 4)), block(256);
-#define KF_LAUNCH(LPR_, VPL_)                                                                                          \
-  if (kind == KF_DISTMULT) hipLaunchKernelGGL((kge_fused_bce_kernel<KF_DISTMULT, LPR_, VPL_>), grid, block, 0, s, z, ldz, head, tail, T, label, inv_total, rel_emb, ldr, n_rel, order, rel_ptr, CH, score, g, loss_part, drel, lddr); \
-  else hipLaunchKernelGGL((kge_fused_bce_kernel<KF_TRANSE, LPR_, VPL_>), grid, block, 0, s, z, ldz, head, tail, T, label, inv_total, rel_emb, ldr, n_rel, order, rel_ptr, CH, score, g, loss_part, drel, lddr)
-  switch (d) {
-    case 8: KF_LAUNCH(2, 1); break;
-    case 16: KF_LAUNCH(4, 1); break;
-    case 24: KF_LAUNCH(2, 3); break;
-    case 32: KF_LAUNCH(8, 1); break;
-    case 48: KF_LAUNCH(4, 3); break;
-    case 64: KF_LAUNCH(16, 1); break;
-    case 96: KF_LAUNCH(8, 3); break;
-    case 128: KF_LAUNCH(32, 1); break;
-    case 256: KF_LAUNCH(64, 1); break;
-    case 512: KF_LAUNCH(64, 2); break;
-    case 768: KF_LAUNCH(64, 3); break;
-    default: set_error_msg("bkg_kge_fused_bce_f32: embedding width must be one of 8,16,24,32,48,64,96,128,256,512,768"); return -1;
-  }
+#define KF_LAUNCH(TT, K)                                                                                            \
+  hipLaunchKernelGGL((kge_fused_bce_kernel<TT, K, LPR, VPL>), grid, block, 0, s, (const TT*)z, ldz, head, tail, T, \
+                     label, inv_total, rel_emb, ldr, n_rel, order, rel_ptr, CH, score, g, loss_part, drel, lddr)
+  BKG_PIECE_DISPATCH(d / epl, {
+    if (z_is_bf16) { if (kind == KF_DISTMULT) KF_LAUNCH(__bf16, KF_DISTMULT); else KF_LAUNCH(__bf16, KF_TRANSE); }
+    else { if (kind == KF_DISTMULT) KF_LAUNCH(float, KF_DISTMULT); else KF_LAUNCH(float, KF_TRANSE); }
+  })
 #undef KF_LAUNCH
   return check_launch("bkg_kge_fused_bce_f32");
 }

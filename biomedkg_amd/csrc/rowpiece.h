@@ -1,0 +1,74 @@
+// 16-byte pieces of a gather-table row, shared by the segment-reduce (spmm.hip) and KGE (kge*.hip)
+// kernels.  A table is fp32 (exact mode) or bf16 (BASELINE config 3: bf16 storage, fp32 accumulate); a
+// 16-byte load carries EPL = 4 or 8 columns and expands to Q = 1 or 2 float4 of accumulator width.
+// Lane `lig` of an LPR-lane group owns, for piece v, columns EPL * (lig + v * LPR) + [0, EPL).
+#pragma once
+#include "common.h"
+
+namespace bkg {
+
+__device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
+  a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
+}
+
+template <typename T> struct Piece;
+
+template <> struct Piece<float> {
+  static constexpr int Q = 1, EPL = 4;
+  float4 v;
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void expand(float4* out) const { out[0] = v; }
+  __device__ __forceinline__ void fma(float4* acc, float w) const { fma4(acc[0], w, v); }
+};
+
+template <> struct Piece<__bf16> {
+  static constexpr int Q = 2, EPL = 8;
+  uint4 v;
+  __device__ __forceinline__ void load(const __bf16* p) { v = *reinterpret_cast<const uint4*>(p); }
+  // bf16 -> fp32 is a 16-bit shift: element 2i is the low half of word i
+  __device__ __forceinline__ void expand(float4* out) const {
+    out[0] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                         __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    out[1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
+                         __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
+  }
+  __device__ __forceinline__ void fma(float4* acc, float w) const {
+    float4 e[2];
+    expand(e);
+    fma4(acc[0], w, e[0]);
+    fma4(acc[1], w, e[1]);
+  }
+};
+
+// column of accumulator chunk vq (= v * Q + q) of lane `lig`
+template <typename T, int LPR>
+__device__ __forceinline__ int piece_col(int lig, int vq) {
+  constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL;
+  return EPL * (lig + (vq / Q) * LPR) + 4 * (vq % Q);
+}
+
+template <int N>
+__device__ __forceinline__ void zero4(float4 (&acc)[N]) {
+#pragma unroll
+  for (int v = 0; v < N; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// d -> (LPR, VPL) instantiations shared by the launchers: PIECES = d / EPL sixteen-byte pieces per row.
+#define BKG_PIECE_DISPATCH(PIECES, ...)                                   \
+  switch (PIECES) {                                                       \
+    case 2: { constexpr int LPR = 2, VPL = 1; __VA_ARGS__; } break;       \
+    case 4: { constexpr int LPR = 4, VPL = 1; __VA_ARGS__; } break;       \
+    case 6: { constexpr int LPR = 2, VPL = 3; __VA_ARGS__; } break;       \
+    case 8: { constexpr int LPR = 8, VPL = 1; __VA_ARGS__; } break;       \
+    case 12: { constexpr int LPR = 4, VPL = 3; __VA_ARGS__; } break;      \
+    case 16: { constexpr int LPR = 16, VPL = 1; __VA_ARGS__; } break;     \
+    case 24: { constexpr int LPR = 8, VPL = 3; __VA_ARGS__; } break;      \
+    case 32: { constexpr int LPR = 32, VPL = 1; __VA_ARGS__; } break;     \
+    case 64: { constexpr int LPR = 64, VPL = 1; __VA_ARGS__; } break;     \
+    case 96: { constexpr int LPR = 32, VPL = 3; __VA_ARGS__; } break;     \
+    case 128: { constexpr int LPR = 64, VPL = 2; __VA_ARGS__; } break;    \
+    case 192: { constexpr int LPR = 64, VPL = 3; __VA_ARGS__; } break;    \
+    default: bkg::set_error_msg("unsupported embedding width (d / 4 for fp32, d / 8 for bf16 tables must be one of 2,4,6,8,12,16,24,32,64,96,128,192)"); return -1; \
+  }
+
+}  // namespace bkg

@@ -21,6 +21,7 @@
 // Replaces (functionally) torch_geometric MessagePassing.propagate + scatter for the call sites
 // /root/reference/biomedkg/model/encoder.py:52,57,155,160.
 #include "common.h"
+#include "rowpiece.h"
 
 namespace bkg {
 
@@ -34,33 +35,6 @@ struct SpmmEpilogue {
   float drop_p;             // used when keep == null and drop_p > 0: in-kernel Philox mask
   uint64_t seed;
   uint32_t stream_id;
-};
-
-__device__ __forceinline__ void fma4(float4& a, float w, const float4& v) {
-  a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w);
-}
-
-// One 16-byte piece of a table row: Q float4 of accumulators (Q = 1 for fp32, 2 for bf16).
-template <typename T> struct Piece;
-template <> struct Piece<float> {
-  static constexpr int Q = 1, EPL = 4;
-  float4 v;
-  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
-  __device__ __forceinline__ void fma(float4* acc, float w) const { fma4(acc[0], w, v); }
-};
-template <> struct Piece<__bf16> {
-  static constexpr int Q = 2, EPL = 8;
-  uint4 v;
-  __device__ __forceinline__ void load(const __bf16* p) { v = *reinterpret_cast<const uint4*>(p); }
-  __device__ __forceinline__ void fma(float4* acc, float w) const {
-    // bf16 -> fp32 is a 16-bit shift: element 2i is the low half of word i
-    const float4 lo = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
-                                  __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
-    const float4 hi = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
-                                  __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
-    fma4(acc[0], w, lo);
-    fma4(acc[1], w, hi);
-  }
 };
 
 // One predicated batch of UT entries per lane group starting at e (entries >= end get weight 0 and a clamped,
@@ -193,12 +167,6 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
     }
 }
 
-template <int N>
-__device__ __forceinline__ void zero4(float4 (&acc)[N]) {
-#pragma unroll
-  for (int v = 0; v < N; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 // one wave per row (no splitting): small or unskewed inputs
 template <typename T, int LPR, int VPL>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict__ rowptr,
@@ -263,14 +231,26 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(bkg_rowsplit rs, const 
   const int row = rs.long_row[l], s0 = rs.long_slot0[l], n = rs.long_cnt[l];
   float4 acc[VPL * Q];
   zero4(acc);
-  for (int c = 0; c < n; ++c) {
+  // a hub row has hundreds of partial slots: keep 8 of them in flight, still added in chunk order
+  constexpr int UF = 8;
+  for (int c0 = 0; c0 < n; c0 += UF) {
+    float4 t[UF][VPL * Q];
 #pragma unroll
-    for (int v = 0; v < VPL; ++v)
+    for (int u = 0; u < UF; ++u) {
+      const int c = min(c0 + u, n - 1);
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(partials + (int64_t)(s0 + c) * d + EPL * (lig + v * LPR) + 4 * q);
-        float4& a = acc[v * Q + q];
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          t[u][v * Q + q] = *reinterpret_cast<const float4*>(partials + (int64_t)(s0 + c) * d + EPL * (lig + v * LPR) + 4 * q);
+    }
+#pragma unroll
+    for (int u = 0; u < UF; ++u)
+      if (c0 + u < n) {
+#pragma unroll
+        for (int vq = 0; vq < VPL * Q; ++vq) {
+          acc[vq].x += t[u][vq].x; acc[vq].y += t[u][vq].y; acc[vq].z += t[u][vq].z; acc[vq].w += t[u][vq].w;
+        }
       }
   }
   spmm_finish<T, LPR, VPL>(acc, row, lig, x, ldx, out, ldo, ep);

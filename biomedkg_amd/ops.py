@@ -349,7 +349,7 @@ class _KgeScore(torch.autograd.Function):
             dz = torch.empty_like(z)
             sp = inc.split
             partials = sp.partials(d, z.device) if sp is not None else None
-            L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
+            L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), 0, z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
                    L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), L.ptr(l1), L.ptr(inc.rowptr), L.ptr(inc.perm),
                    L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None), L.ptr(partials), 0, L.stream())
         if ctx.needs_input_grad[1]:
@@ -369,6 +369,24 @@ def kge_score(z, rel_emb, edge_index, edge_type, kind):
     return _KgeScore.apply(_f32c(z), _f32c(rel_emb), edge_index.contiguous(), edge_type.contiguous(), kind)
 
 
+_KGE_PIECES = (2, 4, 6, 8, 12, 16, 24, 32, 64, 96, 128, 192)   # csrc/rowpiece.h BKG_PIECE_DISPATCH
+_FUSED_CHUNK = 64   # triplets per wave of csrc/kge_fused.hip
+
+
+def _relation_waves(edge_type, rel_ptr, num_relations, n_waves):
+    """Wave ranges of each relation in the fused pass (relation r owns ceil(cnt_r / 64) consecutive waves) as a
+    CSR over wave rows + its long-row table, cached with the relation order on ``edge_type``."""
+    from .graph import RowSplit, _cached
+
+    def build():
+        cnt = (rel_ptr[1:] - rel_ptr[:-1]).long()
+        nw = (cnt + _FUSED_CHUNK - 1) // _FUSED_CHUNK
+        wave_ptr = torch.cat([nw.new_zeros(1), torch.cumsum(nw, 0)]).to(torch.int32)
+        iota = torch.arange(n_waves, dtype=torch.int32, device=edge_type.device)
+        return wave_ptr, iota, RowSplit(wave_ptr, num_relations, n_waves)
+    return _cached(edge_type, "rel_waves", (int(num_relations), int(n_waves)), build)
+
+
 class _KgeBceLoss(torch.autograd.Function):
     """``binary_cross_entropy_with_logits(cat(decode(pos), decode(neg)), cat(1, 0))`` of the reference's
     ``KGEModule.training_step`` (kge_module.py:121-127) as ONE op: the forward sweeps each triplet set once
@@ -382,6 +400,9 @@ class _KgeBceLoss(torch.autograd.Function):
         total = t_pos + t_neg
         dev = z.device
         drel = torch.zeros_like(rel_emb)
+        # bf16 mode: both passes gather the node rows from a bf16 copy of z (half the bytes; fp32 accumulate)
+        zt = to_bf16(z) if (bf16_storage() and d % 8 == 0 and (d // 8) in _KGE_PIECES) else z
+        zt_bf16 = int(zt.dtype == torch.bfloat16)
         scores, grads, loss = [], [], torch.zeros((), dtype=torch.float64, device=dev)
         for ei, et, label in ((pos_ei, pos_et, 1.0), (neg_ei, neg_et, 0.0)):
             t = ei.size(1)
@@ -391,31 +412,40 @@ class _KgeBceLoss(torch.autograd.Function):
                 order, rel_ptr = relation_order_of(et, r)
                 waves = L.lib().bkg_kge_fused_bce_waves(t, r)
                 part = torch.empty(waves, dtype=torch.float32, device=dev)
-                L.call("bkg_kge_fused_bce_f32", kind, L.ptr(z), z.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]), t, label,
-                       1.0 / total, L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order), L.ptr(rel_ptr), L.ptr(s), L.ptr(g),
-                       L.ptr(part), L.ptr(drel), drel.stride(0), L.stream())
+                drel_part = torch.empty(waves, d, dtype=torch.float32, device=dev)
+                wave_ptr, wave_iota, wave_split = _relation_waves(et, rel_ptr, r, waves)
+                L.call("bkg_kge_fused_bce_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]), t,
+                       label, 1.0 / total, L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order), L.ptr(rel_ptr), L.ptr(s),
+                       L.ptr(g), L.ptr(part), L.ptr(drel_part), drel_part.stride(0), L.stream())
                 loss = loss + part.double().sum()
+                # per-relation sum of the waves' partial rows (consecutive waves; fixed order; no atomics)
+                drel = drel + spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
             scores.append(s)
             grads.append(g)
         ctx.kind = kind
         ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
-        ctx.save_for_backward(z, rel_emb, grads[0], grads[1], drel)
+        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel)
         ctx.mark_non_differentiable(scores[0], scores[1])
         return (loss / total).float(), scores[0], scores[1]
 
     @staticmethod
     def backward(ctx, gloss, _gp, _gn):
-        z, rel_emb, g_pos, g_neg, drel = ctx.saved_tensors
+        zt, rel_emb, g_pos, g_neg, drel = ctx.saved_tensors
         pos_ei, pos_et, neg_ei, neg_et = ctx.graphs
         kind = ctx.kind
-        n, d = z.size(0), z.size(1)
+        n, d = zt.size(0), zt.size(1)
+        zt_bf16 = int(zt.dtype == torch.bfloat16)
+        z = zt
         dz = None
         if ctx.needs_input_grad[0]:
             l1 = None
             if kind == KGE_TRANSE:
-                l1 = torch.empty(n, dtype=torch.float32, device=z.device)
-                L.call("bkg_row_l1norm_f32", L.ptr(z), z.stride(0), n, d, L.ptr(l1), L.stream())
-            dz = torch.empty_like(z)
+                if zt_bf16:   # norms of the rows as the kernels read them
+                    l1 = zt.float().abs().sum(1).contiguous()
+                else:
+                    l1 = torch.empty(n, dtype=torch.float32, device=z.device)
+                    L.call("bkg_row_l1norm_f32", L.ptr(z), z.stride(0), n, d, L.ptr(l1), L.stream())
+            dz = torch.empty(n, d, dtype=torch.float32, device=z.device)
             first = True
             for ei, et, g in ((pos_ei, pos_et, g_pos), (neg_ei, neg_et, g_neg)):
                 if ei.size(1) == 0:
@@ -423,8 +453,8 @@ class _KgeBceLoss(torch.autograd.Function):
                 inc = incidence_of(ei, n)
                 sp = inc.split
                 partials = sp.partials(d, z.device) if sp is not None else None
-                L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et),
-                       ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), L.ptr(g), L.ptr(l1), L.ptr(inc.rowptr),
+                L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]),
+                       L.ptr(et), ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), L.ptr(g), L.ptr(l1), L.ptr(inc.rowptr),
                        L.ptr(inc.perm), L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None),
                        L.ptr(partials), 0 if first else 1, L.stream())
                 first = False

@@ -101,17 +101,20 @@ int bkg_kge_score_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, cons
 int bkg_row_l1norm_f32(const float* z, int64_t ldz, int64_t n, int32_t d, float* l1, void* stream);
 /* dz[i] = sum over the incidences of node i (inc_rowptr/inc_perm: the 2T entries cat(head,tail) sorted by node;
  * entry e < T: i is the head of triplet e) -- segment reduce, plain stores, no atomics */
-int bkg_kge_bwd_nodes_f32(int32_t kind, const float* z, int64_t ldz, int64_t n_nodes, int32_t d, const int64_t* head,
+int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z /* fp32 or bf16 table */, int32_t z_is_bf16, int64_t ldz,
+                          int64_t n_nodes, int32_t d, const int64_t* head,
                           const int64_t* tail, const int64_t* rel, int64_t T, const float* rel_emb, int64_t ldr,
                           const float* gscore, const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm,
                           float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
                           void* stream);
 /* Fused training pass for one label (1 = positives, 0 = negatives): score[T], g[T] = (sigmoid(s) - label) *
- * inv_total, per-wave BCE-with-logits partial sums loss_part[bkg_kge_fused_bce_waves(T, n_rel)] and drel += the
- * relation-side gradient, in one sweep over the triplets' rows visited in relation-sorted order (order / rel_ptr).
+ * inv_total, per-wave BCE-with-logits partial sums loss_part[W] and per-wave partial rows drel[W, lddr] of the
+ * relation-side gradient (W = bkg_kge_fused_bce_waves(T, n_rel); relation r owns ceil(cnt_r / 64) consecutive waves;
+ * the caller segment-reduces them), in one sweep over the triplets' rows visited in relation-sorted order.
  * Replaces decode + cat + binary_cross_entropy_with_logits of biomedkg/kge_module.py:121-127 and their autograd. */
 int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel);
-int bkg_kge_fused_bce_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, const int64_t* head,
+int bkg_kge_fused_bce_f32(int32_t kind, const void* z /* fp32 or bf16 table */, int32_t z_is_bf16, int64_t ldz,
+                          int32_t d, const int64_t* head,
                           const int64_t* tail, int64_t T, float label, float inv_total, const float* rel_emb,
                           int64_t ldr, int32_t n_rel, const int32_t* order, const int32_t* rel_ptr, float* score,
                           float* g, float* loss_part, float* drel, int64_t lddr, void* stream);
