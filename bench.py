@@ -72,7 +72,7 @@ def make_step(module, batch, world):
     return step
 
 
-def pmc_traffic(kge_module):
+def pmc_traffic(kge_module, precision):
     """HBM-side bytes per launch of the roofline kernel, from the committed rocprofv3 --pmc passes
     (profiles/*pmc_traffic.json, produced by scripts/pmc_summary.py with the gfx950 FETCH_SIZE
     correction); matched by kernel name and grid size, None if this shape was not profiled."""
@@ -84,7 +84,7 @@ def pmc_traffic(kge_module):
         grid = ((rg.seg_split.n_items_max + 3) // 4) * 256
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
             for k in json.load(open(path))["kernels"]:
-                if k["kernel"].startswith("bkg::spmm_items_f32_kernel<64, 1>") and k["grid_size"] == grid:
+                if "spmm_items" in k["kernel"] and k["grid_size"] == grid and k.get("precision") == precision:
                     return k["traffic_bytes_per_launch"]
     except Exception:  # noqa: BLE001 - reporting only
         return None
@@ -203,9 +203,12 @@ def main():
         durs = [a.elapsed_time(b) for a, b in rec["events"]]
         avg_ms = sum(durs) / len(durs)
         gbs = rec["bytes"] / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "spmm_items_f32_kernel<64,1> + fixup (R-GCN segment-mean aggregate, d=256 fp32)",
+        table = "bf16 table: spmm_items_kernel<__bf16,32,1>" if args.precision == "bf16" else \
+            "fp32 table: spmm_items_kernel<float,64,1>"
+        roof = {"bound": "hbm", "kernel": f"{table} + fixup (R-GCN segment-mean aggregate, d={h}, fp32 accumulate/out)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(rel_graph_of(ei, et, n, r)), "avg_launch_ms": avg_ms, "launches": len(durs),
+                "traffic": pmc_traffic(rel_graph_of(ei, et, n, r), args.precision), "avg_launch_ms": avg_ms,
+                "launches": len(durs),
                 "bytes_per_launch": rec["bytes"],
                 "note": "algorithmic bytes / HIP-event time; the 133 MB feature table is Infinity-Cache/L2 resident, "
                         "so the algorithmic rate can exceed the HBM peak (traffic = PMC bytes that left L2)"}
