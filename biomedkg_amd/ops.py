@@ -284,6 +284,65 @@ def rgcn_conv(x, weight, root, bias, rg, relu=False, drop=None):
     return _RgcnConv.apply(_f32c(x), weight, root, bias, rg, relu, drop)
 
 
+# ----------------------------------------------------------------------------- composable pieces
+# (used by the node-partitioned layers of biomedkg_amd/partition.py, where the gathered table is the
+#  all-gathered [world * n_max, d] matrix and the output rows are the rank's own nodes)
+class _SpmmFn(torch.autograd.Function):
+    """``out = epi(S @ table (+ addend))`` for a rectangular sparse ``S`` given as a forward CSR (rows = outputs,
+    col = table rows) and its transpose (rows = table rows, col = outputs) with matching weights."""
+
+    @staticmethod
+    def forward(ctx, table, addend, bias, fwd, bwd, w_fwd, w_bwd, n_out, relu, drop):
+        out = spmm(fwd.rowptr, fwd.col, w_fwd, _table(table), n_out, addend=addend, bias=bias, relu=relu, drop=drop,
+                   split=fwd.split)
+        ctx.bwd, ctx.w_bwd, ctx.n_table, ctx.relu = bwd, w_bwd, table.size(0), relu
+        ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
+        ctx.gated = relu or ctx.scale != 1.0
+        ctx.save_for_backward(out if ctx.gated else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dout = _f32c(dout)
+        if ctx.gated:
+            dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
+        dtable = None
+        if ctx.needs_input_grad[0]:
+            dtable = spmm(ctx.bwd.rowptr, ctx.bwd.col, ctx.w_bwd, _table(dout), ctx.n_table, split=ctx.bwd.split)
+        dadd = dout if ctx.needs_input_grad[1] else None
+        db = dout.sum(0) if ctx.needs_input_grad[2] else None
+        return dtable, dadd, db, None, None, None, None, None, None, None
+
+
+def spmm_fn(table, fwd, bwd, w_fwd, w_bwd, n_out, addend=None, bias=None, relu=False, drop=None):
+    L.require_cuda(table, addend, bias)
+    return _SpmmFn.apply(_f32c(table), addend, bias, fwd, bwd, w_fwd, w_bwd, n_out, relu, drop)
+
+
+class _GroupedLinear(torch.autograd.Function):
+    """``y[rows of g] = h[rows of g] @ weight[g]`` (RGCNConv's per-relation products)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, group_ptr):
+        ctx.group_ptr = group_ptr
+        ctx.save_for_backward(h, weight)
+        return gemm_grouped_rows(h, weight, group_ptr)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, weight = ctx.saved_tensors
+        dy = _f32c(dy)
+        dh = gemm_grouped_rows(dy, weight, ctx.group_ptr, trans_b=True) if ctx.needs_input_grad[0] else None
+        dw = gemm_grouped_k(h, dy, ctx.group_ptr, weight.size(0)) if ctx.needs_input_grad[1] else None
+        return dh, dw, None
+
+
+def grouped_linear(h, weight, group_ptr):
+    L.require_cuda(h, weight, group_ptr)
+    return _GroupedLinear.apply(_f32c(h), weight, group_ptr)
+
+
 # ----------------------------------------------------------------------------- KGE scorer
 KGE_DISTMULT, KGE_TRANSE = 0, 1
 

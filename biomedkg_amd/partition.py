@@ -1,0 +1,223 @@
+"""Node-partitioned full-graph message passing across the GPUs of one node (BASELINE
+configs[3]): rank p owns a contiguous range of nodes -- chosen so that every rank holds about E/P in-edges
+-- stores the CSR rows (all in-edges) and the activations of its nodes, and keeps a full replica of the
+weights.  Per conv layer the only exchange is an ALL-GATHER of the layer's gather table over xGMI (each
+rank contributes its [n_max, d] shard; direct 1-hop over the 7 links, a shard per link) and, in the
+backward pass, the matching REDUCE-SCATTER of the table's gradient; weight gradients are averaged with the
+flat bucket of ``distributed.GradBucket``.  Nothing here has a reference counterpart: the reference's only
+multi-GPU mode is Lightning DDP over mini-batches, which ``bench.py --gpus N`` reproduces.
+
+Padded slot space: shards are padded to ``n_max`` rows so that the gathered table is one
+``[world * n_max, d]`` matrix and node g lives at ``slot(g) = owner(g) * n_max + (g - lo_owner)``; the local
+CSRs are built directly over slots, so no index translation happens per step.
+
+The arithmetic is injected (``backend``): the product passes ``HipBackend`` (csrc kernels through
+``biomedkg_amd.ops``); the gloo tests pass a torch backend to check the partition / exchange logic on CPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+# ----------------------------------------------------------------------------- exchange
+class _AllGatherRows(torch.autograd.Function):
+    """forward: all-gather of the rank's padded shard; backward: reduce-scatter (sum) of the table gradient."""
+
+    @staticmethod
+    def forward(ctx, shard, world):
+        ctx.world = world
+        if world == 1:
+            return shard.clone()
+        out = torch.empty(world * shard.size(0), shard.size(1), dtype=shard.dtype, device=shard.device)
+        dist.all_gather_into_tensor(out, shard.contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, dtable):
+        if ctx.world == 1:
+            return dtable, None
+        dtable = dtable.contiguous()
+        out = torch.empty(dtable.size(0) // ctx.world, dtable.size(1), dtype=dtable.dtype, device=dtable.device)
+        dist.reduce_scatter_tensor(out, dtable, op=dist.ReduceOp.SUM)
+        return out, None
+
+
+def all_gather_rows(shard, world):
+    return _AllGatherRows.apply(shard, world)
+
+
+# ----------------------------------------------------------------------------- partition
+class NodePartition:
+    """Contiguous node ranges balanced by in-degree (+1 for the self loop every node gets)."""
+
+    def __init__(self, edge_index, num_nodes, rank, world):
+        self.num_nodes, self.rank, self.world = int(num_nodes), int(rank), int(world)
+        dev = edge_index.device
+        load = torch.bincount(edge_index[1], minlength=num_nodes).double() + 1.0
+        cum = torch.cumsum(load, 0)
+        targets = cum[-1] * torch.arange(1, world, device=dev, dtype=torch.float64) / world
+        cuts = torch.searchsorted(cum, targets).tolist()          # one host sync, at partition time only
+        bounds = [0] + [int(c) + 1 for c in cuts] + [self.num_nodes]
+        for i in range(1, len(bounds)):                            # keep the ranges non-decreasing and in range
+            bounds[i] = min(max(bounds[i], bounds[i - 1]), self.num_nodes)
+        self.bounds = bounds
+        self.lo, self.hi = bounds[rank], bounds[rank + 1]
+        self.n_local = self.hi - self.lo
+        self.n_max = max(max(b - a for a, b in zip(bounds[:-1], bounds[1:])), 1)
+        self._bounds_t = torch.tensor(bounds, device=dev, dtype=torch.int64)
+
+    def slots(self, ids):
+        """global node ids -> rows of the gathered ``[world * n_max, d]`` table"""
+        owner = torch.bucketize(ids, self._bounds_t[1:-1], right=True)
+        return owner * self.n_max + (ids - self._bounds_t[owner])
+
+    def is_local(self, ids):
+        return (ids >= self.lo) & (ids < self.hi)
+
+    def pad(self, x_local):
+        """[n_local, d] -> [n_max, d] (zero rows at the end)"""
+        if x_local.size(0) == self.n_max:
+            return x_local
+        return torch.cat([x_local, x_local.new_zeros(self.n_max - x_local.size(0), x_local.size(1))], dim=0)
+
+    def shard(self, x_full):
+        return x_full[self.lo:self.hi]
+
+
+class PartitionedGraph:
+    """The rank's slice of ``A_hat = D^-1/2 (A + I) D^-1/2`` (PyG gcn_norm semantics):
+    rows = its nodes, columns = table slots; degrees are global, so every rank derives them from the full
+    edge list (O(E) integer work, no communication)."""
+
+    def __init__(self, part: NodePartition, edge_index, backend, keep=None):
+        self.part, n = part, part.num_nodes
+        src, dst = edge_index[0], edge_index[1]
+        alive = src != dst
+        if keep is not None:
+            alive = alive & keep.to(torch.bool)
+        deg = torch.bincount(dst[alive], minlength=n).to(torch.float32) + 1.0
+        dis = deg.pow(-0.5)
+        mine = alive & part.is_local(dst)
+        s, d = src[mine], dst[mine]
+        own = torch.arange(part.lo, part.hi, device=edge_index.device)
+        col = torch.cat([part.slots(s), part.slots(own)])                   # neighbours + the unit self loop
+        row = torch.cat([d - part.lo, own - part.lo])
+        w = torch.cat([dis[s] * dis[d], dis[own] * dis[own]])
+        self.n_table = part.world * part.n_max
+        self.fwd = backend.csr(row, col, part.n_local)                       # rows: local targets
+        self.bwd = backend.csr(col, row, self.n_table)                       # rows: table slots
+        self.w_fwd, self.w_bwd = backend.permute(self.fwd, w), backend.permute(self.bwd, w)
+
+
+def gcn_conv_partitioned(x_local, weight, bias, pg: PartitionedGraph, backend, relu=False, drop=None):
+    """``dropout(relu(A_hat[local rows] @ all_gather(x_local W^T) + b))`` -> ``[n_local, out]``."""
+    part = pg.part
+    xw = backend.linear(x_local, weight)                                     # transform BEFORE the exchange:
+    table = all_gather_rows(part.pad(xw), part.world)                        # the wire carries `out` columns
+    return backend.spmm_fn(table, pg.fwd, pg.bwd, pg.w_fwd, pg.w_bwd, part.n_local, bias=bias, relu=relu, drop=drop)
+
+
+class PartitionedRelGraph:
+    """The rank's slice of the R-GCN mean aggregation (PyG RGCNConv aggr="mean"): (relation,
+    local target) segments over table slots, the segment -> target reduction, and their transposes."""
+
+    def __init__(self, part: NodePartition, edge_index, edge_type, num_relations, backend):
+        self.part, self.num_relations = part, int(num_relations)
+        src, dst = edge_index[0], edge_index[1]
+        mine = part.is_local(dst)
+        s, d, t = part.slots(src[mine]), dst[mine] - part.lo, edge_type[mine]
+        key = t * part.n_local + d                                           # segment key, sorted by (rel, target)
+        uniq, seg_of_edge, cnt = torch.unique(key, return_inverse=True, return_counts=True)
+        self.num_segments = int(uniq.numel())
+        seg_dst = uniq % max(part.n_local, 1)
+        seg_rel = uniq // max(part.n_local, 1)
+        w = 1.0 / cnt[seg_of_edge].to(torch.float32)
+        self.n_table = part.world * part.n_max
+        self.seg_fwd = backend.csr(seg_of_edge, s, self.num_segments)        # segment <- table slots (mean)
+        self.seg_bwd = backend.csr(s, seg_of_edge, self.n_table)
+        self.seg_w_fwd, self.seg_w_bwd = backend.permute(self.seg_fwd, w), backend.permute(self.seg_bwd, w)
+        iota = torch.arange(self.num_segments, device=edge_index.device)
+        self.dst_fwd = backend.csr(seg_dst, iota, part.n_local)              # local target <- its segments (sum)
+        self.dst_bwd = backend.csr(iota, seg_dst, self.num_segments)
+        self.rel_ptr = torch.searchsorted(seg_rel, torch.arange(self.num_relations + 1, device=seg_rel.device)
+                                          ).to(torch.int32)
+
+
+def rgcn_conv_partitioned(x_local, weight, root, bias, prg: PartitionedRelGraph, backend, relu=False, drop=None):
+    """RGCNConv over the rank's targets: all-gather the layer input, segment means, per-relation products,
+    per-target sum, + root term + bias, ReLU / dropout in the last epilogue."""
+    part = prg.part
+    table = all_gather_rows(part.pad(x_local), part.world)
+    h = backend.spmm_fn(table, prg.seg_fwd, prg.seg_bwd, prg.seg_w_fwd, prg.seg_w_bwd, prg.num_segments)
+    y = backend.grouped_linear(h, weight, prg.rel_ptr)
+    xr = backend.matmul(x_local, root)
+    return backend.spmm_fn(y, prg.dst_fwd, prg.dst_bwd, None, None, part.n_local, addend=xr, bias=bias, relu=relu,
+                           drop=drop)
+
+
+# ----------------------------------------------------------------------------- encoders over shards
+def _run_stack(layers, x_local, conv, training, drop_out, dropout_of):
+    last = len(layers) - 1
+    for i, layer in enumerate(layers):
+        if i == last:
+            x_local = conv(layer, x_local, False, None)
+        else:
+            drop = dropout_of(x_local.size(0), layer.out_channels, x_local.device) if (drop_out and training) else None
+            x_local = conv(layer, x_local, True, drop)
+    return x_local
+
+
+def gcn_encoder_partitioned(encoder, x_local, pg: PartitionedGraph, backend, dropout_of=None):
+    """``GCNEncoder.forward`` (reference encoder.py:153-162) on the rank's shard; ``encoder`` is the ordinary
+    module (replicated weights ``graph_layers[i].lin.weight / .bias``)."""
+    return _run_stack(encoder.graph_layers, x_local,
+                      lambda L, x, relu, drop: gcn_conv_partitioned(x, L.lin.weight, L.bias, pg, backend, relu, drop),
+                      encoder.training, encoder.drop_out, dropout_of)
+
+
+def rgcn_encoder_partitioned(encoder, x_local, prg: PartitionedRelGraph, backend, dropout_of=None):
+    """``RGCN.forward`` (reference encoder.py:50-59) on the rank's shard."""
+    return _run_stack(encoder.graph_layers, x_local,
+                      lambda L, x, relu, drop: rgcn_conv_partitioned(x, L.weight, L.root, L.bias, prg, backend, relu, drop),
+                      encoder.training, encoder.drop_out, dropout_of)
+
+
+def gather_embeddings(z_local, part: NodePartition):
+    """Full ``[world * n_max, d]`` table of the final embeddings (autograd: reduce-scatter of dz) for the KGE
+    scorer; index it with ``part.slots(node_ids)``."""
+    return all_gather_rows(part.pad(z_local), part.world)
+
+
+# ----------------------------------------------------------------------------- HIP backend
+class HipBackend:
+    """The product arithmetic: csrc kernels through ``biomedkg_amd.ops`` / ``graph``."""
+
+    @staticmethod
+    def csr(key, other, n_rows):
+        from .graph import CSR
+        return CSR(key.to(torch.int64).contiguous(), other.to(torch.int64).contiguous(), n_rows)
+
+    @staticmethod
+    def permute(csr, values):
+        return csr.permute_f32(values.to(torch.float32).contiguous())
+
+    @staticmethod
+    def linear(x, weight, bias=None):
+        from . import ops
+        return ops.linear(x, weight, bias)
+
+    @staticmethod
+    def matmul(x, w):
+        from . import ops
+        return ops.linear(x, w.t())          # root is stored [in, out]
+
+    @staticmethod
+    def spmm_fn(table, fwd, bwd, w_fwd, w_bwd, n_out, addend=None, bias=None, relu=False, drop=None):
+        from . import ops
+        return ops.spmm_fn(table, fwd, bwd, w_fwd, w_bwd, n_out, addend=addend, bias=bias, relu=relu, drop=drop)
+
+    @staticmethod
+    def grouped_linear(h, weight, group_ptr):
+        from . import ops
+        return ops.grouped_linear(h, weight, group_ptr)

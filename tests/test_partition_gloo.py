@@ -1,0 +1,111 @@
+"""Node-partitioned GCN / R-GCN (+ DistMult over all-gathered embeddings) on 2 and 3 gloo ranks vs. the CPU
+oracle on the whole graph: every shard of the output, and every weight gradient after the cross-rank sum,
+must match.  Exercises NodePartition, the padded slot space, the local CSRs and their transposes, and the
+all-gather / reduce-scatter autograd pair.  CPU only (torch arithmetic backend from tests/cpu_backend.py)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _problem():
+    from biomedkg_amd import synthetic
+    g = synthetic.primekg_like(400, 6000, 6, seed=5)
+    torch.manual_seed(5)
+    return g, torch.randn(400, 24), torch.randn(400, 20)
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from cpu_backend import TorchBackend as B
+    from biomedkg_amd import distributed as D
+    from biomedkg_amd import partition as P
+    from oracle import ref_modules as R
+    D.init_from_env(backend="gloo")
+    g, x_gcn, x_rgcn = _problem()
+    ei, et, n = g["edge_index"], g["edge_type"], g["num_nodes"]
+    part = P.NodePartition(ei, n, rank, world)
+    res = {"bounds": part.bounds}
+
+    # ---- GCN encoder (eval mode: ReLU between layers, no dropout)
+    torch.manual_seed(11)
+    enc = R.GCNEncoder(24, 16, 16, 2).eval()
+    for l in enc.graph_layers:
+        with torch.no_grad():
+            l.bias.uniform_(-0.1, 0.1)
+    keep = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(3)) >= 0.3     # a dropout_edge view
+    pg = P.PartitionedGraph(part, ei, B, keep=keep)
+    out = P.gcn_encoder_partitioned(enc, part.shard(x_gcn), pg, B)
+    out.pow(2).sum().backward()
+    grads = [p.grad.clone() for p in enc.parameters()]
+    for t in grads:
+        dist.all_reduce(t)
+    res["gcn_out"], res["gcn_grads"] = out.detach(), grads
+
+    # ---- R-GCN encoder + DistMult over the gathered embeddings, triplets sharded over ranks
+    torch.manual_seed(12)
+    model = R.make_kge_model("rgcn", "dismult", 20, 16, 16, 1, g["num_relations"]).eval()
+    prg = P.PartitionedRelGraph(part, ei, et, g["num_relations"], B)
+    x_local = part.shard(x_rgcn).clone().requires_grad_(True)
+    z_local = P.rgcn_encoder_partitioned(model.encoder, x_local, prg, B)
+    table = P.gather_embeddings(z_local, part)
+    mine = torch.arange(rank, ei.size(1), world)                       # this rank's share of the triplets
+    h, t, r = part.slots(ei[0, mine]), part.slots(ei[1, mine]), et[mine]
+    score = (table[h] * model.decoder.rel_emb[r] * table[t]).sum(1)
+    score.sum().backward()
+    grads = [p.grad.clone() for p in model.parameters()]
+    for gr in grads:
+        dist.all_reduce(gr)
+    res.update(rgcn_z=z_local.detach(), rgcn_grads=grads, rgcn_dx=x_local.grad.clone(), score_sum=score.sum().detach())
+    torch.save(res, os.path.join(outdir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_encoders_match_whole_graph(tmp_path, world):
+    from oracle import ref_modules as R
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"r{i}.pt")) for i in range(world)]
+    g, x_gcn, x_rgcn = _problem()
+    ei, et = g["edge_index"], g["edge_type"]
+    bounds = parts[0]["bounds"]
+    assert bounds[0] == 0 and bounds[-1] == 400 and all(p["bounds"] == bounds for p in parts)
+    load = torch.bincount(ei[1], minlength=400) + 1
+    shares = [int(load[a:b].sum()) for a, b in zip(bounds[:-1], bounds[1:])]
+    assert max(shares) < 1.6 * sum(shares) / world                       # balanced by in-edges
+
+    torch.manual_seed(11)
+    enc = R.GCNEncoder(24, 16, 16, 2).eval()
+    for l in enc.graph_layers:
+        with torch.no_grad():
+            l.bias.uniform_(-0.1, 0.1)
+    keep = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(3)) >= 0.3
+    ref = enc(x_gcn, ei[:, keep])
+    ref.pow(2).sum().backward()
+    torch.testing.assert_close(torch.cat([p["gcn_out"] for p in parts]), ref.detach(), rtol=1e-4, atol=1e-5)
+    for got, p in zip(parts[0]["gcn_grads"], enc.parameters()):
+        torch.testing.assert_close(got, p.grad, rtol=1e-4, atol=1e-5)
+
+    torch.manual_seed(12)
+    model = R.make_kge_model("rgcn", "dismult", 20, 16, 16, 1, g["num_relations"]).eval()
+    x = x_rgcn.clone().requires_grad_(True)
+    z = model.encode(x, ei, et)
+    score = model.decode(z, ei, et)
+    score.sum().backward()
+    torch.testing.assert_close(torch.cat([p["rgcn_z"] for p in parts]), z.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(sum(p["score_sum"] for p in parts), score.sum().detach(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(torch.cat([p["rgcn_dx"] for p in parts]), x.grad, rtol=1e-3, atol=1e-4)
+    for got, p in zip(parts[0]["rgcn_grads"], model.parameters()):
+        torch.testing.assert_close(got, p.grad, rtol=1e-3, atol=1e-3)
