@@ -133,6 +133,20 @@ int bkg_ntxent_rowsum_f32(const float* zn, int64_t ld, int64_t M, int32_t h, flo
 int bkg_ntxent_bwd_f32(const float* zn, int64_t ld, int64_t M, int32_t h, float tau, const float* rden, int32_t splits,
                        float* dz_partial, void* stream);
 
+/* ---- ranking evaluation (filtered MRR / Hits@k for DistMult; build-defined: the reference has no ranking metric,
+ *      BASELINE.json's north_star asks for one).  q [n_q, h] = z[anchor] * rel[r]; z [n_nodes, h] candidates, h <= 256.
+ *      true[i] = q_i . z[target_i] as the MFMA's k-ordered fma chain; gt/eq_partial [splits, n_q] count candidates
+ *      j != target_i with score > / == true[i]; bkg_rank_filter_f32 subtracts the known true candidates
+ *      cand[qptr[i] .. qptr[i+1]) (filtered setting) from summed counts. */
+int bkg_rank_true_score_f32(const float* q, int64_t ldq, const float* z, int64_t ldz, const int64_t* target,
+                            int64_t n_q, int32_t h, float* out, void* stream);
+int bkg_rank_count_f32(const float* q, int64_t ldq, int64_t n_q, const float* z, int64_t ldz, int64_t n_nodes,
+                       int32_t h, const float* true_score, const int64_t* target, int32_t splits, int32_t* gt_partial,
+                       int32_t* eq_partial, void* stream);
+int bkg_rank_filter_f32(const float* q, int64_t ldq, const float* z, int64_t ldz, int32_t h, const float* true_score,
+                        const int64_t* target, const int64_t* qptr, const int64_t* cand, int64_t n_q, int32_t* gt,
+                        int32_t* eq, void* stream);
+
 /* ---- modality fusion epilogues (biomedkg/utils/fusion.py:17-31 AttentionFusion, :49-90 ReDAF) */
 int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_t D, float* out, int64_t ldo,
                       void* stream);

@@ -1,0 +1,31 @@
+"""Dense CPU checker for the ranking evaluation (test infrastructure): fp64 score matrix, python sets for the
+filtered setting, realistic tie rule.  There is no reference counterpart (parity unpinned); the
+definition checked here is the standard filtered MRR / Hits@k protocol stated in biomedkg_amd/eval.py."""
+import torch
+
+
+def distmult_ranking(z, rel_emb, edge_index, edge_type, known=None, ks=(1, 3, 10), side="both"):
+    z, rel_emb = z.double(), rel_emb.double()
+    ranks = []
+    for s in (("tail", "head") if side == "both" else (side,)):
+        anchor, target = (edge_index[0], edge_index[1]) if s == "tail" else (edge_index[1], edge_index[0])
+        scores = (z[anchor] * rel_emb[edge_type]) @ z.t()
+        truth = {}
+        if known is not None:
+            k_ei, k_et = known
+            ka, kt = (k_ei[0], k_ei[1]) if s == "tail" else (k_ei[1], k_ei[0])
+            for a, r, t in zip(ka.tolist(), k_et.tolist(), kt.tolist()):
+                truth.setdefault((a, r), set()).add(t)
+        for i, (a, r, t) in enumerate(zip(anchor.tolist(), edge_type.tolist(), target.tolist())):
+            row = scores[i].clone()
+            true = row[t].item()
+            drop = (truth.get((a, r), set()) | {t})
+            mask = torch.ones_like(row, dtype=torch.bool)
+            mask[list(drop)] = False
+            others = row[mask]
+            ranks.append(1.0 + float((others > true).sum()) + float((others == true).sum()) / 2.0)
+    rank = torch.tensor(ranks, dtype=torch.float64)
+    out = {"MRR": float((1.0 / rank).mean()), "mean_rank": float(rank.mean()), "num_queries": int(rank.numel())}
+    for k in ks:
+        out[f"Hits@{k}"] = float((rank <= k).double().mean())
+    return out
