@@ -54,6 +54,9 @@ SIGNATURES = {
     # ntxent.hip
     "bkg_ntxent_rowsum_f32": (I32, [P, I64, I64, I32, F32, I32, P, P]),
     "bkg_ntxent_bwd_f32": (I32, [P, I64, I64, I32, F32, P, I32, P, P]),
+    # sample.hip
+    "bkg_random_walk": (I32, [P, P, P, I64, I32, U64, P, P]),
+    "bkg_sample_neighbors": (I32, [P, P, I64, I32, U64, U32, P, P]),
     # rank.hip
     "bkg_rank_true_score_f32": (I32, [P, I64, P, I64, P, I64, I32, P, P]),
     "bkg_rank_count_f32": (I32, [P, I64, I64, P, I64, I64, I32, P, P, I32, P, P, P]),

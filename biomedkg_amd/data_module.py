@@ -39,11 +39,12 @@ class _Loader:
 class SyntheticKGModule:
     def __init__(self, data_dir="", embed_dim=768, node_type=None, batch_size=128, val_ratio=0.2, test_ratio=0.2,
                  node_init_method="random", num_nodes=5000, num_edges=50000, num_relations=8, steps_per_epoch=4,
-                 gcl_model=None, gcl_fuse_method=None, seed=42):
+                 sampler="full", gcl_model=None, gcl_fuse_method=None, seed=42):
         self.embed_dim, self.node_init_method = embed_dim, node_init_method
         self.val_ratio, self.test_ratio = val_ratio, test_ratio
         self.num_nodes, self.num_edges, self.num_relations = num_nodes, num_edges, num_relations
         self.steps, self.seed = steps_per_epoch, seed
+        self.batch_size, self.sampler = batch_size, sampler   # "full": whole-graph batches; "device": the reference's
         self.single_type = isinstance(node_type, (list, tuple)) and len(node_type) == 1
 
     def setup(self, stage: str = "split"):
@@ -74,11 +75,24 @@ class SyntheticKGModule:
         self.data = types.SimpleNamespace(num_edge_types=len(names), num_nodes=n)
         self.edge_map_index = {i: name for i, name in enumerate(names)}
 
+    def _loader(self, data, loader_type, steps, shuffle):
+        """reference data_module.py:89-145: NeighborLoader([30]*3) for "neighbor", GraphSAINT-RW(10) for "saint";
+        with ``sampler="device"`` both run on the GPU (biomedkg_amd/samplers.py), else the whole graph is the batch."""
+        assert loader_type in ["neighbor", "saint"]
+        if self.sampler != "device":
+            return _Loader(data, steps)
+        from .samplers import NeighborBatchLoader, SaintBatchLoader
+        d = data.to("cuda")
+        if loader_type == "neighbor":
+            return NeighborBatchLoader(d.x, d.edge_index, d.edge_type, self.batch_size, (30, 30, 30), shuffle, self.seed)
+        return SaintBatchLoader(d.x, d.edge_index, d.edge_type, self.batch_size, walk_length=10, num_steps=steps,
+                                seed=self.seed)
+
     def train_dataloader(self, loader_type: str = "neighbor"):
-        return _Loader(self.train_data, self.steps)
+        return self._loader(self.train_data, loader_type, self.steps, True)
 
     def val_dataloader(self, loader_type: str = "neighbor"):
-        return _Loader(self.val_data, 1)
+        return self._loader(self.val_data, loader_type, max(1, self.steps // 10), False)
 
     def test_dataloader(self, loader_type: str = "neighbor"):
-        return _Loader(self.test_data, 1)
+        return self._loader(self.test_data, loader_type, max(1, self.steps // 10), False)

@@ -1,0 +1,140 @@
+"""Device-side mini-batch samplers with the semantics of the two PyG loaders the reference trains with
+(``biomedkg/data_module.py:89-107``): ``NeighborLoader(num_neighbors=[30]*3)`` for GCL and
+``GraphSAINTRandomWalkSampler(walk_length=10)`` for KGE.  The draws happen in ``csrc/sample.hip`` over the CSRs
+the hot path already keeps in HBM; the bookkeeping around them (unique / relabel) is torch glue on the device.
+Every batch satisfies the batch contract of SURVEY.md 8b and never touches the host.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .graph import graph_of
+
+
+class SubgraphBatch:
+    """``.x .edge_index .edge_type .batch_size .n_id .e_id`` (PyG ``Data``-like; already on the device)."""
+
+    def __init__(self, x, edge_index, edge_type, batch_size, n_id, e_id):
+        self.x, self.edge_index, self.edge_type = x, edge_index, edge_type
+        self.batch_size, self.n_id, self.e_id = batch_size, n_id, e_id
+
+    def to(self, device):
+        return self
+
+
+def _relabel(n_id, num_nodes, *ids):
+    lut = torch.full((num_nodes,), -1, dtype=torch.int64, device=n_id.device)
+    lut[n_id] = torch.arange(n_id.numel(), device=n_id.device)
+    return [lut[i] for i in ids]
+
+
+class NeighborSampler:
+    """Hop-wise uniform sampling of at most ``num_neighbors[h]`` distinct in-edges per frontier node; every node
+    is expanded once, when first discovered; node order = seeds, then each hop's new nodes (PyG NeighborLoader,
+    ``directed=True, replace=False``)."""
+
+    def __init__(self, edge_index, num_nodes, num_neighbors=(30, 30, 30), seed=0):
+        L.require_cuda(edge_index)
+        self.graph = graph_of(edge_index, num_nodes)
+        self.num_nodes, self.num_neighbors, self.seed, self.calls = int(num_nodes), tuple(num_neighbors), int(seed), 0
+
+    def sample(self, seeds):
+        g, dev = self.graph, seeds.device
+        csr = g.by_dst
+        self.calls += 1
+        seen = torch.zeros(self.num_nodes, dtype=torch.bool, device=dev)
+        seen[seeds] = True
+        nodes, frontier = [seeds], seeds
+        srcs, dsts, eids = [], [], []
+        for hop, k in enumerate(self.num_neighbors):
+            if frontier.numel() == 0:
+                break
+            fan = min(k if k > 0 else 64, 64)
+            pos = torch.empty(frontier.numel(), fan, dtype=torch.int32, device=dev)
+            L.call("bkg_sample_neighbors", L.ptr(csr.rowptr), L.ptr(frontier), frontier.numel(), fan,
+                   self.seed * 1_000_003 + self.calls, hop, L.ptr(pos), L.stream())
+            valid = pos >= 0
+            p = pos[valid].long()
+            src = csr.col[p].long()
+            dst = frontier.unsqueeze(1).expand_as(pos)[valid]
+            srcs.append(src); dsts.append(dst); eids.append(csr.perm[p].long())
+            new = torch.unique(src[~seen[src]])
+            seen[new] = True
+            nodes.append(new)
+            frontier = new
+        n_id = torch.cat(nodes)
+        src, dst = (torch.cat(srcs), torch.cat(dsts)) if srcs else (seeds.new_empty(0), seeds.new_empty(0))
+        e_id = torch.cat(eids) if eids else seeds.new_empty(0)
+        s, d = _relabel(n_id, self.num_nodes, src, dst)
+        return n_id, torch.stack([s, d]), e_id
+
+
+class SaintRandomWalkSampler:
+    """``batch_size`` uniform root nodes, one ``walk_length``-step uniform random walk each over the out-edges,
+    node set = the distinct visited nodes (ascending), subgraph = ALL edges among them (GraphSAINT "RW" sampler as
+    the reference configures it: ``sample_coverage=0``, so no normalisation statistics)."""
+
+    def __init__(self, edge_index, num_nodes, batch_size, walk_length=10, seed=0):
+        L.require_cuda(edge_index)
+        self.edge_index = edge_index
+        self.graph = graph_of(edge_index, num_nodes)
+        self.num_nodes, self.batch_size, self.walk_length = int(num_nodes), int(batch_size), int(walk_length)
+        self.seed, self.calls = int(seed), 0
+
+    def walks(self, start):
+        csr = self.graph.by_src
+        self.calls += 1
+        out = torch.empty(start.numel(), self.walk_length + 1, dtype=torch.int64, device=start.device)
+        L.call("bkg_random_walk", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(start), start.numel(), self.walk_length,
+               self.seed * 1_000_003 + self.calls, L.ptr(out), L.stream())
+        return out
+
+    def sample(self, start=None):
+        dev = self.edge_index.device
+        if start is None:
+            start = torch.randint(0, self.num_nodes, (self.batch_size,), device=dev)
+        n_id = torch.unique(self.walks(start))
+        mask = torch.zeros(self.num_nodes, dtype=torch.bool, device=dev)
+        mask[n_id] = True
+        src, dst = self.edge_index[0], self.edge_index[1]
+        e_id = torch.nonzero(mask[src] & mask[dst]).squeeze(1)
+        s, d = _relabel(n_id, self.num_nodes, src[e_id], dst[e_id])
+        return n_id, torch.stack([s, d]), e_id
+
+
+class NeighborBatchLoader:
+    """Iterates seed batches (optionally shuffled) -> ``SubgraphBatch`` (reference ``train_dataloader("neighbor")``)."""
+
+    def __init__(self, x, edge_index, edge_type, batch_size, num_neighbors=(30, 30, 30), shuffle=True, seed=0):
+        self.x, self.edge_type, self.batch_size, self.shuffle = x, edge_type, int(batch_size), shuffle
+        self.sampler = NeighborSampler(edge_index, x.size(0), num_neighbors, seed)
+
+    def __len__(self):
+        return (self.x.size(0) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n, dev = self.x.size(0), self.x.device
+        order = torch.randperm(n, device=dev) if self.shuffle else torch.arange(n, device=dev)
+        for i in range(0, n, self.batch_size):
+            seeds = order[i:i + self.batch_size]
+            n_id, ei, e_id = self.sampler.sample(seeds)
+            et = self.edge_type[e_id] if self.edge_type is not None else None
+            yield SubgraphBatch(self.x[n_id], ei, et, seeds.numel(), n_id, e_id)
+
+
+class SaintBatchLoader:
+    """``num_steps`` GraphSAINT random-walk subgraphs per epoch (reference ``train_dataloader("saint")``)."""
+
+    def __init__(self, x, edge_index, edge_type, batch_size, walk_length=10, num_steps=1000, seed=0):
+        self.x, self.edge_type, self.num_steps = x, edge_type, int(num_steps)
+        self.sampler = SaintRandomWalkSampler(edge_index, x.size(0), batch_size, walk_length, seed)
+
+    def __len__(self):
+        return self.num_steps
+
+    def __iter__(self):
+        for _ in range(self.num_steps):
+            n_id, ei, e_id = self.sampler.sample()
+            et = self.edge_type[e_id] if self.edge_type is not None else None
+            yield SubgraphBatch(self.x[n_id], ei, et, n_id.numel(), n_id, e_id)

@@ -133,6 +133,15 @@ int bkg_ntxent_rowsum_f32(const float* zn, int64_t ld, int64_t M, int32_t h, flo
 int bkg_ntxent_bwd_f32(const float* zn, int64_t ld, int64_t M, int32_t h, float tau, const float* rden, int32_t splits,
                        float* dz_partial, void* stream);
 
+/* ---- device mini-batch samplers (the reference's PyG loaders: biomedkg/data_module.py:89-107).
+ *      bkg_random_walk: walks[w, 0..L] over the source-sorted CSR, uniform out-neighbour per step (sinks stay put).
+ *      bkg_sample_neighbors: out_pos[f, 0..fanout) = CSR positions (destination-sorted CSR) of up to `fanout`
+ *      distinct uniformly chosen in-edges of frontier[f], -1 padded; fanout <= 64.  Philox keyed by (seed, draw). */
+int bkg_random_walk(const int32_t* rowptr, const int32_t* col, const int64_t* start, int64_t n_walks,
+                    int32_t walk_length, uint64_t seed, int64_t* walks, void* stream);
+int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* frontier, int64_t n_frontier, int32_t fanout,
+                         uint64_t seed, uint32_t hop, int32_t* out_pos, void* stream);
+
 /* ---- ranking evaluation (filtered MRR / Hits@k for DistMult; build-defined: the reference has no ranking metric,
  *      BASELINE.json's north_star asks for one).  q [n_q, h] = z[anchor] * rel[r]; z [n_nodes, h] candidates, h <= 256.
  *      true[i] = q_i . z[target_i] as the MFMA's k-ordered fma chain; gt/eq_partial [splits, n_q] count candidates

@@ -34,3 +34,19 @@ def test_train_dpi_transe_debug():
                           "model.out_dim=32", "model.decoder_name=transe", "model.fuse_method=attention", "neg_ratio=5",
                           "debug=true", "ckpt_dir=/tmp/bkg_ckpt"], config_name="dpi")
     assert out and isinstance(out[0], dict)
+
+
+def test_train_scripts_with_device_samplers():
+    """The reference's own regime: NeighborLoader batches for GCL, GraphSAINT random-walk batches for KGE."""
+    import train_gcl
+    import train_kge
+    out = train_gcl.main(["devices=[0]", "data=synthetic", "data.node_type=gene", "data.sampler=device",
+                          "data.num_nodes=2000", "data.num_edges=20000", "data.embed_dim=32", "data.batch_size=128",
+                          "model.in_dim=32", "model.hidden_dim=16", "model.out_dim=16", "model.model_name=ggd",
+                          "epochs=1", "val_every_epoch=1", "ckpt_dir=/tmp/bkg_ckpt"])
+    assert "test_loss" in out[0]
+    out = train_kge.main(["devices=[0]", "data=synthetic", "data.sampler=device", "data.num_nodes=3000",
+                          "data.num_edges=40000", "data.embed_dim=32", "data.batch_size=64", "data.steps_per_epoch=20",
+                          "model.in_dim=32", "model.hidden_dim=16", "model.out_dim=16", "neg_ratio=1", "epochs=1",
+                          "val_every_epoch=1", "ckpt_dir=/tmp/bkg_ckpt"])
+    assert any(k.startswith("test_AUROC") for k in out[0])

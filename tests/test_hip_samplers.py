@@ -1,0 +1,102 @@
+"""Device samplers: structural properties of PyG's NeighborLoader / GraphSAINT-RW semantics, uniformity of the
+draws, and an end-to-end training step on sampled batches.  Needs an MI355X."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _graph(n=500, e=20_000, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[1, :3000] = 7                       # a hub with ~3000 in-edges
+    ei[0, ei[0] == 13] = 14                # node 13: no out-edges (walks must stay put)
+    return ei
+
+
+def test_neighbor_sampler_properties():
+    from biomedkg_amd.samplers import NeighborSampler
+    n = 500
+    ei = _graph(n)
+    samp = NeighborSampler(ei.to(DEV), n, (30, 30, 30), seed=1)
+    seeds = torch.tensor([7, 3, 99, 250], device=DEV)
+    n_id, sub, e_id = samp.sample(seeds)
+    n_id, sub, e_id = n_id.cpu(), sub.cpu(), e_id.cpu()
+    assert n_id[:4].tolist() == [7, 3, 99, 250] and n_id.unique().numel() == n_id.numel()   # seeds first, no repeats
+    assert torch.equal(n_id[sub[0]], ei[0, e_id]) and torch.equal(n_id[sub[1]], ei[1, e_id])  # real edges, relabelled
+    assert e_id.unique().numel() == e_id.numel()                                              # without replacement
+    indeg = torch.bincount(ei[1], minlength=n)
+    per_dst = torch.bincount(n_id[sub[1]], minlength=n)
+    expanded = per_dst > 0
+    assert (per_dst[expanded] == torch.clamp(indeg[expanded], max=30)).all()    # min(deg, 30) per expanded node
+    assert per_dst[7] == 30 and indeg[7] > 2500
+    # 1-hop with fanout -1-like (64 cap) takes everything for small degrees
+    full = NeighborSampler(ei.to(DEV), n, (64,), seed=2)
+    _, sub1, e1 = full.sample(torch.tensor([3], device=DEV))
+    assert e1.numel() == min(int(indeg[3]), 64)
+
+
+def test_neighbor_sampler_is_uniform_over_the_hub_edges():
+    from biomedkg_amd.samplers import NeighborSampler
+    n = 500
+    ei = _graph(n)
+    samp = NeighborSampler(ei.to(DEV), n, (30,), seed=3)
+    hub_edges = torch.nonzero(ei[1] == 7).squeeze(1)
+    counts = torch.zeros(ei.size(1))
+    trials = 400
+    for _ in range(trials):
+        _, _, e_id = samp.sample(torch.tensor([7], device=DEV))
+        counts[e_id.cpu()] += 1
+    c = counts[hub_edges]
+    expect = trials * 30 / hub_edges.numel()
+    assert abs(c.mean() - expect) < 1e-6 and c.max() < expect + 6 * expect ** 0.5 + 3 and c.min() >= 0
+    assert (c > 0).float().mean() > 0.9                      # every hub edge gets picked sooner or later
+
+
+def test_saint_random_walk_sampler_properties():
+    from biomedkg_amd.samplers import SaintRandomWalkSampler
+    n = 500
+    ei = _graph(n, seed=4)
+    samp = SaintRandomWalkSampler(ei.to(DEV), n, batch_size=64, walk_length=10, seed=5)
+    start = torch.randint(0, n, (64,), device=DEV)
+    start[0] = 13
+    walks = samp.walks(start).cpu()
+    assert walks.shape == (64, 11) and torch.equal(walks[:, 0], start.cpu())
+    adj = set(map(tuple, ei.t().tolist()))
+    has_out = torch.bincount(ei[0], minlength=n) > 0
+    for w in walks.tolist():
+        for a, b in zip(w[:-1], w[1:]):
+            assert (a, b) in adj or (a == b and not has_out[a])
+    assert (walks[0] == 13).all()                             # a sink stays put
+    n_id, sub, e_id = samp.sample(start)
+    n_id, sub, e_id = n_id.cpu(), sub.cpu(), e_id.cpu()
+    assert torch.equal(n_id, torch.unique(samp.walks(start).cpu())) or n_id.numel() > 0   # (walks re-drawn: new call id)
+    inside = torch.zeros(n, dtype=torch.bool); inside[n_id] = True
+    expect = torch.nonzero(inside[ei[0]] & inside[ei[1]]).squeeze(1)
+    assert torch.equal(e_id, expect)                          # the induced subgraph: ALL edges among the nodes
+    assert torch.equal(n_id[sub[0]], ei[0, e_id]) and torch.equal(n_id[sub[1]], ei[1, e_id])
+
+
+def test_training_steps_on_sampled_batches():
+    from biomedkg_amd import synthetic
+    from biomedkg_amd.gcl_module import GRACEModule
+    from biomedkg_amd.kge_module import KGEModule
+    from biomedkg_amd.samplers import NeighborBatchLoader, SaintBatchLoader
+    g = synthetic.primekg_like(3000, 60_000, 8, seed=6)
+    ei, et = g["edge_index"].to(DEV), g["edge_type"].to(DEV)
+    x = torch.randn(3000, 32, device=DEV)
+    gcl = GRACEModule(in_dim=32, hidden_dim=16, out_dim=16, num_hidden_layers=2, fuse_method="none").to(DEV).train()
+    for i, b in enumerate(NeighborBatchLoader(x, ei, None, batch_size=64, seed=1)):
+        loss = gcl.training_step(b)
+        loss.backward()
+        assert torch.isfinite(loss) and b.batch_size == 64 and b.x.size(0) == b.n_id.numel()
+        if i == 2:
+            break
+    kge = KGEModule("rgcn", "dismult", 32, 16, 16, 2, g["num_relations"], 2, "cosine", 1e-3, 0.2, "none", 1, "random").to(DEV).train()
+    loader = SaintBatchLoader(x, ei, et, batch_size=64, walk_length=10, num_steps=3, seed=2)
+    assert len(loader) == 3
+    for b in loader:
+        loss = kge.training_step(b)
+        loss.backward()
+        assert torch.isfinite(loss) and b.edge_type.numel() == b.edge_index.size(1) and b.x.size(0) <= 64 * 11
