@@ -259,6 +259,42 @@ def gen_metric():
     save("edge_wise_precision", dict(mapping=mapping, preds=preds, target=target, result=m.compute()))
 
 
+# --------------------------------------------------------------------------- graph construction
+def gen_triplets():
+    """The reference's TripletBase over a small table (loaded by file path: its package __init__ pulls the
+    dataset downloaders); HeteroData comes from the shim."""
+    import pandas as pd
+    spec = importlib.util.spec_from_file_location("ref_base", os.path.join(REF, "biomedkg/data/dataset/_base.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = [
+        ("gene/protein", "TP53", "protein_protein", "gene/protein", "MDM2"),
+        ("gene/protein", "MDM2", "protein_protein", "gene/protein", "TP53"),
+        ("drug", "aspirin", "drug_protein", "gene/protein", "PTGS2"),
+        ("gene/protein", "PTGS2", "drug_protein", "drug", "aspirin"),      # reverse direction: dropped (triples[0])
+        ("drug", "ibuprofen", "drug_protein", "gene/protein", "PTGS2"),
+        ("disease", "pain", "indication", "drug", "aspirin"),
+        ("drug", "aspirin", "indication", "disease", "pain"),              # reverse direction: dropped
+        ("disease", "fever", "indication", "drug", "ibuprofen"),
+        ("drug", "aspirin", "drug_drug", "drug", "ibuprofen"),
+        ("drug", "ibuprofen", "drug_drug", "drug", "aspirin"),
+        ("disease", "pain", "disease_protein", "gene/protein", "TP53"),
+        ("gene/protein", "BRCA1", "protein_protein", "gene/protein", "TP53"),
+        ("drug", "aspirin", "drug_protein", "gene/protein", "PTGS2"),     # duplicate row: kept as a parallel edge
+    ]
+    df = pd.DataFrame(rows, columns=["x_type", "x_name", "relation", "y_type", "y_name"])
+
+    class Enc:
+        random_init_ratio = 0
+
+        def __call__(self, names):
+            return torch.tensor([[float(sum(map(ord, n))), float(len(n))] for n in names])
+
+    tb = mod.TripletBase(df=df, encoder=Enc())
+    save("triplets", dict(rows=rows, x=tb.data.x, edge_index=tb.data.edge_index, edge_type=tb.data.edge_type,
+                          node_type=tb.data.node_type, edge_map_index=tb.edge_map_index, node_list=tb.node_list))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("the reference is only mounted in the authoring container")
@@ -267,5 +303,6 @@ if __name__ == "__main__":
     gen_gcl()
     gen_kge()
     gen_metric()
+    gen_triplets()
     # the reference tree must stay clean
     assert not any("__pycache__" in d for d, _, _ in os.walk(REF)), "left bytecode in /root/reference"
