@@ -136,11 +136,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1 (see module docstring)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # BKG_BENCH_ONE_DEVICE=1 / BKG_BENCH_BACKEND=gloo: functional check of the multi-rank code path on a 1-GPU box
+    # (all ranks share cuda:0, gloo instead of RCCL); never used for reported numbers.
+    if os.environ.get("BKG_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BKG_BENCH_BACKEND", "nccl")
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        torch.distributed.init_process_group(backend, **kw)
 
     from biomedkg_amd import ops, synthetic
     from biomedkg_amd.graph import rel_graph_of
