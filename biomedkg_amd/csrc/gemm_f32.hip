@@ -263,7 +263,10 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
   const bool plain = !bias && act == 0 && !gate && beta == 0.f;
   const int64_t tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
   if (plain && K >= 4096 && tiles64 <= 256) {
-    const bool big = tiles64 >= 64;  // 128x128 tiles once there are enough of them
+    // bf16 operands: 128x128 tiles whenever the output allows -- the product is bound by operand traffic and
+    // every strip is then re-read by half as many tiles (measured 0.21 -> 0.14 ms at 256x256x130k; the split-K
+    // grid supplies the parallelism).  fp32 operands are MFMA-bound there and prefer more, smaller tiles.
+    const bool big = (precision == 1 && M >= 128 && N >= 128) || tiles64 >= 64;
     const int64_t tiles = big ? ((M + 127) / 128) * ((N + 127) / 128) : tiles64;
     int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 2048 / tiles));
     int kchunk = (int)(((K + nsplit - 1) / nsplit + 15) / 16 * 16);
@@ -323,7 +326,7 @@ extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, 
   if (rows_total == 0) return 0;
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   hipStream_t s = (hipStream_t)stream;
-  constexpr int BM = 128, BN = 128, KCHUNK = 2048;
+  constexpr int BM = 128, BN = 128, KCHUNK = 512;  // rows per block: ~4x the CU count in blocks at S ~ 3e5
   dim3 grid((ceil_div(rows_total, KCHUNK) + G) * ceil_div(M, BM) * ceil_div(N, BN)), block(256);
   if (precision) hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
   else hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<0, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
