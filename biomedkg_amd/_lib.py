@@ -61,6 +61,9 @@ SIGNATURES = {
     "bkg_rank_true_score_f32": (I32, [P, I64, P, I64, P, I64, I32, P, P]),
     "bkg_rank_count_f32": (I32, [P, I64, I64, P, I64, I64, I32, P, P, I32, P, P, P]),
     "bkg_rank_filter_f32": (I32, [P, I64, P, I64, I32, P, P, P, P, I64, P, P, P]),
+    "bkg_rank_l1_true_f32": (I32, [P, I64, P, I64, P, I64, I32, P, P]),
+    "bkg_rank_l1_count_f32": (I32, [P, I64, I64, P, I64, I64, I32, P, P, I32, P, P, P]),
+    "bkg_rank_l1_filter_f32": (I32, [P, I64, P, I64, I32, P, P, P, P, I64, P, P, P]),
     # fusion.hip
     "bkg_attn_fuse_f32": (I32, [P, I64, I64, I32, I32, P, I64, P]),
     "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, P, I64, P]),

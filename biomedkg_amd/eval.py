@@ -78,3 +78,54 @@ def distmult_ranking(z, rel_emb, edge_index, edge_type, known=None, ks=(1, 3, 10
     for k in ks:
         out[f"Hits@{k}"] = float((rank <= k).double().mean())
     return out
+
+
+def _l1_counts(q, zn, target, filt=None):
+    n_q, d = q.shape
+    n, dev = zn.size(0), q.device
+    true = torch.empty(n_q, dtype=torch.float32, device=dev)
+    L.call("bkg_rank_l1_true_f32", L.ptr(q), q.stride(0), L.ptr(zn), zn.stride(0), L.ptr(target), n_q, d, L.ptr(true),
+           L.stream())
+    n_qb = (n_q + 7) // 8
+    splits = max(1, min(64, 4096 // n_qb))
+    gt = torch.empty(splits, n_q, dtype=torch.int32, device=dev)
+    eq = torch.empty(splits, n_q, dtype=torch.int32, device=dev)
+    L.call("bkg_rank_l1_count_f32", L.ptr(q), q.stride(0), n_q, L.ptr(zn), zn.stride(0), n, d, L.ptr(true),
+           L.ptr(target), splits, L.ptr(gt), L.ptr(eq), L.stream())
+    gt, eq = gt.sum(0, dtype=torch.int32), eq.sum(0, dtype=torch.int32)
+    if filt is not None:
+        qptr, cand = filt
+        L.call("bkg_rank_l1_filter_f32", L.ptr(q), q.stride(0), L.ptr(zn), zn.stride(0), d, L.ptr(true), L.ptr(target),
+               L.ptr(qptr), L.ptr(cand), n_q, L.ptr(gt), L.ptr(eq), L.stream())
+    return gt, eq
+
+
+@torch.no_grad()
+def transe_ranking(z, rel_emb, edge_index, edge_type, known=None, ks=(1, 3, 10), side="both"):
+    """Filtered MRR / Hits@k for the TransE decoder (reference decoder.py:31-38: rows L1-normalised with eps
+    1e-12, score = -||h^ + r - t^||_1).  Tail prediction ranks by ``-||(h^ + r) - z^_j||_1``, head prediction by
+    ``-||(t^ - r) - z^_j||_1`` (csrc/rank_l1.hip).  Same protocol and tie rule as :func:`distmult_ranking`."""
+    L.require_cuda(z, rel_emb, edge_index, edge_type)
+    z = z.float()
+    zn = (z / z.abs().sum(dim=1, keepdim=True).clamp_min(1e-12)).contiguous()
+    r = rel_emb.size(0)
+    ranks = []
+    for s in (("tail", "head") if side == "both" else (side,)):
+        if s == "tail":
+            anchor, target = edge_index[0], edge_index[1]
+            q = (zn[anchor] + rel_emb[edge_type]).contiguous()
+        else:
+            anchor, target = edge_index[1], edge_index[0]
+            q = (zn[anchor] - rel_emb[edge_type]).contiguous()
+        filt = None
+        if known is not None:
+            k_ei, k_et = known
+            k_anchor, k_target = (k_ei[0], k_ei[1]) if s == "tail" else (k_ei[1], k_ei[0])
+            filt = _filter_lists(anchor, edge_type, k_anchor, k_et, k_target, r)
+        gt, eq = _l1_counts(q, zn, target.contiguous(), filt)
+        ranks.append(1.0 + gt.double() + eq.double() / 2.0)
+    rank = torch.cat(ranks)
+    out = {"MRR": float((1.0 / rank).mean()), "mean_rank": float(rank.mean()), "num_queries": int(rank.numel())}
+    for k in ks:
+        out[f"Hits@{k}"] = float((rank <= k).double().mean())
+    return out

@@ -149,19 +149,21 @@ class KGEModule(LightningModule):
 
     @torch.no_grad()
     def link_prediction_metrics(self, batch, eval_edge_index=None, eval_edge_type=None, known=None, ks=(1, 3, 10)):
-        """Filtered MRR / Hits@k of the DistMult decoder over ``eval_edge_*`` (default: the batch's own edges),
+        """Filtered MRR / Hits@k of the DistMult / TransE decoder over ``eval_edge_*`` (default: the batch's own edges),
         embeddings from the batch's message-passing graph.  Not in the reference (it has no ranking metric,
         SURVEY.md 0.2); provided because BASELINE.json's north_star quotes MRR / Hits@k (``biomedkg_amd/eval.py``)."""
-        from .eval import distmult_ranking
-        if getattr(self.model.decoder, "kind", None) != 0:
-            raise NotImplementedError("ranking evaluation is implemented for the DistMult decoder")
+        from .eval import distmult_ranking, transe_ranking
+        kind = getattr(self.model.decoder, "kind", None)
+        if kind not in (0, 1):
+            raise NotImplementedError("ranking evaluation is implemented for the DistMult and TransE decoders")
+        rank_fn = distmult_ranking if kind == 0 else transe_ranking
         was_training = self.training
         self.eval()
         z = self(batch.x, batch.edge_index, batch.edge_type)
         self.train(was_training)
         ei = batch.edge_index if eval_edge_index is None else eval_edge_index
         et = batch.edge_type if eval_edge_type is None else eval_edge_type
-        return distmult_ranking(z, self.model.decoder.rel_emb, ei, et, known=known, ks=ks)
+        return rank_fn(z, self.model.decoder.rel_emb, ei, et, known=known, ks=ks)
 
     @property
     def edge_mapping(self):

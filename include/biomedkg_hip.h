@@ -156,6 +156,17 @@ int bkg_rank_filter_f32(const float* q, int64_t ldq, const float* z, int64_t ldz
                         const int64_t* target, const int64_t* qptr, const int64_t* cand, int64_t n_q, int32_t* gt,
                         int32_t* eq, void* stream);
 
+/* TransE variant (score = -||q - zn_j||_1 over the L1-normalised table zn; q = zn[h] + r for tails, zn[t] - r for
+ * heads; d <= 768): same three steps as above, VALU kernels (csrc/rank_l1.hip). */
+int bkg_rank_l1_true_f32(const float* q, int64_t ldq, const float* zn, int64_t ldz, const int64_t* target, int64_t n_q,
+                         int32_t d, float* out, void* stream);
+int bkg_rank_l1_count_f32(const float* q, int64_t ldq, int64_t n_q, const float* zn, int64_t ldz, int64_t n_nodes,
+                          int32_t d, const float* true_score, const int64_t* target, int32_t splits,
+                          int32_t* gt_partial, int32_t* eq_partial, void* stream);
+int bkg_rank_l1_filter_f32(const float* q, int64_t ldq, const float* zn, int64_t ldz, int32_t d,
+                           const float* true_score, const int64_t* target, const int64_t* qptr, const int64_t* cand,
+                           int64_t n_q, int32_t* gt, int32_t* eq, void* stream);
+
 /* ---- modality fusion epilogues (biomedkg/utils/fusion.py:17-31 AttentionFusion, :49-90 ReDAF) */
 int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_t D, float* out, int64_t ldo,
                       void* stream);

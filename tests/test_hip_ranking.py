@@ -38,3 +38,21 @@ def test_ranking_ties_and_trained_embeddings():
     s = (z[3] * z).sum(1)
     expect = 1.0 + float((s > s[11]).sum()) + (float((s == s[11]).sum()) - 1) / 2.0
     assert abs(out["mean_rank"] - expect) < 1e-9 and float((s == s[11]).sum()) >= 3
+
+
+@pytest.mark.parametrize("n,d,t", [(400, 32, 300), (900, 256, 500), (250, 768, 40)])
+def test_transe_ranking_matches_dense_checker(n, d, t):
+    from biomedkg_amd import eval as E
+    from oracle import ranking as O
+    torch.manual_seed(n + 1)
+    z, rel = torch.randn(n, d), torch.randn(4, d) * (0.5 / d)
+    z[3] = 0.0                                                    # the eps path of the L1 normalisation
+    all_ei, all_et = torch.randint(0, n, (2, 3 * t)), torch.randint(0, 4, (3 * t,))
+    ei, et = all_ei[:, :t], all_et[:t]
+    for known in (None, (all_ei, all_et)):
+        ref = O.transe_ranking(z, rel, ei, et, known=known)
+        kn = None if known is None else (known[0].to(DEV), known[1].to(DEV))
+        got = E.transe_ranking(z.to(DEV), rel.to(DEV), ei.to(DEV), et.to(DEV), known=kn)
+        assert got["num_queries"] == ref["num_queries"] == 2 * t
+        for k in ("MRR", "Hits@1", "Hits@3", "Hits@10"):
+            assert abs(got[k] - ref[k]) <= 1e-4, (k, got[k], ref[k])
