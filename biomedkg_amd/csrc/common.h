@@ -32,6 +32,20 @@ static inline int check_launch(const char* what) {
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// XCD-aware block -> work mapping.  MI355X dispatches workgroup b of a 1-D grid to XCD b % 8, and each of the 8
+// XCDs has a private L2.  Work is indexed (outer, inner) where the `n_inner` items of one outer index re-read the
+// same operand panel: they take consecutive slots of a single XCD, so the panel crosses the fabric once.  The grid
+// is padded to a multiple of 8 outers; the kernel drops outer >= n_outer.
+constexpr int BKG_XCDS = 8;
+struct XcdSlot { int outer, inner; };
+__device__ __forceinline__ XcdSlot xcd_slot(unsigned block, int n_inner) {
+  const int xcd = block % BKG_XCDS, slot = block / BKG_XCDS;
+  return XcdSlot{(slot / n_inner) * BKG_XCDS + xcd, slot % n_inner};
+}
+static inline unsigned xcd_grid(int64_t n_outer, int64_t n_inner) {
+  return (unsigned)(((n_outer + BKG_XCDS - 1) / BKG_XCDS) * BKG_XCDS * n_inner);
+}
+
 // ---------------------------------------------------------------- Philox4x32-7 (counter RNG)
 // Used for dropout / feature-mask / edge-mask keep decisions generated inside kernels so that
 // the forward and the backward pass can regenerate the same decision from (seed, element id)

@@ -154,9 +154,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ B, int64_t ldb,
                                                        float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                        GemmEpilogue ep) {
-  // blockIdx.x walks N tiles fastest so that blocks sharing an A row-panel are dispatched together.
-  const int n_tiles = (N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
+  // Workgroup b is dispatched to XCD b % 8 and each XCD has its own L2: the N tiles that share an A row-panel take
+  // consecutive slots of ONE XCD, so the panel leaves HBM once (xcd_slot in common.h).
+  const int n_tiles = (N + BN - 1) / BN, m_tiles = (M + BM - 1) / BM;
+  const XcdSlot t = xcd_slot(blockIdx.x, n_tiles);
+  if (t.outer >= m_tiles) return;
+  const int m0 = t.outer * BM, n0 = t.inner * BN;
   gemm_tile_any<PREC, BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, 0, K, ep, vec_ok(A, lda), vec_ok(B, ldb));
 }
 
@@ -167,9 +170,11 @@ __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const float* __res
                                                               const float* __restrict__ B, int64_t ldb,
                                                               float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                               int kchunk, GemmEpilogue ep) {
-  const int n_tiles = (N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / n_tiles) * BM, n0 = (blockIdx.x % n_tiles) * BN;
-  const int kbeg = blockIdx.y * kchunk, kend = min(kbeg + kchunk, K);
+  // the output tiles of one K chunk re-read the same operand strips: keep them on one XCD (see gemm_f32_kernel)
+  const int n_tiles = (N + BN - 1) / BN, tiles = n_tiles * ((M + BM - 1) / BM);
+  const XcdSlot t = xcd_slot(blockIdx.x, tiles);
+  const int m0 = (t.inner / n_tiles) * BM, n0 = (t.inner % n_tiles) * BN;
+  const int kbeg = t.outer * kchunk, kend = min(kbeg + kchunk, K);
   if (kbeg >= kend) return;
   gemm_tile_any<PREC, BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, kbeg, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
 }
@@ -183,8 +188,9 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_rows_kernel(const float*
                                                                     int G, int N, int K, GemmEpilogue ep) {
   __shared__ int s_g, s_m0;
   const int n_tiles = (N + BN - 1) / BN;
+  const XcdSlot xs = xcd_slot(blockIdx.x, n_tiles);
   if (threadIdx.x == 0) {
-    int t = blockIdx.x / n_tiles, g = 0, found = -1, m0 = 0;
+    int t = xs.outer, g = 0, found = -1, m0 = 0;
     for (; g < G; ++g) {
       int rows = group_ptr[g + 1] - group_ptr[g];
       int nt = (rows + BM - 1) / BM;
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_rows_kernel(const float*
   if (g < 0) return;
   const int m0 = s_m0, mend = group_ptr[g + 1];
   const float* Bg = B + (int64_t)g * strideB;
-  gemm_tile_any<PREC, BM, BN, false, TB>(A, lda, Bg, ldb, C, ldc, mend, N, K, m0, (blockIdx.x % n_tiles) * BN, 0, K, ep,
+  gemm_tile_any<PREC, BM, BN, false, TB>(A, lda, Bg, ldb, C, ldc, mend, N, K, m0, xs.inner * BN, 0, K, ep,
                                          vec_ok(A, lda), vec_ok(Bg, ldb));
 }
 
@@ -213,8 +219,9 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const float* __
   __shared__ int s_g, s_k0;
   const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
   const int tiles = m_tiles * n_tiles;
+  const XcdSlot xs = xcd_slot(blockIdx.x, tiles);
   if (threadIdx.x == 0) {
-    int t = blockIdx.x / tiles, g = 0, found = -1, k0 = 0;
+    int t = xs.outer, g = 0, found = -1, k0 = 0;
     for (; g < G; ++g) {
       int rows = group_ptr[g + 1] - group_ptr[g];
       int nc = (rows + kchunk - 1) / kchunk;
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const float* __
   if (g < 0) return;
   const int k0 = s_k0;
   const int kend = min(k0 + kchunk, group_ptr[g + 1]);
-  const int tile = blockIdx.x % tiles;
+  const int tile = xs.inner;
   float* Cg = C + (int64_t)g * strideC;
   // op(A) = A^T: stored [K(rows), M] ; op(B) = B stored [K(rows), N]
   gemm_tile_any<PREC, BM, BN, true, false>(A, lda, B, ldb, Cg, ldc, M, N, kend, (tile / n_tiles) * BM,
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const float* __
 template <int PREC, int BM, int BN>
 static void launch_gemm(bool ta, bool tb, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                         int64_t ldc, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
-  dim3 grid(ceil_div(M, BM) * ceil_div(N, BN)), block(256);
+  dim3 grid(xcd_grid(ceil_div(M, BM), ceil_div(N, BN))), block(256);
   if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<PREC, BM, BN, false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
   else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<PREC, BM, BN, false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
   else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<PREC, BM, BN, true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, ep);
@@ -269,12 +276,12 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     const bool big = (precision == 1 && M >= 128 && N >= 128) || tiles64 >= 64;
     const int64_t tiles = big ? ((M + 127) / 128) * ((N + 127) / 128) : tiles64;
     int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 2048 / tiles));
-    int kchunk = (int)(((K + nsplit - 1) / nsplit + 15) / 16 * 16);
+    int kchunk = (int)(((K + nsplit - 1) / nsplit + 63) / 64 * 64);   // whole staged K tiles (BKH = 64)
     nsplit = (K + kchunk - 1) / kchunk;
     hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
     if (e != hipSuccess) { set_error("bkg_gemm_f32: memset", e); return (int)e; }
     ep.atomic = 1;
-    dim3 grid((unsigned)tiles, (unsigned)nsplit), block(256);
+    dim3 grid(xcd_grid(nsplit, tiles)), block(256);
 #define BKG_SPLITK(BMN, TA_, TB_)                                                                                      \
   if (precision) hipLaunchKernelGGL((gemm_f32_splitk_kernel<1, BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep); \
   else hipLaunchKernelGGL((gemm_f32_splitk_kernel<0, BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep)
@@ -310,7 +317,7 @@ extern "C" int bkg_gemm_grouped_rows_f32(int32_t trans_b, int64_t M_total, int64
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, gate, ldg, gate_scale, 0};
   hipStream_t s = (hipStream_t)stream;
   constexpr int BM = 128, BN = 128;
-  dim3 grid((ceil_div(M_total, BM) + G) * ceil_div(N, BN)), block(256);
+  dim3 grid(xcd_grid(ceil_div(M_total, BM) + G, ceil_div(N, BN))), block(256);
 #define BKG_GROWS(P, TB_) hipLaunchKernelGGL((gemm_f32_grouped_rows_kernel<P, BM, BN, TB_>), grid, block, 0, s, A, lda, B, ldb, strideB, C, ldc, group_ptr, G, (int)N, (int)K, ep)
   if (precision) { if (trans_b) BKG_GROWS(1, true); else BKG_GROWS(1, false); }
   else { if (trans_b) BKG_GROWS(0, true); else BKG_GROWS(0, false); }
@@ -327,7 +334,7 @@ extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, 
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   hipStream_t s = (hipStream_t)stream;
   constexpr int BM = 128, BN = 128, KCHUNK = 512;  // rows per block: ~4x the CU count in blocks at S ~ 3e5
-  dim3 grid((ceil_div(rows_total, KCHUNK) + G) * ceil_div(M, BM) * ceil_div(N, BN)), block(256);
+  dim3 grid(xcd_grid(ceil_div(rows_total, KCHUNK) + G, ceil_div(M, BM) * ceil_div(N, BN))), block(256);
   if (precision) hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
   else hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<0, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
   return check_launch("bkg_gemm_grouped_k_f32");

@@ -9,6 +9,8 @@
 // consecutive k of one row = one ds_read_b128); the 80-byte row stride puts the 16 lanes of a
 // ds_read_b128 group on 16 distinct 16-byte slots (conflict-free).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -18,8 +20,8 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int BKH = 32;        // K per staged tile (two 16-deep MFMA steps)
-constexpr int LDH = BKH + 8;   // bf16 elements per LDS row (80 bytes)
+constexpr int BKH = 64;        // K per staged tile (four 16-deep MFMA steps)
+constexpr int LDH = BKH + 8;   // bf16 elements per LDS row (144 bytes)
 
 __device__ __forceinline__ float4 load4h(const float* __restrict__ base, int64_t ld, int r, int c, int R, int C,
                                          bool vec) {
@@ -44,13 +46,16 @@ struct StagerH {
   static constexpr int NV = (BT * BKH / 4) / 256;
   float4 reg[NV];
 
+  // FULL: the tile is interior and 16-byte aligned -- plain vector loads, no bounds arithmetic in the K loop
+  template <bool FULL>
   __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int t0, int k0, int T, int K,
                                        bool vec) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = threadIdx.x + i * 256;
       const int r = f / (BKH / 4), kc = f % (BKH / 4);
-      reg[i] = load4h(base, ld, t0 + r, k0 + kc * 4, T, K, vec);
+      if constexpr (FULL) reg[i] = *reinterpret_cast<const float4*>(base + (int64_t)(t0 + r) * ld + (k0 + kc * 4));
+      else reg[i] = load4h(base, ld, t0 + r, k0 + kc * 4, T, K, vec);
     }
   }
   __device__ __forceinline__ void store(__bf16 (*lds)[LDH]) {
@@ -76,6 +81,7 @@ struct StagerH<BT, false> {
   static constexpr int NT = (TASKS + 255) / 256;
   float4 reg[NT][4];
 
+  template <bool FULL>
   __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int t0, int k0, int T, int K,
                                        bool vec) {
 #pragma unroll
@@ -84,7 +90,10 @@ struct StagerH<BT, false> {
       const int kq = f % (BKH / 4), tc = f / (BKH / 4);
       if (TASKS % 256 == 0 || f < TASKS) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) reg[i][j] = load4h(base, ld, k0 + kq * 4 + j, t0 + tc * 4, K, T, vec);
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (FULL) reg[i][j] = *reinterpret_cast<const float4*>(base + (int64_t)(k0 + kq * 4 + j) * ld + (t0 + tc * 4));
+          else reg[i][j] = load4h(base, ld, k0 + kq * 4 + j, t0 + tc * 4, K, T, vec);
+        }
       }
     }
   }
@@ -115,8 +124,11 @@ __device__ __forceinline__ void gemm_tile_bf16(const float* __restrict__ A, int6
                                                int n0, int kbeg, int kend, const Epi& ep, bool vecA, bool vecB) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
-  __shared__ __attribute__((aligned(16))) __bf16 As[BM][LDH];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[BN][LDH];
+  // operand images and the epilogue's transpose patches share one allocation (the patches are used after the K loop)
+  constexpr int OPER_BYTES = (BM + BN) * LDH * 2, PATCH_BYTES = 4 * 16 * (WN + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[OPER_BYTES > PATCH_BYTES ? OPER_BYTES : PATCH_BYTES];
+  __bf16 (*As)[LDH] = reinterpret_cast<__bf16 (*)[LDH]>(smem);
+  __bf16 (*Bs)[LDH] = reinterpret_cast<__bf16 (*)[LDH]>(smem + BM * LDH * 2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -131,33 +143,41 @@ __device__ __forceinline__ void gemm_tile_bf16(const float* __restrict__ A, int6
 
   StagerH<BM, !TA> sa;   // A stored [M,K] unless TA
   StagerH<BN, TB> sb;    // B stored [N,K] when TB (a Linear weight); [K,N] otherwise
-  sa.load(A, lda, m0, kbeg, M, kend, vecA);
-  sb.load(B, ldb, n0, kbeg, N, kend, vecB);
-  for (int k0 = kbeg; k0 < kend; k0 += BKH) {
-    __syncthreads();
-    sa.store(As);
-    sb.store(Bs);
-    __syncthreads();
-    if (k0 + BKH < kend) {
-      sa.load(A, lda, m0, k0 + BKH, M, kend, vecA);
-      sb.load(B, ldb, n0, k0 + BKH, N, kend, vecB);
+  auto k_loop = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    sa.template load<FULL>(A, lda, m0, kbeg, M, kend, vecA);
+    sb.template load<FULL>(B, ldb, n0, kbeg, N, kend, vecB);
+    for (int k0 = kbeg; k0 < kend; k0 += BKH) {
+      __syncthreads();
+      sa.store(As);
+      sb.store(Bs);
+      __syncthreads();
+      if (k0 + BKH < kend) {
+        sa.template load<FULL>(A, lda, m0, k0 + BKH, M, kend, vecA);
+        sb.template load<FULL>(B, ldb, n0, k0 + BKH, N, kend, vecB);
+      }
+#pragma unroll
+      for (int ks = 0; ks < BKH; ks += 16) {
+        bf16x8_t a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(&As[wm0 + i * 32 + l31][ks + lh * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[wn0 + j * 32 + l31][ks + lh * 8]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
-#pragma unroll
-    for (int ks = 0; ks < BKH; ks += 16) {
-      bf16x8_t a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(&As[wm0 + i * 32 + l31][ks + lh * 8]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[wn0 + j * 32 + l31][ks + lh * 8]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
+  };
+  // interior tile, 16-byte aligned operands, whole K steps: the loop carries no bounds arithmetic (block-uniform)
+  const bool full = vecA && vecB && m0 + BM <= M && n0 + BN <= N && (kend - kbeg) % BKH == 0;
+  if (full) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
 
-  __shared__ __attribute__((aligned(16))) float patch[4][16 * (WN + 4)];
-  store_acc_tile<TM, TN>(acc, C, ldc, M, N, m0 + wm0, n0 + wn0, ep, patch[wave]);
+  __syncthreads();   // every wave is done reading As / Bs
+  float* patch = reinterpret_cast<float*>(smem) + wave * 16 * (WN + 4);
+  store_acc_tile<TM, TN>(acc, C, ldc, M, N, m0 + wm0, n0 + wn0, ep, patch);
 }
 
 }  // namespace bkg
