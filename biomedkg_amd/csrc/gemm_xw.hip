@@ -1,0 +1,323 @@
+// Tall-skinny "activation x weight" products of the bf16 mode:  C[M, N] = epi(alpha * A[M, K] @ Wt[N, K]^T)
+// with M ~ 1e5..1e6 rows and N, K in {256, 768}: GCNConv.lin / the GGD heads / RGCNConv's root and per-relation
+// weights, forward and input-gradient (reference biomedkg/model/encoder.py:50-59,153-162, gcl.py:86-90).
+//
+// These products are bound by streaming A once; the LDS-staged tile of gemm_tile_bf16.h runs them with the loads
+// fully exposed (measured: t = t_compute + t_loadA + t_loadB, no overlap -- two barriers per 64-deep K step and only
+// two resident blocks per CU).  This kernel removes every barrier from the K loop:
+//   * the weight slab Wt[n0 : n0+128, k0 : k0+256] (bf16, prepared once per step by bkg_weight_to_bf16) is copied
+//     into LDS once and stays there while the block walks over its row tiles (K <= 256: for the whole launch);
+//   * each wave streams ITS OWN 64 rows of A straight from HBM into MFMA operand registers (lane = row, 8 consecutive
+//     k: 32 B of fp32 or 16 B of bf16 per lane and step), four 16-deep steps ahead of the MFMAs, so the only waits
+//     in the loop are counted vmcnt waits of that wave;
+//   * operands are swapped (D = W_frag x A_frag), which leaves each lane with 4 CONSECUTIVE output columns of one
+//     row per accumulator quad: C is written as 16 B/lane (fp32) or 8 B/lane (bf16) row pieces straight from the
+//     accumulators -- no LDS transpose, no epilogue barrier.
+// Rows may be grouped (RGCNConv: rows of relation g use Wt + g * stride_w); tiles never straddle groups.
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace bkg {
+
+typedef float xw_acc_t __attribute__((ext_vector_type(16)));
+typedef __bf16 xw_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 xw_bf16x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int XW_BN = 128;                 // output columns per block: 4 MFMA tiles
+constexpr int XW_TN = XW_BN / 32;
+constexpr int XW_WAVES = 4;
+constexpr int XW_TM = 2;                   // 32-row MFMA tiles per wave
+constexpr int XW_BM = XW_WAVES * XW_TM * 32;   // 256 rows per block
+constexpr int XW_KS = 256;                 // K slab kept in LDS
+constexpr int XW_LDB = XW_KS + 8;          // bf16 per LDS row: 528 B = 33 x 16 B -> conflict-free ds_read_b128
+// A prefetch depth in 16-deep steps: 64 B per lane and row tile in flight for either element type
+template <typename AT> constexpr int xw_pd() { return sizeof(AT) == 4 ? 2 : 4; }
+
+template <typename AT> struct XwFrag;
+template <> struct XwFrag<float> {
+  float4 lo, hi;
+  __device__ __forceinline__ void load(const float* p) {
+    lo = *reinterpret_cast<const float4*>(p);
+    hi = *reinterpret_cast<const float4*>(p + 4);
+  }
+  __device__ __forceinline__ xw_bf16x8_t get() const {
+    xw_bf16x8_t v;
+    v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+    v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+    return v;
+  }
+};
+template <> struct XwFrag<__bf16> {
+  xw_bf16x8_t v;
+  __device__ __forceinline__ void load(const __bf16* p) { v = *reinterpret_cast<const xw_bf16x8_t*>(p); }
+  __device__ __forceinline__ xw_bf16x8_t get() const { return v; }
+};
+
+struct XwArgs {
+  const void* A; int64_t lda;
+  const __bf16* Wt; int64_t ldw, stride_w;
+  void* C; int64_t ldc;
+  const int32_t* group_ptr; int G;
+  int M, N, K;
+  int persist;   // row-tile stride of the persistent loop (plain mode)
+};
+
+__device__ __forceinline__ void xw_store(float* dst, const float4& v) { *reinterpret_cast<float4*>(dst) = v; }
+__device__ __forceinline__ void xw_store(__bf16* dst, const float4& v) {
+  xw_bf16x4_t h;
+  h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+  *reinterpret_cast<xw_bf16x4_t*>(dst) = h;
+}
+
+// one 16-deep step: 4 weight fragments from LDS x 2 row fragments -> 8 MFMAs
+__device__ __forceinline__ void xw_step(xw_acc_t (&acc)[XW_TN][XW_TM], const __bf16 (*Bs)[XW_LDB], int l31, int lh, int ks,
+                                        const xw_bf16x8_t (&a)[XW_TM]) {
+  xw_bf16x8_t w[XW_TN];
+#pragma unroll
+  for (int i = 0; i < XW_TN; ++i) w[i] = *reinterpret_cast<const xw_bf16x8_t*>(&Bs[i * 32 + l31][ks * 16 + lh * 8]);
+#pragma unroll
+  for (int i = 0; i < XW_TN; ++i)
+#pragma unroll
+    for (int j = 0; j < XW_TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i], a[j], acc[i][j], 0, 0, 0);
+}
+
+template <typename AT, typename CT, bool GROUPED>
+__global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue ep) {
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[XW_BN][XW_LDB];
+  __shared__ int s_g, s_m0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int n_tiles = (g.N + XW_BN - 1) / XW_BN;
+  const XcdSlot slot = xcd_slot(blockIdx.x, n_tiles);
+  const int n0 = slot.inner * XW_BN;
+  const int n_slabs = (g.K + XW_KS - 1) / XW_KS;
+  const AT* __restrict__ A = reinterpret_cast<const AT*>(g.A);
+  CT* __restrict__ C = reinterpret_cast<CT*>(g.C);
+
+  int mt = slot.outer, m_tiles, m_lo = 0, m_hi = g.M, step = g.persist;
+  const __bf16* Wg = g.Wt;
+  if constexpr (GROUPED) {
+    if (threadIdx.x == 0) {
+      int t = slot.outer, gi = 0, found = -1, m0 = 0;
+      for (; gi < g.G; ++gi) {
+        const int rows = g.group_ptr[gi + 1] - g.group_ptr[gi];
+        const int nt = (rows + XW_BM - 1) / XW_BM;
+        if (t < nt) { found = gi; m0 = g.group_ptr[gi] + t * XW_BM; break; }
+        t -= nt;
+      }
+      s_g = found; s_m0 = m0;
+    }
+    __syncthreads();
+    if (s_g < 0) return;
+    Wg = g.Wt + (int64_t)s_g * g.stride_w;
+    m_lo = s_m0; m_hi = g.group_ptr[s_g + 1];
+    mt = 0; m_tiles = 1; step = 1;
+  } else {
+    m_tiles = (g.M + XW_BM - 1) / XW_BM;
+  }
+
+  int have_slab = -1;
+  for (; mt < m_tiles; mt += step) {
+    const int m_base = (GROUPED ? m_lo : mt * XW_BM) + wave * (XW_TM * 32);
+    // this lane's two source rows (clamped: out-of-range rows are computed on valid memory and never stored)
+    const AT* arow[XW_TM];
+#pragma unroll
+    for (int j = 0; j < XW_TM; ++j) arow[j] = A + (int64_t)min(m_base + j * 32 + l31, m_hi - 1) * g.lda + lh * 8;
+
+    xw_acc_t acc[XW_TN][XW_TM];
+#pragma unroll
+    for (int i = 0; i < XW_TN; ++i)
+#pragma unroll
+      for (int j = 0; j < XW_TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int s = 0; s < n_slabs; ++s) {
+      const int k0 = s * XW_KS, steps = min(XW_KS, g.K - k0) / 16;
+      if (have_slab != s) {   // block-uniform
+        __syncthreads();      // every wave is done with the previous slab
+        {
+          // 16-byte pieces, 32 per row: one wave-instruction copies two whole 512-byte rows of the slab
+          const int pc = threadIdx.x % (XW_KS / 8), r_in = threadIdx.x / (XW_KS / 8);
+          const __bf16* src = Wg + k0 + pc * 8;
+          const bool live = pc * 8 < steps * 16;
+#pragma unroll 4
+          for (int i = 0; i < (XW_BN * XW_KS / 8) / 256; ++i) {
+            const int row = r_in + i * (256 / (XW_KS / 8));
+            xw_bf16x8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+            if (live) v = *reinterpret_cast<const xw_bf16x8_t*>(src + (int64_t)min(n0 + row, g.N - 1) * g.ldw);
+            *reinterpret_cast<xw_bf16x8_t*>(&Bs[row][pc * 8]) = v;
+          }
+        }
+        __syncthreads();
+        have_slab = s;
+      }
+      constexpr int PD = xw_pd<AT>(), NSTEP = XW_KS / 16;
+      XwFrag<AT> ring[PD][XW_TM];
+      {   // a rolled loop of PD-step groups: counted vmcnt waits only, no barrier (K % 256 == 0: whole slabs)
+#pragma unroll
+        for (int p = 0; p < PD; ++p)
+#pragma unroll
+          for (int j = 0; j < XW_TM; ++j) ring[p][j].load(arow[j] + k0 + p * 16);
+#pragma unroll 1
+        for (int kb = 0; kb < NSTEP - PD; kb += PD) {
+#pragma unroll
+          for (int p = 0; p < PD; ++p) {
+            xw_bf16x8_t a[XW_TM];
+#pragma unroll
+            for (int j = 0; j < XW_TM; ++j) {
+              a[j] = ring[p][j].get();
+              ring[p][j].load(arow[j] + k0 + (kb + PD + p) * 16);
+            }
+            xw_step(acc, Bs, l31, lh, kb + p, a);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+          xw_bf16x8_t a[XW_TM];
+#pragma unroll
+          for (int j = 0; j < XW_TM; ++j) a[j] = ring[p][j].get();
+          xw_step(acc, Bs, l31, lh, NSTEP - PD + p, a);
+        }
+      }
+    }
+    if (n_slabs > 1) have_slab = n_slabs - 1;
+
+    // epilogue: acc[i][j][4q..4q+3] = C[m_base + 32 j + l31][n0 + 32 i + 8 q + 4 lh + 0..3]; one row pointer per j,
+    // every piece at a compile-time offset from it (N % 32 == 0: a 32-column tile is in range or not as a whole)
+    const bool plain = !ep.bias && ep.act == 0 && !ep.gate && ep.beta == 0.f && ep.alpha == 1.f;
+#pragma unroll
+    for (int j = 0; j < XW_TM; ++j) {
+      const int row = m_base + j * 32 + l31;
+      if (row < m_hi) {
+        CT* __restrict__ drow = C + (int64_t)row * g.ldc + n0 + lh * 4;
+        if (plain) {
+#pragma unroll
+          for (int i = 0; i < XW_TN; ++i) {
+            if (n0 + i * 32 < g.N) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                xw_store(drow + i * 32 + q * 8, make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                                                          acc[i][j][4 * q + 3]));
+            }
+          }
+        } else {
+          const float* __restrict__ brow = ep.bias ? ep.bias + n0 + lh * 4 : nullptr;
+          const float* __restrict__ grow = ep.gate ? ep.gate + (int64_t)row * ep.ldg + n0 + lh * 4 : nullptr;
+#pragma unroll
+          for (int i = 0; i < XW_TN; ++i) {
+            if (n0 + i * 32 < g.N) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int off = i * 32 + q * 8;
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                const float4 b = brow ? *reinterpret_cast<const float4*>(brow + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v.x = ep.alpha * v.x + b.x; v.y = ep.alpha * v.y + b.y; v.z = ep.alpha * v.z + b.z; v.w = ep.alpha * v.w + b.w;
+                if (ep.act == 1) {
+                  v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                } else if (ep.act == 2) {
+                  v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
+                  v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
+                }
+                if (grow) {
+                  const float4 gt = *reinterpret_cast<const float4*>(grow + off);
+                  v.x = gt.x > 0.f ? v.x * ep.gate_scale : 0.f; v.y = gt.y > 0.f ? v.y * ep.gate_scale : 0.f;
+                  v.z = gt.z > 0.f ? v.z * ep.gate_scale : 0.f; v.w = gt.w > 0.f ? v.w * ep.gate_scale : 0.f;
+                }
+                if constexpr (sizeof(CT) == 4) {
+                  if (ep.beta != 0.f) {
+                    const float4 o = *reinterpret_cast<const float4*>(drow + off);
+                    v.x = fmaf(ep.beta, o.x, v.x); v.y = fmaf(ep.beta, o.y, v.y);
+                    v.z = fmaf(ep.beta, o.z, v.z); v.w = fmaf(ep.beta, o.w, v.w);
+                  }
+                }
+                xw_store(drow + off, v);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// weights -> the [N][K] bf16 image the kernel above reads (a 64 x 64 patch per block through LDS)
+__global__ __launch_bounds__(256) void weight_to_bf16_kernel(const float* __restrict__ W, int64_t ldw, int64_t stride_w,
+                                                             int rows, int cols, int transpose, __bf16* __restrict__ out,
+                                                             int64_t ldo, int64_t stride_o) {
+  __shared__ float t[64][65];
+  const float* Wb = W + (int64_t)blockIdx.z * stride_w;
+  __bf16* ob = out + (int64_t)blockIdx.z * stride_o;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = e / 64, c = e % 64;
+    t[r][c] = (r0 + r < rows && c0 + c < cols) ? Wb[(int64_t)(r0 + r) * ldw + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int a = e / 64, b = e % 64;
+    if (!transpose) {
+      if (r0 + a < rows && c0 + b < cols) ob[(int64_t)(r0 + a) * ldo + c0 + b] = (__bf16)t[a][b];
+    } else {
+      if (c0 + a < cols && r0 + b < rows) ob[(int64_t)(c0 + a) * ldo + r0 + b] = (__bf16)t[b][a];
+    }
+  }
+}
+
+}  // namespace bkg
+
+using namespace bkg;
+
+extern "C" int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w, int64_t rows, int64_t cols,
+                                  int32_t batch, int32_t transpose, void* out, int64_t ldo, int64_t stride_o,
+                                  void* stream) {
+  BKG_ARG(rows > 0 && cols > 0 && batch > 0 && rows < (1 << 24) && cols < (1 << 24), "bkg_weight_to_bf16: bad shape");
+  dim3 grid(ceil_div(cols, 64), ceil_div(rows, 64), batch);
+  hipLaunchKernelGGL(weight_to_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, stride_w, (int)rows,
+                     (int)cols, transpose, reinterpret_cast<__bf16*>(out), ldo, stride_o);
+  return check_launch("bkg_weight_to_bf16");
+}
+
+extern "C" int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const void* A, int32_t a_is_bf16, int64_t lda,
+                           const void* Wt, int64_t ldw, int64_t stride_w, const int32_t* group_ptr, int32_t G,
+                           float beta, void* C, int32_t c_is_bf16, int64_t ldc, const float* bias, int32_t act,
+                           const float* gate, int64_t ldg, float gate_scale, void* stream) {
+  BKG_ARG(M >= 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1 << 24) && K < (1 << 24), "bkg_gemm_xw: bad shape");
+  BKG_ARG(K % XW_KS == 0 && N % 32 == 0, "bkg_gemm_xw: K must be a multiple of 256 and N of 32");
+  BKG_ARG(act >= 0 && act <= 2, "bkg_gemm_xw: bad act");
+  const int a_el = a_is_bf16 ? 2 : 4, c_el = c_is_bf16 ? 2 : 4;
+  BKG_ARG((uintptr_t)A % 16 == 0 && (lda * a_el) % 16 == 0 && (uintptr_t)Wt % 16 == 0 && (ldw * 2) % 16 == 0 &&
+              (stride_w * 2) % 16 == 0,
+          "bkg_gemm_xw: A / Wt rows must be 16-byte aligned");
+  BKG_ARG((uintptr_t)C % 16 == 0 && (ldc * c_el) % (4 * c_el) == 0 && (!bias || (uintptr_t)bias % 16 == 0) &&
+              (!gate || ((uintptr_t)gate % 16 == 0 && ldg % 4 == 0)),
+          "bkg_gemm_xw: C / bias / gate must allow 4-column vector access");
+  BKG_ARG(!(c_is_bf16 && beta != 0.f), "bkg_gemm_xw: beta needs an fp32 C");
+  BKG_ARG(group_ptr == nullptr || G > 0, "bkg_gemm_xw: G must be positive with group_ptr");
+  if (M == 0) return 0;
+  GemmEpilogue ep{alpha, beta, bias, act, gate, ldg, gate_scale, 0};
+  const int n_tiles = ceil_div(N, XW_BN);
+  XwArgs g{A, lda, reinterpret_cast<const __bf16*>(Wt), ldw, stride_w, C, ldc, group_ptr, G, (int)M, (int)N, (int)K, 0};
+  hipStream_t s = (hipStream_t)stream;
+  unsigned grid;
+  if (group_ptr) {
+    grid = xcd_grid(ceil_div(M, XW_BM) + G, n_tiles);
+  } else {
+    // persistent: two blocks per CU walk the row tiles with a fixed stride; the weight slab is loaded once (K <= 256)
+    const int64_t m_tiles = ceil_div(M, XW_BM);
+    int64_t lanes = std::max<int64_t>(BKG_XCDS, (2 * 256 / n_tiles) / BKG_XCDS * BKG_XCDS);
+    lanes = std::min<int64_t>(lanes, (m_tiles + BKG_XCDS - 1) / BKG_XCDS * BKG_XCDS);
+    g.persist = (int)lanes;
+    grid = (unsigned)(lanes * n_tiles);
+  }
+#define BKG_XW(AT, CT)                                                                                          \
+  do {                                                                                                          \
+    if (group_ptr) hipLaunchKernelGGL((gemm_xw_kernel<AT, CT, true>), dim3(grid), dim3(256), 0, s, g, ep);      \
+    else hipLaunchKernelGGL((gemm_xw_kernel<AT, CT, false>), dim3(grid), dim3(256), 0, s, g, ep);               \
+  } while (0)
+  if (a_is_bf16) { if (c_is_bf16) BKG_XW(__bf16, __bf16); else BKG_XW(__bf16, float); }
+  else { if (c_is_bf16) BKG_XW(float, __bf16); else BKG_XW(float, float); }
+#undef BKG_XW
+  return check_launch("bkg_gemm_xw");
+}

@@ -34,15 +34,64 @@ def _f32c(t):
 
 
 # ----------------------------------------------------------------------------- raw kernels
+def _weight_bf16(w, transpose):
+    """bf16 ``[.., N, K]`` image of a (batch of) weight matrix for ``bkg_gemm_xw`` -- ``w`` itself when it is stored
+    ``[N, K]``, its transpose when stored ``[K, N]``.  One tiny launch per (weight version, orientation)."""
+    cache = getattr(w, "_bkg_w16", None)
+    if cache is None:
+        cache = {}
+        w._bkg_w16 = cache
+    key = (w.data_ptr(), w._version, bool(transpose))
+    hit = cache.get(transpose)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    batch, rows, cols = w3.shape
+    out = torch.empty((batch, cols, rows) if transpose else (batch, rows, cols), dtype=torch.bfloat16, device=w.device)
+    L.call("bkg_weight_to_bf16", L.ptr(w3), w3.stride(1), w3.stride(0), rows, cols, batch, int(transpose), L.ptr(out),
+           out.stride(1), out.stride(0), L.stream())
+    out = out if w.dim() == 3 else out[0]
+    cache[transpose] = (key, out)
+    return out
+
+
+def _xw_ok(a, m, n, k):
+    """Shapes / layouts the streaming activation-x-weight kernel (csrc/gemm_xw.hip) takes in bf16 mode."""
+    el = a.element_size()
+    return (_PRECISION == 1 and m >= 1024 and n * k <= (1 << 22) and k % 256 == 0 and n % 32 == 0 and a.stride(1) == 1 and
+            (a.stride(0) * el) % 16 == 0 and a.data_ptr() % 16 == 0)
+
+
+def _gemm_xw(a, wt, m, n, k, out, out_dtype, alpha, beta, bias, act, gate, gate_scale, group_ptr=None, groups=0):
+    if out is None:
+        out = torch.empty(m, n, dtype=out_dtype, device=a.device)
+    w2 = wt if wt.dim() == 2 else wt[0]
+    L.call("bkg_gemm_xw", m, n, k, alpha, L.ptr(a), int(a.dtype == torch.bfloat16), a.stride(0), L.ptr(wt), w2.stride(0),
+           wt.stride(0) if wt.dim() == 3 else 0, L.ptr(group_ptr), groups, beta, L.ptr(out),
+           int(out.dtype == torch.bfloat16), out.stride(0), L.ptr(bias), act, L.ptr(gate),
+           gate.stride(0) if gate is not None else 0, gate_scale, L.stream())
+    return out
+
+
 def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias=None, act=ACT_NONE, gate=None,
-         gate_scale=1.0):
-    """``out = epi(alpha * op(a) @ op(b))``; a/b 2-D row-major fp32 (exact-fp32 MFMA kernel)."""
+         gate_scale=1.0, out_dtype=torch.float32):
+    """``out = epi(alpha * op(a) @ op(b))``; a/b 2-D row-major fp32.  fp32 mode: exact-fp32 MFMA kernel.  bf16 mode:
+    bf16 operands / fp32 accumulate; tall ``a`` (fp32 or bf16) times a small weight ``b`` streams through
+    ``bkg_gemm_xw`` and may write a bf16 ``out`` (``out_dtype``)."""
     L.require_cuda(a, b, out, bias, gate)
-    a, b = _f32c(a), _f32c(b)
+    b = _f32c(b)
     m, k = (a.size(1), a.size(0)) if trans_a else (a.size(0), a.size(1))
     k2, n = (b.size(1), b.size(0)) if trans_b else (b.size(0), b.size(1))
     if k != k2:
         raise ValueError(f"gemm shape mismatch: {tuple(a.shape)} x {tuple(b.shape)} (ta={trans_a}, tb={trans_b})")
+    if (not trans_a and _xw_ok(a, m, n, k) and (out is None or out.stride(0) % 4 == 0) and
+            (gate is None or (gate.stride(0) % 4 == 0 and gate.data_ptr() % 16 == 0))):
+        if gate is not None:
+            gate = _f32c(gate)
+        return _gemm_xw(a, _weight_bf16(b, not trans_b), m, n, k, out, out_dtype, alpha, beta, bias, act, gate, gate_scale)
+    if out_dtype != torch.float32 or a.dtype != torch.float32:
+        raise TypeError("bf16 activations are only taken / produced by the bf16-mode activation-x-weight products")
+    a = _f32c(a)
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
     L.call("bkg_gemm_f32", int(trans_a), int(trans_b), m, n, k, alpha, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0),
@@ -51,12 +100,18 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias
     return out
 
 
-def gemm_grouped_rows(a, b, group_ptr, trans_b=False):
+def gemm_grouped_rows(a, b, group_ptr, trans_b=False, out_dtype=torch.float32):
     """``out[rows of g] = a[rows of g] @ op(b[g])``; ``b`` is ``[G, k, n]`` (or ``[G, n, k]`` if trans_b)."""
     L.require_cuda(a, b, group_ptr)
-    a, b = _f32c(a), _f32c(b)
+    b = _f32c(b)
     g = b.size(0)
     k, n = (b.size(2), b.size(1)) if trans_b else (b.size(1), b.size(2))
+    if _xw_ok(a, a.size(0), n, k):
+        return _gemm_xw(a, _weight_bf16(b, not trans_b), a.size(0), n, k, None, out_dtype, 1.0, 0.0, None, ACT_NONE, None,
+                        1.0, group_ptr, g)
+    if out_dtype != torch.float32:
+        raise TypeError("bf16 outputs are only produced by the bf16-mode activation-x-weight products")
+    a = _f32c(a)
     out = torch.empty(a.size(0), n, dtype=torch.float32, device=a.device)
     L.call("bkg_gemm_grouped_rows_f32", int(trans_b), a.size(0), n, k, L.ptr(a), a.stride(0), L.ptr(b), b.stride(1),
            b.stride(0), L.ptr(out), out.stride(0), L.ptr(group_ptr), g, None, 0, 1.0, _PRECISION,
@@ -206,7 +261,10 @@ class _GcnConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, graph: Graph, gw: GcnWeights, relu, drop):
-        xw = _table(gemm(x, weight, trans_b=True))
+        if bf16_storage() and _bf16_ok(weight.size(0)) and _xw_ok(x, x.size(0), weight.size(0), weight.size(1)):
+            xw = gemm(x, weight, trans_b=True, out_dtype=torch.bfloat16)   # only ever read as the gather table
+        else:
+            xw = _table(gemm(x, weight, trans_b=True))
         c = graph.by_dst
         out = spmm(c.rowptr, c.col, gw.w_dst, xw, graph.num_nodes, self_w=gw.self_w, bias=bias, relu=relu, drop=drop,
                    tag="gcn_propagate", split=c.split)
@@ -272,7 +330,9 @@ class _RgcnConv(torch.autograd.Function):
         db = dout.sum(0) if ctx.needs_input_grad[3] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dh = gemm_grouped_rows(dy, weight, rg.rel_ptr, trans_b=True)              # [S, in]
+            to16 = bf16_storage() and _bf16_ok(weight.size(1)) and _xw_ok(dy, dy.size(0), weight.size(1), weight.size(2))
+            dh = gemm_grouped_rows(dy, weight, rg.rel_ptr, trans_b=True,
+                                   out_dtype=torch.bfloat16 if to16 else torch.float32)   # [S, in], a gather table
             dx_root = gemm(dout, root, trans_b=True)                                  # [N, in]
             c = rg.src_csr
             dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), rg.num_nodes, addend=dx_root, split=c.split)

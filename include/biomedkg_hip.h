@@ -84,6 +84,17 @@ int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, 
 int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                  int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias,
                  int32_t act, const float* gate, int64_t ldg, float gate_scale, int32_t precision, void* stream);
+/* bf16-mode streaming form of the tall "activation x small weight" products (GCNConv.lin, heads, RGCNConv root and
+ * per-relation weights; forward and input gradient): C[M,N] = epi(alpha * A[M,K] @ Wt[N,K]^T).  A is fp32 or bf16
+ * (a_is_bf16), Wt is the bf16 [N, K] image made by bkg_weight_to_bf16 (out[b] = bf16(W[b]) or bf16(W[b]^T), W[b] =
+ * W + b*stride_w of shape [rows, cols]), C is fp32 or bf16 (c_is_bf16; beta needs fp32).  K % 256 == 0, N % 32 == 0,
+ * 16-byte aligned rows.  group_ptr != NULL: rows of group g use Wt + g*stride_w (device group_ptr[G+1]). */
+int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w, int64_t rows, int64_t cols, int32_t batch,
+                       int32_t transpose, void* out, int64_t ldo, int64_t stride_o, void* stream);
+int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const void* A, int32_t a_is_bf16, int64_t lda,
+                const void* Wt, int64_t ldw, int64_t stride_w, const int32_t* group_ptr, int32_t G, float beta, void* C,
+                int32_t c_is_bf16, int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg,
+                float gate_scale, void* stream);
 /* RGCNConv per-relation products: rows grouped by device-side group_ptr[G+1]; group g uses B + g*strideB */
 int bkg_gemm_grouped_rows_f32(int32_t trans_b, int64_t M_total, int64_t N, int64_t K, const float* A, int64_t lda,
                               const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,

@@ -34,6 +34,23 @@ def main():
     dst = torch.empty_like(src)
     ms = timeit(lambda: dst.copy_(src))
     print(json.dumps({"kernel": "copy 133MB->133MB", "ms": ms, "GBs": 2 * src.numel() * 4 / ms / 1e6}))
+    big_src = torch.empty(1 << 28, device=dev)
+    big_dst = torch.empty_like(big_src)
+    ms = timeit(lambda: big_dst.copy_(big_src))
+    print(json.dumps({"kernel": "copy 1GiB->1GiB", "ms": ms, "GBs": 2 * big_src.numel() * 4 / ms / 1e6}))
+    ms = timeit(lambda: big_src.sum())
+    print(json.dumps({"kernel": "read 1GiB (sum)", "ms": ms, "GBs": big_src.numel() * 4 / ms / 1e6}))
+    del big_src, big_dst
+    if prec == "bf16":
+        for (mm, nn, kk) in ((n, 256, 256), (n, 256, 768)):
+            a = torch.randn(mm, kk, device=dev)
+            b = torch.randn(nn, kk, device=dev)
+            for adt, cdt in ((torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16)):
+                aa = a.to(adt)
+                ms = timeit(lambda: ops.gemm(aa, b, trans_b=True, out_dtype=cdt))
+                byt = mm * kk * aa.element_size() + mm * nn * (2 if cdt == torch.bfloat16 else 4)
+                print(json.dumps({"kernel": "gemm_xw", "A": str(adt)[6:], "C": str(cdt)[6:], "M": mm, "N": nn, "K": kk,
+                                  "ms": round(ms, 4), "GBs_io": round(byt / ms / 1e6)}))
     for (mm, nn, kk, ta, tb) in ((n, 256, 256, False, True), (n, 256, 256, False, False), (n, 256, 768, False, True),
                                  (n, 768, 256, False, False), (256, 256, n, True, False), (256, 768, n, True, False),
                                  (768, 256, n, True, False)):

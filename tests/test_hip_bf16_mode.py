@@ -98,3 +98,61 @@ def test_kge_step_bf16_mode_close_to_reference(golden, name):
     for k, v in g["grads"].items():
         err = (params[k].grad.cpu() - v).norm() / v.norm().clamp_min(1e-6)
         assert err < 1e-1, (k, float(err))
+
+
+@pytest.mark.parametrize("m,n,k", [(1024, 32, 256), (3001, 256, 256), (2600, 160, 768), (70_000, 256, 256)])
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("a_bf16,c_bf16", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_xw_streaming(m, n, k, tb, a_bf16, c_bf16):
+    """Tall activation x small weight (csrc/gemm_xw.hip): fp32 / bf16 A, bf16 weight image, fp32 / bf16 C."""
+    from biomedkg_amd import ops
+    torch.manual_seed(m + n)
+    a = torch.randn(m, k, device=DEV)
+    b = torch.randn((n, k) if tb else (k, n), device=DEV)
+    assert ops._xw_ok(a, m, n, k)
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    ref = ar @ (br.t() if tb else br)
+    out = ops.gemm(a.bfloat16() if a_bf16 else a, b, trans_b=tb,
+                   out_dtype=torch.bfloat16 if c_bf16 else torch.float32)
+    assert out.dtype == (torch.bfloat16 if c_bf16 else torch.float32)
+    if c_bf16:
+        torch.testing.assert_close(out.double(), ref, rtol=2 ** -7, atol=1e-3 * k ** 0.5)
+    else:
+        torch.testing.assert_close(out.double(), ref, rtol=1e-4, atol=1e-3 * k ** 0.5)
+
+
+def test_gemm_xw_epilogues_and_groups():
+    from biomedkg_amd import ops
+    torch.manual_seed(21)
+    m, n, k = 2500, 96, 256
+    a, w = torch.randn(m, k, device=DEV), torch.randn(n, k, device=DEV)
+    bias, c0, gate = torch.randn(n, device=DEV), torch.randn(m, n, device=DEV), torch.randn(m, n, device=DEV)
+    pre = 0.5 * (a.bfloat16().double() @ w.bfloat16().double().t()) + bias.double()
+    tol = dict(rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(ops.gemm(a, w, trans_b=True, alpha=0.5, bias=bias, act=ops.ACT_RELU).double(), pre.relu(), **tol)
+    torch.testing.assert_close(ops.gemm(a, w, trans_b=True, alpha=0.5, bias=bias, act=ops.ACT_ELU).double(),
+                               torch.nn.functional.elu(pre), **tol)
+    out = c0.clone()
+    ops.gemm(a, w, trans_b=True, alpha=0.5, bias=bias, beta=2.0, out=out)
+    torch.testing.assert_close(out.double(), pre + 2.0 * c0.double(), **tol)
+    out = ops.gemm(a, w, trans_b=True, alpha=0.5, bias=bias, gate=gate, gate_scale=1.25)
+    torch.testing.assert_close(out.double(), torch.where(gate > 0, pre * 1.25, 0.0), **tol)
+    # the weight image follows in-place updates of the weight (optimizer steps)
+    w.mul_(2.0)
+    torch.testing.assert_close(ops.gemm(a, w, trans_b=True).double(), a.bfloat16().double() @ w.bfloat16().double().t(), **tol)
+    # grouped rows (RGCNConv per-relation weights), empty / tiny / multi-tile groups, both weight orientations
+    sizes = [0, 700, 1, 0, 1300, 64]
+    gptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=DEV)
+    s, g = sum(sizes), len(sizes)
+    h, wg, dy = torch.randn(s, 256, device=DEV), torch.randn(g, 256, 64, device=DEV), torch.randn(s, 64, device=DEV)
+    wbig = torch.randn(g, 256, 256, device=DEV)
+    y = ops.gemm_grouped_rows(h, wg, gptr)
+    dh = ops.gemm_grouped_rows(h, wbig, gptr, trans_b=True, out_dtype=torch.bfloat16)
+    assert dh.dtype == torch.bfloat16
+    o = 0
+    for i, sz in enumerate(sizes):
+        sl = slice(o, o + sz)
+        torch.testing.assert_close(y[sl].double(), h[sl].bfloat16().double() @ wg[i].bfloat16().double(), **tol)
+        torch.testing.assert_close(dh[sl].double(), h[sl].bfloat16().double() @ wbig[i].bfloat16().double().t(),
+                                   rtol=2 ** -7, atol=2e-2)
+        o += sz
