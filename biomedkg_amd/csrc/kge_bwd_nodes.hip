@@ -117,28 +117,41 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict_
     inv_self = 1.0f / fmaxf(l1[node], KN_EPS);
     kn_load_self<T, LPR, VPL>(z, ldz, node, lig, inv_self, self);
   }
-  // Batches of U incidences per lane group with the three dependent load stages (entry id -> triplet fields
-  // -> rows) each issued for the whole batch.  Slots past the end are clamped and masked out.
-  constexpr int U = (VQ == 1) ? 4 : 2;
-  for (int k0 = start; k0 < end; k0 += U * G) {
-    int64_t e[U];
-    bool ok[U];
+  // Batches of U incidences per lane group through a three-stage software pipeline: with the rows of batch i the
+  // triplet fields of batch i+1 and the entry ids of batch i+2 are in flight (issued before the rows, so the one
+  // wait per iteration retires all three): the chain entry id -> triplet fields -> rows costs one memory latency
+  // per batch.  Slots past the end are clamped and masked out.
+  constexpr int U = (VQ == 1) ? 4 : (VQ >= 8 ? 1 : 2);
+  constexpr int STEP = U * G;
+  int64_t other[U], ri[U];
+  float g[U];
+  bool is_head[U];
+  int e_n[U];
+  auto fields = [&](int e, int64_t& o, int64_t& r, float& gg, bool& hd) {
+    hd = e < tr.T;
+    const int64_t t = hd ? e : e - tr.T;
+    o = hd ? tr.tail[t] : tr.head[t];
+    r = tr.rel[t];
+    gg = gscore[t];
+  };
+  if (start < end) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = k0 + u * G + grp;
-      ok[u] = k < end;
-      e[u] = inc_perm[min(k, end - 1)];
+      const int e0 = inc_perm[min(start + u * G + grp, end - 1)];
+      e_n[u] = inc_perm[min(start + STEP + u * G + grp, end - 1)];
+      fields(e0, other[u], ri[u], g[u], is_head[u]);
     }
-    int64_t other[U], ri[U];
-    float g[U], inv_o[U];
-    bool is_head[U];
+  }
+  for (int k0 = start; k0 < end; k0 += STEP) {
+    int64_t other_n[U], ri_n[U];
+    float g_n[U], inv_o[U];
+    bool is_head_n[U], ok[U];
+    int e_nn[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      is_head[u] = e[u] < tr.T;
-      const int64_t t = is_head[u] ? e[u] : e[u] - tr.T;
-      other[u] = is_head[u] ? tr.tail[t] : tr.head[t];
-      ri[u] = tr.rel[t];
-      g[u] = gscore[t];
+      ok[u] = k0 + u * G + grp < end;
+      fields(e_n[u], other_n[u], ri_n[u], g_n[u], is_head_n[u]);
+      e_nn[u] = inc_perm[min(k0 + 2 * STEP + u * G + grp, end - 1)];
     }
     Piece<T> ob[U][VPL];
 #pragma unroll
@@ -170,6 +183,10 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict_
           acc[q].z = fmaf(sg, kn_sgn(d4.z), acc[q].z); acc[q].w = fmaf(sg, kn_sgn(d4.w), acc[q].w);
         }
       }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      other[u] = other_n[u]; ri[u] = ri_n[u]; g[u] = g_n[u]; is_head[u] = is_head_n[u]; e_n[u] = e_nn[u];
     }
   }
   if (G > 1) {
@@ -270,7 +287,7 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_b
                        (const TT*)z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz,  \
                        none, partials, accumulate);                                                                    \
   }
-  BKG_PIECE_DISPATCH(d / epl, {
+  BKG_PIECE_DISPATCH_(d / epl, 16, 16, {
     if (z_is_bf16) { if (kind == KN_DISTMULT) { KN_LAUNCH(__bf16, KN_DISTMULT) } else { KN_LAUNCH(__bf16, KN_TRANSE) } }
     else { if (kind == KN_DISTMULT) { KN_LAUNCH(float, KN_DISTMULT) } else { KN_LAUNCH(float, KN_TRANSE) } }
   })

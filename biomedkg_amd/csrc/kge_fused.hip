@@ -62,20 +62,32 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const T* __restrict_
     zero4(acc);
 #pragma unroll
     for (int q = 0; q < VQ; ++q) rr[q] = kf_ld4(rel_emb + (int64_t)r * ldr + piece_col<T, LPR>(lig, q));
-    // batches of U triplets per lane group: triplet ids, then endpoints, then rows are each loaded for the
-    // whole batch so the three-deep dependent-load chain is paid once per batch, not once per triplet
-    constexpr int U = (VQ == 1) ? 4 : 2;  // keeps the batch at <= 8 float4 per operand (VGPRs -> occupancy)
-    for (int k0 = beg; k0 < end; k0 += U * G) {
-      int64_t tt[U], hh[U], ta[U];
+    // Batches of U triplets per lane group through a three-stage software pipeline: while the rows of batch i
+    // are in flight, the endpoints of batch i+1 and the triplet ids of batch i+2 are too (issued BEFORE the rows,
+    // so the one wait per iteration -- for the rows -- retires all three).  The dependent chain id -> endpoints ->
+    // rows therefore costs one memory latency per batch instead of three.  Ids past the slice are clamped.
+    constexpr int U = (VQ == 1) ? 4 : (VQ >= 8 ? 1 : 2);  // keeps the batch at <= 8 float4 per operand (VGPRs -> occupancy)
+    constexpr int STEP = U * G;
+    int tt[U], tt_n[U];
+    int64_t hh[U], ta[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      tt[u] = order[min(beg + u * G + grp, end - 1)];
+      tt_n[u] = order[min(beg + STEP + u * G + grp, end - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { hh[u] = head[tt[u]]; ta[u] = tail[tt[u]]; }
+    for (int k0 = beg; k0 < end; k0 += STEP) {
+      int tt_nn[U];
+      int64_t hh_n[U], ta_n[U];
       bool lv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = k0 + u * G + grp;
-        lv[u] = k < end;
-        tt[u] = order[min(k, end - 1)];
+        lv[u] = k0 + u * G + grp < end;
+        hh_n[u] = head[tt_n[u]];
+        ta_n[u] = tail[tt_n[u]];
+        tt_nn[u] = order[min(k0 + 2 * STEP + u * G + grp, end - 1)];
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) { hh[u] = head[tt[u]]; ta[u] = tail[tt[u]]; }
       Piece<T> hb[U][VPL], tb[U][VPL];
 #pragma unroll
       for (int u = 0; u < U; ++u)
@@ -130,6 +142,8 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const T* __restrict_
           }
         }
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { tt[u] = tt_n[u]; hh[u] = hh_n[u]; ta[u] = ta_n[u]; tt_n[u] = tt_nn[u]; }
     }
     if (G > 1) {
 #pragma unroll
@@ -182,7 +196,7 @@ extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const void* z, int32_t z_is_b
 #define KF_LAUNCH(TT, K)                                                                                            \
   hipLaunchKernelGGL((kge_fused_bce_kernel<TT, K, LPR, VPL>), grid, block, 0, s, (const TT*)z, ldz, head, tail, T, \
                      label, inv_total, rel_emb, ldr, n_rel, order, rel_ptr, CH, score, g, loss_part, drel, lddr)
-  BKG_PIECE_DISPATCH(d / epl, {
+  BKG_PIECE_DISPATCH_(d / epl, 8, 16, {
     if (z_is_bf16) { if (kind == KF_DISTMULT) KF_LAUNCH(__bf16, KF_DISTMULT); else KF_LAUNCH(__bf16, KF_TRANSE); }
     else { if (kind == KF_DISTMULT) KF_LAUNCH(float, KF_DISTMULT); else KF_LAUNCH(float, KF_TRANSE); }
   })

@@ -27,7 +27,7 @@ def main():
         loss, _, _ = ops.kge_bce_loss(z, rel, ei, et, neg, nt, kind)
         loss.backward()
         torch.cuda.synchronize()
-        print(f"iter {it}: {1e3 * (time.perf_counter() - t0):.2f} ms  loss {float(loss):.5f}")
+        print(f"iter {it}: {1e3 * (time.perf_counter() - t0):.2f} ms  loss {float(loss.detach()):.5f}")
         z.grad = None; rel.grad = None
 
 
