@@ -67,6 +67,11 @@ SIGNATURES = {
     "bkg_rank_l1_true_f32": (I32, [P, I64, P, I64, P, I64, I32, P, P]),
     "bkg_rank_l1_count_f32": (I32, [P, I64, I64, P, I64, I64, I32, P, P, I32, P, P, P]),
     "bkg_rank_l1_filter_f32": (I32, [P, I64, P, I64, I32, P, P, P, P, I64, P, P, P]),
+    # negsample.hip
+    "bkg_hashset_insert": (I32, [P, P, I64, I64, P, I64, P]),
+    "bkg_negative_sample_workspace_bytes": (I64, [I64]),
+    "bkg_negative_sample": (I32, [I64, I64, I64, U64, P, I64, P, P, P, P, P, I64, I64, P, P, I64, P]),
+    "bkg_permute_gather_i64": (I32, [P, I64, U64, P, P]),
     # fusion.hip
     "bkg_attn_fuse_f32": (I32, [P, I64, I64, I32, I32, P, I64, P]),
     "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, P, I64, P]),

@@ -1,0 +1,181 @@
+// Device negative sampling for the KGE step (reference biomedkg/kge_module.py:86-102: PyG negative_sampling +
+// a randomly permuted copy of the positives' relation ids).  PyG draws `random.sample(range(N*N), m)` on the host and
+// tests membership with np.isin; the first device version of this path did the same with sorts and binary searches
+// (two 8-pass radix sorts + a 22-level searchsorted per step).  Nothing is sorted here:
+//   * sampling WITHOUT replacement = a prefix of a random permutation: candidate i is pi(i) for a keyed bijection pi
+//     of [0, N*N) (6-round Feistel network on the enclosing even power of two + cycle walking), so candidates are
+//     distinct by construction -- random.sample's guarantee -- and later rounds just continue the prefix;
+//   * membership in the positives is a lookup in an open-addressing hash table built once per graph
+//     (bkg_hashset_insert) instead of a binary search;
+//   * survivors are compacted in candidate order (flag -> rocPRIM exclusive scan -> scatter), so the result is a
+//     pure function of (graph, seed): bitwise repeatable, no atomics;
+//   * bkg_permute_gather_i64: out[i] = src[pi(i)] with the same kind of bijection over [0, n) -- the
+//     `x[torch.randperm(n)]` of the reference without the sort behind randperm.
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace bkg {
+
+constexpr unsigned long long HS_EMPTY = ~0ull;
+
+__device__ __host__ __forceinline__ uint64_t hs_mix(uint64_t x) {   // splitmix64 finaliser
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+
+// 0: inserted, 1: was present
+__device__ __forceinline__ int hs_insert(unsigned long long* __restrict__ tab, uint64_t mask, uint64_t key) {
+  uint64_t i = hs_mix(key) & mask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(tab + i, HS_EMPTY, (unsigned long long)key);
+    if (prev == HS_EMPTY) return 0;
+    if (prev == key) return 1;
+    i = (i + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ bool hs_contains(const unsigned long long* __restrict__ tab, uint64_t mask, uint64_t key) {
+  uint64_t i = hs_mix(key) & mask;
+  for (;;) {
+    const unsigned long long v = tab[i];
+    if (v == key) return true;
+    if (v == HS_EMPTY) return false;
+    i = (i + 1) & mask;
+  }
+}
+
+// Keyed bijection of [0, n): balanced Feistel network over 2*half bits (a permutation of [0, 4^half) whatever the
+// round function is), walked until the image falls back into [0, n) -- that keeps it a bijection of [0, n); the
+// enclosing domain is < 4 n, so the walk takes < 4 steps on average.
+struct Feistel {
+  uint64_t n, key[6];
+  int half;
+  __device__ __forceinline__ uint64_t operator()(uint64_t x) const {
+    const uint64_t m = (1ull << half) - 1ull;
+    do {
+      uint64_t l = x >> half, r = x & m;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const uint64_t f = hs_mix(r ^ key[i]) >> 17;
+        const uint64_t t = l ^ (f & m);
+        l = r; r = t;
+      }
+      x = (l << half) | r;
+    } while (x >= n);
+    return x;
+  }
+};
+
+static Feistel make_feistel(uint64_t n, uint64_t seed) {
+  Feistel f;
+  f.n = n;
+  int bits = 2;
+  while (bits < 64 && (1ull << bits) < n) bits += 2;
+  f.half = bits / 2;
+  for (int i = 0; i < 6; ++i) f.key[i] = hs_mix(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1));
+  return f;
+}
+
+__global__ __launch_bounds__(256) void hashset_insert_kernel(const int64_t* __restrict__ hi, const int64_t* __restrict__ lo,
+                                                             int64_t n_lo, int64_t n, unsigned long long* __restrict__ tab,
+                                                             uint64_t mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) hs_insert(tab, mask, (uint64_t)(hi[i] * n_lo + lo[i]));
+}
+
+__global__ __launch_bounds__(256) void negative_candidates_kernel(Feistel pi, int64_t first, int64_t n_cand,
+                                                                  const unsigned long long* __restrict__ pos_tab,
+                                                                  uint64_t pos_mask, uint64_t* __restrict__ keys,
+                                                                  int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_cand) return;
+  const uint64_t key = pi((uint64_t)(first + i));
+  keys[i] = key;
+  flag[i] = hs_contains(pos_tab, pos_mask, key) ? 0 : 1;
+}
+
+__global__ __launch_bounds__(256) void negative_scatter_kernel(const uint64_t* __restrict__ keys,
+                                                               const int32_t* __restrict__ flag,
+                                                               const int32_t* __restrict__ offs, int64_t n_cand,
+                                                               uint64_t n_nodes, int64_t out_offset, int64_t max_out,
+                                                               int64_t* __restrict__ out_head, int64_t* __restrict__ out_tail,
+                                                               int32_t* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_cand) return;
+  if (flag[i]) {
+    const int64_t p = out_offset + offs[i];
+    if (p < max_out) {
+      out_head[p] = (int64_t)(keys[i] / n_nodes);
+      out_tail[p] = (int64_t)(keys[i] % n_nodes);
+    }
+  }
+  if (i == n_cand - 1) *count = offs[i] + flag[i];
+}
+
+__global__ __launch_bounds__(256) void permute_gather_kernel(const int64_t* __restrict__ src, int64_t n, Feistel pi,
+                                                             int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = src[pi((uint64_t)i)];
+}
+
+}  // namespace bkg
+
+using namespace bkg;
+
+static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int bkg_hashset_insert(const int64_t* hi, const int64_t* lo, int64_t n_lo, int64_t n, uint64_t* table,
+                                  int64_t capacity, void* stream) {
+  BKG_ARG(pow2(capacity) && capacity >= 2 * n && n_lo > 0, "bkg_hashset_insert: capacity must be a power of two >= 2 n");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(hashset_insert_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, hi, lo, n_lo, n,
+                     reinterpret_cast<unsigned long long*>(table), (uint64_t)capacity - 1);
+  return check_launch("bkg_hashset_insert");
+}
+
+extern "C" int64_t bkg_negative_sample_workspace_bytes(int64_t n_candidates) {
+  size_t bytes = 0;
+  rocprim::exclusive_scan(nullptr, bytes, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)n_candidates,
+                          rocprim::plus<int32_t>());
+  return (int64_t)bytes + 256;
+}
+
+extern "C" int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int64_t n_candidates, uint64_t seed,
+                                   const uint64_t* pos_table, int64_t pos_capacity, uint64_t* keys_tmp,
+                                   int32_t* flag_tmp, int32_t* offs_tmp, int64_t* out_head, int64_t* out_tail,
+                                   int64_t out_offset, int64_t max_out, int32_t* count, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  BKG_ARG(n_nodes > 0 && n_nodes < (1ll << 31) && n_candidates >= 0 && n_candidates < (1ll << 31) && first_candidate >= 0,
+          "bkg_negative_sample: bad sizes");
+  BKG_ARG(first_candidate + n_candidates <= n_nodes * n_nodes, "bkg_negative_sample: more candidates than cells");
+  BKG_ARG(pow2(pos_capacity), "bkg_negative_sample: table capacity must be a power of two");
+  hipStream_t s = (hipStream_t)stream;
+  if (n_candidates == 0) {
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) { set_error("bkg_negative_sample: memset", e); return (int)e; }
+    return 0;
+  }
+  const Feistel pi = make_feistel((uint64_t)(n_nodes * n_nodes), seed);
+  hipLaunchKernelGGL(negative_candidates_kernel, dim3(ceil_div(n_candidates, 256)), dim3(256), 0, s, pi, first_candidate,
+                     n_candidates, reinterpret_cast<const unsigned long long*>(pos_table), (uint64_t)pos_capacity - 1,
+                     keys_tmp, flag_tmp);
+  size_t bytes = (size_t)workspace_bytes;
+  hipError_t e = rocprim::exclusive_scan(workspace, bytes, flag_tmp, offs_tmp, 0, (size_t)n_candidates,
+                                         rocprim::plus<int32_t>(), s);
+  if (e != hipSuccess) { set_error("bkg_negative_sample: scan", e); return (int)e; }
+  hipLaunchKernelGGL(negative_scatter_kernel, dim3(ceil_div(n_candidates, 256)), dim3(256), 0, s, keys_tmp, flag_tmp,
+                     offs_tmp, n_candidates, (uint64_t)n_nodes, out_offset, max_out, out_head, out_tail, count);
+  return check_launch("bkg_negative_sample");
+}
+
+extern "C" int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t seed, int64_t* out, void* stream) {
+  BKG_ARG(n >= 0, "bkg_permute_gather_i64: bad n");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(permute_gather_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, n,
+                     make_feistel((uint64_t)n, seed), out);
+  return check_launch("bkg_permute_gather_i64");
+}

@@ -55,7 +55,7 @@ class KGEModule(LightningModule):
         num_neg_samples = self.neg_ratio * edge_index.size(-1) if self.neg_ratio else None
         neg_edge_index = r.neg_edges(edge_index, num_neg_samples)
         if self.neg_ratio:
-            neg_edge_type = edge_type.repeat(self.neg_ratio)[r.perm(self.neg_ratio * edge_type.size(0), edge_type.device)]
+            neg_edge_type = r.shuffle(edge_type.repeat(self.neg_ratio))   # == repeat(..)[randperm(..)]
         else:
             neg_edge_type = edge_type
         return neg_edge_index, neg_edge_type

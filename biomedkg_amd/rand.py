@@ -40,9 +40,24 @@ class DeviceRand:
     def coin(self) -> float:
         return float(torch.rand(1).item())
 
+    def _draw_seed(self):
+        self.counter += 1
+        return (self.seed * 0x9E3779B97F4A7C15 + self.counter * 0xD1B54A32D192ED03) & ((1 << 63) - 1)
+
+    def shuffle(self, src):
+        """``src[randperm(len(src))]`` for an int64 vector through a keyed bijection of the index range
+        (csrc/negsample.hip: no sort behind it)."""
+        from . import _lib as L
+        src = src.contiguous()
+        if src.dtype != torch.int64 or src.dim() != 1:
+            return src[torch.randperm(src.size(0), device=src.device)]
+        out = torch.empty_like(src)
+        L.call("bkg_permute_gather_i64", L.ptr(src), src.numel(), self._draw_seed(), L.ptr(out), L.stream())
+        return out
+
     def neg_edges(self, edge_index, num_neg_samples):
         from .sampling import negative_sampling
-        return negative_sampling(edge_index, num_neg_samples=num_neg_samples)
+        return negative_sampling(edge_index, num_neg_samples=num_neg_samples, seed=self._draw_seed())
 
     def skip(self, count):
         pass
@@ -71,6 +86,9 @@ class ReplayRand:
 
     def perm(self, n, device):
         return self._next("perm")
+
+    def shuffle(self, src):
+        return src[self.perm(src.size(0), src.device)]
 
     def coin(self) -> float:
         return float(self._next("coin").item())

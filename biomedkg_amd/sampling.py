@@ -4,8 +4,11 @@ Semantics follow PyG 2.5.3 ``negative_sampling(edge_index, num_neg_samples=k)`` 
 calls it (``biomedkg/kge_module.py:93``): uniform (head, tail) pairs from the
 N x N grid (N = max id + 1) that are not positives, all distinct, at most 3 over-sampling rounds of
 ``int(1.1 k / (1 - E/N^2))`` candidates, truncated to k (fewer may come back).  Upstream draws with
-python ``random.sample`` + ``np.isin`` on the host; here candidates come from the device generator
-and the membership / distinctness tests are sort + binary search on the GPU.
+python ``random.sample`` + ``np.isin`` on the host; here the candidates are a prefix of a keyed random permutation
+of the grid (distinct by construction), membership in the positives is a hash-set lookup (table built once per
+graph) and the survivors are compacted in candidate order (``csrc/negsample.hip``): no sort, no atomics, the
+result is a pure function of (graph, seed).  Graphs so dense that the whole N x N grid is enumerated take
+the sort / binary-search form below (torch glue).
 """
 from __future__ import annotations
 
@@ -40,14 +43,52 @@ def _isin_sorted(values, sorted_keys):
     return sorted_keys[pos] == values
 
 
-def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None):
+def _pow2_at_least(v):
+    return 1 << max(10, int(v - 1).bit_length())
+
+
+def _num_nodes_of(edge_index):
+    return _cached(edge_index, "max_id", (), lambda: int(edge_index.max().item()) + 1 if edge_index.numel() else 0)
+
+
+def _positive_table(edge_index, n):
+    """Open-addressing hash set of the positives' keys ``head * n + tail`` (int64, empty = -1), cached per graph."""
+    def build():
+        ei = edge_index.contiguous()
+        cap = _pow2_at_least(2 * ei.size(1))
+        table = torch.full((cap,), -1, dtype=torch.int64, device=ei.device)
+        L.call("bkg_hashset_insert", L.ptr(ei[0]), L.ptr(ei[1]), n, ei.size(1), L.ptr(table), cap, L.stream())
+        return table
+    return _cached(edge_index, "pos_table", (int(n),), build)
+
+
+def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
+    dev = edge_index.device
+    pos_table = _positive_table(edge_index, n)
+    out = torch.empty(2, k, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    have, first, draw = 0, 0, min(sample_size, n * n)
+    for _ in range(3):                               # PyG: at most three over-sampling rounds
+        keys = torch.empty(draw, dtype=torch.int64, device=dev)
+        flag = torch.empty(2, draw, dtype=torch.int32, device=dev)
+        ws = torch.empty(L.lib().bkg_negative_sample_workspace_bytes(draw), dtype=torch.uint8, device=dev)
+        L.call("bkg_negative_sample", n, first, draw, seed, L.ptr(pos_table), pos_table.numel(), L.ptr(keys),
+               L.ptr(flag[0]), L.ptr(flag[1]), L.ptr(out[0]), L.ptr(out[1]), have, k, L.ptr(count), L.ptr(ws), ws.numel(),
+               L.stream())
+        have = min(have + int(count.item()), k)      # the one host sync of the sampler
+        first += draw
+        if have >= k:
+            return out
+        draw = min(int(1.1 * (k - have) / prob) + 64, n * n - first)   # later rounds continue the permutation's prefix
+        if draw <= 0:
+            break
+    return out[:, :have].contiguous()
+
+
+def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None, seed=None):
     L.require_cuda(edge_index)
     dev = edge_index.device
-    n, pos = _positive_keys(edge_index)
-    if num_nodes is not None:
-        if num_nodes != n:
-            n = int(num_nodes)
-            pos = torch.unique(edge_index[0] * n + edge_index[1])
+    n = _num_nodes_of(edge_index) if num_nodes is None else int(num_nodes)
     population = n * n
     e = edge_index.size(1)  # upstream counts duplicate positives too (idx.numel())
     if e >= population:
@@ -55,6 +96,13 @@ def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None):
     k = num_neg_samples if num_neg_samples else e
     prob = 1.0 - e / population
     sample_size = int(1.1 * k / prob)
+    if population > sample_size and n < (1 << 31):
+        if seed is None:
+            seed = int(torch.randint(0, 1 << 62, (1,)).item())    # CPU generator: follows torch.manual_seed, no device sync
+        return _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed)
+    n0, pos = _positive_keys(edge_index)
+    if n0 != n:
+        pos = torch.unique(edge_index[0] * n + edge_index[1])
     neg = None
     for _ in range(3):
         if population <= sample_size:

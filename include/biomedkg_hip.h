@@ -178,6 +178,23 @@ int bkg_rank_l1_filter_f32(const float* q, int64_t ldq, const float* zn, int64_t
                            const float* true_score, const int64_t* target, const int64_t* qptr, const int64_t* cand,
                            int64_t n_q, int32_t* gt, int32_t* eq, void* stream);
 
+/* ---- negative sampling of the KGE step (PyG negative_sampling + the permuted relation ids of
+ *      biomedkg/kge_module.py:86-102).  bkg_hashset_insert adds the keys hi[i]*n_lo + lo[i] to an open-addressing table
+ *      of uint64 (empty = ~0, capacity a power of two >= 2x the keys).  bkg_negative_sample: candidate c is pi(c), pi a
+ *      bijection of [0, N*N) keyed by seed (candidates are distinct by construction = random.sample); candidates
+ *      [first, first + n) that are not in pos_table are written, in candidate order, as (head, tail) pairs at
+ *      out_offset + rank while < max_out; *count (device) = survivors of this call.  Bitwise repeatable, no atomics.
+ *      keys_tmp / flag_tmp / offs_tmp: [n_candidates] scratch.  bkg_permute_gather_i64: out[i] = src[pi(i)], pi a keyed
+ *      bijection of [0, n) (x[randperm(n)] without the sort). */
+int bkg_hashset_insert(const int64_t* hi, const int64_t* lo, int64_t n_lo, int64_t n, uint64_t* table, int64_t capacity,
+                       void* stream);
+int64_t bkg_negative_sample_workspace_bytes(int64_t n_candidates);
+int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int64_t n_candidates, uint64_t seed,
+                        const uint64_t* pos_table, int64_t pos_capacity, uint64_t* keys_tmp, int32_t* flag_tmp,
+                        int32_t* offs_tmp, int64_t* out_head, int64_t* out_tail, int64_t out_offset, int64_t max_out,
+                        int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
+int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t seed, int64_t* out, void* stream);
+
 /* ---- modality fusion epilogues (biomedkg/utils/fusion.py:17-31 AttentionFusion, :49-90 ReDAF) */
 int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_t D, float* out, int64_t ldo,
                       void* stream);

@@ -161,7 +161,7 @@ def test_kge_loss_full_size(kg, kind):
     all_ei, all_et = torch.cat([ei, neg], 1), torch.cat([et, nt])
     label = torch.cat([torch.ones(E, dtype=torch.float64, device=DEV), torch.zeros(E, dtype=torch.float64, device=DEV)])
     ref_loss, ref_s = _kge_ref(kind, zd, rd, all_ei, all_et, label)
-    assert abs(float(loss) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
     torch.testing.assert_close(torch.cat([pos_s, neg_s]).double(), ref_s, rtol=1e-4, atol=1e-4 if kind == 0 else 1e-5)
     for got, want, name in ((z.grad, zd.grad, "dz"), (rel.grad, rd.grad, "drel")):
         err = float((got.double() - want).norm() / want.norm())
