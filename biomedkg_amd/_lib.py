@@ -67,6 +67,9 @@ SIGNATURES = {
     "bkg_rank_l1_true_f32": (I32, [P, I64, P, I64, P, I64, I32, P, P]),
     "bkg_rank_l1_count_f32": (I32, [P, I64, I64, P, I64, I64, I32, P, P, I32, P, P, P]),
     "bkg_rank_l1_filter_f32": (I32, [P, I64, P, I64, I32, P, P, P, P, I64, P, P, P]),
+    # colsum.hip
+    "bkg_colsum_workspace_floats": (I64, [I64, I32]),
+    "bkg_colsum_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),
     # negsample.hip
     "bkg_hashset_insert": (I32, [P, P, I64, I64, P, I64, P]),
     "bkg_negative_sample_workspace_bytes": (I64, [I64]),

@@ -1,0 +1,112 @@
+// Column sums of a tall activation / gradient table: the bias gradients `dOut.sum(0)` of every Linear / GCNConv /
+// RGCNConv backward (autograd of the `+ bias` in reference biomedkg/model/encoder.py:50-59,153-162, gcl.py:86-90).
+// One streaming pass at HBM rate over an fp32 or bf16 table (16 B per lane), per-block partial rows, then a second
+// tiny launch adds the partial rows in block order (plain stores: bitwise repeatable, no atomics).
+#include "common.h"
+#include "rowpiece.h"
+
+namespace bkg {
+
+constexpr int CS_MAX_BLOCKS = 512;
+
+// block = 256 threads = RPB row slots x PPR pieces per row; thread (slot, piece) walks rows slot, slot + RPB, ...
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t ldx, int64_t n, int d,
+                                                             int64_t rows_per_block, float* __restrict__ partial) {
+  constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL;
+  __shared__ float4 red[256 * Q];
+  const int ppr = d / EPL, rpb = 256 / ppr;             // pieces per row (<= 256), row slots per block
+  const int piece = threadIdx.x % ppr, slot = threadIdx.x / ppr;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, n);
+  float4 acc[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (slot < rpb) {
+    constexpr int U = 8;   // rows in flight per thread
+    int64_t r = r0 + slot;
+    for (; r + (U - 1) * rpb < r1; r += U * rpb) {
+      Piece<T> p[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) p[u].load(x + (r + (int64_t)u * rpb) * ldx + piece * EPL);
+#pragma unroll
+      for (int u = 0; u < U; ++u) p[u].fma(acc, 1.0f);
+    }
+    for (; r < r1; r += rpb) {
+      Piece<T> p;
+      p.load(x + r * ldx + piece * EPL);
+      p.fma(acc, 1.0f);
+    }
+  }
+  // add the row slots in slot order
+#pragma unroll
+  for (int q = 0; q < Q; ++q) red[threadIdx.x * Q + q] = acc[q];
+  __syncthreads();
+  if (slot == 0) {
+    for (int s = 1; s < rpb; ++s)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float4 v = red[(s * ppr + piece) * Q + q];
+        acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w;
+      }
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * d + piece * EPL + 4 * q) = acc[q];
+  }
+}
+
+// block = 8 row groups x 32 columns; group g adds partial rows g, g + 8, ... (8 loads in flight), then the groups are
+// added in group order through LDS
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int n_blocks, int d,
+                                                           float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s = 0.f;
+  if (c < d) {
+    int b = g;
+    for (; b + 56 < n_blocks; b += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + 8 * u) * d + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < n_blocks; b += 8) s += partial[(int64_t)b * d + c];
+  }
+  red[g][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (g == 0 && c < d) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+    out[c] = t;
+  }
+}
+
+}  // namespace bkg
+
+using namespace bkg;
+
+extern "C" int64_t bkg_colsum_workspace_floats(int64_t n, int32_t d) {
+  return (int64_t)std::min<int64_t>(CS_MAX_BLOCKS, std::max<int64_t>(1, (n + 63) / 64)) * d;
+}
+
+extern "C" int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, float* workspace,
+                              float* out, void* stream) {
+  const int epl = x_is_bf16 ? 8 : 4;
+  BKG_ARG(n >= 0 && d > 0 && d % epl == 0 && d / epl <= 256, "bkg_colsum_f32: d must be a multiple of the 16-byte piece, <= 256 pieces");
+  BKG_ARG((uintptr_t)x % 16 == 0 && ldx % epl == 0 && (uintptr_t)workspace % 16 == 0, "bkg_colsum_f32: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * d, s);
+    if (e != hipSuccess) { set_error("bkg_colsum_f32: memset", e); return (int)e; }
+    return 0;
+  }
+  const int n_blocks = (int)(bkg_colsum_workspace_floats(n, d) / d);
+  const int64_t rpb = (n + n_blocks - 1) / n_blocks;
+  if (x_is_bf16)
+    hipLaunchKernelGGL(colsum_partial_kernel<__bf16>, dim3(n_blocks), dim3(256), 0, s, (const __bf16*)x, ldx, n, d, rpb, workspace);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(n_blocks), dim3(256), 0, s, (const float*)x, ldx, n, d, rpb, workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, s, workspace, n_blocks, d, out);
+  return check_launch("bkg_colsum_f32");
+}

@@ -275,8 +275,8 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     // grid supplies the parallelism).  fp32 operands are MFMA-bound there and prefer more, smaller tiles.
     const bool big = (precision == 1 && M >= 128 && N >= 128) || tiles64 >= 64;
     const int64_t tiles = big ? ((M + 127) / 128) * ((N + 127) / 128) : tiles64;
-    int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 2048 / tiles));
-    int kchunk = (int)(((K + nsplit - 1) / nsplit + 63) / 64 * 64);   // whole staged K tiles (BKH = 64)
+    int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, (precision ? 768 : 2048) / tiles));   // bf16: ~3 blocks per CU = the tile's occupancy
+    int kchunk = (int)(((K + nsplit - 1) / nsplit + 63) / 64 * 64);   // whole staged K tiles
     nsplit = (K + kchunk - 1) / kchunk;
     hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
     if (e != hipSuccess) { set_error("bkg_gemm_f32: memset", e); return (int)e; }
@@ -333,7 +333,8 @@ extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, 
   if (rows_total == 0) return 0;
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   hipStream_t s = (hipStream_t)stream;
-  constexpr int BM = 128, BN = 128, KCHUNK = 512;  // rows per block: ~4x the CU count in blocks at S ~ 3e5
+  constexpr int BM = 128, BN = 128;
+  const int KCHUNK = precision ? 1024 : 512;   // rows per block (bf16 operands: fewer, longer blocks; measured)
   dim3 grid(xcd_grid(ceil_div(rows_total, KCHUNK) + G, ceil_div(M, BM) * ceil_div(N, BN))), block(256);
   if (precision) hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
   else hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<0, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);

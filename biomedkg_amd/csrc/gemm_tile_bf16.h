@@ -20,8 +20,8 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
-constexpr int BKH = 64;        // K per staged tile (four 16-deep MFMA steps)
-constexpr int LDH = BKH + 8;   // bf16 elements per LDS row (144 bytes)
+constexpr int BKH = 32;        // K per staged tile (two 16-deep MFMA steps): 80 VGPRs + 64 AGPRs -> 3 blocks per CU
+constexpr int LDH = BKH + 8;   // bf16 elements per LDS row (80 bytes)
 
 __device__ __forceinline__ float4 load4h(const float* __restrict__ base, int64_t ld, int r, int c, int R, int C,
                                          bool vec) {

@@ -130,6 +130,20 @@ def gemm_grouped_k(a, b, group_ptr, num_groups):
     return out
 
 
+def colsum(x):
+    """``x.sum(0)`` in fp32 for a tall fp32 / bf16 table (bias gradients): one streaming pass (csrc/colsum.hip)."""
+    L.require_cuda(x)
+    epl = 8 if x.dtype == torch.bfloat16 else 4
+    n, d = x.shape
+    if (x.dtype not in (torch.float32, torch.bfloat16) or x.stride(1) != 1 or d % epl or d // epl > 256
+            or x.stride(0) % epl or x.data_ptr() % 16):
+        return x.sum(0, dtype=torch.float32)
+    ws = torch.empty(L.lib().bkg_colsum_workspace_floats(n, d), dtype=torch.float32, device=x.device)
+    out = torch.empty(d, dtype=torch.float32, device=x.device)
+    L.call("bkg_colsum_f32", L.ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), n, d, L.ptr(ws), L.ptr(out), L.stream())
+    return out
+
+
 class Dropout:
     """Dropout request for a kernel epilogue: explicit keep mask (replay) or in-kernel Philox."""
 
@@ -243,7 +257,7 @@ class _Linear(torch.autograd.Function):
             dout = torch.where(out > 0, dout, dout * (out + 1.0))
         dx = gemm(dout, weight) if ctx.needs_input_grad[0] else None
         dw = gemm(dout, x, trans_a=True) if ctx.needs_input_grad[1] else None
-        db = dout.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = colsum(dout) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None
 
 
@@ -288,7 +302,7 @@ class _GcnConv(torch.autograd.Function):
         dxw = spmm(c.rowptr, c.col, gw.w_src, dout, g.num_nodes, self_w=gw.self_w, split=c.split)
         dx = gemm(dxw, weight) if ctx.needs_input_grad[0] else None
         dw = gemm(dxw, x, trans_a=True) if ctx.needs_input_grad[1] else None
-        db = dout.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        db = colsum(dout) if ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None, None, None
 
 
@@ -327,7 +341,7 @@ class _RgcnConv(torch.autograd.Function):
         dy = spmm(rg.seg_iota_ptr, rg.seg_dst, None, dout, rg.num_segments)          # dY[s] = dOut[dst_s]
         dweight = gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations) if ctx.needs_input_grad[1] else None
         droot = gemm(x, dout, trans_a=True) if ctx.needs_input_grad[2] else None
-        db = dout.sum(0) if ctx.needs_input_grad[3] else None
+        db = colsum(dout) if ctx.needs_input_grad[3] else None
         dx = None
         if ctx.needs_input_grad[0]:
             to16 = bf16_storage() and _bf16_ok(weight.size(1)) and _xw_ok(dy, dy.size(0), weight.size(1), weight.size(2))
@@ -371,7 +385,7 @@ class _SpmmFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dtable = spmm(ctx.bwd.rowptr, ctx.bwd.col, ctx.w_bwd, _table(dout), ctx.n_table, split=ctx.bwd.split)
         dadd = dout if ctx.needs_input_grad[1] else None
-        db = dout.sum(0) if ctx.needs_input_grad[2] else None
+        db = colsum(dout) if ctx.needs_input_grad[2] else None
         return dtable, dadd, db, None, None, None, None, None, None, None
 
 

@@ -178,6 +178,12 @@ int bkg_rank_l1_filter_f32(const float* q, int64_t ldq, const float* zn, int64_t
                            const float* true_score, const int64_t* target, const int64_t* qptr, const int64_t* cand,
                            int64_t n_q, int32_t* gt, int32_t* eq, void* stream);
 
+/* ---- bias gradients: out[c] = sum_i x[i, c] over an fp32 or bf16 table (autograd of the `+ bias` of every Linear /
+ *      GCNConv / RGCNConv on the path).  workspace: bkg_colsum_workspace_floats(n, d) floats. */
+int64_t bkg_colsum_workspace_floats(int64_t n, int32_t d);
+int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, float* workspace, float* out,
+                   void* stream);
+
 /* ---- negative sampling of the KGE step (PyG negative_sampling + the permuted relation ids of
  *      biomedkg/kge_module.py:86-102).  bkg_hashset_insert adds the keys hi[i]*n_lo + lo[i] to an open-addressing table
  *      of uint64 (empty = ~0, capacity a power of two >= 2x the keys).  bkg_negative_sample: candidate c is pi(c), pi a

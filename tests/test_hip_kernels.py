@@ -153,3 +153,17 @@ def test_rgcn_conv_fwd_bwd_vs_oracle():
     torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
     for got, exp in ((xd, xo), (wd, wo), (rd, ro), (bd, bo)):
         torch.testing.assert_close(got.grad.cpu(), exp.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,d", [(1, 8), (63, 16), (5000, 256), (130_001, 256), (3000, 768), (777, 2048), (500, 12)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum(n, d, dtype):
+    from biomedkg_amd import ops
+    torch.manual_seed(n)
+    x = torch.randn(n, d, device=DEV).to(dtype)
+    got = ops.colsum(x)
+    assert got.dtype == torch.float32
+    torch.testing.assert_close(got.double(), x.double().sum(0), rtol=1e-5, atol=1e-5 * n ** 0.5)
+    assert torch.equal(got, ops.colsum(x))                     # fixed summation order
+    v = torch.randn(n, 2 * d, device=DEV).to(dtype)[:, :d]     # strided rows
+    torch.testing.assert_close(ops.colsum(v).double(), v.double().sum(0), rtol=1e-5, atol=1e-5 * n ** 0.5)
