@@ -321,7 +321,9 @@ class _RgcnConv(torch.autograd.Function):
         n = rg.num_nodes
         h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, _table(x), rg.num_segments, tag="rgcn_segment_mean",
                  split=rg.seg_split)                                                  # [S, in]  segment means
-        y = gemm_grouped_rows(h, weight, rg.rel_ptr)                                  # [S, out] per-relation W_r
+        y16 = bf16_storage() and _bf16_ok(weight.size(2)) and _xw_ok(h, h.size(0), weight.size(2), weight.size(1))
+        y = gemm_grouped_rows(h, weight, rg.rel_ptr,                                  # [S, out] per-relation W_r; only
+                              out_dtype=torch.bfloat16 if y16 else torch.float32)     # read as a gather table
         xr = gemm(x, root)                                                            # [N, out] root term
         c = rg.dst_csr
         out = spmm(c.rowptr, c.col, None, y, n, addend=xr, bias=bias, relu=relu, drop=drop, split=c.split)
