@@ -136,17 +136,20 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, int64_t l
 }
 
 // PREC 0: exact fp32 (v_mfma_f32_32x32x2_f32); PREC 1: bf16 operands, fp32 accumulate (gemm_tile_bf16.h)
-template <int PREC, int BM, int BN, bool TA, bool TB>
-__device__ __forceinline__ void gemm_tile_any(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+template <int PREC, int BM, int BN, bool TA, bool TB, typename AT = float, typename BT = float>
+__device__ __forceinline__ void gemm_tile_any(const AT* __restrict__ A, int64_t lda, const BT* __restrict__ B,
                                               int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                               int m0, int n0, int kbeg, int kend, const GemmEpilogue& ep, bool vecA,
                                               bool vecB) {
   if constexpr (PREC == 0) gemm_tile<BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, kbeg, kend, ep, vecA, vecB);
-  else gemm_tile_bf16<BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, m0, n0, kbeg, kend, ep, vecA, vecB);
+  else gemm_tile_bf16<BM, BN, TA, TB, GemmEpilogue, AT, BT>(A, lda, B, ldb, C, ldc, M, N, m0, n0, kbeg, kend, ep, vecA, vecB);
 }
 
 __device__ __forceinline__ bool vec_ok(const float* p, int64_t ld) {
   return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 4 == 0);
+}
+__device__ __forceinline__ bool vec_ok(const __bf16* p, int64_t ld) {
+  return ((reinterpret_cast<uintptr_t>(p) & 7) == 0) && (ld % 4 == 0);
 }
 
 template <int PREC, int BM, int BN, bool TA, bool TB>
@@ -165,9 +168,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 // Split-K: blockIdx.y owns K range [y*kchunk, (y+1)*kchunk) and adds its tile into a zeroed C with
 // f32 atomics.  For the weight-gradient products dW = dY^T X (K = number of nodes, M x N = a few tiles).
-template <int PREC, int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const float* __restrict__ A, int64_t lda,
-                                                              const float* __restrict__ B, int64_t ldb,
+template <int PREC, int BM, int BN, bool TA, bool TB, typename AT = float, typename BT = float>
+__global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const AT* __restrict__ A, int64_t lda,
+                                                              const BT* __restrict__ B, int64_t ldb,
                                                               float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                               int kchunk, GemmEpilogue ep) {
   // the output tiles of one K chunk re-read the same operand strips: keep them on one XCD (see gemm_f32_kernel)
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const float* __res
   const int m0 = (t.inner / n_tiles) * BM, n0 = (t.inner % n_tiles) * BN;
   const int kbeg = t.outer * kchunk, kend = min(kbeg + kchunk, K);
   if (kbeg >= kend) return;
-  gemm_tile_any<PREC, BM, BN, TA, TB>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, kbeg, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
+  gemm_tile_any<PREC, BM, BN, TA, TB, AT, BT>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, kbeg, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
 }
 
 // C_g[rows of group g, :] = A_g @ op(B_g);  B_g = B + g * strideB.  Tiles never straddle groups.
@@ -210,9 +213,9 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_rows_kernel(const float*
 
 // C_g += A_g^T @ B_g over the rows of group g (K dimension = rows), split into chunks of KCHUNK
 // rows; C_g = C + g * strideC is [M = colsA, N = colsB] and must be zeroed by the caller.
-template <int PREC, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const float* __restrict__ A, int64_t lda,
-                                                                 const float* __restrict__ B, int64_t ldb,
+template <int PREC, int BM, int BN, typename AT = float, typename BT = float>
+__global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const AT* __restrict__ A, int64_t lda,
+                                                                 const BT* __restrict__ B, int64_t ldb,
                                                                  float* __restrict__ C, int64_t ldc, int64_t strideC,
                                                                  const int32_t* __restrict__ group_ptr, int G, int M,
                                                                  int N, int kchunk, GemmEpilogue ep) {
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const float* __
   const int tile = xs.inner;
   float* Cg = C + (int64_t)g * strideC;
   // op(A) = A^T: stored [K(rows), M] ; op(B) = B stored [K(rows), N]
-  gemm_tile_any<PREC, BM, BN, true, false>(A, lda, B, ldb, Cg, ldc, M, N, kend, (tile / n_tiles) * BM,
+  gemm_tile_any<PREC, BM, BN, true, false, AT, BT>(A, lda, B, ldb, Cg, ldc, M, N, kend, (tile / n_tiles) * BM,
                                            (tile % n_tiles) * BN, k0, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
 }
 
@@ -339,4 +342,47 @@ extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, 
   if (precision) hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
   else hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<0, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
   return check_launch("bkg_gemm_grouped_k_f32");
+}
+
+// ---- bf16-mode weight gradients with fp32 OR bf16 operands:  C[M,N] = A[K,M]^T B[K,N]  (split-K, f32 atomics)
+#define BKG_MIXED_DISPATCH(CALL)                                      \
+  if (a_is_bf16) { if (b_is_bf16) { CALL(__bf16, __bf16); } else { CALL(__bf16, float); } } \
+  else { if (b_is_bf16) { CALL(float, __bf16); } else { CALL(float, float); } }
+
+extern "C" int bkg_gemm_tn_bf16(int64_t M, int64_t N, int64_t K, const void* A, int32_t a_is_bf16, int64_t lda,
+                                const void* B, int32_t b_is_bf16, int64_t ldb, float* C, int64_t ldc, void* stream) {
+  BKG_ARG(M > 0 && N > 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "bkg_gemm_tn_bf16: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
+  if (e != hipSuccess) { set_error("bkg_gemm_tn_bf16: memset", e); return (int)e; }
+  if (K == 0) return 0;
+  GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 768 / tiles));
+  const int kchunk = (int)(((K + nsplit - 1) / nsplit + 63) / 64 * 64);
+  nsplit = (K + kchunk - 1) / kchunk;
+  dim3 grid(xcd_grid(nsplit, tiles)), block(256);
+#define BKG_TN(AT_, BT_)                                                                                             \
+  hipLaunchKernelGGL((gemm_f32_splitk_kernel<1, 128, 128, true, false, AT_, BT_>), grid, block, 0, s, (const AT_*)A, lda, \
+                     (const BT_*)B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep)
+  BKG_MIXED_DISPATCH(BKG_TN)
+#undef BKG_TN
+  return check_launch("bkg_gemm_tn_bf16");
+}
+
+extern "C" int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N, const void* A, int32_t a_is_bf16,
+                                       int64_t lda, const void* B, int32_t b_is_bf16, int64_t ldb, float* C, int64_t ldc,
+                                       int64_t strideC, const int32_t* group_ptr, int32_t G, void* stream) {
+  BKG_ARG(rows_total >= 0 && M > 0 && N > 0 && G > 0, "bkg_gemm_grouped_k_bf16: bad shape");
+  if (rows_total == 0) return 0;
+  GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int BM = 128, BN = 128, KCHUNK = 1024;
+  dim3 grid(xcd_grid(ceil_div(rows_total, KCHUNK) + G, ceil_div(M, BM) * ceil_div(N, BN))), block(256);
+#define BKG_GK(AT_, BT_)                                                                                            \
+  hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN, AT_, BT_>), grid, block, 0, s, (const AT_*)A, lda,      \
+                     (const BT_*)B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep)
+  BKG_MIXED_DISPATCH(BKG_GK)
+#undef BKG_GK
+  return check_launch("bkg_gemm_grouped_k_bf16");
 }

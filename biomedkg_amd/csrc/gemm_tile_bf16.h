@@ -39,22 +39,44 @@ __device__ __forceinline__ float4 load4h(const float* __restrict__ base, int64_t
   return v;
 }
 
+// the same 4 consecutive elements from a bf16 operand (8 bytes), widened to fp32 (exact)
+__device__ __forceinline__ float4 widen4(uint2 v) {
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 load4h(const __bf16* __restrict__ base, int64_t ld, int r, int c, int R, int C, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < R) {
+    const __bf16* p = base + (int64_t)r * ld + c;
+    if (vec && c + 3 < C) v = widen4(*reinterpret_cast<const uint2*>(p));
+    else {
+      if (c < C) v.x = (float)p[0];
+      if (c + 1 < C) v.y = (float)p[1];
+      if (c + 2 < C) v.z = (float)p[2];
+      if (c + 3 < C) v.w = (float)p[3];
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ float4 load4v(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4v(const __bf16* p) { return widen4(*reinterpret_cast<const uint2*>(p)); }
+
 // Stage a [BT rows][BKH k] operand tile.  CONTIG_IS_K: stored [tile rows, K] (k contiguous in HBM);
 // otherwise stored [K, tile rows] (tile dim contiguous) and transposed on the way into LDS.
-template <int BT, bool CONTIG_IS_K>
+template <int BT, bool CONTIG_IS_K, typename ST = float>
 struct StagerH {
   static constexpr int NV = (BT * BKH / 4) / 256;
   float4 reg[NV];
 
   // FULL: the tile is interior and 16-byte aligned -- plain vector loads, no bounds arithmetic in the K loop
   template <bool FULL>
-  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int t0, int k0, int T, int K,
+  __device__ __forceinline__ void load(const ST* __restrict__ base, int64_t ld, int t0, int k0, int T, int K,
                                        bool vec) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = threadIdx.x + i * 256;
       const int r = f / (BKH / 4), kc = f % (BKH / 4);
-      if constexpr (FULL) reg[i] = *reinterpret_cast<const float4*>(base + (int64_t)(t0 + r) * ld + (k0 + kc * 4));
+      if constexpr (FULL) reg[i] = load4v(base + (int64_t)(t0 + r) * ld + (k0 + kc * 4));
       else reg[i] = load4h(base, ld, t0 + r, k0 + kc * 4, T, K, vec);
     }
   }
@@ -75,14 +97,14 @@ struct StagerH {
 // {k..k+3} (one per row) -- 4x fewer LDS store instructions than element stores.  Lanes run over the 8 k-quads
 // fastest: a wave's ds_write_b64 then covers 16 banks x 2 half-rows at the 80-byte row stride, i.e. the
 // 4-cycle minimum of a 512-byte store, with no extra conflict.
-template <int BT>
-struct StagerH<BT, false> {
+template <int BT, typename ST>
+struct StagerH<BT, false, ST> {
   static constexpr int TASKS = (BT / 4) * (BKH / 4);         // 256 for BT = 128, 128 for BT = 64
   static constexpr int NT = (TASKS + 255) / 256;
   float4 reg[NT][4];
 
   template <bool FULL>
-  __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int t0, int k0, int T, int K,
+  __device__ __forceinline__ void load(const ST* __restrict__ base, int64_t ld, int t0, int k0, int T, int K,
                                        bool vec) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -91,7 +113,7 @@ struct StagerH<BT, false> {
       if (TASKS % 256 == 0 || f < TASKS) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if constexpr (FULL) reg[i][j] = *reinterpret_cast<const float4*>(base + (int64_t)(k0 + kq * 4 + j) * ld + (t0 + tc * 4));
+          if constexpr (FULL) reg[i][j] = load4v(base + (int64_t)(k0 + kq * 4 + j) * ld + (t0 + tc * 4));
           else reg[i][j] = load4h(base, ld, k0 + kq * 4 + j, t0 + tc * 4, K, T, vec);
         }
       }
@@ -118,8 +140,8 @@ struct StagerH<BT, false> {
   }
 };
 
-template <int BM, int BN, bool TA, bool TB, typename Epi>
-__device__ __forceinline__ void gemm_tile_bf16(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+template <int BM, int BN, bool TA, bool TB, typename Epi, typename AT = float, typename BT = float>
+__device__ __forceinline__ void gemm_tile_bf16(const AT* __restrict__ A, int64_t lda, const BT* __restrict__ B,
                                                int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int m0,
                                                int n0, int kbeg, int kend, const Epi& ep, bool vecA, bool vecB) {
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -141,8 +163,8 @@ __device__ __forceinline__ void gemm_tile_bf16(const float* __restrict__ A, int6
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  StagerH<BM, !TA> sa;   // A stored [M,K] unless TA
-  StagerH<BN, TB> sb;    // B stored [N,K] when TB (a Linear weight); [K,N] otherwise
+  StagerH<BM, !TA, AT> sa;   // A stored [M,K] unless TA
+  StagerH<BN, TB, BT> sb;    // B stored [N,K] when TB (a Linear weight); [K,N] otherwise
   auto k_loop = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     sa.template load<FULL>(A, lda, m0, kbeg, M, kend, vecA);

@@ -35,6 +35,7 @@ struct SpmmEpilogue {
   float drop_p;             // used when keep == null and drop_p > 0: in-kernel Philox mask
   uint64_t seed;
   uint32_t stream_id;
+  int out_bf16;             // 1: `out` is a bf16 [n_rows, ldo] table (a result only GEMMs / gathers read)
 };
 
 // One predicated batch of UT entries per lane group starting at e (entries >= end get weight 0 and a clamped,
@@ -163,7 +164,14 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
         a.x = r.x >= thresh ? a.x * scale : 0.f; a.y = r.y >= thresh ? a.y * scale : 0.f;
         a.z = r.z >= thresh ? a.z * scale : 0.f; a.w = r.w >= thresh ? a.w * scale : 0.f;
       }
-      *reinterpret_cast<float4*>(out + (int64_t)row * ldo + c) = a;
+      if (ep.out_bf16) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 h;
+        h[0] = (__bf16)a.x; h[1] = (__bf16)a.y; h[2] = (__bf16)a.z; h[3] = (__bf16)a.w;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (int64_t)row * ldo + c) = h;
+      } else {
+        *reinterpret_cast<float4*>(out + (int64_t)row * ldo + c) = a;
+      }
     }
 }
 
@@ -329,8 +337,8 @@ static bool dispatch_spmm(int d, const SpmmArgs<T>& a) {
 }  // namespace bkg
 
 extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const void* x,
-                                int32_t x_is_bf16, int64_t ldx, float* out, int64_t ldo, int64_t n_rows, int32_t d,
-                                const float* self_w, const float* addend, int64_t ld_add, const float* bias,
+                                int32_t x_is_bf16, int64_t ldx, void* out_, int32_t out_is_bf16, int64_t ldo,
+                                int64_t n_rows, int32_t d, const float* self_w, const float* addend, int64_t ld_add, const float* bias,
                                 int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
                                 uint32_t stream_id, const bkg_rowsplit* split, float* partials, void* stream) {
   using namespace bkg;
@@ -338,7 +346,8 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   BKG_ARG(drop_p >= 0.f && drop_p < 1.f, "bkg_spmm_csr_f32: drop_p must be in [0,1)");
   BKG_ARG(!split || partials, "bkg_spmm_csr_f32: row splitting needs a partials buffer");
   if (n_rows == 0) return 0;
-  SpmmEpilogue ep{self_w, bias, addend, ld_add, relu, keep, drop_p, seed, stream_id};
+  float* out = reinterpret_cast<float*>(out_);
+  SpmmEpilogue ep{self_w, bias, addend, ld_add, relu, keep, drop_p, seed, stream_id, out_is_bf16 ? 1 : 0};
   const int epl = x_is_bf16 ? 8 : 4;
   const bool vec_ok = (d % epl == 0) && (ldx % epl == 0) && (ldo % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % 16 == 0) &&
                       (!bias || ((uintptr_t)bias % 16 == 0)) && (!keep || ((uintptr_t)keep % 4 == 0)) &&
@@ -354,6 +363,7 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   } else {
     SpmmArgs<float> a{rowptr, col, w, (const float*)x, ldx, out, ldo, (int)n_rows, split, partials, ep, s};
     if (vec_ok) done = dispatch_spmm<float>(d, a);
+    BKG_ARG(done || !out_is_bf16, "bkg_spmm_csr_f32: a bf16 result needs a vector-width d and aligned rows");
     if (!done)
       hipLaunchKernelGGL(spmm_csr_f32_generic_kernel, dim3(ceil_div(n_rows, 4)), dim3(256), 0, s, rowptr, col, w,
                          (const float*)x, ldx, out, ldo, (int)n_rows, d, ep);

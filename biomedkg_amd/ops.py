@@ -62,6 +62,12 @@ def _xw_ok(a, m, n, k):
             (a.stride(0) * el) % 16 == 0 and a.data_ptr() % 16 == 0)
 
 
+def _bf16_operand_ok(rows, n, k):
+    """Would a contiguous bf16 ``[rows, k]`` table be accepted as the tall operand of an x-weight product with an
+    ``[n, k]`` weight?  (Decides whether a producer may emit its result in bf16 only.)"""
+    return _PRECISION == 1 and rows >= 1024 and n * k <= (1 << 22) and k % 256 == 0 and n % 32 == 0
+
+
 def _gemm_xw(a, wt, m, n, k, out, out_dtype, alpha, beta, bias, act, gate, gate_scale, group_ptr=None, groups=0):
     if out is None:
         out = torch.empty(m, n, dtype=out_dtype, device=a.device)
@@ -79,7 +85,8 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias
     bf16 operands / fp32 accumulate; tall ``a`` (fp32 or bf16) times a small weight ``b`` streams through
     ``bkg_gemm_xw`` and may write a bf16 ``out`` (``out_dtype``)."""
     L.require_cuda(a, b, out, bias, gate)
-    b = _f32c(b)
+    if b.dtype != torch.bfloat16:
+        b = _f32c(b)
     m, k = (a.size(1), a.size(0)) if trans_a else (a.size(0), a.size(1))
     k2, n = (b.size(1), b.size(0)) if trans_b else (b.size(0), b.size(1))
     if k != k2:
@@ -89,8 +96,18 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias
         if gate is not None:
             gate = _f32c(gate)
         return _gemm_xw(a, _weight_bf16(b, not trans_b), m, n, k, out, out_dtype, alpha, beta, bias, act, gate, gate_scale)
-    if out_dtype != torch.float32 or a.dtype != torch.float32:
-        raise TypeError("bf16 activations are only taken / produced by the bf16-mode activation-x-weight products")
+    plain = bias is None and act == ACT_NONE and gate is None and alpha == 1.0 and beta == 0.0
+    if (_PRECISION == 1 and trans_a and not trans_b and plain and out_dtype == torch.float32 and k >= 4096
+            and ((m + 63) // 64) * ((n + 63) // 64) <= 256 and a.stride(1) == 1):
+        # deep-K weight gradient dW = A^T B: split-K kernel, either operand may be a bf16 table
+        if out is None:
+            out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+        bb = b if b.stride(1) == 1 else b.contiguous()
+        L.call("bkg_gemm_tn_bf16", m, n, k, L.ptr(a), int(a.dtype == torch.bfloat16), a.stride(0), L.ptr(bb),
+               int(bb.dtype == torch.bfloat16), bb.stride(0), L.ptr(out), out.stride(0), L.stream())
+        return out
+    if out_dtype != torch.float32 or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise TypeError("bf16 activations are only taken / produced by the bf16-mode tall products")
     a = _f32c(a)
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
@@ -122,9 +139,15 @@ def gemm_grouped_rows(a, b, group_ptr, trans_b=False, out_dtype=torch.float32):
 def gemm_grouped_k(a, b, group_ptr, num_groups):
     """``out[g] = a[rows of g]^T @ b[rows of g]`` -> ``[G, a.cols, b.cols]`` (split-K, f32 atomics)."""
     L.require_cuda(a, b, group_ptr)
-    a, b = _f32c(a), _f32c(b)
     m, n = a.size(1), b.size(1)
     out = torch.zeros(num_groups, m, n, dtype=torch.float32, device=a.device)
+    if _PRECISION == 1:
+        a = a if a.stride(1) == 1 else a.contiguous()
+        b = b if b.stride(1) == 1 else b.contiguous()
+        L.call("bkg_gemm_grouped_k_bf16", a.size(0), m, n, L.ptr(a), int(a.dtype == torch.bfloat16), a.stride(0), L.ptr(b),
+               int(b.dtype == torch.bfloat16), b.stride(0), L.ptr(out), n, m * n, L.ptr(group_ptr), num_groups, L.stream())
+        return out
+    a, b = _f32c(a), _f32c(b)
     L.call("bkg_gemm_grouped_k_f32", a.size(0), m, n, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), n,
            m * n, L.ptr(group_ptr), num_groups, _PRECISION, L.stream())
     return out
@@ -183,7 +206,7 @@ def bf16_storage() -> bool:
 
 
 def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=False, drop: Dropout = None, tag=None,
-         split=None):
+         split=None, out_dtype=torch.float32):
     """``out[i] = epi(sum_k w[k] x[col[k]] (+ self_w[i] x[i]) (+ addend[i]))`` (csrc/spmm.hip).
     ``x`` is an fp32 or a bf16 table; the result is fp32."""
     L.require_cuda(rowptr, col, w, x, self_w, addend, bias)
@@ -193,7 +216,7 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
         x = _f32c(x)
     is_bf16 = int(x.dtype == torch.bfloat16)
     d = x.size(1)
-    out = torch.empty(n_rows, d, dtype=torch.float32, device=x.device)
+    out = torch.empty(n_rows, d, dtype=out_dtype, device=x.device)
     keep, p, seed, sid = None, 0.0, 0, 0
     if drop is not None and drop.p > 0.0:
         p, seed, sid = drop.p, drop.seed, drop.stream_id
@@ -209,7 +232,7 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
         ev0.record()
     partials = split.partials(d, x.device) if split is not None else None
     L.call("bkg_spmm_csr_f32", L.ptr(rowptr), L.ptr(col), L.ptr(w), L.ptr(x), is_bf16, x.stride(0), L.ptr(out),
-           out.stride(0), n_rows, d, L.ptr(self_w), L.ptr(addend), addend.stride(0) if addend is not None else 0,
+           int(out_dtype == torch.bfloat16), out.stride(0), n_rows, d, L.ptr(self_w), L.ptr(addend), addend.stride(0) if addend is not None else 0,
            L.ptr(bias), int(relu), L.ptr(keep), p, seed, sid, L.sref(split.c if split is not None else None),
            L.ptr(partials), L.stream())
     if timing:
@@ -299,7 +322,12 @@ class _GcnConv(torch.autograd.Function):
         elif ctx.gated:
             dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
         c = g.by_src
-        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, g.num_nodes, self_w=gw.self_w, split=c.split)
+        # dXW feeds only the two products below: keep it as a bf16 table when both can take one
+        n_rows, d_out, d_in = g.num_nodes, weight.size(0), weight.size(1)
+        to16 = (bf16_storage() and _bf16_ok(d_out) and n_rows >= 4096 and ((d_out + 63) // 64) * ((d_in + 63) // 64) <= 256
+                and (not ctx.needs_input_grad[0] or _bf16_operand_ok(n_rows, d_in, d_out)))
+        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_rows, self_w=gw.self_w, split=c.split,
+                   out_dtype=torch.bfloat16 if to16 else torch.float32)
         dx = gemm(dxw, weight) if ctx.needs_input_grad[0] else None
         dw = gemm(dxw, x, trans_a=True) if ctx.needs_input_grad[1] else None
         db = colsum(dout) if ctx.needs_input_grad[2] else None
@@ -319,8 +347,9 @@ class _RgcnConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop):
         n = rg.num_nodes
+        h16 = bf16_storage() and _bf16_ok(x.size(1)) and _bf16_operand_ok(rg.num_segments, weight.size(2), weight.size(1))
         h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, _table(x), rg.num_segments, tag="rgcn_segment_mean",
-                 split=rg.seg_split)                                                  # [S, in]  segment means
+                 split=rg.seg_split, out_dtype=torch.bfloat16 if h16 else torch.float32)   # [S, in]  segment means
         y16 = bf16_storage() and _bf16_ok(weight.size(2)) and _xw_ok(h, h.size(0), weight.size(2), weight.size(1))
         y = gemm_grouped_rows(h, weight, rg.rel_ptr,                                  # [S, out] per-relation W_r; only
                               out_dtype=torch.bfloat16 if y16 else torch.float32)     # read as a gather table
@@ -340,7 +369,10 @@ class _RgcnConv(torch.autograd.Function):
         dout = _f32c(dout)
         if ctx.gated:
             dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
-        dy = spmm(rg.seg_iota_ptr, rg.seg_dst, None, dout, rg.num_segments)          # dY[s] = dOut[dst_s]
+        dy16 = (bf16_storage() and _bf16_ok(dout.size(1)) and
+                (not ctx.needs_input_grad[0] or _bf16_operand_ok(rg.num_segments, weight.size(1), weight.size(2))))
+        dy = spmm(rg.seg_iota_ptr, rg.seg_dst, None, dout, rg.num_segments,           # dY[s] = dOut[dst_s]; read by
+                  out_dtype=torch.bfloat16 if dy16 else torch.float32)                # the two products below only
         dweight = gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations) if ctx.needs_input_grad[1] else None
         droot = gemm(x, dout, trans_a=True) if ctx.needs_input_grad[2] else None
         db = colsum(dout) if ctx.needs_input_grad[3] else None

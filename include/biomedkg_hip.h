@@ -71,7 +71,8 @@ int bkg_rowsplit_build(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int32
  *      bkg_cast_f32_bf16 makes such a table: dst = bf16(gate ? (gate > 0 ? src * gate_scale : 0) : src), n % 8 == 0. */
 int bkg_cast_f32_bf16(const float* src, const float* gate, float gate_scale, void* dst, int64_t n, void* stream);
 int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const void* x, int32_t x_is_bf16,
-                     int64_t ldx, float* out, int64_t ldo, int64_t n_rows, int32_t d, const float* self_w, const float* addend,
+                     int64_t ldx, void* out /* fp32, or bf16 when out_is_bf16: a result only GEMMs / gathers read */,
+                     int32_t out_is_bf16, int64_t ldo, int64_t n_rows, int32_t d, const float* self_w, const float* addend,
                      int64_t ld_add, const float* bias, int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
                      uint32_t stream_id, const bkg_rowsplit* split, float* partials, void* stream);
 
@@ -84,6 +85,14 @@ int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, 
 int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
                  int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc, const float* bias,
                  int32_t act, const float* gate, int64_t ldg, float gate_scale, int32_t precision, void* stream);
+/* bf16-mode weight gradients with fp32 or bf16 operands (gradients / activations kept as bf16 tables by the producing
+ * kernel): C[M,N] = A[K,M]^T B[K,N] split over K with f32 atomics (C is zeroed inside), and its grouped form
+ * C[g] += A[rows g]^T B[rows g] (C zeroed by the caller).  bf16 MFMA operands, fp32 accumulate / result. */
+int bkg_gemm_tn_bf16(int64_t M, int64_t N, int64_t K, const void* A, int32_t a_is_bf16, int64_t lda, const void* B,
+                     int32_t b_is_bf16, int64_t ldb, float* C, int64_t ldc, void* stream);
+int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N, const void* A, int32_t a_is_bf16, int64_t lda,
+                            const void* B, int32_t b_is_bf16, int64_t ldb, float* C, int64_t ldc, int64_t strideC,
+                            const int32_t* group_ptr, int32_t G, void* stream);
 /* bf16-mode streaming form of the tall "activation x small weight" products (GCNConv.lin, heads, RGCNConv root and
  * per-relation weights; forward and input gradient): C[M,N] = epi(alpha * A[M,K] @ Wt[N,K]^T).  A is fp32 or bf16
  * (a_is_bf16), Wt is the bf16 [N, K] image made by bkg_weight_to_bf16 (out[b] = bf16(W[b]) or bf16(W[b]^T), W[b] =

@@ -156,3 +156,42 @@ def test_gemm_xw_epilogues_and_groups():
         torch.testing.assert_close(dh[sl].double(), h[sl].bfloat16().double() @ wbig[i].bfloat16().double().t(),
                                    rtol=2 ** -7, atol=2e-2)
         o += sz
+
+
+def test_spmm_bf16_result_is_the_rounded_fp32_result():
+    from biomedkg_amd import graph as G, ops
+    n, e, d = 3000, 90_000, 256
+    g = torch.Generator().manual_seed(4)
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    gr = G.Graph(ei, n)
+    gw = gr.gcn_weights()
+    x = torch.randn(n, d, device=DEV)
+    bias = torch.randn(d, device=DEV)
+    c = gr.by_dst
+    for table in (x, ops.to_bf16(x)):
+        ref = ops.spmm(c.rowptr, c.col, gw.w_dst, table, n, self_w=gw.self_w, bias=bias, relu=True, split=c.split)
+        got = ops.spmm(c.rowptr, c.col, gw.w_dst, table, n, self_w=gw.self_w, bias=bias, relu=True, split=c.split,
+                       out_dtype=torch.bfloat16)
+        assert got.dtype == torch.bfloat16
+        assert torch.equal(got, ref.bfloat16())
+
+
+@pytest.mark.parametrize("a16,b16", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 20_000), (256, 768, 9_001), (96, 40, 5_000)])
+def test_weight_gradient_products_with_bf16_tables(a16, b16, m, n, k):
+    from biomedkg_amd import ops
+    torch.manual_seed(k)
+    a, b = torch.randn(k, m, device=DEV), torch.randn(k, n, device=DEV)
+    aa, bb = (a.bfloat16() if a16 else a), (b.bfloat16() if b16 else b)
+    ref = a.bfloat16().double().t() @ b.bfloat16().double()
+    out = ops.gemm(aa, bb, trans_a=True)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-4, atol=1e-3 * k ** 0.5)
+    sizes = [0, 1300, 1, 0, 2600, 64, k - 3965]
+    gptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=DEV)
+    dw = ops.gemm_grouped_k(aa, bb, gptr, len(sizes))
+    o = 0
+    for i, sz in enumerate(sizes):
+        sl = slice(o, o + sz)
+        torch.testing.assert_close(dw[i].double(), a[sl].bfloat16().double().t() @ b[sl].bfloat16().double(),
+                                   rtol=1e-4, atol=1e-3 * max(sz, 1) ** 0.5)
+        o += sz
