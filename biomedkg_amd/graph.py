@@ -114,11 +114,15 @@ class Graph:
         self.by_dst = CSR(self.dst, self.src, num_nodes)   # rows = targets, col = sources  (forward)
         self.by_src = CSR(self.src, self.dst, num_nodes)   # rows = sources, col = targets  (backward)
         self._plain = None
+        self._kept = None
 
     def gcn_weights(self, keep=None) -> GcnWeights:
         """``keep``: optional uint8/bool ``[E]`` dropout_edge mask in original edge order."""
         if keep is None and self._plain is not None:
             return self._plain
+        if keep is not None and self._kept is not None and self._kept[0] is keep and self._kept[1] == keep._version:
+            return self._kept[2]      # every layer (and both GGD views) of a step passes the same mask tensor
+        keep_in = keep
         dev = self.edge_index.device
         if keep is not None:
             keep = keep.to(torch.uint8).contiguous()
@@ -131,6 +135,8 @@ class Graph:
         out = GcnWeights(self.by_dst.permute_f32(w_edge), self.by_src.permute_f32(w_edge), self_w)
         if keep is None:
             self._plain = out
+        else:
+            self._kept = (keep_in, keep_in._version, out)
         return out
 
 
