@@ -211,7 +211,8 @@ def main():
         gbs = rec["bytes"] / (avg_ms * 1e-3) / 1e9
         table = "bf16 table: spmm_items_kernel<__bf16,32,1>" if args.precision == "bf16" else \
             "fp32 table: spmm_items_kernel<float,64,1>"
-        roof = {"bound": "hbm", "kernel": f"{table} + fixup (R-GCN segment-mean aggregate, d={h}, fp32 accumulate/out)",
+        roof = {"bound": "hbm", "kernel": f"{table} + fixup (R-GCN segment-mean aggregate, d={h}, fp32 accumulate, "
+                                            f"{'bf16' if args.precision == 'bf16' else 'fp32'} result)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(rel_graph_of(ei, et, n, r), args.precision), "avg_launch_ms": avg_ms,
                 "launches": len(durs),
@@ -229,8 +230,9 @@ def main():
             "value": world * e / (ms * 1e-3), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
-            "dtype_note": ("matrix-core operands bf16 (rounded while staged into LDS), fp32 accumulate; activations, "
-                           "aggregation, scorer and optimizer state fp32" if args.precision == "bf16"
+            "dtype_note": ("bf16 storage / fp32 accumulate: matrix-core operands, gather tables and the intermediates "
+                           "that only feed products are bf16; every accumulation, layer outputs, scorer, losses, "
+                           "weights, gradients and optimizer state are fp32" if args.precision == "bf16"
                            else "exact fp32 everywhere (fp32-input MFMA)"),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] shape: synthetic PrimeKG++-like graph per GPU, "

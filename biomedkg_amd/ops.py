@@ -181,10 +181,10 @@ class Dropout:
 KERNEL_TIMERS = None
 
 
-def _spmm_bytes(nnz, n_rows, d, has_w, elem=4):
+def _spmm_bytes(nnz, n_rows, d, has_w, elem=4, out_elem=4):
     """Algorithmic bytes of one launch: gathered row (fp32 or bf16 table) + int32 index
-    (+ fp32 weight) per entry, stored fp32 row + int32 rowptr per output row."""
-    return nnz * (d * elem + 4 + (4 if has_w else 0)) + n_rows * (d * 4 + 4)
+    (+ fp32 weight) per entry, stored row (fp32 or bf16) + int32 rowptr per output row."""
+    return nnz * (d * elem + 4 + (4 if has_w else 0)) + n_rows * (d * out_elem + 4)
 
 
 def to_bf16(x, gate=None, gate_scale=1.0):
@@ -238,7 +238,7 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
     if timing:
         ev1.record()
         rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None,
-                                                                             2 if is_bf16 else 4)})
+                                                                             2 if is_bf16 else 4, out.element_size())})
         rec["events"].append((ev0, ev1))
     return out
 
