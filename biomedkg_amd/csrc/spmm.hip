@@ -371,37 +371,59 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   return check_launch("bkg_spmm_csr_f32");
 }
 
-// ---- fp32 -> bf16 (RNE) copy of a gather table, optionally through the ReLU/dropout backward gate:
-//      dst = bf16( gate ? (gate > 0 ? src * scale : 0) : src )
+// ---- bf16 (RNE) gather table from an fp32 or bf16 source, optionally through the ReLU/dropout backward gate
+//      (gate = the layer's saved fp32 or bf16 OUTPUT):  dst = bf16( gate ? (gate > 0 ? src * scale : 0) : src )
 namespace bkg {
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, const float* __restrict__ gate,
+__device__ __forceinline__ void load8(const float* p, int64_t i, float (&v)[8]) {
+  const float4 a = reinterpret_cast<const float4*>(p)[2 * i], b = reinterpret_cast<const float4*>(p)[2 * i + 1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const __bf16* p, int64_t i, float (&v)[8]) {
+  const uint4 u = reinterpret_cast<const uint4*>(p)[i];
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+template <typename ST, typename GT>
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const ST* __restrict__ src, const GT* __restrict__ gate,
                                                         float scale, __bf16* __restrict__ dst, int64_t n8) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
-  float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+  float a[8];
+  load8(src, i, a);
   if (gate) {
-    const float4 ga = reinterpret_cast<const float4*>(gate)[2 * i], gb = reinterpret_cast<const float4*>(gate)[2 * i + 1];
-    a.x = ga.x > 0.f ? a.x * scale : 0.f; a.y = ga.y > 0.f ? a.y * scale : 0.f;
-    a.z = ga.z > 0.f ? a.z * scale : 0.f; a.w = ga.w > 0.f ? a.w * scale : 0.f;
-    b.x = gb.x > 0.f ? b.x * scale : 0.f; b.y = gb.y > 0.f ? b.y * scale : 0.f;
-    b.z = gb.z > 0.f ? b.z * scale : 0.f; b.w = gb.w > 0.f ? b.w * scale : 0.f;
+    float g[8];
+    load8(gate, i, g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = g[e] > 0.f ? a[e] * scale : 0.f;
   }
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   bf16x8 o;
-  o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
-  o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)a[e];
   reinterpret_cast<bf16x8*>(dst)[i] = o;
 }
 }  // namespace bkg
 
+extern "C" int bkg_gate_cast_bf16(const void* src, int32_t src_is_bf16, const void* gate, int32_t gate_is_bf16,
+                                  float gate_scale, void* dst, int64_t n, void* stream) {
+  using namespace bkg;
+  BKG_ARG(n >= 0 && n % 8 == 0, "bkg_gate_cast_bf16: element count must be a multiple of 8");
+  BKG_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && (!gate || (uintptr_t)gate % 16 == 0),
+          "bkg_gate_cast_bf16: 16-byte alignment");
+  if (n == 0) return 0;
+  dim3 grid(ceil_div(n / 8, 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define BKG_CAST(ST, GT) hipLaunchKernelGGL((cast_bf16_kernel<ST, GT>), grid, block, 0, s, (const ST*)src, (const GT*)gate, gate_scale, (__bf16*)dst, n / 8)
+  if (src_is_bf16) { if (gate_is_bf16) BKG_CAST(__bf16, __bf16); else BKG_CAST(__bf16, float); }
+  else { if (gate_is_bf16) BKG_CAST(float, __bf16); else BKG_CAST(float, float); }
+#undef BKG_CAST
+  return check_launch("bkg_gate_cast_bf16");
+}
+
 extern "C" int bkg_cast_f32_bf16(const float* src, const float* gate, float gate_scale, void* dst, int64_t n,
                                  void* stream) {
-  using namespace bkg;
-  BKG_ARG(n >= 0 && n % 8 == 0, "bkg_cast_f32_bf16: element count must be a multiple of 8");
-  BKG_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && (!gate || (uintptr_t)gate % 16 == 0),
-          "bkg_cast_f32_bf16: 16-byte alignment");
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3(ceil_div(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, gate,
-                     gate_scale, (__bf16*)dst, n / 8);
-  return check_launch("bkg_cast_f32_bf16");
+  return bkg_gate_cast_bf16(src, 0, gate, 0, gate_scale, dst, n, stream);
 }

@@ -36,9 +36,10 @@ class GCNConv(torch.nn.Module):
         _glorot(self.lin.weight)
         torch.nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index, edge_keep=None, relu=False, drop=None):
+    def forward(self, x, edge_index, edge_keep=None, relu=False, drop=None, hidden=False):
         g = graph_of(edge_index, x.size(0))
-        return ops.gcn_conv(x, self.lin.weight, self.bias, g, g.gcn_weights(edge_keep), relu=relu, drop=drop)
+        return ops.gcn_conv(x, self.lin.weight, self.bias, g, g.gcn_weights(edge_keep), relu=relu, drop=drop,
+                            hidden=hidden)
 
 
 class RGCNConv(torch.nn.Module):
@@ -57,9 +58,9 @@ class RGCNConv(torch.nn.Module):
         _glorot(self.root)
         torch.nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index, edge_type, relu=False, drop=None):
+    def forward(self, x, edge_index, edge_type, relu=False, drop=None, hidden=False):
         rg = rel_graph_of(edge_index, edge_type, x.size(0), self.num_relations)
-        return ops.rgcn_conv(x, self.weight, self.root, self.bias, rg, relu=relu, drop=drop)
+        return ops.rgcn_conv(x, self.weight, self.root, self.bias, rg, relu=relu, drop=drop, hidden=hidden)
 
 
 class _Stack(torch.nn.Module):
@@ -86,7 +87,8 @@ class _Stack(torch.nn.Module):
                 drop = None
                 if self.drop_out and self.training:
                     drop = _rand.current().dropout((x.size(0), layer.out_channels), 0.2, x.device)
-                x = layer(x, *graph, relu=True, drop=drop, **kw)
+                # hidden=True: in bf16 mode the activation between two conv layers is kept as a bf16 table (ops.py)
+                x = layer(x, *graph, relu=True, drop=drop, hidden=True, **kw)
         return x
 
 

@@ -188,15 +188,22 @@ def _spmm_bytes(nnz, n_rows, d, has_w, elem=4, out_elem=4):
 
 
 def to_bf16(x, gate=None, gate_scale=1.0):
-    """bf16 gather table of ``x`` (csrc/spmm.hip ``bkg_cast_f32_bf16``), optionally through the
-    ReLU/dropout backward gate ``gate > 0 ? x * gate_scale : 0``."""
+    """bf16 gather table of ``x`` (csrc/spmm.hip ``bkg_gate_cast_bf16``), optionally through the ReLU/dropout
+    backward gate ``gate > 0 ? x * gate_scale : 0``.  ``x`` and ``gate`` may each be fp32 or bf16."""
     L.require_cuda(x, gate)
-    x = _f32c(x)
+    if x.dtype == torch.bfloat16 and gate is None:
+        return x if x.is_contiguous() else x.contiguous()
+    x = x if x.is_contiguous() else x.contiguous()
+    if gate is not None:
+        gate = gate if gate.is_contiguous() else gate.contiguous()
+    for t in (x, gate):
+        if t is not None and t.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"expected float32 / bfloat16, got {t.dtype}")
     if x.numel() % 8:
         raise ValueError("to_bf16 needs a multiple of 8 elements")
     out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    L.call("bkg_cast_f32_bf16", L.ptr(x), L.ptr(_f32c(gate) if gate is not None else None), gate_scale, L.ptr(out),
-           x.numel(), L.stream())
+    L.call("bkg_gate_cast_bf16", L.ptr(x), int(x.dtype == torch.bfloat16), L.ptr(gate),
+           int(gate is not None and gate.dtype == torch.bfloat16), gate_scale, L.ptr(out), x.numel(), L.stream())
     return out
 
 
@@ -292,19 +299,34 @@ def linear(x, weight, bias=None, act=ACT_NONE):
 
 
 # ----------------------------------------------------------------------------- GCNConv
+def _hidden_bf16_ok(n_rows, d):
+    """bf16 mode keeps HIDDEN layer outputs (everything between two conv layers) as bf16 tables: each is only ever
+    an MFMA operand, a gather table or the sign gate of the backward, all of which round it to bf16 anyway."""
+    return bf16_storage() and n_rows >= 4096 and d % 256 == 0 and _bf16_ok(d)
+
+
+def _as_f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
 class _GcnConv(torch.autograd.Function):
     """``dropout(relu(A_hat (x W^T) + b))`` -- PyG GCNConv + the encoder's ReLU/dropout
-    (reference biomedkg/model/encoder.py:153-162) fused into the aggregation epilogue."""
+    (reference biomedkg/model/encoder.py:153-162) fused into the aggregation epilogue.  ``x`` is fp32 or (a hidden
+    activation of the bf16 mode) bf16; ``hidden`` asks for a bf16 result."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, graph: Graph, gw: GcnWeights, relu, drop):
-        if bf16_storage() and _bf16_ok(weight.size(0)) and _xw_ok(x, x.size(0), weight.size(0), weight.size(1)):
+    def forward(ctx, x, weight, bias, graph: Graph, gw: GcnWeights, relu, drop, hidden):
+        n_rows, d_out, d_in = graph.num_nodes, weight.size(0), weight.size(1)
+        if x.dtype == torch.bfloat16 and not _xw_ok(x, n_rows, d_out, d_in):
+            x = x.float()                      # shapes the streaming product does not take: widen once
+        if bf16_storage() and _bf16_ok(d_out) and _xw_ok(x, n_rows, d_out, d_in):
             xw = gemm(x, weight, trans_b=True, out_dtype=torch.bfloat16)   # only ever read as the gather table
         else:
             xw = _table(gemm(x, weight, trans_b=True))
         c = graph.by_dst
-        out = spmm(c.rowptr, c.col, gw.w_dst, xw, graph.num_nodes, self_w=gw.self_w, bias=bias, relu=relu, drop=drop,
-                   tag="gcn_propagate", split=c.split)
+        out16 = hidden and _hidden_bf16_ok(n_rows, d_out)
+        out = spmm(c.rowptr, c.col, gw.w_dst, xw, n_rows, self_w=gw.self_w, bias=bias, relu=relu, drop=drop,
+                   tag="gcn_propagate", split=c.split, out_dtype=torch.bfloat16 if out16 else torch.float32)
         ctx.graph, ctx.gw, ctx.relu = graph, gw, relu
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
@@ -315,47 +337,69 @@ class _GcnConv(torch.autograd.Function):
     def backward(ctx, dout):
         x, weight, out = ctx.saved_tensors
         g, gw = ctx.graph, ctx.gw
-        dout = _f32c(dout)
+        dout = dout if dout.is_contiguous() else dout.contiguous()
         if bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(dout.size(1)):
             # gate + bf16 gather table in one pass over dOut (no fp32 gated copy is ever written)
             dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
         elif ctx.gated:
+            dout, out = _as_f32(dout), _as_f32(out)
             dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
+        else:
+            dout = _as_f32(dout)
         c = g.by_src
         # dXW feeds only the two products below: keep it as a bf16 table when both can take one
         n_rows, d_out, d_in = g.num_nodes, weight.size(0), weight.size(1)
+        x16 = x.dtype == torch.bfloat16
         to16 = (bf16_storage() and _bf16_ok(d_out) and n_rows >= 4096 and ((d_out + 63) // 64) * ((d_in + 63) // 64) <= 256
                 and (not ctx.needs_input_grad[0] or _bf16_operand_ok(n_rows, d_in, d_out)))
         dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_rows, self_w=gw.self_w, split=c.split,
                    out_dtype=torch.bfloat16 if to16 else torch.float32)
-        dx = gemm(dxw, weight) if ctx.needs_input_grad[0] else None
-        dw = gemm(dxw, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if x16 and _xw_ok(dxw, n_rows, d_in, d_out):
+                dx = gemm(dxw, weight, out_dtype=torch.bfloat16)     # the gradient of a bf16 activation is bf16
+            else:
+                dx = gemm(dxw, weight).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            if (x16 or dxw.dtype == torch.bfloat16) and n_rows < 4096:
+                dw = gemm(_as_f32(dxw), _as_f32(x), trans_a=True)
+            else:
+                dw = gemm(dxw, x, trans_a=True)
+        else:
+            dw = None
         db = colsum(dout) if ctx.needs_input_grad[2] else None
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def gcn_conv(x, weight, bias, graph, gw, relu=False, drop=None):
+def gcn_conv(x, weight, bias, graph, gw, relu=False, drop=None, hidden=False):
     L.require_cuda(x, weight, bias)
-    return _GcnConv.apply(_f32c(x), weight, bias, graph, gw, relu, drop)
+    if x.dtype != torch.bfloat16:
+        x = _f32c(x)
+    return _GcnConv.apply(x, weight, bias, graph, gw, relu, drop, hidden)
 
 
 # ----------------------------------------------------------------------------- RGCNConv
 class _RgcnConv(torch.autograd.Function):
     """``dropout(relu(sum_r mean_{N_r(i)}(x_j) W_r + x_i W_root + b))`` -- PyG RGCNConv
-    + the encoder's ReLU/dropout (reference biomedkg/model/encoder.py:50-59)."""
+    + the encoder's ReLU/dropout (reference biomedkg/model/encoder.py:50-59).  ``x`` is fp32 or (a hidden activation
+    of the bf16 mode) bf16; ``hidden`` asks for a bf16 result."""
 
     @staticmethod
-    def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop):
-        n = rg.num_nodes
-        h16 = bf16_storage() and _bf16_ok(x.size(1)) and _bf16_operand_ok(rg.num_segments, weight.size(2), weight.size(1))
+    def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop, hidden):
+        n, d_in, d_out = rg.num_nodes, weight.size(1), weight.size(2)
+        if x.dtype == torch.bfloat16 and not _xw_ok(x, n, d_out, d_in):
+            x = x.float()
+        h16 = bf16_storage() and _bf16_ok(d_in) and _bf16_operand_ok(rg.num_segments, d_out, d_in)
         h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, _table(x), rg.num_segments, tag="rgcn_segment_mean",
                  split=rg.seg_split, out_dtype=torch.bfloat16 if h16 else torch.float32)   # [S, in]  segment means
-        y16 = bf16_storage() and _bf16_ok(weight.size(2)) and _xw_ok(h, h.size(0), weight.size(2), weight.size(1))
+        y16 = bf16_storage() and _bf16_ok(d_out) and _xw_ok(h, h.size(0), d_out, d_in)
         y = gemm_grouped_rows(h, weight, rg.rel_ptr,                                  # [S, out] per-relation W_r; only
                               out_dtype=torch.bfloat16 if y16 else torch.float32)     # read as a gather table
         xr = gemm(x, root)                                                            # [N, out] root term
         c = rg.dst_csr
-        out = spmm(c.rowptr, c.col, None, y, n, addend=xr, bias=bias, relu=relu, drop=drop, split=c.split)
+        out16 = hidden and _hidden_bf16_ok(n, d_out)
+        out = spmm(c.rowptr, c.col, None, y, n, addend=xr, bias=bias, relu=relu, drop=drop, split=c.split,
+                   out_dtype=torch.bfloat16 if out16 else torch.float32)
         ctx.rg, ctx.relu = rg, relu
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
@@ -366,30 +410,49 @@ class _RgcnConv(torch.autograd.Function):
     def backward(ctx, dout):
         x, weight, root, h, out = ctx.saved_tensors
         rg = ctx.rg
-        dout = _f32c(dout)
-        if ctx.gated:
-            dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
-        dy16 = (bf16_storage() and _bf16_ok(dout.size(1)) and
-                (not ctx.needs_input_grad[0] or _bf16_operand_ok(rg.num_segments, weight.size(1), weight.size(2))))
+        n, d_in, d_out = rg.num_nodes, weight.size(1), weight.size(2)
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        if (bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(d_out) and n >= 4096
+                and _bf16_operand_ok(n, d_in, d_out)):
+            # gated dOut as one bf16 table: gather table of dY, operand of the root products, source of db
+            dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
+        else:
+            dout = _as_f32(dout)
+            if ctx.gated:
+                out = _as_f32(out)
+                dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
+        dy16 = (bf16_storage() and _bf16_ok(d_out) and
+                (not ctx.needs_input_grad[0] or _bf16_operand_ok(rg.num_segments, d_in, d_out)))
         dy = spmm(rg.seg_iota_ptr, rg.seg_dst, None, dout, rg.num_segments,           # dY[s] = dOut[dst_s]; read by
                   out_dtype=torch.bfloat16 if dy16 else torch.float32)                # the two products below only
         dweight = gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations) if ctx.needs_input_grad[1] else None
-        droot = gemm(x, dout, trans_a=True) if ctx.needs_input_grad[2] else None
+        droot = None
+        if ctx.needs_input_grad[2]:
+            if n < 4096 and (x.dtype == torch.bfloat16 or dout.dtype == torch.bfloat16):
+                droot = gemm(_as_f32(x), _as_f32(dout), trans_a=True)
+            else:
+                droot = gemm(x, dout, trans_a=True)
         db = colsum(dout) if ctx.needs_input_grad[3] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            to16 = bf16_storage() and _bf16_ok(weight.size(1)) and _xw_ok(dy, dy.size(0), weight.size(1), weight.size(2))
+            to16 = bf16_storage() and _bf16_ok(d_in) and _xw_ok(dy, dy.size(0), d_in, d_out)
             dh = gemm_grouped_rows(dy, weight, rg.rel_ptr, trans_b=True,
                                    out_dtype=torch.bfloat16 if to16 else torch.float32)   # [S, in], a gather table
             dx_root = gemm(dout, root, trans_b=True)                                  # [N, in]
             c = rg.src_csr
-            dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), rg.num_nodes, addend=dx_root, split=c.split)
-        return dx, dweight, droot, db, None, None, None
+            x16 = x.dtype == torch.bfloat16 and _bf16_ok(d_in)
+            dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), rg.num_nodes, addend=dx_root, split=c.split,
+                      out_dtype=torch.bfloat16 if x16 else torch.float32)
+            if dx.dtype != x.dtype:
+                dx = dx.to(x.dtype)
+        return dx, dweight, droot, db, None, None, None, None
 
 
-def rgcn_conv(x, weight, root, bias, rg, relu=False, drop=None):
+def rgcn_conv(x, weight, root, bias, rg, relu=False, drop=None, hidden=False):
     L.require_cuda(x, weight, root, bias)
-    return _RgcnConv.apply(_f32c(x), weight, root, bias, rg, relu, drop)
+    if x.dtype != torch.bfloat16:
+        x = _f32c(x)
+    return _RgcnConv.apply(x, weight, root, bias, rg, relu, drop, hidden)
 
 
 # ----------------------------------------------------------------------------- composable pieces

@@ -195,3 +195,39 @@ def test_weight_gradient_products_with_bf16_tables(a16, b16, m, n, k):
         torch.testing.assert_close(dw[i].double(), a[sl].bfloat16().double().t() @ b[sl].bfloat16().double(),
                                    rtol=1e-4, atol=1e-3 * max(sz, 1) ** 0.5)
         o += sz
+
+
+@pytest.mark.parametrize("kind", ["gcn", "rgcn"])
+def test_bf16_hidden_activations_track_the_fp32_encoder(kind):
+    """N >= 4096 and d % 256 == 0: the activations between conv layers are bf16 tables (ops._hidden_bf16_ok) and their
+    gradients flow back in bf16; loss and every parameter gradient stay within bf16 rounding of the exact-fp32 run."""
+    from biomedkg_amd import ops
+    from biomedkg_amd.model.encoder import GCNEncoder, RGCN
+    n, e, r, d = 6000, 90_000, 6, 256
+    g = torch.Generator().manual_seed(8)
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    et = torch.randint(0, r, (e,), generator=g).to(DEV)
+    x = torch.randn(n, 768, generator=g).to(DEV)
+    tgt = torch.randn(n, d, generator=g).to(DEV)
+    torch.manual_seed(0)
+    enc = (GCNEncoder(768, d, d, 2, drop_out=False) if kind == "gcn" else RGCN(768, d, d, 2, r, drop_out=False)).to(DEV)
+    args = (ei,) if kind == "gcn" else (ei, et)
+    seen = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: seen.append(out.dtype)) for m in enc.graph_layers]
+    res = {}
+    for mode in ("fp32", "bf16"):
+        ops.set_matmul_precision(mode)
+        seen.clear()
+        enc.zero_grad(set_to_none=True)
+        z = enc(x, *args)
+        loss = ((z - tgt) ** 2).mean()
+        loss.backward()
+        res[mode] = (float(loss.detach()), [p.grad.clone() for p in enc.parameters()], list(seen))
+    for h in hooks:
+        h.remove()
+    assert res["fp32"][2] == [torch.float32] * 4
+    assert res["bf16"][2] == [torch.bfloat16] * 3 + [torch.float32]
+    assert abs(res["bf16"][0] - res["fp32"][0]) <= 2e-2 * abs(res["fp32"][0])
+    for gb, gf in zip(res["bf16"][1], res["fp32"][1]):
+        assert gb.dtype == torch.float32
+        assert float((gb - gf).norm() / gf.norm().clamp_min(1e-12)) < 5e-2
