@@ -230,9 +230,10 @@ def main():
             "value": world * e / (ms * 1e-3), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
-            "dtype_note": ("bf16 storage / fp32 accumulate: matrix-core operands, gather tables and the intermediates "
-                           "that only feed products are bf16; every accumulation, layer outputs, scorer, losses, "
-                           "weights, gradients and optimizer state are fp32" if args.precision == "bf16"
+            "dtype_note": ("bf16 storage / fp32 accumulate: matrix-core operands, gather tables, hidden activations "
+                           "between conv layers (and their gradients) and intermediates that only feed products are "
+                           "bf16; every accumulation, encoder outputs, scorer, losses, weights, weight gradients and "
+                           "optimizer state are fp32" if args.precision == "bf16"
                            else "exact fp32 everywhere (fp32-input MFMA)"),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] shape: synthetic PrimeKG++-like graph per GPU, "

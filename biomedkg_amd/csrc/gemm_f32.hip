@@ -344,6 +344,15 @@ extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, 
   return check_launch("bkg_gemm_grouped_k_f32");
 }
 
+namespace bkg {   // gemm_tn16.hip: both operands bf16, tile-aligned output
+bool gemm_tn16_ok(int64_t M, int64_t N, const void* A, int64_t lda, const void* B, int64_t ldb);
+void launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                             float* C, int64_t ldc, hipStream_t s);
+void launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const void* A, int64_t lda, const void* B,
+                              int64_t ldb, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
+                              hipStream_t s);
+}  // namespace bkg
+
 // ---- bf16-mode weight gradients with fp32 OR bf16 operands:  C[M,N] = A[K,M]^T B[K,N]  (split-K, f32 atomics)
 #define BKG_MIXED_DISPATCH(CALL)                                      \
   if (a_is_bf16) { if (b_is_bf16) { CALL(__bf16, __bf16); } else { CALL(__bf16, float); } } \
@@ -356,6 +365,10 @@ extern "C" int bkg_gemm_tn_bf16(int64_t M, int64_t N, int64_t K, const void* A, 
   hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
   if (e != hipSuccess) { set_error("bkg_gemm_tn_bf16: memset", e); return (int)e; }
   if (K == 0) return 0;
+  if (a_is_bf16 && b_is_bf16 && gemm_tn16_ok(M, N, A, lda, B, ldb)) {
+    launch_gemm_tn16_splitk(M, N, K, A, lda, B, ldb, C, ldc, s);
+    return check_launch("bkg_gemm_tn_bf16(tn16)");
+  }
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
   int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 768 / tiles));
@@ -377,6 +390,10 @@ extern "C" int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N,
   if (rows_total == 0) return 0;
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   hipStream_t s = (hipStream_t)stream;
+  if (a_is_bf16 && b_is_bf16 && gemm_tn16_ok(M, N, A, lda, B, ldb)) {
+    launch_gemm_tn16_grouped(rows_total, M, N, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, s);
+    return check_launch("bkg_gemm_grouped_k_bf16(tn16)");
+  }
   constexpr int BM = 128, BN = 128, KCHUNK = 1024;
   dim3 grid(xcd_grid(ceil_div(rows_total, KCHUNK) + G, ceil_div(M, BM) * ceil_div(N, BN))), block(256);
 #define BKG_GK(AT_, BT_)                                                                                            \

@@ -1,0 +1,166 @@
+// Weight gradients of the bf16 mode when BOTH operands are bf16 tables:  C[M,N] += A[K,M]^T B[K,N]
+// (dW = dXW^T X, dW_r = H_r^T dY_r: K = number of nodes / segments, M x N = a few 128 x 128 tiles).
+//
+// Both operands are stored with the CONTRACTED index as the row, which is the wrong way round for an MFMA operand
+// (8 consecutive k per lane).  The fp32 form (gemm_tile_bf16.h) transposes 4 x 4 patches in registers while staging.
+// With bf16 sources nothing has to be converted, so the tile is copied into LDS as it lies in memory -- 16 B per
+// lane, rows of 256 B -- and the k-major fragments are produced by the LDS transpose read ds_read_b64_tr_b16
+// (cdna_hip_programming.md T10): per 16-lane group a 4 (k) x 16 (m) block comes back column-major, i.e. each lane
+// gets 4 consecutive k of ITS column; two reads make the 8-deep operand.  The 256-byte rows use the guide's chunk
+// XOR ((row & 3) << 2 | (row >> 2) & 3), without which the four rows of a block share their banks (4-way).
+// Result tiles are added with f32 atomics (split over K), as in the fp32 form.
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace bkg {
+
+typedef float t16_acc_t __attribute__((ext_vector_type(16)));
+typedef __bf16 t16_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short t16_s4_t __attribute__((ext_vector_type(4)));
+
+constexpr int T16_BK = 32;     // k rows per stage
+constexpr int T16_BT = 128;    // tile width (m and n)
+
+__device__ __forceinline__ int t16_off(int row, int ch) {     // byte offset of 16-byte chunk ch of row `row`
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+// 4 consecutive k (rows r0 .. r0+3 chosen by the lane's q) of this lane's column, see T10
+__device__ __forceinline__ t16_s4_t t16_tr_read(const unsigned char* img, int r0, int c0, int lane) {
+  const int q = (lane & 15) >> 2, p = lane & 3;
+  const unsigned char* a = img + t16_off(r0 + q, c0 + (p >> 1)) + 8 * (p & 1);
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) t16_s4_t*)a);
+}
+
+// One block: rows [kbeg, kend) of A[:, m0 : m0+128] and B[:, n0 : n0+128]  ->  C[m0.., n0..] (atomic add)
+__device__ __forceinline__ void gemm_tn16_tile(const __bf16* __restrict__ A, int64_t lda, const __bf16* __restrict__ B,
+                                               int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int m0,
+                                               int n0, int kbeg, int kend, const GemmEpilogue& ep) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[T16_BK * 256];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[T16_BK * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int grp = lane >> 4, lh = grp >> 1, half = grp & 1;
+
+  t16_acc_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: 32 rows x 16 chunks = 512 pieces per operand, two per thread
+  uint4 ra[2], rb[2];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = threadIdx.x + i * 256, row = p >> 4, ch = p & 15;
+      const int k = k0 + row;
+      ra[i] = make_uint4(0u, 0u, 0u, 0u);
+      rb[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (k < kend) {
+        ra[i] = *reinterpret_cast<const uint4*>(A + (int64_t)k * lda + m0 + ch * 8);
+        rb[i] = *reinterpret_cast<const uint4*>(B + (int64_t)k * ldb + n0 + ch * 8);
+      }
+    }
+  };
+  load(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += T16_BK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = threadIdx.x + i * 256, row = p >> 4, ch = p & 15;
+      *reinterpret_cast<uint4*>(As + t16_off(row, ch)) = ra[i];
+      *reinterpret_cast<uint4*>(Bs + t16_off(row, ch)) = rb[i];
+    }
+    __syncthreads();
+    if (k0 + T16_BK < kend) load(k0 + T16_BK);
+#pragma unroll
+    for (int ks = 0; ks < T16_BK; ks += 16) {
+      t16_bf16x8_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ca = (wm0 + i * 32 + 16 * half) >> 3, cb = (wn0 + i * 32 + 16 * half) >> 3;
+        const t16_s4_t a0 = t16_tr_read(As, ks + 8 * lh, ca, lane), a1 = t16_tr_read(As, ks + 8 * lh + 4, ca, lane);
+        const t16_s4_t b0 = t16_tr_read(Bs, ks + 8 * lh, cb, lane), b1 = t16_tr_read(Bs, ks + 8 * lh + 4, cb, lane);
+        typedef short s8_t __attribute__((ext_vector_type(8)));
+        const s8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const s8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        a[i] = __builtin_bit_cast(t16_bf16x8_t, av);
+        b[i] = __builtin_bit_cast(t16_bf16x8_t, bv);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  store_acc_tile<2, 2>(acc, C, ldc, M, N, m0 + wm0, n0 + wn0, ep, nullptr);   // ep.atomic: direct atomic adds
+}
+
+__global__ __launch_bounds__(256) void gemm_tn16_splitk_kernel(const __bf16* __restrict__ A, int64_t lda,
+                                                               const __bf16* __restrict__ B, int64_t ldb,
+                                                               float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                               int kchunk, GemmEpilogue ep) {
+  const int n_tiles = N / T16_BT, tiles = n_tiles * (M / T16_BT);
+  const XcdSlot t = xcd_slot(blockIdx.x, tiles);
+  const int kbeg = t.outer * kchunk, kend = min(kbeg + kchunk, K);
+  if (kbeg >= kend) return;
+  gemm_tn16_tile(A, lda, B, ldb, C, ldc, M, N, (t.inner / n_tiles) * T16_BT, (t.inner % n_tiles) * T16_BT, kbeg, kend, ep);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn16_grouped_kernel(const __bf16* __restrict__ A, int64_t lda,
+                                                                const __bf16* __restrict__ B, int64_t ldb,
+                                                                float* __restrict__ C, int64_t ldc, int64_t strideC,
+                                                                const int32_t* __restrict__ group_ptr, int G, int M,
+                                                                int N, int kchunk, GemmEpilogue ep) {
+  __shared__ int s_g, s_k0;
+  const int n_tiles = N / T16_BT, tiles = n_tiles * (M / T16_BT);
+  const XcdSlot xs = xcd_slot(blockIdx.x, tiles);
+  if (threadIdx.x == 0) {
+    int t = xs.outer, g = 0, found = -1, k0 = 0;
+    for (; g < G; ++g) {
+      const int rows = group_ptr[g + 1] - group_ptr[g];
+      const int nc = (rows + kchunk - 1) / kchunk;
+      if (t < nc) { found = g; k0 = group_ptr[g] + t * kchunk; break; }
+      t -= nc;
+    }
+    s_g = found; s_k0 = k0;
+  }
+  __syncthreads();
+  const int g = s_g;
+  if (g < 0) return;
+  const int k0 = s_k0, kend = min(k0 + kchunk, group_ptr[g + 1]);
+  gemm_tn16_tile(A, lda, B, ldb, C + (int64_t)g * strideC, ldc, M, N, (xs.inner / n_tiles) * T16_BT,
+                 (xs.inner % n_tiles) * T16_BT, k0, kend, ep);
+}
+
+bool gemm_tn16_ok(int64_t M, int64_t N, const void* A, int64_t lda, const void* B, int64_t ldb) {
+  return M % T16_BT == 0 && N % T16_BT == 0 && lda % 8 == 0 && ldb % 8 == 0 && (uintptr_t)A % 16 == 0 &&
+         (uintptr_t)B % 16 == 0;
+}
+
+void launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                             float* C, int64_t ldc, hipStream_t s) {
+  GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
+  const int64_t tiles = (M / T16_BT) * (N / T16_BT);
+  int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 1024 / tiles));
+  const int kchunk = (int)(((K + nsplit - 1) / nsplit + T16_BK - 1) / T16_BK * T16_BK);
+  nsplit = (K + kchunk - 1) / kchunk;
+  hipLaunchKernelGGL(gemm_tn16_splitk_kernel, dim3(xcd_grid(nsplit, tiles)), dim3(256), 0, s, (const __bf16*)A, lda,
+                     (const __bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep);
+}
+
+void launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const void* A, int64_t lda, const void* B,
+                              int64_t ldb, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
+                              hipStream_t s) {
+  GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
+  constexpr int KCHUNK = 1024;
+  const int64_t tiles = (M / T16_BT) * (N / T16_BT);
+  hipLaunchKernelGGL(gemm_tn16_grouped_kernel, dim3(xcd_grid(ceil_div(rows_total, KCHUNK) + G, tiles)), dim3(256), 0, s,
+                     (const __bf16*)A, lda, (const __bf16*)B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK,
+                     ep);
+}
+
+}  // namespace bkg

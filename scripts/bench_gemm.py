@@ -60,6 +60,12 @@ def main():
         print(json.dumps({"kernel": "gemm", "precision": prec, "M": mm, "N": nn, "K": kk, "ta": ta, "tb": tb,
                           "ms": round(ms, 4), "TFLOPs": round(2.0 * mm * nn * kk / ms / 1e9, 1),
                           "GBs_io": round(4.0 * (mm * kk + kk * nn + mm * nn) / ms / 1e6)}))
+    if prec == "bf16":
+        for (mm, nn) in ((256, 256), (256, 768)):
+            a16, b16 = torch.randn(n, mm, device=dev).bfloat16(), torch.randn(n, nn, device=dev).bfloat16()
+            ms = timeit(lambda: ops.gemm(a16, b16, trans_a=True))
+            print(json.dumps({"kernel": "gemm_tn bf16 x bf16", "M": mm, "N": nn, "K": n, "ms": round(ms, 4),
+                              "GBs_io": round(2.0 * n * (mm + nn) / ms / 1e6)}))
     # R-GCN per-relation products over S ~ 3e5 (relation, target) segment rows, skewed group sizes
     s, g = 300_000, 30
     w = torch.arange(1, g + 1, dtype=torch.float64).pow(-1.2)
@@ -70,7 +76,14 @@ def main():
     for name, fn, flops, byt in (
             ("grouped_rows", lambda: ops.gemm_grouped_rows(h, wt, gptr), 2.0 * s * 256 * 256, 8.0 * s * 256),
             ("grouped_rows_T", lambda: ops.gemm_grouped_rows(dy, wt, gptr, trans_b=True), 2.0 * s * 256 * 256, 8.0 * s * 256),
-            ("grouped_k", lambda: ops.gemm_grouped_k(h, dy, gptr, g), 2.0 * s * 256 * 256, 8.0 * s * 256)):
+            ("grouped_k", lambda: ops.gemm_grouped_k(h, dy, gptr, g), 2.0 * s * 256 * 256, 8.0 * s * 256),
+            ("grouped_k bf16 x bf16", lambda: ops.gemm_grouped_k(h.bfloat16(), dy.bfloat16(), gptr, g) if False else None,
+             0.0, 1.0)):
+        if fn() is None and name.endswith("bf16"):
+            if prec != "bf16":
+                continue
+            h16, dy16 = h.bfloat16(), dy.bfloat16()
+            fn, flops, byt = (lambda: ops.gemm_grouped_k(h16, dy16, gptr, g)), 2.0 * s * 256 * 256, 4.0 * s * 256
         ms = timeit(fn)
         print(json.dumps({"kernel": name, "precision": prec, "S": s, "G": g, "ms": round(ms, 4),
                           "TFLOPs": round(flops / ms / 1e9, 1), "GBs_io": round(byt / ms / 1e6)}))
