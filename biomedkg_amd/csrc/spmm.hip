@@ -423,6 +423,42 @@ extern "C" int bkg_gate_cast_bf16(const void* src, int32_t src_is_bf16, const vo
   return check_launch("bkg_gate_cast_bf16");
 }
 
+// ---- feature masking of the GCL augmentations (reference biomedkg/model/gcl.py:42,76: x * (rand >= p), no
+//      rescale) fused with the bf16 table cast: dst = bf16(philox(seed, stream, i) >= p ? src[i] : 0); p = 0: plain cast
+namespace bkg {
+__global__ __launch_bounds__(256) void mask_cast_bf16_kernel(const float* __restrict__ src, float p, uint64_t seed,
+                                                             uint32_t stream_id, __bf16* __restrict__ dst, int64_t n8) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float a[8];
+  load8(src, i, a);
+  if (p > 0.f) {
+    const uint32_t thresh = (uint32_t)fminf(p * 4294967296.0f, 4294967295.0f);
+    const uint4 r0 = philox_keep4(seed, (uint64_t)i * 8, stream_id), r1 = philox_keep4(seed, (uint64_t)i * 8 + 4, stream_id);
+    a[0] = r0.x >= thresh ? a[0] : 0.f; a[1] = r0.y >= thresh ? a[1] : 0.f;
+    a[2] = r0.z >= thresh ? a[2] : 0.f; a[3] = r0.w >= thresh ? a[3] : 0.f;
+    a[4] = r1.x >= thresh ? a[4] : 0.f; a[5] = r1.y >= thresh ? a[5] : 0.f;
+    a[6] = r1.z >= thresh ? a[6] : 0.f; a[7] = r1.w >= thresh ? a[7] : 0.f;
+  }
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (__bf16)a[e];
+  reinterpret_cast<bf16x8*>(dst)[i] = o;
+}
+}  // namespace bkg
+
+extern "C" int bkg_mask_cast_bf16(const float* src, float p, uint64_t seed, uint32_t stream_id, void* dst, int64_t n,
+                                  void* stream) {
+  using namespace bkg;
+  BKG_ARG(n >= 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "bkg_mask_cast_bf16: n must be a multiple of 8, p in [0,1)");
+  BKG_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "bkg_mask_cast_bf16: 16-byte alignment");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(mask_cast_bf16_kernel, dim3(ceil_div(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, p, seed,
+                     stream_id, (__bf16*)dst, n / 8);
+  return check_launch("bkg_mask_cast_bf16");
+}
+
 extern "C" int bkg_cast_f32_bf16(const float* src, const float* gate, float gate_scale, void* dst, int64_t n,
                                  void* stream) {
   return bkg_gate_cast_bf16(src, 0, gate, 0, gate_scale, dst, n, stream);

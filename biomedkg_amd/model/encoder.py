@@ -79,6 +79,8 @@ class _Stack(torch.nn.Module):
             layer.reset_parameters()
 
     def _run(self, x, *graph, **kw):
+        if ops.features_bf16_ok(x) and x.is_cuda:
+            x = ops.cached_bf16(x)      # constant input features: one bf16 table per tensor, not one cast per step
         last = len(self.graph_layers) - 1
         for i, layer in enumerate(self.graph_layers):
             if i == last:

@@ -29,6 +29,8 @@ class DGI(torch.nn.Module):
         return torch.sigmoid(z.mean(dim=0, keepdim=True))
 
     def forward(self, x, edge_index):
+        if ops.features_bf16_ok(x) and x.is_cuda:
+            x = ops.cached_bf16(x)
         z = self.encoder(x, edge_index)
         g = ops.linear(self.summary(z), self.project.weight, self.project.bias)
         zn = self.encoder(*self.corruption(x, edge_index))
@@ -47,10 +49,10 @@ class GRACE(torch.nn.Module):
 
     def _augment(self, x, edge_index):
         r = _rand.current()
-        k1, k2 = r.feat_keep(x, 0.4), r.feat_keep(x, 0.4)
+        x1, x2 = r.masked(x, 0.4), r.masked(x, 0.4)
         e1 = r.edge_keep(edge_index.size(1), 0.4, x.device)
         e2 = r.edge_keep(edge_index.size(1), 0.4, x.device)
-        return (x * k1, e1), (x * k2, e2)
+        return (x1, e1), (x2, e2)
 
     def forward(self, x, edge_index):
         (x1, e1), (x2, e2) = self._augment(x, edge_index)
@@ -84,8 +86,10 @@ class GGD(torch.nn.Module):
         r = _rand.current()
         edge_keep = None
         if r.coin() < self.p:
-            x = x * r.feat_keep(x, 0.4)
+            x = r.masked(x, 0.4)
             edge_keep = r.edge_keep(edge_index.size(1), 0.4, x.device)
+        elif ops.features_bf16_ok(x) and x.is_cuda:
+            x = ops.cached_bf16(x)      # bf16 mode: the corruption below then permutes a bf16 table
         pos_h = self.encoder(x, edge_index, edge_keep=edge_keep)
         # the reference corrupts over the (possibly edge-dropped) graph of the positive pass
         neg_h = self.encoder(self.corruption(x, edge_index)[0], edge_index, edge_keep=edge_keep)

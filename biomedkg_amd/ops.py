@@ -207,6 +207,27 @@ def to_bf16(x, gate=None, gate_scale=1.0):
     return out
 
 
+def masked_bf16(x, p, seed, stream_id):
+    """``bf16(x * (rand >= p))`` -- the GCL feature-masking augmentation fused with the bf16 table cast."""
+    L.require_cuda(x)
+    x = _f32c(x)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.call("bkg_mask_cast_bf16", L.ptr(x), float(p), seed, stream_id, L.ptr(out), x.numel(), L.stream())
+    return out
+
+
+def features_bf16_ok(x):
+    """An fp32 feature matrix that bf16 mode may hand to the first conv layer as a bf16 table."""
+    return (bf16_storage() and x.dtype == torch.float32 and x.dim() == 2 and not x.requires_grad and x.size(0) >= 4096
+            and x.size(1) % 256 == 0 and _bf16_ok(x.size(1)))
+
+
+def cached_bf16(x):
+    """bf16 copy of a constant feature matrix, cached on the tensor object (rebuilt when it is written to)."""
+    from .graph import _cached
+    return _cached(x, "bf16", (), lambda: to_bf16(x))
+
+
 def bf16_storage() -> bool:
     """bf16 mode also keeps the tables the gather kernels read in bf16 (fp32 accumulate)."""
     return _PRECISION == 1

@@ -27,6 +27,14 @@ class DeviceRand:
     def feat_keep(self, x, p):
         return torch.rand_like(x) >= p
 
+    def masked(self, x, p):
+        """``x * feat_keep(x, p)``; in bf16 mode a bf16 table straight from one pass over ``x`` (in-kernel Philox)."""
+        from . import ops
+        if ops.features_bf16_ok(x) and x.is_cuda:
+            self.counter += 1
+            return ops.masked_bf16(x, p, self.seed, self.counter & 0xFFFFFFFF)
+        return x * self.feat_keep(x, p)
+
     def edge_keep(self, num_edges, p, device):
         return torch.rand(num_edges, device=device) >= p
 
@@ -76,6 +84,9 @@ class ReplayRand:
 
     def feat_keep(self, x, p):
         return self._next("feat_keep")
+
+    def masked(self, x, p):
+        return x * self.feat_keep(x, p)
 
     def edge_keep(self, num_edges, p, device):
         return self._next("edge_keep")

@@ -71,6 +71,9 @@ int bkg_rowsplit_build(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int32
  *      bkg_cast_f32_bf16 makes such a table: dst = bf16(gate ? (gate > 0 ? src * gate_scale : 0) : src), n % 8 == 0. */
 int bkg_cast_f32_bf16(const float* src, const float* gate, float gate_scale, void* dst, int64_t n, void* stream);
 /*      typed form: src and gate may each be fp32 or bf16 (bf16 hidden activations / gradients of the bf16 mode) */
+/*      feature masking of the GCL augmentations (biomedkg/model/gcl.py:42,76: x * (rand >= p), no rescale) fused with
+ *      the cast: dst = bf16(Philox(seed, stream_id, i) >= p ? src[i] : 0) */
+int bkg_mask_cast_bf16(const float* src, float p, uint64_t seed, uint32_t stream_id, void* dst, int64_t n, void* stream);
 int bkg_gate_cast_bf16(const void* src, int32_t src_is_bf16, const void* gate, int32_t gate_is_bf16, float gate_scale,
                        void* dst, int64_t n, void* stream);
 int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const void* x, int32_t x_is_bf16,

@@ -231,3 +231,21 @@ def test_bf16_hidden_activations_track_the_fp32_encoder(kind):
     for gb, gf in zip(res["bf16"][1], res["fp32"][1]):
         assert gb.dtype == torch.float32
         assert float((gb - gf).norm() / gf.norm().clamp_min(1e-12)) < 5e-2
+
+
+def test_masked_bf16_features():
+    """GCL feature masking fused with the table cast: kept entries are bf16(x), a fraction ~p is zeroed, the mask is a
+    pure function of (seed, stream), and p = 0 is the plain cast."""
+    from biomedkg_amd import ops
+    x = torch.randn(4096, 768, device=DEV)
+    a = ops.masked_bf16(x, 0.4, 123, 1)
+    assert a.dtype == torch.bfloat16 and torch.equal(a, ops.masked_bf16(x, 0.4, 123, 1))
+    kept = a != 0
+    assert torch.equal(a[kept], x.bfloat16()[kept])
+    frac = 1.0 - float(kept.float().mean())
+    assert abs(frac - 0.4) < 5e-3
+    b = ops.masked_bf16(x, 0.4, 123, 2)
+    assert 0.2 < float(((a != 0) & (b != 0)).float().mean()) < 0.5          # independent masks overlap on ~0.36
+    assert torch.equal(ops.masked_bf16(x, 0.0, 5, 0), x.bfloat16())
+    # column / row structure: no column or row is masked as a whole (element-wise mask, reference gcl.py:42,76)
+    assert float(kept.float().mean(0).min()) > 0.5 and float(kept.float().mean(1).min()) > 0.5
