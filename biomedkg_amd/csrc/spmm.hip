@@ -226,41 +226,51 @@ __global__ __launch_bounds__(256) void spmm_items_kernel(bkg_rowsplit rs, const 
   }
 }
 
-// long rows: add the row's partial slots in chunk order, then the epilogue
+// long rows: one block per row.  Its 4 * G lane groups each add a strided subset of the row's partial slots (8 loads in
+// flight), the group sums are combined through LDS in group order (a fixed tree: bitwise repeatable), then the
+// epilogue.  (One lane group per row walked a hub row's ~150 slots serially: 20 us per launch for a handful of rows.)
 template <typename T, int LPR, int VPL>
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(bkg_rowsplit rs, const T* __restrict__ x, int64_t ldx,
                                                          float* __restrict__ out, int64_t ldo,
                                                          const float* __restrict__ partials, SpmmEpilogue ep) {
-  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, d = EPL * LPR * VPL;
-  const int lane = threadIdx.x & 63;
-  const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR;  // one lane group per long row
-  if (l >= rs.totals[2]) return;
-  const int lig = lane % LPR;
+  constexpr int G = 64 / LPR, NG = 4 * G, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, d = EPL * LPR * VPL;
+  __shared__ __attribute__((aligned(16))) float red[NG * d];
+  const int l = blockIdx.x;
+  if (l >= rs.totals[2]) return;    // block-uniform
+  const int lane = threadIdx.x & 63, lig = lane % LPR, gi = (threadIdx.x >> 6) * G + lane / LPR;
   const int row = rs.long_row[l], s0 = rs.long_slot0[l], n = rs.long_cnt[l];
-  float4 acc[VPL * Q];
+  float4 acc[VQ];
   zero4(acc);
-  // a hub row has hundreds of partial slots: keep 8 of them in flight, still added in chunk order
   constexpr int UF = 8;
-  for (int c0 = 0; c0 < n; c0 += UF) {
-    float4 t[UF][VPL * Q];
+  for (int c0 = gi; c0 < n; c0 += UF * NG) {
+    float4 t[UF][VQ];
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
-      const int c = min(c0 + u, n - 1);
+      const int c = min(c0 + u * NG, n - 1);
 #pragma unroll
-      for (int v = 0; v < VPL; ++v)
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-          t[u][v * Q + q] = *reinterpret_cast<const float4*>(partials + (int64_t)(s0 + c) * d + EPL * (lig + v * LPR) + 4 * q);
+      for (int vq = 0; vq < VQ; ++vq)
+        t[u][vq] = *reinterpret_cast<const float4*>(partials + (int64_t)(s0 + c) * d + EPL * (lig + (vq / Q) * LPR) + 4 * (vq % Q));
     }
 #pragma unroll
     for (int u = 0; u < UF; ++u)
-      if (c0 + u < n) {
+      if (c0 + u * NG < n) {
 #pragma unroll
-        for (int vq = 0; vq < VPL * Q; ++vq) {
+        for (int vq = 0; vq < VQ; ++vq) {
           acc[vq].x += t[u][vq].x; acc[vq].y += t[u][vq].y; acc[vq].z += t[u][vq].z; acc[vq].w += t[u][vq].w;
         }
       }
   }
+#pragma unroll
+  for (int vq = 0; vq < VQ; ++vq)
+    *reinterpret_cast<float4*>(red + gi * d + EPL * (lig + (vq / Q) * LPR) + 4 * (vq % Q)) = acc[vq];
+  __syncthreads();
+  if (gi != 0) return;
+  for (int g2 = 1; g2 < NG; ++g2)
+#pragma unroll
+    for (int vq = 0; vq < VQ; ++vq) {
+      const float4 v = *reinterpret_cast<const float4*>(red + g2 * d + EPL * (lig + (vq / Q) * LPR) + 4 * (vq % Q));
+      acc[vq].x += v.x; acc[vq].y += v.y; acc[vq].z += v.z; acc[vq].w += v.w;
+    }
   spmm_finish<T, LPR, VPL>(acc, row, lig, x, ldx, out, ldo, ep);
 }
 
@@ -308,7 +318,7 @@ static void launch_spmm(const SpmmArgs<T>& a) {
     constexpr int G = 64 / LPR;
     hipLaunchKernelGGL((spmm_items_kernel<T, LPR, VPL>), dim3(ceil_div(a.split->n_items_max, 4)), dim3(256), 0, a.s,
                        *a.split, a.col, a.w, a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
-    hipLaunchKernelGGL((spmm_fixup_kernel<T, LPR, VPL>), dim3(ceil_div(a.split->n_long_max, 4 * G)), dim3(256), 0, a.s,
+    hipLaunchKernelGGL((spmm_fixup_kernel<T, LPR, VPL>), dim3((unsigned)a.split->n_long_max), dim3(256), 0, a.s,
                        *a.split, a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
   } else {
     hipLaunchKernelGGL((spmm_csr_kernel<T, LPR, VPL>), dim3(ceil_div(a.n_rows, 4)), dim3(256), 0, a.s, a.rowptr, a.col,
