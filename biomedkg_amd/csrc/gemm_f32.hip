@@ -349,7 +349,7 @@ bool gemm_tn16_ok(int64_t M, int64_t N, const void* A, int64_t lda, const void* 
 void launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                              float* C, int64_t ldc, hipStream_t s);
 void launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const void* A, int64_t lda, const void* B,
-                              int64_t ldb, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
+                              int64_t ldb, const int32_t* b_rows, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
                               hipStream_t s);
 }  // namespace bkg
 
@@ -384,16 +384,18 @@ extern "C" int bkg_gemm_tn_bf16(int64_t M, int64_t N, int64_t K, const void* A, 
 }
 
 extern "C" int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N, const void* A, int32_t a_is_bf16,
-                                       int64_t lda, const void* B, int32_t b_is_bf16, int64_t ldb, float* C, int64_t ldc,
-                                       int64_t strideC, const int32_t* group_ptr, int32_t G, void* stream) {
+                                       int64_t lda, const void* B, int32_t b_is_bf16, int64_t ldb, const int32_t* b_rows,
+                                       float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int32_t G,
+                                       void* stream) {
   BKG_ARG(rows_total >= 0 && M > 0 && N > 0 && G > 0, "bkg_gemm_grouped_k_bf16: bad shape");
   if (rows_total == 0) return 0;
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   hipStream_t s = (hipStream_t)stream;
   if (a_is_bf16 && b_is_bf16 && gemm_tn16_ok(M, N, A, lda, B, ldb)) {
-    launch_gemm_tn16_grouped(rows_total, M, N, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, s);
+    launch_gemm_tn16_grouped(rows_total, M, N, A, lda, B, ldb, b_rows, C, ldc, strideC, group_ptr, G, s);
     return check_launch("bkg_gemm_grouped_k_bf16(tn16)");
   }
+  BKG_ARG(b_rows == nullptr, "bkg_gemm_grouped_k_bf16: indexed B rows need two bf16 operands and 128-aligned M, N");
   constexpr int BM = 128, BN = 128, KCHUNK = 1024;
   dim3 grid(xcd_grid(ceil_div(rows_total, KCHUNK) + G, ceil_div(M, BM) * ceil_div(N, BN))), block(256);
 #define BKG_GK(AT_, BT_)                                                                                            \

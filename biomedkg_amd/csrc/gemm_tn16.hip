@@ -34,7 +34,7 @@ __device__ __forceinline__ t16_s4_t t16_tr_read(const unsigned char* img, int r0
 
 // One block: rows [kbeg, kend) of A[:, m0 : m0+128] and B[:, n0 : n0+128]  ->  C[m0.., n0..] (atomic add)
 __device__ __forceinline__ void gemm_tn16_tile(const __bf16* __restrict__ A, int64_t lda, const __bf16* __restrict__ B,
-                                               int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int m0,
+                                               int64_t ldb, const int32_t* __restrict__ b_rows, float* __restrict__ C, int64_t ldc, int M, int N, int m0,
                                                int n0, int kbeg, int kend, const GemmEpilogue& ep) {
   __shared__ __attribute__((aligned(16))) unsigned char As[T16_BK * 256];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[T16_BK * 256];
@@ -51,8 +51,20 @@ __device__ __forceinline__ void gemm_tn16_tile(const __bf16* __restrict__ A, int
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // staging: 32 rows x 16 chunks = 512 pieces per operand, two per thread
+  // b_rows (nullable): contracted row k of B is B[b_rows[k]] (RGCNConv backward: dY[s] = dOut[dst_s], never stored);
+  // the indices of the NEXT stage are fetched with the current stage's rows so the dependent load is off the path
   uint4 ra[2], rb[2];
+  int bi[2];
+  auto rows_of = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = k0 + ((threadIdx.x + i * 256) >> 4);
+      bi[i] = (b_rows && k < kend) ? b_rows[k] : k;
+    }
+  };
   auto load = [&](int k0) {
+    int cur[2] = {bi[0], bi[1]};
+    if (b_rows) rows_of(k0 + T16_BK);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int p = threadIdx.x + i * 256, row = p >> 4, ch = p & 15;
@@ -61,10 +73,11 @@ __device__ __forceinline__ void gemm_tn16_tile(const __bf16* __restrict__ A, int
       rb[i] = make_uint4(0u, 0u, 0u, 0u);
       if (k < kend) {
         ra[i] = *reinterpret_cast<const uint4*>(A + (int64_t)k * lda + m0 + ch * 8);
-        rb[i] = *reinterpret_cast<const uint4*>(B + (int64_t)k * ldb + n0 + ch * 8);
+        rb[i] = *reinterpret_cast<const uint4*>(B + (int64_t)(b_rows ? cur[i] : k) * ldb + n0 + ch * 8);
       }
     }
   };
+  rows_of(kbeg);
   load(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += T16_BK) {
     __syncthreads();
@@ -107,11 +120,12 @@ __global__ __launch_bounds__(256) void gemm_tn16_splitk_kernel(const __bf16* __r
   const XcdSlot t = xcd_slot(blockIdx.x, tiles);
   const int kbeg = t.outer * kchunk, kend = min(kbeg + kchunk, K);
   if (kbeg >= kend) return;
-  gemm_tn16_tile(A, lda, B, ldb, C, ldc, M, N, (t.inner / n_tiles) * T16_BT, (t.inner % n_tiles) * T16_BT, kbeg, kend, ep);
+  gemm_tn16_tile(A, lda, B, ldb, nullptr, C, ldc, M, N, (t.inner / n_tiles) * T16_BT, (t.inner % n_tiles) * T16_BT, kbeg, kend, ep);
 }
 
 __global__ __launch_bounds__(256) void gemm_tn16_grouped_kernel(const __bf16* __restrict__ A, int64_t lda,
                                                                 const __bf16* __restrict__ B, int64_t ldb,
+                                                                const int32_t* __restrict__ b_rows,
                                                                 float* __restrict__ C, int64_t ldc, int64_t strideC,
                                                                 const int32_t* __restrict__ group_ptr, int G, int M,
                                                                 int N, int kchunk, GemmEpilogue ep) {
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_tn16_grouped_kernel(const __bf16* __
   const int g = s_g;
   if (g < 0) return;
   const int k0 = s_k0, kend = min(k0 + kchunk, group_ptr[g + 1]);
-  gemm_tn16_tile(A, lda, B, ldb, C + (int64_t)g * strideC, ldc, M, N, (xs.inner / n_tiles) * T16_BT,
+  gemm_tn16_tile(A, lda, B, ldb, b_rows, C + (int64_t)g * strideC, ldc, M, N, (xs.inner / n_tiles) * T16_BT,
                  (xs.inner % n_tiles) * T16_BT, k0, kend, ep);
 }
 
@@ -153,14 +167,14 @@ void launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int
 }
 
 void launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const void* A, int64_t lda, const void* B,
-                              int64_t ldb, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
+                              int64_t ldb, const int32_t* b_rows, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
                               hipStream_t s) {
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   constexpr int KCHUNK = 1024;
   const int64_t tiles = (M / T16_BT) * (N / T16_BT);
   hipLaunchKernelGGL(gemm_tn16_grouped_kernel, dim3(xcd_grid(ceil_div(rows_total, KCHUNK) + G, tiles)), dim3(256), 0, s,
-                     (const __bf16*)A, lda, (const __bf16*)B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK,
-                     ep);
+                     (const __bf16*)A, lda, (const __bf16*)B, ldb, b_rows, C, ldc, strideC, group_ptr, G, (int)M, (int)N,
+                     KCHUNK, ep);
 }
 
 }  // namespace bkg

@@ -55,6 +55,7 @@ template <> struct XwFrag<__bf16> {
 
 struct XwArgs {
   const void* A; int64_t lda;
+  const int32_t* a_rows;   // nullable: output row m reads A row a_rows[m] (RGCNConv backward: dY[s] = dOut[dst_s], never stored)
   const __bf16* Wt; int64_t ldw, stride_w;
   void* C; int64_t ldc;
   const int32_t* group_ptr; int G;
@@ -121,7 +122,10 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
     // this lane's two source rows (clamped: out-of-range rows are computed on valid memory and never stored)
     const AT* arow[XW_TM];
 #pragma unroll
-    for (int j = 0; j < XW_TM; ++j) arow[j] = A + (int64_t)min(m_base + j * 32 + l31, m_hi - 1) * g.lda + lh * 8;
+    for (int j = 0; j < XW_TM; ++j) {
+      const int r = min(m_base + j * 32 + l31, m_hi - 1);
+      arow[j] = A + (int64_t)(g.a_rows ? g.a_rows[r] : r) * g.lda + lh * 8;
+    }
 
     xw_acc_t acc[XW_TN][XW_TM];
 #pragma unroll
@@ -280,7 +284,7 @@ extern "C" int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w,
 }
 
 extern "C" int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const void* A, int32_t a_is_bf16, int64_t lda,
-                           const void* Wt, int64_t ldw, int64_t stride_w, const int32_t* group_ptr, int32_t G,
+                           const int32_t* a_rows, const void* Wt, int64_t ldw, int64_t stride_w, const int32_t* group_ptr, int32_t G,
                            float beta, void* C, int32_t c_is_bf16, int64_t ldc, const float* bias, int32_t act,
                            const float* gate, int64_t ldg, float gate_scale, void* stream) {
   BKG_ARG(M >= 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1 << 24) && K < (1 << 24), "bkg_gemm_xw: bad shape");
@@ -298,7 +302,7 @@ extern "C" int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const v
   if (M == 0) return 0;
   GemmEpilogue ep{alpha, beta, bias, act, gate, ldg, gate_scale, 0};
   const int n_tiles = ceil_div(N, XW_BN);
-  XwArgs g{A, lda, reinterpret_cast<const __bf16*>(Wt), ldw, stride_w, C, ldc, group_ptr, G, (int)M, (int)N, (int)K, 0};
+  XwArgs g{A, lda, a_rows, reinterpret_cast<const __bf16*>(Wt), ldw, stride_w, C, ldc, group_ptr, G, (int)M, (int)N, (int)K, 0};
   hipStream_t s = (hipStream_t)stream;
   unsigned grid;
   if (group_ptr) {

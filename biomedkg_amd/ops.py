@@ -68,11 +68,13 @@ def _bf16_operand_ok(rows, n, k):
     return _PRECISION == 1 and rows >= 1024 and n * k <= (1 << 22) and k % 256 == 0 and n % 32 == 0
 
 
-def _gemm_xw(a, wt, m, n, k, out, out_dtype, alpha, beta, bias, act, gate, gate_scale, group_ptr=None, groups=0):
+def _gemm_xw(a, wt, m, n, k, out, out_dtype, alpha, beta, bias, act, gate, gate_scale, group_ptr=None, groups=0,
+             a_rows=None):
     if out is None:
         out = torch.empty(m, n, dtype=out_dtype, device=a.device)
     w2 = wt if wt.dim() == 2 else wt[0]
-    L.call("bkg_gemm_xw", m, n, k, alpha, L.ptr(a), int(a.dtype == torch.bfloat16), a.stride(0), L.ptr(wt), w2.stride(0),
+    L.call("bkg_gemm_xw", m, n, k, alpha, L.ptr(a), int(a.dtype == torch.bfloat16), a.stride(0), L.ptr(a_rows), L.ptr(wt),
+           w2.stride(0),
            wt.stride(0) if wt.dim() == 3 else 0, L.ptr(group_ptr), groups, beta, L.ptr(out),
            int(out.dtype == torch.bfloat16), out.stride(0), L.ptr(bias), act, L.ptr(gate),
            gate.stride(0) if gate is not None else 0, gate_scale, L.stream())
@@ -117,15 +119,19 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias
     return out
 
 
-def gemm_grouped_rows(a, b, group_ptr, trans_b=False, out_dtype=torch.float32):
-    """``out[rows of g] = a[rows of g] @ op(b[g])``; ``b`` is ``[G, k, n]`` (or ``[G, n, k]`` if trans_b)."""
-    L.require_cuda(a, b, group_ptr)
+def gemm_grouped_rows(a, b, group_ptr, trans_b=False, out_dtype=torch.float32, a_rows=None):
+    """``out[rows of g] = a[rows of g] @ op(b[g])``; ``b`` is ``[G, k, n]`` (or ``[G, n, k]`` if trans_b).
+    ``a_rows`` (int32, bf16 mode's streaming kernel only): output row ``m`` reads ``a[a_rows[m]]``."""
+    L.require_cuda(a, b, group_ptr, a_rows)
     b = _f32c(b)
     g = b.size(0)
     k, n = (b.size(2), b.size(1)) if trans_b else (b.size(1), b.size(2))
-    if _xw_ok(a, a.size(0), n, k):
-        return _gemm_xw(a, _weight_bf16(b, not trans_b), a.size(0), n, k, None, out_dtype, 1.0, 0.0, None, ACT_NONE, None,
-                        1.0, group_ptr, g)
+    rows = a.size(0) if a_rows is None else a_rows.numel()
+    if _xw_ok(a, rows, n, k):
+        return _gemm_xw(a, _weight_bf16(b, not trans_b), rows, n, k, None, out_dtype, 1.0, 0.0, None, ACT_NONE, None,
+                        1.0, group_ptr, g, a_rows)
+    if a_rows is not None:
+        raise ValueError("gathered rows are only taken by the bf16-mode streaming product")
     if out_dtype != torch.float32:
         raise TypeError("bf16 outputs are only produced by the bf16-mode activation-x-weight products")
     a = _f32c(a)
@@ -136,16 +142,27 @@ def gemm_grouped_rows(a, b, group_ptr, trans_b=False, out_dtype=torch.float32):
     return out
 
 
-def gemm_grouped_k(a, b, group_ptr, num_groups):
-    """``out[g] = a[rows of g]^T @ b[rows of g]`` -> ``[G, a.cols, b.cols]`` (split-K, f32 atomics)."""
-    L.require_cuda(a, b, group_ptr)
+def gathered_k_ok(a, b):
+    """``gemm_grouped_k(.., b_rows=..)``: two bf16 tables whose widths are multiples of the 128-column tile."""
+    return (_PRECISION == 1 and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.size(1) % 128 == 0
+            and b.size(1) % 128 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0
+            and b.stride(0) % 8 == 0)
+
+
+def gemm_grouped_k(a, b, group_ptr, num_groups, b_rows=None):
+    """``out[g] = a[rows of g]^T @ b[rows of g]`` -> ``[G, a.cols, b.cols]`` (split-K, f32 atomics).
+    ``b_rows`` (int32; see :func:`gathered_k_ok`): row ``k`` of the second operand is ``b[b_rows[k]]``."""
+    L.require_cuda(a, b, group_ptr, b_rows)
     m, n = a.size(1), b.size(1)
     out = torch.zeros(num_groups, m, n, dtype=torch.float32, device=a.device)
+    if b_rows is not None and not gathered_k_ok(a, b):
+        raise ValueError("gathered rows need two bf16 tables with 128-aligned widths (bf16 mode)")
     if _PRECISION == 1:
         a = a if a.stride(1) == 1 else a.contiguous()
         b = b if b.stride(1) == 1 else b.contiguous()
         L.call("bkg_gemm_grouped_k_bf16", a.size(0), m, n, L.ptr(a), int(a.dtype == torch.bfloat16), a.stride(0), L.ptr(b),
-               int(b.dtype == torch.bfloat16), b.stride(0), L.ptr(out), n, m * n, L.ptr(group_ptr), num_groups, L.stream())
+               int(b.dtype == torch.bfloat16), b.stride(0), L.ptr(b_rows), L.ptr(out), n, m * n, L.ptr(group_ptr),
+               num_groups, L.stream())
         return out
     a, b = _f32c(a), _f32c(b)
     L.call("bkg_gemm_grouped_k_f32", a.size(0), m, n, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0), L.ptr(out), n,
@@ -442,11 +459,19 @@ class _RgcnConv(torch.autograd.Function):
             if ctx.gated:
                 out = _as_f32(out)
                 dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
-        dy16 = (bf16_storage() and _bf16_ok(d_out) and
-                (not ctx.needs_input_grad[0] or _bf16_operand_ok(rg.num_segments, d_in, d_out)))
-        dy = spmm(rg.seg_iota_ptr, rg.seg_dst, None, dout, rg.num_segments,           # dY[s] = dOut[dst_s]; read by
-                  out_dtype=torch.bfloat16 if dy16 else torch.float32)                # the two products below only
-        dweight = gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations) if ctx.needs_input_grad[1] else None
+        # dY[s] = dOut[dst_s] is never stored when both of its consumers can read dOut's rows through seg_dst
+        gathered = (dout.dtype == torch.bfloat16 and gathered_k_ok(h, dout)
+                    and _xw_ok(dout, rg.num_segments, d_in, d_out))
+        if gathered:
+            dy = None
+            dweight = (gemm_grouped_k(h, dout, rg.rel_ptr, rg.num_relations, b_rows=rg.seg_dst)
+                       if ctx.needs_input_grad[1] else None)
+        else:
+            dy16 = (bf16_storage() and _bf16_ok(d_out) and
+                    (not ctx.needs_input_grad[0] or _bf16_operand_ok(rg.num_segments, d_in, d_out)))
+            dy = spmm(rg.seg_iota_ptr, rg.seg_dst, None, dout, rg.num_segments,       # dY[s] = dOut[dst_s]; read by
+                      out_dtype=torch.bfloat16 if dy16 else torch.float32)            # the two products below only
+            dweight = gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations) if ctx.needs_input_grad[1] else None
         droot = None
         if ctx.needs_input_grad[2]:
             if n < 4096 and (x.dtype == torch.bfloat16 or dout.dtype == torch.bfloat16):
@@ -456,9 +481,13 @@ class _RgcnConv(torch.autograd.Function):
         db = colsum(dout) if ctx.needs_input_grad[3] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            to16 = bf16_storage() and _bf16_ok(d_in) and _xw_ok(dy, dy.size(0), d_in, d_out)
-            dh = gemm_grouped_rows(dy, weight, rg.rel_ptr, trans_b=True,
-                                   out_dtype=torch.bfloat16 if to16 else torch.float32)   # [S, in], a gather table
+            if gathered:
+                dh = gemm_grouped_rows(dout, weight, rg.rel_ptr, trans_b=True, a_rows=rg.seg_dst,
+                                       out_dtype=torch.bfloat16 if _bf16_ok(d_in) else torch.float32)
+            else:
+                to16 = bf16_storage() and _bf16_ok(d_in) and _xw_ok(dy, dy.size(0), d_in, d_out)
+                dh = gemm_grouped_rows(dy, weight, rg.rel_ptr, trans_b=True,
+                                       out_dtype=torch.bfloat16 if to16 else torch.float32)   # [S, in], a gather table
             dx_root = gemm(dout, root, trans_b=True)                                  # [N, in]
             c = rg.src_csr
             x16 = x.dtype == torch.bfloat16 and _bf16_ok(d_in)

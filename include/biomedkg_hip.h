@@ -97,7 +97,9 @@ int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t
 int bkg_gemm_tn_bf16(int64_t M, int64_t N, int64_t K, const void* A, int32_t a_is_bf16, int64_t lda, const void* B,
                      int32_t b_is_bf16, int64_t ldb, float* C, int64_t ldc, void* stream);
 int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N, const void* A, int32_t a_is_bf16, int64_t lda,
-                            const void* B, int32_t b_is_bf16, int64_t ldb, float* C, int64_t ldc, int64_t strideC,
+                            const void* B, int32_t b_is_bf16, int64_t ldb,
+                            const int32_t* b_rows /* nullable: row k of B is B[b_rows[k]]; bf16 x bf16, M, N % 128 == 0 */,
+                            float* C, int64_t ldc, int64_t strideC,
                             const int32_t* group_ptr, int32_t G, void* stream);
 /* bf16-mode streaming form of the tall "activation x small weight" products (GCNConv.lin, heads, RGCNConv root and
  * per-relation weights; forward and input gradient): C[M,N] = epi(alpha * A[M,K] @ Wt[N,K]^T).  A is fp32 or bf16
@@ -107,6 +109,7 @@ int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N, const void
 int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w, int64_t rows, int64_t cols, int32_t batch,
                        int32_t transpose, void* out, int64_t ldo, int64_t stride_o, void* stream);
 int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const void* A, int32_t a_is_bf16, int64_t lda,
+                const int32_t* a_rows /* nullable: output row m reads A[a_rows[m]] (a gathered operand, never stored) */,
                 const void* Wt, int64_t ldw, int64_t stride_w, const int32_t* group_ptr, int32_t G, float beta, void* C,
                 int32_t c_is_bf16, int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg,
                 float gate_scale, void* stream);

@@ -249,3 +249,24 @@ def test_masked_bf16_features():
     assert torch.equal(ops.masked_bf16(x, 0.0, 5, 0), x.bfloat16())
     # column / row structure: no column or row is masked as a whole (element-wise mask, reference gcl.py:42,76)
     assert float(kept.float().mean(0).min()) > 0.5 and float(kept.float().mean(1).min()) > 0.5
+
+
+def test_gathered_operands_equal_the_materialised_gather():
+    """RGCNConv backward reads dY[s] = dOut[dst_s] through the index instead of storing it: same numbers."""
+    from biomedkg_amd import ops
+    torch.manual_seed(31)
+    n, s_rows, g = 5000, 9000, 5
+    sizes = [0, 3000, 1, 4999, 1000]
+    gptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=DEV)
+    idx = torch.randint(0, n, (s_rows,), device=DEV, dtype=torch.int32)
+    dout = torch.randn(n, 256, device=DEV).bfloat16()
+    h = torch.randn(s_rows, 256, device=DEV).bfloat16()
+    w = torch.randn(g, 256, 256, device=DEV)
+    dy = dout[idx.long()]
+    assert ops.gathered_k_ok(h, dout)
+    a = ops.gemm_grouped_k(h, dout, gptr, g, b_rows=idx)
+    b = ops.gemm_grouped_k(h, dy, gptr, g)
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-3)            # f32 atomics: order of the K splits
+    c = ops.gemm_grouped_rows(dout, w, gptr, trans_b=True, a_rows=idx, out_dtype=torch.bfloat16)
+    d = ops.gemm_grouped_rows(dy, w, gptr, trans_b=True, out_dtype=torch.bfloat16)
+    assert torch.equal(c, d)
