@@ -49,7 +49,7 @@ SIGNATURES = {
     "bkg_gemm_tn_bf16": (I32, [I64, I64, I64, P, I32, I64, P, I32, I64, P, I64, P]),
     "bkg_gemm_grouped_k_bf16": (I32, [I64, I64, I64, P, I32, I64, P, I32, I64, P, P, I64, I64, P, I32, P]),
     # gemm_xw.hip
-    "bkg_weight_to_bf16": (I32, [P, I64, I64, I64, I64, I32, I32, P, I64, I64, P]),
+    "bkg_weight_to_bf16": (I32, [P, I64, I64, I64, I64, I32, P, I64, I64, P, I64, I64, P]),
     "bkg_gemm_xw": (I32, [I64, I64, I64, F32, P, I32, I64, P, P, I64, I64, P, I32, F32, P, I32, I64, P, I32, P, I64, F32, P]),
     # kge.hip
     "bkg_kge_score_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, P]),

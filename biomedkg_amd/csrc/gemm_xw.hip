@@ -248,11 +248,11 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
 
 // weights -> the [N][K] bf16 image the kernel above reads (a 64 x 64 patch per block through LDS)
 __global__ __launch_bounds__(256) void weight_to_bf16_kernel(const float* __restrict__ W, int64_t ldw, int64_t stride_w,
-                                                             int rows, int cols, int transpose, __bf16* __restrict__ out,
-                                                             int64_t ldo, int64_t stride_o) {
+                                                             int rows, int cols, __bf16* __restrict__ out, int64_t ldo,
+                                                             int64_t stride_o, __bf16* __restrict__ out_t, int64_t ldt,
+                                                             int64_t stride_t) {
   __shared__ float t[64][65];
   const float* Wb = W + (int64_t)blockIdx.z * stride_w;
-  __bf16* ob = out + (int64_t)blockIdx.z * stride_o;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int r = e / 64, c = e % 64;
@@ -261,11 +261,10 @@ __global__ __launch_bounds__(256) void weight_to_bf16_kernel(const float* __rest
   __syncthreads();
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int a = e / 64, b = e % 64;
-    if (!transpose) {
-      if (r0 + a < rows && c0 + b < cols) ob[(int64_t)(r0 + a) * ldo + c0 + b] = (__bf16)t[a][b];
-    } else {
-      if (c0 + a < cols && r0 + b < rows) ob[(int64_t)(c0 + a) * ldo + r0 + b] = (__bf16)t[b][a];
-    }
+    if (out && r0 + a < rows && c0 + b < cols)
+      out[(int64_t)blockIdx.z * stride_o + (int64_t)(r0 + a) * ldo + c0 + b] = (__bf16)t[a][b];
+    if (out_t && c0 + a < cols && r0 + b < rows)
+      out_t[(int64_t)blockIdx.z * stride_t + (int64_t)(c0 + a) * ldt + r0 + b] = (__bf16)t[b][a];
   }
 }
 
@@ -274,12 +273,14 @@ __global__ __launch_bounds__(256) void weight_to_bf16_kernel(const float* __rest
 using namespace bkg;
 
 extern "C" int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w, int64_t rows, int64_t cols,
-                                  int32_t batch, int32_t transpose, void* out, int64_t ldo, int64_t stride_o,
-                                  void* stream) {
+                                  int32_t batch, void* out, int64_t ldo, int64_t stride_o, void* out_t, int64_t ldt,
+                                  int64_t stride_t, void* stream) {
   BKG_ARG(rows > 0 && cols > 0 && batch > 0 && rows < (1 << 24) && cols < (1 << 24), "bkg_weight_to_bf16: bad shape");
+  BKG_ARG(out || out_t, "bkg_weight_to_bf16: no output");
   dim3 grid(ceil_div(cols, 64), ceil_div(rows, 64), batch);
   hipLaunchKernelGGL(weight_to_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, stride_w, (int)rows,
-                     (int)cols, transpose, reinterpret_cast<__bf16*>(out), ldo, stride_o);
+                     (int)cols, reinterpret_cast<__bf16*>(out), ldo, stride_o, reinterpret_cast<__bf16*>(out_t), ldt,
+                     stride_t);
   return check_launch("bkg_weight_to_bf16");
 }
 

@@ -36,23 +36,22 @@ def _f32c(t):
 # ----------------------------------------------------------------------------- raw kernels
 def _weight_bf16(w, transpose):
     """bf16 ``[.., N, K]`` image of a (batch of) weight matrix for ``bkg_gemm_xw`` -- ``w`` itself when it is stored
-    ``[N, K]``, its transpose when stored ``[K, N]``.  One tiny launch per (weight version, orientation)."""
+    ``[N, K]``, its transpose when stored ``[K, N]``.  One tiny launch per weight version writes BOTH orientations
+    (the forward needs one, the backward the other)."""
     cache = getattr(w, "_bkg_w16", None)
-    if cache is None:
-        cache = {}
+    key = (w.data_ptr(), w._version)
+    if cache is None or cache[0] != key:
+        w3 = w if w.dim() == 3 else w.unsqueeze(0)
+        batch, rows, cols = w3.shape
+        plain = torch.empty(batch, rows, cols, dtype=torch.bfloat16, device=w.device)
+        trans = torch.empty(batch, cols, rows, dtype=torch.bfloat16, device=w.device)
+        L.call("bkg_weight_to_bf16", L.ptr(w3), w3.stride(1), w3.stride(0), rows, cols, batch, L.ptr(plain), plain.stride(1),
+               plain.stride(0), L.ptr(trans), trans.stride(1), trans.stride(0), L.stream())
+        if w.dim() == 2:
+            plain, trans = plain[0], trans[0]
+        cache = (key, plain, trans)
         w._bkg_w16 = cache
-    key = (w.data_ptr(), w._version, bool(transpose))
-    hit = cache.get(transpose)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    w3 = w if w.dim() == 3 else w.unsqueeze(0)
-    batch, rows, cols = w3.shape
-    out = torch.empty((batch, cols, rows) if transpose else (batch, rows, cols), dtype=torch.bfloat16, device=w.device)
-    L.call("bkg_weight_to_bf16", L.ptr(w3), w3.stride(1), w3.stride(0), rows, cols, batch, int(transpose), L.ptr(out),
-           out.stride(1), out.stride(0), L.stream())
-    out = out if w.dim() == 3 else out[0]
-    cache[transpose] = (key, out)
-    return out
+    return cache[2] if transpose else cache[1]
 
 
 def _xw_ok(a, m, n, k):

@@ -107,7 +107,9 @@ int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N, const void
  * W + b*stride_w of shape [rows, cols]), C is fp32 or bf16 (c_is_bf16; beta needs fp32).  K % 256 == 0, N % 32 == 0,
  * 16-byte aligned rows.  group_ptr != NULL: rows of group g use Wt + g*stride_w (device group_ptr[G+1]). */
 int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w, int64_t rows, int64_t cols, int32_t batch,
-                       int32_t transpose, void* out, int64_t ldo, int64_t stride_o, void* stream);
+                       void* out /* [batch, rows, cols] bf16, nullable */, int64_t ldo, int64_t stride_o,
+                       void* out_t /* [batch, cols, rows] bf16 (transposed), nullable */, int64_t ldt, int64_t stride_t,
+                       void* stream);
 int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const void* A, int32_t a_is_bf16, int64_t lda,
                 const int32_t* a_rows /* nullable: output row m reads A[a_rows[m]] (a gathered operand, never stored) */,
                 const void* Wt, int64_t ldw, int64_t stride_w, const int32_t* group_ptr, int32_t G, float beta, void* C,
