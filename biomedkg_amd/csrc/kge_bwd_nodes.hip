@@ -33,6 +33,8 @@ struct KnTriplets {
   const int64_t* tail;
   const int64_t* rel;
   int64_t T;
+  const int4* rec;   // nullable: {head, tail, rel, bits(g)} per triplet (written by the fused forward pass); when given
+                     // it replaces head / tail / rel / gscore -- one 16-byte gather per incidence instead of four
 };
 
 // z^_i (TransE) of lane `lig`'s columns
@@ -130,9 +132,16 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict_
   auto fields = [&](int e, int64_t& o, int64_t& r, float& gg, bool& hd) {
     hd = e < tr.T;
     const int64_t t = hd ? e : e - tr.T;
-    o = hd ? tr.tail[t] : tr.head[t];
-    r = tr.rel[t];
-    gg = gscore[t];
+    if (tr.rec) {
+      const int4 v = tr.rec[t];
+      o = hd ? v.y : v.x;
+      r = v.z;
+      gg = __int_as_float(v.w);
+    } else {
+      o = hd ? tr.tail[t] : tr.head[t];
+      r = tr.rel[t];
+      gg = gscore[t];
+    }
   };
   if (start < end) {
 #pragma unroll
@@ -261,7 +270,7 @@ using namespace bkg;
 extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes,
                                      int32_t d, const int64_t* head, const int64_t* tail, const int64_t* rel,
                                      int64_t T, const float* rel_emb, int64_t ldr, const float* gscore,
-                                     const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm, float* dz,
+                                     const void* rec, const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm, float* dz,
                                      int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
                                      void* stream) {
   BKG_ARG(kind == KN_DISTMULT || kind == KN_TRANSE, "bkg_kge_bwd_nodes_f32: bad kind");
@@ -271,7 +280,7 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_b
               (ldr % 4 == 0) && ((uintptr_t)dz % 16 == 0) && (lddz % 4 == 0), "bkg_kge_bwd_nodes_f32: alignment");
   BKG_ARG(!split || (partials && ((uintptr_t)partials % 16 == 0)), "bkg_kge_bwd_nodes_f32: splitting needs partials");
   if (n_nodes == 0) return 0;
-  KnTriplets tr{head, tail, rel, T};
+  KnTriplets tr{head, tail, rel, T, reinterpret_cast<const int4*>(rec)};
   hipStream_t s = (hipStream_t)stream;
   dim3 block(256);
   bkg_rowsplit none{};

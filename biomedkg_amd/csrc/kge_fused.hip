@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const T* __restrict_
                                                             float inv_t, const float* __restrict__ rel_emb,
                                                             int64_t ldr, int n_rel, const int32_t* __restrict__ order,
                                                             const int32_t* __restrict__ rel_ptr, int chunk,
-                                                            float* __restrict__ score, float* __restrict__ g_out,
+                                                            float* __restrict__ score, float* __restrict__ g_out, int4* __restrict__ rec,
                                                             float* __restrict__ loss_part, float* __restrict__ drel,
                                                             int64_t lddr) {
   constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q;
@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const T* __restrict_
         const float g = lv[u] ? (sig - label) * inv_t : 0.f;
         if (lv[u] && lig == 0) {
           score[tt[u]] = s;
-          g_out[tt[u]] = g;
+          if (g_out) g_out[tt[u]] = g;
+          // packed copy of the triplet for the node-side backward: one 16-byte gather there instead of four
+          if (rec) rec[tt[u]] = make_int4((int)hh[u], (int)ta[u], r, __float_as_int(g));
           loss_acc += fmaxf(s, 0.f) - s * label + log1pf(e);
         }
         if (KIND == KF_DISTMULT) {
@@ -182,7 +184,7 @@ extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const void* z, int32_t z_is_b
                                      const int64_t* head, const int64_t* tail, int64_t T, float label,
                                      float inv_total, const float* rel_emb, int64_t ldr, int32_t n_rel,
                                      const int32_t* order, const int32_t* rel_ptr, float* score, float* g,
-                                     float* loss_part, float* drel, int64_t lddr, void* stream) {
+                                     void* rec, float* loss_part, float* drel, int64_t lddr, void* stream) {
   BKG_ARG(kind == KF_DISTMULT || kind == KF_TRANSE, "bkg_kge_fused_bce_f32: bad kind");
   const int epl = z_is_bf16 ? 8 : 4;
   BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) &&
@@ -195,7 +197,8 @@ extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const void* z, int32_t z_is_b
   dim3 grid((unsigned)(bkg_kge_fused_bce_waves(T, n_rel) / 4)), block(256);
 #define KF_LAUNCH(TT, K)                                                                                            \
   hipLaunchKernelGGL((kge_fused_bce_kernel<TT, K, LPR, VPL>), grid, block, 0, s, (const TT*)z, ldz, head, tail, T, \
-                     label, inv_total, rel_emb, ldr, n_rel, order, rel_ptr, CH, score, g, loss_part, drel, lddr)
+                     label, inv_total, rel_emb, ldr, n_rel, order, rel_ptr, CH, score, g, reinterpret_cast<int4*>(rec), loss_part,  \
+                     drel, lddr)
   BKG_PIECE_DISPATCH_(d / epl, 8, 16, {
     if (z_is_bf16) { if (kind == KF_DISTMULT) KF_LAUNCH(__bf16, KF_DISTMULT); else KF_LAUNCH(__bf16, KF_TRANSE); }
     else { if (kind == KF_DISTMULT) KF_LAUNCH(float, KF_DISTMULT); else KF_LAUNCH(float, KF_TRANSE); }

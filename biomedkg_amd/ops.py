@@ -629,7 +629,7 @@ class _KgeScore(torch.autograd.Function):
             sp = inc.split
             partials = sp.partials(d, z.device) if sp is not None else None
             L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), 0, z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
-                   L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), L.ptr(l1), L.ptr(inc.rowptr), L.ptr(inc.perm),
+                   L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), None, L.ptr(l1), L.ptr(inc.rowptr), L.ptr(inc.perm),
                    L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None), L.ptr(partials), 0, L.stream())
         if ctx.needs_input_grad[1]:
             drel = torch.zeros_like(rel_emb)
@@ -682,11 +682,15 @@ class _KgeBceLoss(torch.autograd.Function):
         # bf16 mode: both passes gather the node rows from a bf16 copy of z (half the bytes; fp32 accumulate)
         zt = to_bf16(z) if (bf16_storage() and d % 8 == 0 and (d // 8) in _KGE_PIECES) else z
         zt_bf16 = int(zt.dtype == torch.bfloat16)
-        scores, grads, loss = [], [], torch.zeros((), dtype=torch.float64, device=dev)
+        scores, grads, recs, loss = [], [], [], torch.zeros((), dtype=torch.float64, device=dev)
+        # packed {head, tail, rel, g} per triplet for the node-side backward (ids fit int32; one gather instead of four)
+        pack = bool(ctx.needs_input_grad[0]) and n < (1 << 31) and r < (1 << 31)
         for ei, et, label in ((pos_ei, pos_et, 1.0), (neg_ei, neg_et, 0.0)):
             t = ei.size(1)
             s = torch.empty(t, dtype=torch.float32, device=dev)
-            g = torch.empty(t, dtype=torch.float32, device=dev)
+            rec = torch.empty(t, 4, dtype=torch.int32, device=dev) if (pack and t) else None
+            g = torch.empty(t if rec is None else 0, dtype=torch.float32, device=dev)   # g travels inside rec when packed
+            recs.append(rec)
             if t:
                 order, rel_ptr = relation_order_of(et, r)
                 waves = L.lib().bkg_kge_fused_bce_waves(t, r)
@@ -695,7 +699,8 @@ class _KgeBceLoss(torch.autograd.Function):
                 wave_ptr, wave_iota, wave_split = _relation_waves(et, rel_ptr, r, waves)
                 L.call("bkg_kge_fused_bce_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]), t,
                        label, 1.0 / total, L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order), L.ptr(rel_ptr), L.ptr(s),
-                       L.ptr(g), L.ptr(part), L.ptr(drel_part), drel_part.stride(0), L.stream())
+                       L.ptr(g) if rec is None else None, L.ptr(rec), L.ptr(part), L.ptr(drel_part), drel_part.stride(0),
+                       L.stream())
                 loss = loss + part.double().sum()
                 # per-relation sum of the waves' partial rows (consecutive waves; fixed order; no atomics)
                 drel = drel + spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
@@ -703,13 +708,13 @@ class _KgeBceLoss(torch.autograd.Function):
             grads.append(g)
         ctx.kind = kind
         ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
-        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel)
+        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1])
         ctx.mark_non_differentiable(scores[0], scores[1])
         return (loss / total).float(), scores[0], scores[1]
 
     @staticmethod
     def backward(ctx, gloss, _gp, _gn):
-        zt, rel_emb, g_pos, g_neg, drel = ctx.saved_tensors
+        zt, rel_emb, g_pos, g_neg, drel, rec_pos, rec_neg = ctx.saved_tensors
         pos_ei, pos_et, neg_ei, neg_et = ctx.graphs
         kind = ctx.kind
         n, d = zt.size(0), zt.size(1)
@@ -726,14 +731,15 @@ class _KgeBceLoss(torch.autograd.Function):
                     L.call("bkg_row_l1norm_f32", L.ptr(z), z.stride(0), n, d, L.ptr(l1), L.stream())
             dz = torch.empty(n, d, dtype=torch.float32, device=z.device)
             first = True
-            for ei, et, g in ((pos_ei, pos_et, g_pos), (neg_ei, neg_et, g_neg)):
+            for ei, et, g, rec in ((pos_ei, pos_et, g_pos, rec_pos), (neg_ei, neg_et, g_neg, rec_neg)):
                 if ei.size(1) == 0:
                     continue
                 inc = incidence_of(ei, n)
                 sp = inc.split
                 partials = sp.partials(d, z.device) if sp is not None else None
                 L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]),
-                       L.ptr(et), ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), L.ptr(g), L.ptr(l1), L.ptr(inc.rowptr),
+                       L.ptr(et), ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), L.ptr(g), L.ptr(rec), L.ptr(l1),
+                       L.ptr(inc.rowptr),
                        L.ptr(inc.perm), L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None),
                        L.ptr(partials), 0 if first else 1, L.stream())
                 first = False

@@ -135,7 +135,10 @@ int bkg_row_l1norm_f32(const float* z, int64_t ldz, int64_t n, int32_t d, float*
 int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z /* fp32 or bf16 table */, int32_t z_is_bf16, int64_t ldz,
                           int64_t n_nodes, int32_t d, const int64_t* head,
                           const int64_t* tail, const int64_t* rel, int64_t T, const float* rel_emb, int64_t ldr,
-                          const float* gscore, const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm,
+                          const float* gscore,
+                          const void* rec /* nullable int32[T][4] {head, tail, rel, bits(g)} from the fused pass: replaces
+                                             head / tail / rel / gscore (one 16-byte gather per incidence) */,
+                          const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm,
                           float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
                           void* stream);
 /* Fused training pass for one label (1 = positives, 0 = negatives): score[T], g[T] = (sigmoid(s) - label) *
@@ -148,7 +151,9 @@ int bkg_kge_fused_bce_f32(int32_t kind, const void* z /* fp32 or bf16 table */, 
                           int32_t d, const int64_t* head,
                           const int64_t* tail, int64_t T, float label, float inv_total, const float* rel_emb,
                           int64_t ldr, int32_t n_rel, const int32_t* order, const int32_t* rel_ptr, float* score,
-                          float* g, float* loss_part, float* drel, int64_t lddr, void* stream);
+                          float* g /* nullable when rec is given */,
+                          void* rec /* nullable int32[T][4]: {head, tail, rel, bits(g)} for the backward */,
+                          float* loss_part, float* drel, int64_t lddr, void* stream);
 /* drel[r] += sum_t ... (drel zeroed by the caller); order/rel_ptr (nullable together) = triplet ids sorted by
  * relation and the [n_rel+1] offsets of each relation in that order */
 int bkg_kge_bwd_rel_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, const int64_t* head, const int64_t* tail,
