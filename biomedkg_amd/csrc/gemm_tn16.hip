@@ -18,7 +18,10 @@ typedef float t16_acc_t __attribute__((ext_vector_type(16)));
 typedef __bf16 t16_bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short t16_s4_t __attribute__((ext_vector_type(4)));
 
-constexpr int T16_BK = 32;     // k rows per stage
+constexpr int T16_BK = 32;             // k rows per stage
+constexpr int T16_BLOCKS = 768;        // blocks per launch = 3 per CU = what is resident at once (measured: one full
+                                       // wave of blocks beats 1024 or 1536 by 15-25 %)
+constexpr int T16_NP = T16_BK / 16;    // 16-byte pieces per thread and operand
 constexpr int T16_BT = 128;    // tile width (m and n)
 
 __device__ __forceinline__ int t16_off(int row, int ch) {     // byte offset of 16-byte chunk ch of row `row`
@@ -53,20 +56,22 @@ __device__ __forceinline__ void gemm_tn16_tile(const __bf16* __restrict__ A, int
   // staging: 32 rows x 16 chunks = 512 pieces per operand, two per thread
   // b_rows (nullable): contracted row k of B is B[b_rows[k]] (RGCNConv backward: dY[s] = dOut[dst_s], never stored);
   // the indices of the NEXT stage are fetched with the current stage's rows so the dependent load is off the path
-  uint4 ra[2], rb[2];
-  int bi[2];
+  uint4 ra[T16_NP], rb[T16_NP];
+  int bi[T16_NP];
   auto rows_of = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < T16_NP; ++i) {
       const int k = k0 + ((threadIdx.x + i * 256) >> 4);
       bi[i] = (b_rows && k < kend) ? b_rows[k] : k;
     }
   };
   auto load = [&](int k0) {
-    int cur[2] = {bi[0], bi[1]};
+    int cur[T16_NP];
+#pragma unroll
+    for (int i = 0; i < T16_NP; ++i) cur[i] = bi[i];
     if (b_rows) rows_of(k0 + T16_BK);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < T16_NP; ++i) {
       const int p = threadIdx.x + i * 256, row = p >> 4, ch = p & 15;
       const int k = k0 + row;
       ra[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -82,7 +87,7 @@ __device__ __forceinline__ void gemm_tn16_tile(const __bf16* __restrict__ A, int
   for (int k0 = kbeg; k0 < kend; k0 += T16_BK) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < T16_NP; ++i) {
       const int p = threadIdx.x + i * 256, row = p >> 4, ch = p & 15;
       *reinterpret_cast<uint4*>(As + t16_off(row, ch)) = ra[i];
       *reinterpret_cast<uint4*>(Bs + t16_off(row, ch)) = rb[i];
@@ -159,7 +164,7 @@ void launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int
                              float* C, int64_t ldc, hipStream_t s) {
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   const int64_t tiles = (M / T16_BT) * (N / T16_BT);
-  int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 1024 / tiles));
+  int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, T16_BLOCKS / tiles));
   const int kchunk = (int)(((K + nsplit - 1) / nsplit + T16_BK - 1) / T16_BK * T16_BK);
   nsplit = (K + kchunk - 1) / kchunk;
   hipLaunchKernelGGL(gemm_tn16_splitk_kernel, dim3(xcd_grid(nsplit, tiles)), dim3(256), 0, s, (const __bf16*)A, lda,
@@ -170,8 +175,8 @@ void launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const vo
                               int64_t ldb, const int32_t* b_rows, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
                               hipStream_t s) {
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
-  constexpr int KCHUNK = 1024;
   const int64_t tiles = (M / T16_BT) * (N / T16_BT);
+  constexpr int KCHUNK = 1024;   // (a chunk sized for 768 blocks is slower here: the relations' row counts are skewed)
   hipLaunchKernelGGL(gemm_tn16_grouped_kernel, dim3(xcd_grid(ceil_div(rows_total, KCHUNK) + G, tiles)), dim3(256), 0, s,
                      (const __bf16*)A, lda, (const __bf16*)B, ldb, b_rows, C, ldc, strideC, group_ptr, G, (int)M, (int)N,
                      KCHUNK, ep);
