@@ -136,22 +136,26 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int s = 0; s < n_slabs; ++s) {
-      const int k0 = s * XW_KS, steps = min(XW_KS, g.K - k0) / 16;
+      const int k0 = s * XW_KS;
       if (have_slab != s) {   // block-uniform
         __syncthreads();      // every wave is done with the previous slab
         {
-          // 16-byte pieces, 32 per row: one wave-instruction copies two whole 512-byte rows of the slab
+          // 16-byte pieces, 32 per row: one wave-instruction copies two whole 512-byte rows of the slab.  All 16
+          // loads of a thread are issued before the first LDS store (a load / store pair per iteration makes the
+          // compiler wait for each load in turn: 16 serial L2 round trips per block).
           const int pc = threadIdx.x % (XW_KS / 8), r_in = threadIdx.x / (XW_KS / 8);
           const __bf16* src = Wg + k0 + pc * 8;
-          const bool live = pc * 8 < steps * 16;
-#pragma unroll 4
-          for (int i = 0; i < (XW_BN * XW_KS / 8) / 256; ++i) {
-            const int row = r_in + i * (256 / (XW_KS / 8));
-            xw_bf16x8_t v;
+          constexpr int NP = (XW_BN * XW_KS / 8) / 256, RS = 256 / (XW_KS / 8);
+          constexpr int NB = sizeof(AT) == 4 ? 4 : 2;   // batches of 4 / 8 loads (the accumulators are live: registers)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-            if (live) v = *reinterpret_cast<const xw_bf16x8_t*>(src + (int64_t)min(n0 + row, g.N - 1) * g.ldw);
-            *reinterpret_cast<xw_bf16x8_t*>(&Bs[row][pc * 8]) = v;
+          for (int h = 0; h < NB; ++h) {
+            xw_bf16x8_t v[NP / NB];
+#pragma unroll
+            for (int i = 0; i < NP / NB; ++i)
+              v[i] = *reinterpret_cast<const xw_bf16x8_t*>(src + (int64_t)min(n0 + r_in + (h * (NP / NB) + i) * RS, g.N - 1) * g.ldw);
+#pragma unroll
+            for (int i = 0; i < NP / NB; ++i)
+              *reinterpret_cast<xw_bf16x8_t*>(&Bs[r_in + (h * (NP / NB) + i) * RS][pc * 8]) = v[i];
           }
         }
         __syncthreads();
