@@ -73,17 +73,14 @@ def main():
     sizes[0] += s - sizes.sum()
     gptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)]).to(torch.int32).to(dev)
     h, wt, dy = torch.randn(s, 256, device=dev), torch.randn(g, 256, 256, device=dev), torch.randn(s, 256, device=dev)
-    for name, fn, flops, byt in (
-            ("grouped_rows", lambda: ops.gemm_grouped_rows(h, wt, gptr), 2.0 * s * 256 * 256, 8.0 * s * 256),
-            ("grouped_rows_T", lambda: ops.gemm_grouped_rows(dy, wt, gptr, trans_b=True), 2.0 * s * 256 * 256, 8.0 * s * 256),
-            ("grouped_k", lambda: ops.gemm_grouped_k(h, dy, gptr, g), 2.0 * s * 256 * 256, 8.0 * s * 256),
-            ("grouped_k bf16 x bf16", lambda: ops.gemm_grouped_k(h.bfloat16(), dy.bfloat16(), gptr, g) if False else None,
-             0.0, 1.0)):
-        if fn() is None and name.endswith("bf16"):
-            if prec != "bf16":
-                continue
-            h16, dy16 = h.bfloat16(), dy.bfloat16()
-            fn, flops, byt = (lambda: ops.gemm_grouped_k(h16, dy16, gptr, g)), 2.0 * s * 256 * 256, 4.0 * s * 256
+    cases = [("grouped_rows", lambda: ops.gemm_grouped_rows(h, wt, gptr), 2.0 * s * 256 * 256, 8.0 * s * 256),
+             ("grouped_rows_T", lambda: ops.gemm_grouped_rows(dy, wt, gptr, trans_b=True), 2.0 * s * 256 * 256, 8.0 * s * 256),
+             ("grouped_k", lambda: ops.gemm_grouped_k(h, dy, gptr, g), 2.0 * s * 256 * 256, 8.0 * s * 256)]
+    if prec == "bf16":
+        h16, dy16 = h.bfloat16(), dy.bfloat16()
+        cases.append(("grouped_k bf16 x bf16", lambda: ops.gemm_grouped_k(h16, dy16, gptr, g), 2.0 * s * 256 * 256,
+                      4.0 * s * 256))
+    for name, fn, flops, byt in cases:
         ms = timeit(fn)
         print(json.dumps({"kernel": name, "precision": prec, "S": s, "G": g, "ms": round(ms, 4),
                           "TFLOPs": round(flops / ms / 1e9, 1), "GBs_io": round(byt / ms / 1e6)}))
