@@ -44,7 +44,9 @@ class GradBucket:
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self._flat = None
 
-    def all_reduce(self):
+    def begin(self):
+        """Pack the gradients into the flat bucket and start the all-reduce (asynchronously: the collective runs on
+        the backend's own stream / thread).  ``finish`` must be called before the gradients are used."""
         if self.world == 1:
             return
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
@@ -55,14 +57,27 @@ class GradBucket:
         for g in grads:
             self._flat[off:off + g.numel()].copy_(g.reshape(-1))
             off += g.numel()
-        dist.all_reduce(self._flat)
+        self._grads = grads
+        self._work = dist.all_reduce(self._flat, async_op=True)
+
+    def finish(self):
+        """Wait for the collective started by ``begin`` and write the averaged gradients back."""
+        if self.world == 1 or getattr(self, "_work", None) is None:
+            return
+        self._work.wait()
+        self._work = None
         self._flat.div_(self.world)
         off = 0
-        for p, g in zip(self.params, grads):
+        for p, g in zip(self.params, self._grads):
             if p.grad is None:
                 p.grad = torch.empty_like(p)
             p.grad.copy_(self._flat[off:off + g.numel()].view_as(p))
             off += g.numel()
+        self._grads = None
+
+    def all_reduce(self):
+        self.begin()
+        self.finish()
 
 
 def broadcast_parameters(module, src=0):
