@@ -12,7 +12,9 @@ positive, BCE + L2 reg) over the same synthetic PrimeKG++-shaped graph (BASELINE
 Adam, inputs resident in HBM.  ``value`` = input edges / step time (every input edge counted once
 although both sub-steps consume it), whole job.  N > 1: one process per GPU, each rank owns its
 own graph of the same shape (weak scaling, the reference's Lightning-DDP regime) and gradients are
-all-reduced over RCCL every sub-step.
+all-reduced over RCCL every sub-step (the KGE bucket asynchronously, under the next GGD sub-step).
+Default ``--precision bf16`` = BASELINE's "bf16 storage / fp32 accumulate" configuration; ``--precision fp32``
+is the exact parity mode.
 
 Also reported on the same JSON line: ``roofline`` for the dominant HBM kernel (the R-GCN
 segment-mean gather/aggregate launch, timed with HIP events on the launch stream inside the timed

@@ -8,11 +8,12 @@
 // the label, the relation-side gradient can be accumulated in the scoring pass itself, leaving one more
 // pass for the node side (kge_bwd_nodes.hip, fed with the g written here).  Triplets are visited in
 // relation-sorted order so that a wave owns a slice of ONE relation and keeps its d rel_emb partial in
-// registers (one 1-KiB atomic flush per <= 256 triplets).
+// registers (stored as one partial row per wave; the caller segment-reduces the waves of a relation).
 //
 // The node table z is fp32 or bf16 (rowpiece.h); rel_emb, scores and all gradients are fp32.
 // One launch per label (positives y = 1, negatives y = 0).  Outputs: score[T] (original triplet order),
-// g[T] = (sigmoid(s) - y) * inv_total, loss_part[n_waves] (sum it, multiply by inv_total) and
+// g[T] = (sigmoid(s) - y) * inv_total (or, for the node-side backward, one packed int4 record {head, tail, rel,
+// bits(g)} per triplet: a single 16-byte gather per incidence there), loss_part[n_waves] (sum it, multiply by inv_total) and
 // drel_part[n_waves, d]: wave w's partial of d rel_emb[r(w)], where relation r owns the consecutive waves
 // [sum_{q<r} ceil(cnt_q / 64), ...) -- rows of waves without work are left unwritten and are never read.
 // The caller reduces drel_part per relation and multiplies by the upstream gradient of the loss.
