@@ -63,11 +63,26 @@ struct XwArgs {
   int persist;   // row-tile stride of the persistent loop (plain mode)
 };
 
-__device__ __forceinline__ void xw_store(float* dst, const float4& v) { *reinterpret_cast<float4*>(dst) = v; }
-__device__ __forceinline__ void xw_store(__bf16* dst, const float4& v) {
+// Two adjacent accumulator quads of one lane (columns 8q + 4lh + 0..3 and 8(q+1) + 4lh + 0..3 of a 16-column group).
+// fp32 C: two 16-byte stores.  bf16 C: the lane pair (lh = 0 / 1, same row) swaps one packed quad so that each lane owns
+// 8 CONSECUTIVE columns and writes one 16-byte piece -- 8-byte pieces cost 17-19 us per launch at 130k x 256.
+__device__ __forceinline__ void xw_store_pair(float* base, int lh, const float4& v0, const float4& v1) {
+  *reinterpret_cast<float4*>(base + 4 * lh) = v0;
+  *reinterpret_cast<float4*>(base + 8 + 4 * lh) = v1;
+}
+__device__ __forceinline__ uint2 xw_pack4(const float4& v) {
   xw_bf16x4_t h;
   h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-  *reinterpret_cast<xw_bf16x4_t*>(dst) = h;
+  return __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ void xw_store_pair(__bf16* base, int lh, const float4& v0, const float4& v1) {
+  const uint2 p0 = xw_pack4(v0), p1 = xw_pack4(v1);
+  const uint2 give = lh ? p0 : p1;                       // lh 0 keeps columns 0..3, hands over 8..11; lh 1 the reverse
+  uint2 got;
+  got.x = __shfl_xor(give.x, 32, 64);
+  got.y = __shfl_xor(give.y, 32, 64);
+  const uint4 o = lh ? make_uint4(got.x, got.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, got.x, got.y);
+  *reinterpret_cast<uint4*>(base + 8 * lh) = o;          // lh 0: columns 0..7, lh 1: columns 8..15
 }
 
 // one 16-deep step: 4 weight fragments from LDS x 2 row fragments -> 8 MFMAs
@@ -199,15 +214,17 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
     for (int j = 0; j < XW_TM; ++j) {
       const int row = m_base + j * 32 + l31;
       if (row < m_hi) {
-        CT* __restrict__ drow = C + (int64_t)row * g.ldc + n0 + lh * 4;
+        CT* __restrict__ drow = C + (int64_t)row * g.ldc + n0;
         if (plain) {
 #pragma unroll
           for (int i = 0; i < XW_TN; ++i) {
             if (n0 + i * 32 < g.N) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                xw_store(drow + i * 32 + q * 8, make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                                                          acc[i][j][4 * q + 3]));
+              for (int qp = 0; qp < 2; ++qp)
+                xw_store_pair(drow + i * 32 + qp * 16, lh,
+                              make_float4(acc[i][j][8 * qp], acc[i][j][8 * qp + 1], acc[i][j][8 * qp + 2], acc[i][j][8 * qp + 3]),
+                              make_float4(acc[i][j][8 * qp + 4], acc[i][j][8 * qp + 5], acc[i][j][8 * qp + 6],
+                                          acc[i][j][8 * qp + 7]));
             }
           }
         } else {
@@ -217,30 +234,35 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
           for (int i = 0; i < XW_TN; ++i) {
             if (n0 + i * 32 < g.N) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int off = i * 32 + q * 8;
-                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                const float4 b = brow ? *reinterpret_cast<const float4*>(brow + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-                v.x = ep.alpha * v.x + b.x; v.y = ep.alpha * v.y + b.y; v.z = ep.alpha * v.z + b.z; v.w = ep.alpha * v.w + b.w;
-                if (ep.act == 1) {
-                  v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                } else if (ep.act == 2) {
-                  v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
-                  v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
-                }
-                if (grow) {
-                  const float4 gt = *reinterpret_cast<const float4*>(grow + off);
-                  v.x = gt.x > 0.f ? v.x * ep.gate_scale : 0.f; v.y = gt.y > 0.f ? v.y * ep.gate_scale : 0.f;
-                  v.z = gt.z > 0.f ? v.z * ep.gate_scale : 0.f; v.w = gt.w > 0.f ? v.w * ep.gate_scale : 0.f;
-                }
-                if constexpr (sizeof(CT) == 4) {
-                  if (ep.beta != 0.f) {
-                    const float4 o = *reinterpret_cast<const float4*>(drow + off);
-                    v.x = fmaf(ep.beta, o.x, v.x); v.y = fmaf(ep.beta, o.y, v.y);
-                    v.z = fmaf(ep.beta, o.z, v.z); v.w = fmaf(ep.beta, o.w, v.w);
+              for (int qp = 0; qp < 2; ++qp) {
+                float4 vv[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const int q = 2 * qp + h, off = i * 32 + q * 8;
+                  float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                  const float4 b = brow ? *reinterpret_cast<const float4*>(brow + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                  v.x = ep.alpha * v.x + b.x; v.y = ep.alpha * v.y + b.y; v.z = ep.alpha * v.z + b.z; v.w = ep.alpha * v.w + b.w;
+                  if (ep.act == 1) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                  } else if (ep.act == 2) {
+                    v.x = v.x > 0.f ? v.x : expm1f(v.x); v.y = v.y > 0.f ? v.y : expm1f(v.y);
+                    v.z = v.z > 0.f ? v.z : expm1f(v.z); v.w = v.w > 0.f ? v.w : expm1f(v.w);
                   }
+                  if (grow) {
+                    const float4 gt = *reinterpret_cast<const float4*>(grow + off);
+                    v.x = gt.x > 0.f ? v.x * ep.gate_scale : 0.f; v.y = gt.y > 0.f ? v.y * ep.gate_scale : 0.f;
+                    v.z = gt.z > 0.f ? v.z * ep.gate_scale : 0.f; v.w = gt.w > 0.f ? v.w * ep.gate_scale : 0.f;
+                  }
+                  if constexpr (sizeof(CT) == 4) {
+                    if (ep.beta != 0.f) {
+                      const float4 o = *reinterpret_cast<const float4*>(drow + off + lh * 4);
+                      v.x = fmaf(ep.beta, o.x, v.x); v.y = fmaf(ep.beta, o.y, v.y);
+                      v.z = fmaf(ep.beta, o.z, v.z); v.w = fmaf(ep.beta, o.w, v.w);
+                    }
+                  }
+                  vv[h] = v;
                 }
-                xw_store(drow + off, v);
+                xw_store_pair(drow + i * 32 + qp * 16, lh, vv[0], vv[1]);
               }
             }
           }

@@ -138,6 +138,7 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
   }
   const float scale = (ep.keep || ep.drop_p > 0.f) ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
   const uint32_t thresh = (uint32_t)fminf(ep.drop_p * 4294967296.0f, 4294967295.0f);
+  uint2 lo = make_uint2(0u, 0u);
 #pragma unroll
   for (int v = 0; v < VPL; ++v)
 #pragma unroll
@@ -168,7 +169,13 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         bf16x4 h;
         h[0] = (__bf16)a.x; h[1] = (__bf16)a.y; h[2] = (__bf16)a.z; h[3] = (__bf16)a.w;
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (int64_t)row * ldo + c) = h;
+        if constexpr (Q == 2) {     // the two quads of a 16-byte piece leave as ONE 16-byte store (8 columns)
+          if (q == 0) { lo = __builtin_bit_cast(uint2, h); continue; }
+          const uint2 hi = __builtin_bit_cast(uint2, h);
+          *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(out) + (int64_t)row * ldo + c - 4) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (int64_t)row * ldo + c) = h;
+        }
       } else {
         *reinterpret_cast<float4*>(out + (int64_t)row * ldo + c) = a;
       }
