@@ -98,3 +98,16 @@ def test_kge_module_uses_device_sampler():
         loss = m.training_step(batch, 0)
     loss.backward()
     assert torch.isfinite(loss)
+
+
+def test_degenerate_inputs():
+    from biomedkg_amd import rand as R, sampling
+    empty = torch.empty(2, 0, dtype=torch.int64, device=DEV)
+    assert sampling.negative_sampling(empty, 50, 0, seed=1).shape == (2, 0)          # nothing to draw
+    got = sampling.negative_sampling(empty, 50, 30, seed=1)                         # no positives at all
+    assert got.shape == (2, 30) and torch.unique(got[0] * 50 + got[1]).numel() == 30
+    one = torch.tensor([[3], [3]], device=DEV)
+    got = sampling.negative_sampling(one, 7, 48, seed=2)                            # every free cell of a 7 x 7 grid
+    keys = torch.unique(got[0] * 7 + got[1])
+    assert keys.numel() == got.size(1) and 24 not in keys.tolist()
+    assert R.DeviceRand(seed=1).shuffle(torch.empty(0, dtype=torch.int64, device=DEV)).numel() == 0
