@@ -14,6 +14,8 @@ ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 # loss-parity bar of BASELINE config 2 needs it), "bf16" = operands rounded to bf16 while staged into LDS,
 # fp32 accumulate and fp32 results in HBM (BASELINE config 3 throughput runs).
 _PRECISION = 0
+if __import__("os").environ.get("BKG_PRECISION", "fp32") == "bf16":   # e.g. BKG_PRECISION=bf16 python train_kge.py ...
+    _PRECISION = 1
 
 
 def set_matmul_precision(name: str):
