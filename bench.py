@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                     help="matrix-core operand precision (BASELINE configs[2] is the bf16 config; fp32 = exact mode)")
+    ap.add_argument("--mode", choices=["replicas", "partition"], default="replicas",
+                    help="replicas (default, what the contract measures): one graph per rank, gradient all-reduce only; "
+                         "partition: ONE graph with its nodes partitioned over the ranks (all-gather per conv layer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=int, default=16, help="CPU baseline runs on a 1/scale graph")
     return ap.parse_args()
@@ -92,6 +95,99 @@ def make_step(module, batch, world, overlap=False):
 
     step.finish = finish
     return step
+
+
+def run_partitioned(args, rank, world, dev):
+    """``--mode partition`` (SURVEY 8e / BASELINE configs[3]): ONE graph, nodes partitioned over the ranks, an
+    all-gather of the gather table per conv layer (reduce-scatter in backward), the scorer over each rank's share of
+    the triplets, weight gradients through the flat bucket.  Strong scaling: the total work is fixed.  The step is
+    the same pair of sub-steps as the default mode, minus GGD's optional augmentation (the edge mask would have to be
+    re-partitioned every step)."""
+    from biomedkg_amd import ops, partition as P, sampling, synthetic
+    from biomedkg_amd.distributed import GradBucket
+    from biomedkg_amd.gcl_module import GGDModule
+    from biomedkg_amd.kge_module import KGEModule
+    ops.set_matmul_precision(args.precision)
+    g = synthetic.primekg_like(args.nodes, args.edges, args.relations, seed=42)     # the same graph on every rank
+    n, e, r, h = g["num_nodes"], g["edge_index"].size(1), g["num_relations"], args.hidden
+    ei, et = g["edge_index"].to(dev), g["edge_type"].to(dev)
+    torch.manual_seed(42)
+    xk, xg = torch.randn(n, h, device=dev), torch.randn(n, 768, device=dev)
+    torch.manual_seed(1234)
+    kge = KGEModule("rgcn", "dismult", h, h, h, 2, r, 2, "cosine", 1e-3, 0.2, "none", args.neg_ratio, "random").to(dev)
+    gcl = GGDModule(in_dim=768, hidden_dim=h, out_dim=h, num_hidden_layers=2, fuse_method="none").to(dev)
+    kge.train(); gcl.train()
+    part = P.NodePartition(ei, n, rank, world)
+    pg = P.PartitionedGraph(part, ei, P.HipBackend)
+    prg = P.PartitionedRelGraph(part, ei, et, r, P.HipBackend)
+    share = slice(rank, None, world)                          # this rank's positives (strided: every relation on every rank)
+    pos_ei, pos_et = ei[:, share].contiguous(), et[share].contiguous()
+    seeds = torch.Generator().manual_seed(7)
+
+    def dropout_of(rows, cols, device):
+        return ops.Dropout(0.2, keep=None, seed=int(torch.randint(0, 1 << 31, (1,), generator=seeds)), stream_id=rank)
+
+    def make(params, loss_fn):
+        opt = torch.optim.Adam(params, lr=1e-3)
+        bucket = GradBucket(params, world)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn()
+            loss.backward()
+            bucket.all_reduce()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            return loss
+        return step
+
+    def ggd_loss():
+        perm = torch.randperm(n, generator=seeds).to(dev)     # CPU generator with a common seed: identical on all ranks
+        return P.ggd_loss_partitioned(gcl.model, xg, pg, P.HipBackend, perm, dropout_of)
+
+    def kge_loss():
+        k = args.neg_ratio * pos_ei.size(1)
+        neg = sampling.negative_sampling(ei, n, k, seed=int(torch.randint(0, 1 << 31, (1,), generator=seeds)) * world + rank)
+        nt = pos_et.repeat(args.neg_ratio)[torch.randperm(k, device=dev)]
+        return P.kge_loss_partitioned(kge.model, xk, prg, P.HipBackend, pos_ei, pos_et, neg, nt, kge.model.decoder.kind,
+                                      dropout_of)
+
+    step_g = make(list(gcl.model.parameters()), ggd_loss)
+    step_k = make(list(kge.model.parameters()), kge_loss)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step_g(); step_k()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lg = step_g(); lk = step_k()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    if rank == 0:
+        print(json.dumps({
+            "metric": "edges/sec, GCL (GGD) step + KGE (R-GCN+DistMult) step, PrimeKG++ scale", "value": e / (ms * 1e-3),
+            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"node-partitioned full graph N={n} E={e} R={r} over {world} ranks: all-gather of the "
+                                   "gather table per conv layer, reduce-scatter in backward, scorer over each rank's "
+                                   "share of the triplets; GGD without the optional augmentation",
+                       "parallelism": f"np{world}"},
+            "loss_gcl_rank0": float(lg.detach()), "loss_kge_rank0": float(lk.detach()),
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def pmc_traffic(kge_module, precision):
@@ -169,6 +265,9 @@ def main():
         backend = os.environ.get("BKG_BENCH_BACKEND", "nccl")
         kw = {"device_id": dev} if backend == "nccl" else {}
         torch.distributed.init_process_group(backend, **kw)
+
+    if args.mode == "partition":
+        return run_partitioned(args, rank, world, dev)
 
     from biomedkg_amd import ops, synthetic
     from biomedkg_amd.graph import rel_graph_of

@@ -221,3 +221,45 @@ class HipBackend:
     def grouped_linear(h, weight, group_ptr):
         from . import ops
         return ops.grouped_linear(h, weight, group_ptr)
+
+
+# ----------------------------------------------------------------------------- whole training steps over shards
+def ggd_loss_partitioned(ggd, x_full, pg: PartitionedGraph, backend, perm, dropout_of=None):
+    """``GGDModule.calculate_loss`` (reference gcl_module.py:229-234, gcl.py:73-93 without the optional augmentation)
+    for the rank's nodes: both encoder passes run over the rank's shard (all-gather per layer), the BCE terms of the
+    local nodes are summed and divided by the GLOBAL count, times ``world`` so that the bucket's gradient AVERAGE
+    equals the gradient of the whole-graph loss.  ``perm``: the corruption permutation of all N nodes (every rank
+    must pass the same one)."""
+    part = pg.part
+    x_pos = part.shard(x_full)
+    x_neg = x_full[perm[part.lo:part.hi]]
+    pos_h = gcn_encoder_partitioned(ggd.encoder, x_pos, pg, backend, dropout_of)
+    neg_h = gcn_encoder_partitioned(ggd.encoder, x_neg, pg, backend, dropout_of)
+    for layer in ggd.mlp[:-1]:
+        pos_h = torch.relu(backend.linear(pos_h, layer.weight, layer.bias))
+        neg_h = torch.relu(backend.linear(neg_h, layer.weight, layer.bias))
+    pos_h = backend.linear(pos_h, ggd.mlp[-1].weight, ggd.mlp[-1].bias).sum(1)
+    neg_h = backend.linear(neg_h, ggd.mlp[-1].weight, ggd.mlp[-1].bias).sum(1)
+    pred = torch.cat([pos_h, neg_h])
+    gt = torch.cat([torch.ones_like(pos_h), torch.zeros_like(neg_h)])
+    total = 2.0 * part.num_nodes
+    return torch.nn.functional.binary_cross_entropy_with_logits(pred, gt, reduction="sum") * (part.world / total)
+
+
+def kge_loss_partitioned(model, x_full, prg: PartitionedRelGraph, backend, pos_ei, pos_et, neg_ei, neg_et, kind,
+                         dropout_of=None):
+    """``KGEModule.training_step``'s loss (reference kge_module.py:110-129) with the encoder over the rank's shard
+    and the scorer over the rank's share of the triplets (``pos_* / neg_*``: global node ids; equal shares on every
+    rank, so the mean of the ranks' means is the global mean).  The scorer reads the all-gathered embedding table
+    through slot indices; its gradient goes back through the reduce-scatter of ``gather_embeddings``."""
+    from . import ops
+    part = prg.part
+    z_local = rgcn_encoder_partitioned(model.encoder, part.shard(x_full), prg, backend, dropout_of)
+    table = gather_embeddings(z_local, part)
+    ps = torch.stack([part.slots(pos_ei[0]), part.slots(pos_ei[1])])
+    ns = torch.stack([part.slots(neg_ei[0]), part.slots(neg_ei[1])])
+    rel = model.decoder.rel_emb
+    ce, _, _ = ops.kge_bce_loss(table, rel, ps, pos_et, ns, neg_et, kind)
+    # L2 terms: every rank adds its nodes' share of mean(z^2) (x world for the gradient average) and the full rel term
+    reg = z_local.pow(2).sum() * (part.world / (part.num_nodes * z_local.size(1))) + rel.pow(2).mean()
+    return ce + 1e-2 * reg
