@@ -68,7 +68,7 @@ def make_step(module, batch, world, overlap=False):
     update still lands before the KGE parameters are read again, i.e. the arithmetic of the loop is unchanged."""
     from biomedkg_amd.distributed import GradBucket
     params = [p for p in module.model.parameters()]
-    opt = torch.optim.Adam(params, lr=1e-3)
+    opt = torch.optim.Adam(params, lr=1e-3, fused=True)   # torch's single-kernel Adam (same update; ~0.4 ms per step)
     bucket = GradBucket(params, world)   # one flat RCCL all-reduce per sub-step (<= 49 MB)
     state = {"pending": False}
 
