@@ -343,7 +343,7 @@ def main():
                 "bytes_per_launch": rec["bytes"],
                 "note": "algorithmic bytes / HIP-event time; the 133 MB feature table is Infinity-Cache/L2 resident, "
                         "so the algorithmic rate can exceed the HBM peak (traffic = PMC bytes that left L2)"}
-        rec2 = timers.get("gcn_propagate")
+        rec2 = timers.get("gcn_propagate") or timers.get("gcn_propagate_views")
         if rec2 and rec2["events"]:
             d2 = [a.elapsed_time(b) for a, b in rec2["events"]]
             roof["gcn_propagate_GBs"] = rec2["bytes"] / (sum(d2) / len(d2) * 1e-3) / 1e9

@@ -90,6 +90,8 @@ class GGD(torch.nn.Module):
             edge_keep = r.edge_keep(edge_index.size(1), 0.4, x.device)
         elif ops.features_bf16_ok(x) and x.is_cuda:
             x = ops.cached_bf16(x)      # bf16 mode: the corruption below then permutes a bf16 table
+        if self._views_ok(x, r):
+            return self._forward_views(x, edge_index, edge_keep, r)
         pos_h = self.encoder(x, edge_index, edge_keep=edge_keep)
         # the reference corrupts over the (possibly edge-dropped) graph of the positive pass
         neg_h = self.encoder(self.corruption(x, edge_index)[0], edge_index, edge_keep=edge_keep)
@@ -99,3 +101,24 @@ class GGD(torch.nn.Module):
         pos_h = ops.linear(pos_h, self.mlp[-1].weight, self.mlp[-1].bias)
         neg_h = ops.linear(neg_h, self.mlp[-1].weight, self.mlp[-1].bias)
         return pos_h.sum(1), neg_h.sum(1)
+
+    def _views_ok(self, x, r):
+        """bf16 throughput mode with device randomness: both passes share the graph, the weights and -- because the
+        corruption is a row permutation, ``x[perm] W^T = (x W^T)[perm]`` -- the first layer's product, so they run
+        side by side through every kernel (``GCNEncoder.forward_views``).  Same arithmetic per view."""
+        enc = self.encoder
+        return (getattr(r, "device_draws", False) and ops.bf16_storage() and x.is_cuda and x.dim() == 2 and not x.requires_grad
+                and hasattr(enc, "forward_views") and x.size(1) % 256 == 0 and enc.views_ok(x.size(0)))
+
+    def _forward_views(self, x, edge_index, edge_keep, r):
+        n = x.size(0)
+        layer0 = self.encoder.graph_layers[0]
+        xw = ops.xw_table(x, layer0.lin.weight)                                  # [N, h] bf16, shared by both views
+        perm = r.perm(n, x.device)
+        xw2 = torch.stack([xw, xw[perm]], dim=1).view(n, 2 * xw.size(1))         # node i: [pos_i | neg_i]
+        h2 = self.encoder.forward_views(xw2, edge_index, 2, edge_keep=edge_keep)  # [N, 2 * out]
+        h = h2.view(2 * n, h2.size(1) // 2)
+        for layer in self.mlp[:-1]:
+            h = ops.linear(h, layer.weight, layer.bias, act=ops.ACT_RELU)
+        s = ops.linear(h, self.mlp[-1].weight, self.mlp[-1].bias).sum(1).view(n, 2)
+        return s[:, 0], s[:, 1]

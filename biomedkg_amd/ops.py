@@ -417,6 +417,88 @@ def gcn_conv(x, weight, bias, graph, gw, relu=False, drop=None, hidden=False):
     return _GcnConv.apply(x, weight, bias, graph, gw, relu, drop, hidden)
 
 
+class _XwTable(torch.autograd.Function):
+    """``bf16(x W^T)`` as a gather table shared by several views (GGD / DGI corrupt the input by a row permutation,
+    and ``x[perm] W^T = (x W^T)[perm]``: the first layer's product is computed once)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return gemm(x, weight, trans_b=True, out_dtype=torch.bfloat16)
+
+    @staticmethod
+    def backward(ctx, dxw):
+        x, weight = ctx.saved_tensors
+        dxw = dxw if dxw.is_contiguous() else dxw.contiguous()
+        dx = gemm(dxw, weight, out_dtype=x.dtype) if ctx.needs_input_grad[0] else None
+        dw = gemm(dxw, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def xw_table(x, weight):
+    L.require_cuda(x, weight)
+    return _XwTable.apply(x if x.dtype == torch.bfloat16 else _f32c(x), weight)
+
+
+def views_ok(n_rows, d_in, d_out, views=2):
+    """Shapes for which V views of one graph run through a conv layer as ONE launch per kernel (bf16 mode)."""
+    return (bf16_storage() and n_rows >= 4096 and d_in % 256 == 0 and d_out % 256 == 0 and _bf16_ok(views * d_out)
+            and _bf16_operand_ok(views * n_rows, d_out, d_in) and _bf16_operand_ok(views * n_rows, d_in, d_out))
+
+
+class _GcnConvViews(torch.autograd.Function):
+    """V views of the SAME graph through one GCNConv (GGD: positive + corrupted input).  ``x2`` is ``[N, V * in]`` --
+    row i holds the V views' rows of node i side by side -- so the products see ``[V * N, in]`` (one launch, the
+    weight slab loaded once, one weight-gradient product over K = V * N) and the aggregation gathers ``V * out``-wide
+    rows with one index / weight stream.  ``is_table``: ``x2`` already is the gather table (shared first-layer
+    product, see ``_XwTable``) and ``weight`` is unused.  bf16 mode only (``views_ok``)."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias, graph: Graph, gw: GcnWeights, relu, drop, hidden, views, is_table):
+        n = graph.num_nodes
+        if is_table:
+            table = x2 if x2.is_contiguous() else x2.contiguous()
+        else:
+            d_in, d_out = weight.size(1), weight.size(0)
+            table = gemm(x2.view(views * n, d_in), weight, trans_b=True, out_dtype=torch.bfloat16).view(n, views * d_out)
+        c = graph.by_dst
+        out = spmm(c.rowptr, c.col, gw.w_dst, table, n, self_w=gw.self_w, bias=bias.repeat(views), relu=relu, drop=drop,
+                   tag="gcn_propagate_views", split=c.split, out_dtype=torch.bfloat16 if hidden else torch.float32)
+        ctx.graph, ctx.gw, ctx.relu, ctx.views, ctx.is_table = graph, gw, relu, views, is_table
+        ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
+        ctx.gated = relu or ctx.scale != 1.0
+        ctx.table_dtype = x2.dtype
+        ctx.save_for_backward(None if is_table else x2, weight, out if ctx.gated else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, weight, out = ctx.saved_tensors
+        g, gw, v = ctx.graph, ctx.gw, ctx.views
+        n = g.num_nodes
+        dout = dout if dout.is_contiguous() else dout.contiguous()
+        if ctx.relu or not ctx.gated:
+            dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
+        else:
+            dout = to_bf16(_as_f32(dout) * (_as_f32(out) != 0) * ctx.scale)
+        c = g.by_src
+        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n, self_w=gw.self_w, split=c.split, out_dtype=torch.bfloat16)
+        d_out = dout.size(1) // v
+        db = colsum(dout.view(v * n, d_out)) if ctx.needs_input_grad[2] else None
+        if ctx.is_table:
+            return dxw.to(ctx.table_dtype), None, db, None, None, None, None, None, None, None
+        d_in = weight.size(1)
+        dxw_rows = dxw.view(v * n, d_out)
+        dx = (gemm(dxw_rows, weight, out_dtype=x2.dtype).view(n, v * d_in) if ctx.needs_input_grad[0] else None)
+        dw = gemm(dxw_rows, x2.view(v * n, d_in), trans_a=True) if ctx.needs_input_grad[1] else None
+        return dx, dw, db, None, None, None, None, None, None, None
+
+
+def gcn_conv_views(x2, weight, bias, graph, gw, views, relu=False, drop=None, hidden=False, is_table=False):
+    L.require_cuda(x2, weight, bias)
+    return _GcnConvViews.apply(x2, weight, bias, graph, gw, relu, drop, hidden, views, is_table)
+
+
 # ----------------------------------------------------------------------------- RGCNConv
 class _RgcnConv(torch.autograd.Function):
     """``dropout(relu(sum_r mean_{N_r(i)}(x_j) W_r + x_i W_root + b))`` -- PyG RGCNConv

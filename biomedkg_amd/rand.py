@@ -20,6 +20,8 @@ from .ops import Dropout
 
 
 class DeviceRand:
+    device_draws = True     # draws are made on the device in whatever order / shape the fast path needs (no tape)
+
     def __init__(self, seed=None):
         self.seed = int(torch.initial_seed() if seed is None else seed) & ((1 << 63) - 1)
         self.counter = 0

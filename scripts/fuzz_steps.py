@@ -34,6 +34,7 @@ for it in range(24):
         kge = KGEModule("rgcn", dec, d, d, d, 2, r, 1, "cosine", 1e-3, 0.1, "none", 1, "random").to(dev).train()
         gcl = GGDModule(in_dim=768, hidden_dim=d, out_dim=d, num_hidden_layers=2, fuse_method="none").to(dev).train()
         gcl.model.p = 0.0      # no augmentation: its feature mask is drawn by a different generator in bf16 mode
+        gcl.model.encoder.drop_out = False   # bf16 mode runs both views side by side: other dropout element ids
         out = []
         for mod, batch in ((kge, SimpleNamespace(x=xk, edge_index=ei, edge_type=et)),
                            (gcl, SimpleNamespace(x=xg, edge_index=ei))):
