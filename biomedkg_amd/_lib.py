@@ -71,6 +71,9 @@ SIGNATURES = {
     "bkg_rank_l1_true_f32": (I32, [P, I64, P, I64, P, I64, I32, P, P]),
     "bkg_rank_l1_count_f32": (I32, [P, I64, I64, P, I64, I64, I32, P, P, I32, P, P, P]),
     "bkg_rank_l1_filter_f32": (I32, [P, I64, P, I64, I32, P, P, P, P, I64, P, P, P]),
+    # pair.hip
+    "bkg_pair_rows_bf16": (I32, [P, P, P, I64, I32, P]),
+    "bkg_unpair_rows_bf16": (I32, [P, P, P, I64, I32, P]),
     # colsum.hip
     "bkg_colsum_workspace_floats": (I64, [I64, I32]),
     "bkg_colsum_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),

@@ -115,7 +115,7 @@ class GGD(torch.nn.Module):
         layer0 = self.encoder.graph_layers[0]
         xw = ops.xw_table(x, layer0.lin.weight)                                  # [N, h] bf16, shared by both views
         perm = r.perm(n, x.device)
-        xw2 = torch.stack([xw, xw[perm]], dim=1).view(n, 2 * xw.size(1))         # node i: [pos_i | neg_i]
+        xw2 = ops.pair_rows(xw, perm)                                            # node i: [pos_i | neg_i]
         h2 = self.encoder.forward_views(xw2, edge_index, 2, edge_keep=edge_keep)  # [N, 2 * out]
         h = h2.view(2 * n, h2.size(1) // 2)
         for layer in self.mlp[:-1]:

@@ -440,6 +440,37 @@ def xw_table(x, weight):
     return _XwTable.apply(x if x.dtype == torch.bfloat16 else _f32c(x), weight)
 
 
+class _PairRows(torch.autograd.Function):
+    """``[x | x[perm]]`` row by row for a bf16 table (csrc/pair.hip); the gradient gathers through the inverse perm."""
+
+    @staticmethod
+    def forward(ctx, x, perm):
+        n, h = x.shape
+        out = torch.empty(n, 2 * h, dtype=torch.bfloat16, device=x.device)
+        L.call("bkg_pair_rows_bf16", L.ptr(x), L.ptr(perm), L.ptr(out), n, h, L.stream())
+        ctx.perm = perm
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        perm = ctx.perm
+        n, h = g.size(0), g.size(1) // 2
+        g = g if (g.dtype == torch.bfloat16 and g.is_contiguous()) else g.to(torch.bfloat16).contiguous()
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(n, device=perm.device)
+        out = torch.empty(n, h, dtype=torch.bfloat16, device=g.device)
+        L.call("bkg_unpair_rows_bf16", L.ptr(g), L.ptr(inv), L.ptr(out), n, h, L.stream())
+        return out, None
+
+
+def pair_rows(x, perm):
+    """``[N, 2h]`` bf16: row i = ``[x[i] | x[perm[i]]]`` (``perm`` int64, a permutation of the rows)."""
+    L.require_cuda(x, perm)
+    if x.dtype != torch.bfloat16 or x.size(1) % 8 or not x.is_contiguous():
+        return torch.stack([x, x[perm]], dim=1).view(x.size(0), 2 * x.size(1))
+    return _PairRows.apply(x, perm.contiguous())
+
+
 def views_ok(n_rows, d_in, d_out, views=2):
     """Shapes for which V views of one graph run through a conv layer as ONE launch per kernel (bf16 mode)."""
     return (bf16_storage() and n_rows >= 4096 and d_in % 256 == 0 and d_out % 256 == 0 and _bf16_ok(views * d_out)

@@ -203,6 +203,12 @@ int bkg_rank_l1_filter_f32(const float* q, int64_t ldq, const float* zn, int64_t
                            const float* true_score, const int64_t* target, const int64_t* qptr, const int64_t* cand,
                            int64_t n_q, int32_t* gt, int32_t* eq, void* stream);
 
+/* ---- two views side by side (GGD / DGI corruption = a row permutation, biomedkg/model/gcl.py:69-71,85):
+ *      out[i] = [x[i] | x[perm[i]]] over bf16 rows of width h (h % 8 == 0), and the gradient of that map:
+ *      out[i] = g[i, :h] + g[inv[i], h:] with inv the inverse permutation. */
+int bkg_pair_rows_bf16(const void* x, const int64_t* perm, void* out, int64_t n, int32_t h, void* stream);
+int bkg_unpair_rows_bf16(const void* g, const int64_t* inv, void* out, int64_t n, int32_t h, void* stream);
+
 /* ---- bias gradients: out[c] = sum_i x[i, c] over an fp32 or bf16 table (autograd of the `+ bias` of every Linear /
  *      GCNConv / RGCNConv on the path).  workspace: bkg_colsum_workspace_floats(n, d) floats. */
 int64_t bkg_colsum_workspace_floats(int64_t n, int32_t d);

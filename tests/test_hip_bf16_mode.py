@@ -340,3 +340,17 @@ def test_ggd_two_views_side_by_side_equal_two_passes():
         loss = m.calculate_loss(x, ei)
     loss.backward()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.model.parameters())
+
+
+def test_pair_rows_and_its_gradient():
+    from biomedkg_amd import ops
+    torch.manual_seed(2)
+    n, h = 5003, 256
+    x = torch.randn(n, h, device=DEV).bfloat16().requires_grad_()
+    perm = torch.randperm(n, device=DEV)
+    out = ops.pair_rows(x, perm)
+    assert torch.equal(out[:, :h], x.detach()) and torch.equal(out[:, h:], x.detach()[perm])
+    g = torch.randn(n, 2 * h, device=DEV).bfloat16()
+    out.backward(g)
+    want = (g[:, :h].float() + torch.zeros(n, h, device=DEV).index_add_(0, perm, g[:, h:].float())).bfloat16()
+    assert torch.equal(x.grad, want)
