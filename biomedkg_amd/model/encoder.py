@@ -104,10 +104,11 @@ class GCNEncoder(_Stack):
         return (len(layers) >= 2 and all(ops.views_ok(n_rows, l.in_channels, l.out_channels, views) for l in layers[1:])
                 and ops.views_ok(n_rows, 256, layers[0].out_channels, views))
 
-    def forward_views(self, xw2, edge_index, views, edge_keep=None):
+    def forward_views(self, xw2, edge_index, views, edge_keep=None, out_bf16=False):
         """The stack over ``views`` inputs of the SAME graph at once (bf16 mode; GGD's positive + corrupted pass).
         ``xw2 [N, views * h]``: the first layer's products ``x_v W_0^T`` side by side (``ops.xw_table``); returns the
-        last layer's outputs ``[N, views * out]`` (fp32), view v in columns ``[v * out, (v + 1) * out)``."""
+        last layer's outputs ``[N, views * out]`` (fp32; bf16 with ``out_bf16`` when only products consume them), view v
+        in columns ``[v * out, (v + 1) * out)``."""
         g = graph_of(edge_index, xw2.size(0))
         gw = g.gcn_weights(edge_keep)
         last = len(self.graph_layers) - 1
@@ -117,7 +118,7 @@ class GCNEncoder(_Stack):
             if i != last and self.drop_out and self.training:
                 drop = _rand.current().dropout((h.size(0), views * layer.out_channels), 0.2, h.device)
             h = ops.gcn_conv_views(h, None if i == 0 else layer.lin.weight, layer.bias, g, gw, views, relu=(i != last),
-                                   drop=drop, hidden=(i != last), is_table=(i == 0))
+                                   drop=drop, hidden=(i != last) or out_bf16, is_table=(i == 0))
         return h
 
     def forward(self, x, edge_index, edge_keep=None):

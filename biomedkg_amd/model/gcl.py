@@ -116,7 +116,8 @@ class GGD(torch.nn.Module):
         xw = ops.xw_table(x, layer0.lin.weight)                                  # [N, h] bf16, shared by both views
         perm = r.perm(n, x.device)
         xw2 = ops.pair_rows(xw, perm)                                            # node i: [pos_i | neg_i]
-        h2 = self.encoder.forward_views(xw2, edge_index, 2, edge_keep=edge_keep)  # [N, 2 * out]
+        # [N, 2 * out]; bf16: the embeddings feed the head's product only
+        h2 = self.encoder.forward_views(xw2, edge_index, 2, edge_keep=edge_keep, out_bf16=True)
         h = h2.view(2 * n, h2.size(1) // 2)
         for layer in self.mlp[:-1]:
             h = ops.linear(h, layer.weight, layer.bias, act=ops.ACT_RELU)

@@ -324,8 +324,16 @@ class _Linear(torch.autograd.Function):
             dout = _gate(dout, out, 1.0)
         elif ctx.act == ACT_ELU:  # elu'(pre) = 1 (pre > 0) else elu(pre) + 1
             dout = torch.where(out > 0, dout, dout * (out + 1.0))
-        dx = gemm(dout, weight) if ctx.needs_input_grad[0] else None
-        dw = gemm(dout, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if x.dtype == torch.bfloat16 and _xw_ok(dout, dout.size(0), weight.size(1), weight.size(0)):
+                dx = gemm(dout, weight, out_dtype=torch.bfloat16)        # the gradient of a bf16 activation is bf16
+            else:
+                dx = gemm(dout, weight).to(x.dtype)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            small = dout.size(0) < 4096 and x.dtype == torch.bfloat16
+            dw = gemm(dout, x.float() if small else x, trans_a=True)
         db = colsum(dout) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None
 
