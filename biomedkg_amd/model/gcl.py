@@ -31,6 +31,16 @@ class DGI(torch.nn.Module):
     def forward(self, x, edge_index):
         if ops.features_bf16_ok(x) and x.is_cuda:
             x = ops.cached_bf16(x)
+        r = _rand.current()
+        enc = self.encoder
+        if (getattr(r, "device_draws", False) and ops.bf16_storage() and x.is_cuda and x.dim() == 2 and not x.requires_grad
+                and hasattr(enc, "forward_views") and x.size(1) % 256 == 0 and enc.views_ok(x.size(0))):
+            # both passes side by side, the first layer's product shared (see GGD._views_ok)
+            xw = ops.xw_table(x, enc.graph_layers[0].lin.weight)
+            h2 = enc.forward_views(ops.pair_rows(xw, r.perm(x.size(0), x.device)), edge_index, 2)
+            d = h2.size(1) // 2
+            z, zn = h2[:, :d], h2[:, d:]
+            return z, ops.linear(self.summary(z), self.project.weight, self.project.bias), zn
         z = self.encoder(x, edge_index)
         g = ops.linear(self.summary(z), self.project.weight, self.project.bias)
         zn = self.encoder(*self.corruption(x, edge_index))

@@ -354,3 +354,31 @@ def test_pair_rows_and_its_gradient():
     out.backward(g)
     want = (g[:, :h].float() + torch.zeros(n, h, device=DEV).index_add_(0, perm, g[:, h:].float())).bfloat16()
     assert torch.equal(x.grad, want)
+
+
+def test_dgi_two_views_side_by_side_equal_two_passes():
+    from biomedkg_amd import rand as R
+    from biomedkg_amd.gcl_module import DGIModule
+
+    class TwoPass(R.DeviceRand):
+        device_draws = False
+
+    n, e = 6000, 100_000
+    g = torch.Generator().manual_seed(13)
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    x = torch.randn(n, 768, generator=g).to(DEV)
+    torch.manual_seed(0)
+    m = DGIModule(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="none").to(DEV).train()
+    m.model.encoder.drop_out = False
+    res = []
+    for prov in (TwoPass(seed=1), R.DeviceRand(seed=1)):
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(99)
+        with R.use(prov):
+            loss = m.calculate_loss(x, ei)
+        loss.backward()
+        res.append((float(loss.detach()), [p.grad.clone() for p in m.model.parameters()]))
+    (la, ga), (lb, gb) = res
+    assert abs(la - lb) <= 2e-3 * abs(la), (la, lb)
+    for a, b in zip(ga, gb):
+        assert float((a - b).norm() / a.norm().clamp_min(1e-12)) < 2e-2
