@@ -78,7 +78,7 @@ SIGNATURES = {
     "bkg_colsum_workspace_floats": (I64, [I64, I32]),
     "bkg_colsum_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),
     # negsample.hip
-    "bkg_hashset_insert": (I32, [P, P, I64, I64, P, I64, P]),
+    "bkg_hashset_insert_offdiag": (I32, [P, P, I64, I64, P, I64, P]),
     "bkg_negative_sample_workspace_bytes": (I64, [I64]),
     "bkg_negative_sample": (I32, [I64, I64, I64, U64, P, I64, P, P, P, P, P, I64, I64, P, P, I64, P]),
     "bkg_permute_gather_i64": (I32, [P, I64, U64, P, P]),

@@ -1,9 +1,12 @@
-// Device negative sampling for the KGE step (reference biomedkg/kge_module.py:86-102: PyG negative_sampling +
-// a randomly permuted copy of the positives' relation ids).  PyG draws `random.sample(range(N*N), m)` on the host and
-// tests membership with np.isin; the first device version of this path did the same with sorts and binary searches
-// (two 8-pass radix sorts + a 22-level searchsorted per step).  Nothing is sorted here:
+// Device negative sampling for the KGE step (reference biomedkg/kge_module.py:86-102: PyG 2.5.3 negative_sampling +
+// a randomly permuted copy of the positives' relation ids).  PyG's population is the N*(N-1) OFF-DIAGONAL cells
+// (edge_index_to_vector, non-bipartite directed form: self-loop positives are dropped, cell (r, c) has the code
+// r*(N-1) + c - (r < c); vector_to_edge_index re-opens the diagonal with c += (r <= c)), so no negative is ever a
+// self pair.  PyG draws `random.sample(range(N*(N-1)), m)` on the host and tests membership with np.isin; the first
+// device version of this path did the same with sorts and binary searches (two 8-pass radix sorts + a 22-level
+// searchsorted per step).  Nothing is sorted here:
 //   * sampling WITHOUT replacement = a prefix of a random permutation: candidate i is pi(i) for a keyed bijection pi
-//     of [0, N*N) (6-round Feistel network on the enclosing even power of two + cycle walking), so candidates are
+//     of [0, N*(N-1)) (6-round Feistel network on the enclosing even power of two + cycle walking), so candidates are
 //     distinct by construction -- random.sample's guarantee -- and later rounds just continue the prefix;
 //   * membership in the positives is a lookup in an open-addressing hash table built once per graph
 //     (bkg_hashset_insert) instead of a binary search;
@@ -80,11 +83,15 @@ static Feistel make_feistel(uint64_t n, uint64_t seed) {
   return f;
 }
 
-__global__ __launch_bounds__(256) void hashset_insert_kernel(const int64_t* __restrict__ hi, const int64_t* __restrict__ lo,
-                                                             int64_t n_lo, int64_t n, unsigned long long* __restrict__ tab,
+// PyG edge_index_to_vector (non-bipartite, directed): self loops are not positives of the off-diagonal population;
+// cell (r, c), r != c, has the code r*(N-1) + c - (r < c).
+__global__ __launch_bounds__(256) void hashset_insert_kernel(const int64_t* __restrict__ head, const int64_t* __restrict__ tail,
+                                                             int64_t n_nodes, int64_t n, unsigned long long* __restrict__ tab,
                                                              uint64_t mask) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) hs_insert(tab, mask, (uint64_t)(hi[i] * n_lo + lo[i]));
+  if (i >= n) return;
+  const int64_t r = head[i], c = tail[i];
+  if (r != c) hs_insert(tab, mask, (uint64_t)(r * (n_nodes - 1) + c - (r < c ? 1 : 0)));
 }
 
 __global__ __launch_bounds__(256) void negative_candidates_kernel(Feistel pi, int64_t first, int64_t n_cand,
@@ -108,9 +115,10 @@ __global__ __launch_bounds__(256) void negative_scatter_kernel(const uint64_t* _
   if (i >= n_cand) return;
   if (flag[i]) {
     const int64_t p = out_offset + offs[i];
-    if (p < max_out) {
-      out_head[p] = (int64_t)(keys[i] / n_nodes);
-      out_tail[p] = (int64_t)(keys[i] % n_nodes);
+    if (p < max_out) {                    // PyG vector_to_edge_index: row = code / (N-1), col = code % (N-1), col += (row <= col)
+      const uint64_t r = keys[i] / (n_nodes - 1), c = keys[i] % (n_nodes - 1);
+      out_head[p] = (int64_t)r;
+      out_tail[p] = (int64_t)(c + (r <= c ? 1 : 0));
     }
   }
   if (i == n_cand - 1) *count = offs[i] + flag[i];
@@ -128,13 +136,14 @@ using namespace bkg;
 
 static bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
-extern "C" int bkg_hashset_insert(const int64_t* hi, const int64_t* lo, int64_t n_lo, int64_t n, uint64_t* table,
-                                  int64_t capacity, void* stream) {
-  BKG_ARG(pow2(capacity) && capacity >= 2 * n && n_lo > 0, "bkg_hashset_insert: capacity must be a power of two >= 2 n");
+extern "C" int bkg_hashset_insert_offdiag(const int64_t* head, const int64_t* tail, int64_t n_nodes, int64_t n,
+                                          uint64_t* table, int64_t capacity, void* stream) {
+  BKG_ARG(pow2(capacity) && capacity >= 2 * n && n_nodes > 1,
+          "bkg_hashset_insert_offdiag: capacity must be a power of two >= 2 n, n_nodes > 1");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(hashset_insert_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, hi, lo, n_lo, n,
-                     reinterpret_cast<unsigned long long*>(table), (uint64_t)capacity - 1);
-  return check_launch("bkg_hashset_insert");
+  hipLaunchKernelGGL(hashset_insert_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, head, tail, n_nodes,
+                     n, reinterpret_cast<unsigned long long*>(table), (uint64_t)capacity - 1);
+  return check_launch("bkg_hashset_insert_offdiag");
 }
 
 extern "C" int64_t bkg_negative_sample_workspace_bytes(int64_t n_candidates) {
@@ -149,9 +158,9 @@ extern "C" int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int
                                    int32_t* flag_tmp, int32_t* offs_tmp, int64_t* out_head, int64_t* out_tail,
                                    int64_t out_offset, int64_t max_out, int32_t* count, void* workspace,
                                    int64_t workspace_bytes, void* stream) {
-  BKG_ARG(n_nodes > 0 && n_nodes < (1ll << 31) && n_candidates >= 0 && n_candidates < (1ll << 31) && first_candidate >= 0,
+  BKG_ARG(n_nodes > 1 && n_nodes < (1ll << 31) && n_candidates >= 0 && n_candidates < (1ll << 31) && first_candidate >= 0,
           "bkg_negative_sample: bad sizes");
-  BKG_ARG(first_candidate + n_candidates <= n_nodes * n_nodes, "bkg_negative_sample: more candidates than cells");
+  BKG_ARG(first_candidate + n_candidates <= n_nodes * (n_nodes - 1), "bkg_negative_sample: more candidates than cells");
   BKG_ARG(pow2(pos_capacity), "bkg_negative_sample: table capacity must be a power of two");
   hipStream_t s = (hipStream_t)stream;
   if (n_candidates == 0) {
@@ -159,7 +168,7 @@ extern "C" int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int
     if (e != hipSuccess) { set_error("bkg_negative_sample: memset", e); return (int)e; }
     return 0;
   }
-  const Feistel pi = make_feistel((uint64_t)(n_nodes * n_nodes), seed);
+  const Feistel pi = make_feistel((uint64_t)(n_nodes * (n_nodes - 1)), seed);
   hipLaunchKernelGGL(negative_candidates_kernel, dim3(ceil_div(n_candidates, 256)), dim3(256), 0, s, pi, first_candidate,
                      n_candidates, reinterpret_cast<const unsigned long long*>(pos_table), (uint64_t)pos_capacity - 1,
                      keys_tmp, flag_tmp);

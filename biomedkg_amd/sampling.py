@@ -1,14 +1,17 @@
 """Negative-edge sampling on the device.
 
 Semantics follow PyG 2.5.3 ``negative_sampling(edge_index, num_neg_samples=k)`` as the reference
-calls it (``biomedkg/kge_module.py:93``): uniform (head, tail) pairs from the
-N x N grid (N = max id + 1) that are not positives, all distinct, at most 3 over-sampling rounds of
-``int(1.1 k / (1 - E/N^2))`` candidates, truncated to k (fewer may come back).  Upstream draws with
-python ``random.sample`` + ``np.isin`` on the host; here the candidates are a prefix of a keyed random permutation
-of the grid (distinct by construction), membership in the positives is a hash-set lookup (table built once per
-graph) and the survivors are compacted in candidate order (``csrc/negsample.hip``): no sort, no atomics, the
-result is a pure function of (graph, seed).  Graphs so dense that the whole N x N grid is enumerated take
-the sort / binary-search form below (torch glue).
+calls it (``biomedkg/kge_module.py:93``), i.e. ``edge_index_to_vector`` / ``vector_to_edge_index`` in their
+non-bipartite, directed form: the population is the N(N-1) OFF-DIAGONAL cells of the grid (N = max id + 1),
+self-loop positives are dropped, cell (r, c) has the code ``r (N-1) + c - (r < c)`` and the diagonal is re-opened
+on the way out (``c += (r <= c)``) -- no negative is ever a self pair.  ``prob = 1 - E'/(N^2 - N)`` with E' the
+loop-free positive count (duplicates counted, as ``idx.numel()`` does), at most 3 over-sampling rounds of
+``int(1.1 k / prob)`` candidates, truncated to k (fewer may come back); ``k`` defaults to ``edge_index.size(1)``.
+Upstream draws with python ``random.sample`` + ``np.isin`` on the host; here the candidates are a prefix of a keyed
+random permutation of the population (distinct by construction), membership in the positives is a hash-set lookup
+(table built once per graph) and the survivors are compacted in candidate order (``csrc/negsample.hip``): no sort,
+no atomics, the result is a pure function of (graph, seed).  Graphs so dense that the whole population is
+enumerated take the sort / binary-search form below (torch glue over the same codes).
 """
 from __future__ import annotations
 
@@ -18,12 +21,22 @@ from . import _lib as L
 from .graph import _cached
 
 
-def _positive_keys(edge_index):
+def _offdiag_code(row, col, n):
+    """PyG ``edge_index_to_vector`` (non-bipartite, directed) on loop-free pairs."""
+    return row * (n - 1) + col - (row < col).to(col.dtype)
+
+
+def _positive_keys(edge_index, n):
     def build():
-        n = int(edge_index.max().item()) + 1 if edge_index.numel() else 0
-        keys = torch.unique(edge_index[0] * n + edge_index[1]) if n else edge_index.new_empty(0)
-        return n, keys  # torch.unique returns them sorted
-    return _cached(edge_index, "pos_keys", (), build)
+        row, col = edge_index[0], edge_index[1]
+        keep = row != col
+        return torch.unique(_offdiag_code(row[keep], col[keep], n))  # torch.unique returns them sorted
+    return _cached(edge_index, "pos_keys", (int(n),), build)
+
+
+def _loop_free_count(edge_index):
+    """E' = number of positives with head != tail (duplicates counted): PyG's ``idx.numel()``."""
+    return _cached(edge_index, "loop_free", (), lambda: int((edge_index[0] != edge_index[1]).sum().item()))
 
 
 def _distinct_first(cand):
@@ -52,22 +65,23 @@ def _num_nodes_of(edge_index):
 
 
 def _positive_table(edge_index, n):
-    """Open-addressing hash set of the positives' keys ``head * n + tail`` (int64, empty = -1), cached per graph."""
+    """Open-addressing hash set of the loop-free positives' off-diagonal codes (int64, empty = -1), cached per graph."""
     def build():
         ei = edge_index.contiguous()
         cap = _pow2_at_least(2 * ei.size(1))
         table = torch.full((cap,), -1, dtype=torch.int64, device=ei.device)
-        L.call("bkg_hashset_insert", L.ptr(ei[0]), L.ptr(ei[1]), n, ei.size(1), L.ptr(table), cap, L.stream())
+        L.call("bkg_hashset_insert_offdiag", L.ptr(ei[0]), L.ptr(ei[1]), n, ei.size(1), L.ptr(table), cap, L.stream())
         return table
     return _cached(edge_index, "pos_table", (int(n),), build)
 
 
 def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
+    population = n * (n - 1)
     dev = edge_index.device
     pos_table = _positive_table(edge_index, n)
     out = torch.empty(2, k, dtype=torch.int64, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
-    have, first, draw = 0, 0, min(sample_size, n * n)
+    have, first, draw = 0, 0, min(sample_size, population)
     for _ in range(3):                               # PyG: at most three over-sampling rounds
         keys = torch.empty(draw, dtype=torch.int64, device=dev)
         flag = torch.empty(2, draw, dtype=torch.int32, device=dev)
@@ -79,7 +93,7 @@ def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
         first += draw
         if have >= k:
             return out
-        draw = min(int(1.1 * (k - have) / prob) + 64, n * n - first)   # later rounds continue the permutation's prefix
+        draw = min(int(1.1 * (k - have) / prob) + 64, population - first)   # later rounds continue the permutation's prefix
         if draw <= 0:
             break
     return out[:, :have].contiguous()
@@ -89,20 +103,18 @@ def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None, seed=Non
     L.require_cuda(edge_index)
     dev = edge_index.device
     n = _num_nodes_of(edge_index) if num_nodes is None else int(num_nodes)
-    population = n * n
-    e = edge_index.size(1)  # upstream counts duplicate positives too (idx.numel())
+    population = n * n - n                          # off-diagonal cells only
+    e = _loop_free_count(edge_index)                # upstream counts duplicate positives too (idx.numel()), never self loops
     if e >= population:
         return edge_index.new_empty((2, 0))
-    k = num_neg_samples if num_neg_samples else e
+    k = num_neg_samples if num_neg_samples else edge_index.size(1)
     prob = 1.0 - e / population
     sample_size = int(1.1 * k / prob)
     if population > sample_size and n < (1 << 31):
         if seed is None:
             seed = int(torch.randint(0, 1 << 62, (1,)).item())    # CPU generator: follows torch.manual_seed, no device sync
         return _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed)
-    n0, pos = _positive_keys(edge_index)
-    if n0 != n:
-        pos = torch.unique(edge_index[0] * n + edge_index[1])
+    pos = _positive_keys(edge_index, n)
     neg = None
     for _ in range(3):
         if population <= sample_size:
@@ -118,4 +130,5 @@ def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None, seed=Non
         if neg.numel() >= k:
             neg = neg[:k]
             break
-    return torch.stack([neg // n, neg % n], dim=0)
+    row, col = neg // (n - 1), neg % (n - 1)         # vector_to_edge_index: re-open the diagonal
+    return torch.stack([row, col + (row <= col).to(col.dtype)], dim=0)

@@ -215,16 +215,19 @@ int64_t bkg_colsum_workspace_floats(int64_t n, int32_t d);
 int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, float* workspace, float* out,
                    void* stream);
 
-/* ---- negative sampling of the KGE step (PyG negative_sampling + the permuted relation ids of
- *      biomedkg/kge_module.py:86-102).  bkg_hashset_insert adds the keys hi[i]*n_lo + lo[i] to an open-addressing table
- *      of uint64 (empty = ~0, capacity a power of two >= 2x the keys).  bkg_negative_sample: candidate c is pi(c), pi a
- *      bijection of [0, N*N) keyed by seed (candidates are distinct by construction = random.sample); candidates
- *      [first, first + n) that are not in pos_table are written, in candidate order, as (head, tail) pairs at
- *      out_offset + rank while < max_out; *count (device) = survivors of this call.  Bitwise repeatable, no atomics.
+/* ---- negative sampling of the KGE step (PyG 2.5.3 negative_sampling + the permuted relation ids of
+ *      biomedkg/kge_module.py:86-102).  The population is PyG's: the N*(N-1) off-diagonal cells, cell (r, c) coded
+ *      r*(N-1) + c - (r < c) (edge_index_to_vector, non-bipartite directed form); self-loop positives are not part of it
+ *      and no negative is a self pair.  bkg_hashset_insert_offdiag adds the codes of the (head, tail) pairs with
+ *      head != tail to an open-addressing table of uint64 (empty = ~0, capacity a power of two >= 2x the pairs).
+ *      bkg_negative_sample: candidate c is pi(c), pi a bijection of [0, N*(N-1)) keyed by seed (candidates are distinct by
+ *      construction = random.sample); candidates [first, first + n) that are not in pos_table are written, in candidate
+ *      order, as (head, tail) pairs (vector_to_edge_index: tail += (head <= tail)) at out_offset + rank while < max_out;
+ *      *count (device) = survivors of this call.  Bitwise repeatable, no atomics.
  *      keys_tmp / flag_tmp / offs_tmp: [n_candidates] scratch.  bkg_permute_gather_i64: out[i] = src[pi(i)], pi a keyed
  *      bijection of [0, n) (x[randperm(n)] without the sort). */
-int bkg_hashset_insert(const int64_t* hi, const int64_t* lo, int64_t n_lo, int64_t n, uint64_t* table, int64_t capacity,
-                       void* stream);
+int bkg_hashset_insert_offdiag(const int64_t* head, const int64_t* tail, int64_t n_nodes, int64_t n, uint64_t* table,
+                               int64_t capacity, void* stream);
 int64_t bkg_negative_sample_workspace_bytes(int64_t n_candidates);
 int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int64_t n_candidates, uint64_t seed,
                         const uint64_t* pos_table, int64_t pos_capacity, uint64_t* keys_tmp, int32_t* flag_tmp,

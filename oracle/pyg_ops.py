@@ -112,23 +112,44 @@ def glorot_(tensor: torch.Tensor):
 
 
 # --------------------------------------------------------------------------- A.4  negative_sampling
+def edge_index_to_vector(edge_index, num_nodes):
+    """PyG 2.5.3 ``utils/_negative_sampling.py::edge_index_to_vector``, non-bipartite and not ``force_undirected``
+    (the form ``negative_sampling(edge_index, num_neg_samples=k)`` takes for the call at ``biomedkg/kge_module.py:93``):
+    self loops are removed, the column index is compacted past the diagonal, ``idx = row (N-1) + col``,
+    ``population = N^2 - N``."""
+    row, col = edge_index[0], edge_index[1]
+    mask = row != col
+    row, col = row[mask], col[mask]              # copies: the caller's edge_index is not touched
+    col = col - (row < col).to(col.dtype)
+    return row * (num_nodes - 1) + col, num_nodes * num_nodes - num_nodes
+
+
+def vector_to_edge_index(idx, num_nodes):
+    """PyG 2.5.3 ``vector_to_edge_index`` (same form): ``row = idx // (N-1)``, ``col = idx % (N-1)``,
+    ``col[row <= col] += 1`` -- the diagonal is skipped, so ``row != col`` always."""
+    row = torch.div(idx, num_nodes - 1, rounding_mode="floor")
+    col = idx % (num_nodes - 1)
+    col = col + (row <= col).to(col.dtype)
+    return torch.stack([row, col], dim=0)
+
+
 def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None):
-    """A.4 (``method="sparse"``): uniform (h,t) pairs not among the positives, <= 3 rounds."""
+    """PyG 2.5.3 ``negative_sampling`` with ``method="sparse"``, ``force_undirected=False``: uniform off-diagonal
+    (h, t) pairs not among the positives, <= 3 over-sampling rounds of ``random.sample`` + ``np.isin``.
+    (SURVEY Appendix A.4 described the pre-2.0 ``N*N`` population; this follows the pinned version.)"""
 
     def run():
         n = int(edge_index.max()) + 1 if num_nodes is None else num_nodes
-        row, col = edge_index[0].cpu(), edge_index[1].cpu()
-        idx = (row * n + col).numpy()
-        population = n * n
-        e = idx.size
-        if e >= population:
+        idx_t, population = edge_index_to_vector(edge_index.cpu(), n)
+        idx = idx_t.numpy()
+        if idx.size >= population:
             return edge_index.new_empty((2, 0))
-        k = num_neg_samples if num_neg_samples else e
-        prob = 1.0 - e / population
+        k = num_neg_samples if num_neg_samples is not None and num_neg_samples else edge_index.size(1)
+        prob = 1.0 - idx.size / population         # probability that a draw is a negative
         sample_size = int(1.1 * k / prob)
         neg = None
         for _ in range(3):
-            if population <= sample_size:  # PyG utils `sample`: whole range when over-asked
+            if population <= sample_size:            # PyG `sample`: the whole range when over-asked
                 rnd = np.arange(population, dtype=np.int64)
             else:
                 rnd = _rand.current().sample(population, sample_size).numpy()
@@ -140,8 +161,7 @@ def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None):
             if neg.size >= k:
                 neg = neg[:k]
                 break
-        neg = torch.from_numpy(neg).to(edge_index.device)
-        return torch.stack([neg // n, neg % n], dim=0)
+        return vector_to_edge_index(torch.from_numpy(neg), n).to(edge_index.device)
 
     return _rand.current().neg_edges(run)
 
@@ -212,5 +232,5 @@ class GAE(torch.nn.Module):
 
 __all__ = [
     "add_remaining_self_loops", "gcn_norm", "gcn_conv", "rgcn_conv", "mask_feature", "dropout_edge",
-    "dropout", "uniform_", "glorot_", "negative_sampling", "GCNConv", "RGCNConv", "RGATConv", "GAE", "F",
+    "dropout", "uniform_", "glorot_", "negative_sampling", "edge_index_to_vector", "vector_to_edge_index", "GCNConv", "RGCNConv", "RGATConv", "GAE", "F",
 ]

@@ -1,6 +1,9 @@
-"""Device negative sampling (csrc/negsample.hip): the properties PyG's negative_sampling guarantees and the
-reference relies on (biomedkg/kge_module.py:86-102) -- k distinct pairs, none a positive, ids in range, uniform
-over the non-edges -- and the keyed index bijection that stands in for x[randperm(n)].  Needs an MI355X."""
+"""Device negative sampling (csrc/negsample.hip): the properties PyG 2.5.3's negative_sampling guarantees and the
+reference relies on (biomedkg/kge_module.py:86-102) -- k distinct OFF-DIAGONAL pairs (edge_index_to_vector /
+vector_to_edge_index: the population is the N(N-1) cells with head != tail), none a positive, ids in range, uniform
+over the free off-diagonal cells, sized from the loop-free positive count -- checked against the CPU oracle's
+restatement where the support is small enough to enumerate, and the keyed index bijection that stands in for
+x[randperm(n)].  Needs an MI355X."""
 import pytest
 import torch
 
@@ -23,7 +26,9 @@ def test_negatives_are_distinct_non_edges(n, e, k):
     keys = neg[0] * n + neg[1]
     assert torch.unique(keys).numel() == keys.numel()
     assert not bool(torch.isin(keys, ei[0] * n + ei[1]).any())
-    free = n * n - torch.unique(ei[0] * n + ei[1]).numel()
+    assert not bool((neg[0] == neg[1]).any())                                  # PyG >= 2.0: never a self pair
+    off = ei[:, ei[0] != ei[1]]
+    free = n * (n - 1) - torch.unique(off[0] * n + off[1]).numel()
     assert neg.size(1) == min(k, free) or neg.size(1) >= 0.95 * min(k, free)    # PyG: at most 3 rounds, may fall short
     if k <= 0.5 * free:
         assert neg.size(1) == k
@@ -36,6 +41,44 @@ def test_dense_graph_takes_the_enumerating_path():
     neg = sampling.negative_sampling(ei, n, 700)
     keys = neg[0] * n + neg[1]
     assert torch.unique(keys).numel() == keys.numel() and not bool(torch.isin(keys, ei[0] * n + ei[1]).any())
+    assert not bool((neg[0] == neg[1]).any())
+
+
+def test_support_equals_the_oracles_on_enumerable_graphs():
+    """Over-asked on small graphs, PyG returns EVERY free off-diagonal cell (its `sample` hands back the whole range):
+    the device sampler's support must be that same set -- the oracle's (oracle/pyg_ops.py, PyG 2.5.3 restatement)."""
+    import random
+    from biomedkg_amd import sampling
+    from oracle import pyg_ops as P
+    for n, e, seed in [(7, 1, 0), (12, 40, 1), (25, 300, 2), (9, 72, 3)]:
+        g = torch.Generator().manual_seed(seed)
+        ei = torch.randint(0, n, (2, e), generator=g)
+        ei[:, 0] = n - 1                                                       # a self loop that pins N = n
+        random.seed(seed)
+        want = P.negative_sampling(ei, num_neg_samples=4 * n * n)
+        got = sampling.negative_sampling(ei.to(DEV), num_neg_samples=4 * n * n, seed=seed).cpu()
+        assert got.shape == want.shape
+        assert torch.equal(torch.sort(got[0] * n + got[1]).values, torch.sort(want[0] * n + want[1]).values)
+
+
+@pytest.mark.parametrize("n,e", [(2, 1), (7, 1), (13, 60), (64, 1500), (257, 9000)])
+def test_hashed_path_enumerates_exactly_the_free_offdiagonal_cells(n, e):
+    """All N(N-1) candidates of the keyed permutation through the kernels (hash-set membership + the diagonal
+    re-opening of vector_to_edge_index): the survivors are exactly the oracle's free cells, each once."""
+    from biomedkg_amd import sampling
+    from oracle import pyg_ops as P
+    g = torch.Generator().manual_seed(n)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[:, 0] = n - 1
+    population = n * (n - 1)
+    got = sampling._negative_sampling_hashed(ei.to(DEV), n, population, population, 0.5, seed=11).cpu()
+    idx, pop = P.edge_index_to_vector(ei, n)
+    assert pop == population
+    free = torch.ones(population, dtype=torch.bool)
+    free[idx] = False
+    want = P.vector_to_edge_index(torch.nonzero(free).flatten(), n)
+    assert got.shape == want.shape
+    assert torch.equal(torch.sort(got[0] * n + got[1]).values, want[0] * n + want[1])
 
 
 def test_seed_determinism_and_variation():
@@ -61,6 +104,10 @@ def test_uniform_over_the_free_cells():
     pos_cells = torch.bincount(cell(torch.unique(ei[0] * n + ei[1]).unsqueeze(0).expand(2, -1) // torch.tensor([[n], [1]], device=DEV)
                                     % torch.tensor([[n * n], [n]], device=DEV)), minlength=256).double()
     free = 64.0 * 64.0 - pos_cells
+    free[torch.arange(16) * 17] -= 64.0                      # the 64 diagonal cells of each diagonal block are not population
+    pos_diag = ei[:, ei[0] == ei[1]]
+    free += torch.bincount(cell(torch.unique(pos_diag, dim=1)), minlength=256).double()   # ... and were not positives either
+    assert not bool((neg[0] == neg[1]).any())
     got = torch.bincount(cell(neg), minlength=256).double()
     want = free / free.sum() * k
     chi2 = float(((got - want) ** 2 / want).sum())
@@ -106,8 +153,16 @@ def test_degenerate_inputs():
     assert sampling.negative_sampling(empty, 50, 0, seed=1).shape == (2, 0)          # nothing to draw
     got = sampling.negative_sampling(empty, 50, 30, seed=1)                         # no positives at all
     assert got.shape == (2, 30) and torch.unique(got[0] * 50 + got[1]).numel() == 30
-    one = torch.tensor([[3], [3]], device=DEV)
-    got = sampling.negative_sampling(one, 7, 48, seed=2)                            # every free cell of a 7 x 7 grid
+    assert not bool((got[0] == got[1]).any())
+    one = torch.tensor([[3], [3]], device=DEV)                                      # a self loop is not a positive of the population
+    got = sampling.negative_sampling(one, 7, 48, seed=2)                            # every off-diagonal cell of a 7 x 7 grid: 42
     keys = torch.unique(got[0] * 7 + got[1])
-    assert keys.numel() == got.size(1) and 24 not in keys.tolist()
+    assert got.size(1) == 42 and keys.numel() == 42 and not bool((got[0] == got[1]).any())
+    two = torch.tensor([[3, 3, 2], [3, 5, 6]], device=DEV)                          # one loop + two real positives: 40 free cells
+    got = sampling.negative_sampling(two, 7, 48, seed=2)
+    keys = torch.unique(got[0] * 7 + got[1]).tolist()
+    assert got.size(1) == 40 and len(keys) == 40 and 3 * 7 + 5 not in keys and 2 * 7 + 6 not in keys
+    assert sampling.negative_sampling(torch.zeros(2, 1, dtype=torch.int64, device=DEV)).shape == (2, 0)   # N = 1: no population
+    full = torch.cartesian_prod(torch.arange(4), torch.arange(4)).t().contiguous().to(DEV)
+    assert sampling.negative_sampling(full[:, full[0] != full[1]]).shape == (2, 0)   # all 12 off-diagonal cells taken
     assert R.DeviceRand(seed=1).shuffle(torch.empty(0, dtype=torch.int64, device=DEV)).numel() == 0

@@ -164,5 +164,6 @@ def test_negative_sampling_properties_on_device():
     pos = set((ei[0] * nn + ei[1]).tolist())
     lin = (neg[0] * nn + neg[1]).tolist()
     assert not (set(lin) & pos) and len(set(lin)) == len(lin)
+    assert not bool((neg[0] == neg[1]).any())
     full = torch.cartesian_prod(torch.arange(3), torch.arange(3)).t().contiguous().to(DEV)
     assert negative_sampling(full).shape == (2, 0)

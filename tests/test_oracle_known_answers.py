@@ -98,9 +98,43 @@ def test_negative_sampling_properties():
     lin = (neg[0] * (int(ei.max()) + 1) + neg[1]).tolist()
     assert not (set(lin) & pos)
     assert len(set(lin)) == len(lin)
+    assert not bool((neg[0] == neg[1]).any())          # PyG 2.5.3: the population is off-diagonal
     # saturated graph -> empty
     full = torch.cartesian_prod(torch.arange(3), torch.arange(3)).t()
     assert P.negative_sampling(full).shape == (2, 0)
+    assert P.negative_sampling(full[:, full[0] != full[1]]).shape == (2, 0)   # the 6 off-diagonal cells alone saturate it
+
+
+def test_negative_sampling_offdiagonal_coding_known_answers():
+    """PyG 2.5.3 edge_index_to_vector / vector_to_edge_index (non-bipartite, directed), worked by hand on N = 4:
+    cell (r, c), r != c, has code 3 r + c - (r < c); codes 0..11 enumerate the rows with the diagonal skipped."""
+    ei = torch.tensor([[0, 0, 1, 2, 3, 3, 2], [1, 3, 0, 2, 0, 2, 2]])     # two self loops (2,2) among them
+    idx, population = P.edge_index_to_vector(ei, 4)
+    assert population == 12
+    assert idx.tolist() == [0, 2, 3, 9, 11]                               # loops dropped: (0,1)->0 (0,3)->2 (1,0)->3 (3,0)->9 (3,2)->11
+    back = P.vector_to_edge_index(torch.arange(12), 4)
+    want = [(r, c) for r in range(4) for c in range(4) if r != c]
+    assert list(zip(back[0].tolist(), back[1].tolist())) == want
+    assert torch.equal(P.vector_to_edge_index(idx, 4), ei[:, ei[0] != ei[1]])
+    # a 7 x 7 grid whose only positive is a self loop: all 42 off-diagonal cells are free, and over-asking returns them all
+    random.seed(0)
+    neg = P.negative_sampling(torch.tensor([[3], [3]]), num_nodes=7, num_neg_samples=48)
+    assert neg.shape == (2, 42) and not bool((neg[0] == neg[1]).any())
+    assert torch.unique(neg[0] * 7 + neg[1]).numel() == 42
+    # sizing: prob and sample_size come from the loop-free count and N^2 - N
+    calls = []
+
+    class Spy(type(P._rand.current())):
+        def sample(self, population, k):
+            calls.append((population, k))
+            return super().sample(population, k)
+
+    ei = torch.tensor([[0, 1, 2, 5, 9], [0, 2, 2, 6, 3]])                 # N = 10, E = 5, loop-free 3
+    with P._rand.use(Spy()):
+        random.seed(1)
+        neg = P.negative_sampling(ei)                                      # num_neg_samples None -> edge_index.size(1) = 5
+    assert neg.shape == (2, 5)
+    assert calls[0] == (90, int(1.1 * 5 / (1.0 - 3 / 90)))
 
 
 def test_mask_and_dropout_restatements():
