@@ -84,7 +84,7 @@ SIGNATURES = {
     "bkg_permute_gather_i64": (I32, [P, I64, U64, P, P]),
     # fusion.hip
     "bkg_attn_fuse_f32": (I32, [P, I64, I64, I32, I32, P, I64, P]),
-    "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, P, I64, P]),
+    "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, U32, P, I64, P]),
 }
 
 _lib = None

@@ -6,8 +6,9 @@ batch / graph and the gradients of ``self.model`` are averaged.  That is what th
 sized for xGMI: the R-GCN (R=30, d=256) gradient is 32.5 MB and the GCN+head 1.8 MB, so ALL gradients
 go out as ONE flat bucket per step (a ring all-reduce over 7 x ~153 GB/s links is per-link bound:
 2*(7/8)*32.5 MB / 153 GB/s ~ 0.37 ms; splitting it would only add launch latency).  No collective is on
-the data path of a single-GPU step.  Node-partitioned full-graph training (all-gather of boundary
-embeddings per layer) is the next multi-GPU row and is not built yet.
+the data path of a single-GPU step.  Node-partitioned full-graph training (destination-node shards, all-gather of
+the layer tables / reduce-scatter of their gradients) lives in ``biomedkg_amd/partition.py`` and uses
+the bucket below for the replicated weights.
 """
 from __future__ import annotations
 
@@ -49,15 +50,18 @@ class GradBucket:
         the backend's own stream / thread).  ``finish`` must be called before the gradients are used."""
         if self.world == 1:
             return
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        for p in self.params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in self.params]
         n = sum(g.numel() for g in grads)
         if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
             self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
-        off = 0
-        for g in grads:
-            self._flat[off:off + g.numel()].copy_(g.reshape(-1))
-            off += g.numel()
-        self._grads = grads
+            self._views, off = [], 0
+            for g in grads:                       # persistent views of the bucket, one per parameter
+                self._views.append(self._flat[off:off + g.numel()].view(g.shape))
+                off += g.numel()
+        torch._foreach_copy_(self._views, grads)  # one fused pack instead of a copy_ launch per parameter
         self._work = dist.all_reduce(self._flat, async_op=True)
 
     def finish(self):
@@ -67,13 +71,7 @@ class GradBucket:
         self._work.wait()
         self._work = None
         self._flat.div_(self.world)
-        off = 0
-        for p, g in zip(self.params, self._grads):
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-            p.grad.copy_(self._flat[off:off + g.numel()].view_as(p))
-            off += g.numel()
-        self._grads = None
+        torch._foreach_copy_([p.grad for p in self.params], self._views)
 
     def all_reduce(self):
         self.begin()
@@ -93,3 +91,33 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def broadcast_object(obj, src=0):
+    """Rank ``src``'s python object on every rank (paths, small metadata)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def mean_over_ranks(values, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return (t / dist.get_world_size()).tolist()
+
+
+def any_over_ranks(flag: bool, device) -> bool:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -301,6 +301,17 @@ def _bf16_ok(d):
     return d % 8 == 0 and (d // 8) in (4, 8, 16, 32, 64, 96, 128, 192, 256)
 
 
+def _plain_dropout_keep(relu, drop):
+    """Dropout WITHOUT a ReLU in front (not on the reference's path: encoder.py:50-59,153-162 always pair them):
+    the backward gate cannot be read off the output's sign -- a kept element may be exactly 0 -- so it needs the
+    keep decisions themselves.  An explicit mask is carried to the backward; the in-kernel Philox stream is refused."""
+    if relu or drop is None or drop.p <= 0:
+        return None
+    if drop.keep is None:
+        raise NotImplementedError("dropout without ReLU needs an explicit keep mask (Dropout.keep)")
+    return drop.keep
+
+
 def _gate(dout, out, scale):
     """Backward of ``dropout(relu(.))`` from the saved OUTPUT: ``out > 0`` iff pre > 0 and kept."""
     return torch.where(out > 0, dout * scale, torch.zeros((), dtype=dout.dtype, device=dout.device))
@@ -377,6 +388,7 @@ class _GcnConv(torch.autograd.Function):
         ctx.graph, ctx.gw, ctx.relu = graph, gw, relu
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
+        ctx.keep = _plain_dropout_keep(relu, drop)
         ctx.save_for_backward(x, weight, out if ctx.gated else None)
         return out
 
@@ -390,7 +402,7 @@ class _GcnConv(torch.autograd.Function):
             dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
         elif ctx.gated:
             dout, out = _as_f32(dout), _as_f32(out)
-            dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
+            dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * ctx.keep * ctx.scale
         else:
             dout = _as_f32(dout)
         c = g.by_src
@@ -506,6 +518,7 @@ class _GcnConvViews(torch.autograd.Function):
         ctx.graph, ctx.gw, ctx.relu, ctx.views, ctx.is_table = graph, gw, relu, views, is_table
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
+        ctx.keep = _plain_dropout_keep(relu, drop)
         ctx.table_dtype = x2.dtype
         ctx.save_for_backward(None if is_table else x2, weight, out if ctx.gated else None)
         return out
@@ -519,7 +532,7 @@ class _GcnConvViews(torch.autograd.Function):
         if ctx.relu or not ctx.gated:
             dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
         else:
-            dout = to_bf16(_as_f32(dout) * (_as_f32(out) != 0) * ctx.scale)
+            dout = to_bf16(_as_f32(dout) * ctx.keep * ctx.scale)
         c = g.by_src
         dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n, self_w=gw.self_w, split=c.split, out_dtype=torch.bfloat16)
         d_out = dout.size(1) // v
@@ -563,6 +576,7 @@ class _RgcnConv(torch.autograd.Function):
         ctx.rg, ctx.relu = rg, relu
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
+        ctx.keep = _plain_dropout_keep(relu, drop)
         ctx.save_for_backward(x, weight, root, h, out if ctx.gated else None)
         return out
 
@@ -580,7 +594,7 @@ class _RgcnConv(torch.autograd.Function):
             dout = _as_f32(dout)
             if ctx.gated:
                 out = _as_f32(out)
-                dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
+                dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * ctx.keep * ctx.scale
         # dY[s] = dOut[dst_s] is never stored when both of its consumers can read dOut's rows through seg_dst
         gathered = (dout.dtype == torch.bfloat16 and gathered_k_ok(h, dout)
                     and _xw_ok(dout, rg.num_segments, d_in, d_out))
@@ -641,6 +655,7 @@ class _SpmmFn(torch.autograd.Function):
         ctx.bwd, ctx.w_bwd, ctx.n_table, ctx.relu = bwd, w_bwd, table.size(0), relu
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
+        ctx.keep = _plain_dropout_keep(relu, drop)
         ctx.save_for_backward(out if ctx.gated else None)
         return out
 
@@ -649,7 +664,7 @@ class _SpmmFn(torch.autograd.Function):
         (out,) = ctx.saved_tensors
         dout = _f32c(dout)
         if ctx.gated:
-            dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * (out != 0) * ctx.scale
+            dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * ctx.keep * ctx.scale
         dtable = None
         if ctx.needs_input_grad[0]:
             dtable = spmm(ctx.bwd.rowptr, ctx.bwd.col, ctx.w_bwd, _table(dout), ctx.n_table, split=ctx.bwd.split)
@@ -944,11 +959,11 @@ def redaf_fusion(x, w_t, b_t, scale, drop: Dropout = None):
     n, m, d = x.shape
     t = gemm(_f32c(x).view(n * m, d), w_t, trans_b=True, bias=b_t, act=ACT_RELU)
     out = torch.empty(n, d, dtype=torch.float32, device=x.device)
-    keep, p, seed = None, 0.0, 0
+    keep, p, seed, sid = None, 0.0, 0, 0
     if drop is not None and drop.p > 0:
-        p, seed = drop.p, drop.seed
+        p, seed, sid = drop.p, drop.seed, drop.stream_id      # stream_id: the provider's per-call counter (fresh mask per call)
         if drop.keep is not None:
             keep = drop.keep.to(torch.uint8).contiguous()
-    L.call("bkg_redaf_combine_f32", L.ptr(t), t.stride(0), n, m, d, L.ptr(_f32c(scale)), L.ptr(keep), p, seed,
+    L.call("bkg_redaf_combine_f32", L.ptr(t), t.stride(0), n, m, d, L.ptr(_f32c(scale)), L.ptr(keep), p, seed, sid,
            L.ptr(out), out.stride(0), L.stream())
     return out

@@ -127,6 +127,12 @@ def current():
     return _current
 
 
+def reseed_default(seed):
+    """Re-key the process-wide default provider (the Trainer stand-in gives every rank its own stream)."""
+    global _current
+    _current = DeviceRand(seed)
+
+
 class use:
     def __init__(self, provider):
         self.provider = provider

@@ -110,13 +110,30 @@ class NeighborBatchLoader:
         self.x, self.edge_type, self.batch_size, self.shuffle = x, edge_type, int(batch_size), shuffle
         self.sampler = NeighborSampler(edge_index, x.size(0), num_neighbors, seed)
 
-    def __len__(self):
+        self.rank, self.world, self.epoch, self.seed = 0, 1, 0, int(seed)
+
+    def set_rank(self, rank, world):
+        """DistributedSampler semantics: one shuffled order shared by the ranks (same generator seed), rank r takes
+        seed batches r, r + world, ...; every rank runs the same number of steps (the tail wraps around)."""
+        self.rank, self.world = int(rank), int(world)
+
+    def _num_batches(self):
         return (self.x.size(0) + self.batch_size - 1) // self.batch_size
+
+    def __len__(self):
+        return (self._num_batches() + self.world - 1) // self.world
 
     def __iter__(self):
         n, dev = self.x.size(0), self.x.device
-        order = torch.randperm(n, device=dev) if self.shuffle else torch.arange(n, device=dev)
-        for i in range(0, n, self.batch_size):
+        if self.world > 1:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)      # identical on every rank
+            order = (torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)).to(dev)
+            self.epoch += 1
+        else:
+            order = torch.randperm(n, device=dev) if self.shuffle else torch.arange(n, device=dev)
+        nb = self._num_batches()
+        for step in range(len(self)):
+            i = ((step * self.world + self.rank) % nb) * self.batch_size
             seeds = order[i:i + self.batch_size]
             n_id, ei, e_id = self.sampler.sample(seeds)
             et = self.edge_type[e_id] if self.edge_type is not None else None
@@ -129,6 +146,11 @@ class SaintBatchLoader:
     def __init__(self, x, edge_index, edge_type, batch_size, walk_length=10, num_steps=1000, seed=0):
         self.x, self.edge_type, self.num_steps = x, edge_type, int(num_steps)
         self.sampler = SaintRandomWalkSampler(edge_index, x.size(0), batch_size, walk_length, seed)
+
+    def set_rank(self, rank, world):
+        """Each rank walks from its own roots with its own stream (the steps per epoch stay ``num_steps`` per rank, as
+        under Lightning DDP, where GraphSAINT loaders are not sharded but each process draws independently)."""
+        self.sampler.seed = self.sampler.seed * 131 + int(rank) + 1
 
     def __len__(self):
         return self.num_steps

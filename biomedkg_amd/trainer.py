@@ -4,7 +4,10 @@
 norm over the optimiser's parameters), ``fast_dev_run``, ``ModelCheckpoint(monitor, mode, save_top_k,
 save_last)``, ``EarlyStopping(monitor, patience)``, ``estimated_stepping_batches``, the per-EPOCH
 ``lr_scheduler.step()`` Lightning applies to a bare scheduler, ``test(ckpt_path="best")``
-and -- for ``devices`` > 1 under torch.distributed.run -- DDP-style gradient averaging over RCCL.
+and -- for ``devices`` > 1 under torch.distributed.run -- DDP-style data parallelism over RCCL: every rank draws its
+OWN batches (per-rank seeds; loaders that define ``set_rank`` shard their seed batches), gradients are averaged through
+one flat bucket, the monitored metrics are averaged and ``should_stop`` is OR-ed over the ranks before the callbacks
+act on them (so no rank can leave the loop while the others wait in a collective), and checkpoint paths are rank 0's.
 Used only when ``lightning`` is not importable.
 """
 from __future__ import annotations
@@ -47,7 +50,7 @@ class ModelCheckpoint:
         self.best.sort(key=lambda t: t[0], reverse=self.mode != "min")
         trainer.save_checkpoint(module, path)
         for _, old in self.best[self.save_top_k:]:
-            if os.path.exists(old):
+            if trainer.rank == 0 and os.path.exists(old):
                 os.remove(old)
         self.best = self.best[: self.save_top_k]
         self.best_model_path = self.best[0][1]
@@ -82,6 +85,14 @@ class Trainer:
         self.log_every, self.root = log_every_n_steps, default_root_dir
         self.rank, self.world, self.local = D.init_from_env()
         self.device = torch.device("cuda", self.local) if torch.cuda.is_available() else torch.device("cpu")
+        if self.world > 1:
+            # the entry points stamp their checkpoint directory with time.time() on every rank: use rank 0's everywhere
+            dirs = [self.root] + [getattr(cb, "dirpath", None) for cb in self.callbacks]
+            dirs = D.broadcast_object(dirs, src=0)
+            self.root = dirs[0]
+            for cb, d in zip(self.callbacks, dirs[1:]):
+                if d is not None:
+                    cb.dirpath = d
         self.current_epoch = self.global_step = 0
         self.should_stop = False
         self.estimated_stepping_batches = 0
@@ -97,8 +108,27 @@ class Trainer:
     def _flush_logs(self):
         out = {k: sum(v) / len(v) for k, v in self._epoch_logs.items()}
         self._epoch_logs = {}
+        if self.world > 1 and out:               # every rank logs the same keys: average them (Lightning's sync_dist)
+            keys = sorted(out)
+            vals = D.mean_over_ranks([out[k] for k in keys], self.device)
+            out = dict(zip(keys, vals))
         self.callback_metrics.update(out)
         return out
+
+    def _seed_rank(self, loaders):
+        """Per-rank randomness: without it every rank would draw the same batches, masks and negatives and N GPUs
+        would do one GPU's work (Lightning shards through DistributedSampler; the device samplers through set_rank)."""
+        if self.world == 1:
+            return
+        base = int(os.environ.get("PL_GLOBAL_SEED", torch.initial_seed())) & 0x7FFFFFFF
+        random.seed(base + self.rank)
+        np.random.seed((base + self.rank) % (1 << 32))
+        torch.manual_seed(base + self.rank)
+        from . import rand as R
+        R.reseed_default(base + self.rank)
+        for ld in loaders:
+            if ld is not None and hasattr(ld, "set_rank"):
+                ld.set_rank(self.rank, self.world)
 
     def save_checkpoint(self, module, path):
         if self.rank != 0:
@@ -120,6 +150,7 @@ class Trainer:
         model.trainer = self
         model.to(self.device)
         D.broadcast_parameters(model)
+        self._seed_rank([train_dataloaders, val_dataloaders])
         steps_per_epoch = len(train_dataloaders) if hasattr(train_dataloaders, "__len__") else 1
         epochs = 1 if self.fast_dev_run else self.max_epochs
         self.estimated_stepping_batches = 1 if self.fast_dev_run else steps_per_epoch * epochs
@@ -148,6 +179,7 @@ class Trainer:
                 logs.update(self.validate(model, val_dataloaders))
                 for cb in self.callbacks:
                     cb.on_validation_end(self, model, self.callback_metrics)
+                self.should_stop = D.any_over_ranks(self.should_stop, self.device)
             self.history.append(logs)
             if self.rank == 0:
                 print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in logs.items()}), flush=True)
@@ -171,6 +203,9 @@ class Trainer:
         model.to(self.device)
         if ckpt_path == "best":
             best = next((cb.best_model_path for cb in self.callbacks if isinstance(cb, ModelCheckpoint)), "")
+            if self.world > 1:                   # rank 0 wrote the file: wait for it, then every rank loads the same one
+                D.barrier()
+                best = D.broadcast_object(best, src=0)
             if best and os.path.exists(best):
                 model.load_state_dict(torch.load(best, map_location=self.device, weights_only=False)["state_dict"])
         model.eval()

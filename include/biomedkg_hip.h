@@ -238,8 +238,11 @@ int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t seed, int64_t
 /* ---- modality fusion epilogues (biomedkg/utils/fusion.py:17-31 AttentionFusion, :49-90 ReDAF) */
 int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_t D, float* out, int64_t ldo,
                       void* stream);
+/* ReDAF dropout: `keep` (explicit mask, [n*M, D] bytes) or, when NULL and drop_p > 0, an in-kernel Philox stream keyed by
+ * (seed, stream_id) -- the caller advances stream_id on every call, as nn.Dropout draws a fresh mask per forward. */
 int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int32_t M, int32_t D, const float* scale,
-                          const uint8_t* keep, float drop_p, uint64_t seed, float* out, int64_t ldo, void* stream);
+                          const uint8_t* keep, float drop_p, uint64_t seed, uint32_t stream_id, float* out, int64_t ldo,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -120,3 +120,54 @@ def test_kge_module_step_with_saturated_graph_returns_no_negatives():
     assert neg_ei.shape == (2, 0)
     z = mod(b.x, b.edge_index, b.edge_type)
     assert torch.isfinite(z).all()
+
+
+def test_redaf_training_dropout_draws_a_fresh_mask_every_call():
+    """reference fusion.py:44,84: nn.Dropout(0.1) draws a new mask per forward.  Under the default DeviceRand the
+    in-kernel Philox stream is keyed by the provider's per-call counter (a constant key would zero the same 10 % of
+    positions on every training step)."""
+    from biomedkg_amd import rand as R
+    from biomedkg_amd.utils.fusion import ReDAF
+    torch.manual_seed(0)
+    f = ReDAF(64).to(DEV).train()
+    with torch.no_grad():
+        f.transform_layer.weight.copy_(torch.eye(64))     # t = relu(x): positive x stays > 0 unless dropped
+        f.transform_layer.bias.zero_()
+    x = torch.rand(512, 2, 64, device=DEV) + 0.5
+    with R.use(R.DeviceRand(seed=3)):
+        a, b = f(x), f(x)
+    with R.use(R.DeviceRand(seed=3)):
+        a2 = f(x)
+    assert torch.equal(a, a2)                               # a pure function of (seed, call number)
+    assert not torch.equal(a, b)                            # ... and the second call draws differently
+    # per (row, modality, feature) drop rate ~ 0.1: the mean of two modalities loses one of them w.p. ~0.18
+    f.eval()
+    full = f(x)
+    partial = ((a < 0.75 * full) & (full > 0)).float().mean()
+    assert 0.12 < float(partial) < 0.25, float(partial)
+
+
+def test_dropout_without_relu_gates_by_the_mask_not_by_the_output_sign():
+    """A kept element whose pre-activation is exactly 0 still passes its gradient: GCNConv with
+    relu=False and an explicit keep mask against the oracle; the in-kernel stream is refused for this shape."""
+    from biomedkg_amd import graph as G, ops
+    from oracle import pyg_ops as P
+    torch.manual_seed(5)
+    n, d_in, d_out = 50, 8, 6
+    ei = torch.randint(0, n, (2, 200))
+    x, w = torch.randn(n, d_in), torch.randn(d_out, d_in)
+    x[:10] = 0.0                                            # rows whose neighbourhoods may sum to exactly 0
+    b = torch.zeros(d_out)
+    keep = torch.rand(n, d_out) >= 0.3
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = P.gcn_conv(xo, ei, wo, b) * keep / 0.7
+    (ref * torch.arange(1, d_out + 1)).sum().backward()
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    gr = G.Graph(ei.to(DEV), n)
+    out = ops.gcn_conv(xd, wd, b.to(DEV), gr, gr.gcn_weights(), relu=False, drop=ops.Dropout(0.3, keep=keep.to(DEV)))
+    (out * torch.arange(1, d_out + 1, device=DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), **TOL)
+    torch.testing.assert_close(xd.grad.cpu(), xo.grad, **TOL)
+    torch.testing.assert_close(wd.grad.cpu(), wo.grad, **TOL)
+    with pytest.raises(NotImplementedError):
+        ops.gcn_conv(xd, wd, b.to(DEV), gr, gr.gcn_weights(), relu=False, drop=ops.Dropout(0.3, seed=1, stream_id=1))
