@@ -59,8 +59,12 @@ SIGNATURES = {
     "bkg_kge_fused_bce_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
     "bkg_kge_bwd_rel_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, I32, P, I64, P, P, P]),
     # ntxent.hip
-    "bkg_ntxent_rowsum_f32": (I32, [P, I64, I64, I32, F32, I32, P, P]),
-    "bkg_ntxent_bwd_f32": (I32, [P, I64, I64, I32, F32, P, I32, P, P]),
+    "bkg_ntxent_hpad": (I32, [I32, I32]),
+    "bkg_ntxent_prepare": (I32, [P, I64, P, I64, I64, I32, I32, P, P, P, P, P]),
+    "bkg_ntxent_forward_workspace_floats": (I64, [I64, I32, I32]),
+    "bkg_ntxent_forward": (I32, [P, I32, I64, I32, F32, P, P, P, P, P, P]),
+    "bkg_ntxent_backward_workspace_floats": (I64, [I64, I32, I32]),
+    "bkg_ntxent_backward": (I32, [P, I32, P, P, P, P, I64, I32, F32, P, P, I64, P, I64, P]),
     # sample.hip
     "bkg_random_walk": (I32, [P, P, P, I64, I32, U64, P, P]),
     "bkg_sample_neighbors": (I32, [P, P, I64, I32, U64, U32, P, P]),

@@ -1,0 +1,637 @@
+// NT-Xent / GRACE InfoNCE with intra-view negatives -- v2: register-resident anchor rows, symmetric forward.
+//
+// Reference: PyGCL DualBranchContrast(InfoNCE(tau), "L2L", intraview_negs=True) called at
+// /root/reference/biomedkg/gcl_module.py:171-173,186-190.  With Z = [normalize(h1); normalize(h2)] (M = 2N rows) that
+// loss is exactly
+//     L = 1/M * sum_i ( -z_i.z_p(i)/tau + log D_i ),   D_i = sum_{j != i} E_ij,  E_ij = exp(z_i.z_j / tau),
+// p(i) = (i + N) mod M, and  dL/dz_i = 1/(M tau) * ( sum_{j != i} E_ij (1/D_i + 1/D_j) z_j  -  2 z_p(i) ).
+// PyGCL materialises ~8 [N,2N] fp32 temporaries per direction; here the Gram tiles live only in MFMA accumulators.
+//
+// Structure (one workgroup = NW waves = a PANEL of 32*NW anchor rows i; the other side streams by in 64-row j-tiles):
+//   * each wave keeps ITS 32 anchor rows as the B-operand fragments of the Gram product in registers for the whole
+//     panel (fp32: pre-scaled by log2(e)/tau so that E = exp2(S) needs no multiply; bf16: unscaled, the scale is applied
+//     to the fp32 accumulator), so the only LDS traffic is the j-tile, shared by all NW waves;
+//   * j-tiles are double-buffered in LDS (row-major, padded / XOR-swizzled rows) with the next tile's global loads
+//     in flight under the current tile's MFMAs: ONE barrier per tile;
+//   * the tile is computed transposed, S^T[j][i] (rows j in the accumulator registers, anchor i on the lane), so that
+//     (forward) the row sums over j are lane-local adds, and (backward) W^T = E (1/D_i + 1/D_j) is already the A operand
+//     of the second product dZ_I += W Z_J (cdna_hip_programming.md "An accumulator tile as the next MFMA's operand"):
+//     no LDS round trip for W; Z_J's B fragments come from the same LDS image (fp32: ds_read_b32 along the row;
+//     bf16: ds_read_b64_tr_b16 on the T10 (b) image that also serves the row reads of the first product);
+//   * FORWARD uses E's symmetry: only tiles at or right of the panel's own columns are computed (M^2 h instead of
+//     2 M^2 h flops); a tile strictly right of the panel contributes its row sums to D_i and its COLUMN sums to D_j
+//     (32-lane transpose-reduce butterfly, 31 shuffles per 32 values).  Work = the flattened upper-triangular list of
+//     (panel, j-tile) items, cut into equal contiguous ranges for a resident grid; row sums are written per
+//     (block, panel) segment, column sums per item, and a finishing kernel adds them in a FIXED order: no atomics,
+//     bitwise repeatable;
+//   * BACKWARD recomputes the tile (no symmetry: the transposed contribution would need an M x h float-atomic sum per
+//     tile, which is bound by the 1.3 TB/s atomic rate and is not repeatable); grid = panels x j-splits, partial dZ
+//     per split summed in split order by the finishing kernel, which also applies the -2 z_p(i) term and projects
+//     through the row normalisation.
+//   fp32 = v_mfma_f32_32x32x2_f32 (exact fp32, the 1e-5 loss bar of BASELINE configs[1]); bf16 operands =
+//   v_mfma_f32_32x32x16_bf16 with fp32 exp / sums / accumulators (BASELINE configs[2] scale).
+// No max-subtraction is needed (|cos| <= 1 so exp(s/tau) <= e^5 at tau = 0.2), matching PyGCL.
+#include "common.h"
+
+namespace bkg {
+
+typedef float nx_acc_t __attribute__((ext_vector_type(16)));
+typedef __bf16 nx_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short nx_s4_t __attribute__((ext_vector_type(4)));
+typedef short nx_s8_t __attribute__((ext_vector_type(8)));
+
+constexpr int NX_BJ = 64;   // rows of a j-tile
+
+struct NxArgs {
+  const void* zn;      // [M][HPAD] normalised rows, zero padded columns (fp32 or bf16)
+  int M;
+  float scale;         // log2(e) / tau
+  int n_panels, n_jtiles;
+  // forward
+  long long n_items;   // flattened (panel, j-tile) items
+  float* rowseg;       // [(grid + n_panels)][PR]   row sums per (block, panel) segment, slot = block + panel
+  float* colitem;      // [n_items][64]             column sums per item (diagonal-panel items: not written, not read)
+  // backward
+  const float* rden;   // [M] 1 / D
+  float* dzpart;       // [splits][M][HPAD]
+  int splits, jt_per_split;
+};
+
+// ---- work list of the symmetric forward: panel P owns j-tiles [P*q, n_jtiles), q = PR / 64
+__device__ __host__ __forceinline__ long long nx_start(long long P, int n_jtiles, int q) {
+  return P * n_jtiles - (long long)q * (P * (P - 1) / 2);
+}
+__device__ __forceinline__ int nx_panel_of(long long x, int n_panels, int n_jtiles, int q) {
+  int lo = 0, hi = n_panels - 1;   // largest P with start(P) <= x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (nx_start(mid, n_jtiles, q) <= x) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+// block that owns item x when the n_items are cut as lo(b) = floor(b * n_items / grid)
+__device__ __host__ __forceinline__ long long nx_block_of(long long x, long long n_items, long long grid) {
+  return ((x + 1) * grid - 1) / n_items;
+}
+
+// 32 values per lane (index v = 16 t + r of e[t][r]) -> lane q of each 32-lane half returns the half's sum of value q
+__device__ __forceinline__ float nx_transpose_reduce32(const nx_acc_t& e0, const nx_acc_t& e1, int l31) {
+  float a[16], b[8], c[4], d[2];
+  {
+    const bool hi = l31 & 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float keep = hi ? e1[r] : e0[r], send = hi ? e0[r] : e1[r];
+      a[r] = keep + __shfl_xor(send, 16, 64);
+    }
+  }
+  {
+    const bool hi = l31 & 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float keep = hi ? a[r + 8] : a[r], send = hi ? a[r] : a[r + 8];
+      b[r] = keep + __shfl_xor(send, 8, 64);
+    }
+  }
+  {
+    const bool hi = l31 & 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float keep = hi ? b[r + 4] : b[r], send = hi ? b[r] : b[r + 4];
+      c[r] = keep + __shfl_xor(send, 4, 64);
+    }
+  }
+  {
+    const bool hi = l31 & 2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float keep = hi ? c[r + 2] : c[r], send = hi ? c[r] : c[r + 2];
+      d[r] = keep + __shfl_xor(send, 2, 64);
+    }
+  }
+  const bool hi = l31 & 1;
+  const float keep = hi ? d[1] : d[0], send = hi ? d[0] : d[1];
+  return keep + __shfl_xor(send, 1, 64);
+}
+
+__device__ __forceinline__ int nx_acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// T10 image (b): [slab of 128 columns][row][256 B], 16-byte chunk ch of a row XORed with the row's tag
+__device__ __forceinline__ int nx_off16(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+// ------------------------------------------------------------------------------------------------ main kernel
+// BF16: operand type; HP = padded width / 32; NW waves; BWD.
+template <bool BF16, int HP, int NW, bool BWD>
+__global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
+  constexpr int HPAD = 32 * HP, PR = 32 * NW, NT = 64 * NW, Q = PR / NX_BJ;
+  constexpr int HS = HPAD + 4;                                   // fp32 image: padded row (floats)
+  constexpr int TILE_BYTES = BF16 ? NX_BJ * HPAD * 2 : NX_BJ * HS * 4;
+  constexpr int CH_ROW = BF16 ? HPAD / 8 : HPAD / 4;             // 16-byte chunks per row
+  constexpr int NPC = (NX_BJ * CH_ROW) / NT;                     // chunks staged per thread
+  static_assert((NX_BJ * CH_ROW) % NT == 0, "tile chunks must divide over the threads");
+  static_assert(!BF16 || HP % 4 == 0, "bf16 image is made of 128-column slabs");
+  constexpr int KF = BF16 ? HPAD / 16 : HPAD / 8;                // anchor fragments per lane (uint4 / float4 each)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto tile_at = [&](int b) { return smem + b * TILE_BYTES; };
+  float* aux = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);  // FWD: colbuf[2][NW][64]   BWD: rdj[2][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int M = a.M;
+  const unsigned char* zn = static_cast<const unsigned char*>(a.zn);
+  constexpr int ROW_BYTES = BF16 ? HPAD * 2 : HPAD * 4;
+
+  // ---- this block's work
+  long long x, x_end;
+  int P, jt;
+  if (BWD) {
+    const int split = blockIdx.x % a.splits;
+    P = blockIdx.x / a.splits;
+    jt = split * a.jt_per_split;
+    x = jt;
+    x_end = min(jt + a.jt_per_split, a.n_jtiles);
+    if (x >= x_end) return;
+  } else {
+    x = (long long)blockIdx.x * a.n_items / gridDim.x;
+    x_end = (long long)(blockIdx.x + 1) * a.n_items / gridDim.x;
+    if (x >= x_end) return;
+    P = nx_panel_of(x, a.n_panels, a.n_jtiles, Q);
+    jt = P * Q + (int)(x - nx_start(P, a.n_jtiles, Q));
+  }
+
+  // ---- staging registers: the next j-tile (and, backward, its 1/D values)
+  uint4 st[NPC];
+  float st_rd = 0.f;
+  auto prefetch = [&](int jt_) {
+    const int j0 = jt_ * NX_BJ;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int p = tid + i * NT, row = p / CH_ROW, ch = p % CH_ROW;
+      st[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (j0 + row < M) st[i] = *reinterpret_cast<const uint4*>(zn + (size_t)(j0 + row) * ROW_BYTES + ch * 16);
+    }
+    if (BWD && tid < NX_BJ) st_rd = (j0 + tid < M) ? a.rden[j0 + tid] : 0.f;
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int p = tid + i * NT, row = p / CH_ROW, ch = p % CH_ROW;
+      if (BF16) *reinterpret_cast<uint4*>(tile_at(buf) + (ch >> 4) * (NX_BJ * 256) + nx_off16(row, ch & 15)) = st[i];
+      else *reinterpret_cast<uint4*>(tile_at(buf) + (row * HS + ch * 4) * 4) = st[i];
+    }
+    if (BWD && tid < NX_BJ) aux[buf * NX_BJ + tid] = st_rd;
+  };
+
+  // ---- anchor fragments of this wave's 32 rows
+  uint4 zi[KF];
+  float rd_i = 0.f;
+  int i_glob = 0;
+  auto load_anchor = [&](int P_) {
+    i_glob = P_ * PR + wave * 32 + l31;
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+      zi[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (i_glob < M) {
+        // fp32: k values 8k + 4 lh + {0..3}; bf16: 16k + 8 lh + {0..7}  (16 bytes either way)
+        zi[k] = *reinterpret_cast<const uint4*>(zn + (size_t)i_glob * ROW_BYTES + (2 * k + lh) * 16);
+        if (!BF16) {
+          float4 f = __builtin_bit_cast(float4, zi[k]);
+          f.x *= a.scale; f.y *= a.scale; f.z *= a.scale; f.w *= a.scale;
+          zi[k] = __builtin_bit_cast(uint4, f);
+        }
+      }
+    }
+    if (BWD) rd_i = (i_glob < M) ? a.rden[i_glob] : 0.f;
+  };
+
+  nx_acc_t dz[BWD ? HP : 1];
+  if (BWD) {
+#pragma unroll
+    for (int t = 0; t < HP; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dz[t][r] = 0.f;
+  }
+  float rowsum = 0.f;
+  bool col_pending = false;     // forward: colbuf[buf ^ 1] holds the previous tile's column sums
+  long long col_item = 0;
+
+  prefetch(jt);
+  load_anchor(P);
+  int buf = 0;
+
+  for (; x < x_end; ++x) {
+    commit(buf);
+    __syncthreads();
+    if (!BWD && col_pending && tid < NX_BJ) {      // previous tile's column sums: add the waves in wave order
+      const float* cb = aux + (buf ^ 1) * (NW * NX_BJ);
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += cb[w * NX_BJ + tid];
+      a.colitem[col_item * NX_BJ + tid] = v;
+    }
+    // next item
+    int P_next = P, jt_next = jt + 1;
+    if (!BWD && jt_next == a.n_jtiles) { P_next = P + 1; jt_next = P_next * Q; }
+    if (x + 1 < x_end) prefetch(jt_next);
+
+    const int j0 = jt * NX_BJ;
+    const int iw0 = P * PR + wave * 32;
+    const bool need_mask = (j0 + NX_BJ > M) || (iw0 + 32 > M) || (j0 < iw0 + 32 && j0 + NX_BJ > iw0);
+
+    // ---- S^T[j][i] for the tile's two 32-row halves
+    nx_acc_t s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    if (BF16) {
+#pragma unroll
+      for (int k = 0; k < KF; ++k) {
+        const int cidx = 2 * k + lh;
+        const nx_bf16x8_t b = __builtin_bit_cast(nx_bf16x8_t, zi[k]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint4 av = *reinterpret_cast<const uint4*>(tile_at(buf) + (cidx >> 4) * (NX_BJ * 256) +
+                                                           nx_off16(32 * t + l31, cidx & 15));
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nx_bf16x8_t, av), b, s[t], 0, 0, 0);
+        }
+      }
+    } else {
+      const float* zj = reinterpret_cast<const float*>(tile_at(buf));
+#pragma unroll
+      for (int k = 0; k < KF; ++k) {
+        const float4 b = __builtin_bit_cast(float4, zi[k]);
+        const float4 a0 = *reinterpret_cast<const float4*>(zj + (l31)*HS + 8 * k + 4 * lh);
+        const float4 a1 = *reinterpret_cast<const float4*>(zj + (32 + l31) * HS + 8 * k + 4 * lh);
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, s[0], 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, s[1], 0, 0, 0);
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, s[0], 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, s[1], 0, 0, 0);
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, s[0], 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, s[1], 0, 0, 0);
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, s[0], 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, s[1], 0, 0, 0);
+      }
+    }
+
+    // ---- E = exp2(S) (bf16: S still needs the scale), masked where the tile touches the diagonal / the boundary
+    const float* rdj = aux + buf * NX_BJ;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jl = 32 * t + nx_acc_row(r, lh);
+        float e = __builtin_amdgcn_exp2f(BF16 ? s[t][r] * a.scale : s[t][r]);
+        if (need_mask) {
+          const int jg = j0 + jl;
+          e = (jg < M && i_glob < M && jg != i_glob) ? e : 0.f;
+        }
+        if (BWD) e *= rd_i + rdj[jl];
+        else rowsum += e;
+        s[t][r] = e;
+      }
+
+    if (!BWD) {
+      // column sums, unless the tile lies inside the panel's own columns (those pairs are also computed transposed)
+      col_pending = jt >= (P + 1) * Q;
+      if (col_pending) {
+        const float v = nx_transpose_reduce32(s[0], s[1], l31);
+        aux[buf * (NW * NX_BJ) + wave * NX_BJ + 32 * (l31 >> 4) + nx_acc_row(l31 & 15, lh)] = v;
+        col_item = x;
+      }
+    } else if (BF16) {
+      // dZ[i][c] += sum_j W[j][i] Z_J[j][c]: accumulator registers 8 s2 .. 8 s2 + 7 are the A fragment of k-step s2
+      const int grp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          nx_bf16x8_t wf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wf[e] = (__bf16)s[t][8 * s2 + e];
+          const int r0 = 32 * t + 16 * s2 + 4 * (grp >> 1);
+#pragma unroll
+          for (int ct = 0; ct < HP; ++ct) {
+            const int cchunk = 4 * ct + 2 * (grp & 1);           // first 16-byte chunk of the group's 16 columns
+            const unsigned char* base = tile_at(buf) + (cchunk >> 4) * (NX_BJ * 256);
+            const int ch = (cchunk & 15) + (p4 >> 1);
+            const nx_s4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) nx_s4_t*)(base + nx_off16(r0 + q4, ch) + 8 * (p4 & 1)));
+            const nx_s4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) nx_s4_t*)(base + nx_off16(r0 + 8 + q4, ch) + 8 * (p4 & 1)));
+            const nx_s8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            dz[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(nx_bf16x8_t, bv), dz[ct], 0, 0, 0);
+          }
+        }
+    } else {
+      // register r of W^T is the A operand for k = {row(r, lh = 0), row(r, lh = 1)} of the j-half t
+      const float* zj = reinterpret_cast<const float*>(tile_at(buf));
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* zrow = zj + (32 * t + nx_acc_row(r, lh)) * HS + l31;
+#pragma unroll
+          for (int ct = 0; ct < HP; ++ct)
+            dz[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[t][r], zrow[32 * ct], dz[ct], 0, 0, 0);
+        }
+    }
+
+    // ---- advance; forward: leaving the panel -> write its row sums, take the next panel's anchors
+    const bool leave = (P_next != P) || (x + 1 == x_end);
+    if (!BWD && leave) {
+      const float tot = rowsum + __shfl_xor(rowsum, 32, 64);
+      if (lh == 0) a.rowseg[((size_t)blockIdx.x + P) * PR + wave * 32 + l31] = tot;
+      rowsum = 0.f;
+      if (x + 1 < x_end) load_anchor(P_next);
+    }
+    P = P_next;
+    jt = jt_next;
+    buf ^= 1;
+  }
+
+  if (!BWD) {
+    __syncthreads();
+    if (col_pending && tid < NX_BJ) {
+      const float* cb = aux + (buf ^ 1) * (NW * NX_BJ);
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += cb[w * NX_BJ + tid];
+      a.colitem[col_item * NX_BJ + tid] = v;
+    }
+  } else {
+    // dz[ct][r]: row i = wave*32 + row(r, lh), column 32 ct + l31 of this split's partial
+    const int split = blockIdx.x % a.splits;
+    const int ib = (blockIdx.x / a.splits) * PR + wave * 32;
+    float* out = a.dzpart + (size_t)split * M * HPAD;
+#pragma unroll
+    for (int ct = 0; ct < HP; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ig = ib + nx_acc_row(r, lh);
+        if (ig < M) out[(size_t)ig * HPAD + 32 * ct + l31] = dz[ct][r];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// One wave per positive pair (i, i + N): F.normalize (x / max(|x|, 1e-12)), padded fp32 (+ bf16) images, positive dot.
+__global__ __launch_bounds__(256) void nx_prep_kernel(const float* __restrict__ h1, int64_t ld1,
+                                                      const float* __restrict__ h2, int64_t ld2, int N, int h, int hpad,
+                                                      float* __restrict__ zn, __bf16* __restrict__ zn16,
+                                                      float* __restrict__ norm, float* __restrict__ posdot) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int c = lane * 4;
+  float u[4], v[4];
+  float su = 0.f, sv = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    u[q] = (c + q < h) ? h1[(int64_t)i * ld1 + c + q] : 0.f;
+    v[q] = (c + q < h) ? h2[(int64_t)i * ld2 + c + q] : 0.f;
+    su += u[q] * u[q];
+    sv += v[q] * v[q];
+  }
+  const float nu = fmaxf(sqrtf(wave_sum(su)), 1e-12f), nv = fmaxf(sqrtf(wave_sum(sv)), 1e-12f);
+  float dot = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    u[q] /= nu;
+    v[q] /= nv;
+    dot += u[q] * v[q];
+  }
+  dot = wave_sum(dot);
+  if (c < hpad) {
+    *reinterpret_cast<float4*>(zn + (size_t)i * hpad + c) = make_float4(u[0], u[1], u[2], u[3]);
+    *reinterpret_cast<float4*>(zn + (size_t)(i + N) * hpad + c) = make_float4(v[0], v[1], v[2], v[3]);
+    if (zn16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        zn16[(size_t)i * hpad + c + q] = (__bf16)u[q];
+        zn16[(size_t)(i + N) * hpad + c + q] = (__bf16)v[q];
+      }
+    }
+  }
+  if (lane == 0) {
+    norm[i] = nu;
+    norm[i + N] = nv;
+    posdot[i] = dot;
+  }
+}
+
+// D_i = (row segments of i's panel, in block order) + (column items of i's j-tile, in panel order); 1/D; loss term.
+__global__ __launch_bounds__(256) void nx_fwd_finish_kernel(const float* __restrict__ rowseg, const float* __restrict__ colitem,
+                                                            const float* __restrict__ posdot, int M, int N, int PR,
+                                                            int n_panels, int n_jtiles, long long n_items, long long grid,
+                                                            float inv_tau, float* __restrict__ den, float* __restrict__ rden,
+                                                            double* __restrict__ term) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int q = PR / NX_BJ, P = i / PR, jt = i / NX_BJ;
+  float d = 0.f;
+  const long long b0 = nx_block_of(nx_start(P, n_jtiles, q), n_items, grid);
+  const long long b1 = nx_block_of(nx_start(P + 1, n_jtiles, q) - 1, n_items, grid);
+  for (long long b = b0; b <= b1; ++b) d += rowseg[(size_t)(b + P) * PR + i % PR];
+  const int p_end = min(n_panels, jt / q);          // panels strictly left of this j-tile's own panel columns
+  for (int Pc = 0; Pc < p_end; ++Pc)
+    d += colitem[(size_t)(nx_start(Pc, n_jtiles, q) + jt - Pc * q) * NX_BJ + i % NX_BJ];
+  den[i] = d;
+  rden[i] = 1.0f / d;
+  term[i] = log((double)d) - (i < N ? 2.0 * (double)posdot[i] * (double)inv_tau : 0.0);
+}
+
+// dz = ((sum_s part_s - 2 z_p(i)) * g / (M tau)  projected through x / |x|) for one row per wave
+__global__ __launch_bounds__(256) void nx_bwd_finish_kernel(const float* __restrict__ dzpart, int splits,
+                                                            const float* __restrict__ zn, const float* __restrict__ norm,
+                                                            const float* __restrict__ gout, int M, int N, int h, int hpad,
+                                                            float inv_m_tau, float* __restrict__ dh1, int64_t ld1,
+                                                            float* __restrict__ dh2, int64_t ld2) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= M) return;
+  const int c = lane * 4;
+  const float g = gout[0] * inv_m_tau;
+  float4 d = make_float4(0.f, 0.f, 0.f, 0.f), z = d;
+  if (c < hpad) {
+    for (int s = 0; s < splits; ++s) {
+      const float4 p = *reinterpret_cast<const float4*>(dzpart + ((size_t)s * M + i) * hpad + c);
+      d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
+    }
+    z = *reinterpret_cast<const float4*>(zn + (size_t)i * hpad + c);
+    const int pi = i < N ? i + N : i - N;
+    const float4 zp = *reinterpret_cast<const float4*>(zn + (size_t)pi * hpad + c);
+    d.x = (d.x - 2.f * zp.x) * g; d.y = (d.y - 2.f * zp.y) * g; d.z = (d.z - 2.f * zp.z) * g; d.w = (d.w - 2.f * zp.w) * g;
+  }
+  const float zd = wave_sum(z.x * d.x + z.y * d.y + z.z * d.z + z.w * d.w);
+  const float inv = 1.0f / norm[i];
+  float* out = i < N ? dh1 + (int64_t)i * ld1 : dh2 + (int64_t)(i - N) * ld2;
+  const float o[4] = {(d.x - z.x * zd) * inv, (d.y - z.y * zd) * inv, (d.z - z.z * zd) * inv, (d.w - z.w * zd) * inv};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (c + q < h) out[c + q] = o[q];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct NxPlan { int nw, smem, occ; };
+
+template <bool BF16, int HP, int NW, bool BWD>
+static NxPlan nx_plan() {
+  constexpr int HPAD = 32 * HP;
+  const int tile = BF16 ? NX_BJ * HPAD * 2 : NX_BJ * (HPAD + 4) * 4;
+  const int smem = 2 * tile + (BWD ? 2 * NX_BJ : 2 * NW * NX_BJ) * 4;
+  static int occ_cache = -1;
+  if (occ_cache < 0) {
+    hipFuncSetAttribute((const void*)ntx2_kernel<BF16, HP, NW, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)ntx2_kernel<BF16, HP, NW, BWD>, NW * 64, smem) !=
+            hipSuccess || occ < 1)
+      occ = 1;
+    occ_cache = occ;
+  }
+  return NxPlan{NW, smem, occ_cache};
+}
+
+static int nx_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceProp_t p;
+    cus = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
+// waves per workgroup by (precision, direction, width): 8 waves (a 256-row panel, two waves per SIMD) wherever the
+// kernel fits 256 registers per lane, 4 waves (one per SIMD, up to 512 registers) for the widest accumulators
+static int nx_waves(bool bf16, int hp, bool bwd) { return (bwd && hp > 4) ? 4 : 8; }
+
+// (precision, direction, width) -> instantiation; the workgroup shape follows nx_waves()
+#define NX_FWD_CASES(FN, ...)                                                                     \
+  if (bf16) return hp <= 4 ? FN<true, 4, 8, false>(__VA_ARGS__) : FN<true, 8, 8, false>(__VA_ARGS__); \
+  switch (hp) {                                                                                   \
+    case 1: return FN<false, 1, 8, false>(__VA_ARGS__);                                           \
+    case 2: return FN<false, 2, 8, false>(__VA_ARGS__);                                           \
+    case 3: return FN<false, 3, 8, false>(__VA_ARGS__);                                           \
+    case 4: return FN<false, 4, 8, false>(__VA_ARGS__);                                           \
+    case 5: return FN<false, 5, 8, false>(__VA_ARGS__);                                           \
+    case 6: return FN<false, 6, 8, false>(__VA_ARGS__);                                           \
+    case 7: return FN<false, 7, 8, false>(__VA_ARGS__);                                           \
+    default: return FN<false, 8, 8, false>(__VA_ARGS__);                                          \
+  }
+#define NX_BWD_CASES(FN, ...)                                                                     \
+  if (bf16) return hp <= 4 ? FN<true, 4, 8, true>(__VA_ARGS__) : FN<true, 8, 4, true>(__VA_ARGS__);   \
+  switch (hp) {                                                                                   \
+    case 1: return FN<false, 1, 8, true>(__VA_ARGS__);                                            \
+    case 2: return FN<false, 2, 8, true>(__VA_ARGS__);                                            \
+    case 3: return FN<false, 3, 8, true>(__VA_ARGS__);                                            \
+    case 4: return FN<false, 4, 8, true>(__VA_ARGS__);                                            \
+    case 5: return FN<false, 5, 4, true>(__VA_ARGS__);                                            \
+    case 6: return FN<false, 6, 4, true>(__VA_ARGS__);                                            \
+    case 7: return FN<false, 7, 4, true>(__VA_ARGS__);                                            \
+    default: return FN<false, 8, 4, true>(__VA_ARGS__);                                           \
+  }
+
+template <bool BF16, int HP, int NW, bool BWD>
+static int nx_occ_of() { return nx_plan<BF16, HP, NW, BWD>().occ; }
+template <bool BF16, int HP, int NW, bool BWD>
+static int nx_launch(NxArgs a, int grid, hipStream_t s) {
+  const NxPlan p = nx_plan<BF16, HP, NW, BWD>();
+  hipLaunchKernelGGL((ntx2_kernel<BF16, HP, NW, BWD>), dim3(grid), dim3(NW * 64), p.smem, s, a);
+  return check_launch(BWD ? "bkg_ntxent_backward" : "bkg_ntxent_forward");
+}
+
+static int nx_occ(bool bf16, int hp, bool bwd) {
+  if (bwd) { NX_BWD_CASES(nx_occ_of) }
+  NX_FWD_CASES(nx_occ_of)
+}
+static int nx_run_fwd(bool bf16, int hp, NxArgs a, int grid, hipStream_t s) { NX_FWD_CASES(nx_launch, a, grid, s) }
+static int nx_run_bwd(bool bf16, int hp, NxArgs a, int grid, hipStream_t s) { NX_BWD_CASES(nx_launch, a, grid, s) }
+
+struct NxShape { int hpad, hp, pr, n_panels, n_jtiles, grid, splits, jt_per_split; long long n_items; };
+
+static NxShape nx_shape(int64_t M, int h, bool bf16, bool bwd) {
+  NxShape sh;
+  sh.hpad = bf16 ? (h <= 128 ? 128 : 256) : ((h + 31) / 32) * 32;
+  sh.hp = sh.hpad / 32;
+  sh.pr = 32 * nx_waves(bf16, sh.hp, bwd);
+  sh.n_panels = (int)((M + sh.pr - 1) / sh.pr);
+  sh.n_jtiles = (int)((M + NX_BJ - 1) / NX_BJ);
+  sh.n_items = nx_start(sh.n_panels, sh.n_jtiles, sh.pr / NX_BJ);
+  const int slots = nx_cus() * nx_occ(bf16, sh.hp, bwd);
+  sh.grid = (int)std::min<long long>(sh.n_items, slots);
+  // backward: enough j-splits to fill the chip once; none when the panels alone do (every workgroup then streams
+  // the same j-tiles at the same time: the tile crosses the fabric once per XCD)
+  sh.splits = sh.n_panels >= slots ? 1 : std::max(1, std::min(sh.n_jtiles, (slots + sh.n_panels / 2) / sh.n_panels));
+  sh.jt_per_split = (sh.n_jtiles + sh.splits - 1) / sh.splits;
+  sh.splits = (sh.n_jtiles + sh.jt_per_split - 1) / sh.jt_per_split;
+  return sh;
+}
+
+}  // namespace bkg
+
+using namespace bkg;
+
+// ---- C ABI (declared in include/biomedkg_hip.h)
+extern "C" int32_t bkg_ntxent_hpad(int32_t h, int32_t bf16) {
+  if (h <= 0 || h > 256) return -1;
+  return bf16 ? (h <= 128 ? 128 : 256) : ((h + 31) / 32) * 32;
+}
+
+extern "C" int bkg_ntxent_prepare(const float* h1, int64_t ld1, const float* h2, int64_t ld2, int64_t N, int32_t h,
+                                  int32_t hpad, float* zn, void* zn_bf16, float* norm, float* posdot, void* stream) {
+  BKG_ARG(N > 0 && h > 0 && h <= 256 && hpad >= h && hpad % 32 == 0 && hpad <= 256, "bkg_ntxent_prepare: 0 < h <= hpad <= 256");
+  hipLaunchKernelGGL(nx_prep_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, h1, ld1, h2, ld2, (int)N, h,
+                     hpad, zn, (__bf16*)zn_bf16, norm, posdot);
+  return check_launch("bkg_ntxent_prepare");
+}
+
+extern "C" int64_t bkg_ntxent_forward_workspace_floats(int64_t M, int32_t h, int32_t bf16) {
+  if (M <= 0 || h <= 0 || h > 256) return -1;
+  const NxShape sh = nx_shape(M, h, bf16 != 0, false);
+  return (int64_t)(sh.grid + sh.n_panels) * sh.pr + sh.n_items * NX_BJ;
+}
+
+// den[M], rden[M] = 1/D, term[M] (double) = log D_i - (i < N) * 2 z_i.z_(i+N) / tau;  loss = sum(term) / M
+extern "C" int bkg_ntxent_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau, const float* posdot,
+                                  float* workspace, float* den, float* rden, double* term, void* stream) {
+  BKG_ARG(M > 0 && M % 2 == 0 && M < (1ll << 30) && h > 0 && h <= 256 && tau > 0.f, "bkg_ntxent_forward: bad arguments (h <= 256)");
+  const NxShape sh = nx_shape(M, h, bf16 != 0, false);
+  NxArgs a{};
+  a.zn = zn; a.M = (int)M; a.scale = 1.4426950408889634f / tau;
+  a.n_panels = sh.n_panels; a.n_jtiles = sh.n_jtiles; a.n_items = sh.n_items;
+  a.rowseg = workspace;
+  a.colitem = workspace + (size_t)(sh.grid + sh.n_panels) * sh.pr;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = nx_run_fwd(bf16 != 0, sh.hp, a, sh.grid, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nx_fwd_finish_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, s, a.rowseg, a.colitem, posdot, (int)M,
+                     (int)(M / 2), sh.pr, sh.n_panels, sh.n_jtiles, sh.n_items, (long long)sh.grid, 1.0f / tau, den, rden,
+                     term);
+  return check_launch("bkg_ntxent_forward(finish)");
+}
+
+extern "C" int64_t bkg_ntxent_backward_workspace_floats(int64_t M, int32_t h, int32_t bf16) {
+  if (M <= 0 || h <= 0 || h > 256) return -1;
+  const NxShape sh = nx_shape(M, h, bf16 != 0, true);
+  return (int64_t)sh.splits * M * sh.hpad;
+}
+
+// dh1 / dh2 [N, h]: gradient of the loss wrt the UN-normalised inputs, times the upstream scalar *gout (device)
+extern "C" int bkg_ntxent_backward(const void* zn, int32_t bf16, const float* zn_f32, const float* norm, const float* rden,
+                                   const float* gout, int64_t M, int32_t h, float tau, float* workspace, float* dh1,
+                                   int64_t ld1, float* dh2, int64_t ld2, void* stream) {
+  BKG_ARG(M > 0 && M % 2 == 0 && M < (1ll << 30) && h > 0 && h <= 256 && tau > 0.f, "bkg_ntxent_backward: bad arguments (h <= 256)");
+  const NxShape sh = nx_shape(M, h, bf16 != 0, true);
+  NxArgs a{};
+  a.zn = zn; a.M = (int)M; a.scale = 1.4426950408889634f / tau;
+  a.n_panels = sh.n_panels; a.n_jtiles = sh.n_jtiles;
+  a.rden = rden; a.dzpart = workspace; a.splits = sh.splits; a.jt_per_split = sh.jt_per_split;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = nx_run_bwd(bf16 != 0, sh.hp, a, sh.n_panels * sh.splits, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nx_bwd_finish_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, workspace, sh.splits, zn_f32, norm, gout,
+                     (int)M, (int)(M / 2), h, sh.hpad, 1.0f / ((float)M * tau), dh1, ld1, dh2, ld2);
+  return check_launch("bkg_ntxent_backward(finish)");
+}

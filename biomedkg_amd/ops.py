@@ -894,49 +894,60 @@ def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_
 
 
 # ----------------------------------------------------------------------------- NT-Xent
-def _ntxent_splits(m):
-    n_i = (m + 63) // 64
-    return max(1, min(16, 1024 // n_i))
-
-
 class _NtXent(torch.autograd.Function):
-    """GRACE loss: DualBranchContrast(InfoNCE(tau), L2L, intraview_negs=True)(h1, h2)."""
+    """GRACE loss: DualBranchContrast(InfoNCE(tau), L2L, intraview_negs=True)(h1, h2) -- reference
+    gcl_module.py:171-173,186-190.  Four launches forward (normalise, Gram tiles, fixed-order finish, sum), two
+    backward (csrc/ntxent2.hip); ``operands``: "fp32" = exact fp32 MFMA, "bf16" = bf16 MFMA operands with fp32
+    exp / sums (the matmul precision mode picks it)."""
 
     @staticmethod
-    def forward(ctx, h1, h2, tau):
+    def forward(ctx, h1, h2, tau, bf16):
         n, h = h1.shape
-        m = 2 * n
-        z = torch.cat([h1, h2], dim=0)
-        norm = z.norm(dim=1, keepdim=True).clamp_min(1e-12)
-        zn = (z / norm).contiguous()
-        splits = _ntxent_splits(m)
-        part = torch.empty(splits, m, dtype=torch.float32, device=z.device)
-        L.call("bkg_ntxent_rowsum_f32", L.ptr(zn), zn.stride(0), m, h, tau, splits, L.ptr(part), L.stream())
-        den = part.sum(0)
-        pos = (zn[:n] * zn[n:]).sum(1).double().sum() / tau
-        loss = (torch.log(den.double()).sum() - 2.0 * pos) / m
-        ctx.tau, ctx.n = tau, n
-        ctx.save_for_backward(zn, norm, den)
-        return loss.float()
+        m, dev = 2 * n, h1.device
+        hpad = L.lib().bkg_ntxent_hpad(h, bf16)
+        if hpad < 0:
+            raise ValueError(f"ntxent_loss: embedding width {h} > 256 is not supported")
+        zn = torch.empty(m, hpad, dtype=torch.float32, device=dev)
+        zn16 = torch.empty(m, hpad, dtype=torch.bfloat16, device=dev) if bf16 else None
+        norm = torch.empty(m, dtype=torch.float32, device=dev)
+        posdot = torch.empty(n, dtype=torch.float32, device=dev)
+        L.call("bkg_ntxent_prepare", L.ptr(h1), h1.stride(0), L.ptr(h2), h2.stride(0), n, h, hpad, L.ptr(zn), L.ptr(zn16),
+               L.ptr(norm), L.ptr(posdot), L.stream())
+        ws = torch.empty(L.lib().bkg_ntxent_forward_workspace_floats(m, h, bf16), dtype=torch.float32, device=dev)
+        den = torch.empty(2, m, dtype=torch.float32, device=dev)          # D and 1 / D
+        term = torch.empty(m, dtype=torch.float64, device=dev)
+        L.call("bkg_ntxent_forward", L.ptr(zn16 if bf16 else zn), bf16, m, h, tau, L.ptr(posdot), L.ptr(ws), L.ptr(den[0]),
+               L.ptr(den[1]), L.ptr(term), L.stream())
+        ctx.tau, ctx.n, ctx.h, ctx.bf16 = tau, n, h, bf16
+        ctx.save_for_backward(zn, zn16, norm, den)
+        return (term.sum() / m).float()
 
     @staticmethod
     def backward(ctx, g):
-        zn, norm, den = ctx.saved_tensors
-        n, tau = ctx.n, ctx.tau
-        m, h = zn.shape
-        rden = (1.0 / den).contiguous()
-        splits = _ntxent_splits(m)
-        part = torch.empty(splits, m, h, dtype=torch.float32, device=zn.device)
-        L.call("bkg_ntxent_bwd_f32", L.ptr(zn), zn.stride(0), m, h, tau, L.ptr(rden), splits, L.ptr(part), L.stream())
-        dzn = part.sum(0) - 2.0 * torch.roll(zn, n, dims=0)
-        dzn = dzn * (g / (m * tau))
-        dz = (dzn - zn * (zn * dzn).sum(1, keepdim=True)) / norm
-        return dz[:n], dz[n:], None
+        zn, zn16, norm, den = ctx.saved_tensors
+        n, h, tau, bf16 = ctx.n, ctx.h, ctx.tau, ctx.bf16
+        m, dev = 2 * n, zn.device
+        g = g.reshape(1).to(torch.float32).contiguous()
+        ws = torch.empty(L.lib().bkg_ntxent_backward_workspace_floats(m, h, bf16), dtype=torch.float32, device=dev)
+        dh = torch.empty(2, n, h, dtype=torch.float32, device=dev)
+        L.call("bkg_ntxent_backward", L.ptr(zn16 if bf16 else zn), bf16, L.ptr(zn), L.ptr(norm), L.ptr(den[1]), L.ptr(g), m, h,
+               tau, L.ptr(ws), L.ptr(dh[0]), h, L.ptr(dh[1]), h, L.stream())
+        return dh[0], dh[1], None, None
 
 
-def ntxent_loss(h1, h2, tau=0.2):
+def ntxent_loss(h1, h2, tau=0.2, operands=None):
+    """``operands``: None = follow the matmul precision mode, or "fp32" / "bf16" explicitly."""
     L.require_cuda(h1, h2)
-    return _NtXent.apply(_f32c(h1), _f32c(h2), float(tau))
+    if operands is None:
+        operands = "bf16" if _PRECISION == 1 else "fp32"
+    if h1.shape != h2.shape or h1.dim() != 2:
+        raise ValueError("ntxent_loss expects two [N, h] views")
+    if h1.size(1) > 256:
+        raise ValueError(f"ntxent_loss: embedding width {h1.size(1)} > 256 is not supported")
+    h1, h2 = _f32c(h1), _f32c(h2)
+    if h1.size(0) == 0:
+        return (h1.sum() + h2.sum()) * 0.0
+    return _NtXent.apply(h1, h2, float(tau), int(operands == "bf16"))
 
 
 # ----------------------------------------------------------------------------- modality fusion

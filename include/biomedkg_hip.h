@@ -161,13 +161,28 @@ int bkg_kge_bwd_rel_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, co
                         int32_t n_rel, float* drel, int64_t lddr, const int32_t* order, const int32_t* rel_ptr,
                         void* stream);
 
-/* ---- NT-Xent (PyGCL DualBranchContrast(InfoNCE(tau), "L2L", intraview_negs=True): biomedkg/gcl_module.py:171-173,189)
- *      over zn = [normalize(h1); normalize(h2)] (M = 2N rows, h <= 256): partial row sums of exp(z_i.z_j/tau), j != i,
- *      and the flash-style backward sum_j exp(.)(1/D_i + 1/D_j) zn_j; `splits` column ranges, summed by the caller. */
-int bkg_ntxent_rowsum_f32(const float* zn, int64_t ld, int64_t M, int32_t h, float tau, int32_t splits,
-                          float* rowsum_partial, void* stream);
-int bkg_ntxent_bwd_f32(const float* zn, int64_t ld, int64_t M, int32_t h, float tau, const float* rden, int32_t splits,
-                       float* dz_partial, void* stream);
+/* ---- NT-Xent (PyGCL DualBranchContrast(InfoNCE(tau), "L2L", intraview_negs=True): biomedkg/gcl_module.py:171-173,
+ *      186-190) over Z = [normalize(h1); normalize(h2)] (M = 2N rows, h <= 256):
+ *        L = 1/M sum_i ( log D_i - z_i.z_p(i)/tau ),  D_i = sum_{j != i} exp(z_i.z_j / tau),  p(i) = (i + N) mod M.
+ *      bkg_ntxent_hpad: padded row width of the normalised images (fp32 operands: next multiple of 32; bf16: 128 | 256).
+ *      bkg_ntxent_prepare: F.normalize of both views into zero-padded fp32 [2N, hpad] (and, if zn_bf16 != NULL, bf16)
+ *        images, the row norms [2N] and the positive-pair dots [N].
+ *      bkg_ntxent_forward: D over the Gram tiles on the matrix cores (bf16 = 0: exact fp32 MFMA on the fp32 image;
+ *        1: bf16 operands from the bf16 image, fp32 exp / sums), using the symmetry of the Gram (upper-triangular
+ *        tiles, row + column sums, fixed-order reduction: bitwise repeatable).  Outputs den[M], rden[M] = 1/D and
+ *        term[M] (double) = log D_i - (i < N) 2 z_i.z_(i+N)/tau, so that loss = sum(term) / M.
+ *      bkg_ntxent_backward: dL/dh1, dL/dh2 [N, h] (times the upstream scalar *gout, a DEVICE float), tiles recomputed.
+ *      Workspaces (floats) by the *_workspace_floats queries; every function is stream-ordered, no host sync. */
+int32_t bkg_ntxent_hpad(int32_t h, int32_t bf16);
+int bkg_ntxent_prepare(const float* h1, int64_t ld1, const float* h2, int64_t ld2, int64_t N, int32_t h, int32_t hpad,
+                       float* zn, void* zn_bf16, float* norm, float* posdot, void* stream);
+int64_t bkg_ntxent_forward_workspace_floats(int64_t M, int32_t h, int32_t bf16);
+int bkg_ntxent_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau, const float* posdot,
+                       float* workspace, float* den, float* rden, double* term, void* stream);
+int64_t bkg_ntxent_backward_workspace_floats(int64_t M, int32_t h, int32_t bf16);
+int bkg_ntxent_backward(const void* zn, int32_t bf16, const float* zn_f32, const float* norm, const float* rden,
+                        const float* gout, int64_t M, int32_t h, float tau, float* workspace, float* dh1, int64_t ld1,
+                        float* dh2, int64_t ld2, void* stream);
 
 /* ---- device mini-batch samplers (the reference's PyG loaders: biomedkg/data_module.py:89-107).
  *      bkg_random_walk: walks[w, 0..L] over the source-sorted CSR, uniform out-neighbour per step (sinks stay put).

@@ -32,7 +32,7 @@ def _declared():
 def test_header_declares_the_hot_path():
     d = _declared()
     for name in ("bkg_spmm_csr_f32", "bkg_gemm_f32", "bkg_kge_score_f32", "bkg_kge_bwd_nodes_f32",
-                 "bkg_ntxent_rowsum_f32", "bkg_ntxent_bwd_f32", "bkg_attn_fuse_f32", "bkg_gcn_norm", "bkg_sort_edges"):
+                 "bkg_ntxent_prepare", "bkg_ntxent_forward", "bkg_ntxent_backward", "bkg_attn_fuse_f32", "bkg_gcn_norm", "bkg_sort_edges"):
         assert name in d
 
 
