@@ -65,6 +65,10 @@ SIGNATURES = {
     "bkg_ntxent_forward": (I32, [P, I32, I64, I32, F32, P, P, P, P, P, P]),
     "bkg_ntxent_backward_workspace_floats": (I64, [I64, I32, I32]),
     "bkg_ntxent_backward": (I32, [P, I32, P, P, P, P, I64, I32, F32, P, P, I64, P, I64, P]),
+    "bkg_ntxent_rows_forward_workspace_floats": (I64, [I64, I64, I32, I32]),
+    "bkg_ntxent_rows_forward": (I32, [P, I32, I64, I32, F32, P, I64, P, P, P]),
+    "bkg_ntxent_rows_backward_workspace_floats": (I64, [I64, I64, I32, I32]),
+    "bkg_ntxent_rows_backward": (I32, [P, I32, P, P, P, P, I64, I32, F32, P, I64, I64, F32, P, P, I64, P, I64, P]),
     # sample.hip
     "bkg_random_walk": (I32, [P, P, P, I64, I32, U64, P, P]),
     "bkg_sample_neighbors": (I32, [P, P, I64, I32, U64, U32, P, P]),

@@ -47,6 +47,9 @@ struct NxArgs {
   int M;
   float scale;         // log2(e) / tau
   int n_panels, n_jtiles;
+  const int* anchors;  // anchor a -> row of zn (NULL: a itself); the panels run over the n_anchor anchors
+  int n_anchor;
+  int rect;            // forward over an anchor SUBSET (row-partitioned multi-GPU): every j-tile, row sums only
   // forward
   long long n_items;   // flattened (panel, j-tile) items
   float* rowseg;       // [(grid + n_panels)][PR]   row sums per (block, panel) segment, slot = block + panel
@@ -157,8 +160,13 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     x = (long long)blockIdx.x * a.n_items / gridDim.x;
     x_end = (long long)(blockIdx.x + 1) * a.n_items / gridDim.x;
     if (x >= x_end) return;
-    P = nx_panel_of(x, a.n_panels, a.n_jtiles, Q);
-    jt = P * Q + (int)(x - nx_start(P, a.n_jtiles, Q));
+    if (a.rect) {
+      P = (int)(x / a.n_jtiles);
+      jt = (int)(x % a.n_jtiles);
+    } else {
+      P = nx_panel_of(x, a.n_panels, a.n_jtiles, Q);
+      jt = P * Q + (int)(x - nx_start(P, a.n_jtiles, Q));
+    }
   }
 
   // ---- staging registers: the next j-tile (and, backward, its 1/D values)
@@ -187,13 +195,22 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
   // ---- anchor fragments of this wave's 32 rows
   uint4 zi[KF];
   float rd_i = 0.f;
-  int i_glob = 0;
+  int i_glob = -1, i_lo = 0, i_hi = 0;      // this lane's anchor row (-1: none); the wave's row range
   auto load_anchor = [&](int P_) {
-    i_glob = P_ * PR + wave * 32 + l31;
+    const int a_idx = P_ * PR + wave * 32 + l31;
+    i_glob = a_idx < a.n_anchor ? (a.anchors ? a.anchors[a_idx] : a_idx) : -1;
+    int mn = i_glob < 0 ? 0x7fffffff : i_glob, mx = i_glob;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      mn = min(mn, __shfl_xor(mn, o, 64));
+      mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    i_lo = __builtin_amdgcn_readfirstlane(mn);
+    i_hi = __builtin_amdgcn_readfirstlane(mx);
 #pragma unroll
     for (int k = 0; k < KF; ++k) {
       zi[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (i_glob < M) {
+      if (i_glob >= 0) {
         // fp32: k values 8k + 4 lh + {0..3}; bf16: 16k + 8 lh + {0..7}  (16 bytes either way)
         zi[k] = *reinterpret_cast<const uint4*>(zn + (size_t)i_glob * ROW_BYTES + (2 * k + lh) * 16);
         if (!BF16) {
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
         }
       }
     }
-    if (BWD) rd_i = (i_glob < M) ? a.rden[i_glob] : 0.f;
+    if (BWD) rd_i = (i_glob >= 0) ? a.rden[i_glob] : 0.f;
   };
 
   nx_acc_t dz[BWD ? HP : 1];
@@ -233,12 +250,11 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     }
     // next item
     int P_next = P, jt_next = jt + 1;
-    if (!BWD && jt_next == a.n_jtiles) { P_next = P + 1; jt_next = P_next * Q; }
+    if (!BWD && jt_next == a.n_jtiles) { P_next = P + 1; jt_next = a.rect ? 0 : P_next * Q; }
     if (x + 1 < x_end) prefetch(jt_next);
 
     const int j0 = jt * NX_BJ;
-    const int iw0 = P * PR + wave * 32;
-    const bool need_mask = (j0 + NX_BJ > M) || (iw0 + 32 > M) || (j0 < iw0 + 32 && j0 + NX_BJ > iw0);
+    const bool need_mask = (j0 + NX_BJ > M) || (P * PR + wave * 32 + 32 > a.n_anchor) || (j0 <= i_hi && j0 + NX_BJ > i_lo);
 
     // ---- S^T[j][i] for the tile's two 32-row halves
     nx_acc_t s[2];
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
         float e = __builtin_amdgcn_exp2f(BF16 ? s[t][r] * a.scale : s[t][r]);
         if (need_mask) {
           const int jg = j0 + jl;
-          e = (jg < M && i_glob < M && jg != i_glob) ? e : 0.f;
+          e = (jg < M && i_glob >= 0 && jg != i_glob) ? e : 0.f;
         }
         if (BWD) e *= rd_i + rdj[jl];
         else rowsum += e;
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 
     if (!BWD) {
       // column sums, unless the tile lies inside the panel's own columns (those pairs are also computed transposed)
-      col_pending = jt >= (P + 1) * Q;
+      col_pending = !a.rect && jt >= (P + 1) * Q;
       if (col_pending) {
         const float v = nx_transpose_reduce32(s[0], s[1], l31);
         aux[buf * (NW * NX_BJ) + wave * NX_BJ + 32 * (l31 >> 4) + nx_acc_row(l31 & 15, lh)] = v;
@@ -365,13 +381,13 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     // dz[ct][r]: row i = wave*32 + row(r, lh), column 32 ct + l31 of this split's partial
     const int split = blockIdx.x % a.splits;
     const int ib = (blockIdx.x / a.splits) * PR + wave * 32;
-    float* out = a.dzpart + (size_t)split * M * HPAD;
+    float* out = a.dzpart + (size_t)split * a.n_anchor * HPAD;
 #pragma unroll
     for (int ct = 0; ct < HP; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ig = ib + nx_acc_row(r, lh);
-        if (ig < M) out[(size_t)ig * HPAD + 32 * ct + l31] = dz[ct][r];
+        const int ia = ib + nx_acc_row(r, lh);
+        if (ia < a.n_anchor) out[(size_t)ia * HPAD + 32 * ct + l31] = dz[ct][r];
       }
   }
 }
@@ -422,40 +438,47 @@ __global__ __launch_bounds__(256) void nx_prep_kernel(const float* __restrict__ 
 }
 
 // D_i = (row segments of i's panel, in block order) + (column items of i's j-tile, in panel order); 1/D; loss term.
+// rect (anchor subset): row segments only.
 __global__ __launch_bounds__(256) void nx_fwd_finish_kernel(const float* __restrict__ rowseg, const float* __restrict__ colitem,
-                                                            const float* __restrict__ posdot, int M, int N, int PR,
+                                                            const float* __restrict__ posdot, int n_anchor, int N, int PR,
                                                             int n_panels, int n_jtiles, long long n_items, long long grid,
-                                                            float inv_tau, float* __restrict__ den, float* __restrict__ rden,
-                                                            double* __restrict__ term) {
+                                                            int rect, float inv_tau, float* __restrict__ den,
+                                                            float* __restrict__ rden, double* __restrict__ term) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= M) return;
+  if (i >= n_anchor) return;
   const int q = PR / NX_BJ, P = i / PR, jt = i / NX_BJ;
   float d = 0.f;
-  const long long b0 = nx_block_of(nx_start(P, n_jtiles, q), n_items, grid);
-  const long long b1 = nx_block_of(nx_start(P + 1, n_jtiles, q) - 1, n_items, grid);
+  const long long s0 = rect ? (long long)P * n_jtiles : nx_start(P, n_jtiles, q);
+  const long long s1 = rect ? (long long)(P + 1) * n_jtiles : nx_start(P + 1, n_jtiles, q);
+  const long long b0 = nx_block_of(s0, n_items, grid), b1 = nx_block_of(s1 - 1, n_items, grid);
   for (long long b = b0; b <= b1; ++b) d += rowseg[(size_t)(b + P) * PR + i % PR];
-  const int p_end = min(n_panels, jt / q);          // panels strictly left of this j-tile's own panel columns
-  for (int Pc = 0; Pc < p_end; ++Pc)
-    d += colitem[(size_t)(nx_start(Pc, n_jtiles, q) + jt - Pc * q) * NX_BJ + i % NX_BJ];
+  if (!rect) {
+    const int p_end = min(n_panels, jt / q);          // panels strictly left of this j-tile's own panel columns
+    for (int Pc = 0; Pc < p_end; ++Pc)
+      d += colitem[(size_t)(nx_start(Pc, n_jtiles, q) + jt - Pc * q) * NX_BJ + i % NX_BJ];
+  }
   den[i] = d;
-  rden[i] = 1.0f / d;
-  term[i] = log((double)d) - (i < N ? 2.0 * (double)posdot[i] * (double)inv_tau : 0.0);
+  if (rden) rden[i] = 1.0f / d;
+  if (term) term[i] = log((double)d) - (i < N ? 2.0 * (double)posdot[i] * (double)inv_tau : 0.0);
 }
 
-// dz = ((sum_s part_s - 2 z_p(i)) * g / (M tau)  projected through x / |x|) for one row per wave
+// dh = ((sum_s part_s - 2 z_p(i)) * g * inv_m_tau  projected through x / |x|) for one anchor row per wave.
+// anchors (nullable): anchor a is row anchors[a] of zn; anchor a < n_half goes to dh1[a], the rest to dh2[a - n_half].
 __global__ __launch_bounds__(256) void nx_bwd_finish_kernel(const float* __restrict__ dzpart, int splits,
                                                             const float* __restrict__ zn, const float* __restrict__ norm,
-                                                            const float* __restrict__ gout, int M, int N, int h, int hpad,
+                                                            const float* __restrict__ gout, const int* __restrict__ anchors,
+                                                            int n_anchor, int n_half, int N, int h, int hpad,
                                                             float inv_m_tau, float* __restrict__ dh1, int64_t ld1,
                                                             float* __restrict__ dh2, int64_t ld2) {
-  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= M) return;
+  const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (a >= n_anchor) return;
+  const int i = anchors ? anchors[a] : a;
   const int c = lane * 4;
   const float g = gout[0] * inv_m_tau;
   float4 d = make_float4(0.f, 0.f, 0.f, 0.f), z = d;
   if (c < hpad) {
     for (int s = 0; s < splits; ++s) {
-      const float4 p = *reinterpret_cast<const float4*>(dzpart + ((size_t)s * M + i) * hpad + c);
+      const float4 p = *reinterpret_cast<const float4*>(dzpart + ((size_t)s * n_anchor + a) * hpad + c);
       d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
     }
     z = *reinterpret_cast<const float4*>(zn + (size_t)i * hpad + c);
@@ -464,8 +487,8 @@ __global__ __launch_bounds__(256) void nx_bwd_finish_kernel(const float* __restr
     d.x = (d.x - 2.f * zp.x) * g; d.y = (d.y - 2.f * zp.y) * g; d.z = (d.z - 2.f * zp.z) * g; d.w = (d.w - 2.f * zp.w) * g;
   }
   const float zd = wave_sum(z.x * d.x + z.y * d.y + z.z * d.z + z.w * d.w);
-  const float inv = 1.0f / norm[i];
-  float* out = i < N ? dh1 + (int64_t)i * ld1 : dh2 + (int64_t)(i - N) * ld2;
+  const float inv = 1.0f / norm[a];
+  float* out = a < n_half ? dh1 + (int64_t)a * ld1 : dh2 + (int64_t)(a - n_half) * ld2;
   const float o[4] = {(d.x - z.x * zd) * inv, (d.y - z.y * zd) * inv, (d.z - z.z * zd) * inv, (d.w - z.w * zd) * inv};
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -551,14 +574,17 @@ static int nx_run_bwd(bool bf16, int hp, NxArgs a, int grid, hipStream_t s) { NX
 
 struct NxShape { int hpad, hp, pr, n_panels, n_jtiles, grid, splits, jt_per_split; long long n_items; };
 
-static NxShape nx_shape(int64_t M, int h, bool bf16, bool bwd) {
+// n_anchor < 0: the whole (symmetric) problem; else a rectangular one over n_anchor anchor rows
+static NxShape nx_shape(int64_t M, int64_t n_anchor, int h, bool bf16, bool bwd) {
   NxShape sh;
+  const bool rect = n_anchor >= 0;
+  if (!rect) n_anchor = M;
   sh.hpad = bf16 ? (h <= 128 ? 128 : 256) : ((h + 31) / 32) * 32;
   sh.hp = sh.hpad / 32;
   sh.pr = 32 * nx_waves(bf16, sh.hp, bwd);
-  sh.n_panels = (int)((M + sh.pr - 1) / sh.pr);
+  sh.n_panels = (int)((n_anchor + sh.pr - 1) / sh.pr);
   sh.n_jtiles = (int)((M + NX_BJ - 1) / NX_BJ);
-  sh.n_items = nx_start(sh.n_panels, sh.n_jtiles, sh.pr / NX_BJ);
+  sh.n_items = rect ? (long long)sh.n_panels * sh.n_jtiles : nx_start(sh.n_panels, sh.n_jtiles, sh.pr / NX_BJ);
   const int slots = nx_cus() * nx_occ(bf16, sh.hp, bwd);
   sh.grid = (int)std::min<long long>(sh.n_items, slots);
   // backward: enough j-splits to fill the chip once; none when the panels alone do (every workgroup then streams
@@ -587,51 +613,97 @@ extern "C" int bkg_ntxent_prepare(const float* h1, int64_t ld1, const float* h2,
   return check_launch("bkg_ntxent_prepare");
 }
 
+static bool nx_args_ok(int64_t M, int64_t n_anchor, int32_t h, float tau) {
+  return M > 0 && M % 2 == 0 && M < (1ll << 30) && h > 0 && h <= 256 && tau > 0.f && n_anchor <= M;
+}
+
+extern "C" int64_t bkg_ntxent_rows_forward_workspace_floats(int64_t M, int64_t n_anchor, int32_t h, int32_t bf16) {
+  if (M <= 0 || h <= 0 || h > 256 || n_anchor == 0) return -1;
+  const NxShape sh = nx_shape(M, n_anchor, h, bf16 != 0, false);
+  return (int64_t)(sh.grid + sh.n_panels) * sh.pr + (n_anchor < 0 ? sh.n_items * NX_BJ : 0);
+}
 extern "C" int64_t bkg_ntxent_forward_workspace_floats(int64_t M, int32_t h, int32_t bf16) {
-  if (M <= 0 || h <= 0 || h > 256) return -1;
-  const NxShape sh = nx_shape(M, h, bf16 != 0, false);
-  return (int64_t)(sh.grid + sh.n_panels) * sh.pr + sh.n_items * NX_BJ;
+  return bkg_ntxent_rows_forward_workspace_floats(M, -1, h, bf16);
+}
+
+static int nx_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau, const int32_t* anchors,
+                      int64_t n_anchor, const float* posdot, float* workspace, float* den, float* rden, double* term,
+                      hipStream_t s) {
+  const NxShape sh = nx_shape(M, n_anchor, h, bf16 != 0, false);
+  const bool rect = n_anchor >= 0;
+  NxArgs a{};
+  a.zn = zn; a.M = (int)M; a.scale = 1.4426950408889634f / tau;
+  a.n_panels = sh.n_panels; a.n_jtiles = sh.n_jtiles; a.n_items = sh.n_items;
+  a.anchors = anchors; a.n_anchor = (int)(rect ? n_anchor : M); a.rect = rect;
+  a.rowseg = workspace;
+  a.colitem = workspace + (size_t)(sh.grid + sh.n_panels) * sh.pr;
+  int rc = nx_run_fwd(bf16 != 0, sh.hp, a, sh.grid, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nx_fwd_finish_kernel, dim3(ceil_div(a.n_anchor, 256)), dim3(256), 0, s, a.rowseg, a.colitem, posdot,
+                     a.n_anchor, (int)(M / 2), sh.pr, sh.n_panels, sh.n_jtiles, sh.n_items, (long long)sh.grid, (int)rect,
+                     1.0f / tau, den, rden, term);
+  return check_launch("bkg_ntxent_forward(finish)");
 }
 
 // den[M], rden[M] = 1/D, term[M] (double) = log D_i - (i < N) * 2 z_i.z_(i+N) / tau;  loss = sum(term) / M
 extern "C" int bkg_ntxent_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau, const float* posdot,
                                   float* workspace, float* den, float* rden, double* term, void* stream) {
-  BKG_ARG(M > 0 && M % 2 == 0 && M < (1ll << 30) && h > 0 && h <= 256 && tau > 0.f, "bkg_ntxent_forward: bad arguments (h <= 256)");
-  const NxShape sh = nx_shape(M, h, bf16 != 0, false);
-  NxArgs a{};
-  a.zn = zn; a.M = (int)M; a.scale = 1.4426950408889634f / tau;
-  a.n_panels = sh.n_panels; a.n_jtiles = sh.n_jtiles; a.n_items = sh.n_items;
-  a.rowseg = workspace;
-  a.colitem = workspace + (size_t)(sh.grid + sh.n_panels) * sh.pr;
-  hipStream_t s = (hipStream_t)stream;
-  int rc = nx_run_fwd(bf16 != 0, sh.hp, a, sh.grid, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(nx_fwd_finish_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, s, a.rowseg, a.colitem, posdot, (int)M,
-                     (int)(M / 2), sh.pr, sh.n_panels, sh.n_jtiles, sh.n_items, (long long)sh.grid, 1.0f / tau, den, rden,
-                     term);
-  return check_launch("bkg_ntxent_forward(finish)");
+  BKG_ARG(nx_args_ok(M, M, h, tau), "bkg_ntxent_forward: bad arguments (h <= 256)");
+  return nx_forward(zn, bf16, M, h, tau, nullptr, -1, posdot, workspace, den, rden, term, (hipStream_t)stream);
 }
 
+// den[n_anchor] = D of the anchor rows zn[anchors[a]] against ALL M rows (row-partitioned multi-GPU forward)
+extern "C" int bkg_ntxent_rows_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau,
+                                       const int32_t* anchors, int64_t n_anchor, float* workspace, float* den,
+                                       void* stream) {
+  BKG_ARG(nx_args_ok(M, n_anchor, h, tau) && n_anchor > 0 && anchors, "bkg_ntxent_rows_forward: bad arguments (h <= 256)");
+  return nx_forward(zn, bf16, M, h, tau, anchors, n_anchor, nullptr, workspace, den, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int64_t bkg_ntxent_rows_backward_workspace_floats(int64_t M, int64_t n_anchor, int32_t h, int32_t bf16) {
+  if (M <= 0 || h <= 0 || h > 256 || n_anchor == 0) return -1;
+  const NxShape sh = nx_shape(M, n_anchor, h, bf16 != 0, true);
+  return (int64_t)sh.splits * (n_anchor < 0 ? M : n_anchor) * sh.hpad;
+}
 extern "C" int64_t bkg_ntxent_backward_workspace_floats(int64_t M, int32_t h, int32_t bf16) {
-  if (M <= 0 || h <= 0 || h > 256) return -1;
-  const NxShape sh = nx_shape(M, h, bf16 != 0, true);
-  return (int64_t)sh.splits * M * sh.hpad;
+  return bkg_ntxent_rows_backward_workspace_floats(M, -1, h, bf16);
+}
+
+static int nx_backward(const void* zn, int32_t bf16, const float* zn_f32, const float* norm, const float* rden,
+                       const float* gout, int64_t M, int32_t h, float tau, const int32_t* anchors, int64_t n_anchor,
+                       int64_t n_half, float inv_m_tau, float* workspace, float* dh1, int64_t ld1, float* dh2, int64_t ld2,
+                       hipStream_t s) {
+  const NxShape sh = nx_shape(M, n_anchor, h, bf16 != 0, true);
+  NxArgs a{};
+  a.zn = zn; a.M = (int)M; a.scale = 1.4426950408889634f / tau;
+  a.n_panels = sh.n_panels; a.n_jtiles = sh.n_jtiles;
+  a.anchors = anchors; a.n_anchor = (int)(n_anchor >= 0 ? n_anchor : M);
+  a.rden = rden; a.dzpart = workspace; a.splits = sh.splits; a.jt_per_split = sh.jt_per_split;
+  int rc = nx_run_bwd(bf16 != 0, sh.hp, a, sh.n_panels * sh.splits, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(nx_bwd_finish_kernel, dim3(ceil_div(a.n_anchor, 4)), dim3(256), 0, s, workspace, sh.splits, zn_f32,
+                     norm, gout, anchors, a.n_anchor, (int)n_half, (int)(M / 2), h, sh.hpad, inv_m_tau, dh1, ld1, dh2, ld2);
+  return check_launch("bkg_ntxent_backward(finish)");
 }
 
 // dh1 / dh2 [N, h]: gradient of the loss wrt the UN-normalised inputs, times the upstream scalar *gout (device)
 extern "C" int bkg_ntxent_backward(const void* zn, int32_t bf16, const float* zn_f32, const float* norm, const float* rden,
                                    const float* gout, int64_t M, int32_t h, float tau, float* workspace, float* dh1,
                                    int64_t ld1, float* dh2, int64_t ld2, void* stream) {
-  BKG_ARG(M > 0 && M % 2 == 0 && M < (1ll << 30) && h > 0 && h <= 256 && tau > 0.f, "bkg_ntxent_backward: bad arguments (h <= 256)");
-  const NxShape sh = nx_shape(M, h, bf16 != 0, true);
-  NxArgs a{};
-  a.zn = zn; a.M = (int)M; a.scale = 1.4426950408889634f / tau;
-  a.n_panels = sh.n_panels; a.n_jtiles = sh.n_jtiles;
-  a.rden = rden; a.dzpart = workspace; a.splits = sh.splits; a.jt_per_split = sh.jt_per_split;
-  hipStream_t s = (hipStream_t)stream;
-  int rc = nx_run_bwd(bf16 != 0, sh.hp, a, sh.n_panels * sh.splits, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(nx_bwd_finish_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, workspace, sh.splits, zn_f32, norm, gout,
-                     (int)M, (int)(M / 2), h, sh.hpad, 1.0f / ((float)M * tau), dh1, ld1, dh2, ld2);
-  return check_launch("bkg_ntxent_backward(finish)");
+  BKG_ARG(nx_args_ok(M, M, h, tau), "bkg_ntxent_backward: bad arguments (h <= 256)");
+  return nx_backward(zn, bf16, zn_f32, norm, rden, gout, M, h, tau, nullptr, -1, M / 2, 1.0f / ((float)M * tau), workspace,
+                     dh1, ld1, dh2, ld2, (hipStream_t)stream);
+}
+
+// row-partitioned backward: anchors as in bkg_ntxent_rows_forward, norm[n_anchor] their norms, rden[M] = 1/D of ALL rows
+// (all-gathered); anchor a < n_half -> dh1[a], else dh2[a - n_half]; the gradient is scaled by *gout * grad_scale
+// (grad_scale = world / (M tau) for the whole-graph loss under gradient averaging)
+extern "C" int bkg_ntxent_rows_backward(const void* zn, int32_t bf16, const float* zn_f32, const float* norm,
+                                        const float* rden, const float* gout, int64_t M, int32_t h, float tau,
+                                        const int32_t* anchors, int64_t n_anchor, int64_t n_half, float grad_scale,
+                                        float* workspace, float* dh1, int64_t ld1, float* dh2, int64_t ld2, void* stream) {
+  BKG_ARG(nx_args_ok(M, n_anchor, h, tau) && n_anchor > 0 && anchors && n_half >= 0 && n_half <= n_anchor,
+          "bkg_ntxent_rows_backward: bad arguments (h <= 256)");
+  return nx_backward(zn, bf16, zn_f32, norm, rden, gout, M, h, tau, anchors, n_anchor, n_half, grad_scale, workspace, dh1, ld1,
+                     dh2, ld2, (hipStream_t)stream);
 }

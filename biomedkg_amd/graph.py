@@ -116,13 +116,9 @@ class Graph:
         self._plain = None
         self._kept = None
 
-    def gcn_weights(self, keep=None) -> GcnWeights:
-        """``keep``: optional uint8/bool ``[E]`` dropout_edge mask in original edge order."""
-        if keep is None and self._plain is not None:
-            return self._plain
-        if keep is not None and self._kept is not None and self._kept[0] is keep and self._kept[1] == keep._version:
-            return self._kept[2]      # every layer (and both GGD views) of a step passes the same mask tensor
-        keep_in = keep
+    def gcn_norm_raw(self, keep=None):
+        """PyG gcn_norm over this graph (optionally a ``dropout_edge`` view): ``(w_edge [E] in edge order, self_w [N])``
+        -- existing self loops get weight 0, every node the unit loop ``self_w = 1 / deg``."""
         dev = self.edge_index.device
         if keep is not None:
             keep = keep.to(torch.uint8).contiguous()
@@ -132,11 +128,20 @@ class Graph:
         c = self.by_dst
         L.call("bkg_gcn_norm", L.ptr(c.rowptr), L.ptr(c.col), L.ptr(c.perm), L.ptr(self.src), L.ptr(self.dst),
                L.ptr(keep), self.num_nodes, self.num_edges, L.ptr(dis), L.ptr(self_w), L.ptr(w_edge), L.stream())
+        return w_edge, self_w
+
+    def gcn_weights(self, keep=None) -> GcnWeights:
+        """``keep``: optional uint8/bool ``[E]`` dropout_edge mask in original edge order."""
+        if keep is None and self._plain is not None:
+            return self._plain
+        if keep is not None and self._kept is not None and self._kept[0] is keep and self._kept[1] == keep._version:
+            return self._kept[2]      # every layer (and both GGD views) of a step passes the same mask tensor
+        w_edge, self_w = self.gcn_norm_raw(keep)
         out = GcnWeights(self.by_dst.permute_f32(w_edge), self.by_src.permute_f32(w_edge), self_w)
         if keep is None:
             self._plain = out
         else:
-            self._kept = (keep_in, keep_in._version, out)
+            self._kept = (keep, keep._version, out)
         return out
 
 
@@ -148,7 +153,9 @@ class RelGraph:
     point at segments with weight 1/|segment|.
     """
 
-    def __init__(self, edge_index, edge_type, num_nodes, num_relations):
+    def __init__(self, edge_index, edge_type, num_nodes, num_relations, n_src=None):
+        """``n_src``: number of SOURCE rows when they live in another index space than the ``num_nodes`` targets (a
+        node-partitioned graph: sources are slots of the all-gathered table, targets the rank's own nodes)."""
         L.require_cuda(edge_index, edge_type)
         self.edge_index = edge_index.contiguous()
         self.edge_type = edge_type.contiguous()
@@ -182,7 +189,7 @@ class RelGraph:
         seg_of_edge[perm.long()] = self.seg_of.long()
         w_edge = torch.empty(e, dtype=torch.float32, device=dev)
         w_edge[perm.long()] = self.inv_cnt
-        self.src_csr = CSR(src, seg_of_edge, n)
+        self.src_csr = CSR(src, seg_of_edge, n if n_src is None else int(n_src))
         self.src_w = self.src_csr.permute_f32(w_edge)
         self.seg_iota_ptr = torch.arange(s + 1, dtype=torch.int32, device=dev)
         self.seg_split = rowsplit_for(self.seg_ptr, s, e)

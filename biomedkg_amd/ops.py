@@ -56,17 +56,21 @@ def _weight_bf16(w, transpose):
     return cache[2] if transpose else cache[1]
 
 
+_TALL_ROWS = 256    # fewest rows the streaming product is used for (a heuristic, not a kernel limit; a node-partitioned
+                    # rank that owns hub nodes may hold only ~1k rows)
+
+
 def _xw_ok(a, m, n, k):
     """Shapes / layouts the streaming activation-x-weight kernel (csrc/gemm_xw.hip) takes in bf16 mode."""
     el = a.element_size()
-    return (_PRECISION == 1 and m >= 1024 and n * k <= (1 << 22) and k % 256 == 0 and n % 32 == 0 and a.stride(1) == 1 and
+    return (_PRECISION == 1 and m >= _TALL_ROWS and n * k <= (1 << 22) and k % 256 == 0 and n % 32 == 0 and a.stride(1) == 1 and
             (a.stride(0) * el) % 16 == 0 and a.data_ptr() % 16 == 0)
 
 
 def _bf16_operand_ok(rows, n, k):
     """Would a contiguous bf16 ``[rows, k]`` table be accepted as the tall operand of an x-weight product with an
     ``[n, k]`` weight?  (Decides whether a producer may emit its result in bf16 only.)"""
-    return _PRECISION == 1 and rows >= 1024 and n * k <= (1 << 22) and k % 256 == 0 and n % 32 == 0
+    return _PRECISION == 1 and rows >= _TALL_ROWS and n * k <= (1 << 22) and k % 256 == 0 and n % 32 == 0
 
 
 def _gemm_xw(a, wt, m, n, k, out, out_dtype, alpha, beta, bias, act, gate, gate_scale, group_ptr=None, groups=0,
@@ -284,7 +288,9 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
     if timing:
         ev1.record()
         rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None,
-                                                                             2 if is_bf16 else 4, out.element_size())})
+                                                                             2 if is_bf16 else 4, out.element_size()),
+                                             "d": d,       # rocprofv3's Grid_Size of the main launch (threads)
+                                             "grid": ((split.n_items_max if split is not None else n_rows) + 3) // 4 * 256})
         rec["events"].append((ev0, ev1))
     return out
 
@@ -367,20 +373,34 @@ def _as_f32(t):
     return t if t.dtype == torch.float32 else t.float()
 
 
+def _dims(graph):
+    """(output rows, gather-table rows, exchange) of a message-passing structure: a whole graph has
+    ``n_out == n_table`` and no exchange; a node-partitioned one (biomedkg_amd/partition.py) owns ``n_out`` target rows,
+    gathers from the all-gathered ``n_table``-row table and carries the collective pair in ``comm``."""
+    n = graph.num_nodes
+    return getattr(graph, "n_out", n), getattr(graph, "n_table", n), getattr(graph, "comm", None)
+
+
 class _GcnConv(torch.autograd.Function):
     """``dropout(relu(A_hat (x W^T) + b))`` -- PyG GCNConv + the encoder's ReLU/dropout
     (reference biomedkg/model/encoder.py:153-162) fused into the aggregation epilogue.  ``x`` is fp32 or (a hidden
-    activation of the bf16 mode) bf16; ``hidden`` asks for a bf16 result."""
+    activation of the bf16 mode) bf16; ``hidden`` asks for a bf16 result.  Node-partitioned graphs: the product runs on
+    the rank's rows, the table is all-gathered (transform BEFORE the exchange: the wire carries ``out`` columns), the
+    backward's table gradient is reduce-scattered to its owners."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, graph: Graph, gw: GcnWeights, relu, drop, hidden):
-        n_rows, d_out, d_in = graph.num_nodes, weight.size(0), weight.size(1)
+        n_rows, n_table, comm = _dims(graph)
+        d_out, d_in = weight.size(0), weight.size(1)
         if x.dtype == torch.bfloat16 and not _xw_ok(x, n_rows, d_out, d_in):
             x = x.float()                      # shapes the streaming product does not take: widen once
         if bf16_storage() and _bf16_ok(d_out) and _xw_ok(x, n_rows, d_out, d_in):
-            xw = gemm(x, weight, trans_b=True, out_dtype=torch.bfloat16)   # only ever read as the gather table
+            xw = gemm(x, weight, trans_b=True, out_dtype=torch.bfloat16,      # only ever read as the gather table
+                      out=comm.shard_buffer(d_out, torch.bfloat16, x.device) if comm else None)
         else:
             xw = _table(gemm(x, weight, trans_b=True))
+        if comm is not None:
+            xw = comm.all_gather(xw)
         c = graph.by_dst
         out16 = hidden and _hidden_bf16_ok(n_rows, d_out)
         out = spmm(c.rowptr, c.col, gw.w_dst, xw, n_rows, self_w=gw.self_w, bias=bias, relu=relu, drop=drop,
@@ -396,6 +416,7 @@ class _GcnConv(torch.autograd.Function):
     def backward(ctx, dout):
         x, weight, out = ctx.saved_tensors
         g, gw = ctx.graph, ctx.gw
+        n_rows, n_table, comm = _dims(g)
         dout = dout if dout.is_contiguous() else dout.contiguous()
         if bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(dout.size(1)):
             # gate + bf16 gather table in one pass over dOut (no fp32 gated copy is ever written)
@@ -407,12 +428,15 @@ class _GcnConv(torch.autograd.Function):
             dout = _as_f32(dout)
         c = g.by_src
         # dXW feeds only the two products below: keep it as a bf16 table when both can take one
-        n_rows, d_out, d_in = g.num_nodes, weight.size(0), weight.size(1)
+        d_out, d_in = weight.size(0), weight.size(1)
         x16 = x.dtype == torch.bfloat16
-        to16 = (bf16_storage() and _bf16_ok(d_out) and n_rows >= 4096 and ((d_out + 63) // 64) * ((d_in + 63) // 64) <= 256
+        to16 = (comm is None and bf16_storage() and _bf16_ok(d_out) and n_rows >= 4096
+                and ((d_out + 63) // 64) * ((d_in + 63) // 64) <= 256
                 and (not ctx.needs_input_grad[0] or _bf16_operand_ok(n_rows, d_in, d_out)))
-        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_rows, self_w=gw.self_w, split=c.split,
+        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split,
                    out_dtype=torch.bfloat16 if to16 else torch.float32)
+        if comm is not None:
+            dxw = comm.reduce_scatter(dxw)            # fp32 partial tables summed at their owners
         dx = None
         if ctx.needs_input_grad[0]:
             if x16 and _xw_ok(dxw, n_rows, d_in, d_out):
@@ -502,16 +526,20 @@ class _GcnConvViews(torch.autograd.Function):
     row i holds the V views' rows of node i side by side -- so the products see ``[V * N, in]`` (one launch, the
     weight slab loaded once, one weight-gradient product over K = V * N) and the aggregation gathers ``V * out``-wide
     rows with one index / weight stream.  ``is_table``: ``x2`` already is the gather table (shared first-layer
-    product, see ``_XwTable``) and ``weight`` is unused.  bf16 mode only (``views_ok``)."""
+    product, see ``_XwTable``; on a node-partitioned graph: the ALL-GATHERED table) and ``weight`` is unused.
+    bf16 mode only (``views_ok``).  Node-partitioned graphs exchange the table as ``_GcnConv`` does."""
 
     @staticmethod
     def forward(ctx, x2, weight, bias, graph: Graph, gw: GcnWeights, relu, drop, hidden, views, is_table):
-        n = graph.num_nodes
+        n, n_table, comm = _dims(graph)
         if is_table:
             table = x2 if x2.is_contiguous() else x2.contiguous()
         else:
             d_in, d_out = weight.size(1), weight.size(0)
-            table = gemm(x2.view(views * n, d_in), weight, trans_b=True, out_dtype=torch.bfloat16).view(n, views * d_out)
+            buf = comm.shard_buffer(views * d_out, torch.bfloat16, x2.device) if comm else None
+            table = gemm(x2.view(views * n, d_in), weight, trans_b=True, out_dtype=torch.bfloat16,
+                         out=buf[:n].view(views * n, d_out) if comm else None)
+            table = comm.all_gather(buf) if comm else table.view(n, views * d_out)
         c = graph.by_dst
         out = spmm(c.rowptr, c.col, gw.w_dst, table, n, self_w=gw.self_w, bias=bias.repeat(views), relu=relu, drop=drop,
                    tag="gcn_propagate_views", split=c.split, out_dtype=torch.bfloat16 if hidden else torch.float32)
@@ -527,18 +555,22 @@ class _GcnConvViews(torch.autograd.Function):
     def backward(ctx, dout):
         x2, weight, out = ctx.saved_tensors
         g, gw, v = ctx.graph, ctx.gw, ctx.views
-        n = g.num_nodes
+        n, n_table, comm = _dims(g)
         dout = dout if dout.is_contiguous() else dout.contiguous()
         if ctx.relu or not ctx.gated:
             dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
         else:
             dout = to_bf16(_as_f32(dout) * ctx.keep * ctx.scale)
         c = g.by_src
-        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n, self_w=gw.self_w, split=c.split, out_dtype=torch.bfloat16)
+        exchange = comm is not None and not ctx.is_table     # a gathered input table: its producer owns the exchange
+        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split,
+                   out_dtype=torch.float32 if exchange else torch.bfloat16)
         d_out = dout.size(1) // v
         db = colsum(dout.view(v * n, d_out)) if ctx.needs_input_grad[2] else None
         if ctx.is_table:
             return dxw.to(ctx.table_dtype), None, db, None, None, None, None, None, None, None
+        if exchange:
+            dxw = comm.reduce_scatter(dxw)
         d_in = weight.size(1)
         dxw_rows = dxw.view(v * n, d_out)
         dx = (gemm(dxw_rows, weight, out_dtype=x2.dtype).view(n, v * d_in) if ctx.needs_input_grad[0] else None)
@@ -555,20 +587,30 @@ def gcn_conv_views(x2, weight, bias, graph, gw, views, relu=False, drop=None, hi
 class _RgcnConv(torch.autograd.Function):
     """``dropout(relu(sum_r mean_{N_r(i)}(x_j) W_r + x_i W_root + b))`` -- PyG RGCNConv
     + the encoder's ReLU/dropout (reference biomedkg/model/encoder.py:50-59).  ``x`` is fp32 or (a hidden activation
-    of the bf16 mode) bf16; ``hidden`` asks for a bf16 result."""
+    of the bf16 mode) bf16; ``hidden`` asks for a bf16 result.  Node-partitioned graphs: the layer INPUT is the
+    all-gathered table (started first, the root product runs under it); the backward's table gradient is
+    reduce-scattered while the root / weight-gradient products run."""
 
     @staticmethod
     def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop, hidden):
-        n, d_in, d_out = rg.num_nodes, weight.size(1), weight.size(2)
+        n, n_table, comm = _dims(rg)
+        d_in, d_out = weight.size(1), weight.size(2)
         if x.dtype == torch.bfloat16 and not _xw_ok(x, n, d_out, d_in):
             x = x.float()
+        if comm is None:
+            table = _table(x)
+            pending = None
+        else:
+            pending = comm.all_gather_begin(_table(x))                               # crosses xGMI ...
+        xr = gemm(x, root)                                                            # ... under the [N, out] root term
+        if pending is not None:
+            table = comm.all_gather_end(pending)
         h16 = bf16_storage() and _bf16_ok(d_in) and _bf16_operand_ok(rg.num_segments, d_out, d_in)
-        h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, _table(x), rg.num_segments, tag="rgcn_segment_mean",
+        h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, table, rg.num_segments, tag="rgcn_segment_mean",
                  split=rg.seg_split, out_dtype=torch.bfloat16 if h16 else torch.float32)   # [S, in]  segment means
         y16 = bf16_storage() and _bf16_ok(d_out) and _xw_ok(h, h.size(0), d_out, d_in)
         y = gemm_grouped_rows(h, weight, rg.rel_ptr,                                  # [S, out] per-relation W_r; only
                               out_dtype=torch.bfloat16 if y16 else torch.float32)     # read as a gather table
-        xr = gemm(x, root)                                                            # [N, out] root term
         c = rg.dst_csr
         out16 = hidden and _hidden_bf16_ok(n, d_out)
         out = spmm(c.rowptr, c.col, None, y, n, addend=xr, bias=bias, relu=relu, drop=drop, split=c.split,
@@ -584,7 +626,8 @@ class _RgcnConv(torch.autograd.Function):
     def backward(ctx, dout):
         x, weight, root, h, out = ctx.saved_tensors
         rg = ctx.rg
-        n, d_in, d_out = rg.num_nodes, weight.size(1), weight.size(2)
+        n, n_table, comm = _dims(rg)
+        d_in, d_out = weight.size(1), weight.size(2)
         dout = dout if dout.is_contiguous() else dout.contiguous()
         if (bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(d_out) and n >= 4096
                 and _bf16_operand_ok(n, d_in, d_out)):
@@ -598,24 +641,14 @@ class _RgcnConv(torch.autograd.Function):
         # dY[s] = dOut[dst_s] is never stored when both of its consumers can read dOut's rows through seg_dst
         gathered = (dout.dtype == torch.bfloat16 and gathered_k_ok(h, dout)
                     and _xw_ok(dout, rg.num_segments, d_in, d_out))
-        if gathered:
-            dy = None
-            dweight = (gemm_grouped_k(h, dout, rg.rel_ptr, rg.num_relations, b_rows=rg.seg_dst)
-                       if ctx.needs_input_grad[1] else None)
-        else:
+        dy = None
+        if not gathered:
             dy16 = (bf16_storage() and _bf16_ok(d_out) and
                     (not ctx.needs_input_grad[0] or _bf16_operand_ok(rg.num_segments, d_in, d_out)))
             dy = spmm(rg.seg_iota_ptr, rg.seg_dst, None, dout, rg.num_segments,       # dY[s] = dOut[dst_s]; read by
                       out_dtype=torch.bfloat16 if dy16 else torch.float32)            # the two products below only
-            dweight = gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations) if ctx.needs_input_grad[1] else None
-        droot = None
-        if ctx.needs_input_grad[2]:
-            if n < 4096 and (x.dtype == torch.bfloat16 or dout.dtype == torch.bfloat16):
-                droot = gemm(_as_f32(x), _as_f32(dout), trans_a=True)
-            else:
-                droot = gemm(x, dout, trans_a=True)
-        db = colsum(dout) if ctx.needs_input_grad[3] else None
-        dx = None
+        # the input gradient first: on a partitioned graph its table part goes out while the weight gradients run
+        dx, pending, dx_root = None, None, None
         if ctx.needs_input_grad[0]:
             if gathered:
                 dh = gemm_grouped_rows(dout, weight, rg.rel_ptr, trans_b=True, a_rows=rg.seg_dst,
@@ -624,13 +657,30 @@ class _RgcnConv(torch.autograd.Function):
                 to16 = bf16_storage() and _bf16_ok(d_in) and _xw_ok(dy, dy.size(0), d_in, d_out)
                 dh = gemm_grouped_rows(dy, weight, rg.rel_ptr, trans_b=True,
                                        out_dtype=torch.bfloat16 if to16 else torch.float32)   # [S, in], a gather table
-            dx_root = gemm(dout, root, trans_b=True)                                  # [N, in]
             c = rg.src_csr
             x16 = x.dtype == torch.bfloat16 and _bf16_ok(d_in)
-            dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), rg.num_nodes, addend=dx_root, split=c.split,
-                      out_dtype=torch.bfloat16 if x16 else torch.float32)
-            if dx.dtype != x.dtype:
-                dx = dx.to(x.dtype)
+            if comm is None:
+                dx_root = gemm(dout, root, trans_b=True)                              # [N, in]
+                dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), n_table, addend=dx_root, split=c.split,
+                          out_dtype=torch.bfloat16 if x16 else torch.float32)
+            else:
+                pending = comm.reduce_scatter_begin(spmm(c.rowptr, c.col, rg.src_w, _table(dh), n_table, split=c.split))
+                dx_root = gemm(dout, root, trans_b=True)
+        dweight = None
+        if ctx.needs_input_grad[1]:
+            dweight = (gemm_grouped_k(h, dout, rg.rel_ptr, rg.num_relations, b_rows=rg.seg_dst) if gathered
+                       else gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations))
+        droot = None
+        if ctx.needs_input_grad[2]:
+            if n < 4096 and (x.dtype == torch.bfloat16 or dout.dtype == torch.bfloat16):
+                droot = gemm(_as_f32(x), _as_f32(dout), trans_a=True)
+            else:
+                droot = gemm(x, dout, trans_a=True)
+        db = colsum(dout) if ctx.needs_input_grad[3] else None
+        if pending is not None:
+            dx = comm.reduce_scatter_end(pending) + dx_root
+        if dx is not None and dx.dtype != x.dtype:
+            dx = dx.to(x.dtype)
         return dx, dweight, droot, db, None, None, None, None
 
 
@@ -811,14 +861,18 @@ class _KgeBceLoss(torch.autograd.Function):
     segment reduce for dz.  Returns ``(loss, pos_pred, neg_pred)``; the preds are detached outputs."""
 
     @staticmethod
-    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind):
-        n, d, r = z.size(0), z.size(1), rel_emb.size(0)
+    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total):
+        d, r = z.size(1), rel_emb.size(0)
         t_pos, t_neg = pos_ei.size(1), neg_ei.size(1)
-        total = t_pos + t_neg
+        if total is None:
+            total = t_pos + t_neg
         dev = z.device
         drel = torch.zeros_like(rel_emb)
         # bf16 mode: both passes gather the node rows from a bf16 copy of z (half the bytes; fp32 accumulate)
         zt = to_bf16(z) if (bf16_storage() and d % 8 == 0 and (d // 8) in _KGE_PIECES) else z
+        if comm is not None:              # node-partitioned: the scorer reads the all-gathered table (triplet ids = slots)
+            zt = comm.all_gather(zt)
+        n = zt.size(0)
         zt_bf16 = int(zt.dtype == torch.bfloat16)
         scores, grads, recs, loss = [], [], [], torch.zeros((), dtype=torch.float64, device=dev)
         # packed {head, tail, rel, g} per triplet for the node-side backward (ids fit int32; one gather instead of four)
@@ -844,7 +898,7 @@ class _KgeBceLoss(torch.autograd.Function):
                 drel = drel + spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
             scores.append(s)
             grads.append(g)
-        ctx.kind = kind
+        ctx.kind, ctx.comm = kind, comm
         ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
         ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1])
         ctx.mark_non_differentiable(scores[0], scores[1])
@@ -883,14 +937,18 @@ class _KgeBceLoss(torch.autograd.Function):
                 first = False
             if first:
                 dz.zero_()
+            if ctx.comm is not None:
+                dz = ctx.comm.reduce_scatter(dz)          # the owners' sums of every rank's triplet share
             dz = dz * gloss
-        return dz, (drel * gloss if ctx.needs_input_grad[1] else None), None, None, None, None, None
+        return dz, (drel * gloss if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
 
 
-def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind):
+def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind, comm=None, total=None):
+    """``comm`` (node-partitioned training, biomedkg_amd/partition.py): ``z`` is the rank's shard, the triplet ids are
+    slots of the all-gathered table; ``total``: the count the BCE sum is divided by (default: this call's triplets)."""
     L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type)
     return _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
-                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind)
+                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, comm, total)
 
 
 # ----------------------------------------------------------------------------- NT-Xent
@@ -935,6 +993,58 @@ class _NtXent(torch.autograd.Function):
         return dh[0], dh[1], None, None
 
 
+class NtXentKernels:
+    """The NT-Xent arithmetic behind ``partition.ntxent_partitioned`` (csrc/ntxent2.hip, row-partitioned entry points);
+    the gloo tests inject a dense torch restatement with the same four methods."""
+
+    def __init__(self, operands=None):
+        self.bf16 = int((operands or ("bf16" if _PRECISION == 1 else "fp32")) == "bf16")
+
+    def normalize(self, h1, h2):
+        """-> ``zn [2n, hpad]`` (fp32, view 1 rows then view 2 rows), ``norm [2n]``, positive dots ``[n]``"""
+        h1, h2 = _f32c(h1), _f32c(h2)
+        n, h = h1.shape
+        self.h = h
+        hpad = L.lib().bkg_ntxent_hpad(h, self.bf16)
+        if hpad < 0:
+            raise ValueError(f"ntxent: embedding width {h} > 256 is not supported")
+        zn = torch.empty(2 * n, hpad, dtype=torch.float32, device=h1.device)
+        norm = torch.empty(2 * n, dtype=torch.float32, device=h1.device)
+        posdot = torch.empty(n, dtype=torch.float32, device=h1.device)
+        L.call("bkg_ntxent_prepare", L.ptr(h1), h1.stride(0), L.ptr(h2), h2.stride(0), n, h, hpad, L.ptr(zn), None,
+               L.ptr(norm), L.ptr(posdot), L.stream())
+        return zn, norm, posdot
+
+    def _operand(self, z_all):
+        return to_bf16(z_all) if self.bf16 else z_all
+
+    def row_sums(self, z_all, anchors, tau):
+        m, na = z_all.size(0), anchors.numel()
+        ws = torch.empty(L.lib().bkg_ntxent_rows_forward_workspace_floats(m, na, self.h, self.bf16), dtype=torch.float32,
+                         device=z_all.device)
+        den = torch.empty(na, dtype=torch.float32, device=z_all.device)
+        self._z16 = self._operand(z_all)
+        L.call("bkg_ntxent_rows_forward", L.ptr(self._z16), self.bf16, m, self.h, tau, L.ptr(anchors), na, L.ptr(ws),
+               L.ptr(den), L.stream())
+        return den
+
+    def row_grads(self, z_all, anchors, den_all, norm, tau, scale, n_half):
+        """-> ``dh [n_anchor, h]``: d(loss)/d(un-normalised anchor rows) * scale (``scale``: device scalar tensor)"""
+        m, na = z_all.size(0), anchors.numel()
+        ws = torch.empty(L.lib().bkg_ntxent_rows_backward_workspace_floats(m, na, self.h, self.bf16), dtype=torch.float32,
+                         device=z_all.device)
+        rden = (1.0 / den_all).contiguous()
+        dh = torch.empty(na, self.h, dtype=torch.float32, device=z_all.device)
+        z16 = getattr(self, "_z16", None)
+        if z16 is None or z16.size(0) != m:
+            z16 = self._operand(z_all)
+        scale = scale.reshape(1).to(torch.float32).contiguous()
+        L.call("bkg_ntxent_rows_backward", L.ptr(z16), self.bf16, L.ptr(z_all), L.ptr(norm), L.ptr(rden), L.ptr(scale), m,
+               self.h, tau, L.ptr(anchors), na, n_half, 1.0, L.ptr(ws), L.ptr(dh[:n_half]), self.h,
+               L.ptr(dh[n_half:]), self.h, L.stream())
+        return dh
+
+
 def ntxent_loss(h1, h2, tau=0.2, operands=None):
     """``operands``: None = follow the matmul precision mode, or "fp32" / "bf16" explicitly."""
     L.require_cuda(h1, h2)
@@ -951,15 +1061,30 @@ def ntxent_loss(h1, h2, tau=0.2, operands=None):
 
 
 # ----------------------------------------------------------------------------- modality fusion
+FUSION_CHUNK_NODES = 4096   # 2 * 4096 rows x 2304 fp32 = 75 MB of q|k|v per chunk: stays in the 256 MiB Infinity Cache
+
+
 def attention_fusion(x, w_qkv, b_qkv):
     """AttentionFusion.forward (reference fusion.py:17-31): one QKV GEMM + fused MxM attention/mean.
     ``x [n, M, D]``, ``w_qkv [3D, D]``, ``b_qkv [3D]`` -> ``[n, D]``.  Forward only (the reference never
-    trains the fuser: its parameters are outside every optimizer)."""
+    trains the fuser: its parameters are outside every optimizer).  Runs in node chunks so that the
+    ``[M n, 3D]`` projection (2.4 GB at n = 130k) never makes the HBM round trip between its two kernels: each chunk's
+    q|k|v is consumed out of the Infinity Cache by the attention / mean kernel right behind the product."""
     L.require_cuda(x, w_qkv, b_qkv)
     n, m, d = x.shape
-    qkv = gemm(_f32c(x).view(n * m, d), w_qkv, trans_b=True, bias=b_qkv)
+    x2 = _f32c(x).view(n * m, d)
     out = torch.empty(n, d, dtype=torch.float32, device=x.device)
-    L.call("bkg_attn_fuse_f32", L.ptr(qkv), qkv.stride(0), n, m, d, L.ptr(out), out.stride(0), L.stream())
+    step = FUSION_CHUNK_NODES if n > 2 * FUSION_CHUNK_NODES else max(n, 1)
+    qkv = None
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        rows = (hi - lo) * m
+        buf = None if qkv is None or qkv.size(0) < rows else qkv[:rows]
+        qkv_c = gemm(x2[lo * m: hi * m], w_qkv, trans_b=True, bias=b_qkv, out=buf)
+        if qkv is None:
+            qkv = qkv_c
+        L.call("bkg_attn_fuse_f32", L.ptr(qkv_c), qkv_c.stride(0), hi - lo, m, d, L.ptr(out[lo:hi]), out.stride(0),
+               L.stream())
     return out
 
 

@@ -183,6 +183,19 @@ int64_t bkg_ntxent_backward_workspace_floats(int64_t M, int32_t h, int32_t bf16)
 int bkg_ntxent_backward(const void* zn, int32_t bf16, const float* zn_f32, const float* norm, const float* rden,
                         const float* gout, int64_t M, int32_t h, float tau, float* workspace, float* dh1, int64_t ld1,
                         float* dh2, int64_t ld2, void* stream);
+/*      Row-partitioned form (multi-GPU: the 2N rows are partitioned like the nodes): the rank's n_anchor anchor
+ *      rows zn[anchors[a]] against ALL M (all-gathered) rows.  rows_forward: den[n_anchor] = D of the anchors.
+ *      rows_backward: rden[M] = 1/D of all rows (all-gathered), norm[n_anchor]; anchor a < n_half -> dh1[a], the rest ->
+ *      dh2[a - n_half]; gradient scaled by *gout * grad_scale.  W_ij = E_ij (1/D_i + 1/D_j) is symmetric, so a rank's
+ *      rows need nothing back from the other ranks. */
+int64_t bkg_ntxent_rows_forward_workspace_floats(int64_t M, int64_t n_anchor, int32_t h, int32_t bf16);
+int bkg_ntxent_rows_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau, const int32_t* anchors,
+                            int64_t n_anchor, float* workspace, float* den, void* stream);
+int64_t bkg_ntxent_rows_backward_workspace_floats(int64_t M, int64_t n_anchor, int32_t h, int32_t bf16);
+int bkg_ntxent_rows_backward(const void* zn, int32_t bf16, const float* zn_f32, const float* norm, const float* rden,
+                             const float* gout, int64_t M, int32_t h, float tau, const int32_t* anchors, int64_t n_anchor,
+                             int64_t n_half, float grad_scale, float* workspace, float* dh1, int64_t ld1, float* dh2,
+                             int64_t ld2, void* stream);
 
 /* ---- device mini-batch samplers (the reference's PyG loaders: biomedkg/data_module.py:89-107).
  *      bkg_random_walk: walks[w, 0..L] over the source-sorted CSR, uniform out-neighbour per step (sinks stay put).

@@ -3,7 +3,11 @@
 "rocprofv3 PMC slots" requires) into per-kernel HBM-side traffic per launch.
 
     python scripts/pmc_summary.py gpurun_out/pmc_FETCH_SIZE/*/*_counter_collection.csv \
-                                  gpurun_out/pmc_WRITE_SIZE/*/*_counter_collection.csv  profiles/r01_pmc_traffic.json [fp32|bf16]
+                                  gpurun_out/pmc_WRITE_SIZE/*/*_counter_collection.csv  profiles/rNN_pmc_traffic.json [fp32|bf16] \
+                                  [bench.json]
+
+``bench.json`` (a bench.py output line of the same build): its roofline entries carry (tag, grid_size); the matching
+spmm_items launches get that ``tag`` so that bench.py can look its traffic up.
 
 Units/corrections (MI355X_MICROARCH.md "HBM"): the counters are in KiB; on gfx950 FETCH_SIZE reports
 exactly half of the bytes of wide (16 B/lane) coalesced reads, which is what every gather in these
@@ -25,14 +29,21 @@ def load(path, counter):
     return groups
 
 
-def main(fetch_csv, write_csv, out_json, precision="fp32"):
+def main(fetch_csv, write_csv, out_json, precision="fp32", bench_json=None):
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    tags = {}
+    if bench_json:
+        b = json.loads([ln for ln in open(bench_json) if ln.startswith("{")][-1])
+        for r in [b.get("roofline")] + list(b.get("kernels") or []):
+            if r and r.get("grid_size"):
+                tags[int(r["grid_size"])] = r["tag"]
     out = []
     for key in sorted(f, key=lambda k: -sum(f[k])):
         fv, wv = f[key], w.get(key, [0.0])
         fetch = 2.0 * 1024 * sum(fv) / len(fv)
         write = 1024 * sum(wv) / len(wv)
-        out.append({"kernel": key[0], "grid_size": key[1], "precision": precision, "launches": len(fv),
+        tag = tags.get(key[1]) if "spmm_items" in key[0] else None
+        out.append({"kernel": key[0], "grid_size": key[1], "precision": precision, "launches": len(fv), "tag": tag,
                     "fetch_bytes_per_launch": fetch,
                     "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write})
     prev = []
@@ -48,4 +59,4 @@ def main(fetch_csv, write_csv, out_json, precision="fp32"):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

@@ -68,6 +68,25 @@ def _worker(rank, world, port, outdir):
     for gr in grads:
         dist.all_reduce(gr)
     res.update(rgcn_z=z_local.detach(), rgcn_grads=grads, rgcn_dx=x_local.grad.clone(), score_sum=score.sum().detach())
+
+    # ---- whole GGD loss (corruption permutation + dropout_edge mask shared by the ranks) and row-partitioned NT-Xent
+    from cpu_backend import TorchNtXentKernels
+    torch.manual_seed(13)
+    ggd = R.GGD(R.GCNEncoder(24, 16, 16, 1), 16, 1, 0.5).eval()
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(4))
+    pg2 = P.PartitionedGraph(part, ei, B)
+    loss = P.ggd_loss_partitioned(ggd, part.shard(x_gcn), pg2, B, perm, keep=keep)
+    loss.backward()
+    grads = [p.grad.clone() for p in ggd.parameters()]
+    for gr in grads:
+        dist.all_reduce(gr)
+        gr /= world                                                    # what the gradient bucket does
+    res.update(ggd_loss=P.loss_value(loss, world), ggd_grads=grads)
+    h1 = part.shard(x_gcn)[:, :12].clone().requires_grad_(True)
+    h2 = part.shard(x_gcn)[:, 12:].clone().requires_grad_(True)
+    nl = P.ntxent_partitioned(h1, h2, 0.2, part, TorchNtXentKernels())
+    nl.backward()
+    res.update(ntx_loss=P.loss_value(nl, world), ntx_g1=h1.grad / world, ntx_g2=h2.grad / world)
     torch.save(res, os.path.join(outdir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
@@ -82,9 +101,10 @@ def test_partitioned_encoders_match_whole_graph(tmp_path, world):
     ei, et = g["edge_index"], g["edge_type"]
     bounds = parts[0]["bounds"]
     assert bounds[0] == 0 and bounds[-1] == 400 and all(p["bounds"] == bounds for p in parts)
-    load = torch.bincount(ei[1], minlength=400) + 1
-    shares = [int(load[a:b].sum()) for a, b in zip(bounds[:-1], bounds[1:])]
-    assert max(shares) < 1.6 * sum(shares) / world                       # balanced by in-edges
+    from biomedkg_amd.partition import NodePartition
+    load = torch.bincount(ei[1], minlength=400) + NodePartition.NODE_WEIGHT
+    shares = [float(load[a:b].sum()) for a, b in zip(bounds[:-1], bounds[1:])]
+    assert max(shares) < 1.3 * sum(shares) / world                       # balanced by in-edges + the per-node weight
 
     torch.manual_seed(11)
     enc = R.GCNEncoder(24, 16, 16, 2).eval()
@@ -109,3 +129,27 @@ def test_partitioned_encoders_match_whole_graph(tmp_path, world):
     torch.testing.assert_close(torch.cat([p["rgcn_dx"] for p in parts]), x.grad, rtol=1e-3, atol=1e-4)
     for got, p in zip(parts[0]["rgcn_grads"], model.parameters()):
         torch.testing.assert_close(got, p.grad, rtol=1e-3, atol=1e-3)
+
+    # GGD: same permutation and edge mask on the whole graph through the oracle
+    from oracle import pygcl_ops as G
+    torch.manual_seed(13)
+    ggd = R.GGD(R.GCNEncoder(24, 16, 16, 1), 16, 1, 0.5).eval()
+    perm = torch.randperm(400, generator=torch.Generator().manual_seed(4))
+    pos = ggd.encoder(x_gcn, ei[:, keep])
+    neg = ggd.encoder(x_gcn[perm], ei[:, keep])
+    head = ggd.mlp[-1]
+    pred = torch.cat([head(pos).sum(1), head(neg).sum(1)])
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(pred, torch.cat([torch.ones(400), torch.zeros(400)]))
+    ref.backward()
+    for p in parts:
+        torch.testing.assert_close(p["ggd_loss"], ref.detach(), rtol=1e-5, atol=1e-6)
+    for got, p in zip(parts[0]["ggd_grads"], ggd.parameters()):
+        torch.testing.assert_close(got, p.grad, rtol=1e-4, atol=1e-6)
+    # NT-Xent: the 2N rows partitioned like the nodes vs the oracle on all of them
+    h1, h2 = x_gcn[:, :12].clone().requires_grad_(True), x_gcn[:, 12:].clone().requires_grad_(True)
+    ref = G.dual_branch_l2l_intraview(h1, h2, 0.2)
+    ref.backward()
+    for p in parts:
+        torch.testing.assert_close(p["ntx_loss"], ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(torch.cat([p["ntx_g1"] for p in parts]), h1.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(torch.cat([p["ntx_g2"] for p in parts]), h2.grad, rtol=1e-4, atol=1e-7)

@@ -65,7 +65,7 @@ def test_partitioned_training_losses_world1_match_the_modules():
     x = torch.randn(n, 64, device=DEV)
     perm = torch.randperm(n, device=DEV)
     pg = P.PartitionedGraph(part, ei, P.HipBackend)
-    loss_p = P.ggd_loss_partitioned(gcl.model, x, pg, P.HipBackend, perm)
+    loss_p = P.ggd_loss_partitioned(gcl.model, part.shard(x), pg, P.HipBackend, perm)
     loss_p.backward()
     grads_p = [p.grad.clone() for p in gcl.model.parameters()]
     gcl.model.zero_grad()
@@ -85,7 +85,7 @@ def test_partitioned_training_losses_world1_match_the_modules():
     neg = sampling.negative_sampling(ei, n, ei.size(1), seed=3)
     nt = et[torch.randperm(et.numel(), device=DEV)]
     prg = P.PartitionedRelGraph(part, ei, et, r, P.HipBackend)
-    loss_p = P.kge_loss_partitioned(kge.model, x, prg, P.HipBackend, ei, et, neg, nt, kge.model.decoder.kind)
+    loss_p = P.kge_loss_partitioned(kge.model, part.shard(x), prg, P.HipBackend, ei, et, neg, nt, kge.model.decoder.kind)
     loss_p.backward()
     grads_p = [p.grad.clone() for p in kge.model.parameters()]
     kge.model.zero_grad()
@@ -98,3 +98,165 @@ def test_partitioned_training_losses_world1_match_the_modules():
     torch.testing.assert_close(loss_p, loss, rtol=1e-4, atol=1e-5)
     for a, p in zip(grads_p, kge.model.parameters()):
         torch.testing.assert_close(a, p.grad, rtol=2e-3, atol=1e-4)
+
+
+def test_partitioned_step_world1_in_bf16_mode_runs_the_fused_views_path():
+    """bf16 mode at a size that engages the side-by-side GGD views and the bf16 tables: the partitioned losses and
+    gradients (exchange degenerate at one rank) against the whole-graph modules in the same mode, same permutation,
+    same edge mask, same negatives."""
+    from biomedkg_amd import ops, partition as P, rand as R, sampling, synthetic
+    from biomedkg_amd.gcl_module import GGDModule
+    from biomedkg_amd.kge_module import KGEModule
+    g = synthetic.primekg_like(6000, 120_000, 8, seed=6)
+    ei, et, n, r = g["edge_index"].to(DEV), g["edge_type"].to(DEV), g["num_nodes"], g["num_relations"]
+    part = P.NodePartition(ei, n, 0, 1)
+    torch.manual_seed(0)
+    x = torch.randn(n, 256, device=DEV)
+    perm = torch.randperm(n, device=DEV)
+    keep = torch.rand(ei.size(1), device=DEV) >= 0.4
+    ops.set_matmul_precision("bf16")
+    try:
+        gcl = GGDModule(in_dim=256, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="none").to(DEV).eval()
+        pg = P.PartitionedGraph(part, ei, P.HipBackend)
+        calls = []
+        orig = ops.gcn_conv_views
+        ops.gcn_conv_views = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            loss_p = P.ggd_loss_partitioned(gcl.model, x, pg, P.HipBackend, perm, keep=keep)
+        finally:
+            ops.gcn_conv_views = orig
+        assert len(calls) == 4                                           # the fused side-by-side path was taken
+        loss_p.backward()
+        grads_p = [p.grad.clone() for p in gcl.model.parameters()]
+        gcl.model.zero_grad()
+
+        class Fixed(R.DeviceRand):                                       # same draws for the module's own forward
+            def coin(self): return 0.0
+            def masked(self, xx, p): return xx
+            def edge_keep(self, e, p, device): return keep
+            def perm(self, nn, device): return perm
+        with R.use(Fixed(seed=1)):
+            pos_h, neg_h = gcl.model(x, ei)
+        pred = torch.cat([pos_h, neg_h])
+        gt = torch.cat([torch.ones(n, device=DEV), torch.zeros(n, device=DEV)])
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, gt)
+        loss.backward()
+        torch.testing.assert_close(loss_p, loss, rtol=1e-3, atol=1e-4)
+        for a, p in zip(grads_p, gcl.model.parameters()):
+            err = float((a - p.grad).norm() / p.grad.norm().clamp_min(1e-12))
+            assert err < 2e-2, err
+        # --- KGE
+        kge = KGEModule("rgcn", "dismult", 256, 256, 256, 2, r, 1, "cosine", 1e-3, 0.1, "none", 1, "random").to(DEV).eval()
+        neg = sampling.negative_sampling(ei, n, ei.size(1), seed=3)
+        nt = et[torch.randperm(et.numel(), device=DEV)]
+        prg = P.PartitionedRelGraph(part, ei, et, r, P.HipBackend)
+        loss_p = P.kge_loss_partitioned(kge.model, x, prg, P.HipBackend, ei, et, neg, nt, kge.model.decoder.kind)
+        loss_p.backward()
+        grads_p = [p.grad.clone() for p in kge.model.parameters()]
+        kge.model.zero_grad()
+        z = kge.model.encode(x, ei, et)
+        ce, _, _ = ops.kge_bce_loss(z, kge.model.decoder.rel_emb, ei, et, neg, nt, kge.model.decoder.kind)
+        loss = ce + 1e-2 * (z.pow(2).mean() + kge.model.decoder.rel_emb.pow(2).mean())
+        loss.backward()
+        torch.testing.assert_close(loss_p, loss, rtol=1e-3, atol=1e-4)
+        for a, p in zip(grads_p, kge.model.parameters()):
+            err = float((a - p.grad).norm() / p.grad.norm().clamp_min(1e-12))
+            assert err < 2e-2, err
+    finally:
+        ops.set_matmul_precision("fp32")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_row_partitioned_ntxent_world1_matches_the_whole_problem(mode):
+    """partition.ntxent_partitioned at one rank = the rectangular (anchor subset) kernels over ALL rows: same loss and
+    gradients as the symmetric whole-problem path."""
+    from biomedkg_amd import ops, partition as P, synthetic
+    g = synthetic.primekg_like(1500, 20_000, 4, seed=1)
+    part = P.NodePartition(g["edge_index"].to(DEV), g["num_nodes"], 0, 1)
+    torch.manual_seed(2)
+    a = torch.randn(1500, 96, device=DEV)
+    b = 0.6 * a + 0.4 * torch.randn(1500, 96, device=DEV)
+    a1, b1 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = ops.ntxent_loss(a1, b1, 0.2, operands=mode)
+    (1.7 * ref).backward()
+    a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    got = P.ntxent_partitioned(a2, b2, 0.2, part, ops.NtXentKernels(operands=mode))
+    (1.7 * got).backward()
+    tol = 1e-6 if mode == "fp32" else 1e-5
+    assert abs(float(got) - float(ref)) <= tol * abs(float(ref)), (float(got), float(ref))
+    for x, y in ((a2.grad, a1.grad), (b2.grad, b1.grad)):
+        assert float((x - y).norm() / y.norm()) < (1e-5 if mode == "fp32" else 1e-3)
+
+
+def _two_rank_worker(rank, world, port, outdir):
+    """Two processes on ONE MI355X, gloo as the transport (CUDA tensors go through the host): functional check of
+    the fused partitioned layers' exchange placement at world 2 -- never a performance statement."""
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from biomedkg_amd import ops, partition as P, sampling, synthetic
+    from biomedkg_amd.gcl_module import GGDModule, GRACEModule
+    from biomedkg_amd.kge_module import KGEModule
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops.set_matmul_precision("bf16")
+    g = synthetic.primekg_like(12000, 240_000, 8, seed=6)
+    ei, et, n, r = g["edge_index"].to(DEV), g["edge_type"].to(DEV), g["num_nodes"], g["num_relations"]
+    part = P.NodePartition(ei, n, rank, world)
+    torch.manual_seed(0)
+    x = torch.randn(n, 256, device=DEV)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).to(DEV)
+    keep = (torch.rand(ei.size(1), generator=torch.Generator().manual_seed(2)) >= 0.4).to(DEV)
+    torch.manual_seed(5)
+    gcl = GGDModule(in_dim=256, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="none").to(DEV).eval()
+    kge = KGEModule("rgcn", "dismult", 256, 256, 256, 2, r, 1, "cosine", 1e-3, 0.1, "none", 1, "random").to(DEV).eval()
+    grace = GRACEModule(in_dim=256, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="none").to(DEV).eval()
+    out = {}
+    pg = P.PartitionedGraph(part, ei, P.HipBackend)
+    loss = P.ggd_loss_partitioned(gcl.model, part.shard(x), pg, P.HipBackend, perm, keep=keep)
+    loss.backward()
+    grads = [p.grad.clone() for p in gcl.model.parameters()]
+    for t in grads:
+        dist.all_reduce(t); t /= world
+    out["ggd"] = (P.loss_value(loss, world).cpu(), [t.cpu() for t in grads])
+    neg = sampling.negative_sampling(ei, n, ei.size(1), seed=3)
+    nt = et[torch.randperm(et.numel(), generator=torch.Generator().manual_seed(3)).to(DEV)]
+    prg = P.PartitionedRelGraph(part, ei, et, r, P.HipBackend)
+    sh = slice(rank, None, world)
+    loss = P.kge_loss_partitioned(kge.model, part.shard(x), prg, P.HipBackend, ei[:, sh].contiguous(), et[sh].contiguous(),
+                                  neg[:, sh].contiguous(), nt[sh].contiguous(), kge.model.decoder.kind,
+                                  n_pos_global=ei.size(1), n_neg_global=neg.size(1))
+    loss.backward()
+    grads = [p.grad.clone() for p in kge.model.parameters()]
+    for t in grads:
+        dist.all_reduce(t); t /= world
+    out["kge"] = (P.loss_value(loss, world).cpu(), [t.cpu() for t in grads])
+    # GRACE head on the rank's rows: encoder over the shard (no augmentation), projector, row-partitioned NT-Xent
+    z = P.gcn_encoder_partitioned(grace.model.encoder, part.shard(x), pg, P.HipBackend)
+    h1 = grace.model.project(z)
+    h2 = grace.model.project(z * 0.5 + 0.1)
+    loss = P.ntxent_partitioned(h1, h2, 0.2, part)
+    loss.backward()
+    grads = [p.grad.clone() for p in grace.model.parameters()]
+    for t in grads:
+        dist.all_reduce(t); t /= world
+    out["grace"] = (P.loss_value(loss, world).cpu(), [t.cpu() for t in grads])
+    torch.save(out, os.path.join(outdir, f"w{world}_r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_fused_partitioned_steps_two_ranks_on_one_gpu_match_one_rank(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    res = {}
+    for world in (1, 2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+        res[world] = torch.load(tmp_path / f"w{world}_r0.pt")
+    for key in ("ggd", "kge", "grace"):
+        l1, g1 = res[1][key]
+        l2, g2 = res[2][key]
+        assert abs(float(l1) - float(l2)) <= 2e-3 * abs(float(l1)), (key, float(l1), float(l2))
+        for a, b in zip(g1, g2):
+            err = float((a - b).norm() / a.norm().clamp_min(1e-12))
+            assert err < 3e-2, (key, err)
