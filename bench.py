@@ -117,7 +117,7 @@ def roofline_of(tag, rec, precision):
             "frac": (gbs / peak) if peak else None, "traffic": traffic, "reuse": reuse,
             "hbm_side_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None, "hbm_peak_GBs": HBM_PEAK_GBS,
             "avg_launch_ms": avg_ms, "launches": len(durs), "ms_total": sum(durs), "bytes_per_launch": rec["bytes"],
-            "grid_size": rec.get("grid"),
+            "grid_size": rec.get("grid"), "pieces": max(d // 8, 1) if precision == "bf16" else max(d // 4, 1),
             "guide_gather_GBs": {"infinity_cache": MALL_GATHER_GBS, "l2": L2_GATHER_GBS},
             "peak_definition": "8 TB/s HBM peak x cache reuse (algorithmic bytes / PMC bytes that left L2): frac = HBM-side "
                                "traffic rate / 8 TB/s; null when no PMC pass of this launch is committed under profiles/"}

@@ -378,7 +378,10 @@ def _dims(graph):
     ``n_out == n_table`` and no exchange; a node-partitioned one (biomedkg_amd/partition.py) owns ``n_out`` target rows,
     gathers from the all-gathered ``n_table``-row table and carries the collective pair in ``comm``."""
     n = graph.num_nodes
-    return getattr(graph, "n_out", n), getattr(graph, "n_table", n), getattr(graph, "comm", None)
+    comm = getattr(graph, "comm", None)
+    if comm is not None and comm.world == 1:
+        comm = None                        # one rank: nothing to exchange, no fp32 partial tables needed
+    return getattr(graph, "n_out", n), getattr(graph, "n_table", n), comm
 
 
 class _GcnConv(torch.autograd.Function):

@@ -92,7 +92,11 @@ class F1Score(_Binary):
 
 
 class BootStrapper(Metric):
-    """torchmetrics BootStrapper defaults: 10 bootstraps, poisson resampling, returns mean and std."""
+    """torchmetrics BootStrapper defaults: 10 bootstraps, poisson resampling, returns mean and std.
+    ``poisson`` (class attribute, tests only): ``f(n, device, bootstrap_index) -> int64 [n]`` multiplicities in place of
+    the device draw, so that a run can be replayed into the CPU checker."""
+
+    poisson = None
 
     def __init__(self, base_metric, num_bootstraps: int = 10, **kwargs):
         super().__init__()
@@ -100,9 +104,10 @@ class BootStrapper(Metric):
 
     def update(self, preds, target):
         n = preds.numel()
-        for m in self.metrics:
-            idx = torch.repeat_interleave(torch.arange(n, device=preds.device),
-                                          torch.poisson(torch.ones(n, device=preds.device)).long())
+        for b, m in enumerate(self.metrics):
+            cnt = (self.poisson(n, preds.device, b) if self.poisson is not None
+                   else torch.poisson(torch.ones(n, device=preds.device)).long())
+            idx = torch.repeat_interleave(torch.arange(n, device=preds.device), cnt)
             if idx.numel():
                 m.update(preds[idx], target[idx])
 

@@ -36,13 +36,17 @@ def main(fetch_csv, write_csv, out_json, precision="fp32", bench_json=None):
         b = json.loads([ln for ln in open(bench_json) if ln.startswith("{")][-1])
         for r in [b.get("roofline")] + list(b.get("kernels") or []):
             if r and r.get("grid_size"):
-                tags[int(r["grid_size"])] = r["tag"]
+                tags[(int(r["grid_size"]), int(r["pieces"]))] = r["tag"]
     out = []
     for key in sorted(f, key=lambda k: -sum(f[k])):
         fv, wv = f[key], w.get(key, [0.0])
         fetch = 2.0 * 1024 * sum(fv) / len(fv)
         write = 1024 * sum(wv) / len(wv)
-        tag = tags.get(key[1]) if "spmm_items" in key[0] else None
+        tag = None
+        if "spmm_items" in key[0]:      # "spmm_items_kernel<__bf16, 64, 1>" or its mangled form "...IDF16bLi64ELi1EE..."
+            for (grid, pieces), t in tags.items():
+                if grid == key[1] and (f", {pieces}, " in key[0] or f"Li{pieces}ELi" in key[0]):
+                    tag = t
         out.append({"kernel": key[0], "grid_size": key[1], "precision": precision, "launches": len(fv), "tag": tag,
                     "fetch_bytes_per_launch": fetch,
                     "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write})

@@ -145,3 +145,25 @@ def test_mask_and_dropout_restatements():
     y = P.dropout(x, 0.2, True)
     assert set(y.unique().tolist()) == {0.0, 1.25}
     assert torch.equal(P.dropout(x, 0.2, False), x)
+
+
+def test_metric_restatements_against_scikit_learn():
+    """oracle/metrics.py (torchmetrics' binary AUROC / AveragePrecision / F1 definitions) pinned by an independent
+    implementation: scikit-learn on scores with ties, logits outside [0, 1] and a skewed class balance."""
+    import numpy as np
+    from sklearn.metrics import average_precision_score, f1_score, roc_auc_score
+    from oracle import metrics as M
+    rng = np.random.default_rng(0)
+    for n, pos_rate, ties in ((2000, 0.5, False), (3000, 0.1, True), (500, 0.9, True)):
+        t = (rng.random(n) < pos_rate).astype(np.int64)
+        s = rng.normal(size=n) * 2.0 + t * 1.5                       # logits, well outside [0, 1]
+        if ties:
+            s = np.round(s * 2.0) / 2.0                              # many exact ties
+        prob = 1.0 / (1.0 + np.exp(-s))
+        assert abs(M.binary_auroc(s, t) - roc_auc_score(t, prob)) < 1e-12
+        assert abs(M.binary_average_precision(s, t) - average_precision_score(t, prob)) < 1e-12
+        assert abs(M.binary_f1(s, t) - f1_score(t, prob > 0.5)) < 1e-12
+    assert M.binary_auroc([0.2, 0.7], [1, 1]) == 0.0                 # a class absent: torchmetrics returns 0
+    assert M.binary_f1([0.1, 0.2], [0, 0]) == 0.0
+    got = M.edge_wise_precision([0.7, 0.2, 0.9, -1.0], [0, 0, 2, 2], {0: "a", 1: "b", 2: "c"})
+    assert got == {"a_pre": 0.5, "b_pre": 0.0, "c_pre": 0.5}
