@@ -22,11 +22,12 @@ import numpy as np
 
 
 def _format(preds, target):
-    p = np.asarray(preds, dtype=np.float64).reshape(-1)
+    p = np.asarray(preds).reshape(-1)
     t = np.asarray(target).reshape(-1).astype(np.int64)
     if ((p < 0) | (p > 1)).any():
-        p = 1.0 / (1.0 + np.exp(-p))
-    return p, t
+        # torchmetrics squashes in the predictions' own dtype: fp32 logits saturate (and tie) where fp64 would not
+        p = (1.0 / (1.0 + np.exp(-p))).astype(p.dtype) if p.dtype == np.float32 else 1.0 / (1.0 + np.exp(-p.astype(np.float64)))
+    return p.astype(np.float64), t
 
 
 def _clf_curve(p, t):
@@ -74,7 +75,7 @@ def bootstrap(fn, batches, counts):
         for (p, t), c in zip(batches, per_update):
             idx = np.repeat(np.arange(len(c)), np.asarray(c, dtype=np.int64))
             if idx.size:
-                ps.append(np.asarray(p, dtype=np.float64)[idx]); ts.append(np.asarray(t)[idx])
+                ps.append(np.asarray(p)[idx]); ts.append(np.asarray(t)[idx])     # keeps the dtype: see _format
         vals.append(fn(np.concatenate(ps), np.concatenate(ts)))
     vals = np.asarray(vals, dtype=np.float64)
     return float(vals.mean()), float(vals.std(ddof=1))
