@@ -30,7 +30,31 @@ static inline int check_launch(const char* what) {
     }                               \
   } while (0)
 
+// In a split-K launcher: switch `ep` to plain stores into per-chunk slabs when the deterministic workspace is set.
+#define BKG_DET_SLABS(det, ep, n_chunks, M, N, who)                                              \
+  do {                                                                                           \
+    const bkg::DetWorkspace dw_ = bkg::det_workspace();                                          \
+    if (dw_.ptr) {                                                                               \
+      if ((int64_t)(n_chunks) * (int64_t)(M) * (int64_t)(N) > dw_.floats) {                      \
+        bkg::set_error_msg(who ": deterministic workspace too small (bkg_set_deterministic_workspace)"); \
+        return -1;                                                                               \
+      }                                                                                          \
+      (det) = dw_.ptr;                                                                           \
+      (ep).atomic = 0;                                                                           \
+    }                                                                                            \
+  } while (0)
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Deterministic mode (bkg_set_deterministic_workspace): the split-K weight-gradient products write one [M, N] slab per
+// K chunk into this caller-owned buffer instead of adding with float atomics; splitk_reduce() then sums the slabs of
+// each output in chunk order.  {nullptr, 0} = off.
+struct DetWorkspace { float* ptr; int64_t floats; };
+DetWorkspace det_workspace();
+// C_g[m, n] = sum over the group's chunks (in chunk order) of ws[(first_chunk(g) + c) * M * N + m * N + n];
+// group_ptr == nullptr: one group of `n_chunks` chunks.  Chunks of group g: ceil(rows_g / kchunk).
+void splitk_reduce(const float* ws, float* C, int64_t ldc, int64_t strideC, int M, int N, const int32_t* group_ptr, int G,
+                   int kchunk, int n_chunks, hipStream_t s);
 
 // XCD-aware block -> work mapping.  MI355X dispatches workgroup b of a 1-D grid to XCD b % 8, and each of the 8
 // XCDs has a private L2.  Work is indexed (outer, inner) where the `n_inner` items of one outer index re-read the

@@ -11,7 +11,40 @@ void set_error(const char* what, hipError_t e) {
   snprintf(g_err, sizeof(g_err), "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
 }
 void set_error_msg(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
+
+static DetWorkspace g_det = {nullptr, 0};
+DetWorkspace det_workspace() { return g_det; }
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
+                                                            int64_t strideC, int M, int N, const int32_t* __restrict__ group_ptr,
+                                                            int G, int kchunk, int n_chunks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (int64_t)M * N;
+  if (i >= per * G) return;
+  const int g = (int)(i / per);
+  const int64_t e = i % per;
+  int first = 0, cnt = n_chunks;
+  if (group_ptr) {
+    for (int q = 0; q < g; ++q) first += (group_ptr[q + 1] - group_ptr[q] + kchunk - 1) / kchunk;
+    cnt = (group_ptr[g + 1] - group_ptr[g] + kchunk - 1) / kchunk;
+  }
+  float acc = 0.f;
+  for (int c = 0; c < cnt; ++c) acc += ws[(int64_t)(first + c) * per + e];      // fixed order: bitwise repeatable
+  C[(int64_t)g * strideC + (e / N) * ldc + e % N] = acc;
+}
+
+void splitk_reduce(const float* ws, float* C, int64_t ldc, int64_t strideC, int M, int N, const int32_t* group_ptr, int G,
+                   int kchunk, int n_chunks, hipStream_t s) {
+  const int64_t total = (int64_t)M * N * G;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, C, ldc, strideC, M, N,
+                     group_ptr, G, kchunk, n_chunks);
+}
 }  // namespace bkg
+
+extern "C" int bkg_set_deterministic_workspace(float* workspace, int64_t floats) {
+  bkg::g_det = {workspace, workspace ? floats : 0};
+  return 0;
+}
 
 extern "C" const char* bkg_last_error() { return bkg::g_err; }
 extern "C" int bkg_abi_version() { return 1; }

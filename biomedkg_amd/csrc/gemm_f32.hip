@@ -172,13 +172,14 @@ template <int PREC, int BM, int BN, bool TA, bool TB, typename AT = float, typen
 __global__ __launch_bounds__(256) void gemm_f32_splitk_kernel(const AT* __restrict__ A, int64_t lda,
                                                               const BT* __restrict__ B, int64_t ldb,
                                                               float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                              int kchunk, GemmEpilogue ep) {
+                                                              int kchunk, GemmEpilogue ep, float* __restrict__ det) {
   // the output tiles of one K chunk re-read the same operand strips: keep them on one XCD (see gemm_f32_kernel)
   const int n_tiles = (N + BN - 1) / BN, tiles = n_tiles * ((M + BM - 1) / BM);
   const XcdSlot t = xcd_slot(blockIdx.x, tiles);
   const int m0 = (t.inner / n_tiles) * BM, n0 = (t.inner % n_tiles) * BN;
   const int kbeg = t.outer * kchunk, kend = min(kbeg + kchunk, K);
   if (kbeg >= kend) return;
+  if (det) { C = det + (int64_t)t.outer * M * N; ldc = N; }      // deterministic mode: this chunk's own slab, plain stores
   gemm_tile_any<PREC, BM, BN, TA, TB, AT, BT>(A, lda, B, ldb, C, ldc, M, N, K, m0, n0, kbeg, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
 }
 
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const AT* __res
                                                                  const BT* __restrict__ B, int64_t ldb,
                                                                  float* __restrict__ C, int64_t ldc, int64_t strideC,
                                                                  const int32_t* __restrict__ group_ptr, int G, int M,
-                                                                 int N, int kchunk, GemmEpilogue ep) {
+                                                                 int N, int kchunk, GemmEpilogue ep, float* __restrict__ det) {
   __shared__ int s_g, s_k0;
   const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
   const int tiles = m_tiles * n_tiles;
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_k_kernel(const AT* __res
   const int kend = min(k0 + kchunk, group_ptr[g + 1]);
   const int tile = xs.inner;
   float* Cg = C + (int64_t)g * strideC;
+  if (det) { Cg = det + (int64_t)xs.outer * M * N; ldc = N; }     // deterministic mode: chunk xs.outer's own slab
   // op(A) = A^T: stored [K(rows), M] ; op(B) = B stored [K(rows), N]
   gemm_tile_any<PREC, BM, BN, true, false, AT, BT>(A, lda, B, ldb, Cg, ldc, M, N, kend, (tile / n_tiles) * BM,
                                            (tile % n_tiles) * BN, k0, kend, ep, vec_ok(A, lda), vec_ok(B, ldb));
@@ -284,10 +286,12 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
     if (e != hipSuccess) { set_error("bkg_gemm_f32: memset", e); return (int)e; }
     ep.atomic = 1;
+    float* det = nullptr;
+    BKG_DET_SLABS(det, ep, nsplit, M, N, "bkg_gemm_f32");
     dim3 grid(xcd_grid(nsplit, tiles)), block(256);
 #define BKG_SPLITK(BMN, TA_, TB_)                                                                                      \
-  if (precision) hipLaunchKernelGGL((gemm_f32_splitk_kernel<1, BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep); \
-  else hipLaunchKernelGGL((gemm_f32_splitk_kernel<0, BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep)
+  if (precision) hipLaunchKernelGGL((gemm_f32_splitk_kernel<1, BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep, det); \
+  else hipLaunchKernelGGL((gemm_f32_splitk_kernel<0, BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep, det)
 #define BKG_SPLITK_T(BMN)                                 \
   if (!trans_a && !trans_b) { BKG_SPLITK(BMN, false, false); } \
   else if (!trans_a && trans_b) { BKG_SPLITK(BMN, false, true); } \
@@ -296,6 +300,7 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     if (big) { BKG_SPLITK_T(128) } else { BKG_SPLITK_T(64) }
 #undef BKG_SPLITK_T
 #undef BKG_SPLITK
+    if (det) splitk_reduce(det, C, ldc, 0, (int)M, (int)N, nullptr, 1, kchunk, (int)nsplit, s);
     return check_launch("bkg_gemm_f32(split-K)");
   }
   // big tiles once they fill the chip, small tiles otherwise
@@ -338,19 +343,22 @@ extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, 
   hipStream_t s = (hipStream_t)stream;
   constexpr int BM = 128, BN = 128;
   const int KCHUNK = precision ? 1024 : 512;   // rows per block (bf16 operands: fewer, longer blocks; measured)
+  float* det = nullptr;
+  BKG_DET_SLABS(det, ep, ceil_div(rows_total, KCHUNK) + G, M, N, "bkg_gemm_grouped_k_f32");
   dim3 grid(xcd_grid(ceil_div(rows_total, KCHUNK) + G, ceil_div(M, BM) * ceil_div(N, BN))), block(256);
-  if (precision) hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
-  else hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<0, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep);
+  if (precision) hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep, det);
+  else hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<0, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep, det);
+  if (det) splitk_reduce(det, C, ldc, strideC, (int)M, (int)N, group_ptr, G, KCHUNK, 0, s);
   return check_launch("bkg_gemm_grouped_k_f32");
 }
 
 namespace bkg {   // gemm_tn16.hip: both operands bf16, tile-aligned output
 bool gemm_tn16_ok(int64_t M, int64_t N, const void* A, int64_t lda, const void* B, int64_t ldb);
-void launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
-                             float* C, int64_t ldc, hipStream_t s);
-void launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const void* A, int64_t lda, const void* B,
-                              int64_t ldb, const int32_t* b_rows, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
-                              hipStream_t s);
+int launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                            float* C, int64_t ldc, hipStream_t s);
+int launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const void* A, int64_t lda, const void* B,
+                             int64_t ldb, const int32_t* b_rows, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
+                             hipStream_t s);
 }  // namespace bkg
 
 // ---- bf16-mode weight gradients with fp32 OR bf16 operands:  C[M,N] = A[K,M]^T B[K,N]  (split-K, f32 atomics)
@@ -366,7 +374,7 @@ extern "C" int bkg_gemm_tn_bf16(int64_t M, int64_t N, int64_t K, const void* A, 
   if (e != hipSuccess) { set_error("bkg_gemm_tn_bf16: memset", e); return (int)e; }
   if (K == 0) return 0;
   if (a_is_bf16 && b_is_bf16 && gemm_tn16_ok(M, N, A, lda, B, ldb)) {
-    launch_gemm_tn16_splitk(M, N, K, A, lda, B, ldb, C, ldc, s);
+    if (int rc = launch_gemm_tn16_splitk(M, N, K, A, lda, B, ldb, C, ldc, s)) return rc;
     return check_launch("bkg_gemm_tn_bf16(tn16)");
   }
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
@@ -374,12 +382,15 @@ extern "C" int bkg_gemm_tn_bf16(int64_t M, int64_t N, int64_t K, const void* A, 
   int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 768 / tiles));
   const int kchunk = (int)(((K + nsplit - 1) / nsplit + 63) / 64 * 64);
   nsplit = (K + kchunk - 1) / kchunk;
+  float* det = nullptr;
+  BKG_DET_SLABS(det, ep, nsplit, M, N, "bkg_gemm_tn_bf16");
   dim3 grid(xcd_grid(nsplit, tiles)), block(256);
 #define BKG_TN(AT_, BT_)                                                                                             \
   hipLaunchKernelGGL((gemm_f32_splitk_kernel<1, 128, 128, true, false, AT_, BT_>), grid, block, 0, s, (const AT_*)A, lda, \
-                     (const BT_*)B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep)
+                     (const BT_*)B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep, det)
   BKG_MIXED_DISPATCH(BKG_TN)
 #undef BKG_TN
+  if (det) splitk_reduce(det, C, ldc, 0, (int)M, (int)N, nullptr, 1, kchunk, (int)nsplit, s);
   return check_launch("bkg_gemm_tn_bf16");
 }
 
@@ -392,16 +403,19 @@ extern "C" int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N,
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   hipStream_t s = (hipStream_t)stream;
   if (a_is_bf16 && b_is_bf16 && gemm_tn16_ok(M, N, A, lda, B, ldb)) {
-    launch_gemm_tn16_grouped(rows_total, M, N, A, lda, B, ldb, b_rows, C, ldc, strideC, group_ptr, G, s);
+    if (int rc = launch_gemm_tn16_grouped(rows_total, M, N, A, lda, B, ldb, b_rows, C, ldc, strideC, group_ptr, G, s)) return rc;
     return check_launch("bkg_gemm_grouped_k_bf16(tn16)");
   }
   BKG_ARG(b_rows == nullptr, "bkg_gemm_grouped_k_bf16: indexed B rows need two bf16 operands and 128-aligned M, N");
   constexpr int BM = 128, BN = 128, KCHUNK = 1024;
+  float* det = nullptr;
+  BKG_DET_SLABS(det, ep, ceil_div(rows_total, KCHUNK) + G, M, N, "bkg_gemm_grouped_k_bf16");
   dim3 grid(xcd_grid(ceil_div(rows_total, KCHUNK) + G, ceil_div(M, BM) * ceil_div(N, BN))), block(256);
 #define BKG_GK(AT_, BT_)                                                                                            \
   hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN, AT_, BT_>), grid, block, 0, s, (const AT_*)A, lda,      \
-                     (const BT_*)B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep)
+                     (const BT_*)B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep, det)
   BKG_MIXED_DISPATCH(BKG_GK)
 #undef BKG_GK
+  if (det) splitk_reduce(det, C, ldc, strideC, (int)M, (int)N, group_ptr, G, KCHUNK, 0, s);
   return check_launch("bkg_gemm_grouped_k_bf16");
 }

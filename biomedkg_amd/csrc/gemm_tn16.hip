@@ -41,6 +41,7 @@ __device__ __forceinline__ void gemm_tn16_tile(const __bf16* __restrict__ A, int
                                                int n0, int kbeg, int kend, const GemmEpilogue& ep) {
   __shared__ __attribute__((aligned(16))) unsigned char As[T16_BK * 256];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[T16_BK * 256];
+  __shared__ __attribute__((aligned(16))) float patch[4][16 * (64 + 4)];   // epilogue transpose of the plain-store form
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
   const int grp = lane >> 4, lh = grp >> 1, half = grp & 1;
@@ -114,17 +115,19 @@ __device__ __forceinline__ void gemm_tn16_tile(const __bf16* __restrict__ A, int
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
-  store_acc_tile<2, 2>(acc, C, ldc, M, N, m0 + wm0, n0 + wn0, ep, nullptr);   // ep.atomic: direct atomic adds
+  // ep.atomic: direct atomic adds; deterministic mode: plain stores into this chunk's slab
+  store_acc_tile<2, 2>(acc, C, ldc, M, N, m0 + wm0, n0 + wn0, ep, patch[wave]);
 }
 
 __global__ __launch_bounds__(256) void gemm_tn16_splitk_kernel(const __bf16* __restrict__ A, int64_t lda,
                                                                const __bf16* __restrict__ B, int64_t ldb,
                                                                float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                               int kchunk, GemmEpilogue ep) {
+                                                               int kchunk, GemmEpilogue ep, float* __restrict__ det) {
   const int n_tiles = N / T16_BT, tiles = n_tiles * (M / T16_BT);
   const XcdSlot t = xcd_slot(blockIdx.x, tiles);
   const int kbeg = t.outer * kchunk, kend = min(kbeg + kchunk, K);
   if (kbeg >= kend) return;
+  if (det) { C = det + (int64_t)t.outer * M * N; ldc = N; }
   gemm_tn16_tile(A, lda, B, ldb, nullptr, C, ldc, M, N, (t.inner / n_tiles) * T16_BT, (t.inner % n_tiles) * T16_BT, kbeg, kend, ep);
 }
 
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_tn16_grouped_kernel(const __bf16* __
                                                                 const int32_t* __restrict__ b_rows,
                                                                 float* __restrict__ C, int64_t ldc, int64_t strideC,
                                                                 const int32_t* __restrict__ group_ptr, int G, int M,
-                                                                int N, int kchunk, GemmEpilogue ep) {
+                                                                int N, int kchunk, GemmEpilogue ep, float* __restrict__ det) {
   __shared__ int s_g, s_k0;
   const int n_tiles = N / T16_BT, tiles = n_tiles * (M / T16_BT);
   const XcdSlot xs = xcd_slot(blockIdx.x, tiles);
@@ -151,7 +154,9 @@ __global__ __launch_bounds__(256) void gemm_tn16_grouped_kernel(const __bf16* __
   const int g = s_g;
   if (g < 0) return;
   const int k0 = s_k0, kend = min(k0 + kchunk, group_ptr[g + 1]);
-  gemm_tn16_tile(A, lda, B, ldb, b_rows, C + (int64_t)g * strideC, ldc, M, N, (xs.inner / n_tiles) * T16_BT,
+  float* Cg = C + (int64_t)g * strideC;
+  if (det) { Cg = det + (int64_t)xs.outer * M * N; ldc = N; }
+  gemm_tn16_tile(A, lda, B, ldb, b_rows, Cg, ldc, M, N, (xs.inner / n_tiles) * T16_BT,
                  (xs.inner % n_tiles) * T16_BT, k0, kend, ep);
 }
 
@@ -160,26 +165,34 @@ bool gemm_tn16_ok(int64_t M, int64_t N, const void* A, int64_t lda, const void* 
          (uintptr_t)B % 16 == 0;
 }
 
-void launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
-                             float* C, int64_t ldc, hipStream_t s) {
+int launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                            float* C, int64_t ldc, hipStream_t s) {
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   const int64_t tiles = (M / T16_BT) * (N / T16_BT);
   int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, T16_BLOCKS / tiles));
   const int kchunk = (int)(((K + nsplit - 1) / nsplit + T16_BK - 1) / T16_BK * T16_BK);
   nsplit = (K + kchunk - 1) / kchunk;
+  float* det = nullptr;
+  BKG_DET_SLABS(det, ep, nsplit, M, N, "bkg_gemm_tn_bf16");
   hipLaunchKernelGGL(gemm_tn16_splitk_kernel, dim3(xcd_grid(nsplit, tiles)), dim3(256), 0, s, (const __bf16*)A, lda,
-                     (const __bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep);
+                     (const __bf16*)B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep, det);
+  if (det) splitk_reduce(det, C, ldc, 0, (int)M, (int)N, nullptr, 1, kchunk, (int)nsplit, s);
+  return 0;
 }
 
-void launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const void* A, int64_t lda, const void* B,
-                              int64_t ldb, const int32_t* b_rows, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
-                              hipStream_t s) {
+int launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const void* A, int64_t lda, const void* B,
+                             int64_t ldb, const int32_t* b_rows, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G,
+                             hipStream_t s) {
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   const int64_t tiles = (M / T16_BT) * (N / T16_BT);
   constexpr int KCHUNK = 1024;   // (a chunk sized for 768 blocks is slower here: the relations' row counts are skewed)
+  float* det = nullptr;
+  BKG_DET_SLABS(det, ep, ceil_div(rows_total, KCHUNK) + G, M, N, "bkg_gemm_grouped_k_bf16");
   hipLaunchKernelGGL(gemm_tn16_grouped_kernel, dim3(xcd_grid(ceil_div(rows_total, KCHUNK) + G, tiles)), dim3(256), 0, s,
                      (const __bf16*)A, lda, (const __bf16*)B, ldb, b_rows, C, ldc, strideC, group_ptr, G, (int)M, (int)N,
-                     KCHUNK, ep);
+                     KCHUNK, ep, det);
+  if (det) splitk_reduce(det, C, ldc, strideC, (int)M, (int)N, group_ptr, G, KCHUNK, 0, s);
+  return 0;
 }
 
 }  // namespace bkg

@@ -29,6 +29,36 @@ def get_matmul_precision() -> str:
     return "bf16" if _PRECISION else "fp32"
 
 
+_DET_WS = None
+
+
+def set_deterministic(on: bool, workspace_floats: int = 1 << 26):
+    """Lightning's ``Trainer(deterministic=True)`` (reference train_gcl.py:66, train_kge.py:46) for the HIP path: the
+    split-K weight-gradient products add their K chunks through per-chunk slabs + a fixed-order reduce instead of float
+    atomics (``bkg_set_deterministic_workspace``); every other kernel on the path is order-fixed already (segment reduces,
+    NT-Xent, column sums, the negative sampler).  Costs one extra pass over the slabs per product."""
+    global _DET_WS
+    if on:
+        if not torch.cuda.is_available():
+            raise L.HipLibraryError("deterministic mode needs the GPU workspace")
+        if _DET_WS is None or _DET_WS.numel() < workspace_floats:
+            _DET_WS = torch.empty(workspace_floats, dtype=torch.float32, device="cuda")
+        L.call("bkg_set_deterministic_workspace", L.ptr(_DET_WS), _DET_WS.numel())
+    else:
+        L.call("bkg_set_deterministic_workspace", None, 0)
+        _DET_WS = None
+
+
+def is_deterministic() -> bool:
+    return _DET_WS is not None
+
+
+def _follow_torch_determinism():
+    """Real Lightning's ``Trainer(deterministic=True)`` flips ``torch.use_deterministic_algorithms``: follow it."""
+    if _DET_WS is None and torch.are_deterministic_algorithms_enabled():
+        set_deterministic(True)
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
         raise TypeError(f"expected float32, got {t.dtype}")
@@ -92,6 +122,8 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias
     bf16 operands / fp32 accumulate; tall ``a`` (fp32 or bf16) times a small weight ``b`` streams through
     ``bkg_gemm_xw`` and may write a bf16 ``out`` (``out_dtype``)."""
     L.require_cuda(a, b, out, bias, gate)
+    if trans_a:
+        _follow_torch_determinism()
     if b.dtype != torch.bfloat16:
         b = _f32c(b)
     m, k = (a.size(1), a.size(0)) if trans_a else (a.size(0), a.size(1))
@@ -158,6 +190,7 @@ def gemm_grouped_k(a, b, group_ptr, num_groups, b_rows=None):
     """``out[g] = a[rows of g]^T @ b[rows of g]`` -> ``[G, a.cols, b.cols]`` (split-K, f32 atomics).
     ``b_rows`` (int32; see :func:`gathered_k_ok`): row ``k`` of the second operand is ``b[b_rows[k]]``."""
     L.require_cuda(a, b, group_ptr, b_rows)
+    _follow_torch_determinism()
     m, n = a.size(1), b.size(1)
     out = torch.zeros(num_groups, m, n, dtype=torch.float32, device=a.device)
     if b_rows is not None and not gathered_k_ok(a, b):

@@ -93,6 +93,9 @@ class Trainer:
             for cb, d in zip(self.callbacks, dirs[1:]):
                 if d is not None:
                     cb.dirpath = d
+        if deterministic and torch.cuda.is_available():
+            from . import ops
+            ops.set_deterministic(True)          # fixed-order weight-gradient sums (Lightning: deterministic=True)
         self.current_epoch = self.global_step = 0
         self.should_stop = False
         self.estimated_stepping_batches = 0

@@ -18,6 +18,14 @@ extern "C" {
 int bkg_abi_version(void);
 const char* bkg_last_error(void); /* (host) thread-local text of the last failure */
 
+/* Deterministic mode (Lightning's Trainer(deterministic=True): reference train_gcl.py:66, train_kge.py:46).  With a
+ * workspace set, the split-K weight-gradient products (bkg_gemm_f32 deep-K form, bkg_gemm_grouped_k_f32, bkg_gemm_tn_bf16,
+ * bkg_gemm_grouped_k_bf16) stop adding their K chunks with float atomics: every chunk writes its [M, N] tile set into a
+ * slab of the workspace and a second launch sums the slabs in chunk order -- bitwise repeatable.  The workspace (device,
+ * caller-owned, >= chunks * M * N floats for the largest product: 64 Mi floats cover the bench step) is used by launches
+ * on ONE stream at a time; NULL switches back to atomics.  Everything else on the path is already order-fixed. */
+int bkg_set_deterministic_workspace(float* workspace, int64_t floats);
+
 /* ---- graph preparation (replaces PyG's COO bookkeeping inside GCNConv / RGCNConv /
  *      negative_sampling: biomedkg/model/encoder.py:52,57,155,160; biomedkg/kge_module.py:93) */
 int64_t bkg_sort_workspace_bytes(int64_t n);

@@ -242,3 +242,46 @@ def test_training_step_full_size_repeatable(kg):
         assert torch.isfinite(loss)
         losses.append(float(loss))
     assert losses[0] == losses[1]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_deterministic_mode_every_gradient_repeats_bitwise(kg, precision):
+    """reference train_gcl.py:66 / train_kge.py:46 pass deterministic=True: with ops.set_deterministic(True) the split-K
+    weight-gradient products sum their K chunks in a fixed order, and a full-size GGD + KGE step repeats bit for bit in
+    its losses AND in every parameter gradient (without it the float atomics reorder the sums); the deterministic
+    results equal the atomic ones up to that reordering."""
+    from types import SimpleNamespace
+    from biomedkg_amd import ops, rand as R_
+    from biomedkg_amd.gcl_module import GGDModule
+    from biomedkg_amd.kge_module import KGEModule
+    ei, et = kg
+    bk = SimpleNamespace(x=_x(21), edge_index=ei, edge_type=et)
+    bg = SimpleNamespace(x=_x(22, d=768), edge_index=ei)
+
+    def run():
+        torch.manual_seed(3)
+        kge = KGEModule("rgcn", "dismult", D, D, D, 2, R, 2, "cosine", 1e-3, 0.2, "none", 1, "random").to(DEV).train()
+        gcl = GGDModule(in_dim=768, hidden_dim=D, out_dim=D, num_hidden_layers=2, fuse_method="none").to(DEV).train()
+        out = []
+        for mod, batch in ((gcl, bg), (kge, bk)):
+            with R_.use(R_.DeviceRand(seed=9)):
+                loss = mod.training_step(batch)
+            loss.backward()
+            out.append((loss.detach().clone(), [p.grad.clone() for p in mod.model.parameters()]))
+        return out
+
+    ops.set_matmul_precision(precision)
+    try:
+        ops.set_deterministic(True)
+        a, b = run(), run()
+        ops.set_deterministic(False)
+        c = run()
+    finally:
+        ops.set_deterministic(False)
+        ops.set_matmul_precision("fp32")
+    for (la, ga), (lb, gb), (lc, gc) in zip(a, b, c):
+        assert torch.equal(la, lb)
+        assert all(torch.equal(x, y) for x, y in zip(ga, gb))
+        assert torch.equal(la, lc)                                   # the forward never had atomics
+        for x, y in zip(ga, gc):
+            assert float((x - y).norm() / y.norm().clamp_min(1e-20)) < 1e-5

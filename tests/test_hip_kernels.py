@@ -167,3 +167,40 @@ def test_colsum(n, d, dtype):
     assert torch.equal(got, ops.colsum(x))                     # fixed summation order
     v = torch.randn(n, 2 * d, device=DEV).to(dtype)[:, :d]     # strided rows
     torch.testing.assert_close(ops.colsum(v).double(), v.double().sum(0), rtol=1e-5, atol=1e-5 * n ** 0.5)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_deterministic_split_k_products_match_the_atomic_ones(precision):
+    """Per-chunk slabs + fixed-order reduce (bkg_set_deterministic_workspace) against the float-atomic split-K form:
+    plain and per-relation grouped weight gradients, tile-aligned and ragged shapes, fp32 and bf16 operands."""
+    from biomedkg_amd import ops
+    torch.manual_seed(0)
+    ops.set_matmul_precision(precision)
+    try:
+        cases = [(9000, 64, 48), (20000, 256, 256), (5000, 130, 70)]
+        for k, m, n in cases:
+            a, b = torch.randn(k, m, device=DEV), torch.randn(k, n, device=DEV)
+            if precision == "bf16":
+                a, b = ops.to_bf16(a) if (k * m) % 8 == 0 else a, ops.to_bf16(b) if (k * n) % 8 == 0 else b
+            ref = ops.gemm(a, b, trans_a=True)
+            ops.set_deterministic(True)
+            d1, d2 = ops.gemm(a, b, trans_a=True), ops.gemm(a, b, trans_a=True)
+            ops.set_deterministic(False)
+            assert torch.equal(d1, d2)
+            torch.testing.assert_close(d1, ref, rtol=1e-4, atol=1e-3)
+        # grouped: 5 groups of very different sizes (one empty)
+        sizes = [4000, 0, 1500, 9000, 33]
+        ptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=DEV)
+        for m, n in ((128, 128), (96, 40)):
+            h, dy = torch.randn(sum(sizes), m, device=DEV), torch.randn(sum(sizes), n, device=DEV)
+            if precision == "bf16" and m % 8 == 0 and n % 8 == 0:
+                h, dy = ops.to_bf16(h), ops.to_bf16(dy)
+            ref = ops.gemm_grouped_k(h, dy, ptr, len(sizes))
+            ops.set_deterministic(True)
+            d1, d2 = ops.gemm_grouped_k(h, dy, ptr, len(sizes)), ops.gemm_grouped_k(h, dy, ptr, len(sizes))
+            ops.set_deterministic(False)
+            assert torch.equal(d1, d2) and float(d1[1].abs().max()) == 0.0
+            torch.testing.assert_close(d1, ref, rtol=1e-4, atol=1e-3)
+    finally:
+        ops.set_deterministic(False)
+        ops.set_matmul_precision("fp32")
