@@ -478,6 +478,18 @@ def main():
     total_edges = e if strong or world == 1 else world * e
     roof, others = rooflines(timers, args.precision)
 
+    ms_det = None
+    if world == 1 and not args.no_extras:
+        ops.set_deterministic(True)                     # Trainer(deterministic=True): fixed-order weight-gradient sums
+        for _ in range(2):
+            step_g(); step_k()
+        sync(); t1 = time.perf_counter()
+        for _ in range(5):
+            step_g(); step_k()
+        sync()
+        ms_det = (time.perf_counter() - t1) / 5 * 1e3
+        ops.set_deterministic(False)
+
     ms_fp32 = None
     if world == 1 and not args.no_extras and args.precision == "bf16":
         ops.set_matmul_precision("fp32")                # the exact parity mode on the same modules / graph
@@ -517,7 +529,7 @@ def main():
                                             "built once (the reference's per-batch loaders rebuild PyG's COO bookkeeping)"},
             "triplets_per_sec_kge_step": (total_edges + (n_neg if strong or world == 1 else world * n_neg)) / (ms_k * 1e-3),
             "edges_per_sec_gcl_step": total_edges / (ms_g * 1e-3),
-            "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32,
+            "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
             "roofline": roof, "kernels": others,
             "cpu_baseline": None,
         }

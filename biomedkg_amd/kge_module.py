@@ -93,11 +93,10 @@ class KGEModule(LightningModule):
         z = self.model.encode(x, batch.edge_index, batch.edge_type)
         neg_edge_index, neg_edge_type = self.sample_neg_edges(batch.edge_index, batch.edge_type)
         dec = self.model.decoder
-        ce, pos_pred, neg_pred = ops.kge_bce_loss(z, dec.rel_emb, batch.edge_index, batch.edge_type, neg_edge_index,
-                                                  neg_edge_type, dec.kind)
+        loss, pos_pred, neg_pred = ops.kge_bce_loss(z, dec.rel_emb, batch.edge_index, batch.edge_type, neg_edge_index,
+                                                    neg_edge_type, dec.kind, reg=1e-2)     # BCE + 1e-2 (mean z^2 + mean rel^2)
         self._last_scores = (z, pos_pred, neg_pred)
-        reg_loss = z.pow(2).mean() + dec.rel_emb.pow(2).mean()
-        return ce + 1e-2 * reg_loss
+        return loss
 
     def training_step(self, batch, batch_idx=None):
         if getattr(self.model.decoder, "kind", None) is not None:

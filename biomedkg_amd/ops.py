@@ -53,6 +53,13 @@ def is_deterministic() -> bool:
     return _DET_WS is not None
 
 
+def _det_reserve(floats):
+    """Deterministic mode: make sure the slab workspace holds ``floats`` (one [M, N] slab per K chunk of the product
+    about to be launched); grows it when a wider / longer product comes along."""
+    if _DET_WS is not None and _DET_WS.numel() < floats:
+        set_deterministic(True, int(floats))
+
+
 def _follow_torch_determinism():
     """Real Lightning's ``Trainer(deterministic=True)`` flips ``torch.use_deterministic_algorithms``: follow it."""
     if _DET_WS is None and torch.are_deterministic_algorithms_enabled():
@@ -124,6 +131,7 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias
     L.require_cuda(a, b, out, bias, gate)
     if trans_a:
         _follow_torch_determinism()
+        _det_reserve(2048 * 128 * 128)      # split-K: at most 2048 / tiles chunks of tiles * 128 * 128 floats
     if b.dtype != torch.bfloat16:
         b = _f32c(b)
     m, k = (a.size(1), a.size(0)) if trans_a else (a.size(0), a.size(1))
@@ -192,6 +200,7 @@ def gemm_grouped_k(a, b, group_ptr, num_groups, b_rows=None):
     L.require_cuda(a, b, group_ptr, b_rows)
     _follow_torch_determinism()
     m, n = a.size(1), b.size(1)
+    _det_reserve((a.size(0) // 512 + num_groups + 1) * m * n)       # chunks of >= 512 rows, one partial chunk per group
     out = torch.zeros(num_groups, m, n, dtype=torch.float32, device=a.device)
     if b_rows is not None and not gathered_k_ok(a, b):
         raise ValueError("gathered rows need two bf16 tables with 128-aligned widths (bf16 mode)")
@@ -897,7 +906,7 @@ class _KgeBceLoss(torch.autograd.Function):
     segment reduce for dz.  Returns ``(loss, pos_pred, neg_pred)``; the preds are detached outputs."""
 
     @staticmethod
-    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total):
+    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total, reg):
         d, r = z.size(1), rel_emb.size(0)
         t_pos, t_neg = pos_ei.size(1), neg_ei.size(1)
         if total is None:
@@ -934,15 +943,19 @@ class _KgeBceLoss(torch.autograd.Function):
                 drel = drel + spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
             scores.append(s)
             grads.append(g)
-        ctx.kind, ctx.comm = kind, comm
+        ctx.kind, ctx.comm, ctx.reg = kind, comm, float(reg)
         ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
-        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1])
+        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1], z if reg else None)
         ctx.mark_non_differentiable(scores[0], scores[1])
-        return (loss / total).float(), scores[0], scores[1]
+        loss = loss / total
+        if reg:      # + reg * (mean(z^2) + mean(rel_emb^2)), reference kge_module.py:128-129: two one-launch norms
+            loss = loss + reg * (torch.linalg.vector_norm(z).double().pow(2) / z.numel()
+                                 + torch.linalg.vector_norm(rel_emb).double().pow(2) / rel_emb.numel())
+        return loss.float(), scores[0], scores[1]
 
     @staticmethod
     def backward(ctx, gloss, _gp, _gn):
-        zt, rel_emb, g_pos, g_neg, drel, rec_pos, rec_neg = ctx.saved_tensors
+        zt, rel_emb, g_pos, g_neg, drel, rec_pos, rec_neg, z_reg = ctx.saved_tensors
         pos_ei, pos_et, neg_ei, neg_et = ctx.graphs
         kind = ctx.kind
         n, d = zt.size(0), zt.size(1)
@@ -976,15 +989,26 @@ class _KgeBceLoss(torch.autograd.Function):
             if ctx.comm is not None:
                 dz = ctx.comm.reduce_scatter(dz)          # the owners' sums of every rank's triplet share
             dz = dz * gloss
-        return dz, (drel * gloss if ctx.needs_input_grad[1] else None), None, None, None, None, None, None, None
+            if ctx.reg:
+                dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / z_reg.numel()))
+        drel_out = None
+        if ctx.needs_input_grad[1]:
+            drel_out = drel * gloss
+            if ctx.reg:
+                drel_out = torch.addcmul(drel_out, rel_emb, gloss * (2.0 * ctx.reg / rel_emb.numel()))
+        return dz, drel_out, None, None, None, None, None, None, None, None
 
 
-def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind, comm=None, total=None):
+def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind, comm=None, total=None,
+                 reg=0.0):
     """``comm`` (node-partitioned training, biomedkg_amd/partition.py): ``z`` is the rank's shard, the triplet ids are
-    slots of the all-gathered table; ``total``: the count the BCE sum is divided by (default: this call's triplets)."""
+    slots of the all-gathered table; ``total``: the count the BCE sum is divided by (default: this call's triplets);
+    ``reg``: adds ``reg * (mean(z^2) + mean(rel_emb^2))`` (the reference's L2 term) inside the same op."""
     L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type)
+    if reg and comm is not None:
+        raise ValueError("the L2 term of a partitioned step is scaled by the caller (partition.kge_loss_partitioned)")
     return _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
-                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, comm, total)
+                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, comm, total, float(reg))
 
 
 # ----------------------------------------------------------------------------- NT-Xent

@@ -31,3 +31,15 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _reset_process_wide_modes():
+    """ops.set_matmul_precision / ops.set_deterministic are process-wide switches (a Trainer(deterministic=True) turns
+    the latter on): every test starts and ends in the defaults."""
+    yield
+    if torch.cuda.is_available():
+        from biomedkg_amd import ops
+        ops.set_matmul_precision("fp32")
+        if ops.is_deterministic():
+            ops.set_deterministic(False)

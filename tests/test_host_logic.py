@@ -76,3 +76,33 @@ def test_metrics_small_known_answers():
         m = cls(task="binary")
         m.update(p[:3], t[:3]); m.update(p[3:], t[3:])
         assert abs(float(m.compute()) - exp) < 1e-6, cls.__name__
+
+
+def test_link_split_message_passing_graphs():
+    """reference data_module.py:65-69: RandomLinkSplit(num_val, num_test, neg_sampling_ratio=0) -- the modules only read
+    ``edge_index`` / ``edge_type`` of each split, i.e. the MESSAGE-PASSING graphs: train = the train edges,
+    val = the train edges again, test = train + val edges; relation ids travel with their edges; the three edge sets
+    (train, val, test supervision) partition the input."""
+    from biomedkg_amd.data_module import SyntheticKGModule
+    dm = SyntheticKGModule(embed_dim=16, node_type=["gene", "drug"], val_ratio=0.2, test_ratio=0.1, num_nodes=300,
+                           num_edges=4000, num_relations=5, seed=3)
+    dm.setup("split")
+    from biomedkg_amd import synthetic
+    g = synthetic.primekg_like(300, 4000, 5, seed=3)
+    ei, et = g["edge_index"], g["edge_type"]
+    e = ei.size(1)
+    n_val, n_test = int(0.2 * e), int(0.1 * e)
+    tr, te = dm.train_data, dm.test_data
+    assert tr.edge_index.size(1) == e - n_val - n_test and te.edge_index.size(1) == e - n_test
+    assert dm.val_data is dm.train_data                                  # val message passing = the train graph
+    key = lambda a, t: set(zip(a[0].tolist(), a[1].tolist(), t.tolist(), range(a.size(1))))  # multiset via position
+    full = sorted(zip(ei[0].tolist(), ei[1].tolist(), et.tolist()))
+    tr_k = sorted(zip(tr.edge_index[0].tolist(), tr.edge_index[1].tolist(), tr.edge_type.tolist()))
+    te_k = sorted(zip(te.edge_index[0].tolist(), te.edge_index[1].tolist(), te.edge_type.tolist()))
+    from collections import Counter
+    cf, ct, cte = Counter(full), Counter(tr_k), Counter(te_k)
+    assert not (ct - cf) and not (cte - cf)                              # every split edge is an input edge, with its relation
+    assert not (ct - cte)                                                # test message passing contains the train graph
+    assert sum((cf - cte).values()) == n_test                            # what is left out of it is the test supervision set
+    assert torch.equal(te.edge_index[:, : tr.edge_index.size(1)], tr.edge_index)   # train edges first, then val
+    assert dm.data.num_edge_types == 5 and len(dm.edge_map_index) == 5
