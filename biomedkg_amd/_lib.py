@@ -28,6 +28,7 @@ SIGNATURES = {
     "bkg_abi_version": (c_int32, []),
     "bkg_last_error": (ctypes.c_char_p, []),
     "bkg_set_deterministic_workspace": (I32, [P, I64]),
+    "bkg_set_rng_epoch": (I32, [P]),
     # graph.hip
     "bkg_sort_workspace_bytes": (I64, [I64]),
     "bkg_sort_edges": (I32, [P, P, I64, I64, I64, P, P, P, P, P, I64, P]),

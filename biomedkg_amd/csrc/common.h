@@ -94,6 +94,14 @@ __device__ __forceinline__ uint4 philox_keep4(uint64_t seed, uint64_t e, uint32_
   return philox4x32((uint32_t)q, (uint32_t)(q >> 32), stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// Replay epoch of captured (hipGraph) training steps (bkg_set_rng_epoch): a device counter the captured step bumps
+// once per replay; every in-kernel Philox stream adds it (x 65536) to its stream id, so each replay of the same
+// captured launch draws a fresh mask although its kernel arguments are frozen.  NULL outside graph mode.
+const uint32_t* rng_epoch_ptr();
+__device__ __forceinline__ uint32_t with_epoch(uint32_t stream_id, const uint32_t* __restrict__ epoch) {
+  return epoch ? stream_id + (epoch[0] << 16) : stream_id;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

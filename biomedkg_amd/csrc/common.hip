@@ -14,6 +14,8 @@ void set_error_msg(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what
 
 static DetWorkspace g_det = {nullptr, 0};
 DetWorkspace det_workspace() { return g_det; }
+static const uint32_t* g_rng_epoch = nullptr;
+const uint32_t* rng_epoch_ptr() { return g_rng_epoch; }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc,
                                                             int64_t strideC, int M, int N, const int32_t* __restrict__ group_ptr,
@@ -40,6 +42,11 @@ void splitk_reduce(const float* ws, float* C, int64_t ldc, int64_t strideC, int 
                      group_ptr, G, kchunk, n_chunks);
 }
 }  // namespace bkg
+
+extern "C" int bkg_set_rng_epoch(const uint32_t* epoch) {
+  bkg::g_rng_epoch = epoch;
+  return 0;
+}
 
 extern "C" int bkg_set_deterministic_workspace(float* workspace, int64_t floats) {
   bkg::g_det = {workspace, workspace ? floats : 0};

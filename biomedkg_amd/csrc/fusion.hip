@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void redaf_combine_kernel(const float* __restr
                                                             const float* __restrict__ scale,  // [M, D]
                                                             const uint8_t* __restrict__ keep, float drop_p,
                                                             uint64_t seed, uint32_t stream_id, float* __restrict__ out,
-                                                            int64_t ldo) {
+                                                            int64_t ldo, const uint32_t* __restrict__ epoch) {
+  stream_id = with_epoch(stream_id, epoch);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of one node
   const int chunks = D / 4;
   if (i >= (int64_t)n * chunks) return;
@@ -137,10 +138,10 @@ extern "C" int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int3
   dim3 grid(ceil_div(n * (D / 4), 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
   switch (M) {
-    case 1: hipLaunchKernelGGL(redaf_combine_kernel<1>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo); break;
-    case 2: hipLaunchKernelGGL(redaf_combine_kernel<2>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo); break;
-    case 3: hipLaunchKernelGGL(redaf_combine_kernel<3>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo); break;
-    default: hipLaunchKernelGGL(redaf_combine_kernel<4>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo); break;
+    case 1: hipLaunchKernelGGL(redaf_combine_kernel<1>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo, rng_epoch_ptr()); break;
+    case 2: hipLaunchKernelGGL(redaf_combine_kernel<2>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo, rng_epoch_ptr()); break;
+    case 3: hipLaunchKernelGGL(redaf_combine_kernel<3>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo, rng_epoch_ptr()); break;
+    default: hipLaunchKernelGGL(redaf_combine_kernel<4>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo, rng_epoch_ptr()); break;
   }
   return check_launch("bkg_redaf_combine_f32");
 }

@@ -36,6 +36,7 @@ struct SpmmEpilogue {
   uint64_t seed;
   uint32_t stream_id;
   int out_bf16;             // 1: `out` is a bf16 [n_rows, ldo] table (a result only GEMMs / gathers read)
+  const uint32_t* epoch;    // replay epoch of a captured step (common.h with_epoch) or null
 };
 
 // One predicated batch of UT entries per lane group starting at e (entries >= end get weight 0 and a clamped,
@@ -161,7 +162,7 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
         a.x = k.x ? a.x * scale : 0.f; a.y = k.y ? a.y * scale : 0.f;
         a.z = k.z ? a.z * scale : 0.f; a.w = k.w ? a.w * scale : 0.f;
       } else if (ep.drop_p > 0.f) {
-        const uint4 r = philox_keep4(ep.seed, (uint64_t)row * d + c, ep.stream_id);
+        const uint4 r = philox_keep4(ep.seed, (uint64_t)row * d + c, with_epoch(ep.stream_id, ep.epoch));
         a.x = r.x >= thresh ? a.x * scale : 0.f; a.y = r.y >= thresh ? a.y * scale : 0.f;
         a.z = r.z >= thresh ? a.z * scale : 0.f; a.w = r.w >= thresh ? a.w * scale : 0.f;
       }
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void spmm_csr_f32_generic_kernel(const int32_t
       a = ep.keep[(int64_t)row * d + c] ? a * scale : 0.f;
     } else if (ep.drop_p > 0.f) {
       const uint64_t eid = (uint64_t)row * d + c;
-      const uint4 r = philox_keep4(ep.seed, eid, ep.stream_id);
+      const uint4 r = philox_keep4(ep.seed, eid, with_epoch(ep.stream_id, ep.epoch));
       const uint32_t rv = (eid & 3) == 0 ? r.x : (eid & 3) == 1 ? r.y : (eid & 3) == 2 ? r.z : r.w;
       a = rv >= thresh ? a * scale : 0.f;
     }
@@ -364,7 +365,7 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   BKG_ARG(!split || partials, "bkg_spmm_csr_f32: row splitting needs a partials buffer");
   if (n_rows == 0) return 0;
   float* out = reinterpret_cast<float*>(out_);
-  SpmmEpilogue ep{self_w, bias, addend, ld_add, relu, keep, drop_p, seed, stream_id, out_is_bf16 ? 1 : 0};
+  SpmmEpilogue ep{self_w, bias, addend, ld_add, relu, keep, drop_p, seed, stream_id, out_is_bf16 ? 1 : 0, rng_epoch_ptr()};
   const int epl = x_is_bf16 ? 8 : 4;
   const bool vec_ok = (d % epl == 0) && (ldx % epl == 0) && (ldo % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % 16 == 0) &&
                       (!bias || ((uintptr_t)bias % 16 == 0)) && (!keep || ((uintptr_t)keep % 4 == 0)) &&
@@ -444,9 +445,11 @@ extern "C" int bkg_gate_cast_bf16(const void* src, int32_t src_is_bf16, const vo
 //      rescale) fused with the bf16 table cast: dst = bf16(philox(seed, stream, i) >= p ? src[i] : 0); p = 0: plain cast
 namespace bkg {
 __global__ __launch_bounds__(256) void mask_cast_bf16_kernel(const float* __restrict__ src, float p, uint64_t seed,
-                                                             uint32_t stream_id, __bf16* __restrict__ dst, int64_t n8) {
+                                                             uint32_t stream_id, __bf16* __restrict__ dst, int64_t n8,
+                                                             const uint32_t* __restrict__ epoch) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
+  stream_id = with_epoch(stream_id, epoch);
   float a[8];
   load8(src, i, a);
   if (p > 0.f) {
@@ -472,7 +475,7 @@ extern "C" int bkg_mask_cast_bf16(const float* src, float p, uint64_t seed, uint
   BKG_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "bkg_mask_cast_bf16: 16-byte alignment");
   if (n == 0) return 0;
   hipLaunchKernelGGL(mask_cast_bf16_kernel, dim3(ceil_div(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, p, seed,
-                     stream_id, (__bf16*)dst, n / 8);
+                     stream_id, (__bf16*)dst, n / 8, rng_epoch_ptr());
   return check_launch("bkg_mask_cast_bf16");
 }
 

@@ -118,6 +118,26 @@ class Trainer:
         self.callback_metrics.update(out)
         return out
 
+    def _try_graph(self, model, loader, opt):
+        """Whole-graph loaders hand out the SAME batch every step: capture the step once into a hipGraph and replay it
+        (biomedkg_amd/graphs.py) when the module's step has no host-side draws (GRACE); otherwise stay eager.  Off with
+        BKG_HIPGRAPH=0, for multi-rank runs (the gradient all-reduce is not part of the capture) and under fast_dev_run."""
+        batch = getattr(loader, "batch", None)
+        if (batch is None or self.world > 1 or self.fast_dev_run or os.environ.get("BKG_HIPGRAPH", "1") == "0"
+                or self.device.type != "cuda"):
+            return None
+        from . import graphs
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        try:
+            step = graphs.GraphedStep(model, self._move(batch), opt, clip=self.clip, warmup=2)
+        except graphs.CaptureRefused as why:
+            model.load_state_dict(state)
+            if self.rank == 0:
+                print(f"[trainer] eager steps: {why}", flush=True)
+            return None
+        self.global_step += step.warmup_steps       # the capture's eager warm-up steps are real optimizer steps
+        return step
+
     def _seed_rank(self, loaders):
         """Per-rank randomness: without it every rank would draw the same batches, masks and negatives and N GPUs
         would do one GPU's work (Lightning shards through DistributedSampler; the device samplers through set_rank)."""
@@ -161,11 +181,18 @@ class Trainer:
         opt, sched = conf["optimizer"], conf.get("lr_scheduler")
         params = [p for g in opt.param_groups for p in g["params"]]
         bucket = D.GradBucket(params, self.world)
+        graphed = self._try_graph(model, train_dataloaders, opt)
         for epoch in range(epochs):
             self.current_epoch = epoch
             model.train()
             t0 = time.time()
             for i, batch in self._limit(train_dataloaders):
+                if graphed is not None:            # one hipGraph replay = zero_grad + step + backward + clip + Adam
+                    loss = graphed()
+                    if self.global_step % max(1, self.log_every) == 0:
+                        self._log("train_loss", loss)
+                    self.global_step += 1
+                    continue
                 opt.zero_grad(set_to_none=True)
                 loss = model.training_step(batch)
                 loss.backward()

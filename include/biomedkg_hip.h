@@ -26,6 +26,11 @@ const char* bkg_last_error(void); /* (host) thread-local text of the last failur
  * on ONE stream at a time; NULL switches back to atomics.  Everything else on the path is already order-fixed. */
 int bkg_set_deterministic_workspace(float* workspace, int64_t floats);
 
+/* hipGraph replay of a captured training step (biomedkg_amd/graphs.py): kernel arguments are frozen at capture, so
+ * the in-kernel Philox streams (layer dropout of bkg_spmm_csr_f32, bkg_mask_cast_bf16, bkg_redaf_combine_f32) add
+ * `*epoch << 16` to their stream id -- a DEVICE counter the captured step increments once per replay.  NULL = off. */
+int bkg_set_rng_epoch(const uint32_t* epoch);
+
 /* ---- graph preparation (replaces PyG's COO bookkeeping inside GCNConv / RGCNConv /
  *      negative_sampling: biomedkg/model/encoder.py:52,57,155,160; biomedkg/kge_module.py:93) */
 int64_t bkg_sort_workspace_bytes(int64_t n);

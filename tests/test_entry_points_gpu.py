@@ -50,3 +50,28 @@ def test_train_scripts_with_device_samplers():
                           "model.in_dim=32", "model.hidden_dim=16", "model.out_dim=16", "neg_ratio=1", "epochs=1",
                           "val_every_epoch=1", "ckpt_dir=/tmp/bkg_ckpt"])
     assert any(k.startswith("test_AUROC") for k in out[0])
+
+
+def test_train_gcl_grace_replays_a_hipgraph(capsys):
+    """configs[1]-style run through the entry point: the whole-graph loader hands out one static batch, so the Trainer
+    stand-in captures the GRACE step once and replays it; GGD (host-side augmentation coin) stays eager and says so."""
+    import train_gcl
+    from biomedkg_amd import graphs
+    made = []
+    orig = graphs.GraphedStep.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(self)
+    graphs.GraphedStep.__init__ = spy
+    try:
+        common = ["devices=[0]", "data=synthetic", "data.node_type=gene", "data.node_init_method=lm", "data.num_nodes=1200",
+                  "data.num_edges=9000", "data.embed_dim=64", "data.steps_per_epoch=12", "model.in_dim=64", "model.hidden_dim=32",
+                  "model.out_dim=32", "model.fuse_method=attention", "epochs=2", "val_every_epoch=1", "ckpt_dir=/tmp/bkg_ckpt"]
+        out = train_gcl.main(common + ["model.model_name=grace"])
+        assert "test_loss" in out[0] and len(made) == 1 and made[0].replays == 2 * 12
+        out = train_gcl.main(common + ["model.model_name=ggd"])
+        assert "test_loss" in out[0] and len(made) == 1
+        assert "eager steps" in capsys.readouterr().out
+    finally:
+        graphs.GraphedStep.__init__ = orig

@@ -1,0 +1,136 @@
+"""hipGraph capture of a whole training step (biomedkg_amd/graphs.py) for the launch-bound small-graph regime
+(BASELINE configs[1]: GRACE on the 5k / 50k graph): a replayed step must be the eager step -- same kernels, same order,
+bit for bit when the randomness is pinned --, replays must draw fresh masks (torch's graph-safe generator for the
+feature / edge masks, the device replay epoch for the library's in-kernel Philox dropout), and steps that cannot be
+captured (host-side coin, sort-based permutation, host-counted negative sampler) must be refused loudly.
+Needs an MI355X."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _grace(seed=0, n=1500, e=12000, d_in=64, h=32):
+    from biomedkg_amd import synthetic
+    from biomedkg_amd.gcl_module import GRACEModule
+    torch.manual_seed(seed)
+    mod = GRACEModule(in_dim=d_in, hidden_dim=h, out_dim=h, num_hidden_layers=2, fuse_method="attention").to(DEV).train()
+    batch = SimpleNamespace(x=synthetic.lm_features(n, 2, d_in, seed=1).to(DEV), edge_index=synthetic.gcl_small(n, e, seed=2).to(DEV))
+    return mod, batch
+
+
+def test_replayed_grace_steps_equal_eager_steps_bit_for_bit():
+    from biomedkg_amd import graphs as G, rand as R
+    n, e, d_in = 1500, 12000, 64
+    g = torch.Generator(device=DEV).manual_seed(5)
+    fm = [torch.rand(n, d_in, device=DEV, generator=g) >= 0.4 for _ in range(2)]
+    ek = [torch.rand(e, device=DEV, generator=g) >= 0.4 for _ in range(2)]
+
+    class Pinned(G._GraphRand):                       # the same two augmented views every step
+        def __init__(self):
+            super().__init__(seed=1)
+            self.i = self.j = 0
+
+        def masked(self, x, p):
+            self.i += 1
+            return x * fm[self.i % 2]
+
+        def edge_keep(self, num_edges, p, device):
+            self.j += 1
+            return ek[self.j % 2]
+
+    steps = 6
+    # eager reference: warm-up (3) + steps eager steps with a capturable Adam (same arithmetic as the replayed one)
+    mod, batch = _grace()
+    mod.model.encoder.drop_out = False
+    params = list(mod.model.parameters())
+    opt = G.make_capturable(torch.optim.Adam(params, lr=1e-3, fused=True))
+    eager_losses = []
+    with R.use(Pinned()):
+        for _ in range(3 + steps):
+            opt.zero_grad(set_to_none=True)
+            loss = mod.training_step(batch)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            eager_losses.append(loss.detach().clone())
+    want = [p.detach().clone() for p in params]
+
+    mod2, batch2 = _grace()
+    mod2.model.encoder.drop_out = False
+    params2 = list(mod2.model.parameters())
+    opt2 = torch.optim.Adam(params2, lr=1e-3, fused=True)
+    step = G.GraphedStep(mod2, batch2, opt2, clip=1.0, warmup=3, provider=Pinned())
+    try:
+        got_losses = [step().clone() for _ in range(steps)]
+    finally:
+        step.close()
+    for a, b in zip(got_losses, eager_losses[3:]):
+        assert torch.equal(a, b), (float(a), float(b))
+    for a, b in zip(params2, want):
+        assert torch.equal(a.detach(), b)
+
+
+def test_replays_draw_fresh_randomness_and_train():
+    from biomedkg_amd import graphs as G
+    mod, batch = _grace(seed=3)
+    params = list(mod.model.parameters())
+    step = G.GraphedStep(mod, batch, torch.optim.Adam(params, lr=2e-3, fused=True), clip=1.0, warmup=2, seed=9)
+    try:
+        losses = [float(step()) for _ in range(40)]
+    finally:
+        step.close()
+    assert all(l == l and abs(l) < 1e4 for l in losses)
+    assert len(set(losses)) > 30                                   # new masks every replay
+    assert sum(losses[-10:]) / 10 < sum(losses[:10]) / 10          # and the optimizer is really stepping
+
+
+def test_in_kernel_dropout_follows_the_device_replay_epoch():
+    """The library's Philox dropout under a captured launch: frozen (seed, stream id) arguments, yet every replay
+    masks differently because the kernels add the device epoch; the masks equal the eager ones at the same epoch."""
+    from biomedkg_amd import _lib as L, graph as Gr, ops
+    torch.manual_seed(0)
+    n, d = 512, 64
+    ei = torch.randint(0, n, (2, 4000), device=DEV)
+    gr = Gr.Graph(ei, n)
+    gw = gr.gcn_weights()
+    x = torch.rand(n, d, device=DEV) + 0.5
+    c = gr.by_dst
+    epoch = torch.zeros(1, dtype=torch.int32, device=DEV)
+    run = lambda: ops.spmm(c.rowptr, c.col, gw.w_dst, x, n, self_w=gw.self_w, drop=ops.Dropout(0.3, seed=11, stream_id=4))
+    L.call("bkg_set_rng_epoch", L.ptr(epoch))
+    try:
+        eager = []
+        for k in range(1, 4):
+            epoch.fill_(k)
+            eager.append(run().clone())
+        assert not torch.equal(eager[0] == 0, eager[1] == 0)
+        epoch.zero_()
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            epoch.add_(1)
+            out = run()
+        for k in range(3):
+            graph.replay()
+            assert torch.equal(out, eager[k])
+    finally:
+        L.call("bkg_set_rng_epoch", None)
+    assert abs(float((eager[0] == 0).float().mean()) - 0.3) < 0.03
+
+
+def test_uncapturable_steps_are_refused():
+    from biomedkg_amd import graphs as G, synthetic
+    from biomedkg_amd.gcl_module import GGDModule
+    torch.manual_seed(0)
+    mod = GGDModule(in_dim=32, hidden_dim=16, out_dim=16, num_hidden_layers=1, fuse_method="none").to(DEV).train()
+    batch = SimpleNamespace(x=torch.randn(400, 32, device=DEV), edge_index=synthetic.gcl_small(400, 3000, seed=1).to(DEV))
+    with pytest.raises(G.CaptureRefused):
+        G.GraphedStep(mod, batch, torch.optim.Adam(mod.model.parameters(), lr=1e-3, fused=True))
