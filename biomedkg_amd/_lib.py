@@ -62,7 +62,8 @@ SIGNATURES = {
     "bkg_kge_bwd_rel_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, I32, P, I64, P, P, P]),
     # ntxent.hip
     "bkg_ntxent_hpad": (I32, [I32, I32]),
-    "bkg_ntxent_prepare": (I32, [P, I64, P, I64, I64, I32, I32, P, P, P, P, P]),
+    "bkg_ntxent_bf16_scale": (F32, [F32]),
+    "bkg_ntxent_prepare": (I32, [P, I64, P, I64, I64, I32, I32, F32, P, P, P, P, P]),
     "bkg_ntxent_forward_workspace_floats": (I64, [I64, I32, I32]),
     "bkg_ntxent_forward": (I32, [P, I32, I64, I32, F32, P, P, P, P, P, P]),
     "bkg_ntxent_backward_workspace_floats": (I64, [I64, I32, I32]),

@@ -77,23 +77,32 @@ __device__ __host__ __forceinline__ long long nx_block_of(long long x, long long
   return ((x + 1) * grid - 1) / n_items;
 }
 
-// 32 values per lane (index v = 16 t + r of e[t][r]) -> lane q of each 32-lane half returns the half's sum of value q
+// 32 values per lane (index v = 16 t + r of e[t][r]) -> lane q of each 32-lane half returns the half's sum of value q.
+// Transpose-reduce: at every level a lane keeps the half of its values selected by one bit of its lane id and receives
+// the partner's copy of that half.  Level "16" is one v_permlane16_swap (odd rows of e0 <-> even rows of e1) + one add
+// per value pair, no select; the levels inside a 16-lane row use DPP partners (row_ror:8, row_half_mirror, quad_perm):
+// no LDS crossbar round trips, so nothing waits on lgkmcnt (the ds_bpermute form spent ~600 exposed cycles per tile).
+template <int CTRL>
+__device__ __forceinline__ float nx_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float nx_transpose_reduce32(const nx_acc_t& e0, const nx_acc_t& e1, int l31) {
   float a[16], b[8], c[4], d[2];
-  {
-    const bool hi = l31 & 16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float keep = hi ? e1[r] : e0[r], send = hi ? e0[r] : e1[r];
-      a[r] = keep + __shfl_xor(send, 16, 64);
-    }
+  for (int r = 0; r < 16; ++r) {
+    // x' = {x.row0, y.row0, x.row2, y.row2}, y' = {x.row1, y.row1, x.row3, y.row3}.  Inline asm: on ROCm 7.2 the builtin
+    // __builtin_amdgcn_permlane16_swap hands back the new first operand in BOTH result slots (scripts/dev_lanes.hip);
+    // hipcc pads nothing around an asm statement, hence the s_nop on either side (cdna_hip_programming.md 5.7)
+    float x = e0[r], y = e1[r];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    a[r] = x + y;                                              // rows 0,2: value r; rows 1,3: value 16 + r
   }
   {
     const bool hi = l31 & 8;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const float keep = hi ? a[r + 8] : a[r], send = hi ? a[r] : a[r + 8];
-      b[r] = keep + __shfl_xor(send, 8, 64);
+      b[r] = keep + nx_dpp<0x128>(send);                       // row_ror:8  (lane i <-> i ^ 8)
     }
   }
   {
@@ -101,7 +110,7 @@ __device__ __forceinline__ float nx_transpose_reduce32(const nx_acc_t& e0, const
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float keep = hi ? b[r + 4] : b[r], send = hi ? b[r] : b[r + 4];
-      c[r] = keep + __shfl_xor(send, 4, 64);
+      c[r] = keep + nx_dpp<0x141>(send);                       // row_half_mirror (i <-> i ^ 7: the other quad of the 8)
     }
   }
   {
@@ -109,12 +118,12 @@ __device__ __forceinline__ float nx_transpose_reduce32(const nx_acc_t& e0, const
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const float keep = hi ? c[r + 2] : c[r], send = hi ? c[r] : c[r + 2];
-      d[r] = keep + __shfl_xor(send, 2, 64);
+      d[r] = keep + nx_dpp<0x4E>(send);                        // quad_perm [2,3,0,1]
     }
   }
   const bool hi = l31 & 1;
   const float keep = hi ? d[1] : d[0], send = hi ? d[0] : d[1];
-  return keep + __shfl_xor(send, 1, 64);
+  return keep + nx_dpp<0xB1>(send);                            // quad_perm [1,0,3,2]
 }
 
 __device__ __forceinline__ int nx_acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
@@ -130,7 +139,11 @@ template <bool BF16, int HP, int NW, bool BWD>
 __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
   constexpr int HPAD = 32 * HP, PR = 32 * NW, NT = 64 * NW, Q = PR / NX_BJ;
   constexpr int HS = HPAD + 4;                                   // fp32 image: padded row (floats)
-  constexpr int TILE_BYTES = BF16 ? NX_BJ * HPAD * 2 : NX_BJ * HS * 4;
+  // bf16 images: the forward only reads rows (ds_read_b128): rows padded by 16 B (conflict-free, every address a lane
+  // constant + an immediate); the backward also reads columns (ds_read_b64_tr_b16): the T10 (b) XOR image
+  constexpr bool PAD16 = BF16 && !BWD;
+  constexpr int ROWB16 = HPAD * 2 + 16;
+  constexpr int TILE_BYTES = BF16 ? (PAD16 ? NX_BJ * ROWB16 : NX_BJ * HPAD * 2) : NX_BJ * HS * 4;
   constexpr int CH_ROW = BF16 ? HPAD / 8 : HPAD / 4;             // 16-byte chunks per row
   constexpr int NPC = (NX_BJ * CH_ROW) / NT;                     // chunks staged per thread
   static_assert((NX_BJ * CH_ROW) % NT == 0, "tile chunks must divide over the threads");
@@ -169,10 +182,17 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     }
   }
 
-  // ---- staging registers: the next j-tile (and, backward, its 1/D values)
-  uint4 st[NPC];
-  float st_rd = 0.f;
-  auto prefetch = [&](int jt_) {
+  // ---- staging registers: the j-tiles in flight (and, backward, their 1/D values).  fp32 tiles take ~16x longer to
+  //      consume than to fetch: one tile ahead; bf16 tiles are consumed in about a microsecond, less than an L2-miss round
+  //      trip under load: TWO tiles ahead, in two register sets used alternately
+  //      (not for the widest backward, whose accumulators leave no registers for a second set)
+  //      -- measured: no gain from the second set (27 vs 28 ms forward at N = 130k, h = 256; the bf16 tile is bound by its
+  //      exp / butterfly VALU work, not by the fetch), so DEPTH stays 1 everywhere; the two-set form is kept for a chip
+  //      where the balance differs
+  constexpr int DEPTH = 1;
+  uint4 stA[NPC], stB[NPC];
+  float rdA = 0.f, rdB = 0.f;
+  auto prefetch = [&](int jt_, uint4 (&st)[NPC], float& st_rd) {
     const int j0 = jt_ * NX_BJ;
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
@@ -182,11 +202,12 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     }
     if (BWD && tid < NX_BJ) st_rd = (j0 + tid < M) ? a.rden[j0 + tid] : 0.f;
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, const uint4 (&st)[NPC], float st_rd) {
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
       const int p = tid + i * NT, row = p / CH_ROW, ch = p % CH_ROW;
-      if (BF16) *reinterpret_cast<uint4*>(tile_at(buf) + (ch >> 4) * (NX_BJ * 256) + nx_off16(row, ch & 15)) = st[i];
+      if (PAD16) *reinterpret_cast<uint4*>(tile_at(buf) + row * ROWB16 + ch * 16) = st[i];
+      else if (BF16) *reinterpret_cast<uint4*>(tile_at(buf) + (ch >> 4) * (NX_BJ * 256) + nx_off16(row, ch & 15)) = st[i];
       else *reinterpret_cast<uint4*>(tile_at(buf) + (row * HS + ch * 4) * 4) = st[i];
     }
     if (BWD && tid < NX_BJ) aux[buf * NX_BJ + tid] = st_rd;
@@ -223,6 +244,18 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     if (BWD) rd_i = (i_glob >= 0) ? a.rden[i_glob] : 0.f;
   };
 
+  // T10-image addresses split into a lane constant, an XOR with a lane constant, and compile-time offsets, so that
+  // a fragment read costs at most two VALU operations (the generic off(row, ch) form costs five):
+  //   row read   (first product, row 32 t + l31, chunk 2k + lh):  rowA + ((32 (k & 7)) ^ rowT) + [8192 t + 16384 (k >> 3)]
+  //   tr read    (second product, see below):                     trC[second] + ((64 (ct & 3)) ^ trQ) + [...]
+  const int tag31 = ((l31 & 3) << 2) | ((l31 >> 2) & 3);
+  const int rowA = 256 * l31 + 16 * (lh ^ (tag31 & 1)), rowT = 16 * (tag31 & 14);
+  const int grp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = grp & 1, g2 = grp >> 1;
+  const int trL = 2 * g1 + (p4 >> 1), trQ = 64 * q4;
+  const int trC[2] = {256 * (4 * g2 + q4) + 16 * (trL ^ (g2 & 3)) + 8 * (p4 & 1),
+                      256 * (4 * g2 + q4) + 16 * (trL ^ ((g2 + 2) & 3)) + 8 * (p4 & 1)};
+  const int rowP = l31 * ROWB16 + 16 * lh;                         // padded image: row 32 t + l31, chunk 2k + lh
+
   nx_acc_t dz[BWD ? HP : 1];
   if (BWD) {
 #pragma unroll
@@ -234,12 +267,21 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
   bool col_pending = false;     // forward: colbuf[buf ^ 1] holds the previous tile's column sums
   long long col_item = 0;
 
-  prefetch(jt);
+  auto item_after = [&](int& P_, int& jt_) {          // (panel, j-tile) of the next work item
+    ++jt_;
+    if (!BWD && jt_ == a.n_jtiles) { ++P_; jt_ = a.rect ? 0 : P_ * Q; }
+  };
+  prefetch(jt, stA, rdA);
+  if (DEPTH == 2 && x + 1 < x_end) {
+    int P1 = P, jt1 = jt;
+    item_after(P1, jt1);
+    prefetch(jt1, stB, rdB);
+  }
   load_anchor(P);
   int buf = 0;
 
-  for (; x < x_end; ++x) {
-    commit(buf);
+  auto body = [&](uint4 (&st)[NPC], float& st_rd) {
+    commit(buf, st, st_rd);
     __syncthreads();
     if (!BWD && col_pending && tid < NX_BJ) {      // previous tile's column sums: add the waves in wave order
       const float* cb = aux + (buf ^ 1) * (NW * NX_BJ);
@@ -248,10 +290,14 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
       for (int w = 0; w < NW; ++w) v += cb[w * NX_BJ + tid];
       a.colitem[col_item * NX_BJ + tid] = v;
     }
-    // next item
-    int P_next = P, jt_next = jt + 1;
-    if (!BWD && jt_next == a.n_jtiles) { P_next = P + 1; jt_next = a.rect ? 0 : P_next * Q; }
-    if (x + 1 < x_end) prefetch(jt_next);
+    // next item; the registers just committed take the tile DEPTH items ahead
+    int P_next = P, jt_next = jt;
+    item_after(P_next, jt_next);
+    if (x + DEPTH < x_end) {
+      int Pa = P_next, jta = jt_next;
+      if (DEPTH == 2) item_after(Pa, jta);
+      prefetch(jta, st, st_rd);
+    }
 
     const int j0 = jt * NX_BJ;
     const bool need_mask = (j0 + NX_BJ > M) || (P * PR + wave * 32 + 32 > a.n_anchor) || (j0 <= i_hi && j0 + NX_BJ > i_lo);
@@ -263,16 +309,25 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
     if (BF16) {
+      // fragment reads run RD steps ahead of their MFMAs (an LDS read returns after ~100+ cycles, a 32x32x16 MFMA
+      // issues every 32): the compiler's own schedule kept one step in flight and the matrix pipe waited on lgkmcnt
+      constexpr int RD = (BWD && HP <= 4) ? 1 : 3, RING = RD + 1;
+      uint4 ring[RING][2];
+      auto read_k = [&](int k, uint4 (&dst)[2]) {
+        const int at = PAD16 ? rowP + 32 * k : rowA + ((32 * (k & 7)) ^ rowT) + 16384 * (k >> 3);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          dst[t] = *reinterpret_cast<const uint4*>(tile_at(buf) + at + t * (PAD16 ? 32 * ROWB16 : 8192));
+      };
+#pragma unroll
+      for (int k = 0; k < RD && k < KF; ++k) read_k(k, ring[k % RING]);
 #pragma unroll
       for (int k = 0; k < KF; ++k) {
-        const int cidx = 2 * k + lh;
+        if (k + RD < KF) read_k(k + RD, ring[(k + RD) % RING]);
         const nx_bf16x8_t b = __builtin_bit_cast(nx_bf16x8_t, zi[k]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const uint4 av = *reinterpret_cast<const uint4*>(tile_at(buf) + (cidx >> 4) * (NX_BJ * 256) +
-                                                           nx_off16(32 * t + l31, cidx & 15));
-          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nx_bf16x8_t, av), b, s[t], 0, 0, 0);
-        }
+        for (int t = 0; t < 2; ++t)
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nx_bf16x8_t, ring[k % RING][t]), b, s[t], 0, 0, 0);
       }
     } else {
       const float* zj = reinterpret_cast<const float*>(tile_at(buf));
@@ -299,7 +354,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jl = 32 * t + nx_acc_row(r, lh);
-        float e = __builtin_amdgcn_exp2f(BF16 ? s[t][r] * a.scale : s[t][r]);
+        float e = __builtin_amdgcn_exp2f(s[t][r]);       // both images carry the log2(e)/tau scale (bf16: sqrt on each side)
         if (need_mask) {
           const int jg = j0 + jl;
           e = (jg < M && i_glob >= 0 && jg != i_glob) ? e : 0.f;
@@ -318,29 +373,33 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
         col_item = x;
       }
     } else if (BF16) {
-      // dZ[i][c] += sum_j W[j][i] Z_J[j][c]: accumulator registers 8 s2 .. 8 s2 + 7 are the A fragment of k-step s2
-      const int grp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+      // dZ[i][c] += sum_j W[j][i] Z_J[j][c]: accumulator registers 8 s2 .. 8 s2 + 7 are the A fragment of k-step s2;
+      // its k order is permuted (element e of lane half g2 = row 16 s2 + 8 (e >> 2) + 4 g2 + (e & 3)), so the B
+      // fragment is two transposed 4-row reads, rows r0 .. r0 + 3 and r0 + 8 .. r0 + 11, r0 = 32 t + 16 s2 + 4 g2
+      nx_bf16x8_t wf[4];                                    // the four A fragments of this tile (t, s2)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int ts = 0; ts < 4; ++ts)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          nx_bf16x8_t wf;
+        for (int e = 0; e < 8; ++e) wf[ts][e] = (__bf16)s[ts >> 1][8 * (ts & 1) + e];
+      constexpr int N2 = 4 * HP, RD2 = HP <= 4 ? 2 : 3, RING2 = RD2 + 1;     // steps (ts, ct), reads RD2 steps ahead
+      nx_s8_t bring[RING2];
+      auto read_b = [&](int i) {
+        const int ts = i / HP, ct = i % HP;
+        const int col = ((64 * (ct & 3)) ^ trQ) + 16384 * (ct >> 2) + 256 * (32 * (ts >> 1) + 16 * (ts & 1));
+        const nx_s4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) nx_s4_t*)(tile_at(buf) + trC[0] + col));
+        const nx_s4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) nx_s4_t*)(tile_at(buf) + trC[1] + col + 256 * 8));
+        return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      };
 #pragma unroll
-          for (int e = 0; e < 8; ++e) wf[e] = (__bf16)s[t][8 * s2 + e];
-          const int r0 = 32 * t + 16 * s2 + 4 * (grp >> 1);
+      for (int i = 0; i < RD2; ++i) bring[i % RING2] = read_b(i);
 #pragma unroll
-          for (int ct = 0; ct < HP; ++ct) {
-            const int cchunk = 4 * ct + 2 * (grp & 1);           // first 16-byte chunk of the group's 16 columns
-            const unsigned char* base = tile_at(buf) + (cchunk >> 4) * (NX_BJ * 256);
-            const int ch = (cchunk & 15) + (p4 >> 1);
-            const nx_s4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) nx_s4_t*)(base + nx_off16(r0 + q4, ch) + 8 * (p4 & 1)));
-            const nx_s4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) nx_s4_t*)(base + nx_off16(r0 + 8 + q4, ch) + 8 * (p4 & 1)));
-            const nx_s8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-            dz[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(nx_bf16x8_t, bv), dz[ct], 0, 0, 0);
-          }
-        }
+      for (int i = 0; i < N2; ++i) {
+        if (i + RD2 < N2) bring[(i + RD2) % RING2] = read_b(i + RD2);
+        dz[i % HP] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i / HP], __builtin_bit_cast(nx_bf16x8_t, bring[i % RING2]),
+                                                             dz[i % HP], 0, 0, 0);
+      }
     } else {
       // register r of W^T is the A operand for k = {row(r, lh = 0), row(r, lh = 1)} of the j-half t
       const float* zj = reinterpret_cast<const float*>(tile_at(buf));
@@ -366,6 +425,14 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     P = P_next;
     jt = jt_next;
     buf ^= 1;
+    ++x;
+  };
+  while (x < x_end) {
+    body(stA, rdA);
+    if (DEPTH == 2) {
+      if (x >= x_end) break;
+      body(stB, rdB);
+    }
   }
 
   if (!BWD) {
@@ -397,7 +464,8 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 __global__ __launch_bounds__(256) void nx_prep_kernel(const float* __restrict__ h1, int64_t ld1,
                                                       const float* __restrict__ h2, int64_t ld2, int N, int h, int hpad,
                                                       float* __restrict__ zn, __bf16* __restrict__ zn16,
-                                                      float* __restrict__ norm, float* __restrict__ posdot) {
+                                                      float zn16_scale, float* __restrict__ norm,
+                                                      float* __restrict__ posdot) {
   const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= N) return;
   const int c = lane * 4;
@@ -425,8 +493,8 @@ __global__ __launch_bounds__(256) void nx_prep_kernel(const float* __restrict__ 
     if (zn16) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        zn16[(size_t)i * hpad + c + q] = (__bf16)u[q];
-        zn16[(size_t)(i + N) * hpad + c + q] = (__bf16)v[q];
+        zn16[(size_t)i * hpad + c + q] = (__bf16)(u[q] * zn16_scale);
+        zn16[(size_t)(i + N) * hpad + c + q] = (__bf16)(v[q] * zn16_scale);
       }
     }
   }
@@ -468,7 +536,8 @@ __global__ __launch_bounds__(256) void nx_bwd_finish_kernel(const float* __restr
                                                             const float* __restrict__ zn, const float* __restrict__ norm,
                                                             const float* __restrict__ gout, const int* __restrict__ anchors,
                                                             int n_anchor, int n_half, int N, int h, int hpad,
-                                                            float inv_m_tau, float* __restrict__ dh1, int64_t ld1,
+                                                            float inv_m_tau, float part_scale, float* __restrict__ dh1,
+                                                            int64_t ld1,
                                                             float* __restrict__ dh2, int64_t ld2) {
   const int lane = threadIdx.x & 63, a = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (a >= n_anchor) return;
@@ -481,6 +550,7 @@ __global__ __launch_bounds__(256) void nx_bwd_finish_kernel(const float* __restr
       const float4 p = *reinterpret_cast<const float4*>(dzpart + ((size_t)s * n_anchor + a) * hpad + c);
       d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
     }
+    d.x *= part_scale; d.y *= part_scale; d.z *= part_scale; d.w *= part_scale;   // bf16 image rows carry sqrt(log2e/tau)
     z = *reinterpret_cast<const float4*>(zn + (size_t)i * hpad + c);
     const int pi = i < N ? i + N : i - N;
     const float4 zp = *reinterpret_cast<const float4*>(zn + (size_t)pi * hpad + c);
@@ -501,7 +571,7 @@ struct NxPlan { int nw, smem, occ; };
 template <bool BF16, int HP, int NW, bool BWD>
 static NxPlan nx_plan() {
   constexpr int HPAD = 32 * HP;
-  const int tile = BF16 ? NX_BJ * HPAD * 2 : NX_BJ * (HPAD + 4) * 4;
+  const int tile = BF16 ? (BWD ? NX_BJ * HPAD * 2 : NX_BJ * (HPAD * 2 + 16)) : NX_BJ * (HPAD + 4) * 4;
   const int smem = 2 * tile + (BWD ? 2 * NX_BJ : 2 * NW * NX_BJ) * 4;
   static int occ_cache = -1;
   if (occ_cache < 0) {
@@ -605,11 +675,15 @@ extern "C" int32_t bkg_ntxent_hpad(int32_t h, int32_t bf16) {
   return bf16 ? (h <= 128 ? 128 : 256) : ((h + 31) / 32) * 32;
 }
 
+extern "C" float bkg_ntxent_bf16_scale(float tau) { return sqrtf(1.4426950408889634f / tau); }
+
 extern "C" int bkg_ntxent_prepare(const float* h1, int64_t ld1, const float* h2, int64_t ld2, int64_t N, int32_t h,
-                                  int32_t hpad, float* zn, void* zn_bf16, float* norm, float* posdot, void* stream) {
+                                  int32_t hpad, float tau, float* zn, void* zn_bf16, float* norm, float* posdot,
+                                  void* stream) {
   BKG_ARG(N > 0 && h > 0 && h <= 256 && hpad >= h && hpad % 32 == 0 && hpad <= 256, "bkg_ntxent_prepare: 0 < h <= hpad <= 256");
+  BKG_ARG(tau > 0.f, "bkg_ntxent_prepare: tau > 0");
   hipLaunchKernelGGL(nx_prep_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, h1, ld1, h2, ld2, (int)N, h,
-                     hpad, zn, (__bf16*)zn_bf16, norm, posdot);
+                     hpad, zn, (__bf16*)zn_bf16, bkg_ntxent_bf16_scale(tau), norm, posdot);
   return check_launch("bkg_ntxent_prepare");
 }
 
@@ -681,8 +755,10 @@ static int nx_backward(const void* zn, int32_t bf16, const float* zn_f32, const 
   a.rden = rden; a.dzpart = workspace; a.splits = sh.splits; a.jt_per_split = sh.jt_per_split;
   int rc = nx_run_bwd(bf16 != 0, sh.hp, a, sh.n_panels * sh.splits, s);
   if (rc) return rc;
+  const float part_scale = bf16 ? 1.0f / sqrtf(a.scale) : 1.0f;
   hipLaunchKernelGGL(nx_bwd_finish_kernel, dim3(ceil_div(a.n_anchor, 4)), dim3(256), 0, s, workspace, sh.splits, zn_f32,
-                     norm, gout, anchors, a.n_anchor, (int)n_half, (int)(M / 2), h, sh.hpad, inv_m_tau, dh1, ld1, dh2, ld2);
+                     norm, gout, anchors, a.n_anchor, (int)n_half, (int)(M / 2), h, sh.hpad, inv_m_tau, part_scale, dh1, ld1,
+                     dh2, ld2);
   return check_launch("bkg_ntxent_backward(finish)");
 }
 

@@ -1029,7 +1029,7 @@ class _NtXent(torch.autograd.Function):
         zn16 = torch.empty(m, hpad, dtype=torch.bfloat16, device=dev) if bf16 else None
         norm = torch.empty(m, dtype=torch.float32, device=dev)
         posdot = torch.empty(n, dtype=torch.float32, device=dev)
-        L.call("bkg_ntxent_prepare", L.ptr(h1), h1.stride(0), L.ptr(h2), h2.stride(0), n, h, hpad, L.ptr(zn), L.ptr(zn16),
+        L.call("bkg_ntxent_prepare", L.ptr(h1), h1.stride(0), L.ptr(h2), h2.stride(0), n, h, hpad, tau, L.ptr(zn), L.ptr(zn16),
                L.ptr(norm), L.ptr(posdot), L.stream())
         ws = torch.empty(L.lib().bkg_ntxent_forward_workspace_floats(m, h, bf16), dtype=torch.float32, device=dev)
         den = torch.empty(2, m, dtype=torch.float32, device=dev)          # D and 1 / D
@@ -1071,19 +1071,20 @@ class NtXentKernels:
         zn = torch.empty(2 * n, hpad, dtype=torch.float32, device=h1.device)
         norm = torch.empty(2 * n, dtype=torch.float32, device=h1.device)
         posdot = torch.empty(n, dtype=torch.float32, device=h1.device)
-        L.call("bkg_ntxent_prepare", L.ptr(h1), h1.stride(0), L.ptr(h2), h2.stride(0), n, h, hpad, L.ptr(zn), None,
+        L.call("bkg_ntxent_prepare", L.ptr(h1), h1.stride(0), L.ptr(h2), h2.stride(0), n, h, hpad, 1.0, L.ptr(zn), None,
                L.ptr(norm), L.ptr(posdot), L.stream())
         return zn, norm, posdot
 
-    def _operand(self, z_all):
-        return to_bf16(z_all) if self.bf16 else z_all
+    def _operand(self, z_all, tau):
+        # the bf16 image carries sqrt(log2(e) / tau) on every row (include/biomedkg_hip.h: bkg_ntxent_bf16_scale)
+        return to_bf16(z_all * float(L.lib().bkg_ntxent_bf16_scale(tau))) if self.bf16 else z_all
 
     def row_sums(self, z_all, anchors, tau):
         m, na = z_all.size(0), anchors.numel()
         ws = torch.empty(L.lib().bkg_ntxent_rows_forward_workspace_floats(m, na, self.h, self.bf16), dtype=torch.float32,
                          device=z_all.device)
         den = torch.empty(na, dtype=torch.float32, device=z_all.device)
-        self._z16 = self._operand(z_all)
+        self._z16 = self._operand(z_all, tau)
         L.call("bkg_ntxent_rows_forward", L.ptr(self._z16), self.bf16, m, self.h, tau, L.ptr(anchors), na, L.ptr(ws),
                L.ptr(den), L.stream())
         return den
@@ -1097,7 +1098,7 @@ class NtXentKernels:
         dh = torch.empty(na, self.h, dtype=torch.float32, device=z_all.device)
         z16 = getattr(self, "_z16", None)
         if z16 is None or z16.size(0) != m:
-            z16 = self._operand(z_all)
+            z16 = self._operand(z_all, tau)
         scale = scale.reshape(1).to(torch.float32).contiguous()
         L.call("bkg_ntxent_rows_backward", L.ptr(z16), self.bf16, L.ptr(z_all), L.ptr(norm), L.ptr(rden), L.ptr(scale), m,
                self.h, tau, L.ptr(anchors), na, n_half, 1.0, L.ptr(ws), L.ptr(dh[:n_half]), self.h,

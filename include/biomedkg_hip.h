@@ -187,8 +187,11 @@ int bkg_kge_bwd_rel_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, co
  *      bkg_ntxent_backward: dL/dh1, dL/dh2 [N, h] (times the upstream scalar *gout, a DEVICE float), tiles recomputed.
  *      Workspaces (floats) by the *_workspace_floats queries; every function is stream-ordered, no host sync. */
 int32_t bkg_ntxent_hpad(int32_t h, int32_t bf16);
+/* the bf16 image holds zn * bkg_ntxent_bf16_scale(tau) = zn * sqrt(log2(e) / tau): the Gram of two such rows is already
+ * the exp2 argument, and scaling before the bf16 rounding costs no accuracy (the rounding is relative) */
+float bkg_ntxent_bf16_scale(float tau);
 int bkg_ntxent_prepare(const float* h1, int64_t ld1, const float* h2, int64_t ld2, int64_t N, int32_t h, int32_t hpad,
-                       float* zn, void* zn_bf16, float* norm, float* posdot, void* stream);
+                       float tau, float* zn, void* zn_bf16, float* norm, float* posdot, void* stream);
 int64_t bkg_ntxent_forward_workspace_floats(int64_t M, int32_t h, int32_t bf16);
 int bkg_ntxent_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau, const float* posdot,
                        float* workspace, float* den, float* rden, double* term, void* stream);
