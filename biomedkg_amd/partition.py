@@ -37,7 +37,6 @@ class Comm:
 
     def __init__(self, world, n_local, n_max, group=None):
         self.world, self.n_local, self.n_max, self.group = int(world), int(n_local), int(n_max), group
-        self._const = {}
 
     def shard_buffer(self, d, dtype, device):
         """A padded ``[n_max, d]`` shard for a producer to write its ``n_local`` rows into (the pad rows are never
@@ -51,24 +50,12 @@ class Comm:
         buf[: shard.size(0)].copy_(shard)
         return buf
 
-    def all_gather_begin(self, shard, const_key=None):
-        """``const_key``: the shard is a constant (input features): gather it once per (tensor, version)."""
-        if const_key is not None:
-            hit = self._const.get("table")
-            if hit is not None and hit[0] == const_key:
-                return hit[1], None
+    def all_gather_begin(self, shard):
         shard = self._padded(shard)
         if self.world == 1:
-            out, work = shard, None
-        else:
-            out = torch.empty(self.world * self.n_max, shard.size(1), dtype=shard.dtype, device=shard.device)
-            work = dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True)
-        if const_key is not None:
-            if work is not None:
-                work.wait()
-                work = None
-            self._const["table"] = (const_key, out)
-        return out, work
+            return shard, None
+        out = torch.empty(self.world * self.n_max, shard.size(1), dtype=shard.dtype, device=shard.device)
+        return out, dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True)
 
     @staticmethod
     def all_gather_end(pending):
