@@ -47,6 +47,7 @@ SIGNATURES = {
     # gemm_f32.hip
     "bkg_gemm_f32": (I32, [I32, I32, I64, I64, I64, F32, P, I64, P, I64, F32, P, I64, P, I32, P, I64, F32, I32, P]),
     "bkg_gemm_grouped_rows_f32": (I32, [I32, I64, I64, I64, P, I64, P, I64, I64, P, I64, P, I32, P, I64, F32, I32, P]),
+    "bkg_gemm_grouped_k_chunk": (I32, [I64, I64, I64, I32]),
     "bkg_gemm_grouped_k_f32": (I32, [I64, I64, I64, P, I64, P, I64, P, I64, I64, P, I32, I32, P]),
     "bkg_gemm_tn_bf16": (I32, [I64, I64, I64, P, I32, I64, P, I32, I64, P, I64, P]),
     "bkg_gemm_grouped_k_bf16": (I32, [I64, I64, I64, P, I32, I64, P, I32, I64, P, P, I64, I64, P, I32, P]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "bkg_kge_bwd_nodes_f32": (I32, [I32, P, I32, I64, I64, I32, P, P, P, I64, P, I64, P, P, P, P, P, P, I64, P, P, I32, P]),
     "bkg_kge_fused_bce_waves": (I64, [I64, I32]),
     "bkg_kge_fused_bce_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
+    "bkg_kge_fused_bce_dev_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
     "bkg_kge_bwd_rel_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, I32, P, I64, P, P, P]),
     # ntxent.hip
     "bkg_ntxent_hpad": (I32, [I32, I32]),
@@ -75,6 +77,9 @@ SIGNATURES = {
     # sample.hip
     "bkg_random_walk": (I32, [P, P, P, I64, I32, U64, P, P]),
     "bkg_sample_neighbors": (I32, [P, P, I64, I32, U64, U32, P, P]),
+    "bkg_saint_batch_workspace_bytes": (I64, [I64, I64]),
+    "bkg_saint_batch": (I32, [P, P, P, I64, I32, U64, P, P, P, P, P, I64, I64, P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P,
+                              P, P, I64, P]),
     # rank.hip
     "bkg_rank_true_score_f32": (I32, [P, I64, P, I64, P, I64, I32, P, P]),
     "bkg_rank_count_f32": (I32, [P, I64, I64, P, I64, I64, I32, P, P, I32, P, P, P]),
@@ -93,6 +98,8 @@ SIGNATURES = {
     "bkg_negative_sample_workspace_bytes": (I64, [I64]),
     "bkg_negative_sample": (I32, [I64, I64, I64, U64, P, I64, P, P, P, P, P, I64, I64, P, P, I64, P]),
     "bkg_permute_gather_i64": (I32, [P, I64, U64, P, P]),
+    "bkg_negative_sample_dev_candidates": (I64, [I64]),
+    "bkg_negative_sample_dev": (I32, [P, I64, P, P, P, I64, U64, P, P, I64, P, P, P, I64, I64, P, P, P, P, P, I64, P]),
     # fusion.hip
     "bkg_attn_fuse_f32": (I32, [P, I64, I64, I32, I32, P, I64, P]),
     "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, U32, P, I64, P]),

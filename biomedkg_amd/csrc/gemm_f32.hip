@@ -274,13 +274,16 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
   // Deep-K plain products with few output tiles (weight gradients): split K over the grid.
   const bool plain = !bias && act == 0 && !gate && beta == 0.f;
   const int64_t tiles64 = ((M + 63) / 64) * ((N + 63) / 64);
-  if (plain && K >= 4096 && tiles64 <= 256) {
+  // (a mini-batch weight gradient -- K ~ 10^3 rows, 16 tiles -- would otherwise run on 16 workgroups)
+  const bool shallow = plain && K >= 512 && K < 4096 && tiles64 <= 64;
+  if (plain && ((K >= 4096 && tiles64 <= 256) || shallow)) {
     // bf16 operands: 128x128 tiles whenever the output allows -- the product is bound by operand traffic and
     // every strip is then re-read by half as many tiles (measured 0.21 -> 0.14 ms at 256x256x130k; the split-K
     // grid supplies the parallelism).  fp32 operands are MFMA-bound there and prefer more, smaller tiles.
     const bool big = (precision == 1 && M >= 128 && N >= 128) || tiles64 >= 64;
     const int64_t tiles = big ? ((M + 127) / 128) * ((N + 127) / 128) : tiles64;
     int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, (precision ? 768 : 2048) / tiles));   // bf16: ~3 blocks per CU = the tile's occupancy
+    if (shallow) nsplit = std::min<int64_t>((K + 127) / 128, std::max<int64_t>(1, 512 / tiles));
     int kchunk = (int)(((K + nsplit - 1) / nsplit + 63) / 64 * 64);   // whole staged K tiles
     nsplit = (K + kchunk - 1) / kchunk;
     hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
@@ -324,13 +327,27 @@ extern "C" int bkg_gemm_grouped_rows_f32(int32_t trans_b, int64_t M_total, int64
   if (M_total == 0) return 0;
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, gate, ldg, gate_scale, 0};
   hipStream_t s = (hipStream_t)stream;
-  constexpr int BM = 128, BN = 128;
-  dim3 grid(xcd_grid(ceil_div(M_total, BM) + G, ceil_div(N, BN))), block(256);
-#define BKG_GROWS(P, TB_) hipLaunchKernelGGL((gemm_f32_grouped_rows_kernel<P, BM, BN, TB_>), grid, block, 0, s, A, lda, B, ldb, strideB, C, ldc, group_ptr, G, (int)N, (int)K, ep)
-  if (precision) { if (trans_b) BKG_GROWS(1, true); else BKG_GROWS(1, false); }
-  else { if (trans_b) BKG_GROWS(0, true); else BKG_GROWS(0, false); }
+  // 128x128 tiles once they fill the chip; 64x64 for mini-batches (most groups then hold fewer than 128 rows)
+  const bool big = (ceil_div(M_total, 128) + G) * (int64_t)ceil_div(N, 128) >= 256;
+  const int BT = big ? 128 : 64;
+  dim3 grid(xcd_grid(ceil_div(M_total, BT) + G, ceil_div(N, BT))), block(256);
+#define BKG_GROWS(P, TB_)                                                                                             \
+  if (big) hipLaunchKernelGGL((gemm_f32_grouped_rows_kernel<P, 128, 128, TB_>), grid, block, 0, s, A, lda, B, ldb, strideB, C, ldc, group_ptr, G, (int)N, (int)K, ep); \
+  else hipLaunchKernelGGL((gemm_f32_grouped_rows_kernel<P, 64, 64, TB_>), grid, block, 0, s, A, lda, B, ldb, strideB, C, ldc, group_ptr, G, (int)N, (int)K, ep)
+  if (precision) { if (trans_b) { BKG_GROWS(1, true); } else { BKG_GROWS(1, false); } }
+  else { if (trans_b) { BKG_GROWS(0, true); } else { BKG_GROWS(0, false); } }
 #undef BKG_GROWS
   return check_launch("bkg_gemm_grouped_rows_f32");
+}
+
+// rows per workgroup of the grouped weight-gradient products: 512 (fp32 operands) / 1024 (bf16) at scale, shorter
+// chunks -- multiples of 64 -- when the whole product would otherwise occupy a fraction of the chip (mini-batches)
+extern "C" int32_t bkg_gemm_grouped_k_chunk(int64_t rows_total, int64_t M, int64_t N, int32_t precision) {
+  const int64_t full = precision ? 1024 : 512;
+  const int64_t tiles = (int64_t)ceil_div(M, 128) * ceil_div(N, 128);
+  const int64_t want = std::max<int64_t>(1, 512 / std::max<int64_t>(1, tiles));        // chunks that fill the chip twice
+  int64_t chunk = (rows_total / want + 63) / 64 * 64;
+  return (int32_t)std::min<int64_t>(full, std::max<int64_t>(64, chunk));
 }
 
 extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, const float* A, int64_t lda,
@@ -342,7 +359,7 @@ extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, 
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   hipStream_t s = (hipStream_t)stream;
   constexpr int BM = 128, BN = 128;
-  const int KCHUNK = precision ? 1024 : 512;   // rows per block (bf16 operands: fewer, longer blocks; measured)
+  const int KCHUNK = bkg_gemm_grouped_k_chunk(rows_total, M, N, precision);   // rows per block
   float* det = nullptr;
   BKG_DET_SLABS(det, ep, ceil_div(rows_total, KCHUNK) + G, M, N, "bkg_gemm_grouped_k_f32");
   dim3 grid(xcd_grid(ceil_div(rows_total, KCHUNK) + G, ceil_div(M, BM) * ceil_div(N, BN))), block(256);

@@ -40,7 +40,8 @@ template <typename T, int KIND, int LPR, int VPL>
 __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const T* __restrict__ z, int64_t ldz,
                                                             const int64_t* __restrict__ head,
                                                             const int64_t* __restrict__ tail, int64_t T_, float label,
-                                                            float inv_t, const float* __restrict__ rel_emb,
+                                                            float inv_t, const float* __restrict__ inv_t_dev,
+                                                            const float* __restrict__ rel_emb,
                                                             int64_t ldr, int n_rel, const int32_t* __restrict__ order,
                                                             const int32_t* __restrict__ rel_ptr, int chunk,
                                                             float* __restrict__ score, float* __restrict__ g_out, int4* __restrict__ rec,
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const T* __restrict_
   constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q;
   const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (inv_t_dev) inv_t = inv_t_dev[0];      // padded mini-batches: the triplet count lives in device memory
   int w = __builtin_amdgcn_readfirstlane(wave_id);
   int r = 0, beg = 0, end = 0;
   for (; r < n_rel; ++r) {  // wave-uniform scan of <= n_rel scalars
@@ -181,11 +183,14 @@ extern "C" int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel) {
   return ((T + 63) / 64 + n_rel + 3) / 4 * 4;
 }
 
-extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const void* z, int32_t z_is_bf16, int64_t ldz, int32_t d,
-                                     const int64_t* head, const int64_t* tail, int64_t T, float label,
-                                     float inv_total, const float* rel_emb, int64_t ldr, int32_t n_rel,
-                                     const int32_t* order, const int32_t* rel_ptr, float* score, float* g,
-                                     void* rec, float* loss_part, float* drel, int64_t lddr, void* stream) {
+// `inv_total_dev` (nullable): read 1 / total from device memory instead of the scalar argument.  Triplets whose
+// relation id sorts past `n_rel` (rel_ptr has more groups than n_rel) are never visited: that is how the padded
+// mini-batches of biomedkg_amd/sampled.py keep their pad triplets out of the loss.
+extern "C" int bkg_kge_fused_bce_dev_f32(int32_t kind, const void* z, int32_t z_is_bf16, int64_t ldz, int32_t d,
+                                         const int64_t* head, const int64_t* tail, int64_t T, float label,
+                                         float inv_total, const float* inv_total_dev, const float* rel_emb, int64_t ldr,
+                                         int32_t n_rel, const int32_t* order, const int32_t* rel_ptr, float* score,
+                                         float* g, void* rec, float* loss_part, float* drel, int64_t lddr, void* stream) {
   BKG_ARG(kind == KF_DISTMULT || kind == KF_TRANSE, "bkg_kge_fused_bce_f32: bad kind");
   const int epl = z_is_bf16 ? 8 : 4;
   BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) &&
@@ -198,7 +203,7 @@ extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const void* z, int32_t z_is_b
   dim3 grid((unsigned)(bkg_kge_fused_bce_waves(T, n_rel) / 4)), block(256);
 #define KF_LAUNCH(TT, K)                                                                                            \
   hipLaunchKernelGGL((kge_fused_bce_kernel<TT, K, LPR, VPL>), grid, block, 0, s, (const TT*)z, ldz, head, tail, T, \
-                     label, inv_total, rel_emb, ldr, n_rel, order, rel_ptr, CH, score, g, reinterpret_cast<int4*>(rec), loss_part,  \
+                     label, inv_total, inv_total_dev, rel_emb, ldr, n_rel, order, rel_ptr, CH, score, g, reinterpret_cast<int4*>(rec), loss_part,  \
                      drel, lddr)
   BKG_PIECE_DISPATCH_(d / epl, 8, 16, {
     if (z_is_bf16) { if (kind == KF_DISTMULT) KF_LAUNCH(__bf16, KF_DISTMULT); else KF_LAUNCH(__bf16, KF_TRANSE); }
@@ -206,4 +211,13 @@ extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const void* z, int32_t z_is_b
   })
 #undef KF_LAUNCH
   return check_launch("bkg_kge_fused_bce_f32");
+}
+
+extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const void* z, int32_t z_is_bf16, int64_t ldz, int32_t d,
+                                     const int64_t* head, const int64_t* tail, int64_t T, float label,
+                                     float inv_total, const float* rel_emb, int64_t ldr, int32_t n_rel,
+                                     const int32_t* order, const int32_t* rel_ptr, float* score, float* g,
+                                     void* rec, float* loss_part, float* drel, int64_t lddr, void* stream) {
+  return bkg_kge_fused_bce_dev_f32(kind, z, z_is_bf16, ldz, d, head, tail, T, label, inv_total, nullptr, rel_emb, ldr, n_rel,
+                                   order, rel_ptr, score, g, rec, loss_part, drel, lddr, stream);
 }

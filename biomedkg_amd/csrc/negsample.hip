@@ -73,7 +73,7 @@ struct Feistel {
   }
 };
 
-static Feistel make_feistel(uint64_t n, uint64_t seed) {
+__host__ __device__ static inline Feistel make_feistel(uint64_t n, uint64_t seed) {
   Feistel f;
   f.n = n;
   int bits = 2;
@@ -128,6 +128,91 @@ __global__ __launch_bounds__(256) void permute_gather_kernel(const int64_t* __re
                                                              int64_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = src[pi((uint64_t)i)];
+}
+
+// ---- the same sampler with every extent in DEVICE memory (captured training steps over padded mini-batches,
+// biomedkg_amd/sampled.py): sizes[0] = N (nodes of the batch), sizes[1] = E (its edges), sizes[2] = E' (edges with
+// head != tail); k = neg_ratio * E negatives are asked for.  One round of int(1.1 k / prob) candidates (PyG's first
+// round; the later rounds only matter when fewer than k survive, which the caller rules out on the host: prob > 0.9).
+// The permutation key mixes a device replay counter, so a replayed graph draws fresh negatives.
+__device__ __forceinline__ uint64_t dev_seed(uint64_t seed, const uint32_t* __restrict__ epoch, uint64_t salt) {
+  return hs_mix(seed ^ (salt * 0xD1B54A32D192ED03ull) ^ ((uint64_t)(epoch ? epoch[0] : 0u) << 32));
+}
+
+__global__ __launch_bounds__(256) void hashset_insert_dev_kernel(const int64_t* __restrict__ head,
+                                                                 const int64_t* __restrict__ tail,
+                                                                 const int64_t* __restrict__ sizes, int64_t rows,
+                                                                 unsigned long long* __restrict__ tab, uint64_t mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows || i >= sizes[1]) return;
+  const int64_t r = head[i], c = tail[i], n_nodes = sizes[0];
+  if (r != c) hs_insert(tab, mask, (uint64_t)(r * (n_nodes - 1) + c - (r < c ? 1 : 0)));
+}
+
+__device__ __forceinline__ int64_t dev_candidates(const int64_t* __restrict__ sizes, int64_t neg_ratio, int64_t cap) {
+  const int64_t n = sizes[0], k = neg_ratio * sizes[1];
+  const double population = (double)(n * (n - 1));
+  const double prob = 1.0 - (double)sizes[2] / population;
+  int64_t m = (int64_t)(1.1 * (double)k / prob);                     // PyG: sample_size = int(1.1 * k / prob)
+  if (m > n * (n - 1)) m = n * (n - 1);
+  return m < cap ? m : cap;
+}
+
+__global__ __launch_bounds__(256) void negative_candidates_dev_kernel(const int64_t* __restrict__ sizes, int64_t neg_ratio,
+                                                                      uint64_t seed, const uint32_t* __restrict__ epoch,
+                                                                      int64_t cap,
+                                                                      const unsigned long long* __restrict__ pos_tab,
+                                                                      uint64_t pos_mask, uint64_t* __restrict__ keys,
+                                                                      int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  const int64_t n = sizes[0];
+  if (n < 2 || i >= dev_candidates(sizes, neg_ratio, cap)) { flag[i] = 0; return; }
+  const Feistel pi = make_feistel((uint64_t)(n * (n - 1)), dev_seed(seed, epoch, 1));
+  const uint64_t key = pi((uint64_t)i);
+  keys[i] = key;
+  flag[i] = hs_contains(pos_tab, pos_mask, key) ? 0 : 1;
+}
+
+// survivors in candidate order, the first k of them; slots past the count get pairs spread over the batch's nodes
+// (the caller gives them a relation id no scorer visits; spread, so that no node's incidence list grows long).
+// count = min(survivors, k).
+__global__ __launch_bounds__(256) void negative_scatter_dev_kernel(const uint64_t* __restrict__ keys,
+                                                                   const int32_t* __restrict__ flag,
+                                                                   const int32_t* __restrict__ offs, int64_t cap,
+                                                                   const int64_t* __restrict__ sizes, int64_t neg_ratio,
+                                                                   int64_t out_cap, int64_t* __restrict__ out_head,
+                                                                   int64_t* __restrict__ out_tail, int64_t* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t k = min(neg_ratio * sizes[1], out_cap);
+  const int64_t total = offs[cap - 1] + flag[cap - 1];
+  const int64_t have = total < k ? total : k;
+  if (i < cap && flag[i] && offs[i] < k) {
+    const uint64_t n1 = (uint64_t)sizes[0] - 1;
+    const uint64_t r = keys[i] / n1, c = keys[i] % n1;
+    out_head[offs[i]] = (int64_t)r;
+    out_tail[offs[i]] = (int64_t)(c + (r <= c ? 1 : 0));
+  }
+  if (i < out_cap && i >= have) {
+    const int64_t n = sizes[0] > 1 ? sizes[0] : 2;
+    out_head[i] = i % n; out_tail[i] = (i + 1) % n;
+  }
+  if (i == 0) *count = have;
+}
+
+// out[i] = src[pi(i) % E] for i < count (pi: keyed bijection of [0, neg_ratio * E)) -- the reference's
+// `edge_type.repeat(neg_ratio)[randperm]` -- and `pad` beyond.
+__global__ __launch_bounds__(256) void permute_gather_dev_kernel(const int64_t* __restrict__ src,
+                                                                 const int64_t* __restrict__ sizes, int64_t neg_ratio,
+                                                                 uint64_t seed, const uint32_t* __restrict__ epoch,
+                                                                 const int64_t* __restrict__ count, int64_t pad,
+                                                                 int64_t out_cap, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= out_cap) return;
+  const int64_t e = sizes[1];
+  if (i >= count[0] || e <= 0) { out[i] = pad; return; }
+  const Feistel pi = make_feistel((uint64_t)(neg_ratio * e), dev_seed(seed, epoch, 2));
+  out[i] = src[pi((uint64_t)i) % (uint64_t)e];
 }
 
 }  // namespace bkg
@@ -187,4 +272,39 @@ extern "C" int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t se
   hipLaunchKernelGGL(permute_gather_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, n,
                      make_feistel((uint64_t)n, seed), out);
   return check_launch("bkg_permute_gather_i64");
+}
+
+extern "C" int64_t bkg_negative_sample_dev_candidates(int64_t max_negatives) {
+  return (int64_t)(1.1 * (double)max_negatives / 0.9) + 64;      // the callers guarantee prob > 0.9
+}
+
+// Device-extent form of bkg_hashset_insert_offdiag + bkg_negative_sample + bkg_permute_gather_i64 for one padded
+// mini-batch: head / tail / type hold `rows` entries of which the first sizes[1] are edges.  table: int64[capacity]
+// scratch (re-filled here); keys / flag / offs: scratch of bkg_negative_sample_dev_candidates(out_cap) entries.
+extern "C" int bkg_negative_sample_dev(const int64_t* sizes, int64_t neg_ratio, const int64_t* head, const int64_t* tail,
+                                       const int64_t* type, int64_t rows, uint64_t seed, const uint32_t* epoch,
+                                       uint64_t* table, int64_t capacity, uint64_t* keys_tmp, int32_t* flag_tmp,
+                                       int32_t* offs_tmp, int64_t out_cap, int64_t type_pad, int64_t* out_head,
+                                       int64_t* out_tail, int64_t* out_type, int64_t* count, void* workspace,
+                                       int64_t workspace_bytes, void* stream) {
+  BKG_ARG(rows > 0 && neg_ratio > 0 && out_cap >= neg_ratio * rows && pow2(capacity) && capacity >= 2 * rows,
+          "bkg_negative_sample_dev: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t cap = bkg_negative_sample_dev_candidates(out_cap);
+  hipError_t e = hipMemsetAsync(table, 0xFF, (size_t)capacity * sizeof(uint64_t), s);
+  if (e != hipSuccess) { set_error("bkg_negative_sample_dev: memset", e); return (int)e; }
+  hipLaunchKernelGGL(hashset_insert_dev_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, s, head, tail, sizes, rows,
+                     reinterpret_cast<unsigned long long*>(table), (uint64_t)capacity - 1);
+  hipLaunchKernelGGL(negative_candidates_dev_kernel, dim3(ceil_div(cap, 256)), dim3(256), 0, s, sizes, neg_ratio, seed,
+                     epoch, cap, reinterpret_cast<const unsigned long long*>(table), (uint64_t)capacity - 1, keys_tmp,
+                     flag_tmp);
+  size_t bytes = (size_t)workspace_bytes;
+  e = rocprim::exclusive_scan(workspace, bytes, flag_tmp, offs_tmp, 0, (size_t)cap, rocprim::plus<int32_t>(), s);
+  if (e != hipSuccess) { set_error("bkg_negative_sample_dev: scan", e); return (int)e; }
+  hipLaunchKernelGGL(negative_scatter_dev_kernel, dim3(ceil_div(cap, 256)), dim3(256), 0, s, keys_tmp, flag_tmp, offs_tmp, cap,
+                     sizes, neg_ratio, out_cap, out_head, out_tail, count);
+  if (out_type)
+    hipLaunchKernelGGL(permute_gather_dev_kernel, dim3(ceil_div(out_cap, 256)), dim3(256), 0, s, type, sizes, neg_ratio, seed,
+                       epoch, count, type_pad, out_cap, out_type);
+  return check_launch("bkg_negative_sample_dev");
 }

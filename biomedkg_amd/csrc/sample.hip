@@ -6,6 +6,8 @@
 // Here the graph's CSRs already live in HBM, so sampling is two small kernels and the batch never leaves
 // the device.  Randomness: Philox4x32-7 keyed by (seed, draw id) -- reproducible per seed, not bit-equal to
 // the host RNG streams of the upstream loaders (their streams cannot be reproduced on a device).
+#include <rocprim/device/device_scan.hpp>
+
 #include "common.h"
 
 namespace bkg {
@@ -24,10 +26,12 @@ __device__ __forceinline__ uint32_t rng_below(uint64_t seed, uint64_t ctr, uint3
 // over the SOURCE-sorted CSR (rowptr/col).  torch-sparse random_walk semantics.
 __global__ void random_walk_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                    const int64_t* __restrict__ start, int64_t n_walks, int walk_length, uint64_t seed,
-                                   int64_t* __restrict__ walks) {
+                                   const uint32_t* __restrict__ epoch, int64_t n_nodes, int64_t* __restrict__ walks) {
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_walks) return;
-  int64_t cur = start[w];
+  if (epoch) seed += (uint64_t)epoch[0] * 0x9E3779B97F4A7C15ull;   // captured replays: a fresh stream per replay
+  // roots: given, or uniform nodes from the same keyed stream (lane id no step uses)
+  int64_t cur = start ? start[w] : (int64_t)rng_below(seed, (uint64_t)w, 0xFFFFFFFFu, (uint32_t)n_nodes);
   walks[w * (walk_length + 1)] = cur;
   for (int s = 0; s < walk_length; ++s) {
     const int beg = rowptr[cur], deg = rowptr[cur + 1] - beg;
@@ -63,6 +67,63 @@ __global__ void sample_neighbors_kernel(const int32_t* __restrict__ rowptr, cons
   for (int j = 0; j < fanout; ++j) out[j] = beg + picked[j];
 }
 
+// ---- GraphSAINT batch = distinct walk nodes (ascending) + ALL edges among them, with no host round trip: every
+// size stays in device memory (sizes[0] = nodes, sizes[1] = edges, sizes[2] = edges with head != tail), the outputs
+// are padded to fixed capacities (node pads = n_nodes, i.e. the zero row appended to the feature table; edge pads =
+// edges INTO the local dummy node `pad_node` -- never a real node -- from sources spread over the local ids and with
+// types spread over [0, pad_types): no row of any structure built over them grows long), so a captured step can
+// replay over them.
+__global__ void saint_mark_kernel(const int64_t* __restrict__ walks, int64_t n, int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[walks[i]] = 1;
+}
+
+__global__ void saint_nodes_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ offs, int64_t n_nodes,
+                                   int64_t node_cap, int32_t* __restrict__ lut, int64_t* __restrict__ n_id,
+                                   int64_t* __restrict__ sizes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = offs[n_nodes - 1] + flag[n_nodes - 1];
+  if (i < n_nodes) {
+    const int p = flag[i] ? offs[i] : -1;
+    lut[i] = p;
+    if (p >= 0 && p < node_cap) n_id[p] = i;
+  }
+  if (i < node_cap && i >= total) n_id[i] = n_nodes;
+  if (i == 0) { sizes[0] = total; sizes[2] = 0; }
+}
+
+__global__ void saint_edge_flags_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t n_edges,
+                                        const int32_t* __restrict__ node_flag, int32_t* __restrict__ eflag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_edges) eflag[i] = node_flag[src[i]] & node_flag[dst[i]];
+}
+
+__global__ void saint_edges_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                   const int64_t* __restrict__ type, int64_t n_edges, const int32_t* __restrict__ eflag,
+                                   const int32_t* __restrict__ offs, const int32_t* __restrict__ lut, int64_t edge_cap,
+                                   int64_t pad_node, int64_t pad_types, int64_t* __restrict__ out_src,
+                                   int64_t* __restrict__ out_dst,
+                                   int64_t* __restrict__ out_type, int64_t* __restrict__ out_eid,
+                                   int64_t* __restrict__ sizes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = offs[n_edges - 1] + eflag[n_edges - 1];
+  if (i < n_edges && eflag[i]) {
+    const int64_t p = offs[i];
+    if (p < edge_cap) {
+      const int64_t s = src[i], d = dst[i];
+      out_src[p] = lut[s];
+      out_dst[p] = lut[d];
+      out_type[p] = type ? type[i] : 0;
+      out_eid[p] = i;
+      if (s != d) atomicAdd(reinterpret_cast<unsigned long long*>(sizes + 2), 1ull);   // integer: order-independent
+    }
+  }
+  if (i < edge_cap && i >= total) {
+    out_src[i] = i % (pad_node + 1); out_dst[i] = pad_node; out_type[i] = i % pad_types; out_eid[i] = -1;
+  }
+  if (i == 0) sizes[1] = total;
+}
+
 }  // namespace bkg
 
 using namespace bkg;
@@ -72,8 +133,50 @@ extern "C" int bkg_random_walk(const int32_t* rowptr, const int32_t* col, const 
   BKG_ARG(n_walks >= 0 && walk_length >= 0, "bkg_random_walk: bad sizes");
   if (n_walks == 0) return 0;
   hipLaunchKernelGGL(random_walk_kernel, dim3(ceil_div(n_walks, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col,
-                     start, n_walks, walk_length, seed, walks);
+                     start, n_walks, walk_length, seed, (const uint32_t*)nullptr, (int64_t)0, walks);
   return check_launch("bkg_random_walk");
+}
+
+extern "C" int64_t bkg_saint_batch_workspace_bytes(int64_t n_nodes, int64_t n_edges) {
+  size_t a = 0, b = 0;
+  rocprim::exclusive_scan(nullptr, a, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)n_nodes, rocprim::plus<int32_t>());
+  rocprim::exclusive_scan(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)n_edges, rocprim::plus<int32_t>());
+  return (int64_t)(a > b ? a : b) + 256;
+}
+
+// One GraphSAINT random-walk batch, entirely on the device (see the kernels above).  node_flag / node_offs / lut:
+// int32[n_nodes] scratch (lut = local id or -1 survives the call); edge_flag / edge_offs: int32[n_edges] scratch.
+extern "C" int bkg_saint_batch(const int32_t* rowptr, const int32_t* col, const int64_t* start, int64_t n_walks,
+                               int32_t walk_length, uint64_t seed, const uint32_t* epoch, int64_t* walks,
+                               const int64_t* src, const int64_t* dst, const int64_t* type, int64_t n_nodes,
+                               int64_t n_edges, int32_t* node_flag, int32_t* node_offs, int32_t* lut, int32_t* edge_flag,
+                               int32_t* edge_offs, int64_t node_cap, int64_t edge_cap, int64_t pad_node, int64_t pad_types, int64_t* n_id,
+                               int64_t* out_src, int64_t* out_dst, int64_t* out_type, int64_t* out_eid, int64_t* sizes,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+  BKG_ARG(n_walks > 0 && walk_length >= 0 && n_nodes > 0 && n_edges > 0 && node_cap > 0 && edge_cap > 0 && pad_types > 0 &&
+              n_nodes < (1ll << 31) && n_edges < (1ll << 31), "bkg_saint_batch: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_entries = n_walks * (walk_length + 1);
+  hipLaunchKernelGGL(random_walk_kernel, dim3(ceil_div(n_walks, 256)), dim3(256), 0, s, rowptr, col, start, n_walks,
+                     walk_length, seed, epoch, n_nodes, walks);
+  hipError_t e = hipMemsetAsync(node_flag, 0, (size_t)n_nodes * sizeof(int32_t), s);
+  if (e != hipSuccess) { set_error("bkg_saint_batch: memset", e); return (int)e; }
+  hipLaunchKernelGGL(saint_mark_kernel, dim3(ceil_div(n_entries, 256)), dim3(256), 0, s, walks, n_entries, node_flag);
+  size_t bytes = (size_t)workspace_bytes;
+  e = rocprim::exclusive_scan(workspace, bytes, node_flag, node_offs, 0, (size_t)n_nodes, rocprim::plus<int32_t>(), s);
+  if (e != hipSuccess) { set_error("bkg_saint_batch: node scan", e); return (int)e; }
+  const int64_t tn = n_nodes > node_cap ? n_nodes : node_cap;
+  hipLaunchKernelGGL(saint_nodes_kernel, dim3(ceil_div(tn, 256)), dim3(256), 0, s, node_flag, node_offs, n_nodes, node_cap,
+                     lut, n_id, sizes);
+  hipLaunchKernelGGL(saint_edge_flags_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, src, dst, n_edges, node_flag,
+                     edge_flag);
+  bytes = (size_t)workspace_bytes;
+  e = rocprim::exclusive_scan(workspace, bytes, edge_flag, edge_offs, 0, (size_t)n_edges, rocprim::plus<int32_t>(), s);
+  if (e != hipSuccess) { set_error("bkg_saint_batch: edge scan", e); return (int)e; }
+  const int64_t te = n_edges > edge_cap ? n_edges : edge_cap;
+  hipLaunchKernelGGL(saint_edges_kernel, dim3(ceil_div(te, 256)), dim3(256), 0, s, src, dst, type, n_edges, edge_flag,
+                     edge_offs, lut, edge_cap, pad_node, pad_types, out_src, out_dst, out_type, out_eid, sizes);
+  return check_launch("bkg_saint_batch");
 }
 
 extern "C" int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* frontier, int64_t n_frontier, int32_t fanout,

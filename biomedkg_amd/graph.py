@@ -153,9 +153,12 @@ class RelGraph:
     point at segments with weight 1/|segment|.
     """
 
-    def __init__(self, edge_index, edge_type, num_nodes, num_relations, n_src=None):
+    def __init__(self, edge_index, edge_type, num_nodes, num_relations, n_src=None, static_segments=False):
         """``n_src``: number of SOURCE rows when they live in another index space than the ``num_nodes`` targets (a
-        node-partitioned graph: sources are slots of the all-gathered table, targets the rank's own nodes)."""
+        node-partitioned graph: sources are slots of the all-gathered table, targets the rank's own nodes).
+        ``static_segments`` (padded mini-batches of a captured step, biomedkg_amd/sampled.py): no host read of the
+        segment count -- the structure always carries ``E`` segments, the ones past the real count are EMPTY rows of
+        the last relation, their targets spread over the nodes: zero rows in, zeros added."""
         L.require_cuda(edge_index, edge_type)
         self.edge_index = edge_index.contiguous()
         self.edge_type = edge_type.contiguous()
@@ -172,10 +175,13 @@ class RelGraph:
         seg_ptr, seg_dst, seg_rel = _i32(e + 1, dev), _i32(e, dev), _i32(e, dev)
         self.inv_cnt = torch.empty(e, dtype=torch.float32, device=dev)   # per sorted edge
         n_seg = torch.zeros(1, dtype=torch.int32, device=dev)
+        if static_segments:      # surplus segments: empty, last relation, targets spread over the nodes (they add zeros)
+            seg_ptr.fill_(e); seg_rel.fill_(r - 1)
+            seg_dst.copy_(_spread_pattern(e, n, dev))
         L.call("bkg_rgcn_segments", L.ptr(sorted_keys), e, n, L.ptr(flag), L.ptr(scan), L.ptr(self.seg_of),
                L.ptr(seg_ptr), L.ptr(seg_dst), L.ptr(seg_rel), L.ptr(self.inv_cnt), L.ptr(n_seg), L.ptr(ws),
                ws.numel(), L.stream())
-        self.num_segments = int(n_seg.item())   # one host sync per distinct graph (sizes H)
+        self.num_segments = e if static_segments else int(n_seg.item())   # one host sync per distinct graph (sizes H)
         s = self.num_segments
         self.seg_ptr, self.seg_dst, self.seg_rel = seg_ptr[: s + 1], seg_dst[:s], seg_rel[:s]
         # segment ranges per relation (segments are sorted by (rel, dst))
@@ -193,6 +199,16 @@ class RelGraph:
         self.src_w = self.src_csr.permute_f32(w_edge)
         self.seg_iota_ptr = torch.arange(s + 1, dtype=torch.int32, device=dev)
         self.seg_split = rowsplit_for(self.seg_ptr, s, e)
+
+
+_PATTERNS = {}
+
+
+def _spread_pattern(count, modulus, device):
+    key = (count, modulus, str(device))
+    if key not in _PATTERNS:
+        _PATTERNS[key] = (torch.arange(count, device=device) % modulus).to(torch.int32)
+    return _PATTERNS[key]
 
 
 def _cached(t, slot, key, build):
@@ -216,3 +232,11 @@ def graph_of(edge_index, num_nodes) -> Graph:
 def rel_graph_of(edge_index, edge_type, num_nodes, num_relations) -> RelGraph:
     key = (int(num_nodes), int(num_relations), edge_type.data_ptr(), edge_type._version)
     return _cached(edge_index, "rgcn", key, lambda: RelGraph(edge_index, edge_type, num_nodes, num_relations))
+
+
+def plant_rel_graph(rg: RelGraph):
+    """Make ``rel_graph_of(rg.edge_index, rg.edge_type, ...)`` return this (already built) structure."""
+    ei, et = rg.edge_index, rg.edge_type
+    key = (int(rg.num_nodes), int(rg.num_relations), et.data_ptr(), et._version)
+    _cached(ei, "rgcn", key, lambda: rg)
+    return rg

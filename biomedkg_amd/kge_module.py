@@ -95,7 +95,7 @@ class KGEModule(LightningModule):
         dec = self.model.decoder
         loss, pos_pred, neg_pred = ops.kge_bce_loss(z, dec.rel_emb, batch.edge_index, batch.edge_type, neg_edge_index,
                                                     neg_edge_type, dec.kind, reg=1e-2)     # BCE + 1e-2 (mean z^2 + mean rel^2)
-        self._last_scores = (z, pos_pred, neg_pred)
+        self._last_scores = (z.detach(), pos_pred, neg_pred)      # (detached: must not keep the step's autograd graph alive)
         return loss
 
     def training_step(self, batch, batch_idx=None):

@@ -30,6 +30,7 @@ def get_matmul_precision() -> str:
 
 
 _DET_WS = None
+_DET_RETIRED = []     # outgrown workspaces stay allocated: captured graphs may still hold their address
 
 
 def set_deterministic(on: bool, workspace_floats: int = 1 << 26):
@@ -42,6 +43,8 @@ def set_deterministic(on: bool, workspace_floats: int = 1 << 26):
         if not torch.cuda.is_available():
             raise L.HipLibraryError("deterministic mode needs the GPU workspace")
         if _DET_WS is None or _DET_WS.numel() < workspace_floats:
+            if _DET_WS is not None:
+                _DET_RETIRED.append(_DET_WS)
             _DET_WS = torch.empty(workspace_floats, dtype=torch.float32, device="cuda")
         L.call("bkg_set_deterministic_workspace", L.ptr(_DET_WS), _DET_WS.numel())
     else:
@@ -200,7 +203,8 @@ def gemm_grouped_k(a, b, group_ptr, num_groups, b_rows=None):
     L.require_cuda(a, b, group_ptr, b_rows)
     _follow_torch_determinism()
     m, n = a.size(1), b.size(1)
-    _det_reserve((a.size(0) // 512 + num_groups + 1) * m * n)       # chunks of >= 512 rows, one partial chunk per group
+    chunk = L.lib().bkg_gemm_grouped_k_chunk(a.size(0), m, n, _PRECISION) if _PRECISION == 0 else 512
+    _det_reserve((a.size(0) // chunk + num_groups + 1) * m * n)     # full chunks + one partial chunk per group
     out = torch.zeros(num_groups, m, n, dtype=torch.float32, device=a.device)
     if b_rows is not None and not gathered_k_ok(a, b):
         raise ValueError("gathered rows need two bf16 tables with 128-aligned widths (bf16 mode)")
@@ -906,11 +910,14 @@ class _KgeBceLoss(torch.autograd.Function):
     segment reduce for dz.  Returns ``(loss, pos_pred, neg_pred)``; the preds are detached outputs."""
 
     @staticmethod
-    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total, reg):
+    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total, reg, inv_total):
         d, r = z.size(1), rel_emb.size(0)
         t_pos, t_neg = pos_ei.size(1), neg_ei.size(1)
         if total is None:
             total = t_pos + t_neg
+        # padded mini-batches (biomedkg_amd/sampled.py): ``inv_total`` is a DEVICE scalar, pad triplets carry the
+        # relation id ``r`` -- one group past the real ones, which no wave visits -- and their records stay zero
+        padded = inv_total is not None
         dev = z.device
         drel = torch.zeros_like(rel_emb)
         # bf16 mode: both passes gather the node rows from a bf16 copy of z (half the bytes; fp32 accumulate)
@@ -925,19 +932,22 @@ class _KgeBceLoss(torch.autograd.Function):
         for ei, et, label in ((pos_ei, pos_et, 1.0), (neg_ei, neg_et, 0.0)):
             t = ei.size(1)
             s = torch.empty(t, dtype=torch.float32, device=dev)
-            rec = torch.empty(t, 4, dtype=torch.int32, device=dev) if (pack and t) else None
-            g = torch.empty(t if rec is None else 0, dtype=torch.float32, device=dev)   # g travels inside rec when packed
+            new = torch.zeros if padded else torch.empty
+            rec = new(t, 4, dtype=torch.int32, device=dev) if (pack and t) else None
+            g = new(t if rec is None else 0, dtype=torch.float32, device=dev)   # g travels inside rec when packed
             recs.append(rec)
             if t:
-                order, rel_ptr = relation_order_of(et, r)
+                order, rel_ptr = relation_order_of(et, r + 1 if padded else r)
+                if padded:
+                    rel_ptr = rel_ptr[: r + 1]
                 waves = L.lib().bkg_kge_fused_bce_waves(t, r)
-                part = torch.empty(waves, dtype=torch.float32, device=dev)
+                part = new(waves, dtype=torch.float32, device=dev)
                 drel_part = torch.empty(waves, d, dtype=torch.float32, device=dev)
                 wave_ptr, wave_iota, wave_split = _relation_waves(et, rel_ptr, r, waves)
-                L.call("bkg_kge_fused_bce_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]), t,
-                       label, 1.0 / total, L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order), L.ptr(rel_ptr), L.ptr(s),
-                       L.ptr(g) if rec is None else None, L.ptr(rec), L.ptr(part), L.ptr(drel_part), drel_part.stride(0),
-                       L.stream())
+                L.call("bkg_kge_fused_bce_dev_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]),
+                       t, label, 1.0 / total, L.ptr(inv_total), L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order),
+                       L.ptr(rel_ptr), L.ptr(s), L.ptr(g) if rec is None else None, L.ptr(rec), L.ptr(part),
+                       L.ptr(drel_part), drel_part.stride(0), L.stream())
                 loss = loss + part.double().sum()
                 # per-relation sum of the waves' partial rows (consecutive waves; fixed order; no atomics)
                 drel = drel + spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
@@ -947,7 +957,7 @@ class _KgeBceLoss(torch.autograd.Function):
         ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
         ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1], z if reg else None)
         ctx.mark_non_differentiable(scores[0], scores[1])
-        loss = loss / total
+        loss = (loss * inv_total.double()).reshape(()) if padded else loss / total
         if reg:      # + reg * (mean(z^2) + mean(rel_emb^2)), reference kge_module.py:128-129: two one-launch norms
             loss = loss + reg * (torch.linalg.vector_norm(z).double().pow(2) / z.numel()
                                  + torch.linalg.vector_norm(rel_emb).double().pow(2) / rel_emb.numel())
@@ -996,19 +1006,22 @@ class _KgeBceLoss(torch.autograd.Function):
             drel_out = drel * gloss
             if ctx.reg:
                 drel_out = torch.addcmul(drel_out, rel_emb, gloss * (2.0 * ctx.reg / rel_emb.numel()))
-        return dz, drel_out, None, None, None, None, None, None, None, None
+        return dz, drel_out, None, None, None, None, None, None, None, None, None
 
 
 def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind, comm=None, total=None,
-                 reg=0.0):
+                 reg=0.0, inv_total=None):
     """``comm`` (node-partitioned training, biomedkg_amd/partition.py): ``z`` is the rank's shard, the triplet ids are
     slots of the all-gathered table; ``total``: the count the BCE sum is divided by (default: this call's triplets);
     ``reg``: adds ``reg * (mean(z^2) + mean(rel_emb^2))`` (the reference's L2 term) inside the same op."""
-    L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type)
+    L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, inv_total)
     if reg and comm is not None:
         raise ValueError("the L2 term of a partitioned step is scaled by the caller (partition.kge_loss_partitioned)")
+    if inv_total is not None and (reg or comm is not None or inv_total.dtype != torch.float32):
+        raise ValueError("inv_total (padded mini-batches): a float32 device scalar; no reg / comm on that path")
     return _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
-                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, comm, total, float(reg))
+                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, comm, total, float(reg),
+                             inv_total)
 
 
 # ----------------------------------------------------------------------------- NT-Xent

@@ -123,8 +123,22 @@ class Trainer:
         (biomedkg_amd/graphs.py) when the module's step has no host-side draws (GRACE); otherwise stay eager.  Off with
         BKG_HIPGRAPH=0, for multi-rank runs (the gradient all-reduce is not part of the capture) and under fast_dev_run."""
         batch = getattr(loader, "batch", None)
-        if (batch is None or self.world > 1 or self.fast_dev_run or os.environ.get("BKG_HIPGRAPH", "1") == "0"
+        if (self.world > 1 or self.fast_dev_run or os.environ.get("BKG_HIPGRAPH", "1") == "0"
                 or self.device.type != "cuda"):
+            return None
+        from .samplers import SaintBatchLoader
+        if isinstance(loader, SaintBatchLoader) and getattr(getattr(model, "model", None), "decoder", None) is not None \
+                and getattr(model.model.decoder, "kind", None) is not None:
+            # the reference's KGE regime (GraphSAINT batches): padded sync-free batches, one graph per edge bucket
+            from .sampled import SaintGraphedKge
+            sm = loader.sampler
+            loop = SaintGraphedKge(model, loader.x, sm.edge_index, loader.edge_type, sm.batch_size, sm.walk_length, opt,
+                                   clip=self.clip, seed=sm.seed)
+            step = loop.step
+            step_fn = lambda: step()      # noqa: E731
+            step_fn.loop, step_fn.owns_batches, step_fn.warmup_steps = loop, True, 0
+            return step_fn
+        if batch is None:
             return None
         from . import graphs
         state = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -186,7 +200,10 @@ class Trainer:
             self.current_epoch = epoch
             model.train()
             t0 = time.time()
-            for i, batch in self._limit(train_dataloaders):
+            batches = self._limit(train_dataloaders)
+            if graphed is not None and getattr(graphed, "owns_batches", False):
+                batches = ((i, None) for i in range(len(train_dataloaders)))      # the graphed loop samples for itself
+            for i, batch in batches:
                 if graphed is not None:            # one hipGraph replay = zero_grad + step + backward + clip + Adam
                     loss = graphed()
                     if self.global_step % max(1, self.log_every) == 0:

@@ -133,7 +133,9 @@ int bkg_gemm_grouped_rows_f32(int32_t trans_b, int64_t M_total, int64_t N, int64
                               const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                               const int32_t* group_ptr, int32_t G, const float* gate, int64_t ldg, float gate_scale,
                               int32_t precision, void* stream);
-/* C[g] += A[rows g]^T B[rows g] (C zeroed by the caller; split over row chunks, f32 atomics) */
+/* C[g] += A[rows g]^T B[rows g] (C zeroed by the caller; split over row chunks of bkg_gemm_grouped_k_chunk rows, f32
+ * atomics -- or, in deterministic mode, one workspace slab per chunk: rows_total / chunk + G + 1 slabs at most) */
+int32_t bkg_gemm_grouped_k_chunk(int64_t rows_total, int64_t M, int64_t N, int32_t precision);
 int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, const float* A, int64_t lda, const float* B,
                            int64_t ldb, float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int32_t G,
                            int32_t precision, void* stream);
@@ -167,6 +169,14 @@ int bkg_kge_fused_bce_f32(int32_t kind, const void* z /* fp32 or bf16 table */, 
                           float* g /* nullable when rec is given */,
                           void* rec /* nullable int32[T][4]: {head, tail, rel, bits(g)} for the backward */,
                           float* loss_part, float* drel, int64_t lddr, void* stream);
+/* The same pass for the padded mini-batches of a captured step: 1 / total is read from device memory when
+ * inv_total_dev is given, and triplets whose relation group lies past n_rel in rel_ptr (the pads' sentinel id) are
+ * never visited. */
+int bkg_kge_fused_bce_dev_f32(int32_t kind, const void* z, int32_t z_is_bf16, int64_t ldz, int32_t d,
+                              const int64_t* head, const int64_t* tail, int64_t T, float label, float inv_total,
+                              const float* inv_total_dev /* nullable */, const float* rel_emb, int64_t ldr, int32_t n_rel,
+                              const int32_t* order, const int32_t* rel_ptr, float* score, float* g, void* rec,
+                              float* loss_part, float* drel, int64_t lddr, void* stream);
 /* drel[r] += sum_t ... (drel zeroed by the caller); order/rel_ptr (nullable together) = triplet ids sorted by
  * relation and the [n_rel+1] offsets of each relation in that order */
 int bkg_kge_bwd_rel_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, const int64_t* head, const int64_t* tail,
@@ -221,6 +231,24 @@ int bkg_random_walk(const int32_t* rowptr, const int32_t* col, const int64_t* st
                     int32_t walk_length, uint64_t seed, int64_t* walks, void* stream);
 int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* frontier, int64_t n_frontier, int32_t fanout,
                          uint64_t seed, uint32_t hop, int32_t* out_pos, void* stream);
+/* One whole GraphSAINT random-walk batch (GraphSAINTRandomWalkSampler, biomedkg/data_module.py:100-107) with no host
+ * round trip: walks from start[] (NULL: uniform roots drawn from the keyed stream), node set = distinct visited nodes in ascending order, edge set = ALL edges among them
+ * in edge order, relabelled.  Sizes stay on the device: sizes[0] = nodes, sizes[1] = edges, sizes[2] = edges with
+ * head != tail.  Outputs are padded to fixed capacities so that a captured (hipGraph) step can replay over them:
+ * n_id[node_cap] (pads = n_nodes, the zero row the caller appends to the feature table), out_src / out_dst / out_type /
+ * out_eid[edge_cap] (pads = edges into `pad_node`, the batch's dummy local node, from sources i % (pad_node + 1) with
+ * types i % pad_types and eid -1 -- spread so that no row of a structure built over them grows long; edges past
+ * edge_cap are dropped -- the caller compares sizes[1] with edge_cap).  epoch (nullable): device replay counter mixed into the walk seed.
+ * Scratch: node_flag / node_offs / lut int32[n_nodes] (lut = local id or -1 survives), edge_flag / edge_offs
+ * int32[n_edges], workspace of bkg_saint_batch_workspace_bytes. */
+int64_t bkg_saint_batch_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int bkg_saint_batch(const int32_t* rowptr, const int32_t* col, const int64_t* start, int64_t n_walks,
+                    int32_t walk_length, uint64_t seed, const uint32_t* epoch, int64_t* walks, const int64_t* src,
+                    const int64_t* dst, const int64_t* type /* nullable */, int64_t n_nodes, int64_t n_edges,
+                    int32_t* node_flag, int32_t* node_offs, int32_t* lut, int32_t* edge_flag, int32_t* edge_offs,
+                    int64_t node_cap, int64_t edge_cap, int64_t pad_node, int64_t pad_types, int64_t* n_id, int64_t* out_src,
+                    int64_t* out_dst, int64_t* out_type, int64_t* out_eid, int64_t* sizes, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 /* ---- ranking evaluation (filtered MRR / Hits@k for DistMult; build-defined: the reference has no ranking metric,
  *      BASELINE.json's north_star asks for one).  q [n_q, h] = z[anchor] * rel[r]; z [n_nodes, h] candidates, h <= 256.
@@ -278,6 +306,20 @@ int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int64_t n_cand
                         int32_t* offs_tmp, int64_t* out_head, int64_t* out_tail, int64_t out_offset, int64_t max_out,
                         int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
 int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t seed, int64_t* out, void* stream);
+/* The sampler of biomedkg/kge_module.py:86-102 for one PADDED mini-batch with every extent in device memory (sizes as
+ * written by bkg_saint_batch; head / tail / type hold `rows` entries, the first sizes[1] are edges): hash set of the
+ * positives, ONE round of int(1.1 k / prob) candidates (k = neg_ratio * sizes[1]; the caller has checked prob > 0.9, so
+ * PyG's later rounds never run), the first k survivors in candidate order -> out_head / out_tail[out_cap], *count =
+ * how many (slots past it hold pairs spread over the batch's nodes); out_type (nullable) = type[pi(i) % E] for i < count (edge_type.repeat(neg_ratio)
+ * [randperm]) and type_pad beyond.  epoch (nullable): device replay counter mixed into the keys.  Scratch: table
+ * uint64[capacity >= 2 rows, power of two], keys / flag / offs of bkg_negative_sample_dev_candidates(out_cap) entries,
+ * workspace of bkg_negative_sample_workspace_bytes(that many). */
+int64_t bkg_negative_sample_dev_candidates(int64_t max_negatives);
+int bkg_negative_sample_dev(const int64_t* sizes, int64_t neg_ratio, const int64_t* head, const int64_t* tail,
+                            const int64_t* type, int64_t rows, uint64_t seed, const uint32_t* epoch, uint64_t* table,
+                            int64_t capacity, uint64_t* keys_tmp, int32_t* flag_tmp, int32_t* offs_tmp, int64_t out_cap,
+                            int64_t type_pad, int64_t* out_head, int64_t* out_tail, int64_t* out_type /* nullable */,
+                            int64_t* count, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- modality fusion epilogues (biomedkg/utils/fusion.py:17-31 AttentionFusion, :49-90 ReDAF) */
 int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_t D, float* out, int64_t ldo,
