@@ -38,6 +38,7 @@ SIGNATURES = {
     "bkg_gather_f32": (I32, [P, P, P, I64, P]),
     "bkg_gcn_norm": (I32, [P, P, P, P, P, P, I64, I64, P, P, P, P]),
     "bkg_rgcn_segments": (I32, [P, I64, I64, P, P, P, P, P, P, P, P, P, I64, P]),
+    "bkg_rgcn_edge_order": (I32, [P, P, P, I64, P, P, P]),
     # spmm.hip
     "bkg_rowsplit_build": (I32, [P, I64, I64, I32, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
     "bkg_cast_f32_bf16": (I32, [P, P, F32, P, I64, P]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "bkg_kge_fused_bce_waves": (I64, [I64, I32]),
     "bkg_kge_fused_bce_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
     "bkg_kge_fused_bce_dev_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
+    "bkg_relation_wave_ptr": (I32, [P, I32, I32, P, P]),
     "bkg_kge_bwd_rel_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, I32, P, I64, P, P, P]),
     # ntxent.hip
     "bkg_ntxent_hpad": (I32, [I32, I32]),

@@ -139,6 +139,18 @@ __global__ void segment_inv_count_kernel(const int32_t* __restrict__ seg_of, con
   w[i] = 1.0f / (float)(seg_ptr[s + 1] - seg_ptr[s]);
 }
 
+// sorted-edge attributes back in ORIGINAL edge order: seg_of_edge[perm[k]] = seg_of[k] (int64: it becomes the column
+// of the source-side CSR), w_edge[perm[k]] = inv_cnt[k]
+__global__ void edge_order_kernel(const uint32_t* __restrict__ perm, const int32_t* __restrict__ seg_of,
+                                  const float* __restrict__ inv_cnt, int64_t n, int64_t* __restrict__ seg_of_edge,
+                                  float* __restrict__ w_edge) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t e = perm[k];
+  seg_of_edge[e] = seg_of[k];
+  w_edge[e] = inv_cnt[k];
+}
+
 static inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
 
 }  // namespace bkg
@@ -231,4 +243,11 @@ extern "C" int bkg_rgcn_segments(const uint32_t* sorted, int64_t n, int64_t n_no
   hipLaunchKernelGGL(segment_fill_kernel, grid1(n), dim3(256), 0, s, sorted, scan_tmp, n, (uint32_t)n_nodes, seg_of, seg_ptr, seg_dst, seg_rel, n_seg);
   hipLaunchKernelGGL(segment_inv_count_kernel, grid1(n), dim3(256), 0, s, seg_of, seg_ptr, n, inv_cnt);
   return check_launch("bkg_rgcn_segments");
+}
+
+extern "C" int bkg_rgcn_edge_order(const uint32_t* perm, const int32_t* seg_of, const float* inv_cnt, int64_t n,
+                                   int64_t* seg_of_edge, float* w_edge, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(edge_order_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, perm, seg_of, inv_cnt, n, seg_of_edge, w_edge);
+  return check_launch("bkg_rgcn_edge_order");
 }

@@ -175,9 +175,27 @@ __global__ __launch_bounds__(256) void kge_fused_bce_kernel(const T* __restrict_
   if (lane == 0) loss_part[wave_id] = loss_acc;
 }
 
+// wave_ptr[r] = first wave of relation r in the fused pass (relation r owns ceil(cnt_r / chunk) consecutive waves)
+__global__ void relation_wave_ptr_kernel(const int32_t* __restrict__ rel_ptr, int n_rel, int chunk,
+                                         int32_t* __restrict__ wave_ptr) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int acc = 0;
+  for (int r = 0; r < n_rel; ++r) {
+    wave_ptr[r] = acc;
+    acc += (rel_ptr[r + 1] - rel_ptr[r] + chunk - 1) / chunk;
+  }
+  wave_ptr[n_rel] = acc;
+}
+
 }  // namespace bkg
 
 using namespace bkg;
+
+extern "C" int bkg_relation_wave_ptr(const int32_t* rel_ptr, int32_t n_rel, int32_t chunk, int32_t* wave_ptr, void* stream) {
+  BKG_ARG(n_rel > 0 && chunk > 0, "bkg_relation_wave_ptr: bad sizes");
+  hipLaunchKernelGGL(relation_wave_ptr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rel_ptr, n_rel, chunk, wave_ptr);
+  return check_launch("bkg_relation_wave_ptr");
+}
 
 extern "C" int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel) {
   return ((T + 63) / 64 + n_rel + 3) / 4 * 4;

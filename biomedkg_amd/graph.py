@@ -189,15 +189,15 @@ class RelGraph:
         seg_rel_u = self.seg_rel.contiguous()
         L.call("bkg_lower_bound_u32", L.ptr(seg_rel_u), s, r + 1, 1, L.ptr(self.rel_ptr), L.stream())
         # target -> its segments
-        self.dst_csr = CSR(self.seg_dst.to(torch.int64), torch.arange(s, device=dev), n)
+        self.dst_csr = CSR(self.seg_dst.to(torch.int64), _iota64(s, dev), n)
         # source -> (segment, 1/|segment|) of each out-edge
         seg_of_edge = torch.empty(e, dtype=torch.int64, device=dev)
-        seg_of_edge[perm.long()] = self.seg_of.long()
         w_edge = torch.empty(e, dtype=torch.float32, device=dev)
-        w_edge[perm.long()] = self.inv_cnt
+        L.call("bkg_rgcn_edge_order", L.ptr(perm), L.ptr(self.seg_of), L.ptr(self.inv_cnt), e, L.ptr(seg_of_edge),
+               L.ptr(w_edge), L.stream())
         self.src_csr = CSR(src, seg_of_edge, n if n_src is None else int(n_src))
         self.src_w = self.src_csr.permute_f32(w_edge)
-        self.seg_iota_ptr = torch.arange(s + 1, dtype=torch.int32, device=dev)
+        self.seg_iota_ptr = _spread_pattern(s + 1, 1 << 62, dev)     # 0 .. s (cached per size)
         self.seg_split = rowsplit_for(self.seg_ptr, s, e)
 
 
@@ -208,6 +208,13 @@ def _spread_pattern(count, modulus, device):
     key = (count, modulus, str(device))
     if key not in _PATTERNS:
         _PATTERNS[key] = (torch.arange(count, device=device) % modulus).to(torch.int32)
+    return _PATTERNS[key]
+
+
+def _iota64(count, device):
+    key = (count, "i64", str(device))
+    if key not in _PATTERNS:
+        _PATTERNS[key] = torch.arange(count, device=device)
     return _PATTERNS[key]
 
 

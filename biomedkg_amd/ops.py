@@ -366,7 +366,8 @@ def _plain_dropout_keep(relu, drop):
 
 def _gate(dout, out, scale):
     """Backward of ``dropout(relu(.))`` from the saved OUTPUT: ``out > 0`` iff pre > 0 and kept."""
-    return torch.where(out > 0, dout * scale, torch.zeros((), dtype=dout.dtype, device=dout.device))
+    g = torch.ops.aten.threshold_backward(dout, out, 0.0)        # dout where out > 0, else 0 (one launch)
+    return g.mul_(scale) if scale != 1.0 else g
 
 
 # ----------------------------------------------------------------------------- Linear
@@ -889,6 +890,24 @@ _KGE_PIECES = (2, 4, 6, 8, 12, 16, 24, 32, 64, 96, 128, 192)   # csrc/rowpiece.h
 _FUSED_CHUNK = 64   # triplets per wave of csrc/kge_fused.hip
 
 
+_IOTA32 = {}
+_FEW_WAVES = 1 << 14     # below this the per-relation reduce of the waves' rows needs no long-row table
+
+
+def _iota32(n, device):
+    key = (int(n), str(device))
+    if key not in _IOTA32:
+        _IOTA32[key] = torch.arange(int(n), dtype=torch.int32, device=device)
+    return _IOTA32[key]
+
+
+def _relation_waves_small(rel_ptr, num_relations, n_waves):
+    """The same wave CSR for a mini-batch's few waves: one launch, no long-row table, nothing cached."""
+    wave_ptr = torch.empty(num_relations + 1, dtype=torch.int32, device=rel_ptr.device)
+    L.call("bkg_relation_wave_ptr", L.ptr(rel_ptr), num_relations, _FUSED_CHUNK, L.ptr(wave_ptr), L.stream())
+    return wave_ptr, _iota32(n_waves, rel_ptr.device), None
+
+
 def _relation_waves(edge_type, rel_ptr, num_relations, n_waves):
     """Wave ranges of each relation in the fused pass (relation r owns ceil(cnt_r / 64) consecutive waves) as a
     CSR over wave rows + its long-row table, cached with the relation order on ``edge_type``."""
@@ -903,6 +922,15 @@ def _relation_waves(edge_type, rel_ptr, num_relations, n_waves):
     return _cached(edge_type, "rel_waves", (int(num_relations), int(n_waves)), build)
 
 
+def kge_prepare_structures(pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, num_nodes, num_groups):
+    """Build (and cache on the tensors) what ``kge_bce_loss`` and its backward look up for these triplets -- the
+    relation orders and the node incidence lists -- ahead of time, e.g. on a side stream while the encoder runs."""
+    for ei, et in ((pos_edge_index, pos_edge_type), (neg_edge_index, neg_edge_type)):
+        if ei.size(1):
+            relation_order_of(et, num_groups)
+            incidence_of(ei, num_nodes)
+
+
 class _KgeBceLoss(torch.autograd.Function):
     """``binary_cross_entropy_with_logits(cat(decode(pos), decode(neg)), cat(1, 0))`` of the reference's
     ``KGEModule.training_step`` (kge_module.py:121-127) as ONE op: the forward sweeps each triplet set once
@@ -910,7 +938,7 @@ class _KgeBceLoss(torch.autograd.Function):
     segment reduce for dz.  Returns ``(loss, pos_pred, neg_pred)``; the preds are detached outputs."""
 
     @staticmethod
-    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total, reg, inv_total):
+    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total, reg, inv_total, rows):
         d, r = z.size(1), rel_emb.size(0)
         t_pos, t_neg = pos_ei.size(1), neg_ei.size(1)
         if total is None:
@@ -919,48 +947,64 @@ class _KgeBceLoss(torch.autograd.Function):
         # relation id ``r`` -- one group past the real ones, which no wave visits -- and their records stay zero
         padded = inv_total is not None
         dev = z.device
-        drel = torch.zeros_like(rel_emb)
         # bf16 mode: both passes gather the node rows from a bf16 copy of z (half the bytes; fp32 accumulate)
         zt = to_bf16(z) if (bf16_storage() and d % 8 == 0 and (d // 8) in _KGE_PIECES) else z
         if comm is not None:              # node-partitioned: the scorer reads the all-gathered table (triplet ids = slots)
             zt = comm.all_gather(zt)
         n = zt.size(0)
         zt_bf16 = int(zt.dtype == torch.bfloat16)
-        scores, grads, recs, loss = [], [], [], torch.zeros((), dtype=torch.float64, device=dev)
+        scores, grads, recs, drel = [], [], [], None
         # packed {head, tail, rel, g} per triplet for the node-side backward (ids fit int32; one gather instead of four)
         pack = bool(ctx.needs_input_grad[0]) and n < (1 << 31) and r < (1 << 31)
-        for ei, et, label in ((pos_ei, pos_et, 1.0), (neg_ei, neg_et, 0.0)):
+        if padded and not pack:
+            raise ValueError("padded triplets need the packed gradient records (z must require grad)")
+        sets = ((pos_ei, pos_et, 1.0), (neg_ei, neg_et, 0.0))
+        n_waves = [L.lib().bkg_kge_fused_bce_waves(ei.size(1), r) if ei.size(1) else 0 for ei, _, _ in sets]
+        part = torch.empty(sum(n_waves), dtype=torch.float32, device=dev)      # every wave of a launch writes its slot
+        new = torch.zeros if padded else torch.empty
+        rec_all = new(t_pos + t_neg, 4, dtype=torch.int32, device=dev) if pack else None
+        w0 = t0 = 0
+        for (ei, et, label), waves in zip(sets, n_waves):
             t = ei.size(1)
             s = torch.empty(t, dtype=torch.float32, device=dev)
-            new = torch.zeros if padded else torch.empty
-            rec = new(t, 4, dtype=torch.int32, device=dev) if (pack and t) else None
-            g = new(t if rec is None else 0, dtype=torch.float32, device=dev)   # g travels inside rec when packed
+            rec = rec_all[t0:t0 + t] if (pack and t) else None
+            g = torch.empty(t if rec is None else 0, dtype=torch.float32, device=dev)   # g travels inside rec when packed
             recs.append(rec)
             if t:
                 order, rel_ptr = relation_order_of(et, r + 1 if padded else r)
                 if padded:
                     rel_ptr = rel_ptr[: r + 1]
-                waves = L.lib().bkg_kge_fused_bce_waves(t, r)
-                part = new(waves, dtype=torch.float32, device=dev)
                 drel_part = torch.empty(waves, d, dtype=torch.float32, device=dev)
-                wave_ptr, wave_iota, wave_split = _relation_waves(et, rel_ptr, r, waves)
+                if waves <= _FEW_WAVES:
+                    wave_ptr, wave_iota, wave_split = _relation_waves_small(rel_ptr, r, waves)
+                else:
+                    wave_ptr, wave_iota, wave_split = _relation_waves(et, rel_ptr, r, waves)
                 L.call("bkg_kge_fused_bce_dev_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]),
                        t, label, 1.0 / total, L.ptr(inv_total), L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order),
-                       L.ptr(rel_ptr), L.ptr(s), L.ptr(g) if rec is None else None, L.ptr(rec), L.ptr(part),
-                       L.ptr(drel_part), drel_part.stride(0), L.stream())
-                loss = loss + part.double().sum()
+                       L.ptr(rel_ptr), L.ptr(s), L.ptr(g) if rec is None else None, L.ptr(rec),
+                       L.ptr(part[w0:w0 + waves]), L.ptr(drel_part), drel_part.stride(0), L.stream())
                 # per-relation sum of the waves' partial rows (consecutive waves; fixed order; no atomics)
-                drel = drel + spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
+                dr = spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
+                drel = dr if drel is None else drel + dr
             scores.append(s)
             grads.append(g)
+            w0, t0 = w0 + waves, t0 + t
+        if drel is None:
+            drel = torch.zeros_like(rel_emb)
+        loss = part.sum(dtype=torch.float64)
         ctx.kind, ctx.comm, ctx.reg = kind, comm, float(reg)
         ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
-        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1], z if reg else None)
+        z_reg, ctx.inv_rows = (z if reg else None), None
+        if reg and rows is not None:      # padded mini-batch: the mean runs over the real rows only
+            row_mask, ctx.inv_rows = rows
+            z_reg = z * row_mask
+        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1], z_reg)
         ctx.mark_non_differentiable(scores[0], scores[1])
         loss = (loss * inv_total.double()).reshape(()) if padded else loss / total
         if reg:      # + reg * (mean(z^2) + mean(rel_emb^2)), reference kge_module.py:128-129: two one-launch norms
-            loss = loss + reg * (torch.linalg.vector_norm(z).double().pow(2) / z.numel()
-                                 + torch.linalg.vector_norm(rel_emb).double().pow(2) / rel_emb.numel())
+            zsq = torch.linalg.vector_norm(z_reg).double().pow(2)
+            zsq = zsq / z.numel() if ctx.inv_rows is None else (zsq * ctx.inv_rows.double() / d).reshape(())
+            loss = loss + reg * (zsq + torch.linalg.vector_norm(rel_emb).double().pow(2) / rel_emb.numel())
         return loss.float(), scores[0], scores[1]
 
     @staticmethod
@@ -999,29 +1043,35 @@ class _KgeBceLoss(torch.autograd.Function):
             if ctx.comm is not None:
                 dz = ctx.comm.reduce_scatter(dz)          # the owners' sums of every rank's triplet share
             dz = dz * gloss
-            if ctx.reg:
+            if ctx.reg and ctx.inv_rows is not None:
+                dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / d) * ctx.inv_rows)
+            elif ctx.reg:
                 dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / z_reg.numel()))
         drel_out = None
         if ctx.needs_input_grad[1]:
             drel_out = drel * gloss
             if ctx.reg:
                 drel_out = torch.addcmul(drel_out, rel_emb, gloss * (2.0 * ctx.reg / rel_emb.numel()))
-        return dz, drel_out, None, None, None, None, None, None, None, None, None
+        return dz, drel_out, None, None, None, None, None, None, None, None, None, None
 
 
 def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind, comm=None, total=None,
-                 reg=0.0, inv_total=None):
+                 reg=0.0, inv_total=None, rows=None):
     """``comm`` (node-partitioned training, biomedkg_amd/partition.py): ``z`` is the rank's shard, the triplet ids are
     slots of the all-gathered table; ``total``: the count the BCE sum is divided by (default: this call's triplets);
-    ``reg``: adds ``reg * (mean(z^2) + mean(rel_emb^2))`` (the reference's L2 term) inside the same op."""
+    ``reg``: adds ``reg * (mean(z^2) + mean(rel_emb^2))`` (the reference's L2 term) inside the same op.
+    ``inv_total`` / ``rows`` (padded mini-batches of a captured step, biomedkg_amd/sampled.py): the BCE sum is multiplied
+    by the DEVICE scalar ``inv_total``, triplets with relation id ``R`` (one past the real ones) are pads, and the mean
+    of ``z^2`` runs over the rows selected by ``rows = (mask [n, 1], 1 / count as a device scalar)``."""
     L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, inv_total)
     if reg and comm is not None:
         raise ValueError("the L2 term of a partitioned step is scaled by the caller (partition.kge_loss_partitioned)")
-    if inv_total is not None and (reg or comm is not None or inv_total.dtype != torch.float32):
-        raise ValueError("inv_total (padded mini-batches): a float32 device scalar; no reg / comm on that path")
+    if inv_total is not None and (comm is not None or inv_total.dtype != torch.float32 or (reg and rows is None)):
+        raise ValueError("inv_total (padded mini-batches): a float32 device scalar, reg with rows=(row mask [n, 1], "
+                         "1 / real rows as a device scalar); no comm on that path")
     return _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
                              neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, comm, total, float(reg),
-                             inv_total)
+                             inv_total, rows)
 
 
 # ----------------------------------------------------------------------------- NT-Xent

@@ -167,6 +167,7 @@ class SaintGraphedKge:
         # everything -- sampler, eager steps, captures, replays -- runs on ONE side stream: autograd's AccumulateGrad
         # nodes must not be born on the default stream if a later capture is to meet them (torch.cuda.graphs notes)
         self.stream = torch.cuda.Stream()
+        self.side = torch.cuda.Stream()
 
     # ---- the padded step (captured once per edge bucket)
     def _negatives(self, ei, et, e_b):
@@ -179,7 +180,7 @@ class SaintGraphedKge:
         ws = torch.empty(L.lib().bkg_negative_sample_workspace_bytes(cand), dtype=torch.uint8, device=dev)
         neg = torch.empty(2, k_cap, dtype=torch.int64, device=dev)
         neg_type = torch.empty(k_cap, dtype=torch.int64, device=dev)
-        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        count = torch.empty(1, dtype=torch.int64, device=dev)
         L.call("bkg_negative_sample_dev", L.ptr(self.v["sizes"]), self.neg_ratio, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), e_b,
                self.seed, L.ptr(self.epoch), L.ptr(table), cap, L.ptr(keys), L.ptr(flag[0]), L.ptr(flag[1]), k_cap,
                self.num_relations, L.ptr(neg[0]), L.ptr(neg[1]), L.ptr(neg_type) if self.module.neg_ratio else None,
@@ -188,30 +189,38 @@ class SaintGraphedKge:
         return neg, neg_type, count
 
     def padded_loss(self, e_b):
-        """The loss of ``KGEModule.training_step`` over the batch in ``self.cur`` padded to ``e_b`` edges."""
+        """The loss of ``KGEModule.training_step`` over the batch in ``self.cur`` padded to ``e_b`` edges.
+
+        Two branches that only meet at the loss: the relational structure + encoder on the current stream; the
+        negatives and every triplet-side structure (relation orders, incidence lists) on a side stream -- in a captured
+        graph they become parallel branches, and a step of ~250 tiny launches is bound by the longest chain."""
         m, v = self.module, self.v
         r = self.num_relations
         ei = torch.stack([v["src"][:e_b], v["dst"][:e_b]])                 # fresh tensors: nothing cached survives a step
         et = v["type"][:e_b].clone()
         if m._fix_edge_id is not None:
             et = torch.full_like(et, m._fix_edge_id)
+        n_real, e_real = v["sizes"][0], v["sizes"][1]
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            neg, neg_type, count = self._negatives(ei, et, e_b)
+            if not m.neg_ratio:                                            # reference: the positives' own relation ids
+                neg_type = torch.where(self.iota_e[:e_b] < count, et, r)
+            valid = self.iota_e[:e_b] < e_real
+            et_loss = torch.where(valid, et, r)                            # pads: the relation no wave visits
+            ei_loss = torch.where(valid, ei, self.spread[:, :e_b])
+            inv = torch.reciprocal(torch.stack([e_real + count[0], n_real]).to(torch.float32))   # 1 / triplets, 1 / rows
+            rows = (self.iota_n < n_real).to(torch.float32).unsqueeze(1)
+            ops.kge_prepare_structures(ei_loss, et_loss, neg, neg_type, self.n_cap, r + 1)
         x = m.fusion_fn(x=self.x_ext.index_select(0, v["n_id"]))
         plant_rel_graph(RelGraph(ei, et, self.n_cap, r, static_segments=True))
         z = m.model.encode(x, ei, et)
-        n_real, e_real = v["sizes"][0], v["sizes"][1]
-        neg, neg_type, count = self._negatives(ei, et, e_b)
-        if not m.neg_ratio:                                                # reference: the positives' own relation ids
-            neg_type = torch.where(self.iota_e[:e_b] < count, et, r)
-        valid = self.iota_e[:e_b] < e_real
-        et_loss = torch.where(valid, et, r)                                # pads: the relation no wave visits
-        ei_loss = torch.where(valid, ei, self.spread[:, :e_b])
-        inv_total = (1.0 / (e_real + count[0]).to(torch.float32)).reshape(1)
+        main.wait_stream(self.side)
         dec = m.model.decoder
-        bce, pos_pred, neg_pred = ops.kge_bce_loss(z, dec.rel_emb, ei_loss, et_loss, neg, neg_type, dec.kind,
-                                                   inv_total=inv_total)
-        rows = (self.iota_n < n_real).to(z.dtype).unsqueeze(1)
-        reg = (z * rows).pow(2).sum() / (n_real.to(torch.float32) * z.size(1)) + dec.rel_emb.pow(2).mean()
-        return bce + 1e-2 * reg                                            # reference kge_module.py:127-129
+        loss, pos_pred, neg_pred = ops.kge_bce_loss(z, dec.rel_emb, ei_loss, et_loss, neg, neg_type, dec.kind, reg=1e-2,
+                                                    inv_total=inv[:1], rows=(rows, inv[1:]))
+        return loss                                                        # BCE + 1e-2 L2, reference kge_module.py:127-129
 
     def _padded_step(self, e_b):
         self.epoch.add_(1)

@@ -53,6 +53,9 @@ int bkg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm,
 int bkg_rgcn_segments(const uint32_t* sorted, int64_t n, int64_t n_nodes, int32_t* flag_tmp, int32_t* scan_tmp,
                       int32_t* seg_of, int32_t* seg_ptr, int32_t* seg_dst, int32_t* seg_rel, float* inv_cnt,
                       int32_t* n_seg, void* workspace, int64_t workspace_bytes, void* stream);
+/* per-sorted-edge segment id and 1 / |segment| back in original edge order (perm from bkg_sort_edges) */
+int bkg_rgcn_edge_order(const uint32_t* perm, const int32_t* seg_of, const float* inv_cnt, int64_t n,
+                        int64_t* seg_of_edge, float* w_edge, void* stream);
 
 /* Long-row splitting of a CSR for the segment-reduce kernels: rows longer than `chunk` entries are cut
  * into chunks summed by separate waves (partials added in chunk order by a second pass).  All arrays are
@@ -162,6 +165,8 @@ int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z /* fp32 or bf16 table */, 
  * the caller segment-reduces them), in one sweep over the triplets' rows visited in relation-sorted order.
  * Replaces decode + cat + binary_cross_entropy_with_logits of biomedkg/kge_module.py:121-127 and their autograd. */
 int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel);
+/* wave_ptr[n_rel + 1]: first wave of each relation in that pass (chunk = 64 triplets per wave) */
+int bkg_relation_wave_ptr(const int32_t* rel_ptr, int32_t n_rel, int32_t chunk, int32_t* wave_ptr, void* stream);
 int bkg_kge_fused_bce_f32(int32_t kind, const void* z /* fp32 or bf16 table */, int32_t z_is_bf16, int64_t ldz,
                           int32_t d, const int64_t* head,
                           const int64_t* tail, int64_t T, float label, float inv_total, const float* rel_emb,

@@ -124,7 +124,7 @@ def test_c3_as_timed_bf16_fast_paths_against_exact_fp32():
     assert fast.get("forward_views", 0) == 1                      # GGD's two views side by side
     assert fast.get("_gemm_xw", 0) >= 20                          # streaming activation-x-weight products
     assert fast.get("bkg_gemm_tn_bf16", 0) >= 4 and fast.get("bkg_gemm_grouped_k_bf16", 0) >= 4   # bf16 weight gradients
-    assert fast.get("bkg_kge_fused_bce_f32", 0) == 2
+    assert fast.get("bkg_kge_fused_bce_dev_f32", 0) == 2
     exact = res["fp32"][1]
     assert exact.get("forward_views", 0) == 0 and exact.get("_gemm_xw", 0) == 0
     for key in ("ggd", "kge"):
