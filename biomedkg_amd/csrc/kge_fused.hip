@@ -187,9 +187,88 @@ __global__ void relation_wave_ptr_kernel(const int32_t* __restrict__ rel_ptr, in
   wave_ptr[n_rel] = acc;
 }
 
+// ---- the scalar tail of a MINI-BATCH step in one launch each (a captured step pays ~5 us per launch, and the torch
+// expressions these replace were ~30 of them): fixed thread -> element mapping and a fixed-order tree, so repeatable.
+__device__ __forceinline__ double block_sum_1024(double v, double* sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+#pragma unroll
+  for (int o = 512; o > 0; o >>= 1) {
+    if (t < o) sh[t] += sh[t + o];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// loss = inv_total * sum(part) + reg * (mean_{rows < n_real}(z^2) + mean(rel^2))
+__global__ __launch_bounds__(1024) void kge_loss_finish_kernel(const float* __restrict__ part, int n_part, float inv_total,
+                                                               const float* __restrict__ inv_total_dev,
+                                                               const float* __restrict__ z, int64_t ldz, int n_cap, int d,
+                                                               const int64_t* __restrict__ n_real_dev,
+                                                               const float* __restrict__ rel, int64_t ldr, int n_rel,
+                                                               float reg, float* __restrict__ loss) {
+  __shared__ double sh[1024];
+  const int t = threadIdx.x;
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = t; i < n_part; i += 1024) a += (double)part[i];
+  a = block_sum_1024(a, sh);
+  int n_rows = n_cap;
+  if (n_real_dev) n_rows = (int)min((int64_t)n_cap, n_real_dev[0]);
+  if (reg != 0.f) {
+    const int64_t nz = (int64_t)n_rows * d, nr = (int64_t)n_rel * d;
+    for (int64_t e = t; e < nz; e += 1024) { const float v = z[(e / d) * ldz + e % d]; b += (double)v * v; }
+    for (int64_t e = t; e < nr; e += 1024) { const float v = rel[(e / d) * ldr + e % d]; c += (double)v * v; }
+    b = block_sum_1024(b, sh);
+    c = block_sum_1024(c, sh);
+  }
+  if (t == 0) {
+    const double it = inv_total_dev ? (double)inv_total_dev[0] : (double)inv_total;
+    double out = a * it;
+    if (reg != 0.f) out += (double)reg * (b / ((double)max(n_rows, 1) * d) + c / ((double)n_rel * d));
+    loss[0] = (float)out;
+  }
+}
+
+// dst[row, :] = dst[row, :] * g + src[row, :] * (g * coef / rows)   for row < rows (= n_real or n), dst * g beyond;
+// g = gloss[0] (the upstream gradient of the loss)
+__global__ __launch_bounds__(256) void scale_add_rows_kernel(float* __restrict__ dst, int64_t ldd,
+                                                             const float* __restrict__ src, int64_t lds, int n, int d,
+                                                             const float* __restrict__ gloss, float coef,
+                                                             const int64_t* __restrict__ n_real_dev) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)n * d) return;
+  const int row = (int)(e / d), col = (int)(e % d);
+  const int rows = n_real_dev ? (int)min((int64_t)n, n_real_dev[0]) : n;
+  const float g = gloss[0];
+  float v = dst[(int64_t)row * ldd + col] * g;
+  if (row < rows) v = fmaf(src[(int64_t)row * lds + col], g * (coef / (float)max(rows, 1)), v);
+  dst[(int64_t)row * ldd + col] = v;
+}
+
 }  // namespace bkg
 
 using namespace bkg;
+
+extern "C" int bkg_kge_loss_finish_f32(const float* part, int32_t n_part, float inv_total, const float* inv_total_dev,
+                                       const float* z, int64_t ldz, int32_t n_cap, int32_t d, const int64_t* n_real_dev,
+                                       const float* rel, int64_t ldr, int32_t n_rel, float reg, float* loss, void* stream) {
+  BKG_ARG(n_part >= 0 && n_cap >= 0 && d > 0 && n_rel > 0, "bkg_kge_loss_finish_f32: bad sizes");
+  hipLaunchKernelGGL(kge_loss_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, n_part, inv_total,
+                     inv_total_dev, z, ldz, n_cap, d, n_real_dev, rel, ldr, n_rel, reg, loss);
+  return check_launch("bkg_kge_loss_finish_f32");
+}
+
+extern "C" int bkg_scale_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t n, int32_t d,
+                                      const float* gloss, float coef, const int64_t* n_real_dev, void* stream) {
+  BKG_ARG(n >= 0 && d > 0, "bkg_scale_add_rows_f32: bad sizes");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scale_add_rows_kernel, dim3(ceil_div((int64_t)n * d, 256)), dim3(256), 0, (hipStream_t)stream, dst, ldd,
+                     src, lds, n, d, gloss, coef, n_real_dev);
+  return check_launch("bkg_scale_add_rows_f32");
+}
 
 extern "C" int bkg_relation_wave_ptr(const int32_t* rel_ptr, int32_t n_rel, int32_t chunk, int32_t* wave_ptr, void* stream) {
   BKG_ARG(n_rel > 0 && chunk > 0, "bkg_relation_wave_ptr: bad sizes");

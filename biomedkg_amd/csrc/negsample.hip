@@ -215,6 +215,26 @@ __global__ __launch_bounds__(256) void permute_gather_dev_kernel(const int64_t* 
   out[i] = src[pi((uint64_t)i) % (uint64_t)e];
 }
 
+// The loss-side view of a padded batch in one launch: pad positives get the relation id `pad_rel` (one past the real
+// ones: no scorer wave visits it) and endpoints spread over the local ids (zero gradient records, no long incidence
+// list); inv_total = 1 / (edges + negatives).
+__global__ __launch_bounds__(256) void padded_loss_inputs_kernel(const int64_t* __restrict__ sizes,
+                                                                 const int64_t* __restrict__ count,
+                                                                 const int64_t* __restrict__ src,
+                                                                 const int64_t* __restrict__ dst,
+                                                                 const int64_t* __restrict__ type, int64_t rows,
+                                                                 int64_t node_cap, int64_t pad_rel,
+                                                                 int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst,
+                                                                 int64_t* __restrict__ out_type, float* __restrict__ inv_total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) inv_total[0] = 1.0f / (float)(sizes[1] + count[0]);
+  if (i >= rows) return;
+  const bool valid = i < sizes[1];
+  out_src[i] = valid ? src[i] : i % node_cap;
+  out_dst[i] = valid ? dst[i] : (i + 1) % node_cap;
+  out_type[i] = valid ? type[i] : pad_rel;
+}
+
 }  // namespace bkg
 
 using namespace bkg;
@@ -307,4 +327,13 @@ extern "C" int bkg_negative_sample_dev(const int64_t* sizes, int64_t neg_ratio, 
     hipLaunchKernelGGL(permute_gather_dev_kernel, dim3(ceil_div(out_cap, 256)), dim3(256), 0, s, type, sizes, neg_ratio, seed,
                        epoch, count, type_pad, out_cap, out_type);
   return check_launch("bkg_negative_sample_dev");
+}
+
+extern "C" int bkg_padded_loss_inputs(const int64_t* sizes, const int64_t* count, const int64_t* src, const int64_t* dst,
+                                      const int64_t* type, int64_t rows, int64_t node_cap, int64_t pad_rel, int64_t* out_src,
+                                      int64_t* out_dst, int64_t* out_type, float* inv_total, void* stream) {
+  BKG_ARG(rows > 0 && node_cap > 1, "bkg_padded_loss_inputs: bad sizes");
+  hipLaunchKernelGGL(padded_loss_inputs_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, sizes, count,
+                     src, dst, type, rows, node_cap, pad_rel, out_src, out_dst, out_type, inv_total);
+  return check_launch("bkg_padded_loss_inputs");
 }

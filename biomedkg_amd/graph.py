@@ -153,7 +153,8 @@ class RelGraph:
     point at segments with weight 1/|segment|.
     """
 
-    def __init__(self, edge_index, edge_type, num_nodes, num_relations, n_src=None, static_segments=False):
+    def __init__(self, edge_index, edge_type, num_nodes, num_relations, n_src=None, static_segments=False,
+                 defer_source_side=False):
         """``n_src``: number of SOURCE rows when they live in another index space than the ``num_nodes`` targets (a
         node-partitioned graph: sources are slots of the all-gathered table, targets the rank's own nodes).
         ``static_segments`` (padded mini-batches of a captured step, biomedkg_amd/sampled.py): no host read of the
@@ -190,15 +191,22 @@ class RelGraph:
         L.call("bkg_lower_bound_u32", L.ptr(seg_rel_u), s, r + 1, 1, L.ptr(self.rel_ptr), L.stream())
         # target -> its segments
         self.dst_csr = CSR(self.seg_dst.to(torch.int64), _iota64(s, dev), n)
-        # source -> (segment, 1/|segment|) of each out-edge
-        seg_of_edge = torch.empty(e, dtype=torch.int64, device=dev)
-        w_edge = torch.empty(e, dtype=torch.float32, device=dev)
-        L.call("bkg_rgcn_edge_order", L.ptr(perm), L.ptr(self.seg_of), L.ptr(self.inv_cnt), e, L.ptr(seg_of_edge),
-               L.ptr(w_edge), L.stream())
-        self.src_csr = CSR(src, seg_of_edge, n if n_src is None else int(n_src))
-        self.src_w = self.src_csr.permute_f32(w_edge)
         self.seg_iota_ptr = _spread_pattern(s + 1, 1 << 62, dev)     # 0 .. s (cached per size)
         self.seg_split = rowsplit_for(self.seg_ptr, s, e)
+        self._n_src = n if n_src is None else int(n_src)
+        if not defer_source_side:
+            self.build_source_side()
+
+    def build_source_side(self):
+        """source -> (segment, 1/|segment|) of each out-edge: what the BACKWARD gathers through (the forward never
+        reads it, so a mini-batch step builds it on a parallel branch)."""
+        e, dev = self.num_edges, self.edge_index.device
+        seg_of_edge = torch.empty(e, dtype=torch.int64, device=dev)
+        w_edge = torch.empty(e, dtype=torch.float32, device=dev)
+        L.call("bkg_rgcn_edge_order", L.ptr(self.perm), L.ptr(self.seg_of), L.ptr(self.inv_cnt), e, L.ptr(seg_of_edge),
+               L.ptr(w_edge), L.stream())
+        self.src_csr = CSR(self.edge_index[0], seg_of_edge, self._n_src)
+        self.src_w = self.src_csr.permute_f32(w_edge)
 
 
 _PATTERNS = {}

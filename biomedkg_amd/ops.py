@@ -634,6 +634,17 @@ def gcn_conv_views(x2, weight, bias, graph, gw, views, relu=False, drop=None, hi
 
 
 # ----------------------------------------------------------------------------- RGCNConv
+_BRANCH_ROWS = 8192     # layers over fewer rows than this are launch-bound: independent chains go to a side stream
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class _RgcnConv(torch.autograd.Function):
     """``dropout(relu(sum_r mean_{N_r(i)}(x_j) W_r + x_i W_root + b))`` -- PyG RGCNConv
     + the encoder's ReLU/dropout (reference biomedkg/model/encoder.py:50-59).  ``x`` is fp32 or (a hidden activation
@@ -697,7 +708,28 @@ class _RgcnConv(torch.autograd.Function):
                     (not ctx.needs_input_grad[0] or _bf16_operand_ok(rg.num_segments, d_in, d_out)))
             dy = spmm(rg.seg_iota_ptr, rg.seg_dst, None, dout, rg.num_segments,       # dY[s] = dOut[dst_s]; read by
                       out_dtype=torch.bfloat16 if dy16 else torch.float32)            # the two products below only
-        # the input gradient first: on a partitioned graph its table part goes out while the weight gradients run
+        def weight_grads():
+            dweight = None
+            if ctx.needs_input_grad[1]:
+                dweight = (gemm_grouped_k(h, dout, rg.rel_ptr, rg.num_relations, b_rows=rg.seg_dst) if gathered
+                           else gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations))
+            droot = None
+            if ctx.needs_input_grad[2]:
+                if n < 4096 and (x.dtype == torch.bfloat16 or dout.dtype == torch.bfloat16):
+                    droot = gemm(_as_f32(x), _as_f32(dout), trans_a=True)
+                else:
+                    droot = gemm(x, dout, trans_a=True)
+            db = colsum(dout) if ctx.needs_input_grad[3] else None
+            return dweight, droot, db
+        # mini-batches: the three parameter gradients are a chain of small launches independent of the input-gradient
+        # chain -- run them as a parallel branch (side stream; a parallel branch of a captured graph)
+        branch = comm is None and n < _BRANCH_ROWS and ctx.needs_input_grad[0]
+        if branch:
+            main, side = torch.cuda.current_stream(), _side_stream(dout.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dweight, droot, db = weight_grads()
+        # the input gradient: on a partitioned graph its table part goes out while the weight gradients run
         dx, pending, dx_root = None, None, None
         if ctx.needs_input_grad[0]:
             if gathered:
@@ -716,17 +748,10 @@ class _RgcnConv(torch.autograd.Function):
             else:
                 pending = comm.reduce_scatter_begin(spmm(c.rowptr, c.col, rg.src_w, _table(dh), n_table, split=c.split))
                 dx_root = gemm(dout, root, trans_b=True)
-        dweight = None
-        if ctx.needs_input_grad[1]:
-            dweight = (gemm_grouped_k(h, dout, rg.rel_ptr, rg.num_relations, b_rows=rg.seg_dst) if gathered
-                       else gemm_grouped_k(h, dy, rg.rel_ptr, rg.num_relations))
-        droot = None
-        if ctx.needs_input_grad[2]:
-            if n < 4096 and (x.dtype == torch.bfloat16 or dout.dtype == torch.bfloat16):
-                droot = gemm(_as_f32(x), _as_f32(dout), trans_a=True)
-            else:
-                droot = gemm(x, dout, trans_a=True)
-        db = colsum(dout) if ctx.needs_input_grad[3] else None
+        if branch:
+            main.wait_stream(side)
+        else:
+            dweight, droot, db = weight_grads()
         if pending is not None:
             dx = comm.reduce_scatter_end(pending) + dx_root
         if dx is not None and dx.dtype != x.dtype:
@@ -817,7 +842,9 @@ class Incidence:
         self.rowptr = _i32(num_nodes + 1, ei.device)
         L.call("bkg_lower_bound_u32", L.ptr(sorted_keys), flat.numel(), num_nodes + 1, 1, L.ptr(self.rowptr), L.stream())
         from .graph import rowsplit_for
-        self.split = rowsplit_for(self.rowptr, num_nodes, flat.numel())
+        # mini-batches (a few thousand nodes, a few 10^4 incidences): rows are short, the long-row table is 6 launches
+        small = num_nodes <= 4096 and flat.numel() < (1 << 18)
+        self.split = None if small else rowsplit_for(self.rowptr, num_nodes, flat.numel())
 
 
 def incidence_of(edge_index, num_nodes) -> Incidence:
@@ -991,20 +1018,21 @@ class _KgeBceLoss(torch.autograd.Function):
             w0, t0 = w0 + waves, t0 + t
         if drel is None:
             drel = torch.zeros_like(rel_emb)
-        loss = part.sum(dtype=torch.float64)
         ctx.kind, ctx.comm, ctx.reg = kind, comm, float(reg)
         ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
-        z_reg, ctx.inv_rows = (z if reg else None), None
-        if reg and rows is not None:      # padded mini-batch: the mean runs over the real rows only
-            row_mask, ctx.inv_rows = rows
-            z_reg = z * row_mask
-        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1], z_reg)
+        ctx.n_real = rows
+        ctx.padded = padded
+        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1], z if (reg or padded) else None)
         ctx.mark_non_differentiable(scores[0], scores[1])
-        loss = (loss * inv_total.double()).reshape(()) if padded else loss / total
+        if padded:   # BCE mean + L2 over the real rows in ONE launch (a captured mini-batch step is bound by its launch count)
+            out = torch.empty((), dtype=torch.float32, device=dev)
+            L.call("bkg_kge_loss_finish_f32", L.ptr(part), part.numel(), 0.0, L.ptr(inv_total), L.ptr(z), z.stride(0),
+                   z.size(0), d, L.ptr(rows), L.ptr(rel_emb), rel_emb.stride(0), r, float(reg), L.ptr(out), L.stream())
+            return out, scores[0], scores[1]
+        loss = part.sum(dtype=torch.float64) / total
         if reg:      # + reg * (mean(z^2) + mean(rel_emb^2)), reference kge_module.py:128-129: two one-launch norms
-            zsq = torch.linalg.vector_norm(z_reg).double().pow(2)
-            zsq = zsq / z.numel() if ctx.inv_rows is None else (zsq * ctx.inv_rows.double() / d).reshape(())
-            loss = loss + reg * (zsq + torch.linalg.vector_norm(rel_emb).double().pow(2) / rel_emb.numel())
+            loss = loss + reg * (torch.linalg.vector_norm(z).double().pow(2) / z.numel()
+                                 + torch.linalg.vector_norm(rel_emb).double().pow(2) / rel_emb.numel())
         return loss.float(), scores[0], scores[1]
 
     @staticmethod
@@ -1042,16 +1070,25 @@ class _KgeBceLoss(torch.autograd.Function):
                 dz.zero_()
             if ctx.comm is not None:
                 dz = ctx.comm.reduce_scatter(dz)          # the owners' sums of every rank's triplet share
-            dz = dz * gloss
-            if ctx.reg and ctx.inv_rows is not None:
-                dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / d) * ctx.inv_rows)
-            elif ctx.reg:
-                dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / z_reg.numel()))
+            if ctx.padded:       # dz * gloss + the L2 term's 2 reg z / (real rows * d) on the real rows: one launch
+                gl = gloss.reshape(1).contiguous()
+                L.call("bkg_scale_add_rows_f32", L.ptr(dz), dz.stride(0), L.ptr(z_reg), z_reg.stride(0), n, d, L.ptr(gl),
+                       2.0 * ctx.reg / d, L.ptr(ctx.n_real), L.stream())
+            else:
+                dz = dz * gloss
+                if ctx.reg:
+                    dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / z_reg.numel()))
         drel_out = None
         if ctx.needs_input_grad[1]:
-            drel_out = drel * gloss
-            if ctx.reg:
-                drel_out = torch.addcmul(drel_out, rel_emb, gloss * (2.0 * ctx.reg / rel_emb.numel()))
+            if ctx.padded:
+                drel_out = drel.clone()
+                gl = gloss.reshape(1).contiguous()
+                L.call("bkg_scale_add_rows_f32", L.ptr(drel_out), drel_out.stride(0), L.ptr(rel_emb), rel_emb.stride(0),
+                       rel_emb.size(0), d, L.ptr(gl), 2.0 * ctx.reg / d, None, L.stream())
+            else:
+                drel_out = drel * gloss
+                if ctx.reg:
+                    drel_out = torch.addcmul(drel_out, rel_emb, gloss * (2.0 * ctx.reg / rel_emb.numel()))
         return dz, drel_out, None, None, None, None, None, None, None, None, None, None
 
 
@@ -1062,13 +1099,14 @@ def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_
     ``reg``: adds ``reg * (mean(z^2) + mean(rel_emb^2))`` (the reference's L2 term) inside the same op.
     ``inv_total`` / ``rows`` (padded mini-batches of a captured step, biomedkg_amd/sampled.py): the BCE sum is multiplied
     by the DEVICE scalar ``inv_total``, triplets with relation id ``R`` (one past the real ones) are pads, and the mean
-    of ``z^2`` runs over the rows selected by ``rows = (mask [n, 1], 1 / count as a device scalar)``."""
+    of ``z^2`` runs over the first ``rows`` rows (an int64 DEVICE scalar)."""
     L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, inv_total)
     if reg and comm is not None:
         raise ValueError("the L2 term of a partitioned step is scaled by the caller (partition.kge_loss_partitioned)")
-    if inv_total is not None and (comm is not None or inv_total.dtype != torch.float32 or (reg and rows is None)):
-        raise ValueError("inv_total (padded mini-batches): a float32 device scalar, reg with rows=(row mask [n, 1], "
-                         "1 / real rows as a device scalar); no comm on that path")
+    if inv_total is not None and (comm is not None or inv_total.dtype != torch.float32 or rows is None
+                                  or rows.dtype != torch.int64):
+        raise ValueError("inv_total (padded mini-batches): a float32 device scalar together with rows = the real row "
+                         "count as an int64 device scalar; no comm on that path")
     return _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
                              neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, comm, total, float(reg),
                              inv_total, rows)

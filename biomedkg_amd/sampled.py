@@ -150,9 +150,6 @@ class SaintGraphedKge:
         self.cur = torch.zeros_like(self.sampler.buf)                                   # the batch the step reads
         self.v = SaintDeviceSampler.views(self.cur, self.n_cap, self.e_cap)
         self.iota_e = torch.arange(self.e_cap, device=dev)
-        self.iota_n = torch.arange(self.n_cap, device=dev)
-        # pad triplets of the loss: endpoints spread over the local ids (zero gradient records; no long incidence list)
-        self.spread = torch.stack([self.iota_e % self.n_cap, (self.iota_e + 1) % self.n_cap])
         if optimizer is None:         # the optimizer of KGEModule.configure_optimizers, without the trainer-bound scheduler
             optimizer = torch.optim.Adam(list(module.model.parameters()), lr=module.lr, fused=True)
         self.optimizer = make_capturable(optimizer)
@@ -167,7 +164,8 @@ class SaintGraphedKge:
         # everything -- sampler, eager steps, captures, replays -- runs on ONE side stream: autograd's AccumulateGrad
         # nodes must not be born on the default stream if a later capture is to meet them (torch.cuda.graphs notes)
         self.stream = torch.cuda.Stream()
-        self.side = torch.cuda.Stream()
+        self.side, self.side2, self.sampler_stream = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        self.copied = torch.cuda.Event()
 
     # ---- the padded step (captured once per edge bucket)
     def _negatives(self, ei, et, e_b):
@@ -200,26 +198,29 @@ class SaintGraphedKge:
         et = v["type"][:e_b].clone()
         if m._fix_edge_id is not None:
             et = torch.full_like(et, m._fix_edge_id)
-        n_real, e_real = v["sizes"][0], v["sizes"][1]
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             neg, neg_type, count = self._negatives(ei, et, e_b)
             if not m.neg_ratio:                                            # reference: the positives' own relation ids
                 neg_type = torch.where(self.iota_e[:e_b] < count, et, r)
-            valid = self.iota_e[:e_b] < e_real
-            et_loss = torch.where(valid, et, r)                            # pads: the relation no wave visits
-            ei_loss = torch.where(valid, ei, self.spread[:, :e_b])
-            inv = torch.reciprocal(torch.stack([e_real + count[0], n_real]).to(torch.float32))   # 1 / triplets, 1 / rows
-            rows = (self.iota_n < n_real).to(torch.float32).unsqueeze(1)
+            ei_loss = torch.empty_like(ei)
+            et_loss = torch.empty_like(et)
+            inv_total = torch.empty(1, dtype=torch.float32, device=ei.device)
+            L.call("bkg_padded_loss_inputs", L.ptr(v["sizes"]), L.ptr(count), L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), e_b,
+                   self.n_cap, r, L.ptr(ei_loss[0]), L.ptr(ei_loss[1]), L.ptr(et_loss), L.ptr(inv_total), L.stream())
             ops.kge_prepare_structures(ei_loss, et_loss, neg, neg_type, self.n_cap, r + 1)
         x = m.fusion_fn(x=self.x_ext.index_select(0, v["n_id"]))
-        plant_rel_graph(RelGraph(ei, et, self.n_cap, r, static_segments=True))
+        rg = plant_rel_graph(RelGraph(ei, et, self.n_cap, r, static_segments=True, defer_source_side=True))
+        self.side2.wait_stream(main)
+        with torch.cuda.stream(self.side2):                                # only the backward reads it: third branch
+            rg.build_source_side()
         z = m.model.encode(x, ei, et)
         main.wait_stream(self.side)
+        main.wait_stream(self.side2)
         dec = m.model.decoder
         loss, pos_pred, neg_pred = ops.kge_bce_loss(z, dec.rel_emb, ei_loss, et_loss, neg, neg_type, dec.kind, reg=1e-2,
-                                                    inv_total=inv[:1], rows=(rows, inv[1:]))
+                                                    inv_total=inv_total, rows=v["sizes"][:1])
         return loss                                                        # BCE + 1e-2 L2, reference kge_module.py:127-129
 
     def _padded_step(self, e_b):
@@ -276,14 +277,20 @@ class SaintGraphedKge:
                 self.module.__dict__["trainer"] = trainer
 
     def _step(self):
-        s = self.sampler
+        s, main = self.sampler, torch.cuda.current_stream()
         if not self._primed:
-            s.draw(graph=self.graphs_on)
+            self.sampler_stream.wait_stream(main)
+            with torch.cuda.stream(self.sampler_stream):
+                s.draw(graph=self.graphs_on)
             self._primed = True
         n_b, e_b, e_free = s.sizes()                                       # of the batch drawn one step ago
         self.last_sizes = (n_b, e_b, e_free)
-        self.cur.copy_(s.buf)                                              # private copy, then the sampler moves on
-        s.draw(graph=self.graphs_on)
+        main.wait_event(s.event)
+        self.cur.copy_(s.buf)                                              # private copy, then the sampler moves on:
+        self.copied.record(main)                                           # the next batch is drawn UNDER this step
+        with torch.cuda.stream(self.sampler_stream):
+            self.sampler_stream.wait_event(self.copied)
+            s.draw(graph=self.graphs_on)
         bucket = self.bucket_of(n_b, e_b, e_free)
         if bucket is None:
             self.stats["eager_fallback"] += 1

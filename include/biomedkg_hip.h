@@ -165,6 +165,17 @@ int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z /* fp32 or bf16 table */, 
  * the caller segment-reduces them), in one sweep over the triplets' rows visited in relation-sorted order.
  * Replaces decode + cat + binary_cross_entropy_with_logits of biomedkg/kge_module.py:121-127 and their autograd. */
 int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel);
+/* The scalar tail of a mini-batch step, one launch each (a captured step is bound by its launch count):
+ * loss[0] = inv_total * sum(part[0..n_part)) + reg * (mean over rows < n_real of z^2 + mean of rel^2), the reference's
+ * BCE mean + 1e-2 L2 (biomedkg/kge_module.py:127-129); inv_total_dev / n_real_dev (nullable) read the count / the real
+ * row count from device memory.  bkg_scale_add_rows_f32: dst = dst * g + src * (g * coef / rows) on the first `rows`
+ * rows (n_real_dev[0], or n), dst * g beyond; g = gloss[0] -- the backward of that L2 term folded into the scaling of
+ * the scorer's gradient by the upstream gradient. */
+int bkg_kge_loss_finish_f32(const float* part, int32_t n_part, float inv_total, const float* inv_total_dev, const float* z,
+                            int64_t ldz, int32_t n_cap, int32_t d, const int64_t* n_real_dev, const float* rel,
+                            int64_t ldr, int32_t n_rel, float reg, float* loss, void* stream);
+int bkg_scale_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t n, int32_t d,
+                           const float* gloss, float coef, const int64_t* n_real_dev, void* stream);
 /* wave_ptr[n_rel + 1]: first wave of each relation in that pass (chunk = 64 triplets per wave) */
 int bkg_relation_wave_ptr(const int32_t* rel_ptr, int32_t n_rel, int32_t chunk, int32_t* wave_ptr, void* stream);
 int bkg_kge_fused_bce_f32(int32_t kind, const void* z /* fp32 or bf16 table */, int32_t z_is_bf16, int64_t ldz,
@@ -325,6 +336,11 @@ int bkg_negative_sample_dev(const int64_t* sizes, int64_t neg_ratio, const int64
                             int64_t capacity, uint64_t* keys_tmp, int32_t* flag_tmp, int32_t* offs_tmp, int64_t out_cap,
                             int64_t type_pad, int64_t* out_head, int64_t* out_tail, int64_t* out_type /* nullable */,
                             int64_t* count, void* workspace, int64_t workspace_bytes, void* stream);
+/* The loss-side view of a padded batch (sizes / count as above): rows past sizes[1] get the relation id pad_rel (one
+ * past the real ones: never scored) and endpoints spread over [0, node_cap); inv_total[0] = 1 / (sizes[1] + count[0]). */
+int bkg_padded_loss_inputs(const int64_t* sizes, const int64_t* count, const int64_t* src, const int64_t* dst,
+                           const int64_t* type, int64_t rows, int64_t node_cap, int64_t pad_rel, int64_t* out_src,
+                           int64_t* out_dst, int64_t* out_type, float* inv_total, void* stream);
 
 /* ---- modality fusion epilogues (biomedkg/utils/fusion.py:17-31 AttentionFusion, :49-90 ReDAF) */
 int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_t D, float* out, int64_t ldo,
