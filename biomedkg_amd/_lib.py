@@ -38,6 +38,7 @@ SIGNATURES = {
     "bkg_gather_f32": (I32, [P, P, P, I64, P]),
     "bkg_gcn_norm": (I32, [P, P, P, P, P, P, I64, I64, P, P, P, P]),
     "bkg_rgcn_segments": (I32, [P, I64, I64, P, P, P, P, P, P, P, P, P, I64, P]),
+    "bkg_rgcn_segments_static": (I32, [P, I64, I64, I32, P, P, P, P, P, P, P, P, P, I64, P]),
     "bkg_rgcn_edge_order": (I32, [P, P, P, I64, P, P, P]),
     # spmm.hip
     "bkg_rowsplit_build": (I32, [P, I64, I64, I32, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
@@ -96,6 +97,7 @@ SIGNATURES = {
     "bkg_unpair_rows_bf16": (I32, [P, P, P, I64, I32, P]),
     # colsum.hip
     "bkg_colsum_workspace_floats": (I64, [I64, I32]),
+    "bkg_gate_f32": (I32, [P, P, F32, I64, P, P]),
     "bkg_colsum_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),
     # negsample.hip
     "bkg_hashset_insert_offdiag": (I32, [P, P, I64, I64, P, I64, P]),

@@ -82,9 +82,49 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
+// few rows (a mini-batch): ONE launch -- block = 8 row groups x 32 columns over ALL rows, groups added in group order
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ x, int64_t ldx, int n, int d,
+                                                           float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s = 0.f;
+  if (c < d)
+    for (int r = g; r < n; r += 8) s += (float)x[(int64_t)r * ldx + c];
+  red[g][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (g == 0 && c < d) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+    out[c] = t;
+  }
+}
+
+// out = dout where gate > 0 (times scale), 0 elsewhere: the backward of dropout(relu(.)) read off the saved output
+__global__ __launch_bounds__(256) void gate_f32_kernel(const float* __restrict__ dout, const float* __restrict__ gate,
+                                                       float scale, int64_t n4, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = reinterpret_cast<const float4*>(dout)[i], g = reinterpret_cast<const float4*>(gate)[i];
+  float4 r;
+  r.x = g.x > 0.f ? a.x * scale : 0.f; r.y = g.y > 0.f ? a.y * scale : 0.f;
+  r.z = g.z > 0.f ? a.z * scale : 0.f; r.w = g.w > 0.f ? a.w * scale : 0.f;
+  reinterpret_cast<float4*>(out)[i] = r;
+}
+
 }  // namespace bkg
 
 using namespace bkg;
+
+extern "C" int bkg_gate_f32(const float* dout, const float* gate, float scale, int64_t numel, float* out, void* stream) {
+  BKG_ARG(numel >= 0 && numel % 4 == 0 && (uintptr_t)dout % 16 == 0 && (uintptr_t)gate % 16 == 0 && (uintptr_t)out % 16 == 0,
+          "bkg_gate_f32: contiguous 16-byte aligned tables whose size is a multiple of 4");
+  if (numel == 0) return 0;
+  hipLaunchKernelGGL(gate_f32_kernel, dim3(ceil_div(numel / 4, 256)), dim3(256), 0, (hipStream_t)stream, dout, gate, scale,
+                     numel / 4, out);
+  return check_launch("bkg_gate_f32");
+}
 
 extern "C" int64_t bkg_colsum_workspace_floats(int64_t n, int32_t d) {
   return (int64_t)std::min<int64_t>(CS_MAX_BLOCKS, std::max<int64_t>(1, (n + 63) / 64)) * d;
@@ -100,6 +140,11 @@ extern "C" int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * d, s);
     if (e != hipSuccess) { set_error("bkg_colsum_f32: memset", e); return (int)e; }
     return 0;
+  }
+  if (n <= 4096) {
+    if (x_is_bf16) hipLaunchKernelGGL(colsum_small_kernel<__bf16>, dim3(ceil_div(d, 32)), dim3(256), 0, s, (const __bf16*)x, ldx, (int)n, d, out);
+    else hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(ceil_div(d, 32)), dim3(256), 0, s, (const float*)x, ldx, (int)n, d, out);
+    return check_launch("bkg_colsum_f32(small)");
   }
   const int n_blocks = (int)(bkg_colsum_workspace_floats(n, d) / d);
   const int64_t rpb = (n + n_blocks - 1) / n_blocks;

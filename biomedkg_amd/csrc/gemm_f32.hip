@@ -286,11 +286,13 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     if (shallow) nsplit = std::min<int64_t>((K + 127) / 128, std::max<int64_t>(1, 512 / tiles));
     int kchunk = (int)(((K + nsplit - 1) / nsplit + 63) / 64 * 64);   // whole staged K tiles
     nsplit = (K + kchunk - 1) / kchunk;
-    hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
-    if (e != hipSuccess) { set_error("bkg_gemm_f32: memset", e); return (int)e; }
     ep.atomic = 1;
     float* det = nullptr;
     BKG_DET_SLABS(det, ep, nsplit, M, N, "bkg_gemm_f32");
+    if (!det) {      // atomics accumulate into a zeroed C; the deterministic reduce writes every element itself
+      hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
+      if (e != hipSuccess) { set_error("bkg_gemm_f32: memset", e); return (int)e; }
+    }
     dim3 grid(xcd_grid(nsplit, tiles)), block(256);
 #define BKG_SPLITK(BMN, TA_, TB_)                                                                                      \
   if (precision) hipLaunchKernelGGL((gemm_f32_splitk_kernel<1, BMN, BMN, TA_, TB_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, kchunk, ep, det); \

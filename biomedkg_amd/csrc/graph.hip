@@ -151,6 +151,16 @@ __global__ void edge_order_kernel(const uint32_t* __restrict__ perm, const int32
   w_edge[e] = inv_cnt[k];
 }
 
+// fixed segment count (padded mini-batches): every slot starts out as an EMPTY segment of the last relation whose
+// target is spread over the nodes; segment_fill_kernel then overwrites the real ones
+__global__ void segment_prefill_kernel(int64_t n, int32_t n_nodes, int32_t last_rel, int32_t* __restrict__ seg_ptr,
+                                       int32_t* __restrict__ seg_dst, int32_t* __restrict__ seg_rel) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  seg_ptr[i] = (int32_t)n;
+  if (i < n) { seg_dst[i] = (int32_t)(i % n_nodes); seg_rel[i] = last_rel; }
+}
+
 static inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
 
 }  // namespace bkg
@@ -250,4 +260,17 @@ extern "C" int bkg_rgcn_edge_order(const uint32_t* perm, const int32_t* seg_of, 
   if (n == 0) return 0;
   hipLaunchKernelGGL(edge_order_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, perm, seg_of, inv_cnt, n, seg_of_edge, w_edge);
   return check_launch("bkg_rgcn_edge_order");
+}
+
+// bkg_rgcn_segments with a FIXED segment count n (no host read of n_seg): slots past the real count are empty segments
+// of relation `last_rel`, targets spread over the nodes.
+extern "C" int bkg_rgcn_segments_static(const uint32_t* sorted, int64_t n, int64_t n_nodes, int32_t last_rel,
+                                        int32_t* flag_tmp, int32_t* scan_tmp, int32_t* seg_of, int32_t* seg_ptr,
+                                        int32_t* seg_dst, int32_t* seg_rel, float* inv_cnt, int32_t* n_seg, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+  BKG_ARG(n > 0 && n_nodes > 0 && last_rel >= 0, "bkg_rgcn_segments_static: bad sizes");
+  hipLaunchKernelGGL(segment_prefill_kernel, grid1(n + 1), dim3(256), 0, (hipStream_t)stream, n, (int32_t)n_nodes, last_rel,
+                     seg_ptr, seg_dst, seg_rel);
+  return bkg_rgcn_segments(sorted, n, n_nodes, flag_tmp, scan_tmp, seg_of, seg_ptr, seg_dst, seg_rel, inv_cnt, n_seg,
+                           workspace, workspace_bytes, stream);
 }

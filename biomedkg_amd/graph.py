@@ -175,13 +175,15 @@ class RelGraph:
         self.seg_of = _i32(e, dev)              # sorted edge -> segment
         seg_ptr, seg_dst, seg_rel = _i32(e + 1, dev), _i32(e, dev), _i32(e, dev)
         self.inv_cnt = torch.empty(e, dtype=torch.float32, device=dev)   # per sorted edge
-        n_seg = torch.zeros(1, dtype=torch.int32, device=dev)
+        n_seg = torch.empty(1, dtype=torch.int32, device=dev)
         if static_segments:      # surplus segments: empty, last relation, targets spread over the nodes (they add zeros)
-            seg_ptr.fill_(e); seg_rel.fill_(r - 1)
-            seg_dst.copy_(_spread_pattern(e, n, dev))
-        L.call("bkg_rgcn_segments", L.ptr(sorted_keys), e, n, L.ptr(flag), L.ptr(scan), L.ptr(self.seg_of),
-               L.ptr(seg_ptr), L.ptr(seg_dst), L.ptr(seg_rel), L.ptr(self.inv_cnt), L.ptr(n_seg), L.ptr(ws),
-               ws.numel(), L.stream())
+            L.call("bkg_rgcn_segments_static", L.ptr(sorted_keys), e, n, r - 1, L.ptr(flag), L.ptr(scan), L.ptr(self.seg_of),
+                   L.ptr(seg_ptr), L.ptr(seg_dst), L.ptr(seg_rel), L.ptr(self.inv_cnt), L.ptr(n_seg), L.ptr(ws),
+                   ws.numel(), L.stream())
+        else:
+            L.call("bkg_rgcn_segments", L.ptr(sorted_keys), e, n, L.ptr(flag), L.ptr(scan), L.ptr(self.seg_of),
+                   L.ptr(seg_ptr), L.ptr(seg_dst), L.ptr(seg_rel), L.ptr(self.inv_cnt), L.ptr(n_seg), L.ptr(ws),
+                   ws.numel(), L.stream())
         self.num_segments = e if static_segments else int(n_seg.item())   # one host sync per distinct graph (sizes H)
         s = self.num_segments
         self.seg_ptr, self.seg_dst, self.seg_rel = seg_ptr[: s + 1], seg_dst[:s], seg_rel[:s]

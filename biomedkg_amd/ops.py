@@ -205,7 +205,9 @@ def gemm_grouped_k(a, b, group_ptr, num_groups, b_rows=None):
     m, n = a.size(1), b.size(1)
     chunk = L.lib().bkg_gemm_grouped_k_chunk(a.size(0), m, n, _PRECISION) if _PRECISION == 0 else 512
     _det_reserve((a.size(0) // chunk + num_groups + 1) * m * n)     # full chunks + one partial chunk per group
-    out = torch.zeros(num_groups, m, n, dtype=torch.float32, device=a.device)
+    # atomics accumulate into a zeroed result; the deterministic fp32 path's fixed-order reduce writes every element
+    new = torch.empty if (_PRECISION == 0 and _DET_WS is not None) else torch.zeros
+    out = new(num_groups, m, n, dtype=torch.float32, device=a.device)
     if b_rows is not None and not gathered_k_ok(a, b):
         raise ValueError("gathered rows need two bf16 tables with 128-aligned widths (bf16 mode)")
     if _PRECISION == 1:
@@ -366,7 +368,12 @@ def _plain_dropout_keep(relu, drop):
 
 def _gate(dout, out, scale):
     """Backward of ``dropout(relu(.))`` from the saved OUTPUT: ``out > 0`` iff pre > 0 and kept."""
-    g = torch.ops.aten.threshold_backward(dout, out, 0.0)        # dout where out > 0, else 0 (one launch)
+    if (dout.dtype == torch.float32 and out.dtype == torch.float32 and dout.is_contiguous() and out.is_contiguous()
+            and dout.numel() % 4 == 0 and dout.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0):
+        g = torch.empty_like(dout)
+        L.call("bkg_gate_f32", L.ptr(dout), L.ptr(out), float(scale), dout.numel(), L.ptr(g), L.stream())
+        return g
+    g = torch.ops.aten.threshold_backward(dout, out, 0.0)        # dout where out > 0, else 0
     return g.mul_(scale) if scale != 1.0 else g
 
 

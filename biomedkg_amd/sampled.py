@@ -166,6 +166,7 @@ class SaintGraphedKge:
         self.stream = torch.cuda.Stream()
         self.side, self.side2, self.sampler_stream = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
         self.copied = torch.cuda.Event()
+        self.branches = True
 
     # ---- the padded step (captured once per edge bucket)
     def _negatives(self, ei, et, e_b):
@@ -199,8 +200,9 @@ class SaintGraphedKge:
         if m._fix_edge_id is not None:
             et = torch.full_like(et, m._fix_edge_id)
         main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
+        side, side2 = (self.side, self.side2) if self.branches else (main, main)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             neg, neg_type, count = self._negatives(ei, et, e_b)
             if not m.neg_ratio:                                            # reference: the positives' own relation ids
                 neg_type = torch.where(self.iota_e[:e_b] < count, et, r)
@@ -212,12 +214,12 @@ class SaintGraphedKge:
             ops.kge_prepare_structures(ei_loss, et_loss, neg, neg_type, self.n_cap, r + 1)
         x = m.fusion_fn(x=self.x_ext.index_select(0, v["n_id"]))
         rg = plant_rel_graph(RelGraph(ei, et, self.n_cap, r, static_segments=True, defer_source_side=True))
-        self.side2.wait_stream(main)
-        with torch.cuda.stream(self.side2):                                # only the backward reads it: third branch
+        side2.wait_stream(main)
+        with torch.cuda.stream(side2):                                     # only the backward reads it: third branch
             rg.build_source_side()
         z = m.model.encode(x, ei, et)
-        main.wait_stream(self.side)
-        main.wait_stream(self.side2)
+        main.wait_stream(side)
+        main.wait_stream(side2)
         dec = m.model.decoder
         loss, pos_pred, neg_pred = ops.kge_bce_loss(z, dec.rel_emb, ei_loss, et_loss, neg, neg_type, dec.kind, reg=1e-2,
                                                     inv_total=inv_total, rows=v["sizes"][:1])

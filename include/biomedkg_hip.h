@@ -54,6 +54,11 @@ int bkg_rgcn_segments(const uint32_t* sorted, int64_t n, int64_t n_nodes, int32_
                       int32_t* seg_of, int32_t* seg_ptr, int32_t* seg_dst, int32_t* seg_rel, float* inv_cnt,
                       int32_t* n_seg, void* workspace, int64_t workspace_bytes, void* stream);
 /* per-sorted-edge segment id and 1 / |segment| back in original edge order (perm from bkg_sort_edges) */
+/* bkg_rgcn_segments with a FIXED segment count n (padded mini-batches of a captured step: no host read of n_seg):
+ * slots past the real count are empty segments of relation last_rel whose targets are spread over the nodes */
+int bkg_rgcn_segments_static(const uint32_t* sorted, int64_t n, int64_t n_nodes, int32_t last_rel, int32_t* flag_tmp,
+                             int32_t* scan_tmp, int32_t* seg_of, int32_t* seg_ptr, int32_t* seg_dst, int32_t* seg_rel,
+                             float* inv_cnt, int32_t* n_seg, void* workspace, int64_t workspace_bytes, void* stream);
 int bkg_rgcn_edge_order(const uint32_t* perm, const int32_t* seg_of, const float* inv_cnt, int64_t n,
                         int64_t* seg_of_edge, float* w_edge, void* stream);
 
@@ -302,6 +307,9 @@ int bkg_unpair_rows_bf16(const void* g, const int64_t* inv, void* out, int64_t n
 int64_t bkg_colsum_workspace_floats(int64_t n, int32_t d);
 int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, float* workspace, float* out,
                    void* stream);
+/* out = dout * scale where gate > 0, 0 elsewhere (the backward of the encoder's dropout(relu(.)), read off the saved
+ * output: biomedkg/model/encoder.py:50-59); contiguous fp32 tables */
+int bkg_gate_f32(const float* dout, const float* gate, float scale, int64_t numel, float* out, void* stream);
 
 /* ---- negative sampling of the KGE step (PyG 2.5.3 negative_sampling + the permuted relation ids of
  *      biomedkg/kge_module.py:86-102).  The population is PyG's: the N*(N-1) off-diagonal cells, cell (r, c) coded
