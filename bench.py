@@ -23,7 +23,8 @@ is the exact parity mode (its step time is reported on the same line as ``ms_per
 Also on the same JSON line (rank 0, N = 1): ``roofline`` for the kernel with the most GPU time among the gather /
 aggregate launches (HIP events on the launch stream inside the timed region; see ``roofline_of``), ``kernels`` for the
 others, ``grace_step`` (BASELINE configs[1]: GRACE / GCN d=128 on the 5k/50k graph, fp32) and ``ntxent`` (the NT-Xent
-matrix-core kernels against the fp32 / bf16 MFMA peaks), ``fusion`` (the modality projection), and ``cpu_baseline``
+matrix-core kernels against the fp32 / bf16 MFMA peaks), ``fusion`` (the modality projection), ``sampled_regime`` (the
+reference's own GraphSAINT mini-batch KGE loop: eager steps/s vs one hipGraph replay per step), and ``cpu_baseline``
 (the CPU oracle -- a torch restatement of the reference's PyG path -- timed on this box's host cores on a bounded
 down-scaled sample).
 """
@@ -371,6 +372,61 @@ def fusion_figures(dev, n=130_000):
     return {"workload": f"AttentionFusion over [{n}, 2, 768]", **out}
 
 
+def sampled_figures(dev, ei, et, n, r, walks=128, steps=150):
+    """The reference's own KGE regime (train_kge.py:86: GraphSAINT random-walk batches, walk_length 10, neg_ratio 10,
+    R-GCN 256-256-256 + DistMult) on the bench graph: steps/s of the eager loop (device sampler + ordinary step) and of
+    the padded, sync-free loop replayed as one hipGraph per step (biomedkg_amd/sampled.py), fp32."""
+    from biomedkg_amd import ops
+    from biomedkg_amd.kge_module import KGEModule
+    from biomedkg_amd.sampled import SaintGraphedKge
+    from biomedkg_amd.samplers import SaintBatchLoader
+    prec = ops.get_matmul_precision()
+    ops.set_matmul_precision("fp32")
+    try:
+        torch.manual_seed(7)
+        x = torch.randn(n, 256, device=dev) * 0.05
+        m = KGEModule("rgcn", "dismult", 256, 256, 256, 2, r, 2, "cosine", 1e-3, 0.0, "none", 10, "random").to(dev).train()
+        params = list(m.model.parameters())
+        opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+
+        def eager(k):
+            it = iter(SaintBatchLoader(x, ei, et, walks, walk_length=10, num_steps=k, seed=3))
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            nodes = edges = 0
+            for _ in range(k):
+                b = next(it)
+                opt.zero_grad(set_to_none=True)
+                loss = m.training_step(b)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(params, 1.0)
+                opt.step()
+                nodes += b.x.size(0); edges += b.edge_index.size(1)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / k, nodes / k, edges / k
+        eager(10)
+        t_eager, nodes, edges = eager(steps)
+        out = {"sampler": f"GraphSAINT random walk, {walks} roots x 10 steps", "mean_nodes": round(nodes, 1),
+               "mean_edges": round(edges, 1), "neg_ratio": 10, "eager_steps_per_s": round(1.0 / t_eager, 1)}
+        for key, det in (("graphed_steps_per_s", False), ("graphed_deterministic_steps_per_s", True)):
+            ops.set_deterministic(det)
+            sg = SaintGraphedKge(m, x, ei, et, walks, 10, torch.optim.Adam(params, lr=1e-3, fused=True), clip=1.0, seed=3)
+            for _ in range(60):
+                sg.step()
+            before = dict(sg.stats)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps):
+                sg.step()
+            torch.cuda.synchronize()
+            out[key] = round(steps / (time.perf_counter() - t0), 1)
+            out[key.replace("steps_per_s", "stats")] = {k: sg.stats[k] - before[k] for k in sg.stats}
+        ops.set_deterministic(False)
+        out["speedup"] = round(out["graphed_steps_per_s"] / out["eager_steps_per_s"], 2)
+        return out
+    finally:
+        ops.set_deterministic(False)
+        ops.set_matmul_precision(prec)
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -569,6 +625,8 @@ def main():
             out["grace_step"] = grace_figures(dev)
             out["ntxent"] = ntxent_figures(dev)
             out["fusion"] = fusion_figures(dev)
+            if mode == "single":
+                out["sampled_regime"] = sampled_figures(dev, step_k.batch.edge_index, step_k.batch.edge_type, n, r)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

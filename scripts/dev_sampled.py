@@ -55,7 +55,8 @@ def main(n=130_000, e=4_000_000, walks=128, steps=100, dim=256, neg_ratio=10, on
                     "step_ms": round(tt * 1e3, 3), "steps_per_s": round(1.0 / (ts + tt), 1)}})
     # the same regime through the padded, sync-free loop: eagerly, then as one hipGraph replay per step
     from biomedkg_amd.sampled import SaintGraphedKge
-    for name, graphs in ((("padded_eager", False),) if not only_graphed else ()) + (("graphed", True),):
+    for name, graphs in ((("padded_eager", False),) if not only_graphed else ()) + (("graphed", True), ("graphed_deterministic", True)):
+        ops.set_deterministic(name.endswith("deterministic"))
         opt2 = torch.optim.Adam(m.model.parameters(), lr=1e-3, fused=True)
         sg = SaintGraphedKge(m, x, ei, et, walks, 10, opt2, clip=1.0, seed=3, graphs=graphs)
         for _ in range(60 if graphs else 10):
@@ -67,6 +68,7 @@ def main(n=130_000, e=4_000_000, walks=128, steps=100, dim=256, neg_ratio=10, on
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
         out[name] = {"step_ms": round(dt * 1e3, 3), "steps_per_s": round(1.0 / dt, 1),
                      "stats": {k: sg.stats[k] - before[k] for k in sg.stats}}
+    ops.set_deterministic(False)
     print(json.dumps(out))
 
 

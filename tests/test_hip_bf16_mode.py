@@ -282,6 +282,7 @@ def test_bf16_training_follows_the_fp32_trajectory():
     ei, et = g["edge_index"].to(DEV), g["edge_type"].to(DEV)
     x = torch.randn(6000, 256, generator=torch.Generator().manual_seed(1)).to(DEV)
     curves = {}
+    ops.set_deterministic(True)      # both runs repeatable: the comparison is between precisions, not between atomic orders
     for mode in ("fp32", "bf16"):
         ops.set_matmul_precision(mode)
         torch.manual_seed(0)
