@@ -308,8 +308,15 @@ class SaintGraphedKge:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
-            with torch.cuda.graph(g):
-                self.losses[bucket] = self._padded_step(bucket).detach()
+            try:
+                with torch.cuda.graph(g):
+                    self.losses[bucket] = self._padded_step(bucket).detach()
+            except RuntimeError as why:      # a module on the path that cannot be captured: same steps, run eagerly
+                torch.cuda.synchronize()
+                self.graphs_on = False
+                self.optimizer.zero_grad(set_to_none=True)
+                print(f"[sampled] padded steps stay eager: {str(why).splitlines()[0]}", flush=True)
+                return loss
             self.execs[bucket] = g
             self.stats["captured"] += 1
             return loss

@@ -27,22 +27,22 @@ class AttentionFusion(torch.nn.Module):
         (``fusion.py:22-31`` treats dim 0 as the batch and dim -2 as the sequence), an O(n^2) accident no caller of the
         reference relies on (``fusion_fn`` only routes 3-D inputs with a fuser configured, ``gcl_module.py:43-50``).
         The fuser is never trained, so its output is a constant of (x, weights): it is cached per
-        (input version, weight versions, precision mode) and a steady-state training step pays one dictionary lookup."""
+        (input tensor object and version, weight versions, precision mode) and a steady-state training step pays one dictionary lookup."""
         if x.dim() != 3:
             raise ValueError("AttentionFusion expects [n, modalities, embed_dim]")
         params = (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias,
                   self.v_proj.bias)
-        key = (x.data_ptr(), x._version, tuple(x.shape), tuple((p.data_ptr(), p._version) for p in params),
-               ops.get_matmul_precision())
+        # keyed on the input OBJECT (not its address: a mini-batch loader's next batch may land on the same address)
+        key = (x._version, tuple((p.data_ptr(), p._version) for p in params), ops.get_matmul_precision())
         hit = self.__dict__.get("_fused_cache")
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit[2] is x and hit[0] == key:
             return hit[1]
         w = torch.cat(params[:3], dim=0)
         b = torch.cat(params[3:], dim=0)
         with torch.no_grad():
             out = ops.attention_fusion(x, w, b)
         if not x.requires_grad:
-            self.__dict__["_fused_cache"] = (key, out)          # plain attribute: not a buffer, not in the state_dict
+            self.__dict__["_fused_cache"] = (key, out, x)       # plain attribute: not a buffer, not in the state_dict
         return out
 
 

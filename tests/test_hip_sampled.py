@@ -170,6 +170,57 @@ def test_batches_outside_the_ladder_take_the_ordinary_step():
     assert all(torch.isfinite(l) for l in losses)
 
 
+@pytest.mark.parametrize("init,fuse,decoder,fix", [("lm", "attention", "dismult", None), ("lm", "redaf", "transe", None),
+                                                   ("gcl", "none", "dismult", 1), ("random", "none", "transe", None)])
+def test_every_input_form_of_the_kge_module_replays(init, fuse, decoder, fix):
+    """[N, 2, D] language-model features through the attention / ReDAF fuser, [N, 1, D] GCL embeddings, fix_edge_id
+    (the DPI fine-tuning setting), TransE: the padded step captures and replays, and tracks the eager padded loop."""
+    from biomedkg_amd import synthetic
+    from biomedkg_amd.kge_module import KGEModule
+    from biomedkg_amd.sampled import SaintGraphedKge
+    ei, et, n, r = _graph()
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    if init == "lm":
+        x = synthetic.lm_features(n, 2, 64, seed=4).to(DEV)
+    elif init == "gcl":
+        x = torch.randn(n, 1, 64, device=DEV, generator=gen) * 0.3
+    else:
+        x = torch.randn(n, 64, device=DEV, generator=gen) * 0.3
+    runs = {}
+    for graphs in (True, False):
+        torch.manual_seed(0)
+        mod = KGEModule(encoder_name="rgcn", decoder_name=decoder, in_dim=64, hidden_dim=64, out_dim=64, num_hidden_layers=1,
+                        num_relation=r, num_heads=2, scheduler_type="cosine", learning_rate=1e-3, warm_up_ratio=0.0,
+                        fuse_method=fuse, neg_ratio=2, node_init_method=init).to(DEV).train()
+        if fix is not None:
+            mod.fix_edge_id = fix
+        sg = SaintGraphedKge(mod, x, ei, et, batch_size=32, seed=9, graphs=graphs, buckets=(512, 1024, 2048, 4096))
+        runs[graphs] = [float(sg.step()) for _ in range(12)]
+        if graphs:
+            assert sg.graphs_on and sg.stats["replayed"] >= 6, sg.stats
+    a, b = torch.tensor(runs[True]), torch.tensor(runs[False])
+    assert torch.isfinite(a).all()
+    torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-5)     # (float atomics in the weight gradients: not bitwise here)
+
+
+def test_fusion_cache_is_not_fooled_by_a_recycled_address():
+    """A mini-batch loader's next batch usually lands on the address of the one just freed: the cached AttentionFusion
+    output must belong to the tensor OBJECT, not to its address."""
+    from biomedkg_amd import synthetic
+    from biomedkg_amd.utils.fusion import AttentionFusion
+    torch.manual_seed(0)
+    fuse = AttentionFusion(64).to(DEV)
+    a = synthetic.lm_features(500, 2, 64, seed=1).to(DEV)
+    out_a = fuse(a).clone()
+    del a                                                   # (b usually lands on a's address)
+    b = synthetic.lm_features(500, 2, 64, seed=2).to(DEV)
+    out_b = fuse(b)
+    fresh = AttentionFusion(64).to(DEV)
+    fresh.load_state_dict(fuse.state_dict())
+    torch.testing.assert_close(out_b, fresh(b), rtol=0, atol=0)
+    assert not torch.equal(out_b, out_a)
+
+
 def test_trainer_replays_the_saint_regime(tmp_path):
     """train_kge.py with data.sampler=device: the Trainer stand-in hands the GraphSAINT loader to the graphed loop."""
     import train_kge
