@@ -574,8 +574,8 @@ def main():
             step_k.batch.edge_index = step_g.batch.edge_index = ei
             step_k.batch.edge_type = step_k.batch.edge_type.clone()
             step_g(); step_k()
-        fresh()
-        ms_fresh = timed(fresh) * 1e3
+        fresh(); fresh()
+        ms_fresh = timed(fresh, reps=5) * 1e3
 
     ms_fp32 = None
     if world == 1 and not args.no_extras and args.precision == "bf16":

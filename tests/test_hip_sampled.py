@@ -203,6 +203,32 @@ def test_every_input_form_of_the_kge_module_replays(init, fuse, decoder, fix):
     torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-5)     # (float atomics in the weight gradients: not bitwise here)
 
 
+def test_the_epoch_scheduler_reaches_the_replayed_steps():
+    """The optimizer's learning rate is a device scalar (capturable Adam): torch's schedulers fill it in place, so a
+    replayed graph trains with the scheduled rate -- here a schedule that drops it to 0 freezes the weights."""
+    from biomedkg_amd.sampled import SaintGraphedKge
+    ei, et, n, r = _graph()
+    x = torch.randn(n, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 0.3
+    mod = _module(r).train()
+    opt = torch.optim.Adam(mod.model.parameters(), lr=5e-3, fused=True)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda epoch: 1.0 if epoch == 0 else 0.0)   # built on the float rate
+    sg = SaintGraphedKge(mod, x, ei, et, batch_size=40, optimizer=opt, seed=5, buckets=(4096,))
+    for _ in range(6):
+        sg.step()
+    assert sg.stats["replayed"] >= 4
+    before = [p.detach().clone() for p in mod.model.parameters()]
+    sg.step()
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, mod.model.parameters()))   # still training
+    sched.step()                                                                                 # "epoch 1": rate 0
+    assert float(opt.param_groups[0]["lr"]) == 0.0 and isinstance(opt.param_groups[0]["lr"], torch.Tensor)
+    before = [p.detach().clone() for p in mod.model.parameters()]
+    for _ in range(3):
+        sg.step()
+    assert sg.stats["captured"] == 1
+    for a, p in zip(before, mod.model.parameters()):
+        assert torch.equal(a, p.detach())
+
+
 def test_fusion_cache_is_not_fooled_by_a_recycled_address():
     """A mini-batch loader's next batch usually lands on the address of the one just freed: the cached AttentionFusion
     output must belong to the tensor OBJECT, not to its address."""
