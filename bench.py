@@ -621,14 +621,20 @@ def main():
             "roofline": roof, "kernels": others,
             "cpu_baseline": None,
         }
+        def extra(fn, *a):      # the side figures never cost the headline line: a failure is reported in its place
+            try:
+                return fn(*a)
+            except Exception as why:          # noqa: BLE001
+                torch.cuda.synchronize()
+                return {"error": f"{type(why).__name__}: {why}"[:300]}
         if world == 1 and not args.no_extras:
-            out["grace_step"] = grace_figures(dev)
-            out["ntxent"] = ntxent_figures(dev)
-            out["fusion"] = fusion_figures(dev)
+            out["grace_step"] = extra(grace_figures, dev)
+            out["ntxent"] = extra(ntxent_figures, dev)
+            out["fusion"] = extra(fusion_figures, dev)
             if mode == "single":
-                out["sampled_regime"] = sampled_figures(dev, step_k.batch.edge_index, step_k.batch.edge_type, n, r)
+                out["sampled_regime"] = extra(sampled_figures, dev, step_k.batch.edge_index, step_k.batch.edge_type, n, r)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = extra(cpu_baseline, args)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
