@@ -147,7 +147,13 @@ def sref(struct):
     return None if struct is None else ctypes.cast(ctypes.byref(struct), c_void_p)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """Raw handle of torch's CURRENT stream on the current device (every launch of the library goes there)."""
+    if _raw_stream is not None:          # ~0.3 us instead of ~2 us for the Stream object: it is paid on every launch
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
