@@ -82,21 +82,29 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
-// few rows (a mini-batch): ONE launch -- block = 8 row groups x 32 columns over ALL rows, groups added in group order
+// few rows (a mini-batch): ONE launch -- block = 32 row groups x 32 columns over ALL rows (4 rows in flight per
+// thread), groups added in group order
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ x, int64_t ldx, int n, int d,
-                                                           float* __restrict__ out) {
-  __shared__ float red[8][32];
+__global__ __launch_bounds__(1024) void colsum_small_kernel(const T* __restrict__ x, int64_t ldx, int n, int d,
+                                                            float* __restrict__ out) {
+  __shared__ float red[32][33];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
   float s = 0.f;
-  if (c < d)
-    for (int r = g; r < n; r += 8) s += (float)x[(int64_t)r * ldx + c];
+  if (c < d) {
+    int r = g;
+    for (; r + 96 < n; r += 128) {
+      const float v0 = (float)x[(int64_t)r * ldx + c], v1 = (float)x[(int64_t)(r + 32) * ldx + c];
+      const float v2 = (float)x[(int64_t)(r + 64) * ldx + c], v3 = (float)x[(int64_t)(r + 96) * ldx + c];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; r < n; r += 32) s += (float)x[(int64_t)r * ldx + c];
+  }
   red[g][threadIdx.x & 31] = s;
   __syncthreads();
   if (g == 0 && c < d) {
     float t = red[0][threadIdx.x];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+    for (int k = 1; k < 32; ++k) t += red[k][threadIdx.x];
     out[c] = t;
   }
 }
@@ -142,8 +150,8 @@ extern "C" int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int
     return 0;
   }
   if (n <= 4096) {
-    if (x_is_bf16) hipLaunchKernelGGL(colsum_small_kernel<__bf16>, dim3(ceil_div(d, 32)), dim3(256), 0, s, (const __bf16*)x, ldx, (int)n, d, out);
-    else hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(ceil_div(d, 32)), dim3(256), 0, s, (const float*)x, ldx, (int)n, d, out);
+    if (x_is_bf16) hipLaunchKernelGGL(colsum_small_kernel<__bf16>, dim3(ceil_div(d, 32)), dim3(1024), 0, s, (const __bf16*)x, ldx, (int)n, d, out);
+    else hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(ceil_div(d, 32)), dim3(1024), 0, s, (const float*)x, ldx, (int)n, d, out);
     return check_launch("bkg_colsum_f32(small)");
   }
   const int n_blocks = (int)(bkg_colsum_workspace_floats(n, d) / d);

@@ -203,33 +203,59 @@ __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
   return r;
 }
 
-// loss = inv_total * sum(part) + reg * (mean_{rows < n_real}(z^2) + mean(rel^2))
+// loss = inv_total * sum(part) + reg * (mean_{rows < n_real}(z^2) + mean(rel^2)).  FIN_BLOCKS blocks add their
+// slices (fixed thread -> element mapping, fixed-order tree) into slots of `scratch`; the block that takes the last
+// ticket adds the slots in slot order and writes the loss -- one launch, repeatable.  scratch: 3 * FIN_BLOCKS doubles
+// + one uint32 ticket (zero before the first use; the kernel leaves it zero).
+constexpr int FIN_BLOCKS = 64;
+
 __global__ __launch_bounds__(1024) void kge_loss_finish_kernel(const float* __restrict__ part, int n_part, float inv_total,
                                                                const float* __restrict__ inv_total_dev,
                                                                const float* __restrict__ z, int64_t ldz, int n_cap, int d,
                                                                const int64_t* __restrict__ n_real_dev,
                                                                const float* __restrict__ rel, int64_t ldr, int n_rel,
-                                                               float reg, float* __restrict__ loss) {
+                                                               float reg, double* __restrict__ scratch,
+                                                               unsigned int* __restrict__ ticket, float* __restrict__ loss) {
   __shared__ double sh[1024];
-  const int t = threadIdx.x;
-  double a = 0.0, b = 0.0, c = 0.0;
-  for (int i = t; i < n_part; i += 1024) a += (double)part[i];
-  a = block_sum_1024(a, sh);
+  __shared__ bool last;
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int64_t gt = (int64_t)b * 1024 + t, stride = (int64_t)FIN_BLOCKS * 1024;
+  double a = 0.0, zz = 0.0, rr = 0.0;
+  for (int64_t i = gt; i < n_part; i += stride) a += (double)part[i];
   int n_rows = n_cap;
   if (n_real_dev) n_rows = (int)min((int64_t)n_cap, n_real_dev[0]);
   if (reg != 0.f) {
-    const int64_t nz = (int64_t)n_rows * d, nr = (int64_t)n_rel * d;
-    for (int64_t e = t; e < nz; e += 1024) { const float v = z[(e / d) * ldz + e % d]; b += (double)v * v; }
-    for (int64_t e = t; e < nr; e += 1024) { const float v = rel[(e / d) * ldr + e % d]; c += (double)v * v; }
-    b = block_sum_1024(b, sh);
-    c = block_sum_1024(c, sh);
+    const int d4 = d >> 2;                     // rows are read as float4 (d % 4 == 0, 16-byte aligned rows: host check)
+    const int64_t nz = (int64_t)n_rows * d4, nr = (int64_t)n_rel * d4;
+    for (int64_t e = gt; e < nz; e += stride) {
+      const float4 v = *reinterpret_cast<const float4*>(z + (e / d4) * ldz + (e % d4) * 4);
+      zz += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (int64_t e = gt; e < nr; e += stride) {
+      const float4 v = *reinterpret_cast<const float4*>(rel + (e / d4) * ldr + (e % d4) * 4);
+      rr += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
   }
+  a = block_sum_1024(a, sh);
+  zz = block_sum_1024(zz, sh);
+  rr = block_sum_1024(rr, sh);
   if (t == 0) {
-    const double it = inv_total_dev ? (double)inv_total_dev[0] : (double)inv_total;
-    double out = a * it;
-    if (reg != 0.f) out += (double)reg * (b / ((double)max(n_rows, 1) * d) + c / ((double)n_rel * d));
-    loss[0] = (float)out;
+    scratch[b] = a; scratch[FIN_BLOCKS + b] = zz; scratch[2 * FIN_BLOCKS + b] = rr;
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == (unsigned)(FIN_BLOCKS - 1);
   }
+  __syncthreads();
+  if (!last || t != 0) return;
+  __threadfence();
+  double sa = 0.0, sz = 0.0, sr = 0.0;
+  for (int k = 0; k < FIN_BLOCKS; ++k) {
+    sa += scratch[k]; sz += scratch[FIN_BLOCKS + k]; sr += scratch[2 * FIN_BLOCKS + k];
+  }
+  const double it = inv_total_dev ? (double)inv_total_dev[0] : (double)inv_total;
+  double out = sa * it;
+  if (reg != 0.f) out += (double)reg * (sz / ((double)max(n_rows, 1) * d) + sr / ((double)n_rel * d));
+  loss[0] = (float)out;
+  *ticket = 0u;
 }
 
 // dst[row, :] = dst[row, :] * g + src[row, :] * (g * coef / rows)   for row < rows (= n_real or n), dst * g beyond;
@@ -252,12 +278,19 @@ __global__ __launch_bounds__(256) void scale_add_rows_kernel(float* __restrict__
 
 using namespace bkg;
 
+extern "C" int64_t bkg_kge_loss_finish_scratch_bytes() { return 3 * FIN_BLOCKS * sizeof(double) + 16; }
+
 extern "C" int bkg_kge_loss_finish_f32(const float* part, int32_t n_part, float inv_total, const float* inv_total_dev,
                                        const float* z, int64_t ldz, int32_t n_cap, int32_t d, const int64_t* n_real_dev,
-                                       const float* rel, int64_t ldr, int32_t n_rel, float reg, float* loss, void* stream) {
+                                       const float* rel, int64_t ldr, int32_t n_rel, float reg, void* scratch, float* loss,
+                                       void* stream) {
   BKG_ARG(n_part >= 0 && n_cap >= 0 && d > 0 && n_rel > 0, "bkg_kge_loss_finish_f32: bad sizes");
-  hipLaunchKernelGGL(kge_loss_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, n_part, inv_total,
-                     inv_total_dev, z, ldz, n_cap, d, n_real_dev, rel, ldr, n_rel, reg, loss);
+  BKG_ARG(d % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && (uintptr_t)z % 16 == 0 && (uintptr_t)rel % 16 == 0 &&
+              (uintptr_t)scratch % 8 == 0, "bkg_kge_loss_finish_f32: 16-byte aligned rows, d % 4 == 0");
+  double* slots = reinterpret_cast<double*>(scratch);
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(slots + 3 * FIN_BLOCKS);
+  hipLaunchKernelGGL(kge_loss_finish_kernel, dim3(FIN_BLOCKS), dim3(1024), 0, (hipStream_t)stream, part, n_part, inv_total,
+                     inv_total_dev, z, ldz, n_cap, d, n_real_dev, rel, ldr, n_rel, reg, slots, ticket, loss);
   return check_launch("bkg_kge_loss_finish_f32");
 }
 

@@ -164,11 +164,17 @@ __global__ __launch_bounds__(256) void negative_candidates_dev_kernel(const int6
                                                                       const unsigned long long* __restrict__ pos_tab,
                                                                       uint64_t pos_mask, uint64_t* __restrict__ keys,
                                                                       int32_t* __restrict__ flag) {
+  __shared__ Feistel pi;          // the block's copy of the bijection and of the candidate count: built by one lane
+  __shared__ int64_t n_cand;      // (the count takes a double division, the keys six mixes)
+  if (threadIdx.x == 0) {
+    const int64_t n = sizes[0];
+    n_cand = n < 2 ? 0 : dev_candidates(sizes, neg_ratio, cap);
+    if (n >= 2) pi = make_feistel((uint64_t)(n * (n - 1)), dev_seed(seed, epoch, 1));
+  }
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= cap) return;
-  const int64_t n = sizes[0];
-  if (n < 2 || i >= dev_candidates(sizes, neg_ratio, cap)) { flag[i] = 0; return; }
-  const Feistel pi = make_feistel((uint64_t)(n * (n - 1)), dev_seed(seed, epoch, 1));
+  if (i >= n_cand) { flag[i] = 0; return; }
   const uint64_t key = pi((uint64_t)i);
   keys[i] = key;
   flag[i] = hs_contains(pos_tab, pos_mask, key) ? 0 : 1;
@@ -207,11 +213,13 @@ __global__ __launch_bounds__(256) void permute_gather_dev_kernel(const int64_t* 
                                                                  uint64_t seed, const uint32_t* __restrict__ epoch,
                                                                  const int64_t* __restrict__ count, int64_t pad,
                                                                  int64_t out_cap, int64_t* __restrict__ out) {
+  __shared__ Feistel pi;
+  const int64_t e = sizes[1];
+  if (threadIdx.x == 0 && e > 0) pi = make_feistel((uint64_t)(neg_ratio * e), dev_seed(seed, epoch, 2));
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= out_cap) return;
-  const int64_t e = sizes[1];
   if (i >= count[0] || e <= 0) { out[i] = pad; return; }
-  const Feistel pi = make_feistel((uint64_t)(neg_ratio * e), dev_seed(seed, epoch, 2));
   out[i] = src[pi((uint64_t)i) % (uint64_t)e];
 }
 

@@ -965,6 +965,17 @@ def kge_prepare_structures(pos_edge_index, pos_edge_type, neg_edge_index, neg_ed
             incidence_of(ei, num_nodes)
 
 
+_FINISH_SCRATCH = {}
+
+
+def _finish_scratch(device):
+    """Slots + ticket of bkg_kge_loss_finish_f32 (zeroed once; launches on one stream at a time use it in turn)."""
+    key = str(device)
+    if key not in _FINISH_SCRATCH:
+        _FINISH_SCRATCH[key] = torch.zeros(L.lib().bkg_kge_loss_finish_scratch_bytes(), dtype=torch.uint8, device=device)
+    return _FINISH_SCRATCH[key]
+
+
 class _KgeBceLoss(torch.autograd.Function):
     """``binary_cross_entropy_with_logits(cat(decode(pos), decode(neg)), cat(1, 0))`` of the reference's
     ``KGEModule.training_step`` (kge_module.py:121-127) as ONE op: the forward sweeps each triplet set once
@@ -1034,7 +1045,8 @@ class _KgeBceLoss(torch.autograd.Function):
         if padded:   # BCE mean + L2 over the real rows in ONE launch (a captured mini-batch step is bound by its launch count)
             out = torch.empty((), dtype=torch.float32, device=dev)
             L.call("bkg_kge_loss_finish_f32", L.ptr(part), part.numel(), 0.0, L.ptr(inv_total), L.ptr(z), z.stride(0),
-                   z.size(0), d, L.ptr(rows), L.ptr(rel_emb), rel_emb.stride(0), r, float(reg), L.ptr(out), L.stream())
+                   z.size(0), d, L.ptr(rows), L.ptr(rel_emb), rel_emb.stride(0), r, float(reg),
+                   L.ptr(_finish_scratch(dev)), L.ptr(out), L.stream())
             return out, scores[0], scores[1]
         loss = part.sum(dtype=torch.float64) / total
         if reg:      # + reg * (mean(z^2) + mean(rel_emb^2)), reference kge_module.py:128-129: two one-launch norms

@@ -176,9 +176,10 @@ int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel);
  * row count from device memory.  bkg_scale_add_rows_f32: dst = dst * g + src * (g * coef / rows) on the first `rows`
  * rows (n_real_dev[0], or n), dst * g beyond; g = gloss[0] -- the backward of that L2 term folded into the scaling of
  * the scorer's gradient by the upstream gradient. */
+int64_t bkg_kge_loss_finish_scratch_bytes(void);   /* zero it once; the kernel leaves its ticket zero */
 int bkg_kge_loss_finish_f32(const float* part, int32_t n_part, float inv_total, const float* inv_total_dev, const float* z,
                             int64_t ldz, int32_t n_cap, int32_t d, const int64_t* n_real_dev, const float* rel,
-                            int64_t ldr, int32_t n_rel, float reg, float* loss, void* stream);
+                            int64_t ldr, int32_t n_rel, float reg, void* scratch, float* loss, void* stream);
 int bkg_scale_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t n, int32_t d,
                            const float* gloss, float coef, const int64_t* n_real_dev, void* stream);
 /* wave_ptr[n_rel + 1]: first wave of each relation in that pass (chunk = 64 triplets per wave) */
