@@ -22,16 +22,39 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int G, int kchunk, int n_chunks) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t per = (int64_t)M * N;
+  // the slabs of group g: chunks [first, first + cnt).  When a block lies inside one group (per % 256 == 0) one lane
+  // walks group_ptr for all of them.
+  __shared__ int s_first, s_cnt;
+  int first = 0, cnt = n_chunks;
+  const bool uniform = per % 256 == 0;
+  if (group_ptr && uniform) {
+    if (threadIdx.x == 0) {
+      const int g0 = (int)(((int64_t)blockIdx.x * 256) / per);
+      int f = 0;
+      for (int q = 0; q < g0 && q < G; ++q) f += (group_ptr[q + 1] - group_ptr[q] + kchunk - 1) / kchunk;
+      s_first = f;
+      s_cnt = g0 < G ? (group_ptr[g0 + 1] - group_ptr[g0] + kchunk - 1) / kchunk : 0;
+    }
+    __syncthreads();
+    first = s_first; cnt = s_cnt;
+  }
   if (i >= per * G) return;
   const int g = (int)(i / per);
   const int64_t e = i % per;
-  int first = 0, cnt = n_chunks;
-  if (group_ptr) {
+  if (group_ptr && !uniform) {
+    first = 0;
     for (int q = 0; q < g; ++q) first += (group_ptr[q + 1] - group_ptr[q] + kchunk - 1) / kchunk;
     cnt = (group_ptr[g + 1] - group_ptr[g] + kchunk - 1) / kchunk;
   }
   float acc = 0.f;
-  for (int c = 0; c < cnt; ++c) acc += ws[(int64_t)(first + c) * per + e];      // fixed order: bitwise repeatable
+  const float* p = ws + (int64_t)first * per + e;
+  int c = 0;
+  for (; c + 4 <= cnt; c += 4) {      // four slabs in flight; still added in chunk order: bitwise repeatable
+    const float v0 = p[(int64_t)c * per], v1 = p[(int64_t)(c + 1) * per], v2 = p[(int64_t)(c + 2) * per],
+                v3 = p[(int64_t)(c + 3) * per];
+    acc += v0; acc += v1; acc += v2; acc += v3;
+  }
+  for (; c < cnt; ++c) acc += p[(int64_t)c * per];
   C[(int64_t)g * strideC + (e / N) * ldc + e % N] = acc;
 }
 
