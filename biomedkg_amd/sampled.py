@@ -40,6 +40,21 @@ EDGE_BUCKETS = (1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 3
 _SIZES = 3     # nodes, edges, loop-free edges
 
 
+def choose_bucket(buckets, neg_ratio, n_b, e_b, e_free):
+    """The edge bucket a batch of ``n_b`` nodes / ``e_b`` edges (``e_free`` of them with head != tail) replays under, or
+    None when it must take the ordinary eager step: more edges than the largest bucket, or a batch on which PyG's
+    ``negative_sampling`` would leave its first round (``kge_module.py:93``: all cells enumerated because
+    ``int(1.1 k / prob)`` reaches the population, or so dense -- ``prob <= 0.9`` -- that later rounds could be needed)."""
+    if n_b < 2 or e_b < 1 or e_b > buckets[-1]:
+        return None
+    population = n_b * (n_b - 1)
+    prob = 1.0 - e_free / population
+    k = neg_ratio * e_b
+    if prob <= 0.9 or int(1.1 * k / prob) >= population:
+        return None
+    return next(b for b in buckets if b >= e_b)
+
+
 class SaintDeviceSampler:
     """GraphSAINT random-walk batches into fixed-capacity device buffers (see the module docstring).
 
@@ -253,15 +268,7 @@ class SaintGraphedKge:
         return loss.detach()
 
     def bucket_of(self, n_b, e_b, e_free):
-        """The edge bucket a batch replays under, or None when it must take the ordinary eager step."""
-        if n_b < 2 or e_b < 1 or e_b > self.buckets[-1]:
-            return None
-        population = n_b * (n_b - 1)
-        prob = 1.0 - e_free / population
-        k = self.neg_ratio * e_b
-        if prob <= 0.9 or int(1.1 * k / prob) >= population:              # PyG would enumerate / need later rounds
-            return None
-        return next(b for b in self.buckets if b >= e_b)
+        return choose_bucket(self.buckets, self.neg_ratio, n_b, e_b, e_free)
 
     def step(self):
         trainer = self.module.__dict__.pop("trainer", None)                # .log() inside a step would sync

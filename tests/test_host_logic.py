@@ -106,3 +106,25 @@ def test_link_split_message_passing_graphs():
     assert sum((cf - cte).values()) == n_test                            # what is left out of it is the test supervision set
     assert torch.equal(te.edge_index[:, : tr.edge_index.size(1)], tr.edge_index)   # train edges first, then val
     assert dm.data.num_edge_types == 5 and len(dm.edge_map_index) == 5
+
+
+def test_edge_bucket_choice_of_the_padded_mini_batch_loop():
+    """biomedkg_amd/sampled.py: which captured graph a GraphSAINT batch replays under -- and when it must not."""
+    from biomedkg_amd.sampled import EDGE_BUCKETS, SaintDeviceSampler, choose_bucket
+    b = (1024, 2048, 4096)
+    assert choose_bucket(b, 10, 900, 2700, 2690) == 4096 and choose_bucket(b, 10, 900, 1024, 1000) == 1024
+    assert choose_bucket(b, 10, 900, 1025, 1000) == 2048
+    assert choose_bucket(b, 10, 900, 4097, 4000) is None                 # past the ladder
+    assert choose_bucket(b, 10, 1, 0, 0) is None and choose_bucket(b, 10, 5, 0, 0) is None
+    # PyG's first round would not do: 1.1 k / prob reaches the population (it enumerates every cell then) ...
+    assert choose_bucket(b, 10, 60, 400, 400) is None                    # 60 * 59 = 3540 cells, 4000 negatives asked for
+    # ... or the batch is dense (prob <= 0.9: later rounds could be needed)
+    assert choose_bucket(b, 1, 100, 1100, 1000) is None                  # 1000 / 9900 loop-free positives > 10 %
+    assert choose_bucket(b, 1, 100, 900, 900) == 1024
+    assert list(EDGE_BUCKETS) == sorted(EDGE_BUCKETS) and all(y / x <= 1.51 for x, y in zip(EDGE_BUCKETS, EDGE_BUCKETS[1:]))
+    # the flat batch buffer: sizes | n_id | src | dst | type | eid, disjoint and complete
+    import torch
+    buf = torch.arange(3 + 7 + 4 * 5)
+    v = SaintDeviceSampler.views(buf, 7, 5)
+    assert [k for k in v] == ["sizes", "n_id", "src", "dst", "type", "eid"]
+    assert torch.equal(torch.cat([v[k] for k in v]), buf)
