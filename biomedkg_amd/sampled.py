@@ -34,7 +34,7 @@ from . import ops
 from . import rand as R
 from .graph import RelGraph, graph_of, plant_rel_graph
 from .graphs import make_capturable
-from .samplers import SubgraphBatch
+from .samplers import SubgraphBatch, rows_of
 
 EDGE_BUCKETS = (1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536)
 _SIZES = 3     # nodes, edges, loop-free edges
@@ -182,6 +182,7 @@ class SaintGraphedKge:
         self.side, self.side2, self.sampler_stream = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
         self.copied = torch.cuda.Event()
         self.branches = True
+        self._pinned = []
 
     # ---- the padded step (captured once per edge bucket)
     def _negatives(self, ei, et, e_b):
@@ -227,7 +228,7 @@ class SaintGraphedKge:
             L.call("bkg_padded_loss_inputs", L.ptr(v["sizes"]), L.ptr(count), L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), e_b,
                    self.n_cap, r, L.ptr(ei_loss[0]), L.ptr(ei_loss[1]), L.ptr(et_loss), L.ptr(inv_total), L.stream())
             ops.kge_prepare_structures(ei_loss, et_loss, neg, neg_type, self.n_cap, r + 1)
-        x = m.fusion_fn(x=self.x_ext.index_select(0, v["n_id"]))
+        x = m.fusion_fn(x=rows_of(self.x_ext, v["n_id"]))
         rg = plant_rel_graph(RelGraph(ei, et, self.n_cap, r, static_segments=True, defer_source_side=True))
         side2.wait_stream(main)
         with torch.cuda.stream(side2):                                     # only the backward reads it: third branch
@@ -256,7 +257,8 @@ class SaintGraphedKge:
         v = self.v
         ei = torch.stack([v["src"][:e_b], v["dst"][:e_b]])
         n_id = v["n_id"][:n_b].clone()
-        return SubgraphBatch(self.x[n_id], ei, v["type"][:e_b].clone(), n_b, n_id, v["eid"][:e_b].clone())
+        # (rows of the SAME table object as the padded steps: one fused copy of it serves both)
+        return SubgraphBatch(rows_of(self.x_ext, n_id), ei, v["type"][:e_b].clone(), n_b, n_id, v["eid"][:e_b].clone())
 
     def _eager_step(self, n_b, e_b):
         self.optimizer.zero_grad(set_to_none=True)
@@ -315,6 +317,10 @@ class SaintGraphedKge:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
+            # a captured graph reads the fuser's cached table output by address: keep those tensors alive with the loop
+            for hit in getattr(self.module.modality_transform, "__dict__", {}).get("_fused_cache", []):
+                if all(hit[1] is not t for t in self._pinned):
+                    self._pinned.append(hit[1])
             try:
                 with torch.cuda.graph(g):
                     self.losses[bucket] = self._padded_step(bucket).detach()

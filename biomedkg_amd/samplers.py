@@ -23,6 +23,14 @@ class SubgraphBatch:
         return self
 
 
+def rows_of(table, n_id):
+    """``table[n_id]``, tagged with where it came from: modules whose first op is a row-wise constant function of the
+    features (the never-trained AttentionFusion, ``biomedkg_amd/utils/fusion.py``) apply it to the table once and gather."""
+    x = table.index_select(0, n_id)
+    x._bkg_rows_of = (table, n_id)
+    return x
+
+
 def _relabel(n_id, num_nodes, *ids):
     lut = torch.full((num_nodes,), -1, dtype=torch.int64, device=n_id.device)
     lut[n_id] = torch.arange(n_id.numel(), device=n_id.device)
@@ -137,7 +145,7 @@ class NeighborBatchLoader:
             seeds = order[i:i + self.batch_size]
             n_id, ei, e_id = self.sampler.sample(seeds)
             et = self.edge_type[e_id] if self.edge_type is not None else None
-            yield SubgraphBatch(self.x[n_id], ei, et, seeds.numel(), n_id, e_id)
+            yield SubgraphBatch(rows_of(self.x, n_id), ei, et, seeds.numel(), n_id, e_id)
 
 
 class SaintBatchLoader:
@@ -159,4 +167,4 @@ class SaintBatchLoader:
         for _ in range(self.num_steps):
             n_id, ei, e_id = self.sampler.sample()
             et = self.edge_type[e_id] if self.edge_type is not None else None
-            yield SubgraphBatch(self.x[n_id], ei, et, n_id.numel(), n_id, e_id)
+            yield SubgraphBatch(rows_of(self.x, n_id), ei, et, n_id.numel(), n_id, e_id)

@@ -229,6 +229,25 @@ def test_the_epoch_scheduler_reaches_the_replayed_steps():
         assert torch.equal(a, p.detach())
 
 
+def test_fusing_the_table_once_equals_fusing_every_batch():
+    """The device loaders tag ``x = table[n_id]``; AttentionFusion (row-wise, never trained) then fuses the table once
+    and gathers: bit for bit what fusing the gathered rows gives."""
+    from biomedkg_amd import synthetic
+    from biomedkg_amd.samplers import rows_of
+    from biomedkg_amd.utils.fusion import AttentionFusion
+    torch.manual_seed(0)
+    fuse = AttentionFusion(64).to(DEV)
+    table = synthetic.lm_features(6000, 2, 64, seed=1).to(DEV)
+    for seed in (1, 2):
+        n_id = torch.randint(0, 6000, (1500,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+        tagged = rows_of(table, n_id)
+        plain = table[n_id]
+        assert torch.equal(tagged, plain)
+        a, b = fuse(tagged), fuse(plain)
+        assert torch.equal(a, b)
+    assert any(h[2] is table for h in fuse.__dict__["_fused_cache"])
+
+
 def test_fusion_cache_is_not_fooled_by_a_recycled_address():
     """A mini-batch loader's next batch usually lands on the address of the one just freed: the cached AttentionFusion
     output must belong to the tensor OBJECT, not to its address."""
