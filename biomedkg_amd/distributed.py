@@ -44,11 +44,13 @@ class GradBucket:
         self.params = [p for p in params if p.requires_grad]
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self._flat = None
+        # (BKG_PARTITION_FORCE_COLLECTIVES=1: a 1-rank group still issues its all-reduce -- functional check of the calls)
+        self.live = self.world > 1 or (os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
 
     def begin(self):
         """Pack the gradients into the flat bucket and start the all-reduce (asynchronously: the collective runs on
         the backend's own stream / thread).  ``finish`` must be called before the gradients are used."""
-        if self.world == 1:
+        if not self.live:
             return
         for p in self.params:
             if p.grad is None:
@@ -66,7 +68,7 @@ class GradBucket:
 
     def finish(self):
         """Wait for the collective started by ``begin`` and write the averaged gradients back."""
-        if self.world == 1 or getattr(self, "_work", None) is None:
+        if not self.live or getattr(self, "_work", None) is None:
             return
         self._work.wait()
         self._work = None

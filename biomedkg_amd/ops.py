@@ -433,7 +433,7 @@ def _dims(graph):
     gathers from the all-gathered ``n_table``-row table and carries the collective pair in ``comm``."""
     n = graph.num_nodes
     comm = getattr(graph, "comm", None)
-    if comm is not None and comm.world == 1:
+    if comm is not None and not comm.live:
         comm = None                        # one rank: nothing to exchange, no fp32 partial tables needed
     return getattr(graph, "n_out", n), getattr(graph, "n_table", n), comm
 

@@ -25,6 +25,8 @@ gloo tests pass a torch backend (``tests/cpu_backend.py``) that runs the composa
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -37,6 +39,9 @@ class Comm:
 
     def __init__(self, world, n_local, n_max, group=None):
         self.world, self.n_local, self.n_max, self.group = int(world), int(n_local), int(n_max), group
+        # one rank has nothing to exchange; BKG_PARTITION_FORCE_COLLECTIVES=1 issues the collectives anyway (a 1-rank
+        # RCCL group: the way to run the exact collective calls of the N-rank path on a single-GPU box)
+        self.live = self.world > 1 or os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1"
 
     def shard_buffer(self, d, dtype, device):
         """A padded ``[n_max, d]`` shard for a producer to write its ``n_local`` rows into (the pad rows are never
@@ -52,7 +57,7 @@ class Comm:
 
     def all_gather_begin(self, shard):
         shard = self._padded(shard)
-        if self.world == 1:
+        if not self.live:
             return shard, None
         out = torch.empty(self.world * self.n_max, shard.size(1), dtype=shard.dtype, device=shard.device)
         return out, dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True)
@@ -69,7 +74,7 @@ class Comm:
 
     def reduce_scatter_begin(self, dtable):
         """``dtable [world * n_max, d]`` (this rank's contribution to every owner) -> the rank's summed ``[n_local, d]``."""
-        if self.world == 1:
+        if not self.live:
             return dtable[: self.n_local], None
         dtable = dtable if dtable.is_contiguous() else dtable.contiguous()
         out = torch.empty(self.n_max, dtable.size(1), dtype=dtable.dtype, device=dtable.device)
@@ -91,7 +96,7 @@ class Comm:
         v = v_local.reshape(-1, v_local.size(-1))
         buf = torch.full((v.size(0), self.n_max), fill, dtype=v.dtype, device=v.device)
         buf[:, : v.size(1)] = v
-        if self.world == 1:
+        if not self.live:
             return buf
         out = torch.empty(self.world * v.size(0), self.n_max, dtype=v.dtype, device=v.device)
         dist.all_gather_into_tensor(out, buf, group=self.group)
