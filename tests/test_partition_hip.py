@@ -2,6 +2,8 @@
 the ordinary single-GPU layers -- checks HipBackend, the rectangular segment reduce and its transpose, and the
 autograd chain through all_gather_rows.  The cross-rank logic is covered on CPU by tests/test_partition_gloo.py.
 Needs an MI355X."""
+import os
+
 import pytest
 import torch
 
@@ -260,3 +262,20 @@ def test_fused_partitioned_steps_two_ranks_on_one_gpu_match_one_rank(tmp_path):
         for a, b in zip(g1, g2):
             err = float((a - b).norm() / a.norm().clamp_min(1e-12))
             assert err < 3e-2, (key, err)
+
+
+def test_collectives_of_the_partitioned_step_over_a_one_rank_rccl_group():
+    """BKG_PARTITION_FORCE_COLLECTIVES=1: bench.py's node-partitioned step at ONE rank with every collective of the
+    N-rank path issued for real over RCCL (bf16 all-gather of the gather tables, fp32 reduce-scatter of their gradients,
+    the flat gradient all-reduce) -- the closest a single-GPU box gets to the N-rank RCCL path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BKG_PARTITION_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "partition", "--steps", "2",
+                          "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["value"] > 0 and line["n_gpus"] == 1
