@@ -262,6 +262,23 @@ def build_replica_steps(args, rank, world, dev):
     kge = KGEModule("rgcn", "dismult", h, h, h, 2, r, 2, "cosine", 1e-3, 0.2, "none", args.neg_ratio, "random").to(dev)
     gcl = GGDModule(in_dim=768, hidden_dim=h, out_dim=h, num_hidden_layers=2, fuse_method="none").to(dev)
     kge.train(); gcl.train()
+    # both outcomes of GGD's augmentation coin and the KGE step once, untimed: whichever the seeded coin brings first
+    # inside the timed region then finds its buffers in the caching allocator (a first-time hipMalloc costs ~100 ms)
+    from biomedkg_amd import rand as R
+
+    class Coin(R.DeviceRand):
+        def __init__(self, value):
+            super().__init__()
+            self.value = value
+
+        def coin(self):
+            return self.value
+    for value in (0.0, 1.0):
+        with R.use(Coin(value)):
+            gcl.training_step(bg).backward()
+    kge.training_step(bk).backward()
+    for p in list(gcl.model.parameters()) + list(kge.model.parameters()):
+        p.grad = None
     return make_step(gcl, bg, world), make_step(kge, bk, world, overlap=True), n, e, r
 
 
