@@ -95,6 +95,9 @@ class GraphedStep:
                 with torch.cuda.graph(self.graph):
                     self.loss = self._eager()
         finally:
+            # the captured launches carry the counter's address as a kernel argument: replays need no global state, and
+            # nothing outside this object may keep launching with a pointer to a tensor this object owns
+            L.call("bkg_set_rng_epoch", None)
             if trainer is not None:
                 self.module.__dict__["trainer"] = trainer
         self.warmup_steps = max(1, warmup)                          # (the capture pass records, it does not execute)
@@ -106,4 +109,4 @@ class GraphedStep:
         return self.loss
 
     def close(self):
-        L.call("bkg_set_rng_epoch", None)
+        """Kept for callers of the first version: the replay counter is only registered while capturing."""

@@ -135,3 +135,25 @@ def test_uncapturable_steps_are_refused():
     batch = SimpleNamespace(x=torch.randn(400, 32, device=DEV), edge_index=synthetic.gcl_small(400, 3000, seed=1).to(DEV))
     with pytest.raises(G.CaptureRefused):
         G.GraphedStep(mod, batch, torch.optim.Adam(mod.model.parameters(), lr=1e-3, fused=True))
+
+
+def test_no_replay_counter_is_left_registered_after_a_capture():
+    """The library's in-kernel dropout streams read a replay counter through a registered device pointer; a captured
+    step owns that counter.  Once the capture is done nothing outside the graph may launch with it: with the step object
+    gone, two identical training-mode passes must draw identical masks (they read freed memory otherwise)."""
+    import gc
+    from biomedkg_amd import graphs as G, rand as R
+    from biomedkg_amd.model.encoder import GCNEncoder
+    mod, batch = _grace(seed=4)
+    step = G.GraphedStep(mod, batch, torch.optim.Adam(mod.model.parameters(), lr=1e-3, fused=True), clip=1.0, warmup=2, seed=2)
+    step()
+    del step
+    gc.collect()
+    junk = [torch.randint(0, 1 << 30, (1 << 18,), device=DEV) for _ in range(64)]     # scribble over what was freed
+    enc = GCNEncoder(64, 32, 32, 2).to(DEV).train()
+    outs = []
+    for _ in range(2):
+        junk = [j + 1 for j in junk]
+        with R.use(R.DeviceRand(seed=5)):
+            outs.append(enc(batch.x[:, 0].contiguous(), batch.edge_index).detach().clone())
+    assert torch.equal(outs[0], outs[1])
