@@ -52,6 +52,10 @@ def choose_bucket(buckets, neg_ratio, n_b, e_b, e_free):
     k = neg_ratio * e_b
     if prob <= 0.9 or int(1.1 * k / prob) >= population:
         return None
+    # PyG's first round keeps ~1.1 k of its int(1.1 k / prob) candidates (binomial, sigma^2 <= 1.1 k (1 - prob)); the
+    # captured step has only that round, so the 10 % margin must be worth six sigma -- tiny dense batches go eager
+    if 0.1 * k < 6.0 * (1.1 * k * (1.0 - prob)) ** 0.5:
+        return None
     return next(b for b in buckets if b >= e_b)
 
 

@@ -120,7 +120,10 @@ def test_edge_bucket_choice_of_the_padded_mini_batch_loop():
     assert choose_bucket(b, 10, 60, 400, 400) is None                    # 60 * 59 = 3540 cells, 4000 negatives asked for
     # ... or the batch is dense (prob <= 0.9: later rounds could be needed)
     assert choose_bucket(b, 1, 100, 1100, 1000) is None                  # 1000 / 9900 loop-free positives > 10 %
-    assert choose_bucket(b, 1, 100, 900, 900) == 1024
+    assert choose_bucket(b, 1, 100, 900, 900) == 1024                    # 9.1 % dense, 900 negatives: margin 90 >= 6 sigma = 57
+    # ... or so FEW negatives are asked for that the 10 % over-sampling margin of that one round is under six sigma
+    assert choose_bucket(b, 1, 60, 320, 320) is None and choose_bucket(b, 1, 60, 30, 30) is None
+    assert choose_bucket(b, 10, 60, 30, 30) == 1024 and choose_bucket(b, 10, 400, 50, 50) == 1024
     assert list(EDGE_BUCKETS) == sorted(EDGE_BUCKETS) and all(y / x <= 1.51 for x, y in zip(EDGE_BUCKETS, EDGE_BUCKETS[1:]))
     # the flat batch buffer: sizes | n_id | src | dst | type | eid, disjoint and complete
     import torch
