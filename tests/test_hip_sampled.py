@@ -148,9 +148,11 @@ def _run(graphs, steps, buckets, seed=0, neg_ratio=3, walks=40):
     return sg, losses, sizes, [p.detach().clone() for p in mod.model.parameters()]
 
 
-def test_replayed_steps_equal_the_eager_padded_steps_bit_for_bit():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_replayed_steps_equal_the_eager_padded_steps_bit_for_bit(precision):
     from biomedkg_amd import ops
     ops.set_deterministic(True)      # bitwise claims need the fixed-order weight-gradient sums (Trainer(deterministic=True))
+    ops.set_matmul_precision(precision)
     buckets = (256, 384, 512, 768, 1024, 1536, 2048, 4096, 8192)            # narrow ladder: several buckets get used
     a, la, sa, pa = _run(True, 40, buckets)
     b, lb, sb, pb = _run(False, 40, buckets)
