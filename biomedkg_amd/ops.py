@@ -917,6 +917,8 @@ def kge_score(z, rel_emb, edge_index, edge_type, kind):
     L.require_cuda(z, rel_emb, edge_index, edge_type)
     if edge_index.dtype != torch.int64 or edge_type.dtype != torch.int64:
         raise TypeError("edge_index / edge_type must be int64")
+    if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_type.numel() != edge_index.size(1):
+        raise ValueError(f"edge_index {tuple(edge_index.shape)} and edge_type {tuple(edge_type.shape)} do not match")
     return _KgeScore.apply(_f32c(z), _f32c(rel_emb), edge_index.contiguous(), edge_type.contiguous(), kind)
 
 
@@ -1120,6 +1122,11 @@ def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_
     by the DEVICE scalar ``inv_total``, triplets with relation id ``R`` (one past the real ones) are pads, and the mean
     of ``z^2`` runs over the first ``rows`` rows (an int64 DEVICE scalar)."""
     L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, inv_total)
+    for ei, et, what in ((pos_edge_index, pos_edge_type, "positive"), (neg_edge_index, neg_edge_type, "negative")):
+        if ei.dim() != 2 or ei.size(0) != 2 or et.dim() != 1 or et.numel() != ei.size(1):
+            # (the reference fails here too -- a broadcast error in decode -- e.g. when negative_sampling comes back
+            # with fewer pairs than neg_ratio * E on a tiny dense batch; the kernels index one by the other)
+            raise ValueError(f"{what} triplets: edge_index {tuple(ei.shape)} and edge_type {tuple(et.shape)} do not match")
     if reg and comm is not None:
         raise ValueError("the L2 term of a partitioned step is scaled by the caller (partition.kge_loss_partitioned)")
     if inv_total is not None and (comm is not None or inv_total.dtype != torch.float32 or rows is None

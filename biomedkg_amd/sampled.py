@@ -188,6 +188,18 @@ class SaintGraphedKge:
         self.branches = True
         self._pinned = []
 
+    def close(self):
+        """Wait for everything this loop has in flight (the sampler runs a batch ahead on its own stream): its buffers
+        must not go back to the allocator under a running kernel."""
+        for st in (self.sampler_stream, self.side, self.side2, self.stream):
+            st.synchronize()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+
     # ---- the padded step (captured once per edge bucket)
     def _negatives(self, ei, et, e_b):
         dev, k_cap = ei.device, self.neg_ratio * e_b
@@ -286,6 +298,11 @@ class SaintGraphedKge:
                 loss = self._step()
             outer.wait_stream(self.stream)                                 # the caller reads the loss on its own stream
             return loss
+        except BaseException:
+            # a failed step (e.g. the reference's own shape error on a degenerate batch) leaves work in flight on the
+            # loop's streams: drain them, so that whoever drops this object does not free buffers under running kernels
+            self.close()
+            raise
         finally:
             L.call("bkg_set_rng_epoch", None)
             if trainer is not None:

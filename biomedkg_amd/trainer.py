@@ -232,6 +232,8 @@ class Trainer:
                 print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in logs.items()}), flush=True)
             if self.should_stop:
                 break
+        if graphed is not None and hasattr(getattr(graphed, "loop", None), "close"):
+            graphed.loop.close()              # the sampler runs a batch ahead on its own stream
         return self
 
     @torch.no_grad()

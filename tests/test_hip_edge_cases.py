@@ -171,3 +171,21 @@ def test_dropout_without_relu_gates_by_the_mask_not_by_the_output_sign():
     torch.testing.assert_close(wd.grad.cpu(), wo.grad, **TOL)
     with pytest.raises(NotImplementedError):
         ops.gcn_conv(xd, wd, b.to(DEV), gr, gr.gcn_weights(), relu=False, drop=ops.Dropout(0.3, seed=1, stream_id=1))
+
+
+def test_mismatched_triplet_arrays_are_refused_not_dereferenced():
+    """negative_sampling may come back with fewer pairs than neg_ratio * E (a 2-node batch has one free cell): the
+    reference then dies on a broadcast error in decode; here the scorer would index one array by the other."""
+    import pytest
+    from biomedkg_amd import ops
+    z = torch.randn(5, 64, device="cuda", requires_grad=True)
+    rel = torch.randn(10, 64, device="cuda", requires_grad=True)
+    pos, pt = torch.tensor([[0], [1]], device="cuda"), torch.tensor([2], device="cuda")
+    neg, nt = torch.tensor([[1], [0]], device="cuda"), torch.full((5,), 2, device="cuda")
+    with pytest.raises(ValueError):
+        ops.kge_bce_loss(z, rel, pos, pt, neg, nt, ops.KGE_DISTMULT)
+    with pytest.raises(ValueError):
+        ops.kge_score(z, rel, neg, nt, ops.KGE_DISTMULT)
+    loss, _, _ = ops.kge_bce_loss(z, rel, pos, pt, neg, nt[:1], ops.KGE_DISTMULT, reg=1e-2)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(z.grad).all()
