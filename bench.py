@@ -525,9 +525,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # BKG_PARTITION_FORCE_COLLECTIVES=1 with --gpus 1 --mode partition: a 1-rank RCCL group, every collective of the
+    # BKG_PARTITION_FORCE_COLLECTIVES=1 with --gpus 1 --mode partition | replicas: a 1-rank RCCL group, every collective of the
     # N-rank path issued for real (functional check of the RCCL calls on a single-GPU box; never a reported number)
-    forced = world == 1 and os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1" and args.mode == "partition"
+    forced = world == 1 and os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1" and args.mode in ("partition", "replicas")
     if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
