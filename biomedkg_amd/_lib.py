@@ -83,6 +83,10 @@ SIGNATURES = {
     # sample.hip
     "bkg_random_walk": (I32, [P, P, P, I64, I32, U64, P, P]),
     "bkg_sample_neighbors": (I32, [P, P, I64, I32, U64, U32, P, P]),
+    "bkg_neighbor_workspace_bytes": (I64, [I64, I32]),
+    "bkg_neighbor_begin": (I32, [P, I64, I64, P, P, P, P]),
+    "bkg_neighbor_hop": (I32, [P, P, P, I64, I32, U64, U32, P, P, P, P, P, P, P, P, I64, P, P, P, P, I64, P]),
+    "bkg_neighbor_finish": (I32, [I64, P, P, P, I64, P, P, P]),
     "bkg_saint_batch_workspace_bytes": (I64, [I64, I64]),
     "bkg_saint_batch": (I32, [P, P, P, I64, I32, U64, P, P, P, P, P, I64, I64, P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P,
                               P, P, I64, P]),

@@ -124,6 +124,113 @@ __global__ void saint_edges_kernel(const int64_t* __restrict__ src, const int64_
   if (i == 0) sizes[1] = total;
 }
 
+// ---- NeighborLoader batch without a host round trip per hop: the frontier bounds and the edge count live in `ctr`
+// (device: [0] = first frontier row in n_id, [1] = nodes so far, [2] = edges so far); every launch covers the capacity
+// and exits past the counts.  Same draws, same node / edge order as the hop-by-hop host version (frontier-indexed
+// Philox counters; new nodes appended in ascending id order; edges in (frontier row, pick) order).
+__global__ void nb_begin_kernel(const int64_t* __restrict__ seeds, int64_t n_seeds, int32_t* __restrict__ seen,
+                                int64_t* __restrict__ n_id, int64_t* __restrict__ ctr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_seeds) { n_id[i] = seeds[i]; seen[seeds[i]] = 1; }
+  if (i == 0) { ctr[0] = 0; ctr[1] = n_seeds; ctr[2] = 0; }
+}
+
+template <int MAXF>
+__global__ void nb_sample_kernel(const int32_t* __restrict__ rowptr, const int64_t* __restrict__ n_id,
+                                 const int64_t* __restrict__ ctr, int fanout, uint64_t seed, uint32_t hop,
+                                 int32_t* __restrict__ out_pos) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t lo = ctr[0], cnt = ctr[1] - ctr[0];
+  if (f >= cnt) return;
+  const int64_t v = n_id[lo + f];
+  const int beg = rowptr[v], deg = rowptr[v + 1] - beg;
+  int32_t* out = out_pos + f * fanout;
+  if (deg <= fanout) {
+    for (int j = 0; j < fanout; ++j) out[j] = j < deg ? beg + j : -1;
+    return;
+  }
+  int picked[MAXF];
+  int n = 0;
+  for (int j = deg - fanout; j < deg; ++j) {   // Floyd, as sample_neighbors_kernel
+    int t = (int)rng_below(seed, (uint64_t)f * 64 + (uint64_t)(j - (deg - fanout)), hop, (uint32_t)(j + 1));
+    bool taken = false;
+    for (int q = 0; q < n; ++q) taken |= picked[q] == t;
+    picked[n++] = taken ? j : t;
+  }
+  for (int j = 0; j < fanout; ++j) out[j] = beg + picked[j];
+}
+
+// per candidate slot: valid pick?  (and mark the not-yet-seen sources)
+__global__ void nb_flags_kernel(const int32_t* __restrict__ pos, const int32_t* __restrict__ col,
+                                const int64_t* __restrict__ ctr, int fanout, int64_t slots,
+                                const int32_t* __restrict__ seen, int32_t* __restrict__ new_flag,
+                                int32_t* __restrict__ eflag) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= slots) return;
+  const int64_t cnt = ctr[1] - ctr[0];
+  int ok = 0;
+  if (k / fanout < cnt) {
+    const int32_t p = pos[k];
+    if (p >= 0) {
+      ok = 1;
+      const int32_t s = col[p];
+      if (!seen[s]) new_flag[s] = 1;
+    }
+  }
+  eflag[k] = ok;
+}
+
+__global__ void nb_append_nodes_kernel(const int32_t* __restrict__ new_flag, const int32_t* __restrict__ offs,
+                                       int64_t n_nodes, const int64_t* __restrict__ ctr, int32_t* __restrict__ seen,
+                                       int64_t* __restrict__ n_id) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes || !new_flag[i]) return;
+  n_id[ctr[1] + offs[i]] = i;
+  seen[i] = 1;
+}
+
+__global__ void nb_append_edges_kernel(const int32_t* __restrict__ pos, const int32_t* __restrict__ eflag,
+                                       const int32_t* __restrict__ offs, const int32_t* __restrict__ col,
+                                       const int32_t* __restrict__ perm, const int64_t* __restrict__ n_id,
+                                       const int64_t* __restrict__ ctr, int fanout, int64_t slots, int64_t edge_cap,
+                                       int64_t* __restrict__ e_src, int64_t* __restrict__ e_dst,
+                                       int64_t* __restrict__ e_id) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= slots || !eflag[k]) return;
+  const int64_t o = ctr[2] + offs[k];
+  if (o >= edge_cap) return;
+  const int32_t p = pos[k];
+  e_src[o] = col[p];
+  e_dst[o] = n_id[ctr[0] + k / fanout];
+  e_id[o] = perm[p];
+}
+
+// after both appends: the new nodes become the frontier
+__global__ void nb_advance_kernel(const int32_t* __restrict__ new_flag, const int32_t* __restrict__ node_offs,
+                                  int64_t n_nodes, const int32_t* __restrict__ eflag, const int32_t* __restrict__ edge_offs,
+                                  int64_t slots, int64_t* __restrict__ ctr) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const int64_t new_nodes = node_offs[n_nodes - 1] + new_flag[n_nodes - 1];
+  const int64_t new_edges = edge_offs[slots - 1] + eflag[slots - 1];
+  ctr[0] = ctr[1];
+  ctr[1] += new_nodes;
+  ctr[2] += new_edges;
+}
+
+__global__ void nb_lut_kernel(const int64_t* __restrict__ n_id, const int64_t* __restrict__ ctr, int64_t n_nodes,
+                              int32_t* __restrict__ lut) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_nodes && i < ctr[1]) lut[n_id[i]] = (int32_t)i;
+}
+
+__global__ void nb_relabel_kernel(const int32_t* __restrict__ lut, const int64_t* __restrict__ ctr, int64_t edge_cap,
+                                  int64_t* __restrict__ e_src, int64_t* __restrict__ e_dst) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= edge_cap || k >= ctr[2]) return;
+  e_src[k] = lut[e_src[k]];
+  e_dst[k] = lut[e_dst[k]];
+}
+
 }  // namespace bkg
 
 using namespace bkg;
@@ -186,4 +293,61 @@ extern "C" int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* fronti
   hipLaunchKernelGGL(sample_neighbors_kernel<64>, dim3(ceil_div(n_frontier, 256)), dim3(256), 0, (hipStream_t)stream,
                      rowptr, frontier, n_frontier, fanout, seed, hop, out_pos);
   return check_launch("bkg_sample_neighbors");
+}
+
+// ---- NeighborLoader batches with ONE host read at the end (bkg_neighbor_begin, one bkg_neighbor_hop per hop,
+// bkg_neighbor_finish; ctr[1] = nodes, ctr[2] = edges).  Capacities: n_id / seen / lut / node scratch: n_nodes; pos /
+// edge scratch: n_nodes * fanout slots; e_src / e_dst / e_id: edge_cap (every node is expanded at most once, so
+// n_nodes * max fanout always suffices).
+extern "C" int64_t bkg_neighbor_workspace_bytes(int64_t n_nodes, int32_t max_fanout) {
+  size_t a = 0;
+  rocprim::exclusive_scan(nullptr, a, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)(n_nodes * max_fanout),
+                          rocprim::plus<int32_t>());
+  return (int64_t)a + 256;
+}
+
+extern "C" int bkg_neighbor_begin(const int64_t* seeds, int64_t n_seeds, int64_t n_nodes, int32_t* seen, int64_t* n_id,
+                                  int64_t* ctr, void* stream) {
+  BKG_ARG(n_seeds > 0 && n_seeds <= n_nodes, "bkg_neighbor_begin: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(seen, 0, (size_t)n_nodes * sizeof(int32_t), s);
+  if (e != hipSuccess) { set_error("bkg_neighbor_begin: memset", e); return (int)e; }
+  hipLaunchKernelGGL(nb_begin_kernel, dim3(ceil_div(n_seeds, 256)), dim3(256), 0, s, seeds, n_seeds, seen, n_id, ctr);
+  return check_launch("bkg_neighbor_begin");
+}
+
+extern "C" int bkg_neighbor_hop(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t n_nodes,
+                                int32_t fanout, uint64_t seed, uint32_t hop, int32_t* seen, int64_t* n_id, int64_t* ctr,
+                                int32_t* pos, int32_t* new_flag, int32_t* node_offs, int32_t* eflag, int32_t* edge_offs,
+                                int64_t edge_cap, int64_t* e_src, int64_t* e_dst, int64_t* e_id, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+  BKG_ARG(n_nodes > 0 && fanout > 0 && fanout <= 64 && n_nodes * fanout < (1ll << 31), "bkg_neighbor_hop: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t slots = n_nodes * fanout;
+  hipLaunchKernelGGL(nb_sample_kernel<64>, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, rowptr, n_id, ctr, fanout, seed,
+                     hop, pos);
+  hipError_t e = hipMemsetAsync(new_flag, 0, (size_t)n_nodes * sizeof(int32_t), s);
+  if (e != hipSuccess) { set_error("bkg_neighbor_hop: memset", e); return (int)e; }
+  hipLaunchKernelGGL(nb_flags_kernel, dim3(ceil_div(slots, 256)), dim3(256), 0, s, pos, col, ctr, fanout, slots, seen,
+                     new_flag, eflag);
+  size_t bytes = (size_t)workspace_bytes;
+  e = rocprim::exclusive_scan(workspace, bytes, new_flag, node_offs, 0, (size_t)n_nodes, rocprim::plus<int32_t>(), s);
+  if (e != hipSuccess) { set_error("bkg_neighbor_hop: node scan", e); return (int)e; }
+  bytes = (size_t)workspace_bytes;
+  e = rocprim::exclusive_scan(workspace, bytes, eflag, edge_offs, 0, (size_t)slots, rocprim::plus<int32_t>(), s);
+  if (e != hipSuccess) { set_error("bkg_neighbor_hop: edge scan", e); return (int)e; }
+  hipLaunchKernelGGL(nb_append_edges_kernel, dim3(ceil_div(slots, 256)), dim3(256), 0, s, pos, eflag, edge_offs, col, perm,
+                     n_id, ctr, fanout, slots, edge_cap, e_src, e_dst, e_id);
+  hipLaunchKernelGGL(nb_append_nodes_kernel, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, new_flag, node_offs, n_nodes,
+                     ctr, seen, n_id);
+  hipLaunchKernelGGL(nb_advance_kernel, dim3(1), dim3(64), 0, s, new_flag, node_offs, n_nodes, eflag, edge_offs, slots, ctr);
+  return check_launch("bkg_neighbor_hop");
+}
+
+extern "C" int bkg_neighbor_finish(int64_t n_nodes, const int64_t* n_id, const int64_t* ctr, int32_t* lut,
+                                   int64_t edge_cap, int64_t* e_src, int64_t* e_dst, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(nb_lut_kernel, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, n_id, ctr, n_nodes, lut);
+  hipLaunchKernelGGL(nb_relabel_kernel, dim3(ceil_div(edge_cap, 256)), dim3(256), 0, s, lut, ctr, edge_cap, e_src, e_dst);
+  return check_launch("bkg_neighbor_finish");
 }

@@ -47,7 +47,43 @@ class NeighborSampler:
         self.graph = graph_of(edge_index, num_nodes)
         self.num_nodes, self.num_neighbors, self.seed, self.calls = int(num_nodes), tuple(num_neighbors), int(seed), 0
 
+    def _state(self, dev):
+        """Fixed-capacity device state of the one-read sampler (csrc/sample.hip: bkg_neighbor_*)."""
+        st = getattr(self, "_st", None)
+        if st is None:
+            n, fan = self.num_nodes, max(min(k if k > 0 else 64, 64) for k in self.num_neighbors)
+            i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)      # noqa: E731
+            i64 = lambda k: torch.empty(k, dtype=torch.int64, device=dev)      # noqa: E731
+            cap = n * fan
+            st = self._st = dict(fan=fan, cap=cap, seen=i32(n), n_id=i64(n), ctr=i64(3), pos=i32(cap), new_flag=i32(n),
+                                 node_offs=i32(n), eflag=i32(cap), edge_offs=i32(cap), lut=i32(n), e_src=i64(cap),
+                                 e_dst=i64(cap), e_id=i64(cap),
+                                 ws=torch.empty(L.lib().bkg_neighbor_workspace_bytes(n, fan), dtype=torch.uint8, device=dev))
+        return st
+
     def sample(self, seeds):
+        """One host read per batch (node and edge counts) instead of three per hop; the same batch, draw for draw, as
+        ``sample_hop_by_hop``."""
+        if self.num_nodes * max(min(k if k > 0 else 64, 64) for k in self.num_neighbors) >= (1 << 31) or seeds.numel() == 0:
+            return self.sample_hop_by_hop(seeds)
+        st, csr = self._state(seeds.device), self.graph.by_dst
+        self.calls += 1
+        seeds = seeds.contiguous()
+        L.call("bkg_neighbor_begin", L.ptr(seeds), seeds.numel(), self.num_nodes, L.ptr(st["seen"]), L.ptr(st["n_id"]),
+               L.ptr(st["ctr"]), L.stream())
+        for hop, k in enumerate(self.num_neighbors):
+            fan = min(k if k > 0 else 64, 64)
+            L.call("bkg_neighbor_hop", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(csr.perm), self.num_nodes, fan,
+                   self.seed * 1_000_003 + self.calls, hop, L.ptr(st["seen"]), L.ptr(st["n_id"]), L.ptr(st["ctr"]),
+                   L.ptr(st["pos"]), L.ptr(st["new_flag"]), L.ptr(st["node_offs"]), L.ptr(st["eflag"]),
+                   L.ptr(st["edge_offs"]), st["cap"], L.ptr(st["e_src"]), L.ptr(st["e_dst"]), L.ptr(st["e_id"]),
+                   L.ptr(st["ws"]), st["ws"].numel(), L.stream())
+        L.call("bkg_neighbor_finish", self.num_nodes, L.ptr(st["n_id"]), L.ptr(st["ctr"]), L.ptr(st["lut"]), st["cap"],
+               L.ptr(st["e_src"]), L.ptr(st["e_dst"]), L.stream())
+        _, nn, ne = st["ctr"].tolist()                                       # the one host read of the batch
+        return st["n_id"][:nn].clone(), torch.stack([st["e_src"][:ne], st["e_dst"][:ne]]), st["e_id"][:ne].clone()
+
+    def sample_hop_by_hop(self, seeds):
         g, dev = self.graph, seeds.device
         csr = g.by_dst
         self.calls += 1

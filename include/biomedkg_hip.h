@@ -253,6 +253,23 @@ int bkg_random_walk(const int32_t* rowptr, const int32_t* col, const int64_t* st
                     int32_t walk_length, uint64_t seed, int64_t* walks, void* stream);
 int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* frontier, int64_t n_frontier, int32_t fanout,
                          uint64_t seed, uint32_t hop, int32_t* out_pos, void* stream);
+/* NeighborLoader(num_neighbors=[..]) batches (biomedkg/data_module.py:89-99) with ONE host read at the end instead of
+ * three per hop: begin (seeds -> n_id[0..n_seeds), seen flags, ctr = {frontier start, nodes, edges}), one hop call per
+ * fan-out (up to `fanout` distinct uniformly chosen in-edges per frontier node; new sources appended to n_id in
+ * ascending id order and becoming the next frontier; the picked edges appended as (global source, global target,
+ * original edge id) in (frontier row, pick) order), finish (global -> local ids).  Same draws and orders as
+ * bkg_sample_neighbors driven hop by hop from the host.  Capacities: seen / n_id / lut / new_flag / node_offs: n_nodes;
+ * pos / eflag / edge_offs: n_nodes * fanout; e_src / e_dst / e_id: edge_cap (n_nodes * the largest fan-out always
+ * suffices: every node is expanded once); workspace of bkg_neighbor_workspace_bytes. */
+int64_t bkg_neighbor_workspace_bytes(int64_t n_nodes, int32_t max_fanout);
+int bkg_neighbor_begin(const int64_t* seeds, int64_t n_seeds, int64_t n_nodes, int32_t* seen, int64_t* n_id, int64_t* ctr,
+                       void* stream);
+int bkg_neighbor_hop(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t n_nodes, int32_t fanout,
+                     uint64_t seed, uint32_t hop, int32_t* seen, int64_t* n_id, int64_t* ctr, int32_t* pos,
+                     int32_t* new_flag, int32_t* node_offs, int32_t* eflag, int32_t* edge_offs, int64_t edge_cap,
+                     int64_t* e_src, int64_t* e_dst, int64_t* e_id, void* workspace, int64_t workspace_bytes, void* stream);
+int bkg_neighbor_finish(int64_t n_nodes, const int64_t* n_id, const int64_t* ctr, int32_t* lut, int64_t edge_cap,
+                        int64_t* e_src, int64_t* e_dst, void* stream);
 /* One whole GraphSAINT random-walk batch (GraphSAINTRandomWalkSampler, biomedkg/data_module.py:100-107) with no host
  * round trip: walks from start[] (NULL: uniform roots drawn from the keyed stream), node set = distinct visited nodes in ascending order, edge set = ALL edges among them
  * in edge order, relabelled.  Sizes stay on the device: sizes[0] = nodes, sizes[1] = edges, sizes[2] = edges with

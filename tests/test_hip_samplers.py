@@ -100,3 +100,21 @@ def test_training_steps_on_sampled_batches():
         loss = kge.training_step(b)
         loss.backward()
         assert torch.isfinite(loss) and b.edge_type.numel() == b.edge_index.size(1) and b.x.size(0) <= 64 * 11
+
+
+def test_one_read_neighbor_sampler_equals_the_hop_by_hop_sampler():
+    """The same batch draw for draw: node order (seeds, then each hop's new nodes ascending), edge order ((frontier row,
+    pick) per hop), original edge ids -- over several seed sets, fan-outs (incl. more than any degree) and graphs with
+    isolated nodes."""
+    from biomedkg_amd import synthetic
+    from biomedkg_amd.samplers import NeighborSampler
+    for n, e, fans in ((3000, 40000, (30, 30, 30)), (500, 900, (2, 5)), (2000, 60000, (64,)), (800, 3000, (3, 3, 3, 3))):
+        ei = synthetic.gcl_small(n, e, seed=n).to("cuda")
+        for trial in range(3):
+            gen = torch.Generator(device="cuda").manual_seed(trial)
+            seeds = torch.randperm(n, device="cuda", generator=gen)[: 7 + 40 * trial]
+            a, b = NeighborSampler(ei, n, fans, seed=5), NeighborSampler(ei, n, fans, seed=5)
+            for _ in range(2):                                # (two calls: the per-call seed advances alike)
+                got, want = a.sample(seeds), b.sample_hop_by_hop(seeds)
+                for x, y in zip(got, want):
+                    assert torch.equal(x, y), (n, fans, trial, x.shape, y.shape)
