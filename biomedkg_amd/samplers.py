@@ -134,7 +134,45 @@ class SaintRandomWalkSampler:
                self.seed * 1_000_003 + self.calls, L.ptr(out), L.stream())
         return out
 
+    _EDGE_CAP = 1 << 22      # induced edges the one-call path holds (more: the torch-glue path below)
+
+    def _state(self, dev):
+        st = getattr(self, "_st", None)
+        if st is None:
+            n, e = self.num_nodes, self.edge_index.size(1)
+            cap, ncap = min(e, self._EDGE_CAP), self.batch_size * (self.walk_length + 1) + 1
+            i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)      # noqa: E731
+            i64 = lambda k: torch.empty(k, dtype=torch.int64, device=dev)      # noqa: E731
+            st = self._st = dict(cap=cap, ncap=ncap, walks=i64(self.batch_size * (self.walk_length + 1)), sizes=i64(3),
+                                 node=[i32(n) for _ in range(3)], edge=[i32(e) for _ in range(2)], n_id=i64(ncap),
+                                 out=[i64(cap) for _ in range(4)],
+                                 ws=torch.empty(L.lib().bkg_saint_batch_workspace_bytes(n, e), dtype=torch.uint8, device=dev))
+        return st
+
     def sample(self, start=None):
+        """Walks, node set, induced edges and relabelling in ONE library call (csrc/sample.hip: bkg_saint_batch) and
+        one host read of the two sizes; the same batch as ``sample_with_torch_glue``."""
+        dev = self.edge_index.device
+        if self.edge_index.size(1) == 0 or self.num_nodes >= (1 << 31):
+            return self.sample_with_torch_glue(start)
+        if start is None:
+            start = torch.randint(0, self.num_nodes, (self.batch_size,), device=dev)
+        st, csr = self._state(dev), self.graph.by_src
+        self.calls += 1
+        start = start.contiguous()
+        L.call("bkg_saint_batch", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(start), start.numel(), self.walk_length,
+               self.seed * 1_000_003 + self.calls, None, L.ptr(st["walks"]), L.ptr(self.edge_index[0]),
+               L.ptr(self.edge_index[1]), None, self.num_nodes, self.edge_index.size(1), L.ptr(st["node"][0]),
+               L.ptr(st["node"][1]), L.ptr(st["node"][2]), L.ptr(st["edge"][0]), L.ptr(st["edge"][1]), st["ncap"], st["cap"],
+               st["ncap"] - 1, 1, L.ptr(st["n_id"]), L.ptr(st["out"][0]), L.ptr(st["out"][1]), L.ptr(st["out"][2]),
+               L.ptr(st["out"][3]), L.ptr(st["sizes"]), L.ptr(st["ws"]), st["ws"].numel(), L.stream())
+        nn, ne, _ = st["sizes"].tolist()                                     # the one host read of the batch
+        if ne > st["cap"]:
+            self.calls -= 1
+            return self.sample_with_torch_glue(start)
+        return (st["n_id"][:nn].clone(), torch.stack([st["out"][0][:ne], st["out"][1][:ne]]), st["out"][3][:ne].clone())
+
+    def sample_with_torch_glue(self, start=None):
         dev = self.edge_index.device
         if start is None:
             start = torch.randint(0, self.num_nodes, (self.batch_size,), device=dev)

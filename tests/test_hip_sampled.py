@@ -39,7 +39,7 @@ def test_sync_free_sampler_equals_the_eager_device_sampler():
     for trial in range(3):
         start = torch.randint(0, n, (walks,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(trial))
         ref = SaintRandomWalkSampler(ei, n, walks, walk_length=10, seed=7)
-        n_id, sub, e_id = ref.sample(start)                                 # its walk seed: 7 * 1_000_003 + 1
+        n_id, sub, e_id = ref.sample_with_torch_glue(start)                 # its walk seed: 7 * 1_000_003 + 1
         s = SaintDeviceSampler(ei, et, n, walks, walk_length=10, seed=7 * 1_000_003 + 1, edge_cap=cap, pad_types=5)
         s.draw(start=start, use_epoch=False)
         n_b, e_b, e_free = s.sizes()

@@ -118,3 +118,16 @@ def test_one_read_neighbor_sampler_equals_the_hop_by_hop_sampler():
                 got, want = a.sample(seeds), b.sample_hop_by_hop(seeds)
                 for x, y in zip(got, want):
                     assert torch.equal(x, y), (n, fans, trial, x.shape, y.shape)
+
+
+def test_one_call_saint_sampler_equals_the_torch_glue_sampler():
+    from biomedkg_amd import synthetic
+    from biomedkg_amd.samplers import SaintRandomWalkSampler
+    g = synthetic.primekg_like(4000, 60000, 6, seed=2)
+    ei = g["edge_index"].to("cuda")
+    for trial in range(3):
+        a, b = (SaintRandomWalkSampler(ei, 4000, 48, walk_length=10, seed=9) for _ in range(2))
+        start = torch.randint(0, 4000, (48,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(trial))
+        for _ in range(2):
+            for x, y in zip(a.sample(start), b.sample_with_torch_glue(start)):
+                assert torch.equal(x, y)
