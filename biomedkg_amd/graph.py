@@ -193,7 +193,7 @@ class RelGraph:
         L.call("bkg_lower_bound_u32", L.ptr(seg_rel_u), s, r + 1, 1, L.ptr(self.rel_ptr), L.stream())
         # target -> its segments
         self.dst_csr = CSR(self.seg_dst.to(torch.int64), _iota64(s, dev), n)
-        self.seg_iota_ptr = _spread_pattern(s + 1, 1 << 62, dev)     # 0 .. s (cached per size)
+        self.seg_iota_ptr = iota(s + 1, torch.int32, dev)            # 0 .. s
         self.seg_split = rowsplit_for(self.seg_ptr, s, e)
         self._n_src = n if n_src is None else int(n_src)
         if not defer_source_side:
@@ -211,20 +211,33 @@ class RelGraph:
         self.src_w = self.src_csr.permute_f32(w_edge)
 
 
-_PATTERNS = {}
+_IOTAS = {}        # (dtype, device) -> [current arange, retired ones]: ONE growing table per kind, handed out as prefixes
+
+
+def iota(count, dtype, device):
+    """``arange(count)`` as a prefix view of a cached table that doubles when outgrown -- the structures of every
+    mini-batch ask for a different length, so a table per length would grow without bound.  Outgrown tables stay
+    allocated: captured graphs may hold their address."""
+    key = (dtype, str(device))
+    slot = _IOTAS.setdefault(key, [None, []])
+    if slot[0] is None or slot[0].numel() < count:
+        if slot[0] is not None:
+            slot[1].append(slot[0])
+        slot[0] = torch.arange(max(1024, 1 << int(count - 1).bit_length()), dtype=dtype, device=device)
+    return slot[0][:count]
+
+
+def _iota64(count, device):
+    return iota(count, torch.int64, device)
+
+
+_PATTERNS = {}     # (count, modulus, device) -> i % modulus as int32: only the padded mini-batch steps ask (few sizes)
 
 
 def _spread_pattern(count, modulus, device):
     key = (count, modulus, str(device))
     if key not in _PATTERNS:
         _PATTERNS[key] = (torch.arange(count, device=device) % modulus).to(torch.int32)
-    return _PATTERNS[key]
-
-
-def _iota64(count, device):
-    key = (count, "i64", str(device))
-    if key not in _PATTERNS:
-        _PATTERNS[key] = torch.arange(count, device=device)
     return _PATTERNS[key]
 
 

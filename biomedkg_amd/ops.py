@@ -926,15 +926,12 @@ _KGE_PIECES = (2, 4, 6, 8, 12, 16, 24, 32, 64, 96, 128, 192)   # csrc/rowpiece.h
 _FUSED_CHUNK = 64   # triplets per wave of csrc/kge_fused.hip
 
 
-_IOTA32 = {}
 _FEW_WAVES = 1 << 14     # below this the per-relation reduce of the waves' rows needs no long-row table
 
 
 def _iota32(n, device):
-    key = (int(n), str(device))
-    if key not in _IOTA32:
-        _IOTA32[key] = torch.arange(int(n), dtype=torch.int32, device=device)
-    return _IOTA32[key]
+    from .graph import iota
+    return iota(int(n), torch.int32, device)
 
 
 def _relation_waves_small(rel_ptr, num_relations, n_waves):
