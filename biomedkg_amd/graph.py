@@ -8,6 +8,8 @@ All index work runs in ``csrc/graph.hip``; this file only owns the buffers.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -101,16 +103,42 @@ class GcnWeights:
         self.w_dst, self.w_src, self.self_w = w_dst, w_src, self_w
 
 
-class Graph:
+class _EdgeHolder:
+    """How a structure refers to the ``edge_index`` it was built from.  A structure cached ON that tensor (``graph_of`` /
+    ``rel_graph_of``) must not point back at it strongly: tensor -> cache -> structure -> tensor is a cycle the collector
+    cannot always break (row views keep the base alive on the C++ side), and every mini-batch of a sampled run would leave
+    its structures behind.  ``_weaken`` turns the reference weak once the structure is known to live and die with the
+    tensor; a structure built by hand keeps its strong reference."""
+
+    def _hold(self, edge_index):
+        self._ei_strong, self._ei_weak = edge_index, None
+
+    def _weaken(self, owner):
+        if self._ei_strong is owner:
+            self._ei_strong, self._ei_weak = None, weakref.ref(owner)
+
+    @property
+    def edge_index(self):
+        return self._ei_strong if self._ei_strong is not None else self._ei_weak()
+
+    @property
+    def src(self):
+        return self.edge_index[0]
+
+    @property
+    def dst(self):
+        return self.edge_index[1]
+
+
+class Graph(_EdgeHolder):
     """Homogeneous message-passing graph (GCNConv).  ``num_nodes`` = rows of x."""
 
     def __init__(self, edge_index, num_nodes):
         L.require_cuda(edge_index)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError("edge_index must be int64 [2, E]")
-        self.edge_index = edge_index.contiguous()
+        self._hold(edge_index.contiguous())
         self.num_nodes, self.num_edges = int(num_nodes), edge_index.size(1)
-        self.src, self.dst = self.edge_index[0], self.edge_index[1]
         self.by_dst = CSR(self.dst, self.src, num_nodes)   # rows = targets, col = sources  (forward)
         self.by_src = CSR(self.src, self.dst, num_nodes)   # rows = sources, col = targets  (backward)
         self._plain = None
@@ -145,7 +173,7 @@ class Graph:
         return out
 
 
-class RelGraph:
+class RelGraph(_EdgeHolder):
     """Relational graph (RGCNConv, aggr="mean"): edges grouped into (relation, target) segments.
 
     Forward:  H[s] = mean_{e in s} x[src_e]  (spmm over ``seg_ptr``) -> per-relation GEMM -> sum of the
@@ -161,12 +189,12 @@ class RelGraph:
         segment count -- the structure always carries ``E`` segments, the ones past the real count are EMPTY rows of
         the last relation, their targets spread over the nodes: zero rows in, zeros added."""
         L.require_cuda(edge_index, edge_type)
-        self.edge_index = edge_index.contiguous()
+        self._hold(edge_index.contiguous())
         self.edge_type = edge_type.contiguous()
         dev = edge_index.device
         self.num_nodes, self.num_edges, self.num_relations = int(num_nodes), edge_index.size(1), int(num_relations)
         n, e, r = self.num_nodes, self.num_edges, self.num_relations
-        src, dst = self.edge_index[0], self.edge_index[1]
+        src, dst = self.src, self.dst
         sorted_keys, perm, ws = _Sorter.sort(dst, self.edge_type, n, r)
         self.perm = perm
         self.src_sorted = _i32(e, dev)
@@ -255,18 +283,24 @@ def _cached(t, slot, key, build):
     return hit[1]
 
 
+def _owned(structure, owner):
+    structure._weaken(owner)
+    return structure
+
+
 def graph_of(edge_index, num_nodes) -> Graph:
-    return _cached(edge_index, "gcn", (int(num_nodes),), lambda: Graph(edge_index, num_nodes))
+    return _cached(edge_index, "gcn", (int(num_nodes),), lambda: _owned(Graph(edge_index, num_nodes), edge_index))
 
 
 def rel_graph_of(edge_index, edge_type, num_nodes, num_relations) -> RelGraph:
     key = (int(num_nodes), int(num_relations), edge_type.data_ptr(), edge_type._version)
-    return _cached(edge_index, "rgcn", key, lambda: RelGraph(edge_index, edge_type, num_nodes, num_relations))
+    return _cached(edge_index, "rgcn", key,
+                   lambda: _owned(RelGraph(edge_index, edge_type, num_nodes, num_relations), edge_index))
 
 
 def plant_rel_graph(rg: RelGraph):
     """Make ``rel_graph_of(rg.edge_index, rg.edge_type, ...)`` return this (already built) structure."""
     ei, et = rg.edge_index, rg.edge_type
     key = (int(rg.num_nodes), int(rg.num_relations), et.data_ptr(), et._version)
-    _cached(ei, "rgcn", key, lambda: rg)
+    _cached(ei, "rgcn", key, lambda: _owned(rg, ei))
     return rg

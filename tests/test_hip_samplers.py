@@ -131,3 +131,37 @@ def test_one_call_saint_sampler_equals_the_torch_glue_sampler():
         for _ in range(2):
             for x, y in zip(a.sample(start), b.sample_with_torch_glue(start)):
                 assert torch.equal(x, y)
+
+
+def test_mini_batch_structures_die_with_their_batch():
+    """A structure cached ON a batch's edge_index must not keep the batch alive (tensor -> cache -> structure -> tensor
+    was an uncollectable cycle: 2-3 MB left behind per NeighborLoader step)."""
+    import gc
+    from biomedkg_amd import synthetic
+    from biomedkg_amd.gcl_module import GGDModule
+    from biomedkg_amd.kge_module import KGEModule
+    from biomedkg_amd.samplers import NeighborBatchLoader, SaintBatchLoader
+    ei = synthetic.gcl_small(6000, 90000, seed=2).to("cuda")
+    x3 = synthetic.lm_features(6000, 2, 32, seed=3).to("cuda")
+    gcl = GGDModule(in_dim=32, hidden_dim=32, out_dim=32, num_hidden_layers=1, fuse_method="attention").to("cuda").train()
+    g = synthetic.primekg_like(6000, 90000, 5, seed=1)
+    kei, ket = g["edge_index"].to("cuda"), g["edge_type"].to("cuda")
+    kge = KGEModule("rgcn", "dismult", 32, 32, 32, 1, 5, 2, "cosine", 1e-3, 0.0, "none", 2, "random").to("cuda").train()
+    xk = torch.randn(6000, 32, device="cuda")
+
+    def run(steps):
+        k = 0
+        while k < steps:
+            for b in NeighborBatchLoader(x3, ei, None, 128, (30, 30, 30), True, seed=3):
+                gcl.training_step(b).backward()
+                k += 1
+                if k >= steps:
+                    break
+        for b in SaintBatchLoader(xk, kei, ket, 32, walk_length=10, num_steps=steps, seed=3):
+            kge.training_step(b).backward()
+        gcl.zero_grad(set_to_none=True); kge.zero_grad(set_to_none=True)
+        gc.collect(); torch.cuda.synchronize()
+        return torch.cuda.memory_allocated()
+    base = run(15)
+    grown = run(60) - base
+    assert grown < 8 * 2 ** 20, f"{grown / 2 ** 20:.1f} MiB left behind by 60 more steps"
