@@ -95,11 +95,13 @@ __device__ __forceinline__ uint4 philox_keep4(uint64_t seed, uint64_t e, uint32_
 }
 
 // Replay epoch of captured (hipGraph) training steps (bkg_set_rng_epoch): a device counter the captured step bumps
-// once per replay; every in-kernel Philox stream adds it (x 65536) to its stream id, so each replay of the same
-// captured launch draws a fresh mask although its kernel arguments are frozen.  NULL outside graph mode.
+// once per replay; every in-kernel Philox stream adds it (times an odd constant: a bijection of the 2^32 counter
+// values, so a captured launch only meets the same stream again after 2^32 replays -- "x 65536" wrapped after 65,536
+// steps, less than one long training run) to its stream id, so each replay of the same captured launch draws a fresh
+// mask although its kernel arguments are frozen.  NULL outside graph mode.
 const uint32_t* rng_epoch_ptr();
 __device__ __forceinline__ uint32_t with_epoch(uint32_t stream_id, const uint32_t* __restrict__ epoch) {
-  return epoch ? stream_id + (epoch[0] << 16) : stream_id;
+  return epoch ? stream_id + epoch[0] * 0x9E3779B1u : stream_id;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
