@@ -79,9 +79,22 @@ def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
     population = n * (n - 1)
     dev = edge_index.device
     pos_table = _positive_table(edge_index, n)
-    out = torch.empty(2, k, dtype=torch.int64, device=dev)
+    # PyG's first round keeps ~1.1 k of its int(1.1 k / prob) candidates (binomial, sigma^2 <= 1.1 k (1 - prob)).  When
+    # that 10 % margin is worth six sigma the round cannot fall short of k in practice, and the survivor count need not
+    # be READ: no host round trip in the middle of the step (zero-filled result: a shortfall -- ~1e-9 per call -- would
+    # leave (0, 0) pairs, never stale memory).  Otherwise: count, and go on to rounds two and three like PyG.
+    sure = sample_size <= population and 0.1 * k >= 6.0 * (1.1 * k * max(1.0 - prob, 0.0)) ** 0.5 and prob > 0.9
+    out = (torch.zeros if sure else torch.empty)(2, k, dtype=torch.int64, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
     have, first, draw = 0, 0, min(sample_size, population)
+    if sure:
+        keys = torch.empty(draw, dtype=torch.int64, device=dev)
+        flag = torch.empty(2, draw, dtype=torch.int32, device=dev)
+        ws = torch.empty(L.lib().bkg_negative_sample_workspace_bytes(draw), dtype=torch.uint8, device=dev)
+        L.call("bkg_negative_sample", n, 0, draw, seed, L.ptr(pos_table), pos_table.numel(), L.ptr(keys),
+               L.ptr(flag[0]), L.ptr(flag[1]), L.ptr(out[0]), L.ptr(out[1]), 0, k, L.ptr(count), L.ptr(ws), ws.numel(),
+               L.stream())
+        return out
     for _ in range(3):                               # PyG: at most three over-sampling rounds
         keys = torch.empty(draw, dtype=torch.int64, device=dev)
         flag = torch.empty(2, draw, dtype=torch.int32, device=dev)
