@@ -11,7 +11,7 @@ here: **fixed-capacity buffers, sizes in device memory, pads that are arithmetic
   ``batch_size * (walk_length + 1) + 1`` with the index of a ZERO row appended to the feature table, edges padded to a
   capacity with self loops of the batch's last local node (the *dummy* node, always a pad), the three sizes (nodes,
   edges, loop-free edges) in a device vector that is also copied to pinned host memory -- asynchronously; the host
-  reads it one step later, when it has long arrived (the sampler runs one batch ahead of the trainer).
+  reads it one step later, when it has long arrived (the sampler runs one batch ahead of the trainer, on its own stream).
 * The host only picks the **edge bucket** (a geometric ladder of capacities); one graph per bucket is captured lazily.
 * Inside the step nothing depends on a host-side size: pad nodes are isolated zero-feature rows; pad edges only feed the
   dummy node, which no triplet touches (their sources and types are spread, so no row of any structure grows long); the relational structure always carries ``E_bucket`` segments (the surplus
@@ -110,11 +110,15 @@ class SaintDeviceSampler:
                L.ptr(self._node[1]), L.ptr(self._node[2]), L.ptr(self._edge[0]), L.ptr(self._edge[1]), self.node_cap,
                self.edge_cap, self.pad_node, self.pad_types, L.ptr(v["n_id"]), L.ptr(v["src"]), L.ptr(v["dst"]), L.ptr(v["type"]),
                L.ptr(v["eid"]), L.ptr(v["sizes"]), L.ptr(self._ws), self._ws.numel(), L.stream())
-        self.host.copy_(v["sizes"], non_blocking=True)
 
-    def draw(self, start=None, use_epoch=True, graph=True):
+    def draw(self, start=None, use_epoch=True, graph=False):
         """Enqueue one batch on the current stream (no host wait); ``sizes()`` later waits for its three numbers.
-        ``start`` (test hook): the walks' roots instead of fresh uniform ones."""
+        ``start`` (test hook): the walks' roots instead of fresh uniform ones.
+
+        The eleven launches are issued eagerly (on the loop's sampler stream they run under the previous step anyway).
+        ``graph=True`` replays them as a captured graph instead -- kept for experiments only: on this stack (ROCm 7.2)
+        that graph ends in a GPU page fault after a few thousand replays (20-30 k eager draws and the same kernels with
+        only the last one outside the graph run clean; scripts/dev_sampled.py history), so nothing in the build uses it."""
         if start is not None or not graph:
             self._draw(start, use_epoch)
         else:
@@ -126,6 +130,7 @@ class SaintDeviceSampler:
                     self._draw()
                 self.epoch.zero_()                            # the warm-up draw does not count: same stream as eager
             self.graph_exec.replay()
+        self.host.copy_(self.buf[:_SIZES], non_blocking=True)
         self.event.record()
 
     def sizes(self):
@@ -313,7 +318,7 @@ class SaintGraphedKge:
         if not self._primed:
             self.sampler_stream.wait_stream(main)
             with torch.cuda.stream(self.sampler_stream):
-                s.draw(graph=self.graphs_on)
+                s.draw()
             self._primed = True
         n_b, e_b, e_free = s.sizes()                                       # of the batch drawn one step ago
         self.last_sizes = (n_b, e_b, e_free)
@@ -322,7 +327,7 @@ class SaintGraphedKge:
         self.copied.record(main)                                           # the next batch is drawn UNDER this step
         with torch.cuda.stream(self.sampler_stream):
             self.sampler_stream.wait_event(self.copied)
-            s.draw(graph=self.graphs_on)
+            s.draw()
         bucket = self.bucket_of(n_b, e_b, e_free)
         if bucket is None:
             self.stats["eager_fallback"] += 1
