@@ -289,3 +289,20 @@ def test_trainer_replays_the_saint_regime(tmp_path):
         T.Trainer._try_graph = orig
     st = seen["step"].loop.stats
     assert st["replayed"] + st["captured"] + st["eager_fallback"] == 24 and st["replayed"] > 0, st
+
+
+def test_three_thousand_replays():
+    """A soak: the failure this guards against (a captured SAMPLER graph page-faulting after a few thousand replays on
+    ROCm 7.2) only showed between 1,800 and 4,000 steps of an end-to-end run; the loop as built launches the sampler
+    eagerly and replays only the step."""
+    from biomedkg_amd.sampled import SaintGraphedKge
+    ei, et, n, r = _graph(n=20000, e=400000, r=10)
+    x = torch.randn(n, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 0.1
+    mod = _module(r, neg_ratio=5).train()
+    sg = SaintGraphedKge(mod, x, ei, et, batch_size=64, seed=5)
+    first = float(sg.step())
+    for _ in range(3000):
+        loss = sg.step()
+    sg.close()
+    assert sg.stats["replayed"] >= 2900 and torch.isfinite(loss) and float(loss) < first
+    assert all(bool(torch.isfinite(p).all()) for p in mod.model.parameters())
