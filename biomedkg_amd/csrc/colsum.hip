@@ -145,9 +145,8 @@ extern "C" int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int
   BKG_ARG((uintptr_t)x % 16 == 0 && ldx % epl == 0 && (uintptr_t)workspace % 16 == 0, "bkg_colsum_f32: alignment");
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * d, s);
-    if (e != hipSuccess) { set_error("bkg_colsum_f32: memset", e); return (int)e; }
-    return 0;
+    fill_u32(out, 0u, d, s);
+    return check_launch("bkg_colsum_f32(empty)");
   }
   if (n <= 4096) {
     if (x_is_bf16) hipLaunchKernelGGL(colsum_small_kernel<__bf16>, dim3(ceil_div(d, 32)), dim3(1024), 0, s, (const __bf16*)x, ldx, (int)n, d, out);

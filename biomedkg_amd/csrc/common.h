@@ -94,6 +94,12 @@ __device__ __forceinline__ uint4 philox_keep4(uint64_t seed, uint64_t e, uint32_
   return philox4x32((uint32_t)q, (uint32_t)(q >> 32), stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// Device fills WITHOUT the runtime's memset: a hipMemsetAsync recorded into a hipGraph re-executes wrongly on this
+// stack (ROCm 7.2: a 20 KB or 520 KB memset node leaves stale / non-zero words from the second replay on; 4 MB ones
+// behave) -- every fill of the library is a kernel of its own, so that every entry point can be captured.
+void fill_u32(void* p, uint32_t value, int64_t n_words, hipStream_t s);
+void fill_zero_rows_f32(float* C, int64_t ldc, int64_t M, int64_t N, hipStream_t s);
+
 // Replay epoch of captured (hipGraph) training steps (bkg_set_rng_epoch): a device counter the captured step bumps
 // once per replay; every in-kernel Philox stream adds it (times an odd constant: a bijection of the 2^32 counter
 // values, so a captured launch only meets the same stream again after 2^32 replays -- "x 65536" wrapped after 65,536

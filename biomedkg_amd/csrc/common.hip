@@ -1,6 +1,7 @@
 // Error reporting for the C-ABI (see include/biomedkg_hip.h).
 #include "common.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -56,6 +57,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
   for (; c < cnt; ++c) acc += p[(int64_t)c * per];
   C[(int64_t)g * strideC + (e / N) * ldc + e % N] = acc;
+}
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+
+__global__ __launch_bounds__(256) void fill_zero_rows_kernel(float* __restrict__ C, int64_t ldc, int64_t M, int64_t N) {
+  const int64_t total = M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    C[(i / N) * ldc + i % N] = 0.f;
+}
+
+void fill_u32(void* p, uint32_t value, int64_t n_words, hipStream_t s) {
+  if (n_words <= 0) return;
+  const unsigned blocks = (unsigned)std::min<int64_t>((n_words + 255) / 256, 4096);
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), value, n_words);
+}
+
+void fill_zero_rows_f32(float* C, int64_t ldc, int64_t M, int64_t N, hipStream_t s) {
+  if (M <= 0 || N <= 0) return;
+  if (ldc == N) { fill_u32(C, 0u, M * N, s); return; }
+  const unsigned blocks = (unsigned)std::min<int64_t>((M * N + 255) / 256, 4096);
+  hipLaunchKernelGGL(fill_zero_rows_kernel, dim3(blocks), dim3(256), 0, s, C, ldc, M, N);
 }
 
 void splitk_reduce(const float* ws, float* C, int64_t ldc, int64_t strideC, int M, int N, const int32_t* group_ptr, int G,

@@ -290,8 +290,7 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     float* det = nullptr;
     BKG_DET_SLABS(det, ep, nsplit, M, N, "bkg_gemm_f32");
     if (!det) {      // atomics accumulate into a zeroed C; the deterministic reduce writes every element itself
-      hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
-      if (e != hipSuccess) { set_error("bkg_gemm_f32: memset", e); return (int)e; }
+      fill_zero_rows_f32(C, ldc, M, N, s);
     }
     dim3 grid(xcd_grid(nsplit, tiles)), block(256);
 #define BKG_SPLITK(BMN, TA_, TB_)                                                                                      \
@@ -389,8 +388,7 @@ extern "C" int bkg_gemm_tn_bf16(int64_t M, int64_t N, int64_t K, const void* A, 
                                 const void* B, int32_t b_is_bf16, int64_t ldb, float* C, int64_t ldc, void* stream) {
   BKG_ARG(M > 0 && N > 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "bkg_gemm_tn_bf16: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
-  if (e != hipSuccess) { set_error("bkg_gemm_tn_bf16: memset", e); return (int)e; }
+  fill_zero_rows_f32(C, ldc, M, N, s);
   if (K == 0) return 0;
   if (a_is_bf16 && b_is_bf16 && gemm_tn16_ok(M, N, A, lda, B, ldb)) {
     if (int rc = launch_gemm_tn16_splitk(M, N, K, A, lda, B, ldb, C, ldc, s)) return rc;

@@ -228,8 +228,7 @@ extern "C" int bkg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int
   BKG_ARG(n_nodes >= 0 && n_edges >= 0, "bkg_gcn_norm: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   if (n_nodes) {
-    hipError_t e = hipMemsetAsync(dis, 0, (size_t)n_nodes * sizeof(float), s);
-    if (e != hipSuccess) { set_error("bkg_gcn_norm: memset", e); return (int)e; }
+    fill_u32(dis, 0u, n_nodes, s);
     if (n_edges) hipLaunchKernelGGL(gcn_degree_count_kernel, grid1(n_edges), dim3(256), 0, s, rowptr, col, perm, keep, (int)n_nodes, n_edges, reinterpret_cast<int32_t*>(dis));
     hipLaunchKernelGGL(gcn_degree_finish_kernel, grid1(n_nodes), dim3(256), 0, s, (int)n_nodes, dis, self_w);
   }
@@ -245,7 +244,7 @@ extern "C" int bkg_rgcn_segments(const uint32_t* sorted, int64_t n, int64_t n_no
                                  int32_t* seg_rel, float* inv_cnt, int32_t* n_seg, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (n == 0) { hipMemsetAsync(n_seg, 0, sizeof(int32_t), s); return 0; }
+  if (n == 0) { fill_u32(n_seg, 0u, 1, s); return check_launch("bkg_rgcn_segments(empty)"); }
   hipLaunchKernelGGL(segment_flags_kernel, grid1(n), dim3(256), 0, s, sorted, n, flag_tmp);
   size_t bytes = (size_t)workspace_bytes;
   hipError_t e = rocprim::inclusive_scan(workspace, bytes, flag_tmp, scan_tmp, (size_t)n, rocprim::plus<int32_t>(), s);

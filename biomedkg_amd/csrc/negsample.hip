@@ -277,9 +277,8 @@ extern "C" int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int
   BKG_ARG(pow2(pos_capacity), "bkg_negative_sample: table capacity must be a power of two");
   hipStream_t s = (hipStream_t)stream;
   if (n_candidates == 0) {
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) { set_error("bkg_negative_sample: memset", e); return (int)e; }
-    return 0;
+    fill_u32(count, 0u, 1, s);
+    return check_launch("bkg_negative_sample(empty)");
   }
   const Feistel pi = make_feistel((uint64_t)(n_nodes * (n_nodes - 1)), seed);
   hipLaunchKernelGGL(negative_candidates_kernel, dim3(ceil_div(n_candidates, 256)), dim3(256), 0, s, pi, first_candidate,
@@ -319,8 +318,8 @@ extern "C" int bkg_negative_sample_dev(const int64_t* sizes, int64_t neg_ratio, 
           "bkg_negative_sample_dev: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const int64_t cap = bkg_negative_sample_dev_candidates(out_cap);
-  hipError_t e = hipMemsetAsync(table, 0xFF, (size_t)capacity * sizeof(uint64_t), s);
-  if (e != hipSuccess) { set_error("bkg_negative_sample_dev: memset", e); return (int)e; }
+  fill_u32(table, 0xFFFFFFFFu, capacity * 2, s);
+  hipError_t e = hipSuccess;
   hipLaunchKernelGGL(hashset_insert_dev_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, s, head, tail, sizes, rows,
                      reinterpret_cast<unsigned long long*>(table), (uint64_t)capacity - 1);
   hipLaunchKernelGGL(negative_candidates_dev_kernel, dim3(ceil_div(cap, 256)), dim3(256), 0, s, sizes, neg_ratio, seed,

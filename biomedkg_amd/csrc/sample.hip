@@ -266,8 +266,8 @@ extern "C" int bkg_saint_batch(const int32_t* rowptr, const int32_t* col, const 
   const int64_t n_entries = n_walks * (walk_length + 1);
   hipLaunchKernelGGL(random_walk_kernel, dim3(ceil_div(n_walks, 256)), dim3(256), 0, s, rowptr, col, start, n_walks,
                      walk_length, seed, epoch, n_nodes, walks);
-  hipError_t e = hipMemsetAsync(node_flag, 0, (size_t)n_nodes * sizeof(int32_t), s);
-  if (e != hipSuccess) { set_error("bkg_saint_batch: memset", e); return (int)e; }
+  fill_u32(node_flag, 0u, n_nodes, s);
+  hipError_t e = hipSuccess;
   hipLaunchKernelGGL(saint_mark_kernel, dim3(ceil_div(n_entries, 256)), dim3(256), 0, s, walks, n_entries, node_flag);
   size_t bytes = (size_t)workspace_bytes;
   e = rocprim::exclusive_scan(workspace, bytes, node_flag, node_offs, 0, (size_t)n_nodes, rocprim::plus<int32_t>(), s);
@@ -310,8 +310,7 @@ extern "C" int bkg_neighbor_begin(const int64_t* seeds, int64_t n_seeds, int64_t
                                   int64_t* ctr, void* stream) {
   BKG_ARG(n_seeds > 0 && n_seeds <= n_nodes, "bkg_neighbor_begin: bad sizes");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(seen, 0, (size_t)n_nodes * sizeof(int32_t), s);
-  if (e != hipSuccess) { set_error("bkg_neighbor_begin: memset", e); return (int)e; }
+  fill_u32(seen, 0u, n_nodes, s);
   hipLaunchKernelGGL(nb_begin_kernel, dim3(ceil_div(n_seeds, 256)), dim3(256), 0, s, seeds, n_seeds, seen, n_id, ctr);
   return check_launch("bkg_neighbor_begin");
 }
@@ -326,8 +325,8 @@ extern "C" int bkg_neighbor_hop(const int32_t* rowptr, const int32_t* col, const
   const int64_t slots = n_nodes * fanout;
   hipLaunchKernelGGL(nb_sample_kernel<64>, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, rowptr, n_id, ctr, fanout, seed,
                      hop, pos);
-  hipError_t e = hipMemsetAsync(new_flag, 0, (size_t)n_nodes * sizeof(int32_t), s);
-  if (e != hipSuccess) { set_error("bkg_neighbor_hop: memset", e); return (int)e; }
+  fill_u32(new_flag, 0u, n_nodes, s);
+  hipError_t e = hipSuccess;
   hipLaunchKernelGGL(nb_flags_kernel, dim3(ceil_div(slots, 256)), dim3(256), 0, s, pos, col, ctr, fanout, slots, seen,
                      new_flag, eflag);
   size_t bytes = (size_t)workspace_bytes;

@@ -111,14 +111,10 @@ class SaintDeviceSampler:
                self.edge_cap, self.pad_node, self.pad_types, L.ptr(v["n_id"]), L.ptr(v["src"]), L.ptr(v["dst"]), L.ptr(v["type"]),
                L.ptr(v["eid"]), L.ptr(v["sizes"]), L.ptr(self._ws), self._ws.numel(), L.stream())
 
-    def draw(self, start=None, use_epoch=True, graph=False):
+    def draw(self, start=None, use_epoch=True, graph=True):
         """Enqueue one batch on the current stream (no host wait); ``sizes()`` later waits for its three numbers.
-        ``start`` (test hook): the walks' roots instead of fresh uniform ones.
-
-        The eleven launches are issued eagerly (on the loop's sampler stream they run under the previous step anyway).
-        ``graph=True`` replays them as a captured graph instead -- kept for experiments only: on this stack (ROCm 7.2)
-        that graph ends in a GPU page fault after a few thousand replays (20-30 k eager draws and the same kernels with
-        only the last one outside the graph run clean; scripts/dev_sampled.py history), so nothing in the build uses it."""
+        ``start`` (test hook): the walks' roots instead of fresh uniform ones.  ``graph``: the eleven launches replayed
+        as one captured graph (the copy of the sizes to pinned memory stays outside it)."""
         if start is not None or not graph:
             self._draw(start, use_epoch)
         else:
@@ -318,7 +314,7 @@ class SaintGraphedKge:
         if not self._primed:
             self.sampler_stream.wait_stream(main)
             with torch.cuda.stream(self.sampler_stream):
-                s.draw()
+                s.draw(graph=self.graphs_on)
             self._primed = True
         n_b, e_b, e_free = s.sizes()                                       # of the batch drawn one step ago
         self.last_sizes = (n_b, e_b, e_free)
@@ -327,7 +323,7 @@ class SaintGraphedKge:
         self.copied.record(main)                                           # the next batch is drawn UNDER this step
         with torch.cuda.stream(self.sampler_stream):
             self.sampler_stream.wait_event(self.copied)
-            s.draw()
+            s.draw(graph=self.graphs_on)
         bucket = self.bucket_of(n_b, e_b, e_free)
         if bucket is None:
             self.stats["eager_fallback"] += 1

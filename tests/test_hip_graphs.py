@@ -157,3 +157,53 @@ def test_no_replay_counter_is_left_registered_after_a_capture():
         with R.use(R.DeviceRand(seed=5)):
             outs.append(enc(batch.x[:, 0].contiguous(), batch.edge_index).detach().clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_every_fill_of_the_library_survives_replay():
+    """A hipMemsetAsync recorded into a hipGraph re-executes wrongly on ROCm 7.2 (20 KB - 520 KB nodes leave stale
+    words from the second replay on), so the library fills with kernels of its own.  gcn_norm (degree counters zeroed,
+    then integer atomics) and the GraphSAINT sampler (node flags zeroed) are the two places where a stale fill shows
+    at once: replayed three times each, they must reproduce the eager result."""
+    from biomedkg_amd import synthetic
+    from biomedkg_amd.graph import graph_of
+    from biomedkg_amd.sampled import SaintDeviceSampler
+    ei = synthetic.gcl_small(5000, 50_000, seed=42).to(DEV)
+    gr = graph_of(ei, 5000)
+    keep = torch.rand(ei.size(1), device=DEV) >= 0.4
+    want = [t.clone() for t in gr.gcn_norm_raw(keep)]
+    out = []
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = gr.gcn_norm_raw(keep)
+    for _ in range(3):
+        junk = [torch.full((1 << 16,), float("nan"), device=DEV) for _ in range(64)]     # whatever is free gets poisoned
+        del junk
+        g.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(out, want):
+            assert torch.equal(a, b)
+    kg = synthetic.primekg_like(20000, 300000, 6, seed=2)
+    a = SaintDeviceSampler(kg["edge_index"].to(DEV), kg["edge_type"].to(DEV), 20000, 64, seed=3, edge_cap=8192)
+    b = SaintDeviceSampler(kg["edge_index"].to(DEV), kg["edge_type"].to(DEV), 20000, 64, seed=3, edge_cap=8192)
+    for _ in range(200):
+        a.draw(graph=True); b.draw(graph=False)
+        assert a.sizes() == b.sizes()
+    assert torch.equal(a.buf, b.buf)
+
+
+def test_grace_replays_with_other_work_in_between():
+    """Replays interleaved with unrelated allocations (a Trainer logging a loss every few steps): the learning rate is 0
+    (the warm-up epoch of the reference's schedule), so the loss must stay where it started and nothing may turn NaN --
+    it did, from the second replay on, while gcn_norm's counters were zeroed by a runtime memset node."""
+    from biomedkg_amd import graphs as G
+    mod, batch = _grace(seed=6)
+    step = G.GraphedStep(mod, batch, torch.optim.Adam(mod.model.parameters(), lr=0.0, fused=True), clip=1.0, warmup=2, seed=4)
+    before = [p.detach().clone() for p in mod.model.parameters()]
+    losses = []
+    for _ in range(12):
+        junk = [torch.full((1 << 16,), float("nan"), device=DEV) for _ in range(64)]
+        del junk
+        losses.append(float(step()))
+    assert all(v == v for v in losses) and max(losses) - min(losses) < 0.2, losses
+    for a, p in zip(before, mod.model.parameters()):
+        assert torch.equal(a, p.detach())
