@@ -5,6 +5,7 @@
 // follows has a fixed, input-determined order (bitwise reproducible; no atomics anywhere here).
 #include <cstring>
 
+#include <rocprim/device/device_merge_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -169,9 +170,11 @@ using namespace bkg;
 
 // ----------------------------------------------------------------------------- sort
 extern "C" int64_t bkg_sort_workspace_bytes(int64_t n) {
-  size_t bytes = 0;
+  size_t bytes = 0, merge_bytes = 0;
   uint32_t* p = nullptr;
   rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)n, 0, 32, (hipStream_t)0);
+  rocprim::merge_sort(nullptr, merge_bytes, p, p, p, p, (size_t)n, rocprim::less<uint32_t>(), (hipStream_t)0);
+  bytes = bytes > merge_bytes ? bytes : merge_bytes;
   size_t scan_bytes = 0;
   int32_t* q = nullptr;
   rocprim::inclusive_scan(nullptr, scan_bytes, q, q, (size_t)n, rocprim::plus<int32_t>(), (hipStream_t)0);
@@ -191,8 +194,17 @@ extern "C" int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo
   int bits = 1;
   while (bits < 32 && (1ull << bits) < space) ++bits;
   size_t bytes = (size_t)workspace_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(workspace, bytes, keys_tmp, sorted_keys, iota_tmp, perm, (size_t)n, 0, bits, s);
-  if (e != hipSuccess) { set_error("bkg_sort_edges: radix_sort_pairs", e); return (int)e; }
+  // While the stream is being captured into a hipGraph: the (equally stable) merge sort.  The radix sort's one-sweep
+  // form zeroes its histograms with runtime memsets, and memset nodes re-execute wrongly on this stack (common.h):
+  // a captured 1.5 M-key radix sort page-faults on its second replay, 0.7 M (already a merge sort inside) and 6 M do not.
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  hipError_t e = hipStreamIsCapturing(s, &capturing);
+  if (e != hipSuccess) { set_error("bkg_sort_edges: hipStreamIsCapturing", e); return (int)e; }
+  if (capturing == hipStreamCaptureStatusActive)
+    e = rocprim::merge_sort(workspace, bytes, keys_tmp, sorted_keys, iota_tmp, perm, (size_t)n, rocprim::less<uint32_t>(), s);
+  else
+    e = rocprim::radix_sort_pairs(workspace, bytes, keys_tmp, sorted_keys, iota_tmp, perm, (size_t)n, 0, bits, s);
+  if (e != hipSuccess) { set_error("bkg_sort_edges: sort", e); return (int)e; }
   return check_launch("bkg_sort_edges");
 }
 

@@ -207,3 +207,27 @@ def test_grace_replays_with_other_work_in_between():
     assert all(v == v for v in losses) and max(losses) - min(losses) < 0.2, losses
     for a, p in zip(before, mod.model.parameters()):
         assert torch.equal(a, p.detach())
+
+
+@pytest.mark.parametrize("n,hi", [(3000, 1409), (700_000, 1409), (1_500_000, 60_000), (3_000_000, 130_000)])
+def test_captured_sorts_survive_replay(n, hi):
+    """The library's key sort inside a captured step (the triplet orders and incidence lists of the padded KGE loop):
+    replayed over changing keys it must stay a stable sort.  (The radix sort's one-sweep form zeroes histograms with
+    runtime memsets -- broken as graph nodes on ROCm 7.2: a captured 1.5 M-key sort page-faulted on its second replay;
+    under capture the library uses the merge sort.)"""
+    from biomedkg_amd.graph import _Sorter
+    keys = torch.randint(0, hi, (n,), device=DEV)
+
+    def body():
+        keys.add_(1).remainder_(hi)
+        return _Sorter.sort(keys, None, hi, 1)
+    body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sk, perm, ws = body()
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        ref = torch.sort(keys, stable=True)
+        assert torch.equal(sk.long(), ref.values) and torch.equal(perm.long(), ref.indices)
