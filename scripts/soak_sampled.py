@@ -11,7 +11,8 @@ ei, et = g["edge_index"].to(dev), g["edge_type"].to(dev)
 x = torch.randn(130_000, 256, device=dev) * 0.01
 torch.manual_seed(42)
 m = KGEModule("rgcn", "dismult", 256, 256, 256, 2, 30, 2, "cosine", 1e-3, 0.0, "none", 10, "random").to(dev).train()
-sg = SaintGraphedKge(m, x, ei, et, 128, 10, None, clip=1.0, seed=42)
+walks = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+sg = SaintGraphedKge(m, x, ei, et, walks, 10, None, clip=1.0, seed=42)
 import time
 t0 = time.perf_counter()
 for i in range(steps):
