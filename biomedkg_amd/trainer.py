@@ -128,7 +128,8 @@ class Trainer:
             return None
         from .samplers import SaintBatchLoader
         if isinstance(loader, SaintBatchLoader) and getattr(getattr(model, "model", None), "decoder", None) is not None \
-                and getattr(model.model.decoder, "kind", None) is not None:
+                and getattr(model.model.decoder, "kind", None) is not None \
+                and isinstance(getattr(model, "neg_ratio", None), int):      # (dpi.yaml's default is the STRING "none")
             # the reference's KGE regime (GraphSAINT batches): padded sync-free batches, one graph per edge bucket
             from .sampled import SaintGraphedKge
             sm = loader.sampler
