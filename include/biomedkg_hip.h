@@ -7,6 +7,11 @@
  * (host); matrices are row-major with an explicit leading dimension in ELEMENTS; `stream` is a
  * hipStream_t.  Every function returns 0 on success, a hipError_t (> 0) or -1 (bad argument)
  * otherwise, with text available from bkg_last_error().  fp32 = IEEE binary32 throughout.
+ *
+ * Every entry point only enqueues on `stream` (no synchronisation, no allocation) and may be recorded into a hipGraph:
+ * fills are kernels of the library, never runtime memsets (a hipMemsetAsync node re-executes wrongly on ROCm 7.2), and
+ * bkg_sort_edges uses the merge sort while its stream is being captured (the radix sort's one-sweep form zeroes its
+ * histograms with runtime memsets).
  */
 #ifndef BIOMEDKG_HIP_H
 #define BIOMEDKG_HIP_H
