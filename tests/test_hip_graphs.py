@@ -66,7 +66,11 @@ def test_replayed_grace_steps_equal_eager_steps_bit_for_bit():
     opt2 = torch.optim.Adam(params2, lr=1e-3, fused=True)
     step = G.GraphedStep(mod2, batch2, opt2, clip=1.0, warmup=3, provider=Pinned())
     try:
-        got_losses = [step().clone() for _ in range(steps)]
+        got_losses = []
+        for _ in range(steps):      # with unrelated allocations in between: a replay may only depend on what it owns
+            junk = [torch.full((1 << 16,), float("nan"), device=DEV) for _ in range(32)]
+            del junk
+            got_losses.append(step().clone())
     finally:
         step.close()
     for a, b in zip(got_losses, eager_losses[3:]):

@@ -143,6 +143,8 @@ def _run(graphs, steps, buckets, seed=0, neg_ratio=3, walks=40):
     sg = SaintGraphedKge(mod, x, ei, et, batch_size=walks, seed=5, graphs=graphs, buckets=buckets)
     losses, sizes = [], []
     for _ in range(steps):
+        junk = [torch.full((1 << 16,), float("nan"), device=DEV) for _ in range(16)]   # (a replay may only depend on
+        del junk                                                                      #  what it owns)
         losses.append(sg.step().clone())
         sizes.append(sg.last_sizes)
     return sg, losses, sizes, [p.detach().clone() for p in mod.model.parameters()]
