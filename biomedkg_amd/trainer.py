@@ -145,7 +145,8 @@ class Trainer:
         state = {k: v.detach().clone() for k, v in model.state_dict().items()}
         try:
             step = graphs.GraphedStep(model, self._move(batch), opt, clip=self.clip, warmup=2)
-        except graphs.CaptureRefused as why:
+        except (graphs.CaptureRefused, RuntimeError) as why:      # refused up front, or an op on the path cannot be captured
+            torch.cuda.synchronize()
             model.load_state_dict(state)
             if self.rank == 0:
                 print(f"[trainer] eager steps: {why}", flush=True)
