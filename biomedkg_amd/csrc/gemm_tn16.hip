@@ -18,10 +18,6 @@ typedef float t16_acc_t __attribute__((ext_vector_type(16)));
 typedef __bf16 t16_bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short t16_s4_t __attribute__((ext_vector_type(4)));
 
-constexpr int T16_BK = 32;             // k rows per stage
-constexpr int T16_BLOCKS = 768;        // blocks per launch = 3 per CU = what is resident at once (measured: one full
-                                       // wave of blocks beats 1024 or 1536 by 15-25 %)
-constexpr int T16_NP = T16_BK / 16;    // 16-byte pieces per thread and operand
 constexpr int T16_BT = 128;    // tile width (m and n)
 
 __device__ __forceinline__ int t16_off(int row, int ch) {     // byte offset of 16-byte chunk ch of row `row`
@@ -35,94 +31,11 @@ __device__ __forceinline__ t16_s4_t t16_tr_read(const unsigned char* img, int r0
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) t16_s4_t*)a);
 }
 
-// One block: rows [kbeg, kend) of A[:, m0 : m0+128] and B[:, n0 : n0+128]  ->  C[m0.., n0..] (atomic add)
-__device__ __forceinline__ void gemm_tn16_tile(const __bf16* __restrict__ A, int64_t lda, const __bf16* __restrict__ B,
-                                               int64_t ldb, const int32_t* __restrict__ b_rows, float* __restrict__ C, int64_t ldc, int M, int N, int m0,
-                                               int n0, int kbeg, int kend, const GemmEpilogue& ep) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[T16_BK * 256];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[T16_BK * 256];
-  __shared__ __attribute__((aligned(16))) float patch[4][16 * (64 + 4)];   // epilogue transpose of the plain-store form
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  const int grp = lane >> 4, lh = grp >> 1, half = grp & 1;
-
-  t16_acc_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // staging: 32 rows x 16 chunks = 512 pieces per operand, two per thread
-  // b_rows (nullable): contracted row k of B is B[b_rows[k]] (RGCNConv backward: dY[s] = dOut[dst_s], never stored);
-  // the indices of the NEXT stage are fetched with the current stage's rows so the dependent load is off the path
-  uint4 ra[T16_NP], rb[T16_NP];
-  int bi[T16_NP];
-  auto rows_of = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < T16_NP; ++i) {
-      const int k = k0 + ((threadIdx.x + i * 256) >> 4);
-      bi[i] = (b_rows && k < kend) ? b_rows[k] : k;
-    }
-  };
-  auto load = [&](int k0) {
-    int cur[T16_NP];
-#pragma unroll
-    for (int i = 0; i < T16_NP; ++i) cur[i] = bi[i];
-    if (b_rows) rows_of(k0 + T16_BK);
-#pragma unroll
-    for (int i = 0; i < T16_NP; ++i) {
-      const int p = threadIdx.x + i * 256, row = p >> 4, ch = p & 15;
-      const int k = k0 + row;
-      ra[i] = make_uint4(0u, 0u, 0u, 0u);
-      rb[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (k < kend) {
-        ra[i] = *reinterpret_cast<const uint4*>(A + (int64_t)k * lda + m0 + ch * 8);
-        rb[i] = *reinterpret_cast<const uint4*>(B + (int64_t)(b_rows ? cur[i] : k) * ldb + n0 + ch * 8);
-      }
-    }
-  };
-  rows_of(kbeg);
-  load(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += T16_BK) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < T16_NP; ++i) {
-      const int p = threadIdx.x + i * 256, row = p >> 4, ch = p & 15;
-      *reinterpret_cast<uint4*>(As + t16_off(row, ch)) = ra[i];
-      *reinterpret_cast<uint4*>(Bs + t16_off(row, ch)) = rb[i];
-    }
-    __syncthreads();
-    if (k0 + T16_BK < kend) load(k0 + T16_BK);
-#pragma unroll
-    for (int ks = 0; ks < T16_BK; ks += 16) {
-      t16_bf16x8_t a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ca = (wm0 + i * 32 + 16 * half) >> 3, cb = (wn0 + i * 32 + 16 * half) >> 3;
-        const t16_s4_t a0 = t16_tr_read(As, ks + 8 * lh, ca, lane), a1 = t16_tr_read(As, ks + 8 * lh + 4, ca, lane);
-        const t16_s4_t b0 = t16_tr_read(Bs, ks + 8 * lh, cb, lane), b1 = t16_tr_read(Bs, ks + 8 * lh + 4, cb, lane);
-        typedef short s8_t __attribute__((ext_vector_type(8)));
-        const s8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-        const s8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-        a[i] = __builtin_bit_cast(t16_bf16x8_t, av);
-        b[i] = __builtin_bit_cast(t16_bf16x8_t, bv);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
-  // ep.atomic: direct atomic adds; deterministic mode: plain stores into this chunk's slab
-  store_acc_tile<2, 2>(acc, C, ldc, M, N, m0 + wm0, n0 + wn0, ep, patch[wave]);
-}
-
-// ---- the same tile with the staging done by LDS-DMA into a ring of stages ------------------------------------------
-// The register-staged loop above holds ONE stage (16 KB per block) in flight and restarts the loads after two barriers:
-// with three blocks per CU it is bound by the load latency (3.2 us per 32-row stage at K = 130k: 1.9 TB/s of operand
-// bytes).  Here `global_load_lds_dwordx4` writes the stage image directly (no staging registers, so depth costs LDS
+// ---- one block: rows [kbeg, kend) of A[:, m0 : m0+128] and B[:, n0 : n0+128]  ->  C[m0.., n0..] -------------------------
+// Staging is LDS-DMA into a ring of stages.  (A register-staged loop -- load, barrier, ds_write, barrier, MFMA -- holds
+// ONE 16 KB stage in flight per block and restarts the loads after two barriers: with three blocks per CU it was bound
+// by the load latency, 3.2 us per 32-row stage at K = 130k = 1.9 TB/s of operand bytes.)  `global_load_lds_dwordx4`
+// writes the stage image directly (no staging registers, so depth costs LDS
 // only): NS - 1 stages are in flight per block across ONE raw barrier per stage, retired by counted vmcnt waits
 // (cdna_hip_programming.md section 5, "Pipelining across barriers").  A DMA's LDS destination is lane-linear (1 KiB =
 // four 256-byte rows per wave-instruction), so the chunk XOR of t16_off is applied to the SOURCE address: slot c' of
@@ -304,15 +217,11 @@ __global__ __launch_bounds__(256) void gemm_tn16_grouped_kernel(const __bf16* __
   else gemm_tn16_tile_ring<BK, NS, false>(A, lda, B, ldb, nullptr, Cg, ldc, M, N, m0, n0, k0, kend, ep, ring);
 }
 
-static int g_tn16_cfg = -1, g_tn16_blocks = 512, g_tn16_kchunk = 1024;
-void dev_tn16_tuning(int cfg, int blocks, int kchunk) { g_tn16_cfg = cfg; g_tn16_blocks = blocks; g_tn16_kchunk = kchunk; }
-
 // ring shapes: (rows per stage, slots)
 #define BKG_TN16_CFG(cfg, call)            \
   switch (cfg) {                           \
-    case 1: { call(32, 3); break; }        \
     case 2: { call(64, 4); break; }        \
-    default: { call(32, 4); break; }       \
+    default: { call(32, 3); break; }       \
   }
 
 bool gemm_tn16_ok(int64_t M, int64_t N, const void* A, int64_t lda, const void* B, int64_t ldb) {
@@ -328,8 +237,9 @@ int launch_gemm_tn16_splitk(int64_t M, int64_t N, int64_t K, const void* A, int6
   // (MI355X_MICROARCH.md "Global float atomics"): 64 KB per block.  Few tiles (their operand stream is short): one deep
   // block per CU (64-row stages x 4 slots, 96 KB in flight) keeps the adds at 17 MB; many tiles (every operand column
   // block is re-read from L2 by several tiles: the stream dominates): three shallower blocks per CU.
-  const int cfg = g_tn16_cfg >= 0 ? g_tn16_cfg : (tiles <= 8 ? 2 : 1);
-  const int64_t blocks = g_tn16_cfg >= 0 ? g_tn16_blocks : (tiles <= 8 ? 256 : 768);
+  // (measured at K = 130k, us: 256 x 256 45 against 60; 512 x 256 65 / 75; 256 x 768 147 / 88)
+  const int cfg = tiles <= 8 ? 2 : 1;
+  const int64_t blocks = tiles <= 8 ? 256 : 768;
   int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, blocks / tiles));
   const int kchunk = (int)(((K + nsplit - 1) / nsplit + 63) / 64 * 64);
   nsplit = (K + kchunk - 1) / kchunk;
@@ -349,10 +259,10 @@ int launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const voi
                              hipStream_t s) {
   GemmEpilogue ep{1.f, 0.f, nullptr, 0, nullptr, 0, 1.f, 1};
   const int64_t tiles = (M / T16_BT) * (N / T16_BT);
-  const int cfg = g_tn16_cfg >= 0 ? g_tn16_cfg : 1;
+  const int cfg = 1;
   // rows per block: 64 KB of atomic adds each (see above), so long chunks at scale; short ones for a mini-batch
-  const int KCHUNK = g_tn16_cfg >= 0 ? g_tn16_kchunk
-                                     : (int)std::min<int64_t>(2048, std::max<int64_t>(256, (rows_total / 96 + 63) / 64 * 64));
+  // (300k rows over 30 skewed groups, us: 1024 rows 103, 2048 92, 3072 84 / 100 gathered, 4096 96 / 120)
+  const int KCHUNK = (int)std::min<int64_t>(2048, std::max<int64_t>(256, (rows_total / 96 + 63) / 64 * 64));
   float* det = nullptr;
   BKG_DET_SLABS(det, ep, ceil_div(rows_total, KCHUNK) + G, M, N, "bkg_gemm_grouped_k_bf16");
 #define BKG_TN16_GROUPED(BK, NS)                                                                                        \
@@ -366,5 +276,3 @@ int launch_gemm_tn16_grouped(int64_t rows_total, int64_t M, int64_t N, const voi
 }
 
 }  // namespace bkg
-
-extern "C" void bkg_dev_tn16_tuning(int cfg, int blocks, int kchunk) { bkg::dev_tn16_tuning(cfg, blocks, kchunk); }

@@ -272,6 +272,120 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
   }
 }
 
+// ---- K = 256, N = 256, bf16 rows: the whole weight in REGISTERS, A through LDS in full lines -------------------------
+// The kernel above reads A in MFMA-fragment shape (32 rows x 32 B per wave-instruction: every 128-byte line is asked
+// for four times) and twice (once per 128-column slab): 3.6 TB/s of operand + result bytes.  Here a block is 8 waves
+// and covers all 256 output columns: wave w keeps W[32 w : 32 w + 32, 0 : 256] as 16 MFMA operands (64 VGPRs) for its
+// whole life, so LDS holds nothing but A: 64-row tiles (32 KB) copied by LDS-DMA, two whole 512-byte rows per
+// wave-instruction, into a ring of four slots -- up to three tiles in flight per CU across one raw barrier per tile,
+// retired by counted vmcnt waits -- and read by every wave as b128 fragments.  A 512-byte row stride would put the 32
+// rows of a fragment read on the same banks: slot c' of row r holds chunk c' ^ (r & 31), applied to the DMA's SOURCE
+// address (its destination is lane-linear).  Per tile and CU: 256 KB of LDS reads and 2 x 1024 MFMA cycles per SIMD --
+// both 2048 clocks for 32 KB of A, three times the chip's HBM share.
+constexpr int X8_BM = 64, X8_NS = 4, X8_K = 256, X8_N = 256;
+constexpr int X8_STAGE = X8_BM * X8_K * 2;
+
+template <typename CT>
+__global__ __launch_bounds__(512) void gemm_xw8_kernel(XwArgs g, GemmEpilogue ep) {
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[X8_NS * X8_STAGE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int n0 = wave * 32;
+  const __bf16* __restrict__ A = reinterpret_cast<const __bf16*>(g.A);
+  CT* __restrict__ C = reinterpret_cast<CT*>(g.C);
+
+  const int m_tiles = (g.M + X8_BM - 1) / X8_BM, stride = gridDim.x;
+  // DMA pieces of this lane: rows wave * 8 + 2 j + (lane >> 5) of a tile, slot lane & 31
+  int64_t src_off[4];
+  int drow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    drow[j] = wave * 8 + 2 * j + (lane >> 5);
+    src_off[j] = (int64_t)(((lane & 31) ^ (drow[j] & 31)) * 8);
+  }
+  int t_issue = blockIdx.x;
+  auto issue = [&](int slot) {
+    unsigned char* base = ring + slot * X8_STAGE + wave * (8 * 512);
+    const int m0 = t_issue * X8_BM;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = max(0, min(m0 + drow[j], g.M - 1));   // past the end: valid memory, never stored
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)r * g.lda + src_off[j]),
+                                       (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
+    }
+    t_issue += stride;
+  };
+#pragma unroll
+  for (int s = 0; s < X8_NS - 1; ++s) issue(s);
+  // the weights and the bias travel together with the first tiles (hipcc waits for everything in flight at their first
+  // use, i.e. once, before the first tile); from then on the loop issues nothing but DMAs and stores
+  xw_bf16x8_t w[X8_K / 16];
+#pragma unroll
+  for (int ks = 0; ks < X8_K / 16; ++ks)
+    w[ks] = *reinterpret_cast<const xw_bf16x8_t*>(g.Wt + (int64_t)(n0 + l31) * g.ldw + ks * 16 + lh * 8);
+  // bias of this lane's columns n0 + 8 q + 4 lh + 0..3 (an ordinary load inside the loop would drain the DMAs)
+  float4 bias[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    bias[q] = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + n0 + 8 * q + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+
+  const int p16 = (lh ^ l31) * 16;
+  int slot = 0, it = 0;
+  for (int t = blockIdx.x; t < m_tiles; t += stride) {
+    // This wave's DMAs of tile t have landed.  vmcnt retires in issue order and counts the result stores too: behind
+    // tile t's DMAs this wave has issued the DMAs of two more tiles and the stores of up to three finished ones (a
+    // partial tile -- fewer stores -- can only be a block's last).  Counting the stores keeps both younger tiles in
+    // flight; a wait for "at most 8" would retire the older of them as well.
+    constexpr int SPT = sizeof(CT) == 2 ? 4 : 8;   // 16-byte stores per wave and tile
+    if (it >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 3 * SPT) : "memory");
+    else if (it == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * SPT) : "memory");
+    else if (it == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + SPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    ++it;
+    __builtin_amdgcn_s_barrier();   // ... everyone else's too, and every wave is done with the slot refilled next
+    issue(slot == 0 ? X8_NS - 1 : slot - 1);
+    const unsigned char* tile = ring + slot * X8_STAGE + l31 * 512;
+    xw_acc_t acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < X8_K / 16; ++ks) {
+      const int off = (ks * 32) ^ p16;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const xw_bf16x8_t a = *reinterpret_cast<const xw_bf16x8_t*>(tile + j * (32 * 512) + off);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], a, acc[j], 0, 0, 0);
+      }
+    }
+    // acc[j][4q..4q+3] = C[t * 64 + 32 j + l31][n0 + 8 q + 4 lh + 0..3]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = t * X8_BM + j * 32 + l31;
+      if (row < g.M) {
+        CT* __restrict__ drow_p = C + (int64_t)row * g.ldc + n0;
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = make_float4(ep.alpha * acc[j][4 * q] + bias[q].x, ep.alpha * acc[j][4 * q + 1] + bias[q].y,
+                             ep.alpha * acc[j][4 * q + 2] + bias[q].z, ep.alpha * acc[j][4 * q + 3] + bias[q].w);
+          if (ep.act == 1) {
+            v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f);
+          } else if (ep.act == 2) {
+            v[q].x = v[q].x > 0.f ? v[q].x : expm1f(v[q].x); v[q].y = v[q].y > 0.f ? v[q].y : expm1f(v[q].y);
+            v[q].z = v[q].z > 0.f ? v[q].z : expm1f(v[q].z); v[q].w = v[q].w > 0.f ? v[q].w : expm1f(v[q].w);
+          }
+        }
+        xw_store_pair(drow_p, lh, v[0], v[1]);
+        xw_store_pair(drow_p + 16, lh, v[2], v[3]);
+      }
+    }
+    slot = slot + 1 == X8_NS ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile
+}
+
 // weights -> the [N][K] bf16 image the kernel above reads (a 64 x 64 patch per block through LDS)
 __global__ __launch_bounds__(256) void weight_to_bf16_kernel(const float* __restrict__ W, int64_t ldw, int64_t stride_w,
                                                              int rows, int cols, __bf16* __restrict__ out, int64_t ldo,
@@ -331,6 +445,12 @@ extern "C" int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const v
   const int n_tiles = ceil_div(N, XW_BN);
   XwArgs g{A, lda, a_rows, reinterpret_cast<const __bf16*>(Wt), ldw, stride_w, C, ldc, group_ptr, G, (int)M, (int)N, (int)K, 0};
   hipStream_t s = (hipStream_t)stream;
+  if (a_is_bf16 && !group_ptr && !a_rows && !gate && beta == 0.f && K == X8_K && N == X8_N) {
+    const unsigned blocks = (unsigned)std::min<int64_t>(256, ceil_div(M, X8_BM));
+    if (c_is_bf16) hipLaunchKernelGGL(gemm_xw8_kernel<__bf16>, dim3(blocks), dim3(512), 0, s, g, ep);
+    else hipLaunchKernelGGL(gemm_xw8_kernel<float>, dim3(blocks), dim3(512), 0, s, g, ep);
+    return check_launch("bkg_gemm_xw(8 waves)");
+  }
   unsigned grid;
   if (group_ptr) {
     grid = xcd_grid(ceil_div(M, XW_BM) + G, n_tiles);
