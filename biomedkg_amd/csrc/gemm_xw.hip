@@ -386,6 +386,146 @@ __global__ __launch_bounds__(512) void gemm_xw8_kernel(XwArgs g, GemmEpilogue ep
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile
 }
 
+// The same block for ROW GROUPS (RGCNConv: rows of relation g use Wt + g * stride_w) and gathered rows (a_rows).  Tiles
+// never straddle a group; a block walks a CONTIGUOUS range of the concatenated tile list, so it changes group -- and
+// reloads its 64 weight registers, draining the DMAs once -- two or three times in its life, not per tile.  Partial
+// tiles end every group here, so the number of stores behind a tile's DMAs is not a constant: the waits count DMAs only.
+// Source rows of a gathered product come through scalar loads (two rows per DMA; an ordinary load would make hipcc
+// drain the ring every tile).
+template <typename CT>
+__global__ __launch_bounds__(512) void gemm_xw8_grouped_kernel(XwArgs g, GemmEpilogue ep, const int32_t* __restrict__ gp,
+                                                               const int32_t* __restrict__ a_rows) {
+  // (gp / a_rows as __restrict__ PARAMETERS: read through the argument struct hipcc cannot tell them from C and turns
+  // every group_ptr / index read into a vector load + vmcnt(0))
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[X8_NS * X8_STAGE];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, lh = lane >> 5;
+  const int n0 = wave * 32;
+  const __bf16* __restrict__ A = reinterpret_cast<const __bf16*>(g.A);
+  CT* __restrict__ C = reinterpret_cast<CT*>(g.C);
+  // The group table lives in the lanes (G <= 63): lane q holds group q's row range, tile count and first tile index
+  // (one vector load and a wave prefix sum, before any DMA is in flight); finding a tile's group is a ballot.
+  const int my_lo = gp[min(lane, g.G)], my_hi = gp[min(lane + 1, g.G)];
+  const int my_nt = lane < g.G ? (my_hi - my_lo + X8_BM - 1) / X8_BM : 0;
+  int incl = my_nt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  const int my_first = incl - my_nt;
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  const int t_lo = (int)((int64_t)total * blockIdx.x / gridDim.x), t_hi = (int)((int64_t)total * (blockIdx.x + 1) / gridDim.x);
+  if (t_lo >= t_hi) return;
+  struct Tile { int grp, m0, m_hi; };
+  auto locate = [&](int t) {              // t < total: the last non-empty group that starts at or before tile t
+    const unsigned long long m = __ballot(my_nt > 0 && my_first <= t);
+    const int q = 63 - __builtin_clzll(m);
+    const int lo = __builtin_amdgcn_readlane(my_lo, q), first = __builtin_amdgcn_readlane(my_first, q);
+    return Tile{q, lo + (t - first) * X8_BM, __builtin_amdgcn_readlane(my_hi, q)};
+  };
+
+  int64_t src_off[4];
+  int drow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    drow[j] = wave * 8 + 2 * j + (lane >> 5);
+    src_off[j] = (int64_t)(((lane & 31) ^ (drow[j] & 31)) * 8);
+  }
+  int t_issue = t_lo;
+  auto issue = [&](int slot) {
+    if (t_issue < t_hi) {
+      const Tile ti = locate(t_issue);
+      unsigned char* base = ring + slot * X8_STAGE + wave * (8 * 512);
+      const int m0 = ti.m0, m_last = ti.m_hi - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int r;
+        if (a_rows) {
+          const int i0 = min(m0 + wave * 8 + 2 * j, m_last), i1 = min(m0 + wave * 8 + 2 * j + 1, m_last);
+          const int r0 = a_rows[i0], r1 = a_rows[i1];
+          r = (lane >> 5) ? r1 : r0;
+        } else {
+          r = min(m0 + drow[j], m_last);   // past the end of the group: valid memory, never stored
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)r * g.lda + src_off[j]),
+                                         (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
+      }
+    } else {
+      // past this block's range: the waits below count four DMAs per tile -- issue them on memory that is surely there
+      unsigned char* base = ring + slot * X8_STAGE + wave * (8 * 512);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Wt + (lane & 31) * 8),
+                                         (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
+    }
+    ++t_issue;
+  };
+#pragma unroll
+  for (int s = 0; s < X8_NS - 1; ++s) issue(s);
+
+  float4 bias[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    bias[q] = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + n0 + 8 * q + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
+  xw_bf16x8_t w[X8_K / 16];
+  int g_have = -1;
+
+  const int p16 = (lh ^ l31) * 16;
+  int slot = 0;
+  for (int t = t_lo; t < t_hi; ++t) {
+    const Tile tc = locate(t);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((X8_NS - 2) * 4) : "memory");   // this tile's DMAs (and every older store)
+    __builtin_amdgcn_s_barrier();
+    issue(slot == 0 ? X8_NS - 1 : slot - 1);
+    if (tc.grp != g_have) {   // block-uniform; hipcc waits for these loads -- and with them for the DMAs in flight
+      const __bf16* Wg = g.Wt + (int64_t)tc.grp * g.stride_w;
+#pragma unroll
+      for (int ks = 0; ks < X8_K / 16; ++ks)
+        w[ks] = *reinterpret_cast<const xw_bf16x8_t*>(Wg + (int64_t)(n0 + l31) * g.ldw + ks * 16 + lh * 8);
+      g_have = tc.grp;
+    }
+    const int m0 = tc.m0, m_hi = tc.m_hi;
+    const unsigned char* tile = ring + slot * X8_STAGE + l31 * 512;
+    xw_acc_t acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < X8_K / 16; ++ks) {
+      const int off = (ks * 32) ^ p16;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const xw_bf16x8_t a = *reinterpret_cast<const xw_bf16x8_t*>(tile + j * (32 * 512) + off);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], a, acc[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = m0 + j * 32 + l31;
+      if (row < m_hi) {
+        CT* __restrict__ drow_p = C + (int64_t)row * g.ldc + n0;
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = make_float4(ep.alpha * acc[j][4 * q] + bias[q].x, ep.alpha * acc[j][4 * q + 1] + bias[q].y,
+                             ep.alpha * acc[j][4 * q + 2] + bias[q].z, ep.alpha * acc[j][4 * q + 3] + bias[q].w);
+          if (ep.act == 1) {
+            v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f);
+          } else if (ep.act == 2) {
+            v[q].x = v[q].x > 0.f ? v[q].x : expm1f(v[q].x); v[q].y = v[q].y > 0.f ? v[q].y : expm1f(v[q].y);
+            v[q].z = v[q].z > 0.f ? v[q].z : expm1f(v[q].z); v[q].w = v[q].w > 0.f ? v[q].w : expm1f(v[q].w);
+          }
+        }
+        xw_store_pair(drow_p, lh, v[0], v[1]);
+        xw_store_pair(drow_p + 16, lh, v[2], v[3]);
+      }
+    }
+    slot = slot + 1 == X8_NS ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // weights -> the [N][K] bf16 image the kernel above reads (a 64 x 64 patch per block through LDS)
 __global__ __launch_bounds__(256) void weight_to_bf16_kernel(const float* __restrict__ W, int64_t ldw, int64_t stride_w,
                                                              int rows, int cols, __bf16* __restrict__ out, int64_t ldo,
@@ -450,6 +590,12 @@ extern "C" int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const v
     if (c_is_bf16) hipLaunchKernelGGL(gemm_xw8_kernel<__bf16>, dim3(blocks), dim3(512), 0, s, g, ep);
     else hipLaunchKernelGGL(gemm_xw8_kernel<float>, dim3(blocks), dim3(512), 0, s, g, ep);
     return check_launch("bkg_gemm_xw(8 waves)");
+  }
+  if (a_is_bf16 && group_ptr && G <= 63 && !gate && beta == 0.f && K == X8_K && N == X8_N) {
+    const unsigned blocks = (unsigned)std::min<int64_t>(256, ceil_div(M, X8_BM) + G);
+    if (c_is_bf16) hipLaunchKernelGGL(gemm_xw8_grouped_kernel<__bf16>, dim3(blocks), dim3(512), 0, s, g, ep, group_ptr, a_rows);
+    else hipLaunchKernelGGL(gemm_xw8_grouped_kernel<float>, dim3(blocks), dim3(512), 0, s, g, ep, group_ptr, a_rows);
+    return check_launch("bkg_gemm_xw(8 waves, grouped)");
   }
   unsigned grid;
   if (group_ptr) {

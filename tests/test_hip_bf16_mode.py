@@ -158,6 +158,65 @@ def test_gemm_xw_epilogues_and_groups():
         o += sz
 
 
+@pytest.mark.parametrize("m", [257, 4096, 4161, 33_000])
+@pytest.mark.parametrize("c_bf16", [False, True])
+def test_gemm_xw_register_weight_kernel_epilogues(m, c_bf16):
+    """K = N = 256 over bf16 rows takes the 8-wave kernel (weight in registers, A tiles by LDS-DMA): every epilogue
+    it accepts, partial last tiles, fewer tiles than ring slots, more blocks than tiles."""
+    from biomedkg_amd import ops
+    torch.manual_seed(m)
+    a = (torch.randn(m, 256, device=DEV)).bfloat16()
+    w, bias = torch.randn(256, 256, device=DEV) * 0.1, torch.randn(256, device=DEV)
+    assert ops._xw_ok(a, m, 256, 256)
+    cdt = torch.bfloat16 if c_bf16 else torch.float32
+    tol = dict(rtol=2 ** -7, atol=2e-2) if c_bf16 else dict(rtol=1e-4, atol=2e-3)
+    pre = a.double() @ w.bfloat16().double().t()
+    torch.testing.assert_close(ops.gemm(a, w, trans_b=True, out_dtype=cdt).double(), pre, **tol)
+    torch.testing.assert_close(ops.gemm(a, w.t().contiguous(), out_dtype=cdt).double(), pre, **tol)
+    torch.testing.assert_close(ops.gemm(a, w, trans_b=True, alpha=0.5, bias=bias, act=ops.ACT_RELU, out_dtype=cdt).double(),
+                               (0.5 * pre + bias.double()).relu(), **tol)
+    torch.testing.assert_close(ops.gemm(a, w, trans_b=True, alpha=-1.5, act=ops.ACT_ELU, out_dtype=cdt).double(),
+                               torch.nn.functional.elu(-1.5 * pre), **tol)
+    # rows of a wider table (lda > K) into the columns of a wider result (ldc > N)
+    wide = torch.randn(m, 512, device=DEV).bfloat16()
+    out = torch.full((m, 512), 7.0, device=DEV)
+    ops.gemm(wide[:, 256:], w, trans_b=True, out=out[:, :256])
+    torch.testing.assert_close(out[:, :256].double(), wide[:, 256:].double() @ w.bfloat16().double().t(), rtol=1e-4, atol=2e-3)
+    assert bool((out[:, 256:] == 7.0).all())
+
+
+@pytest.mark.parametrize("c_bf16", [False, True])
+@pytest.mark.parametrize("gathered", [False, True])
+def test_gemm_xw_register_weight_kernel_row_groups(c_bf16, gathered):
+    """The grouped form of the 8-wave kernel (RGCNConv's per-relation weights over bf16 rows, optionally gathered by
+    index): empty, one-row, 63 / 64 / 65-row and multi-tile groups, more groups than blocks' ranges, both weight
+    orientations -- against fp64 products of the same bf16 values."""
+    from biomedkg_amd import ops
+    torch.manual_seed(5 + c_bf16)
+    sizes = [0, 1, 63, 0, 64, 65, 700, 0, 0, 4099, 2, 130, 31, 9000, 0]
+    g, s_rows, n = len(sizes), sum(sizes), 6000
+    gptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=DEV)
+    w = torch.randn(g, 256, 256, device=DEV) * 0.1
+    cdt = torch.bfloat16 if c_bf16 else torch.float32
+    tol = dict(rtol=2 ** -7, atol=2e-2) if c_bf16 else dict(rtol=1e-4, atol=2e-3)
+    if gathered:
+        table = torch.randn(n, 256, device=DEV).bfloat16()
+        idx = torch.randint(0, n, (s_rows,), device=DEV, dtype=torch.int32)
+        rows = table[idx.long()]
+        kw = dict(a_rows=idx)
+    else:
+        table = rows = torch.randn(s_rows, 256, device=DEV).bfloat16()
+        kw = {}
+    for tb in (False, True):
+        out = ops.gemm_grouped_rows(table, w, gptr, trans_b=tb, out_dtype=cdt, **kw)
+        assert out.shape == (s_rows, 256) and out.dtype == cdt
+        o = 0
+        for i, sz in enumerate(sizes):
+            wi = w[i].bfloat16().double()
+            torch.testing.assert_close(out[o:o + sz].double(), rows[o:o + sz].double() @ (wi.t() if tb else wi), **tol)
+            o += sz
+
+
 def test_spmm_bf16_result_is_the_rounded_fp32_result():
     from biomedkg_amd import graph as G, ops
     n, e, d = 3000, 90_000, 256
