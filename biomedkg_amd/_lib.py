@@ -104,6 +104,9 @@ SIGNATURES = {
     "bkg_colsum_workspace_floats": (I64, [I64, I32]),
     "bkg_gate_f32": (I32, [P, P, F32, I64, P, P]),
     "bkg_colsum_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),
+    "bkg_colsum_weighted_f32": (I32, [P, I32, I64, I64, I32, P, P, P, P]),
+    "bkg_rowdot_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),
+    "bkg_scaled_rows": (I32, [P, P, I64, I32, P, I32, I64, P]),
     # negsample.hip
     "bkg_hashset_insert_offdiag": (I32, [P, P, I64, I64, P, I64, P]),
     "bkg_negative_sample_workspace_bytes": (I64, [I64]),

@@ -12,7 +12,8 @@ constexpr int CS_MAX_BLOCKS = 512;
 // block = 256 threads = RPB row slots x PPR pieces per row; thread (slot, piece) walks rows slot, slot + RPB, ...
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t ldx, int64_t n, int d,
-                                                             int64_t rows_per_block, float* __restrict__ partial) {
+                                                             int64_t rows_per_block, const float* __restrict__ row_w,
+                                                             float* __restrict__ partial) {
   constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL;
   __shared__ float4 red[256 * Q];
   const int ppr = d / EPL, rpb = 256 / ppr;             // pieces per row (<= 256), row slots per block
@@ -26,15 +27,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     int64_t r = r0 + slot;
     for (; r + (U - 1) * rpb < r1; r += U * rpb) {
       Piece<T> p[U];
+      float w[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) p[u].load(x + (r + (int64_t)u * rpb) * ldx + piece * EPL);
+      for (int u = 0; u < U; ++u) {
+        p[u].load(x + (r + (int64_t)u * rpb) * ldx + piece * EPL);
+        w[u] = row_w ? row_w[r + (int64_t)u * rpb] : 1.0f;
+      }
 #pragma unroll
-      for (int u = 0; u < U; ++u) p[u].fma(acc, 1.0f);
+      for (int u = 0; u < U; ++u) p[u].fma(acc, w[u]);
     }
     for (; r < r1; r += rpb) {
       Piece<T> p;
       p.load(x + r * ldx + piece * EPL);
-      p.fma(acc, 1.0f);
+      p.fma(acc, row_w ? row_w[r] : 1.0f);
     }
   }
   // add the row slots in slot order
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 // thread), groups added in group order
 template <typename T>
 __global__ __launch_bounds__(1024) void colsum_small_kernel(const T* __restrict__ x, int64_t ldx, int n, int d,
-                                                            float* __restrict__ out) {
+                                                            const float* __restrict__ row_w, float* __restrict__ out) {
   __shared__ float red[32][33];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
   float s = 0.f;
@@ -95,9 +100,13 @@ __global__ __launch_bounds__(1024) void colsum_small_kernel(const T* __restrict_
     for (; r + 96 < n; r += 128) {
       const float v0 = (float)x[(int64_t)r * ldx + c], v1 = (float)x[(int64_t)(r + 32) * ldx + c];
       const float v2 = (float)x[(int64_t)(r + 64) * ldx + c], v3 = (float)x[(int64_t)(r + 96) * ldx + c];
-      s += v0; s += v1; s += v2; s += v3;
+      if (row_w) {
+        s = fmaf(row_w[r], v0, s); s = fmaf(row_w[r + 32], v1, s); s = fmaf(row_w[r + 64], v2, s); s = fmaf(row_w[r + 96], v3, s);
+      } else {
+        s += v0; s += v1; s += v2; s += v3;
+      }
     }
-    for (; r < n; r += 32) s += (float)x[(int64_t)r * ldx + c];
+    for (; r < n; r += 32) s = row_w ? fmaf(row_w[r], (float)x[(int64_t)r * ldx + c], s) : s + (float)x[(int64_t)r * ldx + c];
   }
   red[g][threadIdx.x & 31] = s;
   __syncthreads();
@@ -138,27 +147,39 @@ extern "C" int64_t bkg_colsum_workspace_floats(int64_t n, int32_t d) {
   return (int64_t)std::min<int64_t>(CS_MAX_BLOCKS, std::max<int64_t>(1, (n + 63) / 64)) * d;
 }
 
-extern "C" int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, float* workspace,
-                              float* out, void* stream) {
+static int colsum_launch(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, const float* row_w,
+                         float* workspace, float* out, void* stream, const char* who) {
   const int epl = x_is_bf16 ? 8 : 4;
-  BKG_ARG(n >= 0 && d > 0 && d % epl == 0 && d / epl <= 256, "bkg_colsum_f32: d must be a multiple of the 16-byte piece, <= 256 pieces");
-  BKG_ARG((uintptr_t)x % 16 == 0 && ldx % epl == 0 && (uintptr_t)workspace % 16 == 0, "bkg_colsum_f32: alignment");
+  BKG_ARG(n >= 0 && d > 0 && d % epl == 0 && d / epl <= 256, "column sums: d must be a multiple of the 16-byte piece, <= 256 pieces");
+  BKG_ARG((uintptr_t)x % 16 == 0 && ldx % epl == 0 && (uintptr_t)workspace % 16 == 0, "column sums: alignment");
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
     fill_u32(out, 0u, d, s);
-    return check_launch("bkg_colsum_f32(empty)");
+    return check_launch(who);
   }
   if (n <= 4096) {
-    if (x_is_bf16) hipLaunchKernelGGL(colsum_small_kernel<__bf16>, dim3(ceil_div(d, 32)), dim3(1024), 0, s, (const __bf16*)x, ldx, (int)n, d, out);
-    else hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(ceil_div(d, 32)), dim3(1024), 0, s, (const float*)x, ldx, (int)n, d, out);
-    return check_launch("bkg_colsum_f32(small)");
+    if (x_is_bf16) hipLaunchKernelGGL(colsum_small_kernel<__bf16>, dim3(ceil_div(d, 32)), dim3(1024), 0, s, (const __bf16*)x, ldx, (int)n, d, row_w, out);
+    else hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(ceil_div(d, 32)), dim3(1024), 0, s, (const float*)x, ldx, (int)n, d, row_w, out);
+    return check_launch(who);
   }
   const int n_blocks = (int)(bkg_colsum_workspace_floats(n, d) / d);
   const int64_t rpb = (n + n_blocks - 1) / n_blocks;
   if (x_is_bf16)
-    hipLaunchKernelGGL(colsum_partial_kernel<__bf16>, dim3(n_blocks), dim3(256), 0, s, (const __bf16*)x, ldx, n, d, rpb, workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel<__bf16>, dim3(n_blocks), dim3(256), 0, s, (const __bf16*)x, ldx, n, d, rpb, row_w, workspace);
   else
-    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(n_blocks), dim3(256), 0, s, (const float*)x, ldx, n, d, rpb, workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(n_blocks), dim3(256), 0, s, (const float*)x, ldx, n, d, rpb, row_w, workspace);
   hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, s, workspace, n_blocks, d, out);
-  return check_launch("bkg_colsum_f32");
+  return check_launch(who);
+}
+
+extern "C" int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, float* workspace,
+                              float* out, void* stream) {
+  return colsum_launch(x, x_is_bf16, ldx, n, d, nullptr, workspace, out, stream, "bkg_colsum_f32");
+}
+
+// out[c] = sum_i row_w[i] * x[i, c]: the weight gradient of a Linear whose outputs are summed over the features
+extern "C" int bkg_colsum_weighted_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, const float* row_w,
+                                       float* workspace, float* out, void* stream) {
+  BKG_ARG(row_w != nullptr, "bkg_colsum_weighted_f32: row weights missing");
+  return colsum_launch(x, x_is_bf16, ldx, n, d, row_w, workspace, out, stream, "bkg_colsum_weighted_f32");
 }

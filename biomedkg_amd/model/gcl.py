@@ -131,5 +131,9 @@ class GGD(torch.nn.Module):
         h = h2.view(2 * n, h2.size(1) // 2)
         for layer in self.mlp[:-1]:
             h = ops.linear(h, layer.weight, layer.bias, act=ops.ACT_RELU)
-        s = ops.linear(h, self.mlp[-1].weight, self.mlp[-1].bias).sum(1).view(n, 2)
+        last = self.mlp[-1]
+        if ops.rowsum_linear_ok(h, last.weight):
+            s = ops.linear_rowsum(h, last.weight, last.bias).view(n, 2)      # (W h + b).sum(1) = h . W.sum(0) + b.sum()
+        else:
+            s = ops.linear(h, last.weight, last.bias).sum(1).view(n, 2)
         return s[:, 0], s[:, 1]

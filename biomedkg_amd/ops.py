@@ -416,6 +416,55 @@ def linear(x, weight, bias=None, act=ACT_NONE):
     return y.reshape(*lead, weight.size(0))
 
 
+class _RowDot(torch.autograd.Function):
+    """``s[i] = x[i, :] . w`` over a tall fp32 / bf16 table (csrc/rowdot.hip); backward: ``dx = g (x) w`` as a table of
+    x's type, ``dw = sum_i g[i] x[i, :]`` (column sums with row weights, csrc/colsum.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        out = torch.empty(x.size(0), dtype=torch.float32, device=x.device)
+        L.call("bkg_rowdot_f32", L.ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), x.size(0), x.size(1), L.ptr(w),
+               L.ptr(out), L.stream())
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        n, d = x.shape
+        g = _f32c(g)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(n, d, dtype=x.dtype, device=x.device)
+            L.call("bkg_scaled_rows", L.ptr(g), L.ptr(w), n, d, L.ptr(dx), int(x.dtype == torch.bfloat16), dx.stride(0),
+                   L.stream())
+        if ctx.needs_input_grad[1]:
+            ws = torch.empty(L.lib().bkg_colsum_workspace_floats(n, d), dtype=torch.float32, device=x.device)
+            dw = torch.empty(d, dtype=torch.float32, device=x.device)
+            L.call("bkg_colsum_weighted_f32", L.ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), n, d, L.ptr(g), L.ptr(ws),
+                   L.ptr(dw), L.stream())
+        return dx, dw
+
+
+def rowsum_linear_ok(x, weight):
+    """Can ``linear(x, weight, bias).sum(-1)`` run as one dot product per row (:func:`linear_rowsum`)?"""
+    epl = 8 if x.dtype == torch.bfloat16 else 4
+    d = x.size(-1)
+    return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.stride(1) == 1 and d % epl == 0
+            and d // epl <= 256 and (d // epl) in _KGE_PIECES and x.stride(0) % epl == 0 and x.data_ptr() % 16 == 0
+            and weight.dtype == torch.float32)
+
+
+def linear_rowsum(x, weight, bias=None):
+    """``linear(x, weight, bias).sum(1)`` -- the head of GGD, reference biomedkg/model/gcl.py:86-90 -- without the
+    ``[rows, out]`` product: ``sum_j (W x + b)_j = x . (sum_j W[j, :]) + sum_j b_j``.  Same value up to the order of
+    the fp32 additions (so the exact-fp32 parity path keeps the product); the gradients reach ``weight`` and ``bias``
+    through autograd of the two small sums."""
+    L.require_cuda(x, weight, bias)
+    s = _RowDot.apply(x if x.is_contiguous() else x.contiguous(), weight.sum(0))
+    return s if bias is None else s + bias.sum()
+
+
 # ----------------------------------------------------------------------------- GCNConv
 def _hidden_bf16_ok(n_rows, d):
     """bf16 mode keeps HIDDEN layer outputs (everything between two conv layers) as bf16 tables: each is only ever

@@ -330,6 +330,16 @@ int bkg_unpair_rows_bf16(const void* g, const int64_t* inv, void* out, int64_t n
 int64_t bkg_colsum_workspace_floats(int64_t n, int32_t d);
 int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, float* workspace, float* out,
                    void* stream);
+/* ---- a Linear whose outputs are summed over the features (GGD's head, biomedkg/model/gcl.py:86-90:
+ *      `mlp[-1](h).sum(1)` = h . (sum_j W[j, :]) + sum_j b_j): out[i] = sum_c x[i, c] * w[c]; its backward pieces
+ *      d h = g (x) w (bkg_scaled_rows, fp32 or bf16 table out) and d w = sum_i g[i] * x[i, :] (column sums with row
+ *      weights; workspace as for bkg_colsum_f32). */
+int bkg_rowdot_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, const float* w, float* out,
+                   void* stream);
+int bkg_scaled_rows(const float* g, const float* w, int64_t n, int32_t d, void* out, int32_t out_is_bf16, int64_t ldo,
+                    void* stream);
+int bkg_colsum_weighted_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, const float* row_w,
+                            float* workspace, float* out, void* stream);
 /* out = dout * scale where gate > 0, 0 elsewhere (the backward of the encoder's dropout(relu(.)), read off the saved
  * output: biomedkg/model/encoder.py:50-59); contiguous fp32 tables */
 int bkg_gate_f32(const float* dout, const float* gate, float scale, int64_t numel, float* out, void* stream);

@@ -402,6 +402,37 @@ def test_ggd_two_views_side_by_side_equal_two_passes():
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.model.parameters())
 
 
+@pytest.mark.parametrize("n,d", [(1, 256), (5, 128), (4097, 256), (70_001, 256), (3000, 768)])
+@pytest.mark.parametrize("x_bf16", [False, True])
+def test_linear_rowsum_is_the_summed_linear(n, d, x_bf16):
+    """GGD's head (reference gcl.py:86-90, ``mlp[-1](h).sum(1)``) as one dot product per row: value and every gradient
+    against the fp64 Linear + sum on the same operand values."""
+    from biomedkg_amd import ops
+    torch.manual_seed(n + d)
+    x = torch.randn(n, d, device=DEV)
+    x = (x.bfloat16() if x_bf16 else x).requires_grad_()
+    w = (torch.randn(d, d, device=DEV) * 0.1).requires_grad_()
+    b = torch.randn(d, device=DEV).requires_grad_()
+    assert ops.rowsum_linear_ok(x, w)
+    s = ops.linear_rowsum(x, w, b)
+    g = torch.randn(n, device=DEV)
+    s.backward(g)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    ref = torch.nn.functional.linear(xd, wd, bd).sum(1)
+    ref.backward(g.double())
+    torch.testing.assert_close(s.double(), ref.detach(), rtol=1e-5, atol=1e-4)
+    tol = dict(rtol=2 ** -7, atol=1e-3) if x_bf16 else dict(rtol=1e-5, atol=1e-5)
+    assert x.grad.dtype == x.dtype
+    torch.testing.assert_close(x.grad.double(), xd.grad, **tol)
+    torch.testing.assert_close(w.grad.double(), wd.grad, rtol=1e-4, atol=1e-4 * max(1.0, n ** 0.5))
+    torch.testing.assert_close(b.grad.double(), bd.grad, rtol=1e-5, atol=1e-4)
+    # run-to-run: fixed-order reductions everywhere
+    x.grad = w.grad = b.grad = None
+    s2 = ops.linear_rowsum(x, w, b)
+    s2.backward(g)
+    assert torch.equal(s2, s)
+
+
 def test_pair_rows_and_its_gradient():
     from biomedkg_amd import ops
     torch.manual_seed(2)
