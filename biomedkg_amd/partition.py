@@ -413,7 +413,11 @@ def ggd_loss_partitioned(ggd, x_local, pg: PartitionedGraph, backend, perm, drop
             hh = h.view(2 * n_loc, h.size(1) // 2)
             for layer in ggd.mlp[:-1]:
                 hh = ops.linear(hh, layer.weight, layer.bias, act=ops.ACT_RELU)
-            s = ops.linear(hh, ggd.mlp[-1].weight, ggd.mlp[-1].bias).sum(1).view(n_loc, 2)
+            head = ggd.mlp[-1]
+            if ops.rowsum_linear_ok(hh, head.weight):          # (W h + b).sum(1) = h . W.sum(0) + b.sum(), as model/gcl.py
+                s = ops.linear_rowsum(hh, head.weight, head.bias).view(n_loc, 2)
+            else:
+                s = ops.linear(hh, head.weight, head.bias).sum(1).view(n_loc, 2)
             pred = torch.cat([s[:, 0], s[:, 1]])
             gt = torch.cat([torch.ones_like(s[:, 0]), torch.zeros_like(s[:, 1])])
             return torch.nn.functional.binary_cross_entropy_with_logits(pred, gt, reduction="sum") * (part.world / total)
