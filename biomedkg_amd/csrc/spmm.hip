@@ -30,6 +30,7 @@ struct SpmmEpilogue {
   const float* bias;        // [d] or null
   const float* addend;      // [n_rows, ld_add] or null: added before bias / activation
   int64_t ld_add;
+  int add_bf16;             // 1: `addend` is a bf16 table (a product that only this epilogue reads)
   int relu;                 // 0/1
   const uint8_t* keep;      // [n_rows, d] explicit dropout keep mask or null
   float drop_p;             // used when keep == null and drop_p > 0: in-kernel Philox mask
@@ -147,8 +148,14 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
       const int c = EPL * (lig + v * LPR) + 4 * q;
       float4 a = acc[v * Q + q];
       if (ep.addend) {
-        const float4 t = *reinterpret_cast<const float4*>(ep.addend + (int64_t)row * ep.ld_add + c);
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        if (ep.add_bf16) {
+          const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(ep.addend) + (int64_t)row * ep.ld_add + c);
+          a.x += __uint_as_float(t.x << 16); a.y += __uint_as_float(t.x & 0xffff0000u);
+          a.z += __uint_as_float(t.y << 16); a.w += __uint_as_float(t.y & 0xffff0000u);
+        } else {
+          const float4 t = *reinterpret_cast<const float4*>(ep.addend + (int64_t)row * ep.ld_add + c);
+          a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
       }
       if (ep.bias) {
         const float4 b = *reinterpret_cast<const float4*>(ep.bias + c);
@@ -299,7 +306,9 @@ __global__ __launch_bounds__(256) void spmm_csr_f32_generic_kernel(const int32_t
     float a = 0.f;
     for (int e = start; e < end; ++e) a = fmaf(w ? w[e] : 1.0f, x[(int64_t)col[e] * ldx + c], a);
     if (ep.self_w) a = fmaf(ep.self_w[row], x[(int64_t)row * ldx + c], a);
-    if (ep.addend) a += ep.addend[(int64_t)row * ep.ld_add + c];
+    if (ep.addend)
+      a += ep.add_bf16 ? (float)reinterpret_cast<const __bf16*>(ep.addend)[(int64_t)row * ep.ld_add + c]
+                       : ep.addend[(int64_t)row * ep.ld_add + c];
     if (ep.bias) a += ep.bias[c];
     if (ep.relu) a = fmaxf(a, 0.f);
     if (ep.keep) {
@@ -356,7 +365,8 @@ static bool dispatch_spmm(int d, const SpmmArgs<T>& a) {
 
 extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const void* x,
                                 int32_t x_is_bf16, int64_t ldx, void* out_, int32_t out_is_bf16, int64_t ldo,
-                                int64_t n_rows, int32_t d, const float* self_w, const float* addend, int64_t ld_add, const float* bias,
+                                int64_t n_rows, int32_t d, const float* self_w, const void* addend, int32_t addend_is_bf16,
+                                int64_t ld_add, const float* bias,
                                 int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
                                 uint32_t stream_id, const bkg_rowsplit* split, float* partials, void* stream) {
   using namespace bkg;
@@ -365,7 +375,8 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   BKG_ARG(!split || partials, "bkg_spmm_csr_f32: row splitting needs a partials buffer");
   if (n_rows == 0) return 0;
   float* out = reinterpret_cast<float*>(out_);
-  SpmmEpilogue ep{self_w, bias, addend, ld_add, relu, keep, drop_p, seed, stream_id, out_is_bf16 ? 1 : 0, rng_epoch_ptr()};
+  SpmmEpilogue ep{self_w, bias, reinterpret_cast<const float*>(addend), ld_add, addend_is_bf16 ? 1 : 0, relu, keep, drop_p, seed,
+                  stream_id, out_is_bf16 ? 1 : 0, rng_epoch_ptr()};
   const int epl = x_is_bf16 ? 8 : 4;
   const bool vec_ok = (d % epl == 0) && (ldx % epl == 0) && (ldo % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % 16 == 0) &&
                       (!bias || ((uintptr_t)bias % 16 == 0)) && (!keep || ((uintptr_t)keep % 4 == 0)) &&

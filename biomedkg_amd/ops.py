@@ -322,15 +322,18 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
             keep = drop.keep.to(torch.uint8).contiguous()
             if keep.shape != out.shape:
                 raise ValueError("dropout keep mask shape mismatch")
-    if addend is not None:
-        addend = _f32c(addend)
+    if addend is not None:       # fp32, or a bf16 table (a product only this epilogue reads: RGCNConv's root term)
+        addend = (addend if addend.is_contiguous() else addend.contiguous()) if addend.dtype == torch.bfloat16 else _f32c(addend)
+        if addend.dtype == torch.bfloat16 and (addend.stride(0) % 4 or addend.data_ptr() % 8):
+            addend = addend.float()
     timing = KERNEL_TIMERS is not None and tag is not None
     if timing:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     partials = split.partials(d, x.device) if split is not None else None
     L.call("bkg_spmm_csr_f32", L.ptr(rowptr), L.ptr(col), L.ptr(w), L.ptr(x), is_bf16, x.stride(0), L.ptr(out),
-           int(out_dtype == torch.bfloat16), out.stride(0), n_rows, d, L.ptr(self_w), L.ptr(addend), addend.stride(0) if addend is not None else 0,
+           int(out_dtype == torch.bfloat16), out.stride(0), n_rows, d, L.ptr(self_w), L.ptr(addend),
+           int(addend is not None and addend.dtype == torch.bfloat16), addend.stride(0) if addend is not None else 0,
            L.ptr(bias), int(relu), L.ptr(keep), p, seed, sid, L.sref(split.c if split is not None else None),
            L.ptr(partials), L.stream())
     if timing:
@@ -719,7 +722,10 @@ class _RgcnConv(torch.autograd.Function):
             pending = None
         else:
             pending = comm.all_gather_begin(_table(x))                               # crosses xGMI ...
-        xr = gemm(x, root)                                                            # ... under the [N, out] root term
+        # ... under the [N, out] root term: a bf16 table where the layer's own output is one (a hidden layer of bf16 mode:
+        # every value of the sum is rounded to bf16 right after it), fp32 for the encoder's output layer
+        xr16 = (hidden and _hidden_bf16_ok(n, d_out) and x.dtype == torch.bfloat16 and _xw_ok(x, n, d_out, d_in))
+        xr = gemm(x, root, out_dtype=torch.bfloat16) if xr16 else gemm(x, root)
         if pending is not None:
             table = comm.all_gather_end(pending)
         h16 = bf16_storage() and _bf16_ok(d_in) and _bf16_operand_ok(rg.num_segments, d_out, d_in)
@@ -798,7 +804,9 @@ class _RgcnConv(torch.autograd.Function):
             c = rg.src_csr
             x16 = x.dtype == torch.bfloat16 and _bf16_ok(d_in)
             if comm is None:
-                dx_root = gemm(dout, root, trans_b=True)                              # [N, in]
+                # [N, in]; bf16 where dx itself leaves as a bf16 table
+                root16 = x16 and dout.dtype == torch.bfloat16 and _xw_ok(dout, n, d_in, d_out)
+                dx_root = gemm(dout, root, trans_b=True, out_dtype=torch.bfloat16 if root16 else torch.float32)
                 dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), n_table, addend=dx_root, split=c.split,
                           out_dtype=torch.bfloat16 if x16 else torch.float32)
             else:

@@ -104,7 +104,8 @@ int bkg_gate_cast_bf16(const void* src, int32_t src_is_bf16, const void* gate, i
                        void* dst, int64_t n, void* stream);
 int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const void* x, int32_t x_is_bf16,
                      int64_t ldx, void* out /* fp32, or bf16 when out_is_bf16: a result only GEMMs / gathers read */,
-                     int32_t out_is_bf16, int64_t ldo, int64_t n_rows, int32_t d, const float* self_w, const float* addend,
+                     int32_t out_is_bf16, int64_t ldo, int64_t n_rows, int32_t d, const float* self_w,
+                     const void* addend /* fp32, or bf16 when addend_is_bf16: RGCNConv's root term */, int32_t addend_is_bf16,
                      int64_t ld_add, const float* bias, int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
                      uint32_t stream_id, const bkg_rowsplit* split, float* partials, void* stream);
 

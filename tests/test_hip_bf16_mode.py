@@ -235,6 +235,25 @@ def test_spmm_bf16_result_is_the_rounded_fp32_result():
         assert torch.equal(got, ref.bfloat16())
 
 
+@pytest.mark.parametrize("d", [64, 256])
+def test_spmm_bf16_addend_equals_its_fp32_image(d):
+    """RGCNConv's root term may reach the segment sum as a bf16 table: same result as the fp32 table of those values,
+    on the vector path (row splitting included) and for both result types."""
+    from biomedkg_amd import graph as G, ops
+    n, e = 5000, 150_000
+    g = torch.Generator().manual_seed(8)
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    ei[1, : e // 3] = 7                                   # one long row: split path + fix-up
+    c = G.Graph(ei, n).by_dst
+    x = torch.randn(n, d, device=DEV).bfloat16()
+    add16 = torch.randn(n, d, device=DEV).bfloat16()
+    bias = torch.randn(d, device=DEV)
+    for odt in (torch.float32, torch.bfloat16):
+        a = ops.spmm(c.rowptr, c.col, None, x, n, addend=add16, bias=bias, relu=True, split=c.split, out_dtype=odt)
+        b = ops.spmm(c.rowptr, c.col, None, x, n, addend=add16.float(), bias=bias, relu=True, split=c.split, out_dtype=odt)
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("a16,b16", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 20_000), (256, 768, 9_001), (96, 40, 5_000)])
 def test_weight_gradient_products_with_bf16_tables(a16, b16, m, n, k):
