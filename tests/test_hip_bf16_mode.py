@@ -382,6 +382,45 @@ def test_bf16_training_follows_the_fp32_trajectory():
     assert float(((a - b).abs() / a.abs()).max()) < 2e-2, (curves["fp32"][-3:], curves["bf16"][-3:])
 
 
+def test_ggd_bf16_training_follows_the_fp32_trajectory():
+    """20 Adam steps of the GGD module on a graph large enough for the side-by-side path (both views through every
+    kernel, the head as a dot product per row): the bf16 run's loss curve stays within 2 % of the exact-fp32 run, which
+    keeps the reference's Linear + sum (augmentation and dropout off: the comparison is between arithmetic paths)."""
+    from biomedkg_amd import ops, rand as R
+    from biomedkg_amd.gcl_module import GGDModule
+    n, e = 6000, 100_000
+    g = torch.Generator().manual_seed(12)
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    x = torch.randn(n, 768, generator=g).to(DEV)
+    curves = {}
+    ops.set_deterministic(True)
+    try:
+        for mode in ("fp32", "bf16"):
+            ops.set_matmul_precision(mode)
+            torch.manual_seed(0)
+            m = GGDModule(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="none").to(DEV).train()
+            m.model.encoder.drop_out = False
+            m.model.p = 0.0
+            opt = torch.optim.Adam(m.model.parameters(), lr=1e-3)
+            losses = []
+            with R.use(R.DeviceRand(seed=5)):
+                if mode == "bf16":
+                    assert m.model._views_ok(ops.cached_bf16(x), R.current())
+                for _ in range(20):
+                    opt.zero_grad(set_to_none=True)
+                    loss = m.calculate_loss(x, ei)
+                    loss.backward()
+                    opt.step()
+                    losses.append(float(loss.detach()))
+            curves[mode] = losses
+    finally:
+        ops.set_deterministic(False)
+        ops.set_matmul_precision("bf16")
+    a, b = torch.tensor(curves["fp32"]), torch.tensor(curves["bf16"])
+    assert torch.isfinite(b).all() and b[-1] < b[0]
+    assert float(((a - b).abs() / a.abs()).max()) < 2e-2, (curves["fp32"][-3:], curves["bf16"][-3:])
+
+
 def test_ggd_two_views_side_by_side_equal_two_passes():
     """GGD's positive + corrupted pass through every kernel at once (shared first-layer product, [N, 2h] gather rows,
     [2N, h] products) against the two separate encoder passes: same loss and parameter gradients (bf16 rounding)."""
