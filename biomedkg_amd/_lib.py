@@ -105,6 +105,7 @@ SIGNATURES = {
     "bkg_gate_f32": (I32, [P, P, F32, I64, P, P]),
     "bkg_colsum_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),
     "bkg_colsum_weighted_f32": (I32, [P, I32, I64, I64, I32, P, P, P, P]),
+    "bkg_gate_cast_colsum_bf16": (I32, [P, I32, P, I32, F32, P, I64, I32, P, P, P]),
     "bkg_rowdot_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),
     "bkg_scaled_rows": (I32, [P, P, I64, I32, P, I32, I64, P]),
     # negsample.hip

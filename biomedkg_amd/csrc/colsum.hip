@@ -59,6 +59,85 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   }
 }
 
+// The gated bf16 table of a layer's output gradient (spmm.hip cast_bf16_kernel: bf16(gate > 0 ? s * x : 0)) AND its
+// column sums (the bias gradient) in one pass: same blocking and addition order as colsum_partial_kernel<__bf16> over the
+// finished table, so the sums are bit-identical to the two-pass form -- minus one read of the table.
+template <typename T> struct Load8;
+template <> struct Load8<float> {
+  static __device__ __forceinline__ void get(const float* p, float (&a)[8]) {
+    const float4 u = *reinterpret_cast<const float4*>(p), v = *reinterpret_cast<const float4*>(p + 4);
+    a[0] = u.x; a[1] = u.y; a[2] = u.z; a[3] = u.w; a[4] = v.x; a[5] = v.y; a[6] = v.z; a[7] = v.w;
+  }
+};
+template <> struct Load8<__bf16> {
+  static __device__ __forceinline__ void get(const __bf16* p, float (&a)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    a[0] = __uint_as_float(v.x << 16); a[1] = __uint_as_float(v.x & 0xffff0000u);
+    a[2] = __uint_as_float(v.y << 16); a[3] = __uint_as_float(v.y & 0xffff0000u);
+    a[4] = __uint_as_float(v.z << 16); a[5] = __uint_as_float(v.z & 0xffff0000u);
+    a[6] = __uint_as_float(v.w << 16); a[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+};
+
+template <typename ST, typename GT>
+__global__ __launch_bounds__(256) void gate_cast_colsum_kernel(const ST* __restrict__ src, const GT* __restrict__ gate,
+                                                               float scale, __bf16* __restrict__ dst, int64_t n, int d,
+                                                               int64_t rows_per_block, float* __restrict__ partial) {
+  __shared__ float4 red[256 * 2];
+  const int ppr = d / 8, rpb = 256 / ppr;
+  const int piece = threadIdx.x % ppr, slot = threadIdx.x / ppr;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, n);
+  float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  if (slot < rpb) {
+    constexpr int U = 4;
+    auto one = [&](const float (&x)[8], const float (&g)[8], int64_t r) {
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      bf16x8 o;
+      float back[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = gate ? (g[e] > 0.f ? x[e] * scale : 0.f) : x[e];
+        o[e] = (__bf16)v;
+        back[e] = (float)o[e];
+      }
+      *reinterpret_cast<bf16x8*>(dst + r * d + piece * 8) = o;
+      acc[0].x += back[0]; acc[0].y += back[1]; acc[0].z += back[2]; acc[0].w += back[3];
+      acc[1].x += back[4]; acc[1].y += back[5]; acc[1].z += back[6]; acc[1].w += back[7];
+    };
+    int64_t r = r0 + slot;
+    for (; r + (U - 1) * rpb < r1; r += U * rpb) {
+      float x[U][8], g[U][8];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Load8<ST>::get(src + (r + (int64_t)u * rpb) * d + piece * 8, x[u]);
+        if (gate) Load8<GT>::get(gate + (r + (int64_t)u * rpb) * d + piece * 8, g[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) one(x[u], g[u], r + (int64_t)u * rpb);
+    }
+    for (; r < r1; r += rpb) {
+      float x[8], g[8];
+      Load8<ST>::get(src + r * d + piece * 8, x);
+      if (gate) Load8<GT>::get(gate + r * d + piece * 8, g);
+      one(x, g, r);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) red[threadIdx.x * 2 + q] = acc[q];
+  __syncthreads();
+  if (slot == 0) {
+    for (int s = 1; s < rpb; ++s)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 v = red[(s * ppr + piece) * 2 + q];
+        acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w;
+      }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * d + piece * 8 + 4 * q) = acc[q];
+  }
+}
+
 // block = 8 row groups x 32 columns; group g adds partial rows g, g + 8, ... (8 loads in flight), then the groups are
 // added in group order through LDS
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int n_blocks, int d,
@@ -182,4 +261,27 @@ extern "C" int bkg_colsum_weighted_f32(const void* x, int32_t x_is_bf16, int64_t
                                        float* workspace, float* out, void* stream) {
   BKG_ARG(row_w != nullptr, "bkg_colsum_weighted_f32: row weights missing");
   return colsum_launch(x, x_is_bf16, ldx, n, d, row_w, workspace, out, stream, "bkg_colsum_weighted_f32");
+}
+
+// dst = bf16(gate > 0 ? src * gate_scale : 0) (gate may be NULL: a plain cast) over a contiguous [n, d] table, and
+// out[c] = sum_i dst[i, c] -- the bias gradient of the layer whose output gradient this is.  n > 4096 rows (fewer: the
+// two-pass form); workspace as for bkg_colsum_f32.
+extern "C" int bkg_gate_cast_colsum_bf16(const void* src, int32_t src_is_bf16, const void* gate, int32_t gate_is_bf16,
+                                         float gate_scale, void* dst, int64_t n, int32_t d, float* workspace, float* out,
+                                         void* stream) {
+  BKG_ARG(n > 4096 && d > 0 && d % 8 == 0 && d / 8 <= 256, "bkg_gate_cast_colsum_bf16: n > 4096 rows, d a multiple of 8, <= 2048");
+  BKG_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && (!gate || (uintptr_t)gate % 16 == 0) &&
+              (uintptr_t)workspace % 16 == 0,
+          "bkg_gate_cast_colsum_bf16: 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_blocks = (int)(bkg_colsum_workspace_floats(n, d) / d);
+  const int64_t rpb = (n + n_blocks - 1) / n_blocks;
+#define BKG_GCC(ST, GT)                                                                                               \
+  hipLaunchKernelGGL((gate_cast_colsum_kernel<ST, GT>), dim3(n_blocks), dim3(256), 0, s, (const ST*)src, (const GT*)gate, \
+                     gate_scale, (__bf16*)dst, n, d, rpb, workspace)
+  if (src_is_bf16) { if (gate_is_bf16) BKG_GCC(__bf16, __bf16); else BKG_GCC(__bf16, float); }
+  else { if (gate_is_bf16) BKG_GCC(float, __bf16); else BKG_GCC(float, float); }
+#undef BKG_GCC
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, s, workspace, n_blocks, d, out);
+  return check_launch("bkg_gate_cast_colsum_bf16");
 }

@@ -277,6 +277,26 @@ def to_bf16(x, gate=None, gate_scale=1.0):
     return out
 
 
+def to_bf16_colsum(x, gate=None, gate_scale=1.0):
+    """``(to_bf16(x, gate, gate_scale), its column sums)`` in ONE pass over a tall contiguous table -- the gated output
+    gradient of a layer and its bias gradient (bit-identical to ``colsum`` over the finished table).  The sums are
+    ``None`` where no cast runs at all (``x`` already bf16, no gate) or the shape is out of the kernel's range: the
+    caller then sums the table itself."""
+    L.require_cuda(x, gate)
+    if x.dtype == torch.bfloat16 and gate is None:
+        return (x if x.is_contiguous() else x.contiguous()), None
+    n, d = (x.size(0), x.size(1)) if x.dim() == 2 else (0, 0)
+    if (n <= 4096 or d % 8 or d // 8 > 256 or not x.is_contiguous() or (gate is not None and not gate.is_contiguous())
+            or x.dtype not in (torch.float32, torch.bfloat16) or (gate is not None and gate.dtype not in (torch.float32, torch.bfloat16))):
+        return to_bf16(x, gate, gate_scale), None
+    out = torch.empty(n, d, dtype=torch.bfloat16, device=x.device)
+    ws = torch.empty(L.lib().bkg_colsum_workspace_floats(n, d), dtype=torch.float32, device=x.device)
+    cs = torch.empty(d, dtype=torch.float32, device=x.device)
+    L.call("bkg_gate_cast_colsum_bf16", L.ptr(x), int(x.dtype == torch.bfloat16), L.ptr(gate),
+           int(gate is not None and gate.dtype == torch.bfloat16), gate_scale, L.ptr(out), n, d, L.ptr(ws), L.ptr(cs), L.stream())
+    return out, cs
+
+
 def masked_bf16(x, p, seed, stream_id):
     """``bf16(x * (rand >= p))`` -- the GCL feature-masking augmentation fused with the bf16 table cast."""
     L.require_cuda(x)
@@ -527,9 +547,13 @@ class _GcnConv(torch.autograd.Function):
         g, gw = ctx.graph, ctx.gw
         n_rows, n_table, comm = _dims(g)
         dout = dout if dout.is_contiguous() else dout.contiguous()
+        db = None
         if bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(dout.size(1)):
-            # gate + bf16 gather table in one pass over dOut (no fp32 gated copy is ever written)
-            dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
+            # gate + bf16 gather table (+ the bias gradient) in one pass over dOut (no fp32 gated copy is ever written)
+            if ctx.needs_input_grad[2]:
+                dout, db = to_bf16_colsum(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
+            else:
+                dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
         elif ctx.gated:
             dout, out = _as_f32(dout), _as_f32(out)
             dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * ctx.keep * ctx.scale
@@ -559,7 +583,8 @@ class _GcnConv(torch.autograd.Function):
                 dw = gemm(dxw, x, trans_a=True)
         else:
             dw = None
-        db = colsum(dout) if ctx.needs_input_grad[2] else None
+        if db is None and ctx.needs_input_grad[2]:
+            db = colsum(dout)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -666,8 +691,12 @@ class _GcnConvViews(torch.autograd.Function):
         g, gw, v = ctx.graph, ctx.gw, ctx.views
         n, n_table, comm = _dims(g)
         dout = dout if dout.is_contiguous() else dout.contiguous()
+        cs = None
         if ctx.relu or not ctx.gated:
-            dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
+            if ctx.needs_input_grad[2]:
+                dout, cs = to_bf16_colsum(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
+            else:
+                dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
         else:
             dout = to_bf16(_as_f32(dout) * ctx.keep * ctx.scale)
         c = g.by_src
@@ -675,7 +704,9 @@ class _GcnConvViews(torch.autograd.Function):
         dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split,
                    out_dtype=torch.float32 if exchange else torch.bfloat16)
         d_out = dout.size(1) // v
-        db = colsum(dout.view(v * n, d_out)) if ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.needs_input_grad[2]:        # the views share the bias: their column sums added
+            db = cs.view(v, d_out).sum(0) if cs is not None else colsum(dout.view(v * n, d_out))
         if ctx.is_table:
             return dxw.to(ctx.table_dtype), None, db, None, None, None, None, None, None, None
         if exchange:
@@ -752,10 +783,14 @@ class _RgcnConv(torch.autograd.Function):
         n, n_table, comm = _dims(rg)
         d_in, d_out = weight.size(1), weight.size(2)
         dout = dout if dout.is_contiguous() else dout.contiguous()
+        db0 = None
         if (bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(d_out) and n >= 4096
                 and _bf16_operand_ok(n, d_in, d_out)):
             # gated dOut as one bf16 table: gather table of dY, operand of the root products, source of db
-            dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
+            if ctx.needs_input_grad[3]:
+                dout, db0 = to_bf16_colsum(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
+            else:
+                dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
         else:
             dout = _as_f32(dout)
             if ctx.gated:
@@ -781,7 +816,7 @@ class _RgcnConv(torch.autograd.Function):
                     droot = gemm(_as_f32(x), _as_f32(dout), trans_a=True)
                 else:
                     droot = gemm(x, dout, trans_a=True)
-            db = colsum(dout) if ctx.needs_input_grad[3] else None
+            db = (db0 if db0 is not None else colsum(dout)) if ctx.needs_input_grad[3] else None
             return dweight, droot, db
         # mini-batches: the three parameter gradients are a chain of small launches independent of the input-gradient
         # chain -- run them as a parallel branch (side stream; a parallel branch of a captured graph)

@@ -331,6 +331,10 @@ int bkg_unpair_rows_bf16(const void* g, const int64_t* inv, void* out, int64_t n
 int64_t bkg_colsum_workspace_floats(int64_t n, int32_t d);
 int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int32_t d, float* workspace, float* out,
                    void* stream);
+/* the gated bf16 table of bkg_gate_cast_bf16 over a contiguous [n, d] table (n > 4096) together with its column sums
+ * (the bias gradient of the layer whose output gradient it is): one pass, same sums as bkg_colsum_f32 over the result */
+int bkg_gate_cast_colsum_bf16(const void* src, int32_t src_is_bf16, const void* gate, int32_t gate_is_bf16, float gate_scale,
+                              void* dst, int64_t n, int32_t d, float* workspace, float* out, void* stream);
 /* ---- a Linear whose outputs are summed over the features (GGD's head, biomedkg/model/gcl.py:86-90:
  *      `mlp[-1](h).sum(1)` = h . (sum_j W[j, :]) + sum_j b_j): out[i] = sum_c x[i, c] * w[c]; its backward pieces
  *      d h = g (x) w (bkg_scaled_rows, fp32 or bf16 table out) and d w = sum_i g[i] * x[i, :] (column sums with row

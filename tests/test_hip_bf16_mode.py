@@ -235,6 +235,29 @@ def test_spmm_bf16_result_is_the_rounded_fp32_result():
         assert torch.equal(got, ref.bfloat16())
 
 
+@pytest.mark.parametrize("n,d", [(4097, 64), (5000, 256), (70_001, 512)])
+@pytest.mark.parametrize("src16", [False, True])
+@pytest.mark.parametrize("gate", ["none", "fp32", "bf16"])
+def test_gated_table_and_its_column_sums_in_one_pass(n, d, src16, gate):
+    """The gated bf16 output-gradient table of a layer and its bias gradient from one kernel: bit-identical to the
+    two-pass form (gate + cast, then column sums of the finished table)."""
+    from biomedkg_amd import ops
+    torch.manual_seed(n + d)
+    x = torch.randn(n, d, device=DEV)
+    x = x.bfloat16() if src16 else x
+    g = None if gate == "none" else torch.randn(n, d, device=DEV)
+    if gate == "bf16":
+        g = g.bfloat16()
+    table, cs = ops.to_bf16_colsum(x, gate=g, gate_scale=1.25)
+    want = ops.to_bf16(x, gate=g, gate_scale=1.25)
+    assert torch.equal(table, want)
+    if src16 and g is None:
+        assert cs is None                      # nothing to cast: the caller sums the table it already has
+    else:
+        assert torch.equal(cs, ops.colsum(want))
+        torch.testing.assert_close(cs.double(), want.double().sum(0), rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("d", [64, 256])
 def test_spmm_bf16_addend_equals_its_fp32_image(d):
     """RGCNConv's root term may reach the segment sum as a bf16 table: same result as the fp32 table of those values,
