@@ -259,6 +259,15 @@ static void launch_gemm(bool ta, bool tb, const float* A, int64_t lda, const flo
 
 }  // namespace bkg
 
+namespace bkg {   // gemm_tn32.hip: exact-fp32 weight gradients over row-major [K, M] / [K, N] operands, tile-aligned output
+bool gemm_tn32_ok(int64_t M, int64_t N, const void* A, int64_t lda, const void* B, int64_t ldb);
+void launch_gemm_tn32_splitk(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                             int64_t ldc, int kchunk, int64_t nsplit, const GemmEpilogue& ep, float* det, hipStream_t s);
+void launch_gemm_tn32_grouped(int64_t n_chunks, int64_t M, int64_t N, const float* A, int64_t lda, const float* B, int64_t ldb,
+                              float* C, int64_t ldc, int64_t strideC, const int32_t* group_ptr, int G, int kchunk,
+                              const GemmEpilogue& ep, float* det, hipStream_t s);
+}  // namespace bkg
+
 using namespace bkg;
 
 extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, float alpha,
@@ -280,6 +289,20 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     // bf16 operands: 128x128 tiles whenever the output allows -- the product is bound by operand traffic and
     // every strip is then re-read by half as many tiles (measured 0.21 -> 0.14 ms at 256x256x130k; the split-K
     // grid supplies the parallelism).  fp32 operands are MFMA-bound there and prefer more, smaller tiles.
+    if (precision == 0 && trans_a && !trans_b && K >= 4096 && gemm_tn32_ok(M, N, A, lda, B, ldb)) {
+      // exact-fp32 weight gradient over row-major operands: the LDS-DMA ring form (gemm_tn32.hip), two blocks per CU
+      const int64_t t128 = (M / 128) * (N / 128);
+      int64_t ns = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 512 / t128));
+      const int kc = (int)(((K + ns - 1) / ns + 63) / 64 * 64);
+      ns = (K + kc - 1) / kc;
+      ep.atomic = 1;
+      float* det32 = nullptr;
+      BKG_DET_SLABS(det32, ep, ns, M, N, "bkg_gemm_f32");
+      if (!det32) fill_zero_rows_f32(C, ldc, M, N, s);
+      launch_gemm_tn32_splitk(M, N, K, A, lda, B, ldb, C, ldc, kc, ns, ep, det32, s);
+      if (det32) splitk_reduce(det32, C, ldc, 0, (int)M, (int)N, nullptr, 1, kc, (int)ns, s);
+      return check_launch("bkg_gemm_f32(tn32)");
+    }
     const bool big = (precision == 1 && M >= 128 && N >= 128) || tiles64 >= 64;
     const int64_t tiles = big ? ((M + 127) / 128) * ((N + 127) / 128) : tiles64;
     int64_t nsplit = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, (precision ? 768 : 2048) / tiles));   // bf16: ~3 blocks per CU = the tile's occupancy
@@ -363,6 +386,11 @@ extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, 
   const int KCHUNK = bkg_gemm_grouped_k_chunk(rows_total, M, N, precision);   // rows per block
   float* det = nullptr;
   BKG_DET_SLABS(det, ep, ceil_div(rows_total, KCHUNK) + G, M, N, "bkg_gemm_grouped_k_f32");
+  if (precision == 0 && rows_total >= 4096 && gemm_tn32_ok(M, N, A, lda, B, ldb)) {
+    launch_gemm_tn32_grouped(ceil_div(rows_total, KCHUNK) + G, M, N, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, KCHUNK, ep, det, s);
+    if (det) splitk_reduce(det, C, ldc, strideC, (int)M, (int)N, group_ptr, G, KCHUNK, 0, s);
+    return check_launch("bkg_gemm_grouped_k_f32(tn32)");
+  }
   dim3 grid(xcd_grid(ceil_div(rows_total, KCHUNK) + G, ceil_div(M, BM) * ceil_div(N, BN))), block(256);
   if (precision) hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<1, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep, det);
   else hipLaunchKernelGGL((gemm_f32_grouped_k_kernel<0, BM, BN>), grid, block, 0, s, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, (int)M, (int)N, KCHUNK, ep, det);
