@@ -259,6 +259,12 @@ static void launch_gemm(bool ta, bool tb, const float* A, int64_t lda, const flo
 
 }  // namespace bkg
 
+namespace bkg {   // gemm_xw32.hip: exact-fp32 tall products with K = N = 256, the weight in registers
+bool gemm_xw32_ok(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, bool plain_or_bias_act);
+void launch_gemm_xw32(int64_t M, const float* A, int64_t lda, const float* W, int64_t ldw, int trans_w, float* C, int64_t ldc,
+                      const GemmEpilogue& ep, hipStream_t s);
+}  // namespace bkg
+
 namespace bkg {   // gemm_tn32.hip: exact-fp32 weight gradients over row-major [K, M] / [K, N] operands, tile-aligned output
 bool gemm_tn32_ok(int64_t M, int64_t N, const void* A, int64_t lda, const void* B, int64_t ldb);
 void launch_gemm_tn32_splitk(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
@@ -329,6 +335,10 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
 #undef BKG_SPLITK
     if (det) splitk_reduce(det, C, ldc, 0, (int)M, (int)N, nullptr, 1, kchunk, (int)nsplit, s);
     return check_launch("bkg_gemm_f32(split-K)");
+  }
+  if (precision == 0 && !trans_a && gemm_xw32_ok(M, N, K, A, lda, !gate && beta == 0.f)) {
+    launch_gemm_xw32(M, A, lda, B, ldb, trans_b, C, ldc, ep, s);
+    return check_launch("bkg_gemm_f32(xw32)");
   }
   // big tiles once they fill the chip, small tiles otherwise
   const bool big_tiles = (M / 128) * ((N + 127) / 128) >= 256;

@@ -60,3 +60,28 @@ for det in (False, True):
     assert all(v < 1e-5 for v in err.values()), err
     print(json.dumps({"deterministic": det, "rel_err": err, "times": times(pack)}))
 ops.set_deterministic(False)
+
+# ---- exact-fp32 activation x weight products with K = N = 256 (gemm_xw32.hip)
+torch.manual_seed(1)
+w, bias = torch.randn(256, 256, device=dev) * 0.1, torch.randn(256, device=dev)
+worst = 0.0
+for m in (256, 257, 4097, 130_000, 130_001):
+    a = torch.randn(m, 256, device=dev)
+    for tb in (False, True):
+        for kw in ({}, {"bias": bias, "act": ops.ACT_RELU, "alpha": 0.5}, {"act": ops.ACT_ELU}):
+            out = ops.gemm(a, w, trans_b=tb, **kw)
+            ref = (a.double() @ (w.double().t() if tb else w.double())) * kw.get("alpha", 1.0)
+            ref = ref + (kw["bias"].double() if "bias" in kw else 0.0)
+            if kw.get("act") == ops.ACT_RELU:
+                ref = ref.clamp_min(0)
+            elif kw.get("act") == ops.ACT_ELU:
+                ref = torch.where(ref > 0, ref, torch.expm1(ref))
+            worst = max(worst, float((out.double() - ref).abs().max() / ref.abs().max()))
+assert worst < 1e-5, worst
+r = {"rel_err": worst}
+for m in (130_000, 260_000):
+    a = torch.randn(m, 256, device=dev)
+    for tb in (False, True):
+        ms = timeit(lambda: ops.gemm(a, w, trans_b=tb))
+        r[f"M={m} tb={tb}"] = {"us": round(ms * 1e3, 1), "TFLOPs": round(2.0 * m * 65536 / ms / 1e9, 1)}
+print(json.dumps({"xw32": r}))
