@@ -414,7 +414,30 @@ __global__ __launch_bounds__(512) void gemm_xw8_grouped_kernel(XwArgs g, GemmEpi
   }
   const int my_first = incl - my_nt;
   const int total = __builtin_amdgcn_readlane(incl, 63);
-  const int t_lo = (int)((int64_t)total * blockIdx.x / gridDim.x), t_hi = (int)((int64_t)total * (blockIdx.x + 1) / gridDim.x);
+  // The blocks' ranges are cut by COST, not by tile count: entering a group costs a weight reload and a drained DMA
+  // ring -- about two tiles' worth -- and the relations' row counts are skewed (a range of seventeen one-tile groups
+  // would otherwise be the launch's straggler).  Cost of group q in quarter tiles: 8 + 4 nt_q; tile i of it starts at
+  // pc_q + 8 + 4 i, and a block owns the tiles whose start lies in its share of the total.
+  constexpr int CU = 4, CR = 8;
+  const int my_cost = my_nt > 0 ? CR + CU * my_nt : 0;
+  int cincl = my_cost;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(cincl, d, 64);
+    if (lane >= d) cincl += v;
+  }
+  const int my_pc = cincl - my_cost;
+  const int total_cost = __builtin_amdgcn_readlane(cincl, 63);
+  auto tile_at = [&](int c) {             // index of the first tile whose start cost is >= c (total: none)
+    const unsigned long long m = __ballot(my_nt > 0 && my_pc <= c);
+    if (m == 0ull) return 0;
+    const int q = 63 - __builtin_clzll(m);
+    const int pc = __builtin_amdgcn_readlane(my_pc, q), nt = __builtin_amdgcn_readlane(my_nt, q);
+    const int i = max(0, (c - pc - CR + CU - 1) / CU);
+    return __builtin_amdgcn_readlane(my_first, q) + min(i, nt);
+  };
+  const int t_lo = tile_at((int)((int64_t)total_cost * blockIdx.x / gridDim.x));
+  const int t_hi = blockIdx.x + 1 == gridDim.x ? total : tile_at((int)((int64_t)total_cost * (blockIdx.x + 1) / gridDim.x));
   if (t_lo >= t_hi) return;
   struct Tile { int grp, m0, m_hi; };
   auto locate = [&](int t) {              // t < total: the last non-empty group that starts at or before tile t
