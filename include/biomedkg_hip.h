@@ -112,7 +112,9 @@ int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, 
 /* ---- exact-fp32 MFMA GEMM: C = epi(alpha op(A) op(B)), epi = (+bias[col]) -> act (0 none, 1 relu, 2 elu) ->
  *      (* gate>0 ? gate_scale : 0) -> (+ beta C).  Replaces torch Linear inside GCNConv.lin, the GRACE/GGD/DGI heads
  *      (biomedkg/model/gcl.py:19-21,49-51,86-90), fusion projections (biomedkg/utils/fusion.py:17-20,70).
- *      Large-K plain products (weight gradients) run split-K with f32 atomics into a zeroed C. */
+ *      Large-K plain products (weight gradients) run split-K with f32 atomics into a zeroed C.  Two shapes of the exact
+ *      mode take pipelined (LDS-DMA ring) kernels of their own: A^T B over row-major [K, M] / [K, N] operands with
+ *      128-aligned M, N (gemm_tn32.hip) and tall A[M, 256] x W with K = N = 256, no gate / beta (gemm_xw32.hip). */
 /*      precision: 0 = exact fp32 (v_mfma_f32_32x32x2_f32, the parity default); 1 = operands rounded to bf16 while
  *      staged into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate and fp32 C (BASELINE configs[2] "bf16" runs). */
 int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
@@ -132,7 +134,9 @@ int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N, const void
  * per-relation weights; forward and input gradient): C[M,N] = epi(alpha * A[M,K] @ Wt[N,K]^T).  A is fp32 or bf16
  * (a_is_bf16), Wt is the bf16 [N, K] image made by bkg_weight_to_bf16 (out[b] = bf16(W[b]) or bf16(W[b]^T), W[b] =
  * W + b*stride_w of shape [rows, cols]), C is fp32 or bf16 (c_is_bf16; beta needs fp32).  K % 256 == 0, N % 32 == 0,
- * 16-byte aligned rows.  group_ptr != NULL: rows of group g use Wt + g*stride_w (device group_ptr[G+1]). */
+ * 16-byte aligned rows.  group_ptr != NULL: rows of group g use Wt + g*stride_w (device group_ptr[G+1]).
+ * bf16 rows with K = N = 256 and no gate / beta -- every hidden layer of the bench step -- run the 8-wave form that keeps
+ * the weight in registers and streams A through LDS in full lines (plain; grouped with G <= 63; gathered). */
 int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w, int64_t rows, int64_t cols, int32_t batch,
                        void* out /* [batch, rows, cols] bf16, nullable */, int64_t ldo, int64_t stride_o,
                        void* out_t /* [batch, cols, rows] bf16 (transposed), nullable */, int64_t ldt, int64_t stride_t,
