@@ -125,8 +125,12 @@ def test_c3_as_timed_bf16_fast_paths_against_exact_fp32():
     assert fast.get("_gemm_xw", 0) >= 20                          # streaming activation-x-weight products
     assert fast.get("bkg_gemm_tn_bf16", 0) >= 4 and fast.get("bkg_gemm_grouped_k_bf16", 0) >= 4   # bf16 weight gradients
     assert fast.get("bkg_kge_fused_bce_dev_f32", 0) == 2
+    # GGD's head as a dot product per row (forward + both gradient pieces), gate / cast / bias gradient in one pass
+    assert fast.get("bkg_rowdot_f32", 0) == 1 and fast.get("bkg_scaled_rows", 0) == 1
+    assert fast.get("bkg_colsum_weighted_f32", 0) == 1 and fast.get("bkg_gate_cast_colsum_bf16", 0) >= 4
     exact = res["fp32"][1]
     assert exact.get("forward_views", 0) == 0 and exact.get("_gemm_xw", 0) == 0
+    assert exact.get("bkg_rowdot_f32", 0) == 0                    # the parity mode keeps the reference's Linear + sum
     for key in ("ggd", "kge"):
         l16, g16 = res["bf16"][0][key]
         l32, g32 = res["fp32"][0][key]
