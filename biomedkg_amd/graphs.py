@@ -27,6 +27,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
+from . import ops
 from . import rand as R
 
 
@@ -106,6 +107,7 @@ class GraphedStep:
         """One training step; returns the (static) loss tensor of the replay."""
         self.graph.replay()
         self.replays += 1
+        ops.note_graph_replay()          # weights moved under an unchanged tensor version: per-version caches are stale
         return self.loss
 
     def close(self):

@@ -76,12 +76,23 @@ def _f32c(t):
 
 
 # ----------------------------------------------------------------------------- raw kernels
+_REPLAY_GEN = 0
+
+
+def note_graph_replay():
+    """A captured training step was replayed: its optimizer step changed the weights WITHOUT touching their
+    ``_version``, so everything cached per weight version is stale for eager code from here on (the replay itself
+    rebuilds what it needs inside the graph)."""
+    global _REPLAY_GEN
+    _REPLAY_GEN += 1
+
+
 def _weight_bf16(w, transpose):
     """bf16 ``[.., N, K]`` image of a (batch of) weight matrix for ``bkg_gemm_xw`` -- ``w`` itself when it is stored
     ``[N, K]``, its transpose when stored ``[K, N]``.  One tiny launch per weight version writes BOTH orientations
     (the forward needs one, the backward the other)."""
     cache = getattr(w, "_bkg_w16", None)
-    key = (w.data_ptr(), w._version)
+    key = (w.data_ptr(), w._version, _REPLAY_GEN)
     if cache is None or cache[0] != key:
         w3 = w if w.dim() == 3 else w.unsqueeze(0)
         batch, rows, cols = w3.shape

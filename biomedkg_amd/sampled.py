@@ -357,4 +357,5 @@ class SaintGraphedKge:
             return loss
         g.replay()
         self.stats["replayed"] += 1
+        ops.note_graph_replay()          # weights moved under an unchanged tensor version (ops._weight_bf16)
         return self.losses[bucket]

@@ -131,6 +131,42 @@ def test_in_kernel_dropout_follows_the_device_replay_epoch():
     assert abs(float((eager[0] == 0).float().mean()) - 0.3) < 0.03
 
 
+def test_weight_images_follow_replayed_updates():
+    """bf16 mode caches a bf16 image of every weight per tensor VERSION; a replayed optimizer step changes the weights
+    without touching the version.  Eager code after some replays (validation, export) must not read a stale image."""
+    from biomedkg_amd import ops, rand as R
+    from biomedkg_amd.graphs import GraphedStep
+    ops.set_matmul_precision("bf16")
+    try:
+        mod, batch = _grace(seed=0, n=6000, e=60_000, d_in=256, h=256)       # tall enough for the streaming products
+        opt = torch.optim.Adam(mod.model.parameters(), lr=1e-2)
+        gs = GraphedStep(mod, batch, opt, seed=1)
+        for _ in range(5):
+            gs()
+        torch.cuda.synchronize()
+
+        def loss_now():
+            torch.manual_seed(77)
+            with torch.no_grad(), R.use(R.DeviceRand(seed=9)):
+                return float(mod.training_step(batch))
+        after = loss_now()
+        for p in mod.model.parameters():             # what the loss is with every image rebuilt from the weights as they are
+            p.__dict__.pop("_bkg_w16", None)
+        fresh = loss_now()
+        assert after == fresh, (after, fresh)
+        # ... and again after MORE replays: the eager pass above left images cached under the version the replays keep
+        for _ in range(5):
+            gs()
+        torch.cuda.synchronize()
+        after = loss_now()
+        for p in mod.model.parameters():
+            p.__dict__.pop("_bkg_w16", None)
+        fresh = loss_now()
+        assert after == fresh, (after, fresh)
+    finally:
+        ops.set_matmul_precision("fp32")
+
+
 def test_uncapturable_steps_are_refused():
     from biomedkg_amd import graphs as G, synthetic
     from biomedkg_amd.gcl_module import GGDModule
