@@ -295,7 +295,10 @@ extern "C" int bkg_gemm_f32(int32_t trans_a, int32_t trans_b, int64_t M, int64_t
     // bf16 operands: 128x128 tiles whenever the output allows -- the product is bound by operand traffic and
     // every strip is then re-read by half as many tiles (measured 0.21 -> 0.14 ms at 256x256x130k; the split-K
     // grid supplies the parallelism).  fp32 operands are MFMA-bound there and prefer more, smaller tiles.
-    if (precision == 0 && trans_a && !trans_b && K >= 4096 && gemm_tn32_ok(M, N, A, lda, B, ldb)) {
+    // (only when its 512-row chunks x 128-wide tiles fill the chip: a 5,000-row GRACE batch has 60 such blocks and runs
+    // faster as 240 small LDS-staged tiles -- its captured step went 1.86 -> 2.02 ms when it took this kernel)
+    if (precision == 0 && trans_a && !trans_b && ((K + 511) / 512) * ((M / 128) * (N / 128)) >= 256 &&
+        gemm_tn32_ok(M, N, A, lda, B, ldb)) {
       // exact-fp32 weight gradient over row-major operands: the LDS-DMA ring form (gemm_tn32.hip), two blocks per CU
       const int64_t t128 = (M / 128) * (N / 128);
       int64_t ns = std::min<int64_t>((K + 511) / 512, std::max<int64_t>(1, 512 / t128));
@@ -396,7 +399,7 @@ extern "C" int bkg_gemm_grouped_k_f32(int64_t rows_total, int64_t M, int64_t N, 
   const int KCHUNK = bkg_gemm_grouped_k_chunk(rows_total, M, N, precision);   // rows per block
   float* det = nullptr;
   BKG_DET_SLABS(det, ep, ceil_div(rows_total, KCHUNK) + G, M, N, "bkg_gemm_grouped_k_f32");
-  if (precision == 0 && rows_total >= 4096 && gemm_tn32_ok(M, N, A, lda, B, ldb)) {
+  if (precision == 0 && (ceil_div(rows_total, KCHUNK) + G) * ((M / 128) * (N / 128)) >= 256 && gemm_tn32_ok(M, N, A, lda, B, ldb)) {
     launch_gemm_tn32_grouped(ceil_div(rows_total, KCHUNK) + G, M, N, A, lda, B, ldb, C, ldc, strideC, group_ptr, G, KCHUNK, ep, det, s);
     if (det) splitk_reduce(det, C, ldc, strideC, (int)M, (int)N, group_ptr, G, KCHUNK, 0, s);
     return check_launch("bkg_gemm_grouped_k_f32(tn32)");
