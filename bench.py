@@ -648,7 +648,11 @@ def main():
                        "parallelism": {"single": "dp1", "partition": f"np{world}", "replicas": f"dp{world}"}[mode],
                        "cached_structures": "the step re-uses one graph: CSRs, (relation, target) segments, incidence lists, "
                                             "the positive-edge hash set and the bf16 copy of the constant input features are "
-                                            "built once (the reference's per-batch loaders rebuild PyG's COO bookkeeping)"},
+                                            "built once (the reference's per-batch loaders rebuild PyG's COO bookkeeping)",
+                       "identities": "bf16 mode evaluates two expressions of the reference in an algebraically equal form, "
+                                     "nothing is skipped: the corrupted view's first product x[perm] W^T as (x W^T)[perm], "
+                                     "and GGD's head (W h + b).sum(1) as h . W.sum(0) + b.sum() (every gradient included; "
+                                     "the exact-fp32 mode keeps the reference's form)"},
             "triplets_per_sec_kge_step": (total_edges + (n_neg if strong or world == 1 else world * n_neg)) / (ms_k * 1e-3),
             "edges_per_sec_gcl_step": total_edges / (ms_g * 1e-3),
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
