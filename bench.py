@@ -612,6 +612,22 @@ def main():
         except Exception:                      # noqa: BLE001  (a side figure: never costs the headline line)
             torch.cuda.synchronize()
 
+    ms_linear_head = None
+    if world == 1 and not args.no_extras and args.precision == "bf16":
+        # the same bf16 step with GGD's head in the reference's own form (the [2N, 256] Linear, then the row sum)
+        ok_fn = ops.rowsum_linear_ok
+        ops.rowsum_linear_ok = lambda *a, **k: False
+        try:
+            for _ in range(2):
+                step_g(); step_k()
+            sync(); t1 = time.perf_counter()
+            for _ in range(5):
+                step_g(); step_k()
+            sync()
+            ms_linear_head = (time.perf_counter() - t1) / 5 * 1e3
+        finally:
+            ops.rowsum_linear_ok = ok_fn
+
     ms_fp32 = None
     if world == 1 and not args.no_extras and args.precision == "bf16":
         ops.set_matmul_precision("fp32")                # the exact parity mode on the same modules / graph
@@ -656,6 +672,7 @@ def main():
             "triplets_per_sec_kge_step": (total_edges + (n_neg if strong or world == 1 else world * n_neg)) / (ms_k * 1e-3),
             "edges_per_sec_gcl_step": total_edges / (ms_g * 1e-3),
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
+            "ms_per_step_linear_ggd_head": ms_linear_head,
             "ms_per_step_fresh_structures": ms_fresh,
             "roofline": roof, "kernels": others,
             "cpu_baseline": None,
