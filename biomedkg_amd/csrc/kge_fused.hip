@@ -260,6 +260,27 @@ __global__ __launch_bounds__(1024) void kge_loss_finish_kernel(const float* __re
 
 // dst[row, :] = dst[row, :] * g + src[row, :] * (g * coef / rows)   for row < rows (= n_real or n), dst * g beyond;
 // g = gloss[0] (the upstream gradient of the loss)
+// (four columns per thread when the rows allow 16-byte pieces: the full-graph backward runs this over [N, d])
+__global__ __launch_bounds__(256) void scale_add_rows4_kernel(float* __restrict__ dst, int64_t ldd,
+                                                              const float* __restrict__ src, int64_t lds, int n, int d,
+                                                              const float* __restrict__ gloss, float coef,
+                                                              const int64_t* __restrict__ n_real_dev) {
+  const int d4 = d >> 2;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)n * d4) return;
+  const int row = (int)(e / d4), col = (int)(e % d4) * 4;
+  const int rows = n_real_dev ? (int)min((int64_t)n, n_real_dev[0]) : n;
+  const float g = gloss[0];
+  float4 v = *reinterpret_cast<const float4*>(dst + (int64_t)row * ldd + col);
+  v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+  if (row < rows) {
+    const float c = g * (coef / (float)max(rows, 1));
+    const float4 s = *reinterpret_cast<const float4*>(src + (int64_t)row * lds + col);
+    v.x = fmaf(s.x, c, v.x); v.y = fmaf(s.y, c, v.y); v.z = fmaf(s.z, c, v.z); v.w = fmaf(s.w, c, v.w);
+  }
+  *reinterpret_cast<float4*>(dst + (int64_t)row * ldd + col) = v;
+}
+
 __global__ __launch_bounds__(256) void scale_add_rows_kernel(float* __restrict__ dst, int64_t ldd,
                                                              const float* __restrict__ src, int64_t lds, int n, int d,
                                                              const float* __restrict__ gloss, float coef,
@@ -298,8 +319,12 @@ extern "C" int bkg_scale_add_rows_f32(float* dst, int64_t ldd, const float* src,
                                       const float* gloss, float coef, const int64_t* n_real_dev, void* stream) {
   BKG_ARG(n >= 0 && d > 0, "bkg_scale_add_rows_f32: bad sizes");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(scale_add_rows_kernel, dim3(ceil_div((int64_t)n * d, 256)), dim3(256), 0, (hipStream_t)stream, dst, ldd,
-                     src, lds, n, d, gloss, coef, n_real_dev);
+  if (d % 4 == 0 && ldd % 4 == 0 && lds % 4 == 0 && (uintptr_t)dst % 16 == 0 && (uintptr_t)src % 16 == 0)
+    hipLaunchKernelGGL(scale_add_rows4_kernel, dim3(ceil_div((int64_t)n * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       dst, ldd, src, lds, n, d, gloss, coef, n_real_dev);
+  else
+    hipLaunchKernelGGL(scale_add_rows_kernel, dim3(ceil_div((int64_t)n * d, 256)), dim3(256), 0, (hipStream_t)stream, dst, ldd,
+                       src, lds, n, d, gloss, coef, n_real_dev);
   return check_launch("bkg_scale_add_rows_f32");
 }
 

@@ -1195,6 +1195,11 @@ class _KgeBceLoss(torch.autograd.Function):
                 gl = gloss.reshape(1).contiguous()
                 L.call("bkg_scale_add_rows_f32", L.ptr(dz), dz.stride(0), L.ptr(z_reg), z_reg.stride(0), n, d, L.ptr(gl),
                        2.0 * ctx.reg / d, L.ptr(ctx.n_real), L.stream())
+            elif ctx.reg and gloss.numel() == 1 and z_reg.dtype == torch.float32 and z_reg.shape == dz.shape:
+                # dz * gloss + (2 reg / numel) * gloss * z in one in-place launch (dz is this op's own buffer)
+                gl = gloss.reshape(1).float().contiguous()
+                L.call("bkg_scale_add_rows_f32", L.ptr(dz), dz.stride(0), L.ptr(z_reg), z_reg.stride(0), dz.size(0), d,
+                       L.ptr(gl), 2.0 * ctx.reg / d, None, L.stream())
             else:
                 dz = dz * gloss
                 if ctx.reg:
