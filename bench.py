@@ -2,8 +2,9 @@
 """Benchmark of the BioMedKG GCL + KGE training hot path on MI355X.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (launch_ranks), one per GPU, RCCL
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W   # ... or takes the ranks an outer launcher started
 
 One *step* = one GCL training step (GGD, the reference's default ``model_name``; 4-layer GCN
 768->256) + one KGE training step (4-layer R-GCN d=256 + DistMult, ``neg_ratio`` negatives per
@@ -509,14 +510,54 @@ def cpu_baseline(args):
 
 
 # ----------------------------------------------------------------------------------------------- main
+def launch_ranks(args):
+    """``python3 bench.py --gpus N`` with no launcher around it: this process becomes the launcher -- it never touches
+    the GPU (nothing before this point does: ``import torch`` and ``torch.cuda.device_count()`` do not initialise HIP on
+    this image) -- and starts N fresh interpreters on this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the
+    way Lightning starts the reference's ranks from one ``python train_gcl.py`` (reference train_gcl.py:63-68,
+    configs/gcl.yaml:11).  Rank 0's stdout (the single JSON line) is relayed; the exit code is the worst child's."""
+    import socket
+    import subprocess
+    n = args.gpus
+    one_device = os.environ.get("BKG_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not one_device:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s) (BKG_BENCH_ONE_DEVICE=1 + "
+                         "BKG_BENCH_BACKEND=gloo is the functional single-device check)")
+    with socket.socket() as s:                      # a free rendezvous port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BKG_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this stack
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=max(deadline - time.time(), 1)))
+        except subprocess.TimeoutExpired:           # rank 0 is gone and this one is stuck in a collective
+            p.kill()
+            codes.append(p.wait() or 1)
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    raise SystemExit(max(abs(c) for c in bad) if bad else 0)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1 (see module docstring)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # BKG_BENCH_ONE_DEVICE=1 / BKG_BENCH_BACKEND=gloo: functional check of the multi-rank code path on a 1-GPU box
@@ -528,6 +569,7 @@ def main():
     # BKG_PARTITION_FORCE_COLLECTIVES=1 with --gpus 1 --mode partition | replicas: a 1-rank RCCL group, every collective of the
     # N-rank path issued for real (functional check of the RCCL calls on a single-GPU box; never a reported number)
     forced = world == 1 and os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1" and args.mode in ("partition", "replicas")
+    backend = None
     if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -651,7 +693,9 @@ def main():
                 "replicas": "one graph per rank, gradient all-reduce only (the reference's DDP regime)"}[mode]
         out = {
             "metric": "edges/sec, GCL (GGD) step + KGE (R-GCN+DistMult) step, PrimeKG++ scale",
-            "value": total_edges / (ms * 1e-3), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "value": total_edges / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
+            "ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            "backend": ("rccl" if backend == "nccl" else backend), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",

@@ -279,3 +279,27 @@ def test_collectives_of_the_partitioned_step_over_a_one_rank_rccl_group():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["scaling"] == "strong" and line["value"] > 0 and line["n_gpus"] == 1
+
+
+def test_bench_starts_its_own_ranks():
+    """``python3 bench.py --gpus 2`` with NO launcher around it (the driver's SCALE command form; the reference's users
+    run one command too: train_gcl.py:63-68, Lightning starts the ranks): the parent spawns two fresh rank processes
+    before anything touches the GPU, relays rank 0's single JSON line and returns the worst exit code.  Here the two
+    ranks share the one GPU of the box over gloo (BKG_BENCH_ONE_DEVICE / BKG_BENCH_BACKEND); without those variables
+    the same command selects RCCL with one device per rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BKG_BENCH_ONE_DEVICE="1", BKG_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo"
+    assert line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["parallelism"] == "np2"
