@@ -59,8 +59,13 @@ def make_capturable(optimizer):
 
 
 class GraphedStep:
-    def __init__(self, module, batch, optimizer, clip=1.0, warmup=3, seed=None, provider=None):
+    def __init__(self, module, batch, optimizer, clip=1.0, warmup=3, seed=None, provider=None, rewind=False):
+        """``rewind``: the eager warm-up steps (they build caches, Adam's state buffers and kernel plans) are undone
+        before the capture -- parameters, optimizer state and torch's device generator go back IN PLACE to what they
+        were -- so the first replay is the run's first optimizer step (``warmup_steps == 0``): a Trainer that captures
+        follows the trajectory of one that does not.  Default: the warm-up steps are real steps of the run."""
         L.require_cuda(*[p for g in optimizer.param_groups for p in g["params"]][:1])
+        self.rewind = bool(rewind)
         self.module, self.batch, self.optimizer, self.clip = module, batch, make_capturable(optimizer), clip
         self.params = [p for g in optimizer.param_groups for p in g["params"]]
         self.provider = provider if provider is not None else _GraphRand(seed)
@@ -84,6 +89,12 @@ class GraphedStep:
         L.call("bkg_set_rng_epoch", L.ptr(self.epoch))
         try:
             with R.use(self.provider):
+                if self.rewind:
+                    torch.cuda.synchronize()
+                    saved_p = [p.detach().clone() for p in self.params]
+                    saved_s = {p: {k: v.detach().clone() for k, v in st.items() if isinstance(v, torch.Tensor)}
+                               for p, st in self.optimizer.state.items()}
+                    saved_rng = torch.cuda.get_rng_state(self.params[0].device)
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):                       # eager warm-up: caches, Adam state, kernel plans
@@ -91,6 +102,20 @@ class GraphedStep:
                         self._eager()
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
+                if self.rewind:
+                    with torch.no_grad():
+                        for p, q in zip(self.params, saved_p):
+                            p.copy_(q)
+                        for p, st in self.optimizer.state.items():      # in place: the capture freezes these addresses
+                            for k, v in st.items():
+                                if isinstance(v, torch.Tensor):
+                                    was = saved_s.get(p, {}).get(k)
+                                    v.copy_(was) if was is not None else v.zero_()   # Adam's fresh state is all zeros
+                    torch.cuda.set_rng_state(saved_rng, self.params[0].device)
+                    self.epoch.zero_()
+                    if hasattr(self.provider, "counter"):
+                        self.provider.counter = 0
+                    torch.cuda.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
                 self.optimizer.zero_grad(set_to_none=True)
                 with torch.cuda.graph(self.graph):
@@ -101,7 +126,7 @@ class GraphedStep:
             L.call("bkg_set_rng_epoch", None)
             if trainer is not None:
                 self.module.__dict__["trainer"] = trainer
-        self.warmup_steps = max(1, warmup)                          # (the capture pass records, it does not execute)
+        self.warmup_steps = 0 if self.rewind else max(1, warmup)    # (the capture pass records, it does not execute)
 
     def __call__(self):
         """One training step; returns the (static) loss tensor of the replay."""

@@ -42,13 +42,20 @@ def set_deterministic(on: bool, workspace_floats: int = 1 << 26):
     if on:
         if not torch.cuda.is_available():
             raise L.HipLibraryError("deterministic mode needs the GPU workspace")
-        if _DET_WS is None or _DET_WS.numel() < workspace_floats:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if _DET_WS is None or _DET_WS.numel() < workspace_floats or _DET_WS.device != dev:
             if _DET_WS is not None:
                 _DET_RETIRED.append(_DET_WS)
-            _DET_WS = torch.empty(workspace_floats, dtype=torch.float32, device="cuda")
+            # revive a retired buffer of this device that is large enough before allocating (on/off toggles: bench, tests)
+            hit = next((t for t in _DET_RETIRED if t.device == dev and t.numel() >= workspace_floats), None)
+            if hit is not None:
+                _DET_RETIRED.remove(hit)
+            _DET_WS = hit if hit is not None else torch.empty(workspace_floats, dtype=torch.float32, device=dev)
         L.call("bkg_set_deterministic_workspace", L.ptr(_DET_WS), _DET_WS.numel())
     else:
         L.call("bkg_set_deterministic_workspace", None, 0)
+        if _DET_WS is not None:
+            _DET_RETIRED.append(_DET_WS)      # a graph captured in deterministic mode still launches with its address
         _DET_WS = None
 
 
@@ -59,8 +66,10 @@ def is_deterministic() -> bool:
 def _det_reserve(floats):
     """Deterministic mode: make sure the slab workspace holds ``floats`` (one [M, N] slab per K chunk of the product
     about to be launched); grows it when a wider / longer product comes along."""
-    if _DET_WS is not None and _DET_WS.numel() < floats:
-        set_deterministic(True, int(floats))
+    if _DET_WS is not None and (_DET_WS.numel() < floats or _DET_WS.device.index != torch.cuda.current_device()):
+        # (one process drives one GPU -- SURVEY 3.5 -- and the slab users are serialised on the launch stream; a second
+        # device in the same process gets a workspace of its own here rather than another device's pointer)
+        set_deterministic(True, int(max(floats, _DET_WS.numel())))
 
 
 def _follow_torch_determinism():
@@ -1316,8 +1325,14 @@ class NtXentKernels:
         ws = torch.empty(L.lib().bkg_ntxent_rows_forward_workspace_floats(m, na, self.h, self.bf16), dtype=torch.float32,
                          device=z_all.device)
         den = torch.empty(na, dtype=torch.float32, device=z_all.device)
-        self._z16 = self._operand(z_all, tau)
-        L.call("bkg_ntxent_rows_forward", L.ptr(self._z16), self.bf16, m, self.h, tau, L.ptr(anchors), na, L.ptr(ws),
+        z16 = self._operand(z_all, tau)
+        # kept for the backward of THIS forward only: keyed on the saved tensor itself (one kernels object may serve
+        # several forwards before their backwards -- two GRACE losses in a step, gradient accumulation)
+        stash = self.__dict__.setdefault("_z16", {})
+        if len(stash) >= 4:
+            stash.pop(next(iter(stash)))
+        stash[(z_all.data_ptr(), z_all._version, float(tau))] = z16
+        L.call("bkg_ntxent_rows_forward", L.ptr(z16), self.bf16, m, self.h, tau, L.ptr(anchors), na, L.ptr(ws),
                L.ptr(den), L.stream())
         return den
 
@@ -1328,7 +1343,7 @@ class NtXentKernels:
                          device=z_all.device)
         rden = (1.0 / den_all).contiguous()
         dh = torch.empty(na, self.h, dtype=torch.float32, device=z_all.device)
-        z16 = getattr(self, "_z16", None)
+        z16 = self.__dict__.get("_z16", {}).pop((z_all.data_ptr(), z_all._version, float(tau)), None)
         if z16 is None or z16.size(0) != m:
             z16 = self._operand(z_all, tau)
         scale = scale.reshape(1).to(torch.float32).contiguous()

@@ -34,7 +34,7 @@ from . import ops
 from . import rand as R
 from .graph import RelGraph, graph_of, plant_rel_graph
 from .graphs import make_capturable
-from .samplers import SubgraphBatch, rows_of
+from .samplers import SubgraphBatch, _relabel, rows_of
 
 EDGE_BUCKETS = (1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536)
 _SIZES = 3     # nodes, edges, loop-free edges
@@ -272,8 +272,20 @@ class SaintGraphedKge:
     # ---- the ordinary step on the unpadded batch (outside the captured regime)
     def unpadded_batch(self, n_b, e_b):
         v = self.v
-        ei = torch.stack([v["src"][:e_b], v["dst"][:e_b]])
         n_id = v["n_id"][:n_b].clone()
+        if e_b > self.e_cap:
+            # the sampler stores the first ``edge_cap`` induced edges only (and reports the true total): the node set is
+            # complete, so the induced subgraph is rebuilt from it -- the eager sampler's own torch-glue path
+            # (samplers.SaintRandomWalkSampler.sample_with_torch_glue), same edge order (ascending edge id)
+            s = self.sampler
+            mask = torch.zeros(s.num_nodes, dtype=torch.bool, device=n_id.device)
+            mask[n_id] = True
+            e_id = torch.nonzero(mask[s.edge_index[0]] & mask[s.edge_index[1]]).squeeze(1)
+            if e_id.numel() != e_b:
+                raise RuntimeError(f"induced-edge count {e_id.numel()} != the sampler's {e_b}")
+            src, dst = _relabel(n_id, s.num_nodes, s.edge_index[0][e_id], s.edge_index[1][e_id])
+            return SubgraphBatch(rows_of(self.x_ext, n_id), torch.stack([src, dst]), s.edge_type[e_id].clone(), n_b, n_id, e_id)
+        ei = torch.stack([v["src"][:e_b], v["dst"][:e_b]])
         # (rows of the SAME table object as the padded steps: one fused copy of it serves both)
         return SubgraphBatch(rows_of(self.x_ext, n_id), ei, v["type"][:e_b].clone(), n_b, n_id, v["eid"][:e_b].clone())
 

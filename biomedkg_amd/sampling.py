@@ -75,6 +75,35 @@ def _positive_table(edge_index, n):
     return _cached(edge_index, "pos_table", (int(n),), build)
 
 
+_PENDING_COUNTS = []     # (pinned survivor count, event, k) of "sure" calls whose count nobody has looked at yet
+SHORTFALLS = 0           # calls whose single round came up short (expected: never; ~1e-9 per call under the guard)
+
+
+def _watch_shortfall(count, k):
+    """The "sure" path never READS its survivor count inside the step (that would be a host round trip); the count is
+    copied to pinned memory asynchronously and looked at by a LATER call, once its event has completed -- a shortfall
+    (PyG would have gone on to rounds two and three; here the missing slots hold (0, 0) pairs) is reported, late but
+    loudly, instead of passing silently.  Skipped while a stream is being captured."""
+    global SHORTFALLS
+    if torch.cuda.is_current_stream_capturing():
+        return
+    for item in list(_PENDING_COUNTS):
+        host, event, want = item
+        if event.query():
+            _PENDING_COUNTS.remove(item)
+            if int(host) < want:
+                SHORTFALLS += 1
+                import warnings
+                warnings.warn(f"negative_sampling: an earlier call kept {int(host)} of {want} negatives in its single "
+                              "round (the rest are (0, 0) pairs); PyG would have drawn further rounds", RuntimeWarning)
+    if len(_PENDING_COUNTS) < 8:
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(count, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        _PENDING_COUNTS.append((host, event, int(k)))
+
+
 def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
     population = n * (n - 1)
     dev = edge_index.device
@@ -94,6 +123,7 @@ def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
         L.call("bkg_negative_sample", n, 0, draw, seed, L.ptr(pos_table), pos_table.numel(), L.ptr(keys),
                L.ptr(flag[0]), L.ptr(flag[1]), L.ptr(out[0]), L.ptr(out[1]), 0, k, L.ptr(count), L.ptr(ws), ws.numel(),
                L.stream())
+        _watch_shortfall(count, k)
         return out
     for _ in range(3):                               # PyG: at most three over-sampling rounds
         keys = torch.empty(draw, dtype=torch.int64, device=dev)

@@ -142,12 +142,18 @@ class Trainer:
         if batch is None:
             return None
         from . import graphs
+        import copy
         state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        opt_state = copy.deepcopy(opt.state_dict())              # param_groups too: make_capturable rewrites lr / capturable
+        rng = torch.cuda.get_rng_state(self.device)
         try:
-            step = graphs.GraphedStep(model, self._move(batch), opt, clip=self.clip, warmup=2)
+            # rewind: the warm-up passes are undone before the capture, the run has exactly epochs x steps optimizer steps
+            step = graphs.GraphedStep(model, self._move(batch), opt, clip=self.clip, warmup=2, rewind=True)
         except (graphs.CaptureRefused, RuntimeError) as why:      # refused up front, or an op on the path cannot be captured
             torch.cuda.synchronize()
             model.load_state_dict(state)
+            opt.load_state_dict(opt_state)                        # Adam's moments / step counters of the warm-up steps go too
+            torch.cuda.set_rng_state(rng, self.device)
             if self.rank == 0:
                 print(f"[trainer] eager steps: {why}", flush=True)
             return None
@@ -197,6 +203,7 @@ class Trainer:
         opt, sched = conf["optimizer"], conf.get("lr_scheduler")
         params = [p for g in opt.param_groups for p in g["params"]]
         bucket = D.GradBucket(params, self.world)
+        model.train()                       # (a fit() after test() would otherwise capture an eval-mode step)
         graphed = self._try_graph(model, train_dataloaders, opt)
         for epoch in range(epochs):
             self.current_epoch = epoch
@@ -204,7 +211,8 @@ class Trainer:
             t0 = time.time()
             batches = self._limit(train_dataloaders)
             if graphed is not None and getattr(graphed, "owns_batches", False):
-                batches = ((i, None) for i in range(len(train_dataloaders)))      # the graphed loop samples for itself
+                # the graphed loop samples for itself (fast_dev_run never gets here: _try_graph declines it)
+                batches = ((i, None) for i in range(len(train_dataloaders)))
             for i, batch in batches:
                 if graphed is not None:            # one hipGraph replay = zero_grad + step + backward + clip + Adam
                     loss = graphed()

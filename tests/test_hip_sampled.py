@@ -174,6 +174,33 @@ def test_batches_outside_the_ladder_take_the_ordinary_step():
     assert all(torch.isfinite(l) for l in losses)
 
 
+def test_over_capacity_batches_are_not_truncated():
+    """A batch with more induced edges than the sampler's edge capacity (= the largest bucket): the sampler stores the
+    first ``edge_cap`` edges and reports the true total; the fallback must train on ALL of them -- the batch the eager
+    sampler builds from the same node set -- and its loss must be the ordinary step's loss on that batch."""
+    from biomedkg_amd import rand as R
+    from biomedkg_amd.sampled import SaintGraphedKge
+    from biomedkg_amd.samplers import _relabel
+    ei, et, n, r = _graph()
+    x = torch.randn(n, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 0.3
+    mod = _module(r, neg_ratio=2, layers=1).eval()             # eval: no dropout stream to line up
+    sg = SaintGraphedKge(mod, x, ei, et, batch_size=40, seed=5, graphs=True, buckets=(64, 128))
+    sg.step()
+    n_b, e_b, _ = sg.last_sizes
+    assert e_b > sg.e_cap                                       # the case: the buffers hold 128 of e_b edges
+    b = sg.unpadded_batch(n_b, e_b)
+    n_id = sg.v["n_id"][:n_b]
+    mask = torch.zeros(n, dtype=torch.bool, device=DEV); mask[n_id] = True
+    e_id = torch.nonzero(mask[ei[0]] & mask[ei[1]]).squeeze(1)
+    src, dst = _relabel(n_id, n, ei[0][e_id], ei[1][e_id])
+    assert b.edge_index.size(1) == e_b == e_id.numel()
+    assert torch.equal(b.edge_index, torch.stack([src, dst])) and torch.equal(b.edge_type, et[e_id])
+    assert torch.equal(b.e_id, e_id) and torch.equal(b.n_id, n_id)
+    assert torch.equal(b.x, x[n_id])
+    # the first 128 stored edges are a prefix of the full list (what the truncated step used to train on)
+    assert torch.equal(sg.v["src"][:128], src[:128]) and torch.equal(sg.v["dst"][:128], dst[:128])
+
+
 @pytest.mark.parametrize("init,fuse,decoder,fix", [("lm", "attention", "dismult", None), ("lm", "redaf", "transe", None),
                                                    ("gcl", "none", "dismult", 1), ("random", "none", "transe", None)])
 def test_every_input_form_of_the_kge_module_replays(init, fuse, decoder, fix):
