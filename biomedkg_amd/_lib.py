@@ -19,8 +19,9 @@ I32, I64, U32, U64, F32 = c_int32, c_int64, c_uint32, c_uint64, c_float
 class RowSplitStruct(ctypes.Structure):
     """``bkg_rowsplit`` of include/biomedkg_hip.h (device pointers + upper-bound sizes)."""
     _fields_ = [(n, c_void_p) for n in ("item_row", "item_beg", "item_end", "item_slot", "long_row", "long_slot0",
-                                        "long_cnt", "totals")] + [(n, c_int64) for n in
-                                                                  ("n_items_max", "n_slots_max", "n_long_max")]
+                                        "long_cnt", "short_desc", "short_col", "totals")] + [(n, c_int64) for n in
+                                                                                ("n_items_max", "n_slots_max", "n_long_max",
+                                                                                 "n_short_max")]
 
 
 # name -> (restype, argtypes); mirrors include/biomedkg_hip.h one to one.
@@ -41,7 +42,7 @@ SIGNATURES = {
     "bkg_rgcn_segments_static": (I32, [P, I64, I64, I32, P, P, P, P, P, P, P, P, P, I64, P]),
     "bkg_rgcn_edge_order": (I32, [P, P, P, I64, P, P, P]),
     # spmm.hip
-    "bkg_rowsplit_build": (I32, [P, I64, I64, I32, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
+    "bkg_rowsplit_build": (I32, [P, I64, I64, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
     "bkg_cast_f32_bf16": (I32, [P, P, F32, P, I64, P]),
     "bkg_mask_cast_bf16": (I32, [P, F32, U64, U32, P, I64, P]),
     "bkg_gate_cast_bf16": (I32, [P, I32, P, I32, F32, P, I64, P]),

@@ -286,9 +286,11 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_b
   bkg_rowsplit none{};
 #define KN_LAUNCH(TT, K)                                                                                               \
   if (split) {                                                                                                         \
+    if (split->n_items_max > 0)                                                                                        \
     hipLaunchKernelGGL((kge_bwd_nodes_kernel<TT, K, LPR, VPL, true>), dim3(ceil_div(split->n_items_max, 4)), block, 0, \
                        s, (const TT*)z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz,    \
                        lddz, *split, partials, accumulate);                                                            \
+    if (split->n_long_max > 0)   /* (bounds cut to the table's actual counts may be zero) */                          \
     hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, K, LPR, VPL>), dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), \
                        block, 0, s, *split, (const TT*)z, ldz, l1, partials, dz, lddz, accumulate);                    \
   } else {                                                                                                             \

@@ -40,77 +40,128 @@ struct SpmmEpilogue {
   const uint32_t* epoch;    // replay epoch of a captured step (common.h with_epoch) or null
 };
 
-// One predicated batch of UT entries per lane group starting at e (entries >= end get weight 0 and a clamped,
-// valid index so that the batch's loads are unconditional).
-template <typename T, int LPR, int VPL, int UT>
-__device__ __forceinline__ void spmm_tail(float4* acc, int e, int end, const int32_t* __restrict__ col,
-                                          const float* __restrict__ w, const T* __restrict__ x, int64_t ldx, int grp,
-                                          int lig) {
-  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL;
-  int idx[UT];
-  float wt[UT];
-  bool ok[UT];
+// ---- entry batches.  An item's entry range is wave-uniform (its bounds come through readfirstlane), so when the wave
+// has one or two lane groups the indices and weights of a batch of NB consecutive entries are read with SCALAR loads
+// into SGPRs: no vector registers, no texture-addresser cycles (a wave-wide 4-byte load with two distinct addresses
+// occupies the addresser like a full one), and -- on their own counter (lgkmcnt) -- the NEXT batch's indices arrive
+// while this batch's rows are in flight.  Lane group g of the G = 64 / LPR groups takes entries g, g + G, ... of the
+// batch (a v_cndmask between two SGPRs).  With four or more groups a batch would not fit the scalar register file:
+// those widths (d <= 128 bf16 / d <= 64 fp32) keep per-lane loads.
+template <int G, int UT>
+struct EntryIdx {
+  static constexpr bool SCALAR = G <= 2;
+  int v[SCALAR ? UT * G : UT];
+  __device__ __forceinline__ void load(int e, int last, const int32_t* __restrict__ col, int grp) {
+    if constexpr (SCALAR) {
 #pragma unroll
-  for (int u = 0; u < UT; ++u) {
-    const int k = e + u * G + grp;
-    const int kc = min(k, end - 1);
-    ok[u] = k < end;
-    idx[u] = col[kc];
-    wt[u] = w ? w[kc] : 1.0f;
+      for (int j = 0; j < UT * G; ++j) v[j] = col[min(e + j, last)];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UT; ++u) v[u] = col[min(e + u * G + grp, last)];
+    }
   }
-  Piece<T> val[UT][VPL];
+  __device__ __forceinline__ int mine(int u, int grp) const {
+    if constexpr (!SCALAR) return v[u];
+    else if constexpr (G == 1) return v[u];
+    else return grp ? v[u * G + 1] : v[u * G];
+  }
+};
+template <int G, int UT, bool HAS_W>
+struct EntryWt {
+  static constexpr bool SCALAR = G <= 2;
+  float v[HAS_W ? (SCALAR ? UT * G : UT) : 1];
+  __device__ __forceinline__ void load(int e, int last, const float* __restrict__ w, int grp) {
+    if constexpr (HAS_W) {
+      if constexpr (SCALAR) {
+#pragma unroll
+        for (int j = 0; j < UT * G; ++j) v[j] = w[min(e + j, last)];
+      } else {
+#pragma unroll
+        for (int u = 0; u < UT; ++u) v[u] = w[min(e + u * G + grp, last)];
+      }
+    }
+  }
+  __device__ __forceinline__ float mine(int u, int grp) const {
+    if constexpr (!HAS_W) return 1.0f;
+    else if constexpr (!SCALAR || G == 1) return v[u];
+    else return grp ? v[u * G + 1] : v[u * G];
+  }
+};
+constexpr int NO_CLAMP = 0x7fffffff;
+
+template <typename T, int LPR, int VPL, int UT>
+__device__ __forceinline__ void gather_rows(Piece<T> (&val)[UT][VPL], const EntryIdx<64 / LPR, UT>& idx,
+                                            const T* __restrict__ x, int64_t ldx, int grp, int lig) {
+  constexpr int EPL = Piece<T>::EPL;
 #pragma unroll
   for (int u = 0; u < UT; ++u) {
-    const T* src = x + (int64_t)idx[u] * ldx + EPL * lig;
+    const T* src = x + (int64_t)idx.mine(u, grp) * ldx + EPL * lig;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) val[u][v].load(src + EPL * v * LPR);
   }
+}
+
+// One predicated batch of UT entries per lane group starting at e (entries >= end read a clamped, valid index so that
+// the batch's loads are unconditional, and contribute nothing).
+template <typename T, int LPR, int VPL, int UT, bool HAS_W>
+__device__ __forceinline__ void spmm_tail(float4* acc, int e, int end, const int32_t* __restrict__ col,
+                                          const float* __restrict__ w, const T* __restrict__ x, int64_t ldx, int grp,
+                                          int lig) {
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q;
+  EntryIdx<G, UT> idx;
+  idx.load(e, end - 1, col, grp);
+  EntryWt<G, UT, HAS_W> wt;
+  wt.load(e, end - 1, w, grp);
+  Piece<T> val[UT][VPL];
+  gather_rows<T, LPR, VPL, UT>(val, idx, x, ldx, grp, lig);
 #pragma unroll
   for (int u = 0; u < UT; ++u)
-    if (ok[u]) {  // a padded slot contributes nothing, whatever the clamped row holds
+    if (e + u * G + grp < end) {  // a padded slot contributes nothing, whatever the clamped row holds
+      const float wu = wt.mine(u, grp);
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) val[u][v].fma(acc + v * Q, wt[u]);
+      for (int v = 0; v < VPL; ++v) val[u][v].fma(acc + v * Q, wu);
     }
 }
 
 // acc += sum over entries [beg, end) of this item (all lane groups, then combined across groups).
 // acc has VPL * Q float4: piece v of lane `lig` covers columns EPL * (lig + v * LPR) + [0, EPL).
-template <typename T, int LPR, int VPL>
-__device__ __forceinline__ void spmm_accumulate(float4* acc, int beg, int end, const int32_t* __restrict__ col,
-                                                const float* __restrict__ w, const T* __restrict__ x, int64_t ldx,
-                                                int grp, int lig) {
-  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL;
+template <typename T, int LPR, int VPL, bool HAS_W>
+__device__ __forceinline__ void spmm_accumulate_w(float4* acc, int beg, int end, const int32_t* __restrict__ col,
+                                                  const float* __restrict__ w, const T* __restrict__ x, int64_t ldx,
+                                                  int grp, int lig) {
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q;
   constexpr int U = (VPL == 1) ? 8 : 4;  // entries in flight per lane group
+  constexpr int NB = U * G;
   int e = beg;
-  for (; e + U * G <= end; e += U * G) {
-    int idx[U];
-    float wt[U];
+  if (e + NB <= end) {
+    EntryIdx<G, U> idx;
+    idx.load(e, NO_CLAMP, col, grp);
+    for (;;) {
+      Piece<T> val[U][VPL];
+      gather_rows<T, LPR, VPL, U>(val, idx, x, ldx, grp, lig);
+      EntryWt<G, U, HAS_W> wt;
+      wt.load(e, NO_CLAMP, w, grp);              // arrives long before the rows
+      e += NB;
+      const bool more = e + NB <= end;           // wave-uniform
+      if (more) idx.load(e, NO_CLAMP, col, grp); // the next batch's indices, under this batch's row loads
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      idx[u] = col[e + u * G + grp];
-      wt[u] = w ? w[e + u * G + grp] : 1.0f;
+      for (int u = 0; u < U; ++u) {
+        const float wu = wt.mine(u, grp);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) val[u][v].fma(acc + v * Q, wu);
+      }
+      if (!more) break;
     }
-    Piece<T> val[U][VPL];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const T* src = x + (int64_t)idx[u] * ldx + EPL * lig;
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) val[u][v].load(src + EPL * v * LPR);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) val[u][v].fma(acc + v * Q, wt[u]);
   }
   // Remainder (the common case: most rows are shorter than one full batch).  One PREDICATED batch sized to
   // the wave-uniform remainder keeps all its index loads, then all its row loads, in flight together; a
   // one-entry-per-iteration tail would pay the index -> row latency chain once per entry.
   const int rem = end - e;  // wave-uniform, < U * G
   if (rem > 0) {
-    if (rem > 4 * G) spmm_tail<T, LPR, VPL, (U > 4 ? U : 4)>(acc, e, end, col, w, x, ldx, grp, lig);
-    else if (rem > 2 * G) spmm_tail<T, LPR, VPL, 4>(acc, e, end, col, w, x, ldx, grp, lig);
-    else if (rem > G) spmm_tail<T, LPR, VPL, 2>(acc, e, end, col, w, x, ldx, grp, lig);
-    else spmm_tail<T, LPR, VPL, 1>(acc, e, end, col, w, x, ldx, grp, lig);
+    if (rem > 4 * G) spmm_tail<T, LPR, VPL, (U > 4 ? U : 4), HAS_W>(acc, e, end, col, w, x, ldx, grp, lig);
+    else if (rem > 2 * G) spmm_tail<T, LPR, VPL, 4, HAS_W>(acc, e, end, col, w, x, ldx, grp, lig);
+    else if (rem > G) spmm_tail<T, LPR, VPL, 2, HAS_W>(acc, e, end, col, w, x, ldx, grp, lig);
+    else spmm_tail<T, LPR, VPL, 1, HAS_W>(acc, e, end, col, w, x, ldx, grp, lig);
   }
   if (G > 1) {
 #pragma unroll
@@ -121,6 +172,14 @@ __device__ __forceinline__ void spmm_accumulate(float4* acc, int beg, int end, c
         acc[v].z += __shfl_xor(acc[v].z, o, 64); acc[v].w += __shfl_xor(acc[v].w, o, 64);
       }
   }
+}
+
+template <typename T, int LPR, int VPL>
+__device__ __forceinline__ void spmm_accumulate(float4* acc, int beg, int end, const int32_t* __restrict__ col,
+                                                const float* __restrict__ w, const T* __restrict__ x, int64_t ldx,
+                                                int grp, int lig) {
+  if (w) spmm_accumulate_w<T, LPR, VPL, true>(acc, beg, end, col, w, x, ldx, grp, lig);
+  else spmm_accumulate_w<T, LPR, VPL, false>(acc, beg, end, col, w, x, ldx, grp, lig);
 }
 
 // self-loop term, addend, bias, ReLU, dropout, store (lane group 0 only)
@@ -190,6 +249,48 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
     }
 }
 
+// ---- short rows (rowsplit.hip: rows of 0..8 entries of a packed table).  RPW = 64 / LS rows per wave: lane group g
+// of LS lanes owns row desc[i0 + g] alone -- VS 16-byte pieces per lane cover the row -- so there is no cross-lane
+// reduction and no per-row wave.  Descriptor and the row's (padded) indices arrive in one round trip, the weights
+// travel beside the rows: two dependent memory levels per wave instead of four, every load unconditional.
+template <typename T, int LS, int VS>
+__device__ __forceinline__ void spmm_short_rows(int i, int n_short, const int32_t* __restrict__ desc,
+                                                const int32_t* __restrict__ scol, const float* __restrict__ w,
+                                                const T* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+                                                const SpmmEpilogue& ep, int lig) {
+  constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VS * Q;
+  constexpr int UB = 4;                                       // entries per pass (88 % of the bench graph's short rows
+  const bool live = i < n_short;                              // have <= 4: most waves stop after the first)
+  const int ic = live ? i : 0;                                // (n_short_max >= 1 rows are allocated)
+  const int4 dsc = reinterpret_cast<const int4*>(desc)[ic];
+  const int4 c0 = reinterpret_cast<const int4*>(scol)[2 * ic], c1 = reinterpret_cast<const int4*>(scol)[2 * ic + 1];
+  const int idx[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const int row = dsc.x, beg = dsc.y, len = live ? dsc.z : 0;
+  float4 acc[VQ];
+  zero4(acc);
+#pragma unroll
+  for (int b0 = 0; b0 < 8; b0 += UB) {
+    if (b0 > 0 && !__any(b0 < len)) break;
+    Piece<T> val[UB][VS];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {     // unconditional (pads repeat the row's last index: an L1 hit); exec-masking the
+      const T* src = x + (int64_t)idx[b0 + u] * ldx + EPL * lig;   // pads was measured slower (54 -> 62 us)
+#pragma unroll
+      for (int v = 0; v < VS; ++v) val[u][v].load(src + EPL * v * LS);
+    }
+    float wt[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) wt[u] = (w && b0 + u < len) ? w[beg + b0 + u] : 1.0f;
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (b0 + u < len) {
+#pragma unroll
+        for (int v = 0; v < VS; ++v) val[u][v].fma(acc + v * Q, wt[u]);
+      }
+  }
+  if (live) spmm_finish<T, LS, VS>(acc, row, lig, x, ldx, out, ldo, ep);
+}
+
 // one wave per row (no splitting): small or unskewed inputs
 template <typename T, int LPR, int VPL>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict__ rowptr,
@@ -209,15 +310,16 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
   if (grp == 0) spmm_finish<T, LPR, VPL>(acc, row, lig, x, ldx, out, ldo, ep);
 }
 
-// one wave per work item of the row-split table
+// First launch of a split table: one wave per work item (a whole row, or one <= chunk-entry slice of a long row)
 template <typename T, int LPR, int VPL>
 __global__ __launch_bounds__(256) void spmm_items_kernel(bkg_rowsplit rs, const int32_t* __restrict__ col,
                                                          const float* __restrict__ w, const T* __restrict__ x,
                                                          int64_t ldx, float* __restrict__ out, int64_t ldo,
                                                          float* __restrict__ partials, SpmmEpilogue ep) {
   constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL;
+  const int bi = blockIdx.x;
   const int lane = threadIdx.x & 63;
-  int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int item = bi * 4 + (threadIdx.x >> 6);
   if (item >= rs.totals[0]) return;
   item = __builtin_amdgcn_readfirstlane(item);
   const int grp = lane / LPR, lig = lane % LPR;
@@ -241,15 +343,25 @@ __global__ __launch_bounds__(256) void spmm_items_kernel(bkg_rowsplit rs, const 
   }
 }
 
-// long rows: one block per row.  Its 4 * G lane groups each add a strided subset of the row's partial slots (8 loads in
-// flight), the group sums are combined through LDS in group order (a fixed tree: bitwise repeatable), then the
-// epilogue.  (One lane group per row walked a hub row's ~150 slots serially: 20 us per launch for a handful of rows.)
-template <typename T, int LPR, int VPL>
-__global__ __launch_bounds__(256) void spmm_fixup_kernel(bkg_rowsplit rs, const T* __restrict__ x, int64_t ldx,
+// Second launch of a split table.  Blocks [0, n_long_max): long rows, one block per row.  Its 4 * G lane groups each
+// add a strided subset of the row's partial slots (8 loads in flight), the group sums are combined through LDS in group
+// order (a fixed tree: bitwise repeatable), then the epilogue.  (One lane group per row walked a hub row's ~150 slots
+// serially: 20 us per launch for a handful of rows.)  Blocks from n_long_max on: the packed table's short rows,
+// 256 / LS per block (spmm_short_rows).  (The two roles in ONE launch with the item waves, interleaved block by block,
+// was measured and lost: the union of their register needs costs the item waves two of their seven slots per SIMD --
+// 254 against 174 us on the bench graph's segments.)
+template <typename T, int LPR, int VPL, int LS, int VS>
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(bkg_rowsplit rs, const float* __restrict__ w,
+                                                         const T* __restrict__ x, int64_t ldx,
                                                          float* __restrict__ out, int64_t ldo,
                                                          const float* __restrict__ partials, SpmmEpilogue ep) {
   constexpr int G = 64 / LPR, NG = 4 * G, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, d = EPL * LPR * VPL;
   __shared__ __attribute__((aligned(16))) float red[NG * d];
+  if (blockIdx.x >= (unsigned)rs.n_long_max) {      // block-uniform
+    const int i = ((int)blockIdx.x - (int)rs.n_long_max) * (256 / LS) + (int)threadIdx.x / LS;
+    spmm_short_rows<T, LS, VS>(i, rs.totals[3], rs.short_desc, rs.short_col, w, x, ldx, out, ldo, ep, (int)threadIdx.x % LS);
+    return;
+  }
   const int l = blockIdx.x;
   if (l >= rs.totals[2]) return;    // block-uniform
   const int lane = threadIdx.x & 63, lig = lane % LPR, gi = (threadIdx.x >> 6) * G + lane / LPR;
@@ -329,14 +441,27 @@ struct SpmmArgs {
   int n_rows; const bkg_rowsplit* split; float* partials; SpmmEpilogue ep; hipStream_t s;
 };
 
+// lanes per SHORT row for a row of LPR * VPL pieces: two pieces per lane where the width allows (16 lanes x 2 pieces for
+// the d = 256 bf16 table: 4 rows per wave, all 8 entries of each in flight), never fewer than 4 lanes
+template <int LPR, int VPL> struct ShortShape {
+  static constexpr int P = LPR * VPL, C = P / 2;                        // candidate: two pieces per lane
+  static constexpr bool OK = P % 2 == 0 && C >= 4 && C <= 64 && 64 % C == 0;
+  static constexpr int LS = OK ? C : LPR, VS = OK ? 2 : VPL;
+};
+
 template <typename T, int LPR, int VPL>
 static void launch_spmm(const SpmmArgs<T>& a) {
   if (a.split) {
-    constexpr int G = 64 / LPR;
-    hipLaunchKernelGGL((spmm_items_kernel<T, LPR, VPL>), dim3(ceil_div(a.split->n_items_max, 4)), dim3(256), 0, a.s,
-                       *a.split, a.col, a.w, a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
-    hipLaunchKernelGGL((spmm_fixup_kernel<T, LPR, VPL>), dim3((unsigned)a.split->n_long_max), dim3(256), 0, a.s,
-                       *a.split, a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
+    using SS = ShortShape<LPR, VPL>;
+    static_assert(SS::LS * SS::VS == LPR * VPL && 64 % SS::LS == 0, "short-row shape");
+    const int nb_items = ceil_div(a.split->n_items_max, 4);
+    const int64_t nb_short = a.split->short_desc ? ceil_div(a.split->n_short_max, 256 / SS::LS) : 0;
+    if (nb_items > 0)
+      hipLaunchKernelGGL((spmm_items_kernel<T, LPR, VPL>), dim3(nb_items), dim3(256), 0, a.s, *a.split, a.col, a.w, a.x,
+                         a.ldx, a.out, a.ldo, a.partials, a.ep);
+    if (a.split->n_long_max + nb_short > 0)
+      hipLaunchKernelGGL((spmm_fixup_kernel<T, LPR, VPL, SS::LS, SS::VS>), dim3((unsigned)(a.split->n_long_max + nb_short)),
+                         dim3(256), 0, a.s, *a.split, a.w, a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
   } else {
     hipLaunchKernelGGL((spmm_csr_kernel<T, LPR, VPL>), dim3(ceil_div(a.n_rows, 4)), dim3(256), 0, a.s, a.rowptr, a.col,
                        a.w, a.x, a.ldx, a.out, a.ldo, a.n_rows, a.ep);

@@ -39,30 +39,59 @@ SPLIT_CHUNK = 256        # entries per work item of a long row (csrc/rowsplit.hi
 SPLIT_MIN_NNZ = 1 << 15  # below this one wave per row is fine and the table is not worth building
 
 
+TIGHT_GRIDS = __import__("os").environ.get("BKG_TIGHT_GRIDS", "1") != "0"
+
+
 class RowSplit:
     """Device work-item table cutting rows longer than ``SPLIT_CHUNK`` entries (``bkg_rowsplit``)."""
 
-    def __init__(self, rowptr, n_rows, nnz, chunk=SPLIT_CHUNK):
+    def __init__(self, rowptr, n_rows, nnz, chunk=SPLIT_CHUNK, pack=False, col=None):
+        """``pack``: rows of <= 8 entries leave the item list for ``short_desc`` (csrc/rowsplit.hip) -- the tables
+        ``bkg_spmm_csr_f32`` walks finish them several per wave; the KGE kernels' tables stay one row per item."""
         dev = rowptr.device
+        self.pack = bool(pack) and col is not None
         self.n_items_max = n_rows + nnz // chunk
         self.n_slots_max = 2 * (nnz // chunk) + 2
         self.n_long_max = nnz // chunk + 1
-        cnt, scan = _i32(3 * (n_rows + 1), dev), _i32(3 * (n_rows + 1), dev)
+        self.n_short_max = n_rows if self.pack else 0
+        cnt, scan = _i32(4 * (n_rows + 1), dev), _i32(4 * (n_rows + 1), dev)
         self.bufs = [_i32(self.n_items_max, dev) for _ in range(4)] + [_i32(self.n_long_max, dev) for _ in range(3)]
-        self.totals = torch.zeros(3, dtype=torch.int32, device=dev)
+        self.short_desc = _i32(4 * self.n_short_max, dev) if self.pack else None
+        self.short_col = _i32(8 * self.n_short_max, dev) if self.pack else None
+        self.totals = torch.zeros(4, dtype=torch.int32, device=dev)
         ws_bytes = L.lib().bkg_sort_workspace_bytes(max(n_rows + 1, 1))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        L.call("bkg_rowsplit_build", L.ptr(rowptr), n_rows, nnz, chunk, L.ptr(cnt), L.ptr(scan),
-               *[L.ptr(b) for b in self.bufs], L.ptr(self.totals), L.ptr(ws), ws_bytes, L.stream())
-        self.c = L.RowSplitStruct(*[b.data_ptr() for b in self.bufs], self.totals.data_ptr(), self.n_items_max,
-                                  self.n_slots_max, self.n_long_max)
+        L.call("bkg_rowsplit_build", L.ptr(rowptr), n_rows, nnz, chunk, int(self.pack), L.ptr(cnt), L.ptr(scan),
+               *[L.ptr(b) for b in self.bufs], L.ptr(self.short_desc), L.ptr(col) if self.pack else None,
+               L.ptr(self.short_col), L.ptr(self.totals), L.ptr(ws), ws_bytes, L.stream())
+        self.c = L.RowSplitStruct(*[b.data_ptr() for b in self.bufs], L.ptr(self.short_desc), L.ptr(self.short_col),
+                                  self.totals.data_ptr(),
+                                  self.n_items_max, self.n_slots_max, self.n_long_max, self.n_short_max)
+
+        self.exact = False
+        if TIGHT_GRIDS and not torch.cuda.is_current_stream_capturing():
+            self.tighten()
+
+    def tighten(self):
+        """Replace the launch bounds (array-size upper bounds: no host read needed to build the table) by the table's
+        actual counts -- ONE host read per table, i.e. per graph structure, never per step.  On the bench graph's
+        (relation, target) segments the bounds are 288 k items for 57 k real ones; the 58 k dead blocks cost ~20 us of
+        each 190 us launch.  Skipped while a stream is being captured (the captured mini-batch steps keep the bounds)."""
+        n_items, n_slots, n_long, n_short = self.totals.tolist()
+        self.n_items_max, self.n_long_max, self.n_short_max = n_items, n_long, n_short
+        self.n_slots_max = max(n_slots, 1)
+        self.c.n_items_max, self.c.n_slots_max, self.c.n_long_max, self.c.n_short_max = n_items, self.n_slots_max, n_long, n_short
+        self.exact = True
 
     def partials(self, d, device):
         return torch.empty(self.n_slots_max, d, dtype=torch.float32, device=device)
 
 
-def rowsplit_for(rowptr, n_rows, nnz):
-    return RowSplit(rowptr, n_rows, nnz) if nnz >= SPLIT_MIN_NNZ else None
+PACK_SHORT_ROWS = __import__("os").environ.get("BKG_PACK_SHORT_ROWS", "1") != "0"
+
+
+def rowsplit_for(rowptr, n_rows, nnz, pack=False, col=None):
+    return RowSplit(rowptr, n_rows, nnz, pack=pack and PACK_SHORT_ROWS, col=col) if nnz >= SPLIT_MIN_NNZ else None
 
 
 class CSR:
@@ -73,7 +102,7 @@ class CSR:
     @property
     def split(self):
         if self._split is False:
-            self._split = rowsplit_for(self.rowptr, self.n_rows, self.nnz)
+            self._split = rowsplit_for(self.rowptr, self.n_rows, self.nnz, pack=True, col=self.col)
         return self._split
 
     def __init__(self, key, other, n_rows):
@@ -222,7 +251,7 @@ class RelGraph(_EdgeHolder):
         # target -> its segments
         self.dst_csr = CSR(self.seg_dst.to(torch.int64), _iota64(s, dev), n)
         self.seg_iota_ptr = iota(s + 1, torch.int32, dev)            # 0 .. s
-        self.seg_split = rowsplit_for(self.seg_ptr, s, e)
+        self.seg_split = rowsplit_for(self.seg_ptr, s, e, pack=True, col=self.src_sorted)
         self._n_src = n if n_src is None else int(n_src)
         if not defer_source_side:
             self.build_source_side()

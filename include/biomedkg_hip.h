@@ -70,7 +70,8 @@ int bkg_rgcn_edge_order(const uint32_t* perm, const int32_t* seg_of, const float
 /* Long-row splitting of a CSR for the segment-reduce kernels: rows longer than `chunk` entries are cut
  * into chunks summed by separate waves (partials added in chunk order by a second pass).  All arrays are
  * sized by the upper bounds n_items_max = n_rows + nnz/chunk, n_slots_max = 2*(nnz/chunk) + 2,
- * n_long_max = nnz/chunk + 1; totals[3] = {n_items, n_slots, n_long} stays on the device (no host sync). */
+ * n_long_max = nnz/chunk + 1, n_short_max = n_rows; totals[4] = {n_items, n_slots, n_long, n_short} stays on the
+ * device (no host sync). */
 typedef struct bkg_rowsplit {
   const int32_t* item_row;   /* [n_items_max] */
   const int32_t* item_beg;   /* [n_items_max] entry range of the item */
@@ -79,12 +80,21 @@ typedef struct bkg_rowsplit {
   const int32_t* long_row;   /* [n_long_max] */
   const int32_t* long_slot0; /* [n_long_max] first slot of the row */
   const int32_t* long_cnt;   /* [n_long_max] number of slots */
-  const int32_t* totals;     /* [3] device */
-  int64_t n_items_max, n_slots_max, n_long_max;
+  const int32_t* short_desc; /* [n_short_max][4] {row, first entry, length, 0} of the rows with <= 8 entries when the table
+                                was built with pack != 0 (16-byte aligned; they are then NOT in the item list), else NULL */
+  const int32_t* short_col;  /* [n_short_max][8] their column indices, padded with the row's last one (16-byte aligned) */
+  const int32_t* totals;     /* [4] device: n_items, n_slots, n_long, n_short */
+  int64_t n_items_max, n_slots_max, n_long_max, n_short_max;
 } bkg_rowsplit;
-int bkg_rowsplit_build(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int32_t chunk, int32_t* cnt_tmp /*[3*(n_rows+1)]*/,
-                       int32_t* scan_tmp /*[3*(n_rows+1)]*/, int32_t* item_row, int32_t* item_beg, int32_t* item_end,
-                       int32_t* item_slot, int32_t* long_row, int32_t* long_slot0, int32_t* long_cnt, int32_t* totals,
+/* pack != 0 (the tables bkg_spmm_csr_f32 walks): rows of 0..8 entries go to short_desc instead of the item list and are
+ * finished several per wave (one row per group of 4..16 lanes).  0 for the tables the KGE kernels read.
+ * cnt_tmp / scan_tmp: [4 * (n_rows + 1)]. */
+int bkg_rowsplit_build(const int32_t* rowptr, int64_t n_rows, int64_t nnz, int32_t chunk, int32_t pack, int32_t* cnt_tmp,
+                       int32_t* scan_tmp, int32_t* item_row, int32_t* item_beg, int32_t* item_end,
+                       int32_t* item_slot, int32_t* long_row, int32_t* long_slot0, int32_t* long_cnt,
+                       int32_t* short_desc /* [n_rows][4], nullable when pack == 0 */,
+                       const int32_t* col /* [nnz] the CSR's column indices (read when pack != 0) */,
+                       int32_t* short_col /* [n_rows][8], nullable when pack == 0 */, int32_t* totals /* [4] */,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- message passing: out[i,:] = epi(sum_k w[k] x[col[k],:] (+ self_w[i] x[i,:]) (+ addend[i,:]))
