@@ -10,7 +10,8 @@ from biomedkg_amd import graph as G, ops, synthetic  # noqa: E402
 
 ops.set_matmul_precision("bf16")
 dev = "cuda"
-N, D = 130_000, 256
+N, D = 130_000, int(os.environ.get("SEGMEAN_D", "256"))
+GCN = os.environ.get("SEGMEAN_GRAPH", "rgcn") == "gcn"     # the GCN propagate's by-target CSR instead of the segments
 
 
 def t(fn, reps=30):
@@ -36,6 +37,15 @@ def main():
     x = torch.randn(N, D, device=dev).bfloat16()
     g = synthetic.primekg_like(N, 4_000_000, 30, seed=42)
     rg = G.RelGraph(g["edge_index"].to(dev), g["edge_type"].to(dev), N, g["num_relations"])
+    if GCN:
+        gr = G.Graph(g["edge_index"].to(dev), N)
+        c = gr.by_src if os.environ.get("SEGMEAN_BWD") == "1" else gr.by_dst
+        gw = gr.gcn_weights()
+
+        class RG:
+            seg_ptr, src_sorted, num_segments, seg_split = c.rowptr, c.col, N, c.split
+            inv_cnt = gw.w_src if os.environ.get("SEGMEAN_BWD") == "1" else gw.w_dst
+        rg = RG
     run = lambda: ops.spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, x, rg.num_segments, split=rg.seg_split, out_dtype=torch.bfloat16)  # noqa: E731
     out = run().float()
     ref = reference(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, x, rg.num_segments)
@@ -48,7 +58,7 @@ def main():
     sp.c.n_items_max, sp.c.n_long_max, sp.c.n_short_max = max(tot[0], 1), max(tot[2], 1), tot[3]
     print(f"real segments, exact grids: {t(run):.1f} us", flush=True)
     sp.c.n_items_max, sp.c.n_long_max, sp.c.n_short_max = keep
-    by = 4e6 * (D * 2 + 8) + rg.num_segments * (D * 2 + 4)
+    by = rg.src_sorted.numel() * (D * 2 + 8) + rg.num_segments * (D * 2 + 4)
     print(f"real segments: S={rg.num_segments} {us:.1f} us  {by / us / 1e6:.2f} TB/s algorithmic  max rel err {err:.2e}", flush=True)
     cfgs = {}
     for chunk in (64, 128, 256):

@@ -245,6 +245,65 @@ def gen_kge():
     save("kge_steps", out)
 
 
+# --------------------------------------------------------------------------- checkpoint (BASELINE configs[4])
+def gen_ckpt():
+    """A checkpoint as Lightning 2.2.3 lays it out, written from the reference's OWN ``KGEModule`` (rgcn + transe,
+    node_init_method = lm, fuse_method = attention -- the DPI fine-tune's starting point, reference train_dpi.py:24-38):
+    ``state_dict`` is the module's own (encoder, decoder, the frozen fuser, and the torchmetrics states the module
+    registers once ``edge_mapping`` is set), ``hyper_parameters`` what ``save_hyperparameters`` recorded
+    (kge_module.py:37).  Beside it: a DPI-shaped evaluation graph, the reference module's embeddings on it with every
+    relation id forced to ``fix_edge_id = 1`` (train_dpi.py:33-35, kge_module.py:112-113) and the filtered MRR / Hits@k
+    of those embeddings by the dense fp64 checker (oracle/ranking.py)."""
+    from biomedkg.kge_module import KGEModule
+    from oracle import ranking
+
+    seed_all(31)
+    n, e, r, h, d_in = 60, 150, 4, 16, 32
+    hp = dict(encoder_name="rgcn", decoder_name="transe", in_dim=d_in, hidden_dim=h, out_dim=h, num_hidden_layers=2,
+              num_relation=r, num_heads=2, scheduler_type="cosine", learning_rate=1e-3, warm_up_ratio=0.2,
+              fuse_method="attention", neg_ratio=2, node_init_method="lm")
+    mod = KGEModule(**hp)
+    mod.edge_mapping = {0: "drug_drug", 1: "drug_protein", 2: "protein_protein", 3: "disease_protein"}
+    for layer in mod.model.encoder.graph_layers:
+        with torch.no_grad():
+            layer.bias.uniform_(-0.1, 0.1)
+    # a few optimizer steps, so that the saved weights are a trained state and not an initialisation pattern
+    b = Batch()
+    b.x, b.edge_index = lm_features(n, 2, d_in, 31), graph(n, e, 31, with_self_loops=False)
+    b.edge_type = torch.randint(0, r, (e,))
+    opt = torch.optim.Adam(mod.model.parameters(), lr=5e-3)
+    mod.train()
+    with patched_rng(), orand.use(orand.TapeRand()):
+        for _ in range(5):
+            opt.zero_grad()
+            mod.training_step(b).backward()
+            opt.step()
+    mod.eval()
+    ckpt = {"epoch": 4, "global_step": 5, "pytorch-lightning_version": "2.2.3",
+            "state_dict": {k: v.detach().clone() for k, v in mod.state_dict().items()},
+            "hyper_parameters": dict(vars(mod.hparams)), "loops": {}, "callbacks": {}, "optimizer_states": [],
+            "lr_schedulers": []}
+    torch.save(ckpt, os.path.join(HERE, "kge_reference.ckpt"))
+    # DPI-shaped evaluation: bipartite drug -> protein edges made undirected (data_module.py ToUndirected), relation 1
+    g = torch.Generator().manual_seed(77)
+    drugs, prots = torch.arange(0, 25), torch.arange(25, n)
+    src = drugs[torch.randint(0, 25, (70,), generator=g)]
+    dst = prots[torch.randint(0, n - 25, (70,), generator=g)]
+    pairs = torch.unique(torch.stack([src, dst]), dim=1)
+    ei = torch.cat([pairs, pairs.flip(0)], dim=1)
+    et = torch.randint(0, r, (ei.size(1),), generator=g)            # as loaded: mixed ids, overwritten by fix_edge_id
+    x = lm_features(n, 2, d_in, 32)
+    fixed = torch.full_like(et, 1)
+    with torch.no_grad():
+        z = mod(x, ei, fixed)
+    held = pairs[:, ::3]                                            # the queries: every third drug -> protein pair
+    q_et = torch.ones(held.size(1), dtype=torch.int64)
+    want = ranking.transe_ranking(z, mod.model.decoder.rel_emb.detach(), held, q_et, known=(ei, fixed))
+    save("kge_ckpt_eval", dict(hparams=hp, x=x, edge_index=ei, edge_type=et, fix_edge_id=1, z=z.clone(),
+                               eval_edge_index=held, eval_edge_type=q_et, ranking=want,
+                               state_keys=sorted(ckpt["state_dict"].keys())))
+
+
 # --------------------------------------------------------------------------- metric
 def gen_metric():
     from biomedkg.utils.metrics import EdgeWisePrecision
@@ -302,6 +361,7 @@ if __name__ == "__main__":
     gen_fusion()
     gen_gcl()
     gen_kge()
+    gen_ckpt()
     gen_metric()
     gen_triplets()
     # the reference tree must stay clean

@@ -194,3 +194,45 @@ def test_c5_dpi_step_transe_1000_negatives_per_positive():
             acc += float(torch.nn.functional.binary_cross_entropy_with_logits(s, torch.full_like(s, label), reduction="sum"))
     ref = acc / total + 1e-2 * float(z.detach().double().pow(2).mean() + rel.pow(2).mean())
     assert abs(float(loss) - ref) <= 1e-5 * max(1.0, abs(ref)), (float(loss), ref)
+
+
+def test_c5_reference_checkpoint_loads_strictly_and_ranks_like_the_reference(golden):
+    """BASELINE configs[4] as written -- "MRR vs reference ckpt" (reference train_dpi.py:24-38): the checkpoint
+    tests/golden/kge_reference.ckpt was written by the reference's OWN ``KGEModule`` (rgcn + transe, lm + attention
+    fuser) in Lightning's layout.  ``KGEModule.load_from_checkpoint(strict=True)`` of this build takes it as it is,
+    ``fix_edge_id = 1`` / ``neg_ratio`` are set the way train_dpi.py does, the embeddings on the DPI-shaped graph equal
+    the reference module's own, and the device ranking evaluation gives the filtered MRR / Hits@k that the dense fp64
+    checker computed on the reference's embeddings -- within 1e-4, the tolerance north_star states."""
+    import os
+    from tests.conftest import GOLDEN
+    from biomedkg_amd.kge_module import KGEModule
+    g = golden("kge_ckpt_eval")
+    path = os.path.join(GOLDEN, "kge_reference.ckpt")
+    mod = KGEModule.load_from_checkpoint(path, strict=True)
+    raw = torch.load(path, weights_only=False)
+    own = mod.state_dict()
+    assert set(raw["state_dict"]) <= set(own)                       # every key of the reference's checkpoint is taken
+    for k, v in raw["state_dict"].items():
+        assert torch.equal(own[k].cpu(), v), k
+    assert {k: getattr(mod.hparams, k) for k in g["hparams"]} == g["hparams"]
+    mod.fix_edge_id = g["fix_edge_id"]                              # train_dpi.py:33-36
+    mod.neg_ratio = 1000
+    mod.edge_mapping = {0: "drug_drug", 1: "drug_protein", 2: "protein_protein", 3: "disease_protein"}
+    mod = mod.to(DEV).eval()
+    b = SimpleNamespace(x=g["x"].to(DEV), edge_index=g["edge_index"].to(DEV),
+                        edge_type=torch.full_like(g["edge_type"], g["fix_edge_id"]).to(DEV))  # (what training_step's overwrite leaves)
+    with torch.no_grad():
+        z = mod(b.x, b.edge_index, b.edge_type)
+    torch.testing.assert_close(z.cpu(), g["z"], rtol=1e-4, atol=1e-5)
+    got = mod.link_prediction_metrics(b, g["eval_edge_index"].to(DEV), g["eval_edge_type"].to(DEV),
+                                      known=(b.edge_index, b.edge_type))
+    assert got["num_queries"] == g["ranking"]["num_queries"]
+    for k in ("MRR", "Hits@1", "Hits@3", "Hits@10"):
+        assert abs(got[k] - g["ranking"][k]) <= 1e-4, (k, got[k], g["ranking"][k])
+    # and one DPI training step from that state (TransE, every relation id forced to 1) runs and is finite
+    mod.neg_ratio = 10
+    mod.train()
+    b.edge_type = g["edge_type"].to(DEV)
+    loss = mod.training_step(b)
+    loss.backward()
+    assert torch.isfinite(loss) and bool((b.edge_type == 1).all())

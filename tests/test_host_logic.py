@@ -131,3 +131,35 @@ def test_edge_bucket_choice_of_the_padded_mini_batch_loop():
     v = SaintDeviceSampler.views(buf, 7, 5)
     assert [k for k in v] == ["sizes", "n_id", "src", "dst", "type", "eid"]
     assert torch.equal(torch.cat([v[k] for k in v]), buf)
+
+
+def test_reference_lightning_checkpoint_loads_strictly():
+    """tests/golden/kge_reference.ckpt: written from the reference's own KGEModule in Lightning's layout
+    (tests/golden/make_goldens.py gen_ckpt).  Strict load, hyper-parameters restored, extra torchmetrics states (which a
+    checkpoint of the real module may carry) ignored, a missing parameter refused."""
+    import os
+    import pytest
+    from biomedkg_amd.kge_module import KGEModule
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kge_reference.ckpt")
+    m = KGEModule.load_from_checkpoint(path, strict=True)
+    ckpt = torch.load(path, weights_only=False)
+    for k, v in ckpt["state_dict"].items():
+        assert torch.equal(m.state_dict()[k], v), k
+    assert m.hparams["decoder_name"] == "transe" and m.hparams["node_init_method"] == "lm" and m.neg_ratio == 2
+    assert type(m.modality_transform).__name__ == "AttentionFusion"
+
+
+def test_checkpoint_with_metric_states_or_missing_weights(tmp_path):
+    import os
+    import pytest
+    from biomedkg_amd.kge_module import KGEModule
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kge_reference.ckpt")
+    ckpt = torch.load(src, weights_only=False)
+    extra = dict(ckpt, state_dict=dict(ckpt["state_dict"], **{"valid_metrics.BinaryAUROC.metrics.0.preds": torch.zeros(3),
+                                                               "edge_wise_pre_valid.true_positive": torch.zeros(4)}))
+    torch.save(extra, tmp_path / "extra.ckpt")
+    KGEModule.load_from_checkpoint(str(tmp_path / "extra.ckpt"), strict=True)
+    short = dict(ckpt, state_dict={k: v for k, v in ckpt["state_dict"].items() if k != "model.decoder.rel_emb"})
+    torch.save(short, tmp_path / "short.ckpt")
+    with pytest.raises(RuntimeError):
+        KGEModule.load_from_checkpoint(str(tmp_path / "short.ckpt"), strict=True)

@@ -111,3 +111,33 @@ def test_edge_wise_precision(golden):
     got = R.edge_wise_precision(g["preds"], g["target"], len(g["mapping"]))
     for c, name in g["mapping"].items():
         assert abs(got[c] - g["result"][name + "_pre"]) < 1e-7
+
+
+def test_reference_checkpoint_embeddings_and_ranking(golden):
+    """BASELINE configs[4] ("MRR vs reference ckpt"): tests/golden/kge_reference.ckpt was written from the reference's
+    own KGEModule in Lightning's layout (make_goldens.py gen_ckpt).  The oracle, loaded from that state_dict, reproduces
+    the reference module's embeddings on the DPI-shaped graph with fix_edge_id = 1, and the dense fp64 ranking checker
+    its recorded filtered MRR / Hits@k."""
+    import os
+    from oracle import ranking
+    from tests.conftest import GOLDEN
+    g = golden("kge_ckpt_eval")
+    ckpt = torch.load(os.path.join(GOLDEN, "kge_reference.ckpt"), weights_only=False)
+    hp = ckpt["hyper_parameters"]
+    assert hp == g["hparams"] and sorted(ckpt["state_dict"]) == g["state_keys"]
+    assert {"state_dict", "hyper_parameters", "epoch", "global_step", "pytorch-lightning_version"} <= set(ckpt)
+    model = R.make_kge_model(hp["encoder_name"], hp["decoder_name"], hp["in_dim"], hp["hidden_dim"], hp["out_dim"],
+                             hp["num_hidden_layers"], hp["num_relation"])
+    model.load_state_dict({k[len("model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")})
+    fuser = R.create_fuser(hp["fuse_method"], hp["in_dim"])
+    fuser.load_state_dict({k[len("modality_transform."):]: v for k, v in ckpt["state_dict"].items()
+                           if k.startswith("modality_transform.")})
+    model.eval()
+    et = torch.full_like(g["edge_type"], g["fix_edge_id"])
+    with torch.no_grad():
+        z = model.encode(R.fusion_fn(fuser, g["x"]), g["edge_index"], et)
+    torch.testing.assert_close(z, g["z"], **TOL)
+    got = ranking.transe_ranking(z, model.decoder.rel_emb.detach(), g["eval_edge_index"], g["eval_edge_type"],
+                                 known=(g["edge_index"], et))
+    for k, v in g["ranking"].items():
+        assert abs(got[k] - v) <= 1e-9, (k, got[k], v)
