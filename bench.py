@@ -245,7 +245,9 @@ def build_partitioned_steps(args, rank, world, dev):
         loss_fn().backward()
     for p in list(gcl.model.parameters()) + list(kge.model.parameters()):
         p.grad = None
-    return make(list(gcl.model.parameters()), ggd_loss), make(list(kge.model.parameters()), kge_loss), n, e, r
+    step_g, step_k = make(list(gcl.model.parameters()), ggd_loss), make(list(kge.model.parameters()), kge_loss)
+    step_g.part = part
+    return step_g, step_k, n, e, r
 
 
 def build_replica_steps(args, rank, world, dev):
@@ -622,6 +624,39 @@ def main():
         return (time.perf_counter() - t) / reps
 
     ms_g, ms_k = timed(step_g) * 1e3, timed(step_k) * 1e3
+
+    exchange = None
+    if mode == "partition":
+        # what crosses the wire per step and how long the compute stream waits for it (events around every wait); then
+        # the same steps with every exchange waited for at once (BKG_PARTITION_SERIAL semantics): all of the collective
+        # time shows as exposed -- the ratio is how much of the exchange the schedule hides
+        part = step_g.part
+        comm = part.comm
+        reps = 3
+
+        def measure(serial):
+            comm.serial, comm.timed = serial, True
+            comm.take_stats()
+            sync(); t = time.perf_counter()
+            for _ in range(reps):
+                step_g(); step_k()
+            sync()
+            wall = (time.perf_counter() - t) / reps * 1e3
+            rx, tx, count, exposed = comm.take_stats()
+            comm.serial, comm.timed = False, False
+            return wall, rx / reps, tx / reps, count / reps, exposed / reps
+        wall_o, rx, tx, count, exposed_o = measure(False)
+        wall_s, _, _, _, exposed_s = measure(True)
+        exchange = {"wire_bytes_received_per_step": rx, "wire_bytes_sent_per_step": tx, "exchanges_per_step": count,
+                    "exchange_exposed_ms": exposed_o, "exchange_serial_ms": exposed_s,
+                    "exposed_fraction": (exposed_o / exposed_s) if exposed_s else None,
+                    "ms_per_step_overlapped": wall_o, "ms_per_step_serial": wall_s,
+                    "halo": {k: {"used": comm.patterns.get(k) is not None, "max_share_of_remote_rows_read": v}
+                             for k, v in part.halo_fraction.items()},
+                    "rows": {"n_local": part.n_local, "n_max": part.n_max, "bounds": part.bounds},
+                    "note": "rank 0's counts; gathers only (forward tables and the backward's gated output gradients, bf16 "
+                            "in bf16 mode) + the scorer's table gather and dz reduce-scatter + the flat gradient all-reduce "
+                            "(not counted here)"}
     n_neg = args.neg_ratio * e
     strong = mode == "partition"
     total_edges = e if strong or world == 1 else world * e
@@ -722,7 +757,7 @@ def main():
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
             "ms_per_step_linear_ggd_head": ms_linear_head,
             "ms_per_step_fresh_structures": ms_fresh,
-            "roofline": roof, "kernels": others,
+            "roofline": roof, "kernels": others, "exchange": exchange,
             "cpu_baseline": None,
         }
         def extra(fn, *a):      # the side figures never cost the headline line: a failure is reported in its place

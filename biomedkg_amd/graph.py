@@ -211,13 +211,16 @@ class RelGraph(_EdgeHolder):
     """
 
     def __init__(self, edge_index, edge_type, num_nodes, num_relations, n_src=None, static_segments=False,
-                 defer_source_side=False):
+                 defer_source_side=False, edge_weight=None):
         """``n_src``: number of SOURCE rows when they live in another index space than the ``num_nodes`` targets (a
         node-partitioned graph: sources are slots of the all-gathered table, targets the rank's own nodes).
         ``static_segments`` (padded mini-batches of a captured step, biomedkg_amd/sampled.py): no host read of the
         segment count -- the structure always carries ``E`` segments, the ones past the real count are EMPTY rows of
-        the last relation, their targets spread over the nodes: zero rows in, zeros added."""
-        L.require_cuda(edge_index, edge_type)
+        the last relation, their targets spread over the nodes: zero rows in, zeros added.
+        ``edge_weight`` (fp32, edge order): per-edge weights INSTEAD of the segment means' ``1 / |segment|`` -- the
+        backward side of a node-partitioned layer (biomedkg_amd/partition.py) regroups the forward's weighted edges by
+        (relation, source)."""
+        L.require_cuda(edge_index, edge_type, edge_weight)
         self._hold(edge_index.contiguous())
         self.edge_type = edge_type.contiguous()
         dev = edge_index.device
@@ -241,6 +244,8 @@ class RelGraph(_EdgeHolder):
             L.call("bkg_rgcn_segments", L.ptr(sorted_keys), e, n, L.ptr(flag), L.ptr(scan), L.ptr(self.seg_of),
                    L.ptr(seg_ptr), L.ptr(seg_dst), L.ptr(seg_rel), L.ptr(self.inv_cnt), L.ptr(n_seg), L.ptr(ws),
                    ws.numel(), L.stream())
+        if edge_weight is not None:
+            L.call("bkg_gather_f32", L.ptr(edge_weight), L.ptr(perm), L.ptr(self.inv_cnt), e, L.stream())
         self.num_segments = e if static_segments else int(n_seg.item())   # one host sync per distinct graph (sizes H)
         s = self.num_segments
         self.seg_ptr, self.seg_dst, self.seg_rel = seg_ptr[: s + 1], seg_dst[:s], seg_rel[:s]

@@ -530,6 +530,23 @@ def _dims(graph):
     return getattr(graph, "n_out", n), getattr(graph, "n_table", n), comm
 
 
+def _exchanged_product(comm, n_rows, d_out, dtype, device, make_rows):
+    """A node-partitioned layer's gather table: ``make_rows(lo, hi, out)`` writes rows ``[lo, hi)`` of the rank's product
+    into ``out``; every finished row chunk leaves for its readers while the next one is computed (halo patterns; the
+    plain all-gather moves the whole shard after the last chunk).  -> the ``[world * n_max, d_out]`` table."""
+    buf = comm.shard_buffer(d_out, dtype, device)
+    chunks = comm.chunks("in")
+    pending = []
+    for c, (lo, hi) in enumerate(chunks):
+        if hi > lo:
+            make_rows(lo, hi, buf[lo:hi])
+        pending.append(comm.exchange_begin(buf, "in", chunk=c if len(chunks) > 1 else None))
+    table = None
+    for p in pending:
+        table = comm.exchange_end(p)
+    return table
+
+
 class _GcnConv(torch.autograd.Function):
     """``dropout(relu(A_hat (x W^T) + b))`` -- PyG GCNConv + the encoder's ReLU/dropout
     (reference biomedkg/model/encoder.py:153-162) fused into the aggregation epilogue.  ``x`` is fp32 or (a hidden
@@ -544,12 +561,15 @@ class _GcnConv(torch.autograd.Function):
         if x.dtype == torch.bfloat16 and not _xw_ok(x, n_rows, d_out, d_in):
             x = x.float()                      # shapes the streaming product does not take: widen once
         if bf16_storage() and _bf16_ok(d_out) and _xw_ok(x, n_rows, d_out, d_in):
-            xw = gemm(x, weight, trans_b=True, out_dtype=torch.bfloat16,      # only ever read as the gather table
-                      out=comm.shard_buffer(d_out, torch.bfloat16, x.device) if comm else None)
+            if comm is not None:          # row chunks of the product leave for their readers while the next one runs
+                xw = _exchanged_product(comm, n_rows, d_out, torch.bfloat16, x.device,
+                                        lambda lo, hi, out: gemm(x[lo:hi], weight, trans_b=True, out_dtype=torch.bfloat16, out=out))
+            else:
+                xw = gemm(x, weight, trans_b=True, out_dtype=torch.bfloat16)      # only ever read as the gather table
         else:
             xw = _table(gemm(x, weight, trans_b=True))
-        if comm is not None:
-            xw = comm.all_gather(xw)
+            if comm is not None:
+                xw = comm.exchange(xw, "in")
         c = graph.by_dst
         out16 = hidden and _hidden_bf16_ok(n_rows, d_out)
         out = spmm(c.rowptr, c.col, gw.w_dst, xw, n_rows, self_w=gw.self_w, bias=bias, relu=relu, drop=drop,
@@ -583,13 +603,17 @@ class _GcnConv(torch.autograd.Function):
         # dXW feeds only the two products below: keep it as a bf16 table when both can take one
         d_out, d_in = weight.size(0), weight.size(1)
         x16 = x.dtype == torch.bfloat16
-        to16 = (comm is None and bf16_storage() and _bf16_ok(d_out) and n_rows >= 4096
+        to16 = (bf16_storage() and _bf16_ok(d_out) and n_rows >= 4096
                 and ((d_out + 63) // 64) * ((d_in + 63) // 64) <= 256
                 and (not ctx.needs_input_grad[0] or _bf16_operand_ok(n_rows, d_in, d_out)))
-        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split,
-                   out_dtype=torch.bfloat16 if to16 else torch.float32)
         if comm is not None:
-            dxw = comm.reduce_scatter(dxw)            # fp32 partial tables summed at their owners
+            # node-partitioned: the (gated, bf16) output gradient goes to the ranks whose out-edges point at it, and this
+            # rank sums the table gradient of ITS OWN rows over its out-edge CSR -- the single-GPU sum, no reduce-scatter
+            dout_t, rows = comm.exchange(dout, "out"), n_rows
+        else:
+            dout_t, rows = dout, n_table
+        dxw = spmm(c.rowptr, c.col, gw.w_src, dout_t, rows, self_w=gw.self_w, split=c.split,
+                   out_dtype=torch.bfloat16 if to16 else torch.float32)
         dx = None
         if ctx.needs_input_grad[0]:
             if x16 and _xw_ok(dxw, n_rows, d_in, d_out):
@@ -690,10 +714,14 @@ class _GcnConvViews(torch.autograd.Function):
             table = x2 if x2.is_contiguous() else x2.contiguous()
         else:
             d_in, d_out = weight.size(1), weight.size(0)
-            buf = comm.shard_buffer(views * d_out, torch.bfloat16, x2.device) if comm else None
-            table = gemm(x2.view(views * n, d_in), weight, trans_b=True, out_dtype=torch.bfloat16,
-                         out=buf[:n].view(views * n, d_out) if comm else None)
-            table = comm.all_gather(buf) if comm else table.view(n, views * d_out)
+            if comm is not None:
+                xr = x2.view(views * n, d_in)
+                table = _exchanged_product(comm, n, views * d_out, torch.bfloat16, x2.device,
+                                           lambda lo, hi, out: gemm(xr[views * lo:views * hi], weight, trans_b=True,
+                                                                    out_dtype=torch.bfloat16,
+                                                                    out=out.view(views * (hi - lo), d_out)))
+            else:
+                table = gemm(x2.view(views * n, d_in), weight, trans_b=True, out_dtype=torch.bfloat16).view(n, views * d_out)
         c = graph.by_dst
         out = spmm(c.rowptr, c.col, gw.w_dst, table, n, self_w=gw.self_w, bias=bias.repeat(views), relu=relu, drop=drop,
                    tag="gcn_propagate_views", split=c.split, out_dtype=torch.bfloat16 if hidden else torch.float32)
@@ -720,17 +748,21 @@ class _GcnConvViews(torch.autograd.Function):
         else:
             dout = to_bf16(_as_f32(dout) * ctx.keep * ctx.scale)
         c = g.by_src
-        exchange = comm is not None and not ctx.is_table     # a gathered input table: its producer owns the exchange
-        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split,
-                   out_dtype=torch.float32 if exchange else torch.bfloat16)
         d_out = dout.size(1) // v
         db = None
         if ctx.needs_input_grad[2]:        # the views share the bias: their column sums added
             db = cs.view(v, d_out).sum(0) if cs is not None else colsum(dout.view(v * n, d_out))
-        if ctx.is_table:
-            return dxw.to(ctx.table_dtype), None, db, None, None, None, None, None, None, None
-        if exchange:
-            dxw = comm.reduce_scatter(dxw)
+        if comm is not None:               # gather dOut, sum the table gradient of the rank's own rows (see _GcnConv)
+            dxw = spmm(c.rowptr, c.col, gw.w_src, comm.exchange(dout, "out"), n, self_w=gw.self_w, split=c.split,
+                       out_dtype=torch.bfloat16)
+            if ctx.is_table:               # a gathered input table: only the rank's own slots carry a gradient
+                full = torch.zeros(n_table, dxw.size(1), dtype=ctx.table_dtype, device=dxw.device)
+                comm.own_rows(full)[:n] = dxw
+                return full, None, db, None, None, None, None, None, None, None
+        else:
+            dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split, out_dtype=torch.bfloat16)
+            if ctx.is_table:
+                return dxw.to(ctx.table_dtype), None, db, None, None, None, None, None, None, None
         d_in = weight.size(1)
         dxw_rows = dxw.view(v * n, d_out)
         dx = (gemm(dxw_rows, weight, out_dtype=x2.dtype).view(n, v * d_in) if ctx.needs_input_grad[0] else None)
@@ -772,13 +804,13 @@ class _RgcnConv(torch.autograd.Function):
             table = _table(x)
             pending = None
         else:
-            pending = comm.all_gather_begin(_table(x))                               # crosses xGMI ...
+            pending = comm.exchange_begin(_table(x), "in")                           # crosses xGMI ...
         # ... under the [N, out] root term: a bf16 table where the layer's own output is one (a hidden layer of bf16 mode:
         # every value of the sum is rounded to bf16 right after it), fp32 for the encoder's output layer
         xr16 = (hidden and _hidden_bf16_ok(n, d_out) and x.dtype == torch.bfloat16 and _xw_ok(x, n, d_out, d_in))
         xr = gemm(x, root, out_dtype=torch.bfloat16) if xr16 else gemm(x, root)
         if pending is not None:
-            table = comm.all_gather_end(pending)
+            table = comm.exchange_end(pending)
         h16 = bf16_storage() and _bf16_ok(d_in) and _bf16_operand_ok(rg.num_segments, d_out, d_in)
         h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, table, rg.num_segments, tag="rgcn_segment_mean",
                  split=rg.seg_split, out_dtype=torch.bfloat16 if h16 else torch.float32)   # [S, in]  segment means
@@ -846,6 +878,33 @@ class _RgcnConv(torch.autograd.Function):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 dweight, droot, db = weight_grads()
+        if comm is not None:
+            # node-partitioned: dOut (bf16) goes to the ranks whose out-edges point at it while the weight / root / bias
+            # gradients -- all local -- are computed; then the table gradient of the rank's OWN rows is regrouped from the
+            # gathered dOut: (relation, source) segment sums with the forward's edge weights, products with W_r^T,
+            # per-source sum + the root part.  The forward's three kernels over rg.rev; nothing is reduce-scattered.
+            pending = comm.exchange_begin(dout, "out") if ctx.needs_input_grad[0] else None
+            dweight, droot, db = weight_grads()
+            dx = None
+            if ctx.needs_input_grad[0]:
+                x16 = x.dtype == torch.bfloat16 and _bf16_ok(d_in)
+                b16 = dout.dtype == torch.bfloat16
+                dx_root = gemm(dout, root, trans_b=True,
+                               out_dtype=torch.bfloat16 if (x16 and b16 and _xw_ok(dout, n, d_in, d_out)) else torch.float32)
+                dtable = comm.exchange_end(pending)
+                rev = rg.rev
+                t16 = b16 and bf16_storage() and _bf16_ok(d_out) and _bf16_operand_ok(rev.num_segments, d_in, d_out)
+                t = spmm(rev.seg_ptr, rev.src_sorted, rev.inv_cnt, dtable, rev.num_segments, split=rev.seg_split,
+                         out_dtype=torch.bfloat16 if t16 else torch.float32)
+                s16 = bf16_storage() and _bf16_ok(d_in) and _xw_ok(t, t.size(0), d_in, d_out)
+                dxs = gemm_grouped_rows(t, weight, rev.rel_ptr, trans_b=True,
+                                        out_dtype=torch.bfloat16 if s16 else torch.float32)
+                c = rev.dst_csr
+                dx = spmm(c.rowptr, c.col, None, dxs, n, addend=dx_root, split=c.split,
+                          out_dtype=torch.bfloat16 if x16 else torch.float32)
+                if dx.dtype != x.dtype:
+                    dx = dx.to(x.dtype)
+            return dx, dweight, droot, db, None, None, None, None
         # the input gradient: on a partitioned graph its table part goes out while the weight gradients run
         dx, pending, dx_root = None, None, None
         if ctx.needs_input_grad[0]:
@@ -858,21 +917,15 @@ class _RgcnConv(torch.autograd.Function):
                                        out_dtype=torch.bfloat16 if to16 else torch.float32)   # [S, in], a gather table
             c = rg.src_csr
             x16 = x.dtype == torch.bfloat16 and _bf16_ok(d_in)
-            if comm is None:
-                # [N, in]; bf16 where dx itself leaves as a bf16 table
-                root16 = x16 and dout.dtype == torch.bfloat16 and _xw_ok(dout, n, d_in, d_out)
-                dx_root = gemm(dout, root, trans_b=True, out_dtype=torch.bfloat16 if root16 else torch.float32)
-                dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), n_table, addend=dx_root, split=c.split,
-                          out_dtype=torch.bfloat16 if x16 else torch.float32)
-            else:
-                pending = comm.reduce_scatter_begin(spmm(c.rowptr, c.col, rg.src_w, _table(dh), n_table, split=c.split))
-                dx_root = gemm(dout, root, trans_b=True)
+            # [N, in]; bf16 where dx itself leaves as a bf16 table
+            root16 = x16 and dout.dtype == torch.bfloat16 and _xw_ok(dout, n, d_in, d_out)
+            dx_root = gemm(dout, root, trans_b=True, out_dtype=torch.bfloat16 if root16 else torch.float32)
+            dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), n_table, addend=dx_root, split=c.split,
+                      out_dtype=torch.bfloat16 if x16 else torch.float32)
         if branch:
             main.wait_stream(side)
         else:
             dweight, droot, db = weight_grads()
-        if pending is not None:
-            dx = comm.reduce_scatter_end(pending) + dx_root
         if dx is not None and dx.dtype != x.dtype:
             dx = dx.to(x.dtype)
         return dx, dweight, droot, db, None, None, None, None
@@ -1094,7 +1147,7 @@ class _KgeBceLoss(torch.autograd.Function):
     segment reduce for dz.  Returns ``(loss, pos_pred, neg_pred)``; the preds are detached outputs."""
 
     @staticmethod
-    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total, reg, inv_total, rows):
+    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total, reg, inv_total, rows, reg_rows=None):
         d, r = z.size(1), rel_emb.size(0)
         t_pos, t_neg = pos_ei.size(1), neg_ei.size(1)
         if total is None:
@@ -1148,6 +1201,7 @@ class _KgeBceLoss(torch.autograd.Function):
         if drel is None:
             drel = torch.zeros_like(rel_emb)
         ctx.kind, ctx.comm, ctx.reg = kind, comm, float(reg)
+        ctx.reg_rows = reg_rows
         ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
         ctx.n_real = rows
         ctx.padded = padded
@@ -1161,7 +1215,8 @@ class _KgeBceLoss(torch.autograd.Function):
             return out, scores[0], scores[1]
         loss = part.sum(dtype=torch.float64) / total
         if reg:      # + reg * (mean(z^2) + mean(rel_emb^2)), reference kge_module.py:128-129: two one-launch norms
-            loss = loss + reg * (torch.linalg.vector_norm(z).double().pow(2) / z.numel()
+            z_rows = z.size(0) if reg_rows is None else reg_rows        # a partitioned step: the mean over N / world rows
+            loss = loss + reg * (torch.linalg.vector_norm(z).double().pow(2) / (z_rows * z.size(1))
                                  + torch.linalg.vector_norm(rel_emb).double().pow(2) / rel_emb.numel())
         return loss.float(), scores[0], scores[1]
 
@@ -1205,14 +1260,19 @@ class _KgeBceLoss(torch.autograd.Function):
                 L.call("bkg_scale_add_rows_f32", L.ptr(dz), dz.stride(0), L.ptr(z_reg), z_reg.stride(0), n, d, L.ptr(gl),
                        2.0 * ctx.reg / d, L.ptr(ctx.n_real), L.stream())
             elif ctx.reg and gloss.numel() == 1 and z_reg.dtype == torch.float32 and z_reg.shape == dz.shape:
-                # dz * gloss + (2 reg / numel) * gloss * z in one in-place launch (dz is this op's own buffer)
+                # dz * gloss + (2 reg / numel) * gloss * z in one in-place launch (dz is this op's own buffer); the kernel
+                # divides by the rows it is given: a partitioned step's mean runs over reg_rows rows instead
+                ratio = 1.0 if ctx.reg_rows is None else dz.size(0) / ctx.reg_rows
+                if not dz.is_contiguous() or dz.data_ptr() % 16:
+                    dz = dz.contiguous()
                 gl = gloss.reshape(1).float().contiguous()
                 L.call("bkg_scale_add_rows_f32", L.ptr(dz), dz.stride(0), L.ptr(z_reg), z_reg.stride(0), dz.size(0), d,
-                       L.ptr(gl), 2.0 * ctx.reg / d, None, L.stream())
+                       L.ptr(gl), 2.0 * ctx.reg / d * ratio, None, L.stream())
             else:
                 dz = dz * gloss
                 if ctx.reg:
-                    dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / z_reg.numel()))
+                    z_rows = z_reg.size(0) if ctx.reg_rows is None else ctx.reg_rows
+                    dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / (z_rows * z_reg.size(1))))
         drel_out = None
         if ctx.needs_input_grad[1]:
             if ctx.padded:
@@ -1224,32 +1284,33 @@ class _KgeBceLoss(torch.autograd.Function):
                 drel_out = drel * gloss
                 if ctx.reg:
                     drel_out = torch.addcmul(drel_out, rel_emb, gloss * (2.0 * ctx.reg / rel_emb.numel()))
-        return dz, drel_out, None, None, None, None, None, None, None, None, None, None
+        return dz, drel_out, None, None, None, None, None, None, None, None, None, None, None
 
 
 def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind, comm=None, total=None,
-                 reg=0.0, inv_total=None, rows=None):
+                 reg=0.0, inv_total=None, rows=None, reg_rows=None):
     """``comm`` (node-partitioned training, biomedkg_amd/partition.py): ``z`` is the rank's shard, the triplet ids are
     slots of the all-gathered table; ``total``: the count the BCE sum is divided by (default: this call's triplets);
     ``reg``: adds ``reg * (mean(z^2) + mean(rel_emb^2))`` (the reference's L2 term) inside the same op.
     ``inv_total`` / ``rows`` (padded mini-batches of a captured step, biomedkg_amd/sampled.py): the BCE sum is multiplied
     by the DEVICE scalar ``inv_total``, triplets with relation id ``R`` (one past the real ones) are pads, and the mean
-    of ``z^2`` runs over the first ``rows`` rows (an int64 DEVICE scalar)."""
+    of ``z^2`` runs over the first ``rows`` rows (an int64 DEVICE scalar).  ``reg_rows`` (partitioned steps): the number
+    of rows the mean of ``z^2`` is taken over when ``z`` is a shard (N / world: the bucket average is the whole mean)."""
     L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, inv_total)
     for ei, et, what in ((pos_edge_index, pos_edge_type, "positive"), (neg_edge_index, neg_edge_type, "negative")):
         if ei.dim() != 2 or ei.size(0) != 2 or et.dim() != 1 or et.numel() != ei.size(1):
             # (the reference fails here too -- a broadcast error in decode -- e.g. when negative_sampling comes back
             # with fewer pairs than neg_ratio * E on a tiny dense batch; the kernels index one by the other)
             raise ValueError(f"{what} triplets: edge_index {tuple(ei.shape)} and edge_type {tuple(et.shape)} do not match")
-    if reg and comm is not None:
-        raise ValueError("the L2 term of a partitioned step is scaled by the caller (partition.kge_loss_partitioned)")
+    if reg and comm is not None and reg_rows is None:
+        raise ValueError("the L2 term of a partitioned step needs reg_rows = N / world (the rows its mean runs over)")
     if inv_total is not None and (comm is not None or inv_total.dtype != torch.float32 or rows is None
                                   or rows.dtype != torch.int64):
         raise ValueError("inv_total (padded mini-batches): a float32 device scalar together with rows = the real row "
                          "count as an int64 device scalar; no comm on that path")
     return _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
                              neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, comm, total, float(reg),
-                             inv_total, rows)
+                             inv_total, rows, reg_rows)
 
 
 # ----------------------------------------------------------------------------- NT-Xent

@@ -1,17 +1,31 @@
 """Node-partitioned full-graph training across the GPUs of one node (BASELINE configs[3]): rank p owns a
-contiguous range of nodes -- chosen so that every rank holds about E/P in-edges -- stores the CSR rows (all in-edges)
-and the activations of its nodes, and keeps a full replica of the weights.  Nothing here has a reference counterpart:
-the reference's only multi-GPU mode is Lightning DDP over mini-batches (``bench.py --mode replicas``).
+contiguous range of nodes -- chosen so that every rank holds about the same number of incident edges -- stores the CSR
+rows of its nodes' IN-edges (forward) and OUT-edges (backward) and the activations of its nodes, and keeps a full replica
+of the weights.  Nothing here has a reference counterpart: the reference's only multi-GPU mode is Lightning DDP over
+mini-batches (``bench.py --mode replicas``).
 
-Exchange, per conv layer (``Comm``): an ALL-GATHER of the layer's gather table (GCN: after the ``x W^T`` transform, so
-the wire carries ``out`` columns; R-GCN: the layer input) and, in the backward pass, the REDUCE-SCATTER of the table's
-gradient (fp32 partial tables summed at their owners).  Both are issued asynchronously and waited for where the data is
-needed: the R-GCN root product runs under the all-gather, the root / weight-gradient products under the reduce-scatter.
-In bf16 mode the tables cross xGMI as bf16 (half the bytes).  Weight gradients are averaged with the flat bucket of
-``distributed.GradBucket``; losses are scaled by ``world / global count`` so that this AVERAGE is the gradient of the
-whole-graph loss.  NT-Xent is ROW partitioned (``ntxent_partitioned``): the normalised rows and the row sums D are
-all-gathered, each rank runs its anchor rows against all columns; because W_ij = E_ij (1/D_i + 1/D_j) is symmetric no
-gradient has to be sent back.
+Exchange (``Comm``): **gathers only, bf16 on the wire, no reduce-scatter anywhere.**
+
+* forward, per conv layer: the rank's rows of the gather table (GCN: after the ``x W^T`` transform, so the wire carries
+  ``out`` columns; R-GCN: the layer input) go to the ranks whose in-edges read them;
+* backward, per conv layer: the rank's rows of the (gated, bf16) OUTPUT gradient go to the ranks whose out-edges point at
+  them, and every rank computes the table gradient of ITS OWN rows from its out-edge CSR:
+  ``dXW[j] = sum over out-edges (j -> i) of w_ji dOut[i]`` -- the same sum the single-GPU layer runs, so the partitioned
+  backward is the single-GPU arithmetic.  (Round 2 reduce-scattered fp32 partial tables ``A_loc^T dOut`` instead: four
+  times the bytes of this bf16 gather, plus an ``[N, d]`` fp32 scratch table per layer and rank.)  R-GCN's table gradient
+  is regrouped the same way: ``dX[s] = sum_r (sum over out-edges s -> i of type r of dOut[i] / |N_r(i)|) W_r^T`` -- a
+  (relation, source) segment reduce of the gathered ``dOut``, the per-relation products with ``W_r^T``, a per-source sum:
+  the forward's three kernels over the reversed local graph;
+* ``HaloPattern``: which rows each peer needs is known to every rank (all hold the edge list), so only THOSE rows travel
+  (one ``all_to_all_single`` with per-peer counts, packed by a row gather, landed by a row scatter); where nearly all
+  rows are needed anyway -- a randomly wired graph -- the pattern falls back to the plain all-gather (no pack / unpack);
+* every exchange is begin / end split: R-GCN's root product runs under the input gather, its weight-gradient products
+  under the gather of ``dOut``; GCN's product is cut into row chunks whose rows leave while the next chunk is computed.
+
+Weight gradients are averaged with the flat bucket of ``distributed.GradBucket``; losses are scaled by
+``world / global count`` so that this AVERAGE is the gradient of the whole-graph loss.  NT-Xent is ROW partitioned
+(``ntxent_partitioned``): the normalised rows and the row sums D are all-gathered, each rank runs its anchor rows against
+all columns; because W_ij = E_ij (1/D_i + 1/D_j) is symmetric no gradient has to be sent back.
 
 Padded slot space: shards are padded to ``n_max`` rows so that the gathered table is one ``[world * n_max, d]`` matrix and
 node g lives at ``slot(g) = owner(g) * n_max + (g - lo_owner)``; the local CSRs are built directly over slots, so no
@@ -32,64 +46,199 @@ import torch.distributed as dist
 
 
 # ----------------------------------------------------------------------------- exchange
-class Comm:
-    """The collective pair of one partition: padded-shard all-gather and its reduce-scatter, begin / end split so that
-    independent kernels run while the bytes cross xGMI (RCCL runs the collective on its own stream; ``end`` makes the
-    current stream wait for it)."""
+class HaloPattern:
+    """Who needs which rows.  ``needed_by [world, N]`` (bool, the same on every rank): rank q's CSRs reference node g.
+    From it every rank derives its side of the exchange without talking to anybody: the rows it sends to each peer
+    (ascending node id) and the table slots where each peer's rows land (the same order) -- whole, and cut into
+    ``CHUNKS`` row ranges per owner (chunk c of rank q = its local rows ``[c n_q / CHUNKS, (c + 1) n_q / CHUNKS)``) for
+    producers that hand their rows over while still computing the next ones."""
 
-    def __init__(self, world, n_local, n_max, group=None):
-        self.world, self.n_local, self.n_max, self.group = int(world), int(n_local), int(n_max), group
+    CHUNKS = 4
+
+    def __init__(self, part, needed_by):
+        rank, world, b = part.rank, part.world, part.bounds
+        self.world = world
+        dev = needed_by.device
+        k = self.CHUNKS
+        cut = lambda q, c: b[q] + ((b[q + 1] - b[q]) * c) // k                                     # noqa: E731
+        self.chunk_rows = [(cut(rank, c) - b[rank], cut(rank, c + 1) - b[rank]) for c in range(k)]  # my local row ranges
+        self.parts = []                      # per chunk: (send_rows, send_counts, recv_slots, recv_counts)
+        for c in range(k):
+            send, recv, sc, rc = [], [], [], []
+            for q in range(world):
+                if q == rank:
+                    sc.append(0); rc.append(0)
+                    continue
+                lo, hi = cut(rank, c), cut(rank, c + 1)
+                mine = torch.nonzero(needed_by[q, lo:hi]).squeeze(1) + (lo - b[rank])            # my rows q reads
+                lo, hi = cut(q, c), cut(q, c + 1)
+                theirs = torch.nonzero(needed_by[rank, lo:hi]).squeeze(1) + (lo - b[q]) + q * part.n_max   # slots
+                send.append(mine); recv.append(theirs)
+                sc.append(int(mine.numel())); rc.append(int(theirs.numel()))
+            cat = lambda parts: (torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)).contiguous()  # noqa: E731
+            self.parts.append((cat(send), sc, cat(recv), rc))
+        # the whole exchange at once: per peer, the chunks' lists one after the other
+        self.send_counts = [sum(p[1][q] for p in self.parts) for q in range(world)]
+        self.recv_counts = [sum(p[3][q] for p in self.parts) for q in range(world)]
+
+        def whole(idx, cnt):
+            out = []
+            for q in range(world):
+                for c in range(k):
+                    off = sum(self.parts[c][cnt][:q])
+                    out.append(self.parts[c][idx][off:off + self.parts[c][cnt][q]])
+            return torch.cat(out).contiguous() if out else torch.zeros(0, dtype=torch.int64, device=dev)
+        self.send_rows, self.recv_slots = whole(0, 1), whole(2, 3)
+        self.n_send, self.n_recv = int(self.send_rows.numel()), int(self.recv_slots.numel())
+        # a collective decision: the halo exchange only if EVERY rank reads a clearly smaller part of the others' rows
+        share = []
+        for q in range(world):
+            own = int(needed_by[q, b[q]:b[q + 1]].sum())
+            share.append((int(needed_by[q].sum()) - own) / max(part.num_nodes - (b[q + 1] - b[q]), 1))
+        self.max_fraction = max(share) if world > 1 else 0.0
+
+
+HALO_THRESHOLD = float(os.environ.get("BKG_HALO_THRESHOLD", "0.75"))   # halo exchange when every rank reads <= this share
+
+
+class Comm:
+    """The exchange of one partition: ``exchange_begin`` / ``exchange_end`` move the rank's shard of a node table to the
+    ranks that read it (RCCL / gloo run the collective on their own stream; ``end`` makes the current stream wait for
+    it) and return the ``[world * n_max, d]`` table in slot space.  ``stats`` counts what crossed the wire and, with
+    ``timed``, how long the compute stream waited (``exposed``) -- bench.py's ``wire_bytes_per_step`` /
+    ``exchange_exposed_ms``."""
+
+    def __init__(self, world, n_local, n_max, group=None, rank=0):
+        self.world, self.n_local, self.n_max, self.group, self.rank = int(world), int(n_local), int(n_max), group, int(rank)
         # one rank has nothing to exchange; BKG_PARTITION_FORCE_COLLECTIVES=1 issues the collectives anyway (a 1-rank
         # RCCL group: the way to run the exact collective calls of the N-rank path on a single-GPU box)
         self.live = self.world > 1 or os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1"
+        self.patterns = {}          # name -> HaloPattern (None: every row travels -- the plain all-gather)
+        self.serial = os.environ.get("BKG_PARTITION_SERIAL") == "1"     # begin() waits at once: nothing is hidden
+        self.timed = False
+        self.stats = {"bytes_received": 0, "bytes_sent": 0, "exchanges": 0}
+        self._waits = []            # (event before the wait, event after it) of this step
+
+    # ---- buffers
+    def table_buffer(self, d, dtype, device):
+        """The full ``[world * n_max, d]`` table for a producer to write its rows straight into (``own_rows``): the
+        exchange then fills in the other ranks' rows around them -- no copy of the shard."""
+        return torch.empty(self.world * self.n_max, d, dtype=dtype, device=device)
+
+    def own_rows(self, table):
+        """The rank's ``n_max`` padded rows of a table (the pad rows are never referenced by any CSR)."""
+        return table[self.rank * self.n_max:(self.rank + 1) * self.n_max]
 
     def shard_buffer(self, d, dtype, device):
-        """A padded ``[n_max, d]`` shard for a producer to write its ``n_local`` rows into (the pad rows are never
-        referenced by any CSR: their content is irrelevant)."""
-        return torch.empty(self.n_max, d, dtype=dtype, device=device)
+        """A padded ``[n_max, d]`` shard that IS the rank's slice of a fresh table (``exchange`` recognises it)."""
+        table = self.table_buffer(d, dtype, device)
+        shard = self.own_rows(table)
+        shard._bkg_table = table
+        return shard
 
-    def _padded(self, shard):
-        if shard.size(0) == self.n_max:
-            return shard if shard.is_contiguous() else shard.contiguous()
-        buf = self.shard_buffer(shard.size(1), shard.dtype, shard.device)
-        buf[: shard.size(0)].copy_(shard)
-        return buf
+    def _table_of(self, shard):
+        table = getattr(shard, "_bkg_table", None)
+        if table is not None and table.size(1) == shard.size(1) and table.dtype == shard.dtype:
+            return table
+        if not self.live:                                  # one rank: the (padded) shard IS the table
+            if shard.size(0) == self.n_max:
+                return shard if shard.is_contiguous() else shard.contiguous()
+            table = torch.empty(self.n_max, shard.size(1), dtype=shard.dtype, device=shard.device)
+            table[: shard.size(0)].copy_(shard)
+            return table
+        table = self.table_buffer(shard.size(1), shard.dtype, shard.device)
+        self.own_rows(table)[: shard.size(0)].copy_(shard)
+        return table
 
-    def all_gather_begin(self, shard):
-        shard = self._padded(shard)
+    def chunks(self, pattern):
+        """Row ranges ``[(lo, hi), ...]`` of the rank's shard that ``exchange_begin(.., chunk=c)`` sends one by one; one
+        range (everything) where this pattern moves whole shards."""
+        pat = self.patterns.get(pattern) if self.live else None
+        return pat.chunk_rows if pat is not None else [(0, self.n_local)]
+
+    # ---- the exchange
+    def exchange_begin(self, shard, pattern="in", chunk=None):
+        """Start moving the rank's rows (``shard [n_local | n_max, d]``) to their readers.  ``chunk``: only that row
+        range of ``chunks(pattern)`` leaves now (a product still being computed hands over what is finished); the table
+        is complete once every chunk's ``exchange_end`` has run."""
+        table = self._table_of(shard)
         if not self.live:
-            return shard, None
-        out = torch.empty(self.world * self.n_max, shard.size(1), dtype=shard.dtype, device=shard.device)
-        return out, dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True)
+            return table, None
+        pat = self.patterns.get(pattern)
+        el = table.element_size() * table.size(1)
+        own = self.own_rows(table)
+        if pat is None:
+            # every row travels: the plain all-gather (in place where the backend allows it: the shard already sits at its
+            # offset of the table)
+            src = own if dist.get_backend(self.group) == "nccl" else own.clone()
+            work = dist.all_gather_into_tensor(table, src, group=self.group, async_op=True)
+            self._count(el * self.n_max * (self.world - 1), el * self.n_max * (self.world - 1))
+            return self._issued((table, work, None, None))
+        if chunk is None:
+            send_rows, send_counts, recv_slots, recv_counts = pat.send_rows, pat.send_counts, pat.recv_slots, pat.recv_counts
+        else:
+            send_rows, send_counts, recv_slots, recv_counts = pat.parts[chunk]
+        packed = own.index_select(0, send_rows)
+        recv = torch.empty(sum(recv_counts), table.size(1), dtype=table.dtype, device=table.device)
+        work = dist.all_to_all_single(recv, packed, recv_counts, send_counts, group=self.group, async_op=True)
+        self._count(el * recv.size(0), el * packed.size(0))
+        return self._issued((table, work, recv, recv_slots))
 
-    @staticmethod
-    def all_gather_end(pending):
-        out, work = pending
-        if work is not None:
-            work.wait()
+    def _issued(self, pending):
+        if self.serial:                                    # (measurement: the whole collective shows as exposed time)
+            return self.exchange_end(pending), None
+        return pending
+
+    def exchange_end(self, pending):
+        if pending[1] is None:
+            return pending[0]
+        table, work, recv, recv_slots = pending
+        if self.timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        work.wait()
+        if self.timed:
+            b.record()
+            self._waits.append((a, b))
+        if recv is not None and recv.size(0):
+            table.index_copy_(0, recv_slots, recv)
+        return table
+
+    def exchange(self, shard, pattern="in"):
+        return self.exchange_end(self.exchange_begin(shard, pattern))
+
+    def _count(self, received, sent):
+        self.stats["bytes_received"] += int(received)
+        self.stats["bytes_sent"] += int(sent)
+        self.stats["exchanges"] += 1
+
+    def take_stats(self):
+        """-> (bytes received, bytes sent, exchanges, exposed ms) since the last call (``timed``: synchronises)."""
+        exposed = None
+        if self.timed:
+            torch.cuda.synchronize()
+            exposed = sum(a.elapsed_time(b) for a, b in self._waits)
+        out = (self.stats["bytes_received"], self.stats["bytes_sent"], self.stats["exchanges"], exposed)
+        self.stats = {"bytes_received": 0, "bytes_sent": 0, "exchanges": 0}
+        self._waits = []
         return out
 
+    # ---- the two whole-table collectives that remain (small or once per step)
     def all_gather(self, shard):
-        return self.all_gather_end(self.all_gather_begin(shard))
-
-    def reduce_scatter_begin(self, dtable):
-        """``dtable [world * n_max, d]`` (this rank's contribution to every owner) -> the rank's summed ``[n_local, d]``."""
-        if not self.live:
-            return dtable[: self.n_local], None
-        dtable = dtable if dtable.is_contiguous() else dtable.contiguous()
-        out = torch.empty(self.n_max, dtable.size(1), dtype=dtable.dtype, device=dtable.device)
-        work = dist.reduce_scatter_tensor(out, dtable, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        return out[: self.n_local], work
-
-    @staticmethod
-    def reduce_scatter_end(pending):
-        out, work = pending
-        if work is not None:
-            work.wait()
-        return out
+        """Every row to every rank (NT-Xent's normalised rows; the scorer's embedding table)."""
+        return self.exchange(shard, pattern="all")
 
     def reduce_scatter(self, dtable):
-        return self.reduce_scatter_end(self.reduce_scatter_begin(dtable))
+        """``dtable [world * n_max, d]`` (this rank's contribution to every owner) -> the rank's summed ``[n_local, d]``
+        (the scorer's ``dz``: a rank's triplets touch other ranks' nodes)."""
+        if not self.live:
+            return dtable[: self.n_local]
+        dtable = dtable if dtable.is_contiguous() else dtable.contiguous()
+        out = torch.empty(self.n_max, dtable.size(1), dtype=dtable.dtype, device=dtable.device)
+        dist.reduce_scatter_tensor(out, dtable, op=dist.ReduceOp.SUM, group=self.group)
+        el = dtable.element_size() * dtable.size(1) * self.n_max * (self.world - 1)
+        self._count(el, el)
+        return out[: self.n_local]
 
     def all_gather_vector(self, v_local, fill=0.0):
         """``[n_local]`` (or ``[k, n_local]``) per rank -> ``[k, world * n_max]`` in slot order."""
@@ -103,14 +252,14 @@ class Comm:
         return out.view(self.world, v.size(0), self.n_max).permute(1, 0, 2).reshape(v.size(0), self.world * self.n_max)
 
 
-class _AllGatherRows(torch.autograd.Function):
-    """forward: all-gather of the rank's padded shard; backward: reduce-scatter (sum) of the table gradient."""
+class _GatherRows(torch.autograd.Function):
+    """forward: every rank's rows to every rank (``pattern``); backward: reduce-scatter (sum) of the table gradient.
+    Only for tables whose READERS are not a sparse structure of the graph (the scorer's embedding table)."""
 
     @staticmethod
     def forward(ctx, shard, comm):
         ctx.comm, ctx.dtype = comm, shard.dtype
-        out = comm.all_gather(shard)
-        return out.clone() if out.data_ptr() == shard.data_ptr() else out
+        return comm.all_gather(shard)
 
     @staticmethod
     def backward(ctx, dtable):
@@ -119,22 +268,24 @@ class _AllGatherRows(torch.autograd.Function):
 
 
 def all_gather_rows(shard, comm):
-    return _AllGatherRows.apply(shard, comm)
+    return _GatherRows.apply(shard, comm)
 
 
 # ----------------------------------------------------------------------------- partition
 class NodePartition:
-    """Contiguous node ranges balanced by ``in-degree + node_weight``: the gather / aggregate kernels cost per in-edge,
-    the products, epilogues and row stores per node (about 16 edge-gathers' worth at d = 256), and the floor keeps the
-    ranks that own hub nodes from shrinking to a few hundred rows."""
+    """Contiguous node ranges balanced by ``(in-degree + out-degree) / 2 + node_weight``: the forward's gather /
+    aggregate kernels cost per in-edge, the backward's per out-edge, the products, epilogues and row stores per node
+    (about 16 edge-gathers' worth at d = 256), and the floor keeps the ranks that own hub nodes from shrinking to a few
+    hundred rows.  Holds the two halo patterns of the edge set (``comm.patterns``): ``"in"`` -- the rows the rank's
+    in-edges read (forward tables) -- and ``"out"`` -- the rows its out-edges point at (the gathered ``dOut``)."""
 
     NODE_WEIGHT = 16.0
 
-    def __init__(self, edge_index, num_nodes, rank, world, node_weight=None):
+    def __init__(self, edge_index, num_nodes, rank, world, node_weight=None, halo=None):
         self.num_nodes, self.rank, self.world = int(num_nodes), int(rank), int(world)
         dev = edge_index.device
         self.node_weight = float(self.NODE_WEIGHT if node_weight is None else node_weight)
-        load = torch.bincount(edge_index[1], minlength=num_nodes).double() + self.node_weight
+        load = self.load_of(edge_index, num_nodes, self.node_weight)
         cum = torch.cumsum(load, 0)
         targets = cum[-1] * torch.arange(1, world, device=dev, dtype=torch.float64) / world
         cuts = torch.searchsorted(cum, targets).tolist()          # one host sync, at partition time only
@@ -146,8 +297,27 @@ class NodePartition:
         self.n_local = self.hi - self.lo
         self.n_max = max(max(b - a for a, b in zip(bounds[:-1], bounds[1:])), 1)
         self._bounds_t = torch.tensor(bounds, device=dev, dtype=torch.int64)
-        self.comm = Comm(world, self.n_local, self.n_max)
+        self.comm = Comm(world, self.n_local, self.n_max, rank=rank)
         self._valid = None
+        self.halo_fraction = {}
+        if world > 1:
+            src, dst = edge_index[0], edge_index[1]
+            own_s = torch.bucketize(src, self._bounds_t[1:-1], right=True)
+            own_d = torch.bucketize(dst, self._bounds_t[1:-1], right=True)
+            for name, reader, read in (("in", own_d, src), ("out", own_s, dst)):
+                needed = torch.zeros(world, self.num_nodes, dtype=torch.bool, device=dev)
+                needed[reader, read] = True                       # rank `reader` reads node `read`'s row
+                pat = HaloPattern(self, needed)
+                self.halo_fraction[name] = pat.max_fraction
+                # every rank takes the same decision (max_fraction is a global quantity): halo rows only when that saves
+                # a clear share of the table, else the plain all-gather (no pack / unpack); halo=True / False forces it
+                use = pat.max_fraction <= HALO_THRESHOLD if halo is None else bool(halo)
+                self.comm.patterns[name] = pat if use else None
+
+    @staticmethod
+    def load_of(edge_index, num_nodes, node_weight):
+        deg = torch.bincount(edge_index[1], minlength=num_nodes) + torch.bincount(edge_index[0], minlength=num_nodes)
+        return deg.double() * 0.5 + node_weight
 
     def slots(self, ids):
         """global node ids -> rows of the gathered ``[world * n_max, d]`` table"""
@@ -174,27 +344,32 @@ class NodePartition:
 
 
 class PartitionedGraph:
-    """The rank's slice of ``A_hat = D^-1/2 (A + I) D^-1/2`` (PyG gcn_norm semantics): rows = its nodes,
-    columns = table slots, the unit self loops as explicit entries.  Carries what the fused layers read off a graph
-    (``by_dst`` / ``by_src`` / ``n_out`` / ``n_table`` / ``comm``); ``gcn_weights(keep)`` re-weights the same CSRs for a
-    ``dropout_edge`` view -- global degrees from the full edge list, no communication, nothing re-sorted."""
+    """The rank's slices of ``A_hat = D^-1/2 (A + I) D^-1/2`` (PyG gcn_norm semantics) with the unit self
+    loops as explicit entries: ``by_dst`` -- rows = its nodes as TARGETS, columns = table slots of the sources (forward:
+    ``out = by_dst @ gathered table``) -- and ``by_src`` -- rows = its nodes as SOURCES, columns = table slots of the
+    targets (backward: ``dXW = by_src @ gathered dOut``: every rank sums the table gradient of its own rows, nothing is
+    reduce-scattered).  Carries what the fused layers read off a graph (``by_dst`` / ``by_src`` / ``n_out`` / ``n_table``
+    / ``comm``); ``gcn_weights(keep)`` re-weights the same CSRs for a ``dropout_edge`` view -- global degrees from the full
+    edge list, no communication, nothing re-sorted."""
 
     def __init__(self, part: NodePartition, edge_index, backend, keep=None):
         self.part, self.backend, n = part, backend, part.num_nodes
         self.edge_index = edge_index
         src, dst = edge_index[0], edge_index[1]
-        mine = part.is_local(dst)
-        eid = torch.nonzero(mine).squeeze(1)
-        s, d = src[eid], dst[eid]
+        e = edge_index.size(1)
         own = torch.arange(part.lo, part.hi, device=edge_index.device)
-        col = torch.cat([part.slots(s), part.slots(own)])                   # neighbours + the unit self loop
-        row = torch.cat([d - part.lo, own - part.lo])
-        self._entry = torch.cat([eid, edge_index.size(1) + own])            # entry -> index into cat(w_edge, self_w)
+        own_slot = part.slots(own)
+        eid = torch.nonzero(part.is_local(dst)).squeeze(1)                  # in-edges of my nodes
+        self._entry_in = torch.cat([eid, e + own])                          # entry -> index into cat(w_edge, self_w)
+        self.by_dst = backend.csr(torch.cat([dst[eid] - part.lo, own - part.lo]),      # rows: local targets
+                                  torch.cat([part.slots(src[eid]), own_slot]), part.n_local)   # neighbours + the self loop
+        eid = torch.nonzero(part.is_local(src)).squeeze(1)                  # out-edges of my nodes
+        self._entry_out = torch.cat([eid, e + own])
+        self.by_src = backend.csr(torch.cat([src[eid] - part.lo, own - part.lo]),      # rows: local sources
+                                  torch.cat([part.slots(dst[eid]), own_slot]), part.n_local)
         self.num_nodes = self.n_out = part.n_local
         self.n_table = part.world * part.n_max
         self.comm = part.comm
-        self.by_dst = backend.csr(row, col, part.n_local)                    # rows: local targets
-        self.by_src = backend.csr(col, row, self.n_table)                    # rows: table slots
         self.fwd, self.bwd = self.by_dst, self.by_src
         self._weights = {}
         self._default_keep = keep
@@ -210,61 +385,138 @@ class PartitionedGraph:
         if hit is not None and hit[0] == key:
             return hit[1]
         w_edge, self_w = self.backend.gcn_norm(self.edge_index, self.part.num_nodes, keep)
-        w = torch.cat([w_edge, self_w])[self._entry]
-        out = GcnWeights(self.backend.permute(self.by_dst, w), self.backend.permute(self.by_src, w), None)
+        w = torch.cat([w_edge, self_w])
+        out = GcnWeights(self.backend.permute(self.by_dst, w[self._entry_in]),
+                         self.backend.permute(self.by_src, w[self._entry_out]), None)
         self._weights["kept" if keep is not None else "plain"] = (key, out, keep)   # (keep kept alive: id() stays unique)
         return out
 
 
+class _PartSpmm(torch.autograd.Function):
+    """``epi(fwd @ gather(x_local))`` over a partition (composable form; the product's fused layers do the same inside
+    ``ops``): forward -- the rank's rows go to their readers (pattern "in"), the rank reduces its target rows; backward --
+    the (gated) output gradient goes to ITS readers (pattern "out") and the rank reduces the table gradient of its own
+    rows over its out-edge CSR.  No reduce-scatter."""
+
+    @staticmethod
+    def forward(ctx, x_local, addend, bias, comm, backend, fwd, bwd, w_fwd, w_bwd, relu, drop):
+        table = comm.exchange(x_local, "in")
+        out = backend.spmm_epilogue(fwd, w_fwd, table, fwd.n_rows, addend, bias, relu, drop)
+        ctx.comm, ctx.backend, ctx.bwd, ctx.w_bwd, ctx.relu, ctx.drop = comm, backend, bwd, w_bwd, relu, drop
+        ctx.n_local, ctx.x_dtype = x_local.size(0), x_local.dtype
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dout = ctx.backend.gate(dout, out, ctx.relu, ctx.drop)
+        need = ctx.needs_input_grad
+        dx = None
+        if need[0]:
+            dtable = ctx.comm.exchange(dout.contiguous(), "out")
+            dx = ctx.backend.spmm_epilogue(ctx.bwd, ctx.w_bwd, dtable, ctx.bwd.n_rows, None, None, False, None)
+            dx = dx[: ctx.n_local].to(ctx.x_dtype)
+        return (dx, dout if need[1] else None, dout.sum(0) if need[2] else None, None, None, None, None, None, None, None,
+                None)
+
+
+def part_spmm(x_local, comm, backend, fwd, bwd, w_fwd, w_bwd, addend=None, bias=None, relu=False, drop=None):
+    return _PartSpmm.apply(x_local, addend, bias, comm, backend, fwd, bwd, w_fwd, w_bwd, relu, drop)
+
+
 def gcn_conv_partitioned(x_local, weight, bias, pg: PartitionedGraph, backend, relu=False, drop=None, gw=None):
-    """``dropout(relu(A_hat[local rows] @ all_gather(x_local W^T) + b))`` -> ``[n_local, out]`` (composable form)."""
-    part = pg.part
+    """``dropout(relu(A_hat[local rows] @ gather(x_local W^T) + b))`` -> ``[n_local, out]`` (composable form)."""
     gw = gw if gw is not None else pg.gcn_weights()
     xw = backend.linear(x_local, weight)                                     # transform BEFORE the exchange:
-    table = all_gather_rows(xw, part.comm)                                   # the wire carries `out` columns
-    return backend.spmm_fn(table, pg.by_dst, pg.by_src, gw.w_dst, gw.w_src, part.n_local, bias=bias, relu=relu, drop=drop)
+    return part_spmm(xw, pg.comm, backend, pg.by_dst, pg.by_src, gw.w_dst, gw.w_src, bias=bias, relu=relu, drop=drop)
+
+
+class _RelSide:
+    """(relation, local node) segments over table slots for one direction of the R-GCN layer (composable form):
+    ``seg`` -- rows = segments, columns = table slots, per-entry weights ``seg_w``; ``rows`` -- rows = local nodes,
+    columns = their segments (plain sum); ``rel_ptr`` -- segment ranges per relation; ``seg_node`` -- each segment's
+    local node."""
+
+    def __init__(self, backend, node_local, slot_other, edge_type, w_edge, n_local, num_relations):
+        key = edge_type * max(n_local, 1) + node_local                       # sorted by (relation, local node)
+        uniq, seg_of_edge = torch.unique(key, return_inverse=True)
+        self.num_segments = int(uniq.numel())
+        self.seg_node = uniq % max(n_local, 1)
+        seg_rel = uniq // max(n_local, 1)
+        self.seg = backend.csr(seg_of_edge, slot_other, self.num_segments)
+        self.seg_w = backend.permute(self.seg, w_edge)
+        iota = torch.arange(self.num_segments, device=node_local.device)
+        self.rows = backend.csr(self.seg_node, iota, n_local)
+        self.rel_ptr = torch.searchsorted(seg_rel, torch.arange(num_relations + 1, device=seg_rel.device)).to(torch.int32)
 
 
 class PartitionedRelGraph:
-    """The rank's slice of the R-GCN mean aggregation (PyG RGCNConv aggr="mean"): (relation, local target)
-    segments over table slots, the segment -> target reduction, and their transposes.  With ``HipBackend`` this IS a
-    ``graph.RelGraph`` over (slot sources, local targets), i.e. what ``ops.rgcn_conv`` takes."""
+    """The rank's slices of the R-GCN mean aggregation (PyG RGCNConv aggr="mean").  Forward side: the
+    (relation, local TARGET) segments of the rank's in-edges over the table slots of their sources, mean weights
+    ``1 / |N_r(i)|``.  Backward side: the (relation, local SOURCE) segments of its out-edges over the slots of their
+    targets, each edge carrying the SAME weight it has in the forward (``1 / |N_r(target)|``, a global count every rank
+    derives from the full edge list) -- ``dX[s] = sum_r (sum_e w_e dOut[target_e]) W_r^T`` runs the forward's three
+    kernels over it, so no partial table is ever reduce-scattered.  With ``HipBackend`` both sides are ``graph.RelGraph``
+    objects (``fused`` / ``fused.rev``), i.e. what ``ops.rgcn_conv`` takes."""
 
     def __init__(self, part: NodePartition, edge_index, edge_type, num_relations, backend):
         self.part, self.num_relations = part, int(num_relations)
         src, dst = edge_index[0], edge_index[1]
+        n = part.num_nodes
+        # 1 / |N_r(i)| of every edge: in-edges of type r at its target (global: all edges are known to every rank)
+        _, inv, cnt = torch.unique(edge_type * n + dst, return_inverse=True, return_counts=True)
+        w_edge = 1.0 / cnt[inv].to(torch.float32)
         mine = part.is_local(dst)
-        s, d, t = part.slots(src[mine]), dst[mine] - part.lo, edge_type[mine]
+        outs = part.is_local(src)
         self.n_table = part.world * part.n_max
-        self.fused = backend.rel_graph(torch.stack([s, d]), t, part.n_local, self.num_relations, self.n_table, part.comm)
+        fwd_edges = torch.stack([part.slots(src[mine]), dst[mine] - part.lo])
+        rev_edges = torch.stack([part.slots(dst[outs]), src[outs] - part.lo])
+        self.fused = backend.rel_graph(fwd_edges, edge_type[mine], part.n_local, self.num_relations, self.n_table, part.comm,
+                                       rev=(rev_edges, edge_type[outs], w_edge[outs]))
         if self.fused is not None:
             return
-        key = t * part.n_local + d                                           # segment key, sorted by (rel, target)
-        uniq, seg_of_edge, cnt = torch.unique(key, return_inverse=True, return_counts=True)
-        self.num_segments = int(uniq.numel())
-        seg_dst = uniq % max(part.n_local, 1)
-        seg_rel = uniq // max(part.n_local, 1)
-        w = 1.0 / cnt[seg_of_edge].to(torch.float32)
-        self.seg_fwd = backend.csr(seg_of_edge, s, self.num_segments)        # segment <- table slots (mean)
-        self.seg_bwd = backend.csr(s, seg_of_edge, self.n_table)
-        self.seg_w_fwd, self.seg_w_bwd = backend.permute(self.seg_fwd, w), backend.permute(self.seg_bwd, w)
-        iota = torch.arange(self.num_segments, device=edge_index.device)
-        self.dst_fwd = backend.csr(seg_dst, iota, part.n_local)              # local target <- its segments (sum)
-        self.dst_bwd = backend.csr(iota, seg_dst, self.num_segments)
-        self.rel_ptr = torch.searchsorted(seg_rel, torch.arange(self.num_relations + 1, device=seg_rel.device)
-                                          ).to(torch.int32)
+        self.fwd = _RelSide(backend, fwd_edges[1], fwd_edges[0], edge_type[mine], w_edge[mine], part.n_local, self.num_relations)
+        self.bwd = _RelSide(backend, rev_edges[1], rev_edges[0], edge_type[outs], w_edge[outs], part.n_local, self.num_relations)
+
+
+class _PartRgcn(torch.autograd.Function):
+    """One RGCNConv over the rank's nodes (composable form; ``ops._RgcnConv`` is the product's fused one): forward --
+    gather the layer input (pattern "in"), segment means, per-relation products, per-target sum + root + bias; backward
+    -- local weight / root / bias gradients, then gather ``dOut`` (pattern "out") and regroup: (relation, source)
+    segment sums of it, products with ``W_r^T``, per-source sum + root part."""
+
+    @staticmethod
+    def forward(ctx, x_local, weight, root, bias, prg, backend, relu, drop):
+        comm, f = prg.part.comm, prg.fwd
+        table = comm.exchange(x_local, "in")
+        h = backend.spmm_epilogue(f.seg, f.seg_w, table, f.num_segments, None, None, False, None)
+        y = backend.grouped_linear(h, weight, f.rel_ptr)
+        out = backend.spmm_epilogue(f.rows, None, y, x_local.size(0), backend.matmul(x_local, root), bias, relu, drop)
+        ctx.prg, ctx.backend, ctx.relu, ctx.drop = prg, backend, relu, drop
+        ctx.save_for_backward(x_local, weight, root, h, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x_local, weight, root, h, out = ctx.saved_tensors
+        prg, be = ctx.prg, ctx.backend
+        comm, f, b = prg.part.comm, prg.fwd, prg.bwd
+        dout = be.gate(dout, out, ctx.relu, ctx.drop).contiguous()
+        pending = comm.exchange_begin(dout, "out")                          # crosses the wire under the local products
+        dweight = be.grouped_outer(h, dout[f.seg_node], f.rel_ptr, weight.size(0))        # dW_r = H_r^T dY_r
+        droot = x_local.t() @ dout
+        db = dout.sum(0)
+        dtable = comm.exchange_end(pending)
+        t = be.spmm_epilogue(b.seg, b.seg_w, dtable, b.num_segments, None, None, False, None)
+        dxs = be.grouped_linear(t, weight.transpose(1, 2), b.rel_ptr)
+        dx = be.spmm_epilogue(b.rows, None, dxs, x_local.size(0), dout @ root.t(), None, False, None)
+        return dx, dweight, droot, db, None, None, None, None
 
 
 def rgcn_conv_partitioned(x_local, weight, root, bias, prg: PartitionedRelGraph, backend, relu=False, drop=None):
-    """RGCNConv over the rank's targets (composable form): all-gather the layer input, segment means, per-relation
-    products, per-target sum, + root term + bias, ReLU / dropout in the last epilogue."""
-    part = prg.part
-    table = all_gather_rows(x_local, part.comm)
-    h = backend.spmm_fn(table, prg.seg_fwd, prg.seg_bwd, prg.seg_w_fwd, prg.seg_w_bwd, prg.num_segments)
-    y = backend.grouped_linear(h, weight, prg.rel_ptr)
-    xr = backend.matmul(x_local, root)
-    return backend.spmm_fn(y, prg.dst_fwd, prg.dst_bwd, None, None, part.n_local, addend=xr, bias=bias, relu=relu,
-                           drop=drop)
+    """RGCNConv over the rank's targets (composable form)."""
+    return _PartRgcn.apply(x_local, weight, root, bias, prg, backend, relu, drop)
 
 
 # ----------------------------------------------------------------------------- encoders over shards
@@ -336,10 +588,16 @@ class HipBackend:
         return graph_of(edge_index, num_nodes).gcn_norm_raw(keep)
 
     @staticmethod
-    def rel_graph(slot_edges, edge_type, n_local, num_relations, n_table, comm):
+    def rel_graph(slot_edges, edge_type, n_local, num_relations, n_table, comm, rev=None):
         from .graph import RelGraph
-        rg = RelGraph(slot_edges.contiguous(), edge_type.contiguous(), n_local, num_relations, n_src=n_table)
+        live = rev is not None and comm is not None and comm.live      # one rank: the ordinary single-GPU backward
+        rg = RelGraph(slot_edges.contiguous(), edge_type.contiguous(), n_local, num_relations, n_src=n_table,
+                      defer_source_side=live)
         rg.n_out, rg.n_table, rg.comm = n_local, n_table, comm
+        if live:                 # the backward side: (relation, local source) segments over the targets' slots, forward weights
+            r_edges, r_type, r_w = rev
+            rg.rev = RelGraph(r_edges.contiguous(), r_type.contiguous(), n_local, num_relations, n_src=n_table,
+                              defer_source_side=True, edge_weight=r_w.to(torch.float32).contiguous())
         return rg
 
     @staticmethod
@@ -350,17 +608,55 @@ class HipBackend:
     @staticmethod
     def matmul(x, w):
         from . import ops
-        return ops.linear(x, w.t())          # root is stored [in, out]
+        return ops.gemm(x, w)
 
     @staticmethod
-    def spmm_fn(table, fwd, bwd, w_fwd, w_bwd, n_out, addend=None, bias=None, relu=False, drop=None):
+    def gcn_conv(x_local, weight, bias, pg, gw, relu=False, drop=None):
         from . import ops
-        return ops.spmm_fn(table, fwd, bwd, w_fwd, w_bwd, n_out, addend=addend, bias=bias, relu=relu, drop=drop)
+        return ops.gcn_conv(x_local, weight, bias, pg, gw, relu=relu, drop=drop)
 
     @staticmethod
-    def grouped_linear(h, weight, group_ptr):
+    def table_conv(table, bias, pg, gw, relu=False, drop=None):
+        return _TableConv.apply(table, bias, pg.comm, HipBackend, pg.by_dst, pg.by_src, gw.w_dst, gw.w_src, relu, drop)
+
+    @staticmethod
+    def spmm_epilogue(csr, w, table, n_out, addend, bias, relu, drop):
         from . import ops
-        return ops.grouped_linear(h, weight, group_ptr)
+        return ops.spmm(csr.rowptr, csr.col, w, ops._table(table), n_out, addend=addend, bias=bias, relu=relu, drop=drop,
+                        split=csr.split)
+
+    @staticmethod
+    def gate(dout, out, relu, drop):
+        from . import ops
+        scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
+        if not relu and scale == 1.0:
+            return dout
+        if not relu:
+            raise ValueError("dropout without a ReLU in front is not on the reference's path")
+        return ops._gate(ops._as_f32(dout), ops._as_f32(out), scale)
+
+
+class _TableConv(torch.autograd.Function):
+    """``epi(by_dst @ table)`` for a table that is ALREADY gathered (GGD's paired first product): the gradient handed
+    back has the rank's own slots filled (``by_src @ gathered dOut``) and zeros elsewhere -- ``_PairedTable`` knows."""
+
+    @staticmethod
+    def forward(ctx, table, bias, comm, backend, fwd, bwd, w_fwd, w_bwd, relu, drop):
+        out = backend.spmm_epilogue(fwd, w_fwd, table, fwd.n_rows, None, bias, relu, drop)
+        ctx.comm, ctx.backend, ctx.bwd, ctx.w_bwd, ctx.relu, ctx.drop, ctx.shape = comm, backend, bwd, w_bwd, relu, drop, table.shape
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        comm = ctx.comm
+        dout = ctx.backend.gate(dout, out, ctx.relu, ctx.drop).contiguous()
+        dtable = comm.exchange(dout, "out")
+        own = ctx.backend.spmm_epilogue(ctx.bwd, ctx.w_bwd, dtable, ctx.bwd.n_rows, None, None, False, None)
+        g = own.new_zeros(ctx.shape)
+        (comm.own_rows(g) if comm.live else g)[: own.size(0)] = own
+        return g, dout.sum(0), None, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- whole training steps over shards
@@ -375,6 +671,34 @@ def _ggd_head(ggd, pos_h, neg_h, backend, total, world):
     return torch.nn.functional.binary_cross_entropy_with_logits(pred, gt, reduction="sum") * (world / total)
 
 
+class _PairedTable(torch.autograd.Function):
+    """GGD's first layer over a partition.  ``x[perm] W^T = (x W^T)[perm]``: the corrupted view needs ARBITRARY rows of
+    the first product, so that one table is all-gathered whole (h columns, once for both views) and paired on every
+    rank: slot j -> ``[xw_j | xw_perm(j)]``.  Backward: the consumer hands back the table gradient of the rank's OWN
+    slots (both halves; ``ops.gcn_conv_views(is_table=True)`` / ``part_spmm`` compute nothing else); the corrupted
+    halves belong to other nodes' rows -- ``d xw[k] = dT_pos[k] + dT_neg[perm^-1(k)]`` -- so they are all-gathered (h
+    columns, bf16 in bf16 mode) and every rank picks the rows of its own nodes.  No reduce-scatter."""
+
+    @staticmethod
+    def forward(ctx, xw_local, perm_slots, comm, pair):
+        table = comm.all_gather(xw_local)
+        ctx.comm, ctx.n_local, ctx.h = comm, xw_local.size(0), xw_local.size(1)
+        ctx.save_for_backward(perm_slots)
+        return pair(table, perm_slots)
+
+    @staticmethod
+    def backward(ctx, g):
+        (perm_slots,) = ctx.saved_tensors
+        comm, h = ctx.comm, ctx.h
+        own = comm.own_rows(g) if comm.live else g                          # [n_max, 2h]: the only rows that are filled
+        neg_all = comm.all_gather(own[:, h:].contiguous())                  # [n_table, h]
+        inv = torch.empty_like(perm_slots)
+        inv[perm_slots] = torch.arange(perm_slots.numel(), device=perm_slots.device)
+        mine = comm.own_rows(inv) if comm.live else inv                     # perm^-1 of the rank's own slots
+        d = own[:, :h].float() + neg_all[mine].float()
+        return d[: ctx.n_local].to(g.dtype), None, None, None
+
+
 def ggd_loss_partitioned(ggd, x_local, pg: PartitionedGraph, backend, perm, dropout_of=None, keep=None, mask_feature=None):
     """``GGDModule.calculate_loss`` (reference gcl_module.py:229-234, gcl.py:73-93) for the rank's nodes: both encoder
     passes run over the rank's shard, the BCE terms of the local nodes are summed and divided by the GLOBAL count, times
@@ -382,7 +706,7 @@ def ggd_loss_partitioned(ggd, x_local, pg: PartitionedGraph, backend, perm, drop
     rows of the (possibly feature-masked) input; ``perm``: the corruption permutation of all N nodes and ``keep``: the
     optional ``dropout_edge`` mask over all E edges (every rank must pass the same ones).  The corrupted pass never
     needs other ranks' input rows: ``x[perm] W^T = (x W^T)[perm]``, so the permutation is applied to the gathered table
-    of the FIRST layer's product (the wire carries h columns once for both views)."""
+    of the FIRST layer's product (``_PairedTable``: the wire carries h columns once for both views)."""
     part = pg.part
     total = 2.0 * part.num_nodes
     enc = ggd.encoder
@@ -391,9 +715,11 @@ def ggd_loss_partitioned(ggd, x_local, pg: PartitionedGraph, backend, perm, drop
     node_slots = part.node_slots()
     perm_slots[node_slots] = node_slots[perm]                               # slot(j) -> slot(perm[j]): a bijection
     layer0 = enc.graph_layers[0]
+    last = len(enc.graph_layers) - 1
+    n_loc = part.n_local
     if backend.fused:
         from . import ops
-        n_loc, n_dec = part.n_local, part.n_max        # the path is chosen from rank-invariant sizes: all ranks alike
+        n_dec = part.n_max                              # the path is chosen from rank-invariant sizes: all ranks alike
         if (ops.bf16_storage() and x_local.dim() == 2 and x_local.size(1) % 256 == 0 and len(enc.graph_layers) >= 2
                 and all(ops.views_ok(n_dec, l.in_channels, l.out_channels, 2) for l in enc.graph_layers[1:])
                 and ops.views_ok(n_dec, 256, layer0.out_channels, 2)):
@@ -401,9 +727,7 @@ def ggd_loss_partitioned(ggd, x_local, pg: PartitionedGraph, backend, perm, drop
             if ops.features_bf16_ok(x_local):
                 x_local = ops.cached_bf16(x_local)
             xw = ops.xw_table(x_local, layer0.lin.weight)                   # [n_local, h] bf16
-            table = all_gather_rows(xw, part.comm)                          # [n_table, h]: ONE exchange for both views
-            h = ops.pair_rows(table, perm_slots)                            # slot j: [xw_j | xw_perm(j)]
-            last = len(enc.graph_layers) - 1
+            h = _PairedTable.apply(xw, perm_slots, part.comm, ops.pair_rows)    # slot j: [xw_j | xw_perm(j)], whole table
             for i, layer in enumerate(enc.graph_layers):
                 drop = None
                 if i != last and enc.drop_out and enc.training and dropout_of is not None:
@@ -421,21 +745,39 @@ def ggd_loss_partitioned(ggd, x_local, pg: PartitionedGraph, backend, perm, drop
             pred = torch.cat([s[:, 0], s[:, 1]])
             gt = torch.cat([torch.ones_like(s[:, 0]), torch.zeros_like(s[:, 1])])
             return torch.nn.functional.binary_cross_entropy_with_logits(pred, gt, reduction="sum") * (part.world / total)
-    # composable form: first layer by hand (shared product, permuted table), the rest through the stack
+    # composable form: the shared first product paired over the whole table, then the two views one after the other
     xw = backend.linear(x_local, layer0.lin.weight)
-    table = all_gather_rows(xw, part.comm)
+    hdim = xw.size(1)
+    paired = _PairedTable.apply(xw, perm_slots, part.comm,
+                                lambda table, ps: torch.cat([table, table[ps]], dim=1))      # [n_table, 2h]
     outs = []
-    for t in (table, table[perm_slots]):
-        drop = (dropout_of(part.n_local, layer0.out_channels, t.device)
-                if (dropout_of is not None and enc.drop_out and enc.training) else None)
-        h = backend.spmm_fn(t, pg.by_dst, pg.by_src, gw.w_dst, gw.w_src, part.n_local, bias=layer0.bias, relu=True, drop=drop)
-        last = len(enc.graph_layers) - 1
+    for v in range(2):
+        t = _TableView.apply(paired, v, hdim)                                # this view's table, [n_table, h]
+        drop = (dropout_of(n_loc, layer0.out_channels, t.device)
+                if (dropout_of is not None and enc.drop_out and enc.training and last > 0) else None)
+        h = backend.table_conv(t, layer0.bias, pg, gw, relu=(last > 0), drop=drop)
         for i, layer in enumerate(enc.graph_layers[1:], start=1):
-            drop = (dropout_of(part.n_local, layer.out_channels, h.device)
+            drop = (dropout_of(n_loc, layer.out_channels, h.device)
                     if (i != last and dropout_of is not None and enc.drop_out and enc.training) else None)
-            h = gcn_conv_partitioned(h, layer.lin.weight, layer.bias, pg, backend, relu=(i != last), drop=drop, gw=gw)
+            h = backend.gcn_conv(h, layer.lin.weight, layer.bias, pg, gw, relu=(i != last), drop=drop)
         outs.append(h)
     return _ggd_head(ggd, outs[0], outs[1], backend, total, part.world)
+
+
+class _TableView(torch.autograd.Function):
+    """Columns ``[v h, (v + 1) h)`` of the paired table; the gradient goes back into its half (own rows only are filled
+    by the consumer, the rest stays zero)."""
+
+    @staticmethod
+    def forward(ctx, paired, v, h):
+        ctx.v, ctx.h, ctx.width = v, h, paired.size(1)
+        return paired[:, v * h:(v + 1) * h].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        out = g.new_zeros(g.size(0), ctx.width)
+        out[:, ctx.v * ctx.h:(ctx.v + 1) * ctx.h] = g
+        return out, None, None
 
 
 def kge_loss_partitioned(model, x_local, prg: PartitionedRelGraph, backend, pos_ei, pos_et, neg_ei, neg_et, kind,
@@ -454,10 +796,11 @@ def kge_loss_partitioned(model, x_local, prg: PartitionedRelGraph, backend, pos_
     total = None
     if n_pos_global is not None:
         total = (n_pos_global + n_neg_global) / part.world
-    ce, _, _ = ops.kge_bce_loss(z_local, rel, ps, pos_et, ns, neg_et, kind, comm=part.comm, total=total)
-    # L2 terms: every rank adds its nodes' share of mean(z^2) (x world for the gradient average) and the full rel term
-    reg = z_local.float().pow(2).sum() * (part.world / (part.num_nodes * z_local.size(1))) + rel.pow(2).mean()
-    return ce + 1e-2 * reg
+    # BCE + the L2 terms in ONE op: every rank adds its nodes' share of mean(z^2) -- sum over its rows / (N / world) rows,
+    # i.e. x world for the gradient average -- and the full rel term (kge_bce_loss(reg_rows=...))
+    loss, _, _ = ops.kge_bce_loss(z_local, rel, ps, pos_et, ns, neg_et, kind, comm=part.comm, total=total, reg=1e-2,
+                                  reg_rows=part.num_nodes / part.world)
+    return loss
 
 
 # ----------------------------------------------------------------------------- NT-Xent, rows partitioned

@@ -1,5 +1,5 @@
 """A torch (CPU) arithmetic backend for biomedkg_amd.partition -- TEST INFRASTRUCTURE ONLY: it lets the gloo tests
-exercise the partition / all-gather / reduce-scatter logic without a GPU.  The product always passes HipBackend."""
+exercise the partition / halo-exchange logic without a GPU.  The product always passes HipBackend."""
 import torch
 import torch.nn.functional as F
 
@@ -25,38 +25,10 @@ def _spmm(csr, w, table, n_out):
     return torch.zeros(n_out, table.size(1), dtype=table.dtype).index_add_(0, csr.rows(), vals)
 
 
-class _SpmmFn(torch.autograd.Function):
-    """Mirrors biomedkg_amd.ops._SpmmFn: the backward really goes through the TRANSPOSED CSR."""
-
-    @staticmethod
-    def forward(ctx, table, addend, bias, fwd, bwd, w_fwd, w_bwd, n_out, relu, keep, scale):
-        out = _spmm(fwd, w_fwd, table, n_out)
-        if addend is not None:
-            out = out + addend
-        if bias is not None:
-            out = out + bias
-        if relu:
-            out = out.relu()
-        if keep is not None:
-            out = out * keep * scale
-        ctx.bwd, ctx.w_bwd, ctx.n_table, ctx.scale, ctx.gated = bwd, w_bwd, table.size(0), scale, relu or keep is not None
-        ctx.save_for_backward(out)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        (out,) = ctx.saved_tensors
-        if ctx.gated:
-            dout = torch.where(out > 0, dout * ctx.scale, torch.zeros(()))
-        need = ctx.needs_input_grad
-        return (_spmm(ctx.bwd, ctx.w_bwd, dout, ctx.n_table) if need[0] else None, dout if need[1] else None,
-                dout.sum(0) if need[2] else None, None, None, None, None, None, None, None, None)
-
-
 class TorchBackend:
     fused = False            # the composable form of biomedkg_amd/partition.py (the product's HipBackend runs the fused layers)
     csr = staticmethod(lambda key, other, n_rows: TorchCSR(key, other, n_rows))
-    rel_graph = staticmethod(lambda *a: None)
+    rel_graph = staticmethod(lambda *a, **k: None)
 
     @staticmethod
     def gcn_norm(edge_index, num_nodes, keep):
@@ -74,15 +46,44 @@ class TorchBackend:
     matmul = staticmethod(lambda x, w: x @ w)
 
     @staticmethod
-    def spmm_fn(table, fwd, bwd, w_fwd, w_bwd, n_out, addend=None, bias=None, relu=False, drop=None):
-        keep = drop.keep if drop is not None else None
+    def spmm_epilogue(csr, w, table, n_out, addend, bias, relu, drop):
+        out = _spmm(csr, w, table, n_out)
+        if addend is not None:
+            out = out + addend
+        if bias is not None:
+            out = out + bias
+        if relu:
+            out = out.relu()
+        if drop is not None:
+            out = out * drop.keep / (1.0 - drop.p)
+        return out
+
+    @staticmethod
+    def gate(dout, out, relu, drop):
         scale = 1.0 / (1.0 - drop.p) if drop is not None else 1.0
-        return _SpmmFn.apply(table, addend, bias, fwd, bwd, w_fwd, w_bwd, n_out, relu, keep, scale)
+        if relu or drop is not None:
+            return torch.where(out > 0, dout * scale, torch.zeros(()))
+        return dout
 
     @staticmethod
     def grouped_linear(h, weight, group_ptr):
         ptr = group_ptr.tolist()
         return torch.cat([h[a:b] @ weight[g] for g, (a, b) in enumerate(zip(ptr[:-1], ptr[1:]))], dim=0)
+
+    @staticmethod
+    def grouped_outer(h, dy, group_ptr, num_groups):
+        ptr = group_ptr.tolist()
+        return torch.stack([h[a:b].t() @ dy[a:b] for a, b in zip(ptr[:-1], ptr[1:])])
+
+    @staticmethod
+    def gcn_conv(x_local, weight, bias, pg, gw, relu=False, drop=None):
+        from biomedkg_amd.partition import gcn_conv_partitioned
+        return gcn_conv_partitioned(x_local, weight, bias, pg, TorchBackend, relu, drop, gw)
+
+    @staticmethod
+    def table_conv(table, bias, pg, gw, relu=False, drop=None):
+        from biomedkg_amd.partition import _TableConv
+        return _TableConv.apply(table, bias, pg.comm, TorchBackend, pg.by_dst, pg.by_src, gw.w_dst, gw.w_src, relu, drop)
 
 
 class TorchNtXentKernels:

@@ -1,7 +1,9 @@
 """Node-partitioned GCN / R-GCN (+ DistMult over all-gathered embeddings) on 2 and 3 gloo ranks vs. the CPU
 oracle on the whole graph: every shard of the output, and every weight gradient after the cross-rank sum,
-must match.  Exercises NodePartition, the padded slot space, the local CSRs and their transposes, and the
-all-gather / reduce-scatter autograd pair.  CPU only (torch arithmetic backend from tests/cpu_backend.py)."""
+must match.  Exercises NodePartition, the padded slot space, the in-edge / out-edge CSRs, the gather-only exchange
+(forward tables AND the backward's output gradients travel as gathers; nothing is reduce-scattered) in both of its
+transports -- the plain all-gather and the halo exchange that moves only the rows a peer's CSRs reference, whole and
+in row chunks.  CPU only (torch arithmetic backend from tests/cpu_backend.py)."""
 import os
 import socket
 import sys
@@ -24,7 +26,7 @@ def _problem():
     return g, torch.randn(400, 24), torch.randn(400, 20)
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, halo):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -35,8 +37,9 @@ def _worker(rank, world, port, outdir):
     D.init_from_env(backend="gloo")
     g, x_gcn, x_rgcn = _problem()
     ei, et, n = g["edge_index"], g["edge_type"], g["num_nodes"]
-    part = P.NodePartition(ei, n, rank, world)
-    res = {"bounds": part.bounds}
+    part = P.NodePartition(ei, n, rank, world, halo=halo)
+    res = {"bounds": part.bounds, "halo_fraction": dict(part.halo_fraction),
+           "halo_used": {k: v is not None for k, v in part.comm.patterns.items()}}
 
     # ---- GCN encoder (eval mode: ReLU between layers, no dropout)
     torch.manual_seed(11)
@@ -52,6 +55,28 @@ def _worker(rank, world, port, outdir):
     for t in grads:
         dist.all_reduce(t)
     res["gcn_out"], res["gcn_grads"] = out.detach(), grads
+    res["gcn_wire"] = part.comm.take_stats()[:3]
+
+    # ---- the exchange itself: every row the rank's CSRs read arrives with its owner's content, whole or in row chunks
+    comm = part.comm
+    shard = part.shard(x_gcn).contiguous()
+    whole = comm.exchange(shard.clone(), "in")
+    buf = comm.shard_buffer(shard.size(1), shard.dtype, shard.device)
+    chunks = comm.chunks("in")
+    pend = []
+    for c, (lo, hi) in enumerate(chunks):
+        buf[lo:hi] = shard[lo:hi]                                       # "computed" chunk by chunk
+        pend.append(comm.exchange_begin(buf, "in", chunk=c if len(chunks) > 1 else None))
+    for pnd in pend:
+        chunked = comm.exchange_end(pnd)
+    slot_node = torch.full((part.world * part.n_max,), -1, dtype=torch.int64)
+    slot_node[part.node_slots()] = torch.arange(n)
+    read = torch.unique(pg.by_dst.col)
+    res["exchange_ok"] = bool(torch.equal(whole[read], x_gcn[slot_node[read]]) and torch.equal(chunked[read], whole[read]))
+    back = torch.unique(pg.by_src.col)                                  # pattern "out": the rows the out-edges point at
+    res["exchange_ok"] &= bool(torch.equal(comm.exchange(shard.clone(), "out")[back], x_gcn[slot_node[back]]))
+    res["chunks"] = len(chunks)
+    comm.take_stats()
 
     # ---- R-GCN encoder + DistMult over the gathered embeddings, triplets sharded over ranks
     torch.manual_seed(12)
@@ -91,20 +116,38 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_encoders_match_whole_graph(tmp_path, world):
+@pytest.mark.parametrize("world,halo", [(2, False), (2, True), (3, True), (3, None)])
+def test_partitioned_encoders_match_whole_graph(tmp_path, world, halo):
     from oracle import ref_modules as R
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), halo), nprocs=world, join=True)
     parts = [torch.load(os.path.join(tmp_path, f"r{i}.pt")) for i in range(world)]
     g, x_gcn, x_rgcn = _problem()
     ei, et = g["edge_index"], g["edge_type"]
     bounds = parts[0]["bounds"]
     assert bounds[0] == 0 and bounds[-1] == 400 and all(p["bounds"] == bounds for p in parts)
     from biomedkg_amd.partition import NodePartition
-    load = torch.bincount(ei[1], minlength=400) + NodePartition.NODE_WEIGHT
+    load = NodePartition.load_of(ei, 400, NodePartition.NODE_WEIGHT)
     shares = [float(load[a:b].sum()) for a, b in zip(bounds[:-1], bounds[1:])]
-    assert max(shares) < 1.3 * sum(shares) / world                       # balanced by in-edges + the per-node weight
+    assert max(shares) < 1.3 * sum(shares) / world                       # balanced by incident edges + the per-node weight
+    # what crossed the wire for the 4-layer GCN encoder (4 forward tables + 4 gathered output gradients, fp32 here):
+    # the halo exchange moves only the rows the peer's CSRs reference, the all-gather every (padded) row
+    n_max = max(b - a for a, b in zip(bounds[:-1], bounds[1:]))
+    for rank, p in enumerate(parts):
+        received, sent, count = p["gcn_wire"]
+        everything = 8 * 16 * 4 * n_max * (world - 1)
+        used = p["halo_used"]
+        assert halo is None or (used["in"] == used["out"] == bool(halo))
+        if used["in"] and used["out"]:
+            own = bounds[rank + 1] - bounds[rank]
+            assert count == 8 and received <= 8 * 16 * 4 * (400 - own) and received < everything
+        elif not used["in"] and not used["out"]:
+            assert count == 8 and received == everything
+        else:
+            assert count == 8 and received < everything
+    assert all(0.0 < f <= 1.0 for f in parts[0]["halo_fraction"].values())
+    assert all(p["exchange_ok"] for p in parts)
+    assert all(p["chunks"] == (4 if p["halo_used"]["in"] else 1) for p in parts)
 
     torch.manual_seed(11)
     enc = R.GCNEncoder(24, 16, 16, 2).eval()
