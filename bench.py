@@ -75,54 +75,67 @@ def parse():
 
 # ----------------------------------------------------------------------------------------------- roofline
 def pmc_traffic(tag, precision):
-    """HBM-side bytes per launch of a tagged kernel from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic.json,
-    scripts/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE x2 correction); the newest file
-    that has the (tag, precision) wins; None if this launch was not profiled."""
+    """Bytes per call that left the XCD L2s for a tagged library call, from the committed rocprofv3 --pmc passes
+    (profiles/*pmc_traffic.json, scripts/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH_SIZE x2
+    correction; a call's launches -- e.g. the item kernel and the fix-up / short-row kernel of one SpMM -- are summed);
+    plus the L2 hit rate of those launches when a TCC_HIT / TCC_MISS pass is there.  The newest file that has the
+    (tag, precision) wins; (None, None) if this call was not profiled."""
     try:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
-            for k in json.load(open(path))["kernels"]:
-                if k.get("tag") == tag and k.get("precision") == precision:
-                    return k["traffic_bytes_per_launch"]
+            hits = [k for k in json.load(open(path))["kernels"] if k.get("tag") == tag and k.get("precision") == precision]
+            if hits:
+                total = sum(k["traffic_bytes_per_launch"] * k.get("launches_per_call", 1) for k in hits)
+                h, m = sum(k.get("tcc_hit", 0) for k in hits), sum(k.get("tcc_miss", 0) for k in hits)
+                return total, (h / (h + m) if (h + m) else None), os.path.basename(path)
     except Exception:  # noqa: BLE001 - reporting only
-        return None
-    return None
+        return None, None, None
+    return None, None, None
 
 
 KERNEL_NAMES = {
-    "rgcn_segment_mean": "spmm_items_kernel<{t},{p},1> + fixup: R-GCN (relation, target) segment-mean gather/aggregate, d={d}",
-    "gcn_propagate": "spmm_items_kernel<{t},{p},1> + fixup: GCN A_hat (X W^T) gather/aggregate, d={d}",
-    "gcn_propagate_views": "spmm_items_kernel<{t},{p},1> + fixup: GCN A_hat (X W^T) gather/aggregate, two GGD views side by "
-                           "side, d={d}",
+    "rgcn_segment_mean": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel (long-row fix-up, short rows): R-GCN (relation, "
+                         "target) segment-mean gather/aggregate, d={d}",
+    "gcn_propagate": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel: GCN A_hat (X W^T) gather/aggregate, d={d}",
+    "gcn_propagate_views": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel: GCN A_hat (X W^T) gather/aggregate, two GGD "
+                           "views side by side, d={d}",
+    "kge_fused_bce": "kge_fused_bce_kernel<{t}>: DistMult scores + BCE terms + d score + d rel_emb partials, one triplet set, d={d}",
+    "kge_bwd_nodes": "kge_bwd_nodes_kernel<{t}> + fixup: dz by per-node segment reduce over the triplet incidences, d={d}",
 }
 
 
 def roofline_of(tag, rec, precision):
-    """One tagged gather / aggregate launch.  ``achieved`` = algorithmic bytes (gathered row + index + weight
-    per entry, stored row + rowptr per output row) / HIP-event time.  The gather table (66-133 MB) is resident in the
-    256 MiB Infinity Cache and its hot rows in the XCD L2s, so the algorithmic rate is NOT bounded by the 8 TB/s HBM
-    figure; what is bounded by it is the traffic that leaves L2 (PMC: FETCH_SIZE x 2 + WRITE_SIZE per launch).  ``peak``
-    is therefore the algorithmic rate this launch would reach if that measured traffic moved at the full HBM rate,
-    ``peak = 8 TB/s x reuse`` with ``reuse = algorithmic bytes / traffic``, and ``frac = achieved / peak`` is exactly the
-    HBM-side fraction ``traffic / time / 8 TB/s``.  For orientation the guide's measured rates for such gathers are
-    listed too (8.6 TB/s from the Infinity Cache, 16.8 TB/s from L2)."""
+    """One tagged gather / aggregate call.  ``achieved`` = algorithmic bytes / HIP-event time on the launch
+    stream.  The gather tables (66-133 MB) are resident in the 256 MiB Infinity Cache and their hot rows in the XCD L2s,
+    so the ALGORITHMIC rate exceeds the 8 TB/s HBM figure (``algorithmic_over_hbm`` > 1): it is not an HBM fraction.
+    What the memory side sees is ``traffic`` = the bytes that left the XCD L2s (PMC FETCH_SIZE x 2 + WRITE_SIZE per
+    call); MI355X_MICROARCH.md "HBM" (l. 297): those counters are the L2's fabric-side requests and Infinity-Cache hits
+    ARE counted in them, so ``l2_miss_GBs = traffic / time`` is L2-miss traffic served by Infinity Cache + HBM together,
+    not HBM alone.  It is reported against both ceilings: ``frac_hbm_spec`` (/ 8 TB/s, the figure north_star's "HBM
+    roofline" names; = ``frac``) and ``frac_mall_gather`` (/ 8.6 TB/s, the guide's measured row-gather rate out of the
+    Infinity Cache)."""
     durs = [a.elapsed_time(b) for a, b in rec["events"]]
     avg_ms = sum(durs) / len(durs)
     gbs = rec["bytes"] / (avg_ms * 1e-3) / 1e9
-    traffic = pmc_traffic(tag, precision)
-    reuse = rec["bytes"] / traffic if traffic else None
-    peak = HBM_PEAK_GBS * reuse if reuse else None
+    traffic, l2_hit, source = pmc_traffic(tag, precision)
+    miss_gbs = (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None
     d = rec.get("d", 0)
-    name = KERNEL_NAMES.get(tag, tag).format(t="__bf16" if precision == "bf16" else "float", p=max(d // 8, 1) if precision == "bf16"
-                                              else max(d // 4, 1), d=d)
-    return {"bound": "hbm", "kernel": name, "tag": tag, "achieved": gbs, "peak": peak, "unit": "GB/s",
-            "frac": (gbs / peak) if peak else None, "traffic": traffic, "reuse": reuse,
-            "hbm_side_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None, "hbm_peak_GBs": HBM_PEAK_GBS,
+    pieces = max(d // 8, 1) if precision == "bf16" else max(d // 4, 1)
+    name = KERNEL_NAMES.get(tag, tag).format(t="__bf16" if precision == "bf16" else "float", p=min(pieces, 64), d=d)
+    return {"bound": "hbm", "kernel": name, "tag": tag, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (miss_gbs / HBM_PEAK_GBS) if miss_gbs else None, "traffic": traffic,
+            "l2_miss_GBs": miss_gbs, "frac_hbm_spec": (miss_gbs / HBM_PEAK_GBS) if miss_gbs else None,
+            "frac_mall_gather": (miss_gbs / MALL_GATHER_GBS) if miss_gbs else None,
+            "algorithmic_over_hbm": gbs / HBM_PEAK_GBS, "reuse": (rec["bytes"] / traffic) if traffic else None,
+            "l2_hit_rate": l2_hit, "pmc_source": source,
             "avg_launch_ms": avg_ms, "launches": len(durs), "ms_total": sum(durs), "bytes_per_launch": rec["bytes"],
-            "grid_size": rec.get("grid"), "pieces": max(d // 8, 1) if precision == "bf16" else max(d // 4, 1),
-            "guide_gather_GBs": {"infinity_cache": MALL_GATHER_GBS, "l2": L2_GATHER_GBS},
-            "peak_definition": "8 TB/s HBM peak x cache reuse (algorithmic bytes / PMC bytes that left L2): frac = HBM-side "
-                               "traffic rate / 8 TB/s; null when no PMC pass of this launch is committed under profiles/"}
+            "grid_size": rec.get("grid"), "grid_size_second_launch": rec.get("grid2"), "pieces": pieces,
+            "guide_GBs": {"hbm_spec": HBM_PEAK_GBS, "hbm_achievable": 6300.0, "infinity_cache_gather": MALL_GATHER_GBS,
+                          "l2_gather": L2_GATHER_GBS},
+            "frac_definition": "frac = frac_hbm_spec = (PMC bytes that left the XCD L2s per call / HIP-event time) / 8 TB/s; "
+                               "those bytes include Infinity-Cache hits (guide l. 297), so this is L2-miss traffic against "
+                               "the HBM spec, an upper bound of the HBM fraction; achieved / peak = algorithmic_over_hbm is "
+                               "NOT a fraction (cache reuse); null when no PMC pass of this call is committed under profiles/"}
 
 
 def rooflines(timers, precision):
@@ -196,6 +209,8 @@ def build_partitioned_steps(args, rank, world, dev):
     share = slice(rank, None, world)                          # this rank's positives (strided: every relation on every rank)
     pos_ei, pos_et = ei[:, share].contiguous(), et[share].contiguous()
     shared = torch.Generator(device=dev).manual_seed(7)       # replicated draws: identical on every rank
+    shared_host = torch.Generator().manual_seed(7)            # ... the augmentation coin: a host draw, no device round trip
+    pos_slots = part.slots(pos_ei).contiguous()               # the positives' rows of the gathered table
     own = torch.Generator().manual_seed(1000 + rank)          # per-rank seeds for the in-kernel streams
     counter = [0]
     from biomedkg_amd import rand as R
@@ -225,7 +240,7 @@ def build_partitioned_steps(args, rank, world, dev):
 
     def ggd_loss(force_aug=None):
         x, keep = xg, None
-        coin = float(torch.rand(1, generator=shared, device=dev)) < gcl.model.p      # reference gcl.py:75-76
+        coin = float(torch.rand(1, generator=shared_host)) < gcl.model.p             # reference gcl.py:75-76
         if coin if force_aug is None else force_aug:
             x = ops.masked_bf16(xg, 0.4, own_seed(), rank) if ops.bf16_storage() else xg * (torch.rand_like(xg) >= 0.4)
             keep = torch.rand(e, generator=shared, device=dev) >= 0.4
@@ -237,7 +252,7 @@ def build_partitioned_steps(args, rank, world, dev):
         neg = sampling.negative_sampling(ei, n, k, seed=own_seed() * world + rank)
         nt = shuffler.shuffle(pos_et.repeat(args.neg_ratio))       # == repeat(..)[randperm(k)] without the sort behind it
         return P.kge_loss_partitioned(kge.model, xk, prg, P.HipBackend, pos_ei, pos_et, neg, nt, kge.model.decoder.kind,
-                                      dropout_of, n_pos_global=e, n_neg_global=args.neg_ratio * e)
+                                      dropout_of, n_pos_global=e, n_neg_global=args.neg_ratio * e, pos_slots=pos_slots)
 
     # both outcomes of GGD's augmentation coin and the KGE step once, untimed: whichever comes first inside the timed
     # region then finds its buffers in the caching allocator (a first-time hipMalloc costs ~100 ms)
@@ -774,9 +789,15 @@ def main():
                 out["sampled_regime"] = extra(sampled_figures, dev, step_k.batch.edge_index, step_k.batch.edge_type, n, r)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = extra(cpu_baseline, args)
-        print(json.dumps(out), flush=True)
     if world > 1 or forced:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        try:      # RCCL writes its version banner through C stdio: flush it out BEFORE the line, which must come last
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:      # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

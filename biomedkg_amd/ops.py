@@ -271,6 +271,28 @@ class Dropout:
 KERNEL_TIMERS = None
 
 
+class _Timed:
+    """HIP events around one tagged library call on the launch stream, when bench.py collects them (KERNEL_TIMERS)."""
+
+    def __init__(self, tag, algorithmic_bytes, **extra):
+        self.on = KERNEL_TIMERS is not None and tag is not None
+        self.tag, self.bytes, self.extra = tag, algorithmic_bytes, extra
+
+    def __enter__(self):
+        if self.on:
+            self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.ev0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on and exc[0] is None:
+            self.ev1.record()
+            by = self.bytes() if callable(self.bytes) else self.bytes
+            rec = KERNEL_TIMERS.setdefault(self.tag, {"events": [], "bytes": by, **self.extra})
+            rec["events"].append((self.ev0, self.ev1))
+        return False
+
+
 def _spmm_bytes(nnz, n_rows, d, has_w, elem=4, out_elem=4):
     """Algorithmic bytes of one launch: gathered row (fp32 or bf16 table) + int32 index
     (+ fp32 weight) per entry, stored row (fp32 or bf16) + int32 rowptr per output row."""
@@ -380,10 +402,24 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
         ev1.record()
         rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None,
                                                                              2 if is_bf16 else 4, out.element_size()),
-                                             "d": d,       # rocprofv3's Grid_Size of the main launch (threads)
-                                             "grid": ((split.n_items_max if split is not None else n_rows) + 3) // 4 * 256})
+                                             "d": d,       # rocprofv3's Grid_Size of the two launches (threads)
+                                             "grid": ((split.n_items_max if split is not None else n_rows) + 3) // 4 * 256,
+                                             "grid2": _spmm_second_grid(split, d, is_bf16)})
         rec["events"].append((ev0, ev1))
     return out
+
+
+def _spmm_second_grid(split, d, is_bf16):
+    """Grid_Size (threads) of bkg_spmm_csr_f32's second launch -- long-row fix-up blocks + short-row blocks
+    (csrc/spmm.hip launch_spmm / ShortShape) -- so that a PMC pass can be attributed to the tagged call."""
+    if split is None:
+        return None
+    pieces = d // (8 if is_bf16 else 4)
+    lpr, vpl = {96: (32, 3), 128: (64, 2), 192: (64, 3), 256: (64, 4)}.get(pieces, (min(pieces, 64), 1))
+    c = pieces // 2
+    ls = c if (pieces % 2 == 0 and 4 <= c <= 64 and 64 % c == 0) else lpr
+    short_blocks = (split.n_short_max + 256 // ls - 1) // (256 // ls) if split.pack else 0
+    return (split.n_long_max + short_blocks) * 256
 
 
 def _table(x):
@@ -1188,10 +1224,13 @@ class _KgeBceLoss(torch.autograd.Function):
                     wave_ptr, wave_iota, wave_split = _relation_waves_small(rel_ptr, r, waves)
                 else:
                     wave_ptr, wave_iota, wave_split = _relation_waves(et, rel_ptr, r, waves)
-                L.call("bkg_kge_fused_bce_dev_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]),
-                       t, label, 1.0 / total, L.ptr(inv_total), L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order),
-                       L.ptr(rel_ptr), L.ptr(s), L.ptr(g) if rec is None else None, L.ptr(rec),
-                       L.ptr(part[w0:w0 + waves]), L.ptr(drel_part), drel_part.stride(0), L.stream())
+                # algorithmic bytes: two node rows + head / tail ids + order + score + the 16-byte record
+                with _Timed("kge_fused_bce" if not padded else None, t * (2 * d * zt.element_size() + 16 + 4 + 4 + 16),
+                            d=d, launches_per_call=1):
+                    L.call("bkg_kge_fused_bce_dev_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), d, L.ptr(ei[0]), L.ptr(ei[1]),
+                           t, label, 1.0 / total, L.ptr(inv_total), L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order),
+                           L.ptr(rel_ptr), L.ptr(s), L.ptr(g) if rec is None else None, L.ptr(rec),
+                           L.ptr(part[w0:w0 + waves]), L.ptr(drel_part), drel_part.stride(0), L.stream())
                 # per-relation sum of the waves' partial rows (consecutive waves; fixed order; no atomics)
                 dr = spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
                 drel = dr if drel is None else drel + dr
@@ -1245,11 +1284,15 @@ class _KgeBceLoss(torch.autograd.Function):
                 inc = incidence_of(ei, n)
                 sp = inc.split
                 partials = sp.partials(d, z.device) if sp is not None else None
-                L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]),
-                       L.ptr(et), ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), L.ptr(g), L.ptr(rec), L.ptr(l1),
-                       L.ptr(inc.rowptr),
-                       L.ptr(inc.perm), L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None),
-                       L.ptr(partials), 0 if first else 1, L.stream())
+                # algorithmic bytes: per incidence the OTHER endpoint's row + the 16-byte record + the incidence id; per
+                # node the fp32 gradient row (read back too when accumulating the second triplet set) + its row pointer
+                with _Timed("kge_bwd_nodes" if not ctx.padded else None,
+                            2 * ei.size(1) * (d * zt.element_size() + 16 + 4) + n * (4 * d * (1 if first else 2) + 4), d=d):
+                    L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]),
+                           L.ptr(et), ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), L.ptr(g), L.ptr(rec), L.ptr(l1),
+                           L.ptr(inc.rowptr),
+                           L.ptr(inc.perm), L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None),
+                           L.ptr(partials), 0 if first else 1, L.stream())
                 first = False
             if first:
                 dz.zero_()

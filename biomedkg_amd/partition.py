@@ -321,6 +321,8 @@ class NodePartition:
 
     def slots(self, ids):
         """global node ids -> rows of the gathered ``[world * n_max, d]`` table"""
+        if self.world == 1:
+            return ids
         owner = torch.bucketize(ids, self._bounds_t[1:-1], right=True)
         return owner * self.n_max + (ids - self._bounds_t[owner])
 
@@ -781,7 +783,7 @@ class _TableView(torch.autograd.Function):
 
 
 def kge_loss_partitioned(model, x_local, prg: PartitionedRelGraph, backend, pos_ei, pos_et, neg_ei, neg_et, kind,
-                         dropout_of=None, n_pos_global=None, n_neg_global=None):
+                         dropout_of=None, n_pos_global=None, n_neg_global=None, pos_slots=None):
     """``KGEModule.training_step``'s loss (reference kge_module.py:110-129) with the encoder over the rank's shard
     and the scorer over the rank's share of the triplets (``pos_* / neg_*``: global node ids).  The BCE terms are
     normalised by the GLOBAL triplet count over ``world`` (``n_*_global``; default: equal shares), so the bucket's
@@ -790,8 +792,9 @@ def kge_loss_partitioned(model, x_local, prg: PartitionedRelGraph, backend, pos_
     from . import ops
     part = prg.part
     z_local = rgcn_encoder_partitioned(model.encoder, x_local, prg, backend, dropout_of)
-    ps = torch.stack([part.slots(pos_ei[0]), part.slots(pos_ei[1])])
-    ns = torch.stack([part.slots(neg_ei[0]), part.slots(neg_ei[1])])
+    # (``pos_slots``: the positives' table slots, computed once by a caller whose positives do not change)
+    ps = pos_slots if pos_slots is not None else part.slots(pos_ei)
+    ns = part.slots(neg_ei)
     rel = model.decoder.rel_emb
     total = None
     if n_pos_global is not None:

@@ -1,17 +1,18 @@
 #!/usr/bin/env python3
-"""Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md
-"rocprofv3 PMC slots" requires) into per-kernel HBM-side traffic per launch.
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and optionally TCC_HIT_sum + TCC_MISS_sum; separate runs as
+MI355X_MICROARCH.md "rocprofv3 PMC slots" requires) into per-kernel L2-miss traffic per launch.
 
-    python scripts/pmc_summary.py gpurun_out/pmc_FETCH_SIZE/*/*_counter_collection.csv \
-                                  gpurun_out/pmc_WRITE_SIZE/*/*_counter_collection.csv  profiles/rNN_pmc_traffic.json [fp32|bf16] \
-                                  [bench.json]
+    python scripts/pmc_summary.py FETCH_counter_collection.csv WRITE_counter_collection.csv profiles/rNN_pmc_traffic.json \
+                                  [fp32|bf16] [bench.json] [TCC_counter_collection.csv]
 
-``bench.json`` (a bench.py output line of the same build): its roofline entries carry (tag, grid_size); the matching
-spmm_items launches get that ``tag`` so that bench.py can look its traffic up.
+``bench.json`` (a bench.py output line of the same build): its roofline entries carry (tag, grid_size,
+grid_size_second_launch, pieces); the matching spmm_items / spmm_fixup launches get that ``tag`` so that bench.py can look
+the call's traffic up (it sums the launches of a call).  The two KGE kernels of the step are tagged by name.
 
 Units/corrections (MI355X_MICROARCH.md "HBM"): the counters are in KiB; on gfx950 FETCH_SIZE reports
 exactly half of the bytes of wide (16 B/lane) coalesced reads, which is what every gather in these
-kernels is, so fetched bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16 B/lane stores.
+kernels is, so fetched bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16 B/lane stores.  Both derive from the
+L2's fabric-side request counters: Infinity-Cache hits are INCLUDED (this is L2-miss traffic, not HBM traffic).
 Launches of one kernel are grouped by Grid_Size (= one call site / shape).
 """
 import collections
@@ -29,38 +30,53 @@ def load(path, counter):
     return groups
 
 
-def main(fetch_csv, write_csv, out_json, precision="fp32", bench_json=None):
+def main(fetch_csv, write_csv, out_json, precision="fp32", bench_json=None, tcc_csv=None):
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    hit = load(tcc_csv, "TCC_HIT_sum") if tcc_csv else {}
+    miss = load(tcc_csv, "TCC_MISS_sum") if tcc_csv else {}
     tags = {}
     if bench_json:
         b = json.loads([ln for ln in open(bench_json) if ln.startswith("{")][-1])
         for r in [b.get("roofline")] + list(b.get("kernels") or []):
             if r and r.get("grid_size"):
-                tags[(int(r["grid_size"]), int(r["pieces"]))] = r["tag"]
+                tags[("spmm_items", int(r["grid_size"]), int(r["pieces"]))] = r["tag"]
+                if r.get("grid_size_second_launch"):
+                    tags[("spmm_fixup", int(r["grid_size_second_launch"]), int(r["pieces"]))] = r["tag"]
     out = []
     for key in sorted(f, key=lambda k: -sum(f[k])):
         fv, wv = f[key], w.get(key, [0.0])
         fetch = 2.0 * 1024 * sum(fv) / len(fv)
         write = 1024 * sum(wv) / len(wv)
         tag = None
-        if "spmm_items" in key[0]:      # "spmm_items_kernel<__bf16, 64, 1>" or its mangled form "...IDF16bLi64ELi1EE..."
-            for (grid, pieces), t in tags.items():
-                if grid == key[1] and (f", {pieces}, " in key[0] or f"Li{pieces}ELi" in key[0]):
-                    tag = t
-        out.append({"kernel": key[0], "grid_size": key[1], "precision": precision, "launches": len(fv), "tag": tag,
-                    "fetch_bytes_per_launch": fetch,
-                    "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write})
+        for kind in ("spmm_items", "spmm_fixup"):      # "spmm_items_kernel<__bf16, 64, 1>" or mangled "...IDF16bLi64ELi1E..."
+            if kind in key[0]:
+                for (k2, grid, pieces), t in tags.items():
+                    lpr = min(pieces, 64)
+                    if k2 == kind and grid == key[1] and (f", {lpr}, " in key[0] or f"Li{lpr}ELi" in key[0]):
+                        tag = t
+        if "kge_bwd_nodes_kernel" in key[0] or "kge_bwd_nodes_fixup" in key[0]:
+            tag = "kge_bwd_nodes"
+        if "kge_fused_bce_kernel" in key[0]:
+            tag = "kge_fused_bce"
+        rec = {"kernel": key[0], "grid_size": key[1], "precision": precision, "launches": len(fv), "tag": tag,
+               "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write}
+        if key in hit or key in miss:
+            rec["tcc_hit"] = sum(hit.get(key, [0.0])) / max(len(hit.get(key, [0.0])), 1)
+            rec["tcc_miss"] = sum(miss.get(key, [0.0])) / max(len(miss.get(key, [0.0])), 1)
+            rec["l2_hit_rate"] = rec["tcc_hit"] / max(rec["tcc_hit"] + rec["tcc_miss"], 1.0)
+        out.append(rec)
     prev = []
     try:
         prev = [k for k in json.load(open(out_json))["kernels"] if k.get("precision") != precision]
     except (OSError, ValueError, KeyError):
         pass
-    json.dump({"note": "FETCH_SIZE doubled (gfx950 wide-read correction), KiB -> bytes; separate --pmc passes; "
+    json.dump({"note": "FETCH_SIZE doubled (gfx950 wide-read correction), KiB -> bytes; separate --pmc passes; L2 fabric-side "
+                       "requests: Infinity-Cache hits included (guide l. 297); tcc_* = TCC_HIT_sum / TCC_MISS_sum per launch; "
                        "bench.py --precision given per entry", "kernels": prev + out}, open(out_json, "w"), indent=1)
-    for o in out[:8]:
-        print(f"{o['kernel'][:48]:48s} grid={o['grid_size']:>10d} n={o['launches']:3d} "
-              f"traffic={o['traffic_bytes_per_launch'] / 1e9:6.2f} GB")
+    for o in out[:10]:
+        print(f"{o['kernel'][:48]:48s} grid={o['grid_size']:>10d} n={o['launches']:3d} tag={str(o['tag']):20s} "
+              f"traffic={o['traffic_bytes_per_launch'] / 1e9:6.2f} GB  l2 hit {o.get('l2_hit_rate', float('nan')):.2f}")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])
