@@ -10,7 +10,7 @@ One *step* = one GCL training step (GGD, the reference's default ``model_name``;
 768->256) + one KGE training step (4-layer R-GCN d=256 + DistMult, ``neg_ratio`` negatives per
 positive, BCE + L2 reg) over the same synthetic PrimeKG++-shaped graph (BASELINE.json configs[2]:
 ~130k nodes / ~4M edges / 30 relations), each step = forward + loss + backward + grad-clip 1.0 +
-Adam, inputs resident in HBM.  ``value`` = input edges / step time (every input edge counted once
+Adam (clip + update fused: biomedkg_amd/optim.py), inputs resident in HBM.  ``value`` = input edges / step time (every input edge counted once
 although both sub-steps consume it), whole job.
 
 N = 1 runs the whole graph on the GPU.  N > 1 (``--mode auto`` -> ``partition``, BASELINE configs[3] / north_star):
@@ -39,6 +39,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def clip_adam_step(opt, max_norm):
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) + opt.step() as two launches (biomedkg_amd/optim.py: the same
+    update on the torch.optim.Adam object's own state)."""
+    from biomedkg_amd.optim import clip_adam_step as fused
+    return fused(opt, max_norm)
 
 # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0        # HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
@@ -161,8 +168,7 @@ def make_step(module, batch, world, overlap=False):
     def finish():
         if state["pending"]:
             bucket.finish()
-            torch.nn.utils.clip_grad_norm_(params, 1.0)
-            opt.step()
+            clip_adam_step(opt, 1.0)
             state["pending"] = False
 
     def step():
@@ -175,8 +181,7 @@ def make_step(module, batch, world, overlap=False):
             state["pending"] = True
         else:
             bucket.all_reduce()
-            torch.nn.utils.clip_grad_norm_(params, 1.0)
-            opt.step()
+            clip_adam_step(opt, 1.0)
         return loss
 
     step.finish = finish
@@ -232,8 +237,7 @@ def build_partitioned_steps(args, rank, world, dev):
             loss = loss_fn()
             loss.backward()
             bucket.all_reduce()
-            torch.nn.utils.clip_grad_norm_(params, 1.0)
-            opt.step()
+            clip_adam_step(opt, 1.0)
             return loss
         step.finish = lambda: None
         return step
@@ -357,8 +361,7 @@ def grace_figures(dev):
             opt.zero_grad(set_to_none=True)
             loss = mod.training_step(b)
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(params, 1.0)
-            opt.step()
+            clip_adam_step(opt, 1.0)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -442,8 +445,7 @@ def sampled_figures(dev, ei, et, n, r, walks=128, steps=150):
                 opt.zero_grad(set_to_none=True)
                 loss = m.training_step(b)
                 loss.backward()
-                torch.nn.utils.clip_grad_norm_(params, 1.0)
-                opt.step()
+                clip_adam_step(opt, 1.0)
                 nodes += b.x.size(0); edges += b.edge_index.size(1)
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / k, nodes / k, edges / k
@@ -468,6 +470,51 @@ def sampled_figures(dev, ei, et, n, r, walks=128, steps=150):
         return out
     finally:
         ops.set_deterministic(False)
+        ops.set_matmul_precision(prec)
+
+
+def sampled_gcl_figures(dev, n=27_000, e=640_000, seeds=128, steps=40):
+    """The reference's GCL regime (train_gcl.py:106-122, data_module.py:93-99: NeighborLoader batches of 128 seeds, fan-out
+    [30] * 3, GGD over GCN 768 -> 256 with the attention fuser) on a single-type graph of PrimeKG's gene/protein size:
+    steps/s of the eager loop (device sampler + ordinary step, fp32), and whether the GPU or the host bounds it -- the
+    host's time to ENQUEUE a step (no synchronisation inside the loop) against the step's wall time: a launch-bound loop has
+    the two equal (the GPU waits for the host), a GPU-bound one has the host run ahead.  The kernel-trace busy fraction of
+    the same loop: scripts/busy_fraction.py over a rocprofv3 --kernel-trace of scripts/dev_gcl_sampled.py (profiles/)."""
+    from biomedkg_amd import ops, synthetic
+    from biomedkg_amd.gcl_module import GGDModule
+    from biomedkg_amd.samplers import NeighborBatchLoader
+    prec = ops.get_matmul_precision()
+    ops.set_matmul_precision("fp32")
+    try:
+        ei = synthetic.gcl_small(n, e, seed=1).to(dev)
+        x = synthetic.lm_features(n, 2, 768, seed=2).to(dev)
+        torch.manual_seed(0)
+        m = GGDModule(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="attention").to(dev).train()
+        params = list(m.model.parameters())
+        opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+
+        def loop(k):
+            it = iter(NeighborBatchLoader(x, ei, None, seeds, (30, 30, 30), True, seed=3))
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            nodes = edges = 0
+            for _ in range(k):
+                b = next(it)
+                opt.zero_grad(set_to_none=True)
+                loss = m.training_step(b)
+                loss.backward()
+                clip_adam_step(opt, 1.0)
+                nodes += b.x.size(0); edges += b.edge_index.size(1)
+            t_host = time.perf_counter() - t0              # everything enqueued (the sampler's two size reads included)
+            torch.cuda.synchronize()
+            return t_host / k, (time.perf_counter() - t0) / k, nodes / k, edges / k
+        loop(5)
+        t_host, t_wall, nodes, edges = loop(steps)
+        return {"sampler": f"NeighborLoader semantics on the device, {seeds} seeds x fan-out 30/30/30, GGD (GCN 768->256, "
+                           f"attention fuser), fp32, graph N={n} E={e}", "mean_nodes": round(nodes, 1), "mean_edges": round(edges, 1),
+                "eager_steps_per_s": round(1.0 / t_wall, 1), "ms_per_step": t_wall * 1e3, "host_enqueue_ms_per_step": t_host * 1e3,
+                "host_share_of_wall": t_host / t_wall,
+                "bound": "gpu" if t_host < 0.8 * t_wall else "host (launch-bound)"}
+    finally:
         ops.set_matmul_precision(prec)
 
 
@@ -787,6 +834,7 @@ def main():
             out["fusion"] = extra(fusion_figures, dev)
             if mode == "single":
                 out["sampled_regime"] = extra(sampled_figures, dev, step_k.batch.edge_index, step_k.batch.edge_type, n, r)
+                out["sampled_regime_gcl"] = extra(sampled_gcl_figures, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = extra(cpu_baseline, args)
     if world > 1 or forced:

@@ -101,4 +101,4 @@ extern "C" int bkg_set_deterministic_workspace(float* workspace, int64_t floats)
 }
 
 extern "C" const char* bkg_last_error() { return bkg::g_err; }
-extern "C" int bkg_abi_version() { return 2; }
+extern "C" int bkg_abi_version() { return 3; }

@@ -1,0 +1,154 @@
+// Global-norm gradient clipping + Adam over a LIST of parameter tensors as two launches.
+//
+// The reference's step tail -- Lightning's gradient_clip_val = 1.0 (train_gcl.py:63-68, train_kge.py:44-50:
+// torch.nn.utils.clip_grad_norm_) followed by torch.optim.Adam.step() (gcl_module.py:78-87, kge_module.py:208-217) -- is,
+// on the GPU, a chain of small launches: per-tensor norms, a stack + norm, a clamp, a multiply per tensor, then the
+// multi-tensor Adam (torch: FusedAdam + norm + mul + addcmul, ~3 % of the bench step and 12 of the ~150 nodes of a
+// replayed mini-batch step).  Here:
+//
+//   launch 1  partial[b] = sum of g^2 over block b's 4096-element chunk (chunks of all tensors in one grid)
+//   launch 2  every block re-adds the partials in index order (same total on every block, bitwise repeatable),
+//             c = min(1, max_norm / (sqrt(total) + 1e-6));  g' = c g;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;
+//             p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)       [torch.optim.Adam, no amsgrad / decay]
+//
+// Tensor pointers travel BY VALUE in the kernel arguments (<= 48 tensors, 1.7 KB): gradients are re-allocated every step
+// (zero_grad(set_to_none=True)), a device-side pointer table would need a host-to-device copy per step.  The step count
+// and the learning rate are host scalars, or device scalars for captured (hipGraph) steps: `step_dev` is incremented by
+// the kernel, `lr_dev` is what the LR scheduler fills between replays.
+#include "common.h"
+
+namespace bkg {
+
+constexpr int OPT_MAX_TENSORS = 48;
+constexpr int OPT_CHUNK = 4096;       // elements per block
+
+struct OptTensors {
+  float* p[OPT_MAX_TENSORS];
+  const float* g[OPT_MAX_TENSORS];
+  float* m[OPT_MAX_TENSORS];
+  float* v[OPT_MAX_TENSORS];
+  int64_t n[OPT_MAX_TENSORS];
+  int32_t first_chunk[OPT_MAX_TENSORS + 1];   // chunk ranges per tensor (prefix sums)
+  int32_t count;
+};
+
+__device__ __forceinline__ int opt_tensor_of(const OptTensors& t, int chunk) {
+  int lo = 0, hi = t.count;                   // first_chunk[lo] <= chunk < first_chunk[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (t.first_chunk[mid] <= chunk) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float out = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return out;
+}
+
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(OptTensors t, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  const int chunk = blockIdx.x;
+  const int k = opt_tensor_of(t, chunk);
+  const int64_t base = (int64_t)(chunk - t.first_chunk[k]) * OPT_CHUNK;
+  const int64_t n = t.n[k];
+  const float* g = t.g[k];
+  float acc = 0.f;
+  if (((uintptr_t)g & 15) == 0) {
+#pragma unroll
+    for (int it = 0; it < OPT_CHUNK / 1024; ++it) {
+      const int64_t i = base + (int64_t)it * 1024 + threadIdx.x * 4;
+      if (i + 3 < n) {
+        const float4 x = *reinterpret_cast<const float4*>(g + i);
+        acc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+      } else {
+        for (int64_t j = i; j < n && j < i + 4; ++j) acc += g[j] * g[j];
+      }
+    }
+  } else {
+    for (int64_t i = base + threadIdx.x; i < n && i < base + OPT_CHUNK; i += 256) acc += g[i] * g[i];
+  }
+  const float s = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) partial[chunk] = s;
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(OptTensors t, const float* __restrict__ partial, int n_partial,
+                                                        float max_norm, float lr, const float* __restrict__ lr_dev,
+                                                        float beta1, float beta2, float eps, float step,
+                                                        float* __restrict__ step_dev, float* __restrict__ norm_out) {
+  __shared__ float sh[4];
+  // the total in index order: every block computes the same sum (n_partial <= a few thousand floats, L2-resident)
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+  const float total = block_sum_256(acc, sh);
+  const float norm = sqrtf(total);
+  const float clip = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+  float tstep = step;
+  if (step_dev) tstep = step_dev[0] + 1.0f;     // (the counter itself is bumped by block 0 below, after everybody's read...)
+  const float rate = lr_dev ? lr_dev[0] : lr;
+  const float bc1 = 1.0f - powf(beta1, tstep), bc2 = 1.0f - powf(beta2, tstep);
+  const float step_size = rate / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  const int chunk = blockIdx.x;
+  const int k = opt_tensor_of(t, chunk);
+  const int64_t base = (int64_t)(chunk - t.first_chunk[k]) * OPT_CHUNK;
+  const int64_t n = t.n[k];
+  float* __restrict__ p = t.p[k];
+  const float* __restrict__ g = t.g[k];
+  float* __restrict__ m = t.m[k];
+  float* __restrict__ v = t.v[k];
+  for (int64_t i = base + threadIdx.x; i < n && i < base + OPT_CHUNK; i += 256) {
+    const float gi = g[i] * clip;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+  if (chunk == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+}
+
+// the device step counter is bumped by its own one-thread launch AFTER the update (a block of the update kernel doing it
+// would race with the other blocks' reads of the old value)
+__global__ void bump_step_kernel(float* __restrict__ step_dev) { step_dev[0] += 1.0f; }
+
+}  // namespace bkg
+
+using namespace bkg;
+
+extern "C" int64_t bkg_clip_adam_max_tensors() { return OPT_MAX_TENSORS; }
+extern "C" int64_t bkg_clip_adam_chunks(const int64_t* numel, int32_t count) {
+  int64_t c = 0;
+  for (int i = 0; i < count; ++i) c += (numel[i] + OPT_CHUNK - 1) / OPT_CHUNK;
+  return c;
+}
+
+extern "C" int bkg_clip_adam_f32(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                                 float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr,
+                                 const float* lr_dev, float beta1, float beta2, float eps, float step, float* step_dev,
+                                 float* partial, int64_t n_partial, float* norm_out, void* stream) {
+  BKG_ARG(count >= 0 && count <= OPT_MAX_TENSORS, "bkg_clip_adam_f32: at most 48 tensors per call");
+  BKG_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, "bkg_clip_adam_f32: bad hyper-parameters");
+  if (count == 0) return 0;
+  OptTensors t;
+  int64_t chunks = 0;
+  t.count = count;
+  for (int i = 0; i < count; ++i) {
+    BKG_ARG(numel[i] >= 0 && params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i], "bkg_clip_adam_f32: null tensor");
+    t.p[i] = params[i]; t.g[i] = grads[i]; t.m[i] = exp_avg[i]; t.v[i] = exp_avg_sq[i]; t.n[i] = numel[i];
+    t.first_chunk[i] = (int32_t)chunks;
+    chunks += (numel[i] + OPT_CHUNK - 1) / OPT_CHUNK;
+  }
+  t.first_chunk[count] = (int32_t)chunks;
+  BKG_ARG(chunks < (1 << 30) && n_partial >= chunks && partial, "bkg_clip_adam_f32: partial needs bkg_clip_adam_chunks floats");
+  if (chunks == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, partial);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, partial, (int)chunks, max_norm, lr, lr_dev,
+                     beta1, beta2, eps, step, step_dev, norm_out);
+  if (step_dev) hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step_dev);
+  return check_launch("bkg_clip_adam_f32");
+}

@@ -29,6 +29,7 @@ import torch
 from . import _lib as L
 from . import ops
 from . import rand as R
+from .optim import clip_adam_step
 
 
 class CaptureRefused(RuntimeError):
@@ -79,9 +80,7 @@ class GraphedStep:
         self.epoch.add_(1)
         loss = self.module.training_step(self.batch)
         loss.backward()
-        if self.clip:
-            torch.nn.utils.clip_grad_norm_(self.params, self.clip)
-        self.optimizer.step()
+        clip_adam_step(self.optimizer, self.clip)        # clip_grad_norm_ + step(): two launches (biomedkg_amd/optim.py)
         return loss
 
     def _capture(self, warmup):

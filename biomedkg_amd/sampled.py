@@ -34,6 +34,7 @@ from . import ops
 from . import rand as R
 from .graph import RelGraph, graph_of, plant_rel_graph
 from .graphs import make_capturable
+from .optim import clip_adam_step
 from .samplers import SubgraphBatch, _relabel, rows_of
 
 EDGE_BUCKETS = (1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536)
@@ -264,9 +265,7 @@ class SaintGraphedKge:
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.padded_loss(e_b)
         loss.backward()
-        if self.clip:
-            torch.nn.utils.clip_grad_norm_(self.params, self.clip)
-        self.optimizer.step()
+        clip_adam_step(self.optimizer, self.clip)
         return loss
 
     # ---- the ordinary step on the unpadded batch (outside the captured regime)
@@ -293,9 +292,7 @@ class SaintGraphedKge:
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.module.training_step(self.unpadded_batch(n_b, e_b))
         loss.backward()
-        if self.clip:
-            torch.nn.utils.clip_grad_norm_(self.params, self.clip)
-        self.optimizer.step()
+        clip_adam_step(self.optimizer, self.clip)
         return loss.detach()
 
     def bucket_of(self, n_b, e_b, e_free):

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import distributed as D
+from .optim import clip_adam_step
 
 
 def seed_everything(seed: int):
@@ -224,9 +225,7 @@ class Trainer:
                 loss = model.training_step(batch)
                 loss.backward()
                 bucket.all_reduce()
-                if self.clip:
-                    torch.nn.utils.clip_grad_norm_(params, self.clip)
-                opt.step()
+                clip_adam_step(opt, self.clip)     # clip_grad_norm_ + opt.step(): two launches (biomedkg_amd/optim.py)
                 self.global_step += 1
             if sched is not None:
                 sched.step()                      # Lightning's default interval for a bare scheduler: "epoch"

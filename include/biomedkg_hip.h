@@ -411,6 +411,23 @@ int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int32_t M, int3
                           const uint8_t* keep, float drop_p, uint64_t seed, uint32_t stream_id, float* out, int64_t ldo,
                           void* stream);
 
+/* ---- the step tail: global-norm gradient clipping + Adam over a list of parameter tensors, two launches (csrc/optim.hip).
+ *      Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) -- Lightning's gradient_clip_val = 1.0 of
+ *      train_gcl.py:63-68 / train_kge.py:44-50 -- followed by torch.optim.Adam.step() (gcl_module.py:78-87,
+ *      kge_module.py:208-217; no amsgrad, no weight decay): c = min(1, max_norm / (||g|| + 1e-6)), g' = c g,
+ *      m = b1 m + (1 - b1) g', v = b2 v + (1 - b2) g'^2, p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+ *      params / grads / exp_avg / exp_avg_sq: HOST arrays of `count` device pointers (<= bkg_clip_adam_max_tensors());
+ *      max_norm <= 0: no clipping.  lr_dev / step_dev (nullable device scalars, captured steps): the learning rate is
+ *      read from lr_dev, the step count t = step_dev[0] + 1 and step_dev is incremented; else the host values lr / step
+ *      (t = step, already incremented by the caller).  partial: bkg_clip_adam_chunks(numel, count) floats of scratch;
+ *      norm_out (nullable): the total gradient norm before clipping.  The gradients themselves are left unscaled. */
+int64_t bkg_clip_adam_max_tensors(void);
+int64_t bkg_clip_adam_chunks(const int64_t* numel, int32_t count);
+int bkg_clip_adam_f32(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, const float* lr_dev,
+                      float beta1, float beta2, float eps, float step, float* step_dev, float* partial, int64_t n_partial,
+                      float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

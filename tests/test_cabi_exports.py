@@ -48,7 +48,7 @@ def test_binding_matches_header(lib):
     for name, (_, args) in _lib.SIGNATURES.items():
         assert len(args) == decl[name], f"{name}: binding has {len(args)} args, header {decl[name]}"
     assert _lib.lib().bkg_abi_version() >= 1
-    assert ctypes.sizeof(_lib.RowSplitStruct) == 8 * 8 + 3 * 8
+    assert ctypes.sizeof(_lib.RowSplitStruct) == 10 * 8 + 4 * 8      # ten device pointers + four bounds (bkg_rowsplit)
 
 
 def test_no_cpu_fallback():
