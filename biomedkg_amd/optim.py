@@ -48,7 +48,8 @@ def clip_adam_step(opt, max_norm=None):
     for p in params:
         st = opt.state[p]
         if len(st) == 0:                                   # torch.optim.Adam._init_group
-            st["step"] = (torch.zeros((), dtype=torch.float32, device=dev) if capturable else torch.tensor(0.0, dtype=torch.float32))
+            st["step"] = (torch.zeros((), dtype=torch.float32, device=dev) if (capturable or group.get("fused"))
+                          else torch.tensor(0.0, dtype=torch.float32))      # (torch keeps a fused optimizer's counter on the device)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
     steps = [opt.state[p]["step"] for p in params]

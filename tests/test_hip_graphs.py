@@ -24,6 +24,7 @@ def _grace(seed=0, n=1500, e=12000, d_in=64, h=32):
 
 def test_replayed_grace_steps_equal_eager_steps_bit_for_bit():
     from biomedkg_amd import graphs as G, ops, rand as R
+    from biomedkg_amd.optim import clip_adam_step
     ops.set_deterministic(True)      # bitwise claims need the fixed-order weight-gradient sums (Trainer(deterministic=True))
     n, e, d_in = 1500, 12000, 64
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -55,8 +56,7 @@ def test_replayed_grace_steps_equal_eager_steps_bit_for_bit():
             opt.zero_grad(set_to_none=True)
             loss = mod.training_step(batch)
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(params, 1.0)
-            opt.step()
+            clip_adam_step(opt, 1.0)                    # the step tail GraphedStep records (biomedkg_amd/optim.py)
             eager_losses.append(loss.detach().clone())
     want = [p.detach().clone() for p in params]
 
