@@ -394,7 +394,7 @@ def grace_figures(dev):
         ops.set_matmul_precision(prev)
 
 
-def fusion_figures(dev, n=130_000):
+def fusion_figures(dev, edge_index=None, n=130_000):
     """The modality projection (reference fusion.py:17-31) over [N,2,768]: first call (QKV product + 2x2 attention + mean,
     3 x 2N x 768 x 768 x 2 flops) and the steady-state call (the fuser is frozen -- SURVEY 0.3-1 -- so the result is cached
     per (input, weights) version)."""
@@ -416,7 +416,47 @@ def fusion_figures(dev, n=130_000):
             out[mode] = {"first_call_ms": first, "steady_ms": steady, "first_call_TFLOPs": 2.0 * 2 * n * 768 * 2304 / first / 1e9}
         finally:
             ops.set_matmul_precision(prev)
-    return {"workload": f"AttentionFusion over [{n}, 2, 768]", **out}
+    # ReDAF (reference fusion.py:49-90): dropout makes it new every training step -- nothing to cache -- so its cost is
+    # per step: the transform product + scale / dropout / ReLU / modality mean, in node chunks (ops.redaf_fusion)
+    from biomedkg_amd.utils.fusion import ReDAF
+    torch.manual_seed(3)
+    r = ReDAF(768).to(dev).train()
+    redaf = {}
+    for mode in ("bf16", "fp32"):
+        prev = ops.get_matmul_precision()
+        ops.set_matmul_precision(mode)
+        try:
+            ms = _event_ms(lambda: r(x), 5, warm=2)
+            redaf[mode] = {"step_ms": ms, "TFLOPs": 2.0 * 2 * n * 768 * 768 / ms / 1e9}
+        finally:
+            ops.set_matmul_precision(prev)
+    ggd = None
+    if edge_index is not None and edge_index.numel() and int(n) == 130_000:
+        # the GGD step of the headline with the [N, 2, 768] language-model features through the ReDAF fuser in front
+        from biomedkg_amd.gcl_module import GGDModule
+        torch.manual_seed(1234)
+        mod = GGDModule(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="redaf").to(dev).train()
+        b = Batch()
+        b.x, b.edge_index = x, edge_index
+        params = list(mod.model.parameters())
+        opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            mod.training_step(b).backward()
+            clip_adam_step(opt, 1.0)
+        prev = ops.get_matmul_precision()
+        ops.set_matmul_precision("bf16")
+        try:
+            for _ in range(4):
+                step()
+            ggd = {"ms_per_step_bf16": _event_ms(step, 6, warm=1),
+                   "note": "GGD / GCN 768->256 step over [N, 2, 768] features, fuse_method=redaf (the fuser runs every step)"}
+        finally:
+            ops.set_matmul_precision(prev)
+    return {"workload": f"AttentionFusion over [{n}, 2, 768]", **out,
+            "redaf": {"workload": f"ReDAF over [{n}, 2, 768], training mode (fresh dropout mask per call)", **redaf,
+                      "ggd_step": ggd}}
 
 
 def sampled_figures(dev, ei, et, n, r, walks=128, steps=150):
@@ -831,7 +871,7 @@ def main():
         if world == 1 and not args.no_extras:
             out["grace_step"] = extra(grace_figures, dev)
             out["ntxent"] = extra(ntxent_figures, dev)
-            out["fusion"] = extra(fusion_figures, dev)
+            out["fusion"] = extra(fusion_figures, dev, step_g.batch.edge_index if mode == "single" else None)
             if mode == "single":
                 out["sampled_regime"] = extra(sampled_figures, dev, step_k.batch.edge_index, step_k.batch.edge_type, n, r)
                 out["sampled_regime_gcl"] = extra(sampled_gcl_figures, dev)

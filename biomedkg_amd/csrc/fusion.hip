@@ -75,8 +75,9 @@ template <int M>
 __global__ __launch_bounds__(256) void redaf_combine_kernel(const float* __restrict__ t, int64_t ld, int n, int D,
                                                             const float* __restrict__ scale,  // [M, D]
                                                             const uint8_t* __restrict__ keep, float drop_p,
-                                                            uint64_t seed, uint32_t stream_id, float* __restrict__ out,
-                                                            int64_t ldo, const uint32_t* __restrict__ epoch) {
+                                                            uint64_t seed, uint32_t stream_id, int64_t row0,
+                                                            float* __restrict__ out, int64_t ldo,
+                                                            const uint32_t* __restrict__ epoch) {
   stream_id = with_epoch(stream_id, epoch);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of one node
   const int chunks = D / 4;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void redaf_combine_kernel(const float* __restr
       uchar4 k = *reinterpret_cast<const uchar4*>(keep + row * D + c);
       v.x = k.x ? v.x * ks : 0.f; v.y = k.y ? v.y * ks : 0.f; v.z = k.z ? v.z * ks : 0.f; v.w = k.w ? v.w * ks : 0.f;
     } else if (drop_p > 0.f) {
-      uint4 r = philox_keep4(seed, (uint64_t)row * D + c, stream_id);
+      uint4 r = philox_keep4(seed, (uint64_t)(row0 + row) * D + c, stream_id);   // row0: this call's first row of the whole input
       v.x = r.x >= thresh ? v.x * ks : 0.f; v.y = r.y >= thresh ? v.y * ks : 0.f;
       v.z = r.z >= thresh ? v.z * ks : 0.f; v.w = r.w >= thresh ? v.w * ks : 0.f;
     }
@@ -128,8 +129,8 @@ extern "C" int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_
 }
 
 extern "C" int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int32_t M, int32_t D, const float* scale,
-                                     const uint8_t* keep, float drop_p, uint64_t seed, uint32_t stream_id, float* out,
-                                     int64_t ldo, void* stream) {
+                                     const uint8_t* keep, float drop_p, uint64_t seed, uint32_t stream_id, int64_t row0,
+                                     float* out, int64_t ldo, void* stream) {
   BKG_ARG(M >= 1 && M <= 4, "bkg_redaf_combine_f32: 1 <= modalities <= 4");
   BKG_ARG(D % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)t % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
               ((uintptr_t)scale % 16 == 0), "bkg_redaf_combine_f32: alignment");
@@ -138,10 +139,10 @@ extern "C" int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int3
   dim3 grid(ceil_div(n * (D / 4), 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
   switch (M) {
-    case 1: hipLaunchKernelGGL(redaf_combine_kernel<1>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo, rng_epoch_ptr()); break;
-    case 2: hipLaunchKernelGGL(redaf_combine_kernel<2>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo, rng_epoch_ptr()); break;
-    case 3: hipLaunchKernelGGL(redaf_combine_kernel<3>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo, rng_epoch_ptr()); break;
-    default: hipLaunchKernelGGL(redaf_combine_kernel<4>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, out, ldo, rng_epoch_ptr()); break;
+    case 1: hipLaunchKernelGGL(redaf_combine_kernel<1>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, row0, out, ldo, rng_epoch_ptr()); break;
+    case 2: hipLaunchKernelGGL(redaf_combine_kernel<2>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, row0, out, ldo, rng_epoch_ptr()); break;
+    case 3: hipLaunchKernelGGL(redaf_combine_kernel<3>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, row0, out, ldo, rng_epoch_ptr()); break;
+    default: hipLaunchKernelGGL(redaf_combine_kernel<4>, grid, block, 0, s, t, ld, (int)n, D, scale, keep, drop_p, seed, stream_id, row0, out, ldo, rng_epoch_ptr()); break;
   }
   return check_launch("bkg_redaf_combine_f32");
 }

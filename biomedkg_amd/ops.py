@@ -1502,16 +1502,32 @@ def attention_fusion(x, w_qkv, b_qkv):
 
 def redaf_fusion(x, w_t, b_t, scale, drop: Dropout = None):
     """ReDAF.forward (reference fusion.py:49-90): relu(Linear_T(x)) in the GEMM epilogue, then
-    mean_m relu(dropout(t * scale[m])) with ``scale = modal_weights * zeta`` ``[M, D]``."""
+    mean_m relu(dropout(t * scale[m])) with ``scale = modal_weights * zeta`` ``[M, D]``.  Dropout makes the result new
+    every training step (nothing to cache, unlike AttentionFusion), so the ``[M n, D]`` transform must not make an HBM
+    round trip per step: like ``attention_fusion`` it runs in node chunks -- 4,096 nodes = 8,192 x 768 fp32 = 25 MB --
+    and the combine kernel reads each chunk's ``t`` out of the Infinity Cache right behind the product (at n = 130,000:
+    one 25 MB scratch instead of an 800 MB intermediate; the Philox stream is indexed by the GLOBAL row, so the masks
+    do not depend on the chunking)."""
     L.require_cuda(x, w_t, b_t, scale)
     n, m, d = x.shape
-    t = gemm(_f32c(x).view(n * m, d), w_t, trans_b=True, bias=b_t, act=ACT_RELU)
+    x2 = _f32c(x).view(n * m, d)
+    scale = _f32c(scale)
     out = torch.empty(n, d, dtype=torch.float32, device=x.device)
     keep, p, seed, sid = None, 0.0, 0, 0
     if drop is not None and drop.p > 0:
         p, seed, sid = drop.p, drop.seed, drop.stream_id      # stream_id: the provider's per-call counter (fresh mask per call)
         if drop.keep is not None:
             keep = drop.keep.to(torch.uint8).contiguous()
-    L.call("bkg_redaf_combine_f32", L.ptr(t), t.stride(0), n, m, d, L.ptr(_f32c(scale)), L.ptr(keep), p, seed, sid,
-           L.ptr(out), out.stride(0), L.stream())
+    step = FUSION_CHUNK_NODES if n > 2 * FUSION_CHUNK_NODES else max(n, 1)
+    t = None
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        rows = (hi - lo) * m
+        buf = None if t is None or t.size(0) < rows else t[:rows]
+        t_c = gemm(x2[lo * m: hi * m], w_t, trans_b=True, bias=b_t, act=ACT_RELU, out=buf)
+        if t is None:
+            t = t_c
+        L.call("bkg_redaf_combine_f32", L.ptr(t_c), t_c.stride(0), hi - lo, m, d, L.ptr(scale),
+               L.ptr(keep[lo * m: hi * m]) if keep is not None else None, p, seed, sid, lo * m, L.ptr(out[lo:hi]),
+               out.stride(0), L.stream())
     return out

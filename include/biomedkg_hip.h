@@ -408,8 +408,10 @@ int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_
 /* ReDAF dropout: `keep` (explicit mask, [n*M, D] bytes) or, when NULL and drop_p > 0, an in-kernel Philox stream keyed by
  * (seed, stream_id) -- the caller advances stream_id on every call, as nn.Dropout draws a fresh mask per forward. */
 int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int32_t M, int32_t D, const float* scale,
-                          const uint8_t* keep, float drop_p, uint64_t seed, uint32_t stream_id, float* out, int64_t ldo,
-                          void* stream);
+                          const uint8_t* keep, float drop_p, uint64_t seed, uint32_t stream_id,
+                          int64_t row0 /* index of t's first row in the whole [n_total * M, D] input: the Philox stream is
+                                          keyed by the global element, so a chunked call draws the same mask */,
+                          float* out, int64_t ldo, void* stream);
 
 /* ---- the step tail: global-norm gradient clipping + Adam over a list of parameter tensors, two launches (csrc/optim.hip).
  *      Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) -- Lightning's gradient_clip_val = 1.0 of
