@@ -92,8 +92,15 @@ def pmc_traffic(tag, precision):
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
             hits = [k for k in json.load(open(path))["kernels"] if k.get("tag") == tag and k.get("precision") == precision]
             if hits:
-                total = sum(k["traffic_bytes_per_launch"] * k.get("launches_per_call", 1) for k in hits)
-                h, m = sum(k.get("tcc_hit", 0) for k in hits), sum(k.get("tcc_miss", 0) for k in hits)
+                # a call = one launch of its main kernel (+ its second kernel); a tag may cover several shapes of the same
+                # call (the positive and the negative triplet set): bytes over all launches / number of calls
+                per_kernel = {}
+                for k in hits:
+                    per_kernel[k["kernel"]] = per_kernel.get(k["kernel"], 0) + k["launches"]
+                calls = max(per_kernel.values())
+                total = sum(k["traffic_bytes_per_launch"] * k["launches"] for k in hits) / calls
+                h = sum(k.get("tcc_hit", 0) * k["launches"] for k in hits)
+                m = sum(k.get("tcc_miss", 0) * k["launches"] for k in hits)
                 return total, (h / (h + m) if (h + m) else None), os.path.basename(path)
     except Exception:  # noqa: BLE001 - reporting only
         return None, None, None
