@@ -709,14 +709,23 @@ def main():
         step_g(); step_k()
     step_k.finish()
     sync()
-    ops.KERNEL_TIMERS = {}
+    ops.KERNEL_TIMERS = None if os.environ.get("BKG_BENCH_NO_KERNEL_TIMERS") == "1" else {}
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step GPU times (no sync inside)
+    for ev in marks:                                    # (created for real here, not inside the timed loop)
+        ev.record()
+    ops.reserve_events(64 * args.steps + 64)            # ... and the tagged calls' events (~50 per step)
+    sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step_g(); step_k()
+        marks[i + 1].record()
     step_k.finish()                                     # the last KGE update belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
-    timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS, None
+    per_step_raw = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+    per_step = sorted(per_step_raw)
+    timers, ops.KERNEL_TIMERS = ops.KERNEL_TIMERS or {}, None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -863,6 +872,8 @@ def main():
                                      "the exact-fp32 mode keeps the reference's form)"},
             "triplets_per_sec_kge_step": (total_edges + (n_neg if strong or world == 1 else world * n_neg)) / (ms_k * 1e-3),
             "edges_per_sec_gcl_step": total_edges / (ms_g * 1e-3),
+            "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_max": per_step[-1],
+            "ms_per_step_slowest_index": per_step_raw.index(per_step[-1]),
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
             "ms_per_step_linear_ggd_head": ms_linear_head,
             "ms_per_step_fresh_structures": ms_fresh,

@@ -271,6 +271,23 @@ class Dropout:
 KERNEL_TIMERS = None
 
 
+_EVENTS = []
+
+
+def reserve_events(count):
+    """Timing events for the tagged calls, created AND recorded once ahead of a timed region: the runtime grows its event /
+    signal pools lazily, and on a fresh process that growth showed up as one ~70 ms step inside bench.py's timed loop."""
+    fresh = [torch.cuda.Event(enable_timing=True) for _ in range(max(0, count - len(_EVENTS)))]
+    for ev in fresh:
+        ev.record()
+    torch.cuda.synchronize()
+    _EVENTS.extend(fresh)
+
+
+def _event():
+    return _EVENTS.pop() if _EVENTS else torch.cuda.Event(enable_timing=True)
+
+
 class _Timed:
     """HIP events around one tagged library call on the launch stream, when bench.py collects them (KERNEL_TIMERS)."""
 
@@ -280,7 +297,7 @@ class _Timed:
 
     def __enter__(self):
         if self.on:
-            self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.ev0, self.ev1 = _event(), _event()
             self.ev0.record()
         return self
 
@@ -390,7 +407,7 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
             addend = addend.float()
     timing = KERNEL_TIMERS is not None and tag is not None
     if timing:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1 = _event(), _event()
         ev0.record()
     partials = split.partials(d, x.device) if split is not None else None
     L.call("bkg_spmm_csr_f32", L.ptr(rowptr), L.ptr(col), L.ptr(w), L.ptr(x), is_bf16, x.stride(0), L.ptr(out),

@@ -75,7 +75,7 @@ def _positive_table(edge_index, n):
     return _cached(edge_index, "pos_table", (int(n),), build)
 
 
-_PENDING_COUNTS = []     # (pinned survivor count, event, k) of "sure" calls whose count nobody has looked at yet
+_WATCH = {"host": None, "slots": [None] * 8, "next": 0}   # ONE pinned buffer, made once; (event, k) per slot in flight
 SHORTFALLS = 0           # calls whose single round came up short (expected: never; ~1e-9 per call under the guard)
 
 
@@ -83,25 +83,29 @@ def _watch_shortfall(count, k):
     """The "sure" path never READS its survivor count inside the step (that would be a host round trip); the count is
     copied to pinned memory asynchronously and looked at by a LATER call, once its event has completed -- a shortfall
     (PyG would have gone on to rounds two and three; here the missing slots hold (0, 0) pairs) is reported, late but
-    loudly, instead of passing silently.  Skipped while a stream is being captured."""
+    loudly, instead of passing silently.  Skipped while a stream is being captured.  The pinned buffer is allocated once
+    (a hipHostMalloc per call showed up as a 60 ms stall inside a timed bench step)."""
     global SHORTFALLS
     if torch.cuda.is_current_stream_capturing():
         return
-    for item in list(_PENDING_COUNTS):
-        host, event, want = item
-        if event.query():
-            _PENDING_COUNTS.remove(item)
-            if int(host) < want:
+    w = _WATCH
+    if w["host"] is None:
+        w["host"] = torch.zeros(len(w["slots"]), dtype=torch.int32).pin_memory()
+    for i, item in enumerate(w["slots"]):
+        if item is not None and item[0].query():
+            w["slots"][i] = None
+            if int(w["host"][i]) < item[1]:
                 SHORTFALLS += 1
                 import warnings
-                warnings.warn(f"negative_sampling: an earlier call kept {int(host)} of {want} negatives in its single "
-                              "round (the rest are (0, 0) pairs); PyG would have drawn further rounds", RuntimeWarning)
-    if len(_PENDING_COUNTS) < 8:
-        host = torch.empty(1, dtype=torch.int32).pin_memory()
-        host.copy_(count, non_blocking=True)
+                warnings.warn(f"negative_sampling: an earlier call kept {int(w['host'][i])} of {item[1]} negatives in its "
+                              "single round (the rest are (0, 0) pairs); PyG would have drawn further rounds", RuntimeWarning)
+    i = w["next"]
+    if w["slots"][i] is None:                       # (all slots busy: this call goes unwatched)
+        w["host"][i:i + 1].copy_(count, non_blocking=True)
         event = torch.cuda.Event()
         event.record()
-        _PENDING_COUNTS.append((host, event, int(k)))
+        w["slots"][i] = (event, int(k))
+        w["next"] = (i + 1) % len(w["slots"])
 
 
 def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
