@@ -261,7 +261,8 @@ __device__ __forceinline__ void spmm_short_rows(int i, int n_short, const int32_
   constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VS * Q;
   constexpr int UB = 4;                                       // entries per pass (88 % of the bench graph's short rows
   const bool live = i < n_short;                              // have <= 4: most waves stop after the first)
-  const int ic = live ? i : 0;                                // (n_short_max >= 1 rows are allocated)
+  if (!__any(live)) return;                                   // (bounds not cut to the count: whole waves past the list)
+  const int ic = live ? i : 0;                                // a live lane exists, so entry 0 of the table is valid
   const int4 dsc = reinterpret_cast<const int4*>(desc)[ic];
   const int4 c0 = reinterpret_cast<const int4*>(scol)[2 * ic], c1 = reinterpret_cast<const int4*>(scol)[2 * ic + 1];
   const int idx[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};

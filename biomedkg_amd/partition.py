@@ -168,10 +168,9 @@ class Comm:
         el = table.element_size() * table.size(1)
         own = self.own_rows(table)
         if pat is None:
-            # every row travels: the plain all-gather (in place where the backend allows it: the shard already sits at its
-            # offset of the table)
-            src = own if dist.get_backend(self.group) == "nccl" else own.clone()
-            work = dist.all_gather_into_tensor(table, src, group=self.group, async_op=True)
+            # every row travels: the plain all-gather (from a copy of the shard: it already sits at its offset of the
+            # table, and an input that aliases the output is not something every backend promises to take)
+            work = dist.all_gather_into_tensor(table, own.clone(), group=self.group, async_op=True)
             self._count(el * self.n_max * (self.world - 1), el * self.n_max * (self.world - 1))
             return self._issued((table, work, None, None))
         if chunk is None:

@@ -83,3 +83,53 @@ def test_kge_backward_split_and_sorted_paths(kind):
         for got, exp in ((zd.grad, zo.grad), (rd.grad, ro.grad)):
             err = (got.cpu().double() - exp).norm() / exp.norm()
             assert err < 2e-3, err
+
+
+@pytest.mark.parametrize("tight", [True, False])
+@pytest.mark.parametrize("mix", ["mixed", "no_short_rows", "only_short_rows", "empty_rows_at_the_end"])
+@pytest.mark.parametrize("d,dtype", [(256, torch.bfloat16), (512, torch.bfloat16), (128, torch.float32), (96, torch.float32)])
+def test_spmm_row_classes(mix, tight, d, dtype):
+    """The three row classes of the split table (csrc/rowsplit.hip, spmm.hip): rows of <= 8 entries finished several per
+    wave from the descriptor table, rows of 9..256 entries one wave each, longer rows in slices + a fix-up -- every mix of
+    them, with the launch bounds cut to the table's counts (``tight``) and with the array-size bounds a captured step
+    keeps (whole waves past the lists), epilogue included, against an fp64 scatter-add."""
+    from biomedkg_amd import graph as G, ops
+    gen = torch.Generator(device=DEV).manual_seed(17)
+    rows, n_table = 40_000, 50_000
+    lens = torch.randint(0, 9, (rows,), device=DEV, generator=gen)
+    if mix == "mixed":
+        pick = torch.rand(rows, device=DEV, generator=gen)
+        lens[pick < 0.06] = torch.randint(9, 60, (rows,), device=DEV, generator=gen)[pick < 0.06]
+        lens[:4] = torch.tensor([900, 0, 1, 300], device=DEV)
+    elif mix == "no_short_rows":
+        lens = torch.randint(9, 20, (rows,), device=DEV, generator=gen)
+        lens[5] = 700
+    elif mix == "only_short_rows":
+        lens = lens.clamp_min(1)
+    else:
+        lens[-300:] = 0
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), torch.cumsum(lens, 0)]).to(torch.int32)
+    nnz = int(rowptr[-1])
+    assert nnz >= G.SPLIT_MIN_NNZ
+    col = torch.randint(0, n_table, (nnz,), device=DEV, dtype=torch.int32, generator=gen)
+    w = torch.rand(nnz, device=DEV, generator=gen)
+    x = torch.randn(n_table, d, device=DEV, generator=gen).to(dtype)
+    bias = torch.randn(d, device=DEV, generator=gen)
+    was = G.TIGHT_GRIDS
+    G.TIGHT_GRIDS = tight
+    try:
+        sp = G.RowSplit(rowptr, rows, nnz, pack=True, col=col)
+    finally:
+        G.TIGHT_GRIDS = was
+    assert sp.exact == tight
+    n_items, _, n_long, n_short = sp.totals.tolist()
+    assert n_short == int((lens <= 8).sum()) and n_long == int((lens > 256).sum())
+    row_of = torch.repeat_interleave(torch.arange(rows, device=DEV), lens.long())
+    ref = torch.zeros(rows, d, dtype=torch.float64, device=DEV)
+    ref.index_add_(0, row_of, x.double()[col.long()] * w.double()[:, None])
+    out = ops.spmm(rowptr, col, w, x, rows, split=sp, bias=bias, relu=True)
+    torch.testing.assert_close(out.double(), (ref + bias.double()).relu(), rtol=1e-4, atol=1e-4)     # (fp32 sums of up to 900 terms)
+    plain = ops.spmm(rowptr, col, None, x, rows, split=sp, out_dtype=torch.bfloat16 if dtype == torch.bfloat16 else torch.float32)
+    ref1 = torch.zeros(rows, d, dtype=torch.float64, device=DEV).index_add_(0, row_of, x.double()[col.long()])
+    torch.testing.assert_close(plain.double(), ref1, rtol=1e-2 if dtype == torch.bfloat16 else 1e-5, atol=1e-2 if dtype == torch.bfloat16 else 1e-5)
+    assert torch.equal(out, ops.spmm(rowptr, col, w, x, rows, split=sp, bias=bias, relu=True))      # run to run
