@@ -194,11 +194,19 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
   float rdA = 0.f, rdB = 0.f;
   auto prefetch = [&](int jt_, uint4 (&st)[NPC], float& st_rd) {
     const int j0 = jt_ * NX_BJ;
+    if (j0 + NX_BJ <= M) {      // an interior tile (all but the last): unconditional loads, no per-chunk branch -- the
+#pragma unroll                  // loads then sit in one scheduling region with the tile's MFMAs
+      for (int i = 0; i < NPC; ++i) {
+        const int p = tid + i * NT, row = p / CH_ROW, ch = p % CH_ROW;
+        st[i] = *reinterpret_cast<const uint4*>(zn + (size_t)(j0 + row) * ROW_BYTES + ch * 16);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      const int p = tid + i * NT, row = p / CH_ROW, ch = p % CH_ROW;
-      st[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (j0 + row < M) st[i] = *reinterpret_cast<const uint4*>(zn + (size_t)(j0 + row) * ROW_BYTES + ch * 16);
+      for (int i = 0; i < NPC; ++i) {
+        const int p = tid + i * NT, row = p / CH_ROW, ch = p % CH_ROW;
+        st[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (j0 + row < M) st[i] = *reinterpret_cast<const uint4*>(zn + (size_t)(j0 + row) * ROW_BYTES + ch * 16);
+      }
     }
     if (BWD && tid < NX_BJ) st_rd = (j0 + tid < M) ? a.rden[j0 + tid] : 0.f;
   };
@@ -349,20 +357,32 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 
     // ---- E = exp2(S) (bf16: S still needs the scale), masked where the tile touches the diagonal / the boundary
     const float* rdj = aux + buf * NX_BJ;
+    // two copies of the loop, chosen ONCE per tile by the wave-uniform predicate: interior tiles (all but the few that
+    // touch the diagonal or the boundary) run without the per-element compare / select / branch
+    if (need_mask) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int jl = 32 * t + nx_acc_row(r, lh);
-        float e = __builtin_amdgcn_exp2f(s[t][r]);       // both images carry the log2(e)/tau scale (bf16: sqrt on each side)
-        if (need_mask) {
+        for (int r = 0; r < 16; ++r) {
+          const int jl = 32 * t + nx_acc_row(r, lh);
+          float e = __builtin_amdgcn_exp2f(s[t][r]);     // both images carry the log2(e)/tau scale (bf16: sqrt on each side)
           const int jg = j0 + jl;
           e = (jg < M && i_glob >= 0 && jg != i_glob) ? e : 0.f;
+          if (BWD) e *= rd_i + rdj[jl];
+          else rowsum += e;
+          s[t][r] = e;
         }
-        if (BWD) e *= rd_i + rdj[jl];
-        else rowsum += e;
-        s[t][r] = e;
-      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float e = __builtin_amdgcn_exp2f(s[t][r]);
+          if (BWD) e *= rd_i + rdj[32 * t + nx_acc_row(r, lh)];
+          else rowsum += e;
+          s[t][r] = e;
+        }
+    }
 
     if (!BWD) {
       // column sums, unless the tile lies inside the panel's own columns (those pairs are also computed transposed)
