@@ -312,10 +312,12 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 
     // ---- S^T[j][i] for the tile's two 32-row halves
     nx_acc_t s[2];
+    if (!BF16) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    }
     if (BF16) {
       // fragment reads run RD steps ahead of their MFMAs (an LDS read returns after ~100+ cycles, a 32x32x16 MFMA
       // issues every 32): the compiler's own schedule kept one step in flight and the matrix pipe waited on lgkmcnt
@@ -329,13 +331,15 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
       };
 #pragma unroll
       for (int k = 0; k < RD && k < KF; ++k) read_k(k, ring[k % RING]);
+      const nx_acc_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < KF; ++k) {
         if (k + RD < KF) read_k(k + RD, ring[(k + RD) % RING]);
         const nx_bf16x8_t b = __builtin_bit_cast(nx_bf16x8_t, zi[k]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nx_bf16x8_t, ring[k % RING][t]), b, s[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t)     // (k = 0: a literal zero C operand instead of 32 zeroed accumulator registers)
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nx_bf16x8_t, ring[k % RING][t]), b,
+                                                         k == 0 ? zero16 : s[t], 0, 0, 0);
       }
     } else {
       const float* zj = reinterpret_cast<const float*>(tile_at(buf));
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     }
 
     // ---- E = exp2(S) (bf16: S still needs the scale), masked where the tile touches the diagonal / the boundary
-    const float* rdj = aux + buf * NX_BJ;
+    const float* rdj = aux + buf * NX_BJ + 4 * lh;     // per-lane base: the row of register r is a compile-time offset from it
     // two copies of the loop, chosen ONCE per tile by the wave-uniform predicate: interior tiles (all but the few that
     // touch the diagonal or the boundary) run without the per-element compare / select / branch
     if (need_mask) {
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
           float e = __builtin_amdgcn_exp2f(s[t][r]);     // both images carry the log2(e)/tau scale (bf16: sqrt on each side)
           const int jg = j0 + jl;
           e = (jg < M && i_glob >= 0 && jg != i_glob) ? e : 0.f;
-          if (BWD) e *= rd_i + rdj[jl];
+          if (BWD) e *= rd_i + rdj[32 * t + nx_acc_row(r, 0)];
           else rowsum += e;
           s[t][r] = e;
         }
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float e = __builtin_amdgcn_exp2f(s[t][r]);
-          if (BWD) e *= rd_i + rdj[32 * t + nx_acc_row(r, lh)];
+          if (BWD) e *= rd_i + rdj[32 * t + nx_acc_row(r, 0)];
           else rowsum += e;
           s[t][r] = e;
         }
