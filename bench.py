@@ -193,6 +193,7 @@ def make_step(module, batch, world, overlap=False):
 
     step.finish = finish
     step.batch = batch
+    step.params = params
     return step
 
 

@@ -29,12 +29,12 @@ def run():
         losses.append((float(gstep().detach()), float(kstep().detach())))
     torch.cuda.synchronize()
     h = hashlib.sha256()
+    count = 0
     for st in (gstep, kstep):
-        for cell in st.__closure__:
-            v = cell.cell_contents
-            if isinstance(v, list) and v and isinstance(v[0], torch.nn.Parameter):
-                for p in v:
-                    h.update(p.detach().cpu().numpy().tobytes())
+        for p in st.params:
+            h.update(p.detach().cpu().numpy().tobytes())
+            count += 1
+    assert count > 0
     return h.hexdigest(), losses
 
 
