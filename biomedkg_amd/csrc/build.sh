@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 JOBS=${JOBS:-4}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Wno-unused-value"
+FLAGS="${EXTRA_FLAGS} --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Wno-unused-value"
 mkdir -p obj
 pids=()
 for f in *.hip; do

@@ -41,6 +41,9 @@ typedef short nx_s4_t __attribute__((ext_vector_type(4)));
 typedef short nx_s8_t __attribute__((ext_vector_type(8)));
 
 constexpr int NX_BJ = 64;   // rows of a j-tile
+#ifndef NX_FWD16_NW
+#define NX_FWD16_NW 8        // waves per workgroup of the bf16 forward at h > 128 (experiment knob)
+#endif
 
 struct NxArgs {
   const void* zn;      // [M][HPAD] normalised rows, zero padded columns (fp32 or bf16)
@@ -622,11 +625,11 @@ static int nx_cus() {
 
 // waves per workgroup by (precision, direction, width): 8 waves (a 256-row panel, two waves per SIMD) wherever the
 // kernel fits 256 registers per lane, 4 waves (one per SIMD, up to 512 registers) for the widest accumulators
-static int nx_waves(bool bf16, int hp, bool bwd) { return (bwd && hp > 4) ? 4 : 8; }
+static int nx_waves(bool bf16, int hp, bool bwd) { return ((bwd || (bf16 && NX_FWD16_NW == 4)) && hp > 4) ? 4 : 8; }
 
 // (precision, direction, width) -> instantiation; the workgroup shape follows nx_waves()
 #define NX_FWD_CASES(FN, ...)                                                                     \
-  if (bf16) return hp <= 4 ? FN<true, 4, 8, false>(__VA_ARGS__) : FN<true, 8, 8, false>(__VA_ARGS__); \
+  if (bf16) return hp <= 4 ? FN<true, 4, 8, false>(__VA_ARGS__) : FN<true, 8, NX_FWD16_NW, false>(__VA_ARGS__); \
   switch (hp) {                                                                                   \
     case 1: return FN<false, 1, 8, false>(__VA_ARGS__);                                           \
     case 2: return FN<false, 2, 8, false>(__VA_ARGS__);                                           \
