@@ -1493,6 +1493,18 @@ def ntxent_loss(h1, h2, tau=0.2, operands=None):
 FUSION_CHUNK_NODES = 4096   # 2 * 4096 rows x 2304 fp32 = 75 MB of q|k|v per chunk: stays in the 256 MiB Infinity Cache
 
 
+def _fusion_rows(x):
+    """``x [n, M, D]`` as the ``[n M, D]`` operand of the fuser's product: fp32, or -- bf16 mode, constant input features
+    -- a bf16 copy cached on the tensor (the streaming product re-reads its A operand once per 128-column tile of the
+    weight: 6 (ReDAF) or 18 (q|k|v) times 400 MB instead of 800 MB)."""
+    n, m, d = x.shape
+    x2 = _f32c(x).view(n * m, d)
+    if bf16_storage() and not x.requires_grad and d % 8 == 0 and n * m >= 4096 and x.is_contiguous():
+        from .graph import _cached
+        return _cached(x, "bf16_rows", (), lambda: to_bf16(x2))
+    return x2
+
+
 def attention_fusion(x, w_qkv, b_qkv):
     """AttentionFusion.forward (reference fusion.py:17-31): one QKV GEMM + fused MxM attention/mean.
     ``x [n, M, D]``, ``w_qkv [3D, D]``, ``b_qkv [3D]`` -> ``[n, D]``.  Forward only (the reference never
@@ -1501,7 +1513,7 @@ def attention_fusion(x, w_qkv, b_qkv):
     q|k|v is consumed out of the Infinity Cache by the attention / mean kernel right behind the product."""
     L.require_cuda(x, w_qkv, b_qkv)
     n, m, d = x.shape
-    x2 = _f32c(x).view(n * m, d)
+    x2 = _fusion_rows(x)
     out = torch.empty(n, d, dtype=torch.float32, device=x.device)
     step = FUSION_CHUNK_NODES if n > 2 * FUSION_CHUNK_NODES else max(n, 1)
     qkv = None
@@ -1527,7 +1539,7 @@ def redaf_fusion(x, w_t, b_t, scale, drop: Dropout = None):
     do not depend on the chunking)."""
     L.require_cuda(x, w_t, b_t, scale)
     n, m, d = x.shape
-    x2 = _f32c(x).view(n * m, d)
+    x2 = _fusion_rows(x)
     scale = _f32c(scale)
     out = torch.empty(n, d, dtype=torch.float32, device=x.device)
     keep, p, seed, sid = None, 0.0, 0, 0
