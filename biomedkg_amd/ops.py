@@ -1490,7 +1490,10 @@ def ntxent_loss(h1, h2, tau=0.2, operands=None):
 
 
 # ----------------------------------------------------------------------------- modality fusion
-FUSION_CHUNK_NODES = 4096   # 2 * 4096 rows x 2304 fp32 = 75 MB of q|k|v per chunk: stays in the 256 MiB Infinity Cache
+FUSION_CHUNK_NODES = int(__import__("os").environ.get("BKG_FUSION_CHUNK", "8192"))   # 2 * 8192 rows x 2304 fp32 = 151 MB of
+#                            q|k|v per chunk: stays in the 256 MiB Infinity Cache (4,096: 3.4 ms first call, 8,192: 3.1)
+REDAF_CHUNK_NODES = int(__import__("os").environ.get("BKG_REDAF_CHUNK", "16384"))    # 2 * 16384 rows x 768 fp32 = 100 MB of t
+#                            (4,096-node chunks: 1.47 ms per call at N = 130k -- products too small to fill the chip --, 16,384: 1.0)
 
 
 def _fusion_rows(x):
@@ -1547,7 +1550,7 @@ def redaf_fusion(x, w_t, b_t, scale, drop: Dropout = None):
         p, seed, sid = drop.p, drop.seed, drop.stream_id      # stream_id: the provider's per-call counter (fresh mask per call)
         if drop.keep is not None:
             keep = drop.keep.to(torch.uint8).contiguous()
-    step = FUSION_CHUNK_NODES if n > 2 * FUSION_CHUNK_NODES else max(n, 1)
+    step = REDAF_CHUNK_NODES if n > 2 * REDAF_CHUNK_NODES else max(n, 1)
     t = None
     for lo in range(0, n, step):
         hi = min(n, lo + step)
