@@ -17,6 +17,9 @@ namespace bkg {
 
 enum { KN_DISTMULT = 0, KN_TRANSE = 1 };
 constexpr float KN_EPS = 1e-12f;
+#ifndef KN_U4
+#define KN_U4 2      // incidences in flight per lane group at four accumulator quads (experiment knob)
+#endif
 
 __device__ __forceinline__ float kn_sgn(float v) { return (v > 0.f) - (v < 0.f); }
 __device__ __forceinline__ float4 kn_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict_
   // triplet fields of batch i+1 and the entry ids of batch i+2 are in flight (issued before the rows, so the one
   // wait per iteration retires all three): the chain entry id -> triplet fields -> rows costs one memory latency
   // per batch.  Slots past the end are clamped and masked out.
-  constexpr int U = (VQ == 1) ? 4 : (VQ >= 8 ? 1 : 2);
+  constexpr int U = (VQ == 1) ? 4 : (VQ >= 8 ? 1 : (VQ == 4 ? KN_U4 : 2));
   constexpr int STEP = U * G;
   int64_t other[U], ri[U];
   float g[U];
