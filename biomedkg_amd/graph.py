@@ -49,6 +49,8 @@ class RowSplit:
         """``pack``: rows of <= 8 entries leave the item list for ``short_desc`` (csrc/rowsplit.hip) -- the tables
         ``bkg_spmm_csr_f32`` walks finish them several per wave; the KGE kernels' tables stay one row per item."""
         dev = rowptr.device
+        self._src = (rowptr, n_rows, nnz, chunk)
+        self._plain = None
         self.pack = bool(pack) and col is not None
         self.n_items_max = n_rows + nnz // chunk
         self.n_slots_max = 2 * (nnz // chunk) + 2
@@ -82,6 +84,17 @@ class RowSplit:
         self.n_slots_max = max(n_slots, 1)
         self.c.n_items_max, self.c.n_slots_max, self.c.n_long_max, self.c.n_short_max = n_items, self.n_slots_max, n_long, n_short
         self.exact = True
+
+    def plain(self):
+        """The same rows as one item each (no short-row table): rows of 64 sixteen-byte pieces or more already fill a
+        wave, and finishing the short ones in the second launch costs more than it saves there (two-view GCN propagate,
+        d = 512 bf16: 331 vs 335 us per launch).  Built on first use, kept with this table."""
+        if not self.pack:
+            return self
+        if self._plain is None:
+            rowptr, n_rows, nnz, chunk = self._src
+            self._plain = RowSplit(rowptr, n_rows, nnz, chunk=chunk, pack=False)
+        return self._plain
 
     def partials(self, d, device):
         return torch.empty(self.n_slots_max, d, dtype=torch.float32, device=device)

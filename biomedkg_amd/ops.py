@@ -405,6 +405,8 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
         addend = (addend if addend.is_contiguous() else addend.contiguous()) if addend.dtype == torch.bfloat16 else _f32c(addend)
         if addend.dtype == torch.bfloat16 and (addend.stride(0) % 4 or addend.data_ptr() % 8):
             addend = addend.float()
+    if split is not None and split.pack and d // (8 if is_bf16 else 4) >= 64 and not torch.cuda.is_current_stream_capturing():
+        split = split.plain()          # wide rows: one wave per row already (RowSplit.plain)
     timing = KERNEL_TIMERS is not None and tag is not None
     if timing:
         ev0, ev1 = _event(), _event()
