@@ -114,6 +114,7 @@ SIGNATURES = {
     "bkg_negative_sample_workspace_bytes": (I64, [I64]),
     "bkg_negative_sample": (I32, [I64, I64, I64, U64, P, I64, P, P, P, P, P, I64, I64, P, P, I64, P]),
     "bkg_permute_gather_i64": (I32, [P, I64, U64, P, P]),
+    "bkg_randperm_dev": (I32, [P, I64, U64, P, P, P]),
     "bkg_negative_sample_dev_candidates": (I64, [I64]),
     "bkg_negative_sample_dev": (I32, [P, I64, P, P, P, I64, U64, P, P, I64, P, P, P, I64, I64, P, P, P, P, P, I64, P]),
     "bkg_padded_loss_inputs": (I32, [P, P, P, P, P, I64, I64, I64, P, P, P, P, P]),

@@ -223,6 +223,19 @@ __global__ __launch_bounds__(256) void permute_gather_dev_kernel(const int64_t* 
   out[i] = src[pi((uint64_t)i) % (uint64_t)e];
 }
 
+// out[i] = pi(i) for i < n[0], pi a keyed bijection of [0, n[0]) (n in DEVICE memory), and i beyond: torch.randperm over
+// the real rows of a padded batch, the pads staying where they are (GGD's corruption inside a captured mini-batch step).
+__global__ __launch_bounds__(256) void randperm_dev_kernel(const int64_t* __restrict__ n_dev, int64_t cap, uint64_t seed,
+                                                           const uint32_t* __restrict__ epoch, int64_t* __restrict__ out) {
+  __shared__ Feistel pi;
+  const int64_t n = n_dev[0] < cap ? n_dev[0] : cap;
+  if (threadIdx.x == 0 && n > 0) pi = make_feistel((uint64_t)n, dev_seed(seed, epoch, 3));
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  out[i] = i < n ? (int64_t)pi((uint64_t)i) : i;
+}
+
 // The loss-side view of a padded batch in one launch: pad positives get the relation id `pad_rel` (one past the real
 // ones: no scorer wave visits it) and endpoints spread over the local ids (zero gradient records, no long incidence
 // list); inv_total = 1 / (edges + negatives).
@@ -299,6 +312,15 @@ extern "C" int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t se
   hipLaunchKernelGGL(permute_gather_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, n,
                      make_feistel((uint64_t)n, seed), out);
   return check_launch("bkg_permute_gather_i64");
+}
+
+extern "C" int bkg_randperm_dev(const int64_t* n_dev, int64_t cap, uint64_t seed, const uint32_t* epoch, int64_t* out,
+                                void* stream) {
+  BKG_ARG(cap >= 0 && n_dev, "bkg_randperm_dev: bad arguments");
+  if (cap == 0) return 0;
+  hipLaunchKernelGGL(randperm_dev_kernel, dim3(ceil_div(cap, 256)), dim3(256), 0, (hipStream_t)stream, n_dev, cap, seed,
+                     epoch, out);
+  return check_launch("bkg_randperm_dev");
 }
 
 extern "C" int64_t bkg_negative_sample_dev_candidates(int64_t max_negatives) {

@@ -40,6 +40,26 @@ SPLIT_MIN_NNZ = 1 << 15  # below this one wave per row is fine and the table is 
 
 
 TIGHT_GRIDS = __import__("os").environ.get("BKG_TIGHT_GRIDS", "1") != "0"
+_AS_CAPTURED = 0
+
+
+class as_captured:
+    """Build structures the way a captured step does (launch bounds instead of counts, no host read) although nothing is
+    being captured: the padded mini-batch loops run their eager steps under it, so that an eager padded step and its
+    replayed graph launch the same kernels over the same tables (bit-equal by construction, tests/test_hip_sampled*.py)."""
+
+    def __enter__(self):
+        global _AS_CAPTURED
+        _AS_CAPTURED += 1
+
+    def __exit__(self, *exc):
+        global _AS_CAPTURED
+        _AS_CAPTURED -= 1
+        return False
+
+
+def capturing():
+    return _AS_CAPTURED > 0 or torch.cuda.is_current_stream_capturing()
 
 
 class RowSplit:
@@ -71,7 +91,7 @@ class RowSplit:
                                   self.n_items_max, self.n_slots_max, self.n_long_max, self.n_short_max)
 
         self.exact = False
-        if TIGHT_GRIDS and not torch.cuda.is_current_stream_capturing():
+        if TIGHT_GRIDS and not capturing():
             self.tighten()
 
     def tighten(self):

@@ -123,7 +123,7 @@ _TALL_ROWS = 256    # fewest rows the streaming product is used for (a heuristic
 def _xw_ok(a, m, n, k):
     """Shapes / layouts the streaming activation-x-weight kernel (csrc/gemm_xw.hip) takes in bf16 mode."""
     el = a.element_size()
-    return (_PRECISION == 1 and m >= _TALL_ROWS and n * k <= (1 << 22) and k % 256 == 0 and n % 32 == 0 and a.stride(1) == 1 and
+    return (_PRECISION == 1 and (m >= _TALL_ROWS or a.dtype == torch.bfloat16) and n * k <= (1 << 22) and k % 256 == 0 and n % 32 == 0 and a.stride(1) == 1 and
             (a.stride(0) * el) % 16 == 0 and a.data_ptr() % 16 == 0)
 
 
@@ -405,7 +405,7 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
         addend = (addend if addend.is_contiguous() else addend.contiguous()) if addend.dtype == torch.bfloat16 else _f32c(addend)
         if addend.dtype == torch.bfloat16 and (addend.stride(0) % 4 or addend.data_ptr() % 8):
             addend = addend.float()
-    if split is not None and split.pack and d // (8 if is_bf16 else 4) >= 64 and not torch.cuda.is_current_stream_capturing():
+    if split is not None and split.pack and d // (8 if is_bf16 else 4) >= 64 and split.exact:
         split = split.plain()          # wide rows: one wave per row already (RowSplit.plain)
     timing = KERNEL_TIMERS is not None and tag is not None
     if timing:
@@ -1498,13 +1498,15 @@ REDAF_CHUNK_NODES = int(__import__("os").environ.get("BKG_REDAF_CHUNK", "16384")
 #                            (4,096-node chunks: 1.47 ms per call at N = 130k -- products too small to fill the chip --, 16,384: 1.0)
 
 
-def _fusion_rows(x):
-    """``x [n, M, D]`` as the ``[n M, D]`` operand of the fuser's product: fp32, or -- bf16 mode, constant input features
-    -- a bf16 copy cached on the tensor (the streaming product re-reads its A operand once per 128-column tile of the
-    weight: 6 (ReDAF) or 18 (q|k|v) times 400 MB instead of 800 MB)."""
+def _fusion_rows(x, n_out):
+    """``x [n, M, D]`` as the ``[n M, D]`` operand of the fuser's product with an ``[n_out, D]`` weight: fp32, or -- bf16
+    mode, constant input features, a shape the streaming product takes -- a bf16 copy cached on the tensor (that product
+    re-reads its A operand once per 128-column tile of the weight: 6 (ReDAF) or 18 (q|k|v) times 400 MB instead of 800)."""
     n, m, d = x.shape
     x2 = _f32c(x).view(n * m, d)
-    if bf16_storage() and not x.requires_grad and d % 8 == 0 and n * m >= 4096 and x.is_contiguous():
+    chunk_rows = min(n, FUSION_CHUNK_NODES, REDAF_CHUNK_NODES) * m          # every chunk of it must be a tall operand too
+    if (bf16_storage() and not x.requires_grad and n * m >= 4096 and x.is_contiguous()
+            and _bf16_operand_ok(chunk_rows, n_out, d)):
         from .graph import _cached
         return _cached(x, "bf16_rows", (), lambda: to_bf16(x2))
     return x2
@@ -1518,7 +1520,7 @@ def attention_fusion(x, w_qkv, b_qkv):
     q|k|v is consumed out of the Infinity Cache by the attention / mean kernel right behind the product."""
     L.require_cuda(x, w_qkv, b_qkv)
     n, m, d = x.shape
-    x2 = _fusion_rows(x)
+    x2 = _fusion_rows(x, w_qkv.size(0))
     out = torch.empty(n, d, dtype=torch.float32, device=x.device)
     step = FUSION_CHUNK_NODES if n > 2 * FUSION_CHUNK_NODES else max(n, 1)
     qkv = None
@@ -1544,7 +1546,7 @@ def redaf_fusion(x, w_t, b_t, scale, drop: Dropout = None):
     do not depend on the chunking)."""
     L.require_cuda(x, w_t, b_t, scale)
     n, m, d = x.shape
-    x2 = _fusion_rows(x)
+    x2 = _fusion_rows(x, w_t.size(0))
     scale = _f32c(scale)
     out = torch.empty(n, d, dtype=torch.float32, device=x.device)
     keep, p, seed, sid = None, 0.0, 0, 0

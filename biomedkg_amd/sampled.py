@@ -32,7 +32,7 @@ import torch
 from . import _lib as L
 from . import ops
 from . import rand as R
-from .graph import RelGraph, graph_of, plant_rel_graph
+from .graph import RelGraph, as_captured, graph_of, plant_rel_graph
 from .graphs import make_capturable
 from .optim import clip_adam_step
 from .samplers import SubgraphBatch, _relabel, rows_of
@@ -260,12 +260,13 @@ class SaintGraphedKge:
         return loss                                                        # BCE + 1e-2 L2, reference kge_module.py:127-129
 
     def _padded_step(self, e_b):
-        self.epoch.add_(1)
-        self.rand.begin_step()
-        self.optimizer.zero_grad(set_to_none=True)
-        loss = self.padded_loss(e_b)
-        loss.backward()
-        clip_adam_step(self.optimizer, self.clip)
+        with as_captured():               # eager or recorded: the same kernels over the same (untightened) tables
+            self.epoch.add_(1)
+            self.rand.begin_step()
+            self.optimizer.zero_grad(set_to_none=True)
+            loss = self.padded_loss(e_b)
+            loss.backward()
+            clip_adam_step(self.optimizer, self.clip)
         return loss
 
     # ---- the ordinary step on the unpadded batch (outside the captured regime)

@@ -1,0 +1,288 @@
+"""hipGraph replay of the reference's SAMPLED GCL regime: ``train_gcl.py`` trains on ``NeighborLoader`` batches
+(``biomedkg/data_module.py:93-99``: 128 seed nodes, fan-out ``[30] * 3``), i.e. on a single-type graph of PrimeKG's
+gene/protein size a subgraph of ~25 k nodes and ~220 k edges per step.  Run eagerly that step is ~2.5 ms of kernels under
+~3.6 ms of host work (sampler calls, ~300 launches, autograd bookkeeping): the GPU is idle 30 % of the time
+(``bench.py sampled_regime_gcl``; profiles/README.md).  Here the step is replayed as ONE captured graph, with the recipe of
+``biomedkg_amd/sampled.py`` (fixed-capacity buffers, sizes in device memory, pads that are arithmetically invisible):
+
+* ``NeighborDeviceSampler`` leaves a batch in one int64 vector ``sizes[3] | n_id[N] | src[cap] | dst[cap]`` with no host
+  read (``samplers.NeighborSampler.enqueue``); the two sizes travel to pinned host memory asynchronously and are read ONE
+  STEP LATER -- the sampler runs a batch ahead of the trainer, on its own stream.
+* The host only picks the **edge bucket** (a geometric ladder of capacities) and GGD's augmentation coin
+  (``biomedkg/model/gcl.py:74``: a host-side ``torch.rand(1).item()`` in the reference too); one graph per
+  (bucket, augmented?) is captured lazily.
+* Inside the step nothing depends on a host-side size.  The node capacity is the graph's node count: pad NODES read the
+  zero row appended to the feature table and have no edges, so nothing gathers them; pad EDGES are self loops spread over
+  the nodes, which ``gcn_norm`` gives weight 0 (``add_remaining_self_loops`` replaces them by the unit loop every node
+  gets anyway); GGD's corruption permutes the real rows only (``bkg_randperm_dev``: a keyed bijection of ``[0, n_b)`` with
+  ``n_b`` read on the device); the BCE sums over the real rows and divides by a device scalar, so the pad rows' logits
+  get zero gradient and with them every pad row of every layer.
+
+Arithmetic: the padded step computes ``GGDModule.training_step`` (``biomedkg/gcl_module.py:52-56,229-234``) on the real
+part of the batch -- ``tests/test_hip_sampled_gcl.py`` holds it against the ordinary step on the unpadded batch with the
+same draws, and a replayed graph against the same padded step run eagerly (bit-equal).  Only GGD is built this way (DGI's
+summary and GRACE's NT-Xent would need their own masked forms); the other modules keep the eager loop.
+"""
+from __future__ import annotations
+
+import random
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops
+from . import rand as R
+from .graph import as_captured
+from .graphs import make_capturable
+from .optim import clip_adam_step
+from .samplers import NeighborSampler, SubgraphBatch, rows_of
+
+_SIZES = 3     # (unused), nodes, edges -- the sampler's own counter vector
+
+
+def edge_buckets(e_max, first=4096, ratio=1.25):
+    """Edge capacities ``first * ratio^k`` (multiples of 1024) up to ``e_max``: a batch wastes < 25 % of its edge work."""
+    out, b = [], float(first)
+    while b < e_max:
+        out.append(int(-(-b // 1024)) * 1024)
+        b *= ratio
+    out.append(int(e_max))
+    return tuple(sorted(set(min(v, int(e_max)) for v in out)))
+
+
+class NeighborDeviceSampler:
+    """``samplers.NeighborSampler`` with its outputs in ONE int64 vector, so that a consumer takes a private copy of a
+    batch with a single launch; ``draw`` enqueues a batch, ``sizes`` waits (a step later) for its two counts."""
+
+    def __init__(self, edge_index, num_nodes, num_neighbors=(30, 30, 30), seed=0):
+        self.inner = NeighborSampler(edge_index, num_nodes, num_neighbors, seed)
+        if not self.inner.one_read_ok():
+            raise ValueError("graph too large for the one-read neighbor sampler")
+        dev = edge_index.device
+        st = self.inner._state(dev)
+        self.num_nodes = int(num_nodes)
+        # every node is expanded once and draws distinct in-edges: a batch holds at most min(E, N * fan-out) edges
+        self.edge_cap = max(min(st["cap"], edge_index.size(1)), 1)
+        self.buf = torch.zeros(_SIZES + self.num_nodes + 2 * st["cap"], dtype=torch.int64, device=dev)
+        o = _SIZES + self.num_nodes
+        st["ctr"], st["n_id"] = self.buf[:_SIZES], self.buf[_SIZES:o]
+        st["e_src"], st["e_dst"] = self.buf[o:o + st["cap"]], self.buf[o + st["cap"]:o + 2 * st["cap"]]
+        self.cap = st["cap"]
+        self.host = torch.zeros(_SIZES, dtype=torch.int64).pin_memory()
+        self.event = torch.cuda.Event()
+
+    def views(self, buf):
+        o = _SIZES + self.num_nodes
+        return dict(sizes=buf[:_SIZES], n_id=buf[_SIZES:o], src=buf[o:o + self.cap], dst=buf[o + self.cap:o + 2 * self.cap])
+
+    def draw(self, seeds):
+        self.inner.enqueue(seeds.contiguous())
+        self.host.copy_(self.buf[:_SIZES], non_blocking=True)
+        self.event.record()
+
+    def sizes(self):
+        self.event.synchronize()
+        return int(self.host[1]), int(self.host[2])
+
+
+class _StepRand(R.DeviceRand):
+    """DeviceRand of a padded GGD step: in-kernel stream ids restart at every step (a captured step freezes them; the
+    device replay counter tells two steps apart), the corruption permutes the real rows, the coin is the loop's."""
+
+    def __init__(self, seed, n_dev, epoch):
+        super().__init__(seed)
+        self.n_dev, self.epoch, self.aug, self.last_perm = n_dev, epoch, False, None
+
+    def begin_step(self, aug):
+        self.counter, self.aug = 0, bool(aug)
+
+    def coin(self):
+        return 0.0 if self.aug else 1.0          # GGD augments when coin < p (p in (0, 1]): decided by the loop, on the host
+
+    def perm(self, n, device):
+        out = torch.empty(n, dtype=torch.int64, device=device)
+        self.counter += 1
+        L.call("bkg_randperm_dev", L.ptr(self.n_dev), n, (self.seed + 0x9E3779B9 * self.counter) & ((1 << 63) - 1),
+               L.ptr(self.epoch), L.ptr(out), L.stream())
+        self.last_perm = out
+        return out
+
+
+class NeighborGraphedGcl:
+    """``GGDModule`` training steps over NeighborLoader batches, one hipGraph replay each (see the module docstring).
+
+    ``step()`` = sample (one batch ahead) + zero_grad + forward + loss + backward + clip + Adam; returns the loss as a
+    device scalar (the replay's static output; read it before the next step).  ``graphs=False`` runs the same padded step
+    eagerly (the bit-equality check of the tests).  One epoch = ``len(self)`` steps over a shuffled seed order."""
+
+    def __init__(self, module, x, edge_index, batch_size=128, num_neighbors=(30, 30, 30), optimizer=None, clip=1.0, seed=0,
+                 shuffle=True, buckets=None, graphs=True):
+        L.require_cuda(x, edge_index)
+        from .model.gcl import GGD
+        if not isinstance(getattr(module, "model", None), GGD):
+            raise ValueError("the padded NeighborLoader step is built for GGD")
+        self.module, self.clip, self.graphs_on = module, clip, graphs
+        dev = x.device
+        self.sampler = NeighborDeviceSampler(edge_index, x.size(0), num_neighbors, seed)
+        self.n_cap, self.e_cap = self.sampler.num_nodes, self.sampler.edge_cap
+        self.buckets = tuple(sorted(int(b) for b in (buckets or edge_buckets(self.e_cap))))
+        self.batch_size, self.shuffle = int(batch_size), shuffle
+        self.x = x
+        self.x_ext = torch.cat([x, x.new_zeros((1,) + tuple(x.shape[1:]))])           # + the zero row pad nodes read
+        self.cur = torch.zeros_like(self.sampler.buf)                                   # the batch the step reads
+        self.v = self.sampler.views(self.cur)
+        self.iota_n = torch.arange(self.n_cap, device=dev)
+        self.iota_e = torch.arange(self.buckets[-1], device=dev)
+        self.spread = self.iota_e % self.n_cap                                          # pad edges: self loops, one per node in turn
+        self.pad_row = torch.full((), self.n_cap, dtype=torch.int64, device=dev)
+        if optimizer is None:         # the optimizer of BaseGCL.configure_optimizers, without the trainer-bound scheduler
+            optimizer = torch.optim.Adam(list(module.model.parameters()), lr=module.lr, fused=True)
+        self.optimizer = make_capturable(optimizer)
+        self.epoch = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.rand = _StepRand(seed, self.v["sizes"][1:2], self.epoch)
+        self.coins = random.Random(int(seed) * 7919 + 1)
+        self.execs, self.losses = {}, {}
+        self.stats = {"replayed": 0, "captured": 0, "eager_padded": 0}
+        self.last_sizes = self.last_aug = None
+        self._order, self._pos, self._primed = None, 0, False
+        self._gen = torch.Generator(device=dev).manual_seed(int(seed) + 17)
+        # everything runs on ONE side stream (autograd's AccumulateGrad nodes must not be born on the default stream if a
+        # later capture is to meet them); the sampler on its own, a batch ahead
+        self.stream, self.sampler_stream = torch.cuda.Stream(), torch.cuda.Stream()
+        self.copied = torch.cuda.Event()
+        self._pinned = []
+
+    def __len__(self):
+        return (self.n_cap + self.batch_size - 1) // self.batch_size
+
+    def close(self):
+        for st in (self.sampler_stream, self.stream):
+            st.synchronize()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    # ---- seeds: DataLoader(shuffle=True) over the node ids, batches of ``batch_size``, the tail batch shorter
+    def _next_seeds(self):
+        if self._order is None or self._pos >= self.n_cap:
+            dev = self.x.device
+            self._order = (torch.randperm(self.n_cap, device=dev, generator=self._gen) if self.shuffle
+                           else torch.arange(self.n_cap, device=dev))
+            self._pos = 0
+        seeds = self._order[self._pos:self._pos + self.batch_size]
+        self._pos += self.batch_size
+        return seeds
+
+    # ---- the padded step (captured once per edge bucket and augmentation branch)
+    def padded_batch(self, e_b):
+        v = self.v
+        real_n = self.iota_n < v["sizes"][1]
+        real_e = self.iota_e[:e_b] < v["sizes"][2]
+        n_id = torch.where(real_n, v["n_id"], self.pad_row)
+        ei = torch.stack([torch.where(real_e, v["src"][:e_b], self.spread[:e_b]),
+                          torch.where(real_e, v["dst"][:e_b], self.spread[:e_b])])     # fresh tensor: no structure cached on it survives the step
+        return n_id, ei, real_n
+
+    def padded_loss(self, e_b):
+        """``GGDModule.training_step`` (fusion -> GGD -> BCE with logits, mean over the 2 n_b real logits) over the batch
+        in ``self.cur`` padded to ``n_cap`` nodes / ``e_b`` edges."""
+        m = self.module
+        n_id, ei, real_n = self.padded_batch(e_b)
+        x = m.fusion_fn(x=rows_of(self.x_ext, n_id))
+        pos_h, neg_h = m.model(x, ei)
+        w = real_n.to(pos_h.dtype)
+        inv = 0.5 / self.v["sizes"][1].to(pos_h.dtype)
+        return (F.binary_cross_entropy_with_logits(pos_h, torch.ones_like(pos_h), weight=w, reduction="sum")
+                + F.binary_cross_entropy_with_logits(neg_h, torch.zeros_like(neg_h), weight=w, reduction="sum")) * inv
+
+    def _padded_step(self, e_b, aug):
+        with as_captured():               # eager or recorded: the same kernels over the same (untightened) tables
+            self.epoch.add_(1)
+            self.rand.begin_step(aug)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss = self.padded_loss(e_b)
+            loss.backward()
+            clip_adam_step(self.optimizer, self.clip)
+        return loss
+
+    def unpadded_batch(self):
+        """The batch in ``self.cur`` as the eager loader would hand it out (tests)."""
+        n_b, e_b = self.last_sizes
+        v = self.v
+        n_id = v["n_id"][:n_b].clone()
+        return SubgraphBatch(rows_of(self.x_ext, n_id), torch.stack([v["src"][:e_b], v["dst"][:e_b]]), None,
+                             min(self.batch_size, n_b), n_id, None)
+
+    def step(self):
+        trainer = self.module.__dict__.pop("trainer", None)                # .log() inside a step would sync
+        L.call("bkg_set_rng_epoch", L.ptr(self.epoch))
+        outer = torch.cuda.current_stream()
+        self.stream.wait_stream(outer)
+        try:
+            with R.use(self.rand), torch.cuda.stream(self.stream):
+                loss = self._step()
+            outer.wait_stream(self.stream)                                 # the caller reads the loss on its own stream
+            return loss
+        except BaseException:
+            self.close()                  # drain the loop's streams before anybody drops its buffers
+            raise
+        finally:
+            L.call("bkg_set_rng_epoch", None)
+            if trainer is not None:
+                self.module.__dict__["trainer"] = trainer
+
+    def _draw_ahead(self, main):
+        with torch.cuda.stream(self.sampler_stream):
+            self.sampler_stream.wait_event(self.copied)
+            self.sampler.draw(self._next_seeds())
+
+    def _step(self):
+        s, main = self.sampler, torch.cuda.current_stream()
+        if not self._primed:
+            self.copied.record(main)
+            self._draw_ahead(main)
+            self._primed = True
+        n_b, e_b = s.sizes()                                               # of the batch drawn one step ago
+        self.last_sizes = (n_b, e_b)
+        main.wait_event(s.event)
+        self.cur.copy_(s.buf)                                              # private copy, then the sampler moves on:
+        self.copied.record(main)                                           # the next batch is drawn UNDER this step
+        self._draw_ahead(main)
+        bucket = next(b for b in self.buckets if b >= max(e_b, 1))
+        aug = self.last_aug = self.coins.random() < self.module.model.p
+        if not self.graphs_on:
+            self.stats["eager_padded"] += 1
+            return self._padded_step(bucket, aug).detach()
+        key = (bucket, aug)
+        g = self.execs.get(key)
+        if g is None:
+            # first batch of this kind: one eager padded step (it IS this batch's training step; it also warms the
+            # allocator and the kernel plans), then the capture pass, which records and does not execute
+            loss = self._padded_step(bucket, aug).detach().clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            # a captured graph reads the fuser's cached table output by address: keep those tensors alive with the loop
+            for hit in getattr(self.module.modality_transform, "__dict__", {}).get("_fused_cache", []):
+                if all(hit[1] is not t for t in self._pinned):
+                    self._pinned.append(hit[1])
+            try:
+                with torch.cuda.graph(g):
+                    self.losses[key] = self._padded_step(bucket, aug).detach()
+            except RuntimeError as why:      # a module on the path that cannot be captured: same steps, run eagerly
+                torch.cuda.synchronize()
+                self.graphs_on = False
+                self.optimizer.zero_grad(set_to_none=True)
+                print(f"[sampled-gcl] padded steps stay eager: {str(why).splitlines()[0]}", flush=True)
+                return loss
+            self.execs[key] = g
+            self.stats["captured"] += 1
+            return loss
+        g.replay()
+        self.stats["replayed"] += 1
+        ops.note_graph_replay()          # weights moved under an unchanged tensor version (ops._weight_bf16)
+        return self.losses[key]

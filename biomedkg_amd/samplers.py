@@ -61,11 +61,21 @@ class NeighborSampler:
                                  ws=torch.empty(L.lib().bkg_neighbor_workspace_bytes(n, fan), dtype=torch.uint8, device=dev))
         return st
 
+    def one_read_ok(self):
+        return self.num_nodes * max(min(k if k > 0 else 64, 64) for k in self.num_neighbors) < (1 << 31)
+
     def sample(self, seeds):
         """One host read per batch (node and edge counts) instead of three per hop; the same batch, draw for draw, as
         ``sample_hop_by_hop``."""
-        if self.num_nodes * max(min(k if k > 0 else 64, 64) for k in self.num_neighbors) >= (1 << 31) or seeds.numel() == 0:
+        if not self.one_read_ok() or seeds.numel() == 0:
             return self.sample_hop_by_hop(seeds)
+        st = self.enqueue(seeds)
+        _, nn, ne = st["ctr"].tolist()                                       # the one host read of the batch
+        return st["n_id"][:nn].clone(), torch.stack([st["e_src"][:ne], st["e_dst"][:ne]]), st["e_id"][:ne].clone()
+
+    def enqueue(self, seeds):
+        """The batch of ``sample`` left in the fixed-capacity device state (``ctr[1]`` nodes in ``n_id``, ``ctr[2]`` edges
+        in ``e_src / e_dst / e_id``, already relabelled) -- no host read; biomedkg_amd/sampled_gcl.py trains on it as is."""
         st, csr = self._state(seeds.device), self.graph.by_dst
         self.calls += 1
         seeds = seeds.contiguous()
@@ -80,8 +90,7 @@ class NeighborSampler:
                    L.ptr(st["ws"]), st["ws"].numel(), L.stream())
         L.call("bkg_neighbor_finish", self.num_nodes, L.ptr(st["n_id"]), L.ptr(st["ctr"]), L.ptr(st["lut"]), st["cap"],
                L.ptr(st["e_src"]), L.ptr(st["e_dst"]), L.stream())
-        _, nn, ne = st["ctr"].tolist()                                       # the one host read of the batch
-        return st["n_id"][:nn].clone(), torch.stack([st["e_src"][:ne], st["e_dst"][:ne]]), st["e_id"][:ne].clone()
+        return st
 
     def sample_hop_by_hop(self, seeds):
         g, dev = self.graph, seeds.device

@@ -140,6 +140,20 @@ class Trainer:
             step_fn = lambda: step()      # noqa: E731
             step_fn.loop, step_fn.owns_batches, step_fn.warmup_steps = loop, True, 0
             return step_fn
+        from .samplers import NeighborBatchLoader
+        from .model.gcl import GGD
+        if isinstance(loader, NeighborBatchLoader) and isinstance(getattr(model, "model", None), GGD) \
+                and loader.sampler.one_read_ok() and loader.x.size(0) > 0:
+            # the reference's GCL regime (NeighborLoader batches): padded sync-free batches, one graph per edge bucket and
+            # augmentation branch (biomedkg_amd/sampled_gcl.py)
+            from .sampled_gcl import NeighborGraphedGcl
+            sm = loader.sampler
+            loop = NeighborGraphedGcl(model, loader.x, sm.graph.edge_index, loader.batch_size, sm.num_neighbors, opt,
+                                      clip=self.clip, seed=sm.seed, shuffle=loader.shuffle)
+            step = loop.step
+            step_fn = lambda: step()      # noqa: E731
+            step_fn.loop, step_fn.owns_batches, step_fn.warmup_steps = loop, True, 0
+            return step_fn
         if batch is None:
             return None
         from . import graphs

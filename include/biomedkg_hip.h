@@ -382,6 +382,10 @@ int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int64_t n_cand
                         int32_t* offs_tmp, int64_t* out_head, int64_t* out_tail, int64_t out_offset, int64_t max_out,
                         int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
 int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t seed, int64_t* out, void* stream);
+/* torch.randperm over the REAL rows of a padded mini-batch (GGD's corruption, reference biomedkg/model/gcl.py:70-71, inside
+ * a captured step): out[i] = pi(i) for i < n_dev[0] (device scalar), pi a bijection of [0, n_dev[0]) keyed by seed and the
+ * device replay counter `epoch` (nullable); out[i] = i for n_dev[0] <= i < cap. */
+int bkg_randperm_dev(const int64_t* n_dev, int64_t cap, uint64_t seed, const uint32_t* epoch, int64_t* out, void* stream);
 /* The sampler of biomedkg/kge_module.py:86-102 for one PADDED mini-batch with every extent in device memory (sizes as
  * written by bkg_saint_batch; head / tail / type hold `rows` entries, the first sizes[1] are edges): hash set of the
  * positives, ONE round of int(1.1 k / prob) candidates (k = neg_ratio * sizes[1]; the caller has checked prob > 0.9, so

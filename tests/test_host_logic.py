@@ -163,3 +163,13 @@ def test_checkpoint_with_metric_states_or_missing_weights(tmp_path):
     torch.save(short, tmp_path / "short.ckpt")
     with pytest.raises(RuntimeError):
         KGEModule.load_from_checkpoint(str(tmp_path / "short.ckpt"), strict=True)
+
+
+def test_gcl_edge_bucket_ladder():
+    """biomedkg_amd/sampled_gcl.py: geometric capacities (< 25 % padding), capped by the most edges a batch can hold."""
+    from biomedkg_amd.sampled_gcl import edge_buckets
+    b = edge_buckets(640_000)
+    assert b[-1] == 640_000 and b[0] == 4096 and list(b) == sorted(set(b))
+    assert all(v % 1024 == 0 for v in b[:-1])
+    assert all(hi <= 1.25 * lo + 1024 for lo, hi in zip(b, b[1:]))
+    assert edge_buckets(1000) == (1000,) and edge_buckets(5000) == (4096, 5000)
