@@ -44,6 +44,18 @@ constexpr int NX_BJ = 64;   // rows of a j-tile
 #ifndef NX_FWD16_NW
 #define NX_FWD16_NW 8        // waves per workgroup of the bf16 forward at h > 128 (experiment knob)
 #endif
+#ifndef NX_FWD16_X2
+#define NX_FWD16_X2 1        // bf16 forward: 64 anchor rows per wave, LDS-DMA staging (ntx2_fwd16x2_kernel); 0: the generic kernel
+#endif
+#ifndef NX_X2_RD
+#define NX_X2_RD 2           // fragment reads in flight ahead of their MFMAs in the x2 forward at h = 256 (2: 24 B of scratch)
+#endif
+#ifndef NX_PINGPONG
+#define NX_PINGPONG 1        // 8-wave bf16 forward: the two waves of a SIMD run half a tile apart (0: all waves in step; 2: fp32 too)
+#endif
+#ifndef NX_PP_PRIO
+#define NX_PP_PRIO 0         // s_setprio of the later-dispatched half in the ping-pong forward (experiment knob)
+#endif
 
 struct NxArgs {
   const void* zn;      // [M][HPAD] normalised rows, zero padded columns (fp32 or bf16)
@@ -89,14 +101,17 @@ template <int CTRL>
 __device__ __forceinline__ float nx_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float nx_transpose_reduce32(const nx_acc_t& e0, const nx_acc_t& e1, int l31) {
+// (TWO: the values are e0 + f0 / e1 + f1, the tiles of a wave's two anchor blocks, added pair by pair on the way in)
+template <bool TWO>
+__device__ __forceinline__ float nx_transpose_reduce32_of(const nx_acc_t& e0, const nx_acc_t& e1, const nx_acc_t& f0,
+                                                          const nx_acc_t& f1, int l31) {
   float a[16], b[8], c[4], d[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     // x' = {x.row0, y.row0, x.row2, y.row2}, y' = {x.row1, y.row1, x.row3, y.row3}.  Inline asm: on ROCm 7.2 the builtin
     // __builtin_amdgcn_permlane16_swap hands back the new first operand in BOTH result slots (scripts/dev_lanes.hip);
     // hipcc pads nothing around an asm statement, hence the s_nop on either side (cdna_hip_programming.md 5.7)
-    float x = e0[r], y = e1[r];
+    float x = TWO ? e0[r] + f0[r] : e0[r], y = TWO ? e1[r] + f1[r] : e1[r];
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
     a[r] = x + y;                                              // rows 0,2: value r; rows 1,3: value 16 + r
   }
@@ -128,6 +143,9 @@ __device__ __forceinline__ float nx_transpose_reduce32(const nx_acc_t& e0, const
   const float keep = hi ? d[1] : d[0], send = hi ? d[0] : d[1];
   return keep + nx_dpp<0xB1>(send);                            // quad_perm [1,0,3,2]
 }
+__device__ __forceinline__ float nx_transpose_reduce32(const nx_acc_t& e0, const nx_acc_t& e1, int l31) {
+  return nx_transpose_reduce32_of<false>(e0, e1, e0, e1, l31);
+}
 
 __device__ __forceinline__ int nx_acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
@@ -155,7 +173,14 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   auto tile_at = [&](int b) { return smem + b * TILE_BYTES; };
-  float* aux = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);  // FWD: colbuf[2][NW][64]   BWD: rdj[2][64]
+  // Forward at 8 waves (two per SIMD): every tile is a matrix phase (the Gram product) followed by a vector phase (exp2,
+  // row sums, the column-sum butterfly) of about the same length, and the per-tile barrier keeps the two waves of a SIMD
+  // in the SAME phase -- they queue for the matrix pipe, then for the vector issue port (MI355X_MICROARCH.md "Two waves
+  // per SIMD": both are per-SIMD resources).  PP: waves NW/2.. ("late" half, the second wave of each SIMD) finish tile
+  // t-1's vector phase BEFORE tile t's matrix phase, so between two barriers a SIMD always has one wave on each pipe.
+  constexpr bool PP = (NX_PINGPONG == 2 || (NX_PINGPONG == 1 && BF16)) && !BWD && NW == 8;   // (2: the fp32 forward too)
+  constexpr int NSLOT = PP ? 3 : 2;                              // column-sum buffers in flight (PP: the late half writes a tile later)
+  float* aux = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);  // FWD: colbuf[NSLOT][NW][64]   BWD: rdj[2][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int M = a.M;
@@ -291,30 +316,8 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
   load_anchor(P);
   int buf = 0;
 
-  auto body = [&](uint4 (&st)[NPC], float& st_rd) {
-    commit(buf, st, st_rd);
-    __syncthreads();
-    if (!BWD && col_pending && tid < NX_BJ) {      // previous tile's column sums: add the waves in wave order
-      const float* cb = aux + (buf ^ 1) * (NW * NX_BJ);
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) v += cb[w * NX_BJ + tid];
-      a.colitem[col_item * NX_BJ + tid] = v;
-    }
-    // next item; the registers just committed take the tile DEPTH items ahead
-    int P_next = P, jt_next = jt;
-    item_after(P_next, jt_next);
-    if (x + DEPTH < x_end) {
-      int Pa = P_next, jta = jt_next;
-      if (DEPTH == 2) item_after(Pa, jta);
-      prefetch(jta, st, st_rd);
-    }
-
-    const int j0 = jt * NX_BJ;
-    const bool need_mask = (j0 + NX_BJ > M) || (P * PR + wave * 32 + 32 > a.n_anchor) || (j0 <= i_hi && j0 + NX_BJ > i_lo);
-
-    // ---- S^T[j][i] for the tile's two 32-row halves
-    nx_acc_t s[2];
+  // ---- S^T[j][i] for the two 32-row halves of the j-tile in LDS buffer buf_
+  auto gram = [&](int buf_, nx_acc_t (&s)[2]) {
     if (!BF16) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
         const int at = PAD16 ? rowP + 32 * k : rowA + ((32 * (k & 7)) ^ rowT) + 16384 * (k >> 3);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          dst[t] = *reinterpret_cast<const uint4*>(tile_at(buf) + at + t * (PAD16 ? 32 * ROWB16 : 8192));
+          dst[t] = *reinterpret_cast<const uint4*>(tile_at(buf_) + at + t * (PAD16 ? 32 * ROWB16 : 8192));
       };
 #pragma unroll
       for (int k = 0; k < RD && k < KF; ++k) read_k(k, ring[k % RING]);
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
                                                          k == 0 ? zero16 : s[t], 0, 0, 0);
       }
     } else {
-      const float* zj = reinterpret_cast<const float*>(tile_at(buf));
+      const float* zj = reinterpret_cast<const float*>(tile_at(buf_));
 #pragma unroll
       for (int k = 0; k < KF; ++k) {
         const float4 b = __builtin_bit_cast(float4, zi[k]);
@@ -362,8 +365,10 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
       }
     }
 
-    // ---- E = exp2(S) (bf16: S still needs the scale), masked where the tile touches the diagonal / the boundary
-    const float* rdj = aux + buf * NX_BJ + 4 * lh;     // per-lane base: the row of register r is a compile-time offset from it
+  };
+  // ---- E = exp2(S), masked where the tile touches the diagonal / the boundary; row sums (forward) or W (backward)
+  auto expsum = [&](nx_acc_t (&s)[2], int j0, bool need_mask, int buf_) {
+    const float* rdj = aux + buf_ * NX_BJ + 4 * lh;     // per-lane base: the row of register r is a compile-time offset from it
     // two copies of the loop, chosen ONCE per tile by the wave-uniform predicate: interior tiles (all but the few that
     // touch the diagonal or the boundary) run without the per-element compare / select / branch
     if (need_mask) {
@@ -391,12 +396,50 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
         }
     }
 
+  };
+  // ---- forward: this wave's column sums of the tile -> colbuf[slot_][wave]
+  auto colwrite = [&](const nx_acc_t (&s)[2], int slot_) {
+    const float v = nx_transpose_reduce32(s[0], s[1], l31);
+    aux[slot_ * (NW * NX_BJ) + wave * NX_BJ + 32 * (l31 >> 4) + nx_acc_row(l31 & 15, lh)] = v;
+  };
+  // the waves' column sums of one item, added in wave order by the first 64 threads
+  auto colreduce = [&](int slot_, long long item_) {
+    const float* cb = aux + slot_ * (NW * NX_BJ);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += cb[w * NX_BJ + tid];
+    a.colitem[item_ * NX_BJ + tid] = v;
+  };
+  auto rowseg_write = [&](int P_) {
+    const float tot = rowsum + __shfl_xor(rowsum, 32, 64);
+    if (lh == 0) a.rowseg[((size_t)blockIdx.x + P_) * PR + wave * 32 + l31] = tot;
+    rowsum = 0.f;
+  };
+  auto body = [&](uint4 (&st)[NPC], float& st_rd) {
+    commit(buf, st, st_rd);
+    __syncthreads();
+    if (!BWD && col_pending && tid < NX_BJ) colreduce(buf ^ 1, col_item);      // previous tile's column sums
+    // next item; the registers just committed take the tile DEPTH items ahead
+    int P_next = P, jt_next = jt;
+    item_after(P_next, jt_next);
+    if (x + DEPTH < x_end) {
+      int Pa = P_next, jta = jt_next;
+      if (DEPTH == 2) item_after(Pa, jta);
+      prefetch(jta, st, st_rd);
+    }
+
+    const int j0 = jt * NX_BJ;
+    const bool need_mask = (j0 + NX_BJ > M) || (P * PR + wave * 32 + 32 > a.n_anchor) || (j0 <= i_hi && j0 + NX_BJ > i_lo);
+
+    nx_acc_t s[2];
+    gram(buf, s);
+    expsum(s, j0, need_mask, buf);
+
     if (!BWD) {
       // column sums, unless the tile lies inside the panel's own columns (those pairs are also computed transposed)
       col_pending = !a.rect && jt >= (P + 1) * Q;
       if (col_pending) {
-        const float v = nx_transpose_reduce32(s[0], s[1], l31);
-        aux[buf * (NW * NX_BJ) + wave * NX_BJ + 32 * (l31 >> 4) + nx_acc_row(l31 & 15, lh)] = v;
+        colwrite(s, buf);
         col_item = x;
       }
     } else if (BF16) {
@@ -444,9 +487,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     // ---- advance; forward: leaving the panel -> write its row sums, take the next panel's anchors
     const bool leave = (P_next != P) || (x + 1 == x_end);
     if (!BWD && leave) {
-      const float tot = rowsum + __shfl_xor(rowsum, 32, 64);
-      if (lh == 0) a.rowseg[((size_t)blockIdx.x + P) * PR + wave * 32 + l31] = tot;
-      rowsum = 0.f;
+      rowseg_write(P);
       if (x + 1 < x_end) load_anchor(P_next);
     }
     P = P_next;
@@ -454,6 +495,66 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
     buf ^= 1;
     ++x;
   };
+  if constexpr (PP) {
+    const bool late = wave >= NW / 2;
+    if (late && NX_PP_PRIO) __builtin_amdgcn_s_setprio(NX_PP_PRIO);
+    nx_acc_t s[2];
+    bool owed = false, d_mask = false, d_col = false;      // late half: the tile whose vector phase is still owed
+    int d_P = 0, d_j0 = 0, d_slot = 0;
+    bool p1 = false, p2 = false;                           // column sums of items x-1 / x-2 still to be added over the waves
+    long long it1 = 0, it2 = 0;
+    int slot = 0;                                          // colbuf slot of item x (x mod 3 from this block's first item)
+    while (x < x_end) {
+      commit(buf, stA, rdA);
+      __syncthreads();
+      if (p2 && tid < NX_BJ) colreduce(slot == 2 ? 0 : slot + 1, it2);       // item x-2: both halves have written it
+      int P_next = P, jt_next = jt;
+      item_after(P_next, jt_next);
+      if (x + 1 < x_end) prefetch(jt_next, stA, rdA);
+      const int j0 = jt * NX_BJ;
+      const bool col_now = !a.rect && jt >= (P + 1) * Q;
+      if (!late) {
+        const bool need_mask = (j0 + NX_BJ > M) || (P * PR + wave * 32 + 32 > a.n_anchor) || (j0 <= i_hi && j0 + NX_BJ > i_lo);
+        gram(buf, s);
+        expsum(s, j0, need_mask, buf);
+        if (col_now) colwrite(s, slot);
+        if (P_next != P || x + 1 == x_end) {
+          rowseg_write(P);
+          if (x + 1 < x_end) load_anchor(P_next);
+        }
+      } else {
+        if (owed) {
+          expsum(s, d_j0, d_mask, buf);
+          if (d_col) colwrite(s, d_slot);
+          if (d_P != P) {
+            rowseg_write(d_P);
+            load_anchor(P);
+          }
+        }
+        d_mask = (j0 + NX_BJ > M) || (P * PR + wave * 32 + 32 > a.n_anchor) || (j0 <= i_hi && j0 + NX_BJ > i_lo);
+        gram(buf, s);
+        owed = true; d_P = P; d_j0 = j0; d_col = col_now; d_slot = slot;
+      }
+      p2 = p1; it2 = it1;
+      p1 = col_now; it1 = x;
+      P = P_next; jt = jt_next;
+      buf ^= 1;
+      slot = slot == 2 ? 0 : slot + 1;
+      ++x;
+    }
+    if (late && owed) {
+      expsum(s, d_j0, d_mask, buf);
+      if (d_col) colwrite(s, d_slot);
+      rowseg_write(d_P);
+    }
+    __syncthreads();
+    if (tid < NX_BJ) {                                     // the last two items (slot = the slot the next item would take)
+      if (p2) colreduce(slot == 2 ? 0 : slot + 1, it2);
+      if (p1) colreduce(slot == 0 ? 2 : slot - 1, it1);
+    }
+    return;
+  }
+
   while (x < x_end) {
     body(stA, rdA);
     if (DEPTH == 2) {
@@ -464,13 +565,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 
   if (!BWD) {
     __syncthreads();
-    if (col_pending && tid < NX_BJ) {
-      const float* cb = aux + (buf ^ 1) * (NW * NX_BJ);
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) v += cb[w * NX_BJ + tid];
-      a.colitem[col_item * NX_BJ + tid] = v;
-    }
+    if (col_pending && tid < NX_BJ) colreduce(buf ^ 1, col_item);
   } else {
     // dz[ct][r]: row i = wave*32 + row(r, lh), column 32 ct + l31 of this split's partial
     const int split = blockIdx.x % a.splits;
@@ -484,6 +579,241 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
         if (ia < a.n_anchor) out[(size_t)ia * HPAD + 32 * ct + l31] = dz[ct][r];
       }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ bf16 forward, 64 anchors per wave
+// The forward kernel above reads one 1 KB A fragment from LDS per 32x32x16 MFMA (the B fragment is the wave's 32 anchor
+// rows in registers): 32 B per cycle and SIMD = 128 B per cycle and CU, exactly what the LDS delivers -- the Gram phase is
+// LDS-bound as much as matrix-bound, and the exp / sum phase queues behind it (MFMA busy 0.41, 0.34 of the bf16 peak at
+// N = 130k).  Here every wave keeps TWO 32-row anchor blocks in registers (128 VGPRs at h = 256), so each fragment read
+// feeds two MFMAs: half the LDS traffic per flop, 512-row panels.  What pays for the registers: the j-tile is written to
+// LDS by global_load_lds_dwordx4 (no staging registers; the T10 (b) XOR image, the swizzle applied to the SOURCE address
+// since an LDS-DMA's destination is lane-linear -- cdna_hip_programming.md section 5).  The two waves of a SIMD run half
+// a tile apart (PP above): one in its matrix phase (64 MFMAs), the other in its vector phase (64 exp2, the row sums, one
+// column-sum butterfly over the SUM of its two blocks' tiles).
+template <int HP>
+__global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
+  constexpr int NW = 8, AB = 2, HPAD = 32 * HP, PR = 32 * NW * AB, Q = PR / NX_BJ;
+  constexpr int ROW_BYTES = HPAD * 2, TILE_BYTES = NX_BJ * ROW_BYTES, KF = HPAD / 16;
+  constexpr int NG = TILE_BYTES / 1024 / NW;                     // LDS-DMA instructions per wave and tile (4 rows of a slab each)
+  static_assert(HP % 4 == 0 && NG >= 1, "bf16 image is made of 128-column slabs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto tile_at = [&](int b) { return smem + b * TILE_BYTES; };
+  float* aux = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);  // colbuf[3][NW][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = tid >> 6;      // (left in a VGPR on purpose: with scalar control flow hipcc's schedule of this loop spills 400 B)
+  const int M = a.M;
+  const unsigned char* zn = static_cast<const unsigned char*>(a.zn);
+
+  long long x = (long long)blockIdx.x * a.n_items / gridDim.x;
+  const long long x_end = (long long)(blockIdx.x + 1) * a.n_items / gridDim.x;
+  if (x >= x_end) return;
+  int P, jt;
+  if (a.rect) {
+    P = (int)(x / a.n_jtiles);
+    jt = (int)(x % a.n_jtiles);
+  } else {
+    P = nx_panel_of(x, a.n_panels, a.n_jtiles, Q);
+    jt = P * Q + (int)(x - nx_start(P, a.n_jtiles, Q));
+  }
+  auto item_after = [&](int& P_, int& jt_) {
+    ++jt_;
+    if (jt_ == a.n_jtiles) { ++P_; jt_ = a.rect ? 0 : P_ * Q; }
+  };
+
+  // ---- j-tile -> LDS image [slab][row][256 B], chunk c of a row at position c ^ tag(row); rows past M: row M - 1 (masked).
+  // DMA q = wave * NG + g of a tile writes rows 4 (q & 15) .. + 3 of slab q >> 4; lane: row 4 (q & 15) + (lane >> 4) -- whose
+  // tag is ((lane >> 4) << 2) | (q & 3) -- position lane & 15.  Per lane that is ONE offset, XORed with 16 (q & 3) per DMA
+  // (opaque to the optimiser on purpose: hoisted out of the tile loop, the NG variants would cost registers this kernel
+  // does not have)
+  const int st_row = lane >> 4;
+  const unsigned st_lane = (unsigned)(st_row * ROW_BYTES + 16 * ((lane & 15) ^ (st_row << 2)));
+  auto stage = [&](int jt_, int buf_) {
+    const int j0 = jt_ * NX_BJ;
+    unsigned off = st_lane;
+    asm volatile("" : "+v"(off));
+    const int ws = __builtin_amdgcn_readfirstlane(wave);     // scalar here: bases and LDS targets are SGPR arithmetic
+    if (j0 + NX_BJ <= M) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int q = ws * NG + g, slab = q >> 4;
+        const unsigned char* base = zn + (size_t)(j0 + 4 * (q & 15)) * ROW_BYTES + slab * 256;     // wave-uniform
+        unsigned char* dst = tile_at(buf_) + slab * (NX_BJ * 256) + (q & 15) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (off ^ (16u * (q & 3)))),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int q = ws * NG + g, slab = q >> 4, row = 4 * (q & 15) + st_row;
+        const int jr = min(j0 + row, M - 1);
+        const unsigned char* src = zn + (size_t)jr * ROW_BYTES + slab * 256 + ((off ^ (16u * (q & 3))) & 255u);
+        unsigned char* dst = tile_at(buf_) + slab * (NX_BJ * 256) + (q & 15) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- anchor fragments: block b of this wave = anchors P * PR + wave * 64 + 32 b + l31 (their row ids are recomputed
+  //      where a masked tile needs them: this kernel has no registers to keep them in)
+  uint4 zi[AB][KF];
+  auto anchor_row = [&](int P_, int b) {
+    const int a_idx = P_ * PR + wave * 64 + 32 * b + l31;
+    return a_idx < a.n_anchor ? (a.anchors ? a.anchors[a_idx] : a_idx) : -1;
+  };
+  auto load_anchor = [&](int P_) {
+#pragma unroll
+    for (int b = 0; b < AB; ++b) {
+      const int ig = anchor_row(P_, b);
+#pragma unroll
+      for (int k = 0; k < KF; ++k) {
+        zi[b][k] = make_uint4(0u, 0u, 0u, 0u);
+        if (ig >= 0) zi[b][k] = *reinterpret_cast<const uint4*>(zn + (size_t)ig * ROW_BYTES + (2 * k + lh) * 16);
+      }
+    }
+  };
+
+  // fragment k (chunk 2 (k & 7) + lh of slab k >> 3) of row 32 t + l31 sits at position (2 (k & 7)) ^ (tag ^ lh): ONE lane
+  // constant, XORed with 32 (k & 7) per read (again kept from being hoisted into eight registers)
+  const int tag31 = ((l31 & 3) << 2) | ((l31 >> 2) & 3);
+  const int row_lc = 256 * l31 + 16 * (tag31 ^ lh);
+
+  nx_acc_t s[AB][2];
+  float rowsum[AB] = {0.f, 0.f};
+
+  auto gram = [&](int buf_) {
+    constexpr int RD = HP > 4 ? NX_X2_RD : 3, RING = RD + 1;      // (h = 256: the two anchor blocks leave little room for reads ahead)
+    uint4 ring[RING][2];
+    int lc = row_lc + buf_ * TILE_BYTES;
+    asm volatile("" : "+v"(lc));
+    auto read_k = [&](int k, uint4 (&dst)[2]) {
+      const int at = (lc ^ (32 * (k & 7))) + 16384 * (k >> 3);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) dst[t] = *reinterpret_cast<const uint4*>(smem + at + t * 8192);
+    };
+#pragma unroll
+    for (int k = 0; k < RD && k < KF; ++k) read_k(k, ring[k % RING]);
+    const nx_acc_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+      if (k + RD < KF) read_k(k + RD, ring[(k + RD) % RING]);
+#pragma unroll
+      for (int b = 0; b < AB; ++b)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          s[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nx_bf16x8_t, ring[k % RING][t]),
+                                                            __builtin_bit_cast(nx_bf16x8_t, zi[b][k]),
+                                                            k == 0 ? zero16 : s[b][t], 0, 0, 0);
+    }
+  };
+  // E = exp2(S) (both images carry sqrt(log2(e) / tau)), masked on the diagonal / at the boundary; row sums; with `col`
+  // the column sums over the wave's 64 anchors -> colbuf[slot_][wave]
+  auto vector_phase = [&](int P_, int j0, bool need_mask, bool col, int slot_) {
+#pragma unroll
+    for (int b = 0; b < AB; ++b) {
+      if (need_mask) {
+        const int ig = anchor_row(P_, b);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int jg = j0 + 32 * t + nx_acc_row(r, lh);
+            float e = __builtin_amdgcn_exp2f(s[b][t][r]);
+            e = (jg < M && ig >= 0 && jg != ig) ? e : 0.f;
+            rowsum[b] += e;
+            s[b][t][r] = e;
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(s[b][t][r]);
+            rowsum[b] += e;
+            s[b][t][r] = e;
+          }
+      }
+    }
+    if (col) {
+      const float v = nx_transpose_reduce32_of<true>(s[0][0], s[0][1], s[1][0], s[1][1], l31);
+      aux[slot_ * (NW * NX_BJ) + wave * NX_BJ + 32 * (l31 >> 4) + nx_acc_row(l31 & 15, lh)] = v;
+    }
+  };
+  auto colreduce = [&](int slot_, long long item_) {
+    const float* cb = aux + slot_ * (NW * NX_BJ);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += cb[w * NX_BJ + tid];
+    a.colitem[item_ * NX_BJ + tid] = v;
+  };
+  auto rowseg_write = [&](int P_) {
+#pragma unroll
+    for (int b = 0; b < AB; ++b) {
+      const float tot = rowsum[b] + __shfl_xor(rowsum[b], 32, 64);
+      if (lh == 0) a.rowseg[((size_t)blockIdx.x + P_) * PR + wave * 64 + 32 * b + l31] = tot;
+      rowsum[b] = 0.f;
+    }
+  };
+  // does the tile touch the boundary (rows past M, anchors past n_anchor) or the wave's own diagonal?  (an anchor LIST
+  // -- the rectangular forward of a row-partitioned run -- has no range to test: always masked)
+  auto mask_of = [&](int P_, int j0) {
+    const int i0 = P_ * PR + wave * 64;
+    return (j0 + NX_BJ > M) || (i0 + 64 > a.n_anchor) || a.anchors != nullptr || (j0 < i0 + 64 && j0 + NX_BJ > i0);
+  };
+
+  // ---- the loop runs over HALF-steps h: a wave is in its matrix phase (gram) on the even ones and in its vector phase
+  //      on the odd ones of ITS OWN count hh = h - late, so that the two waves of a SIMD are always in different phases.
+  //      Block-level duties sit on the even half-steps h = 2k: the column sums of item k - 2 (early waves wrote them at
+  //      h = 2k - 3, late ones at 2k - 2) are added over the waves, and tile k + 1 is sent to the buffer tile k - 1 was
+  //      last read from at h = 2k - 1.
+  const int n_it = (int)(x_end - x);
+  const bool late = wave >= NW / 2;
+  if (late && NX_PP_PRIO) __builtin_amdgcn_s_setprio(NX_PP_PRIO);
+  int Pe = P, jte = jt;                                    // block timeline: item k at h = 2k
+  bool p0 = false, p1 = false, p2 = false;                 // column-sum flags of items k, k - 1, k - 2
+  int slot_e = 0;
+  int kw = 0;                                              // this wave's own item (P, jt; the kw-th of the block), its buffer and colbuf slot
+  int buf = 0, slot = 0;
+  stage(jt, 0);
+  load_anchor(P);
+  for (int h = 0; h <= 2 * n_it; ++h) {
+    __syncthreads();                                       // (waits for this wave's LDS-DMAs first)
+    if ((h & 1) == 0) {
+      const int k = h >> 1;
+      p2 = p1; p1 = p0;
+      p0 = k < n_it && !a.rect && jte >= (Pe + 1) * Q;
+      if (p2 && tid < NX_BJ) colreduce(slot_e == 0 ? 1 : (slot_e == 1 ? 2 : 0), x + k - 2);   // slot of k - 2 = (k + 1) mod 3
+      if (k + 1 < n_it) {
+        item_after(Pe, jte);
+        stage(jte, (int)((k + 1) & 1));
+      }
+      slot_e = slot_e == 2 ? 0 : slot_e + 1;
+    }
+    const int hh = h - (late ? 1 : 0);
+    if (hh < 0 || hh >= 2 * n_it) continue;
+    const int j0 = jt * NX_BJ;
+    if ((hh & 1) == 0) {
+      gram(buf);
+    } else {
+      vector_phase(P, j0, mask_of(P, j0), !a.rect && jt >= (P + 1) * Q, slot);
+      int P_next = P, jt_next = jt;
+      item_after(P_next, jt_next);
+      const bool last = kw + 1 == n_it;
+      if (P_next != P || last) {
+        rowseg_write(P);
+        if (!last) load_anchor(P_next);
+      }
+      P = P_next; jt = jt_next;
+      ++kw;
+      buf ^= 1;
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  }
+  __syncthreads();
+  // the last item (early waves wrote it at h = 2 n - 1, late ones at 2 n); slot_e = (n + 1) mod 3, the item's = (n - 1) mod 3
+  if (p1 && tid < NX_BJ) colreduce(slot_e == 0 ? 1 : (slot_e == 1 ? 2 : 0), x + n_it - 1);
 }
 
 // ------------------------------------------------------------------------------------------------ small kernels
@@ -599,7 +929,7 @@ template <bool BF16, int HP, int NW, bool BWD>
 static NxPlan nx_plan() {
   constexpr int HPAD = 32 * HP;
   const int tile = BF16 ? (BWD ? NX_BJ * HPAD * 2 : NX_BJ * (HPAD * 2 + 16)) : NX_BJ * (HPAD + 4) * 4;
-  const int smem = 2 * tile + (BWD ? 2 * NX_BJ : 2 * NW * NX_BJ) * 4;
+  const int smem = 2 * tile + (BWD ? 2 * NX_BJ : (((NX_PINGPONG == 2 || (NX_PINGPONG == 1 && BF16)) && NW == 8) ? 3 : 2) * NW * NX_BJ) * 4;
   static int occ_cache = -1;
   if (occ_cache < 0) {
     hipFuncSetAttribute((const void*)ntx2_kernel<BF16, HP, NW, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -662,11 +992,35 @@ static int nx_launch(NxArgs a, int grid, hipStream_t s) {
   return check_launch(BWD ? "bkg_ntxent_backward" : "bkg_ntxent_forward");
 }
 
+template <int HP>
+static NxPlan nx_plan_x2() {
+  const int smem = 2 * NX_BJ * 64 * HP + 3 * 8 * NX_BJ * 4;
+  static int occ_cache = -1;
+  if (occ_cache < 0) {
+    hipFuncSetAttribute((const void*)ntx2_fwd16x2_kernel<HP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)ntx2_fwd16x2_kernel<HP>, 512, smem) != hipSuccess || occ < 1)
+      occ = 1;
+    occ_cache = occ;
+  }
+  return NxPlan{8, smem, occ_cache};
+}
+template <int HP>
+static int nx_launch_x2(NxArgs a, int grid, hipStream_t s) {
+  const NxPlan p = nx_plan_x2<HP>();
+  hipLaunchKernelGGL((ntx2_fwd16x2_kernel<HP>), dim3(grid), dim3(512), p.smem, s, a);
+  return check_launch("bkg_ntxent_forward");
+}
+
 static int nx_occ(bool bf16, int hp, bool bwd) {
   if (bwd) { NX_BWD_CASES(nx_occ_of) }
+  if (bf16 && NX_FWD16_X2) return hp <= 4 ? nx_plan_x2<4>().occ : nx_plan_x2<8>().occ;
   NX_FWD_CASES(nx_occ_of)
 }
-static int nx_run_fwd(bool bf16, int hp, NxArgs a, int grid, hipStream_t s) { NX_FWD_CASES(nx_launch, a, grid, s) }
+static int nx_run_fwd(bool bf16, int hp, NxArgs a, int grid, hipStream_t s) {
+  if (bf16 && NX_FWD16_X2) return hp <= 4 ? nx_launch_x2<4>(a, grid, s) : nx_launch_x2<8>(a, grid, s);
+  NX_FWD_CASES(nx_launch, a, grid, s)
+}
 static int nx_run_bwd(bool bf16, int hp, NxArgs a, int grid, hipStream_t s) { NX_BWD_CASES(nx_launch, a, grid, s) }
 
 struct NxShape { int hpad, hp, pr, n_panels, n_jtiles, grid, splits, jt_per_split; long long n_items; };
@@ -678,7 +1032,7 @@ static NxShape nx_shape(int64_t M, int64_t n_anchor, int h, bool bf16, bool bwd)
   if (!rect) n_anchor = M;
   sh.hpad = bf16 ? (h <= 128 ? 128 : 256) : ((h + 31) / 32) * 32;
   sh.hp = sh.hpad / 32;
-  sh.pr = 32 * nx_waves(bf16, sh.hp, bwd);
+  sh.pr = (bf16 && !bwd && NX_FWD16_X2) ? 512 : 32 * nx_waves(bf16, sh.hp, bwd);      // (x2 forward: 64 anchors per wave)
   sh.n_panels = (int)((n_anchor + sh.pr - 1) / sh.pr);
   sh.n_jtiles = (int)((M + NX_BJ - 1) / NX_BJ);
   sh.n_items = rect ? (long long)sh.n_panels * sh.n_jtiles : nx_start(sh.n_panels, sh.n_jtiles, sh.pr / NX_BJ);
