@@ -50,6 +50,9 @@ constexpr int NX_BJ = 64;   // rows of a j-tile
 #ifndef NX_X2_RD
 #define NX_X2_RD 2           // fragment reads in flight ahead of their MFMAs in the x2 forward at h = 256 (2: 24 B of scratch)
 #endif
+#ifndef NX_X2_ODD
+#define NX_X2_ODD 0          // the x2 forward's barrier between a tile's two half-steps: 0 none (15.8 ms at N = 130k), 1 raw s_barrier (16.5), 2 __syncthreads (16.3)
+#endif
 #ifndef NX_PINGPONG
 #define NX_PINGPONG 1        // 8-wave bf16 forward: the two waves of a SIMD run half a tile apart (0: all waves in step; 2: fp32 too)
 #endif
@@ -107,13 +110,22 @@ __device__ __forceinline__ float nx_transpose_reduce32_of(const nx_acc_t& e0, co
                                                           const nx_acc_t& f1, int l31) {
   float a[16], b[8], c[4], d[2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int r0 = 0; r0 < 16; r0 += 4) {
     // x' = {x.row0, y.row0, x.row2, y.row2}, y' = {x.row1, y.row1, x.row3, y.row3}.  Inline asm: on ROCm 7.2 the builtin
     // __builtin_amdgcn_permlane16_swap hands back the new first operand in BOTH result slots (scripts/dev_lanes.hip);
-    // hipcc pads nothing around an asm statement, hence the s_nop on either side (cdna_hip_programming.md 5.7)
-    float x = TWO ? e0[r] + f0[r] : e0[r], y = TWO ? e1[r] + f1[r] : e1[r];
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-    a[r] = x + y;                                              // rows 0,2: value r; rows 1,3: value 16 + r
+    // hipcc pads nothing around an asm statement, hence the s_nop on either side (cdna_hip_programming.md 5.7) -- of a
+    // group of four swaps on independent registers, not of each one (32 s_nop per tile less)
+    float x[4], y[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      x[q] = TWO ? e0[r0 + q] + f0[r0 + q] : e0[r0 + q];
+      y[q] = TWO ? e1[r0 + q] + f1[r0 + q] : e1[r0 + q];
+    }
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                 "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[r0 + q] = x[q] + y[q];       // rows 0,2: value r; rows 1,3: value 16 + r
   }
   {
     const bool hi = l31 & 8;
@@ -779,7 +791,14 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
   stage(jt, 0);
   load_anchor(P);
   for (int h = 0; h <= 2 * n_it; ++h) {
-    __syncthreads();                                       // (waits for this wave's LDS-DMAs first)
+    // even h: the full barrier (the compiler drains this wave's LDS-DMAs in front of it: tile k is complete); odd h: the
+    // waves only change phase -- a raw s_barrier, so that tile k + 1's DMAs stay in flight across it (NX_X2_ODD: 0 none,
+    // 1 raw, 2 full)
+    if ((h & 1) == 0 || NX_X2_ODD == 2) __syncthreads();
+    else if (NX_X2_ODD == 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     if ((h & 1) == 0) {
       const int k = h >> 1;
       p2 = p1; p1 = p0;
