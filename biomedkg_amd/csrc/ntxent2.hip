@@ -53,6 +53,18 @@ constexpr int NX_BJ = 64;   // rows of a j-tile
 #ifndef NX_X2_ODD
 #define NX_X2_ODD 0          // the x2 forward's barrier between a tile's two half-steps: 0 none (15.8 ms at N = 130k), 1 raw s_barrier (16.5), 2 __syncthreads (16.3)
 #endif
+#ifndef NX_BWD16_PIPE
+#define NX_BWD16_PIPE 1        // bf16 backward at h > 128: the three-tile software pipeline (ntx2_bwd16p_kernel); 0: ntx2_kernel
+#endif
+#ifndef NX_PIPE_DS           // ntx2_bwd16p_kernel: instructions of each class issued behind every MFMA (sweep: DESIGN.md 9-3)
+#define NX_PIPE_DS 4
+#endif
+#ifndef NX_PIPE_VALU
+#define NX_PIPE_VALU 4
+#endif
+#ifndef NX_PIPE_TRANS
+#define NX_PIPE_TRANS 0         // (1: hipcc then puts the whole vector phase in front of the MFMAs: 69 -> slower)
+#endif
 #ifndef NX_PINGPONG
 #define NX_PINGPONG 1        // 8-wave bf16 forward: the two waves of a SIMD run half a tile apart (0: all waves in step; 2: fp32 too)
 #endif
@@ -835,6 +847,231 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
   if (p1 && tid < NX_BJ) colreduce(slot_e == 0 ? 1 : (slot_e == 1 ? 2 : 0), x + n_it - 1);
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 backward, software-pipelined
+// The backward of ntx2_kernel at h = 256 runs one wave per SIMD (444 registers), and a tile is a chain: Gram product (32
+// MFMAs) -> exp2 / (1/D_i + 1/D_j) / bf16 convert (~430 vector instructions) -> dZ product (32 MFMAs): nothing overlaps,
+// the matrix pipe is busy 0.43 of the time.  Here the chain is cut across THREE tiles: iteration t issues, as one
+// straight-line region of mutually independent work,
+//     V(t)    the vector phase of tile t          S(t) -> W(t) (bf16 A fragments)
+//     G(t+1)  the Gram product of tile t + 1      -> S(t + 1)
+//     D(t-1)  the dZ product of tile t - 1        W(t - 1), tile t - 1 -> dZ
+// so every MFMA has vector work of another tile to issue beside it.  Four j-tiles live in LDS (t - 1 for D, t, t + 1 for G,
+// t + 2 arriving), written by global_load_lds_dwordx4 (the T10 (b) image, swizzle on the source address) together with
+// their 1/D_j values; two S and two W register sets alternate (the loop body is instantiated twice).  The ends are not
+// peeled: D(-1) runs with W = 0 over tile 0, G(n) recomputes tile n - 1; the last D runs after the loop.
+template <int HP>
+__global__ __launch_bounds__(256) void ntx2_bwd16p_kernel(NxArgs a) {
+  constexpr int NW = 4, HPAD = 32 * HP, PR = 32 * NW, NB = 4;
+  constexpr int ROW_BYTES = HPAD * 2, TILE_BYTES = NX_BJ * ROW_BYTES, KF = HPAD / 16;
+  constexpr int NG = TILE_BYTES / 1024 / NW;                     // LDS-DMAs per wave and tile
+  static_assert(HP % 4 == 0, "bf16 image is made of 128-column slabs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* rdj_ring = reinterpret_cast<float*>(smem + NB * TILE_BYTES);   // [NB][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int M = a.M;
+  const unsigned char* zn = static_cast<const unsigned char*>(a.zn);
+
+  const int split = blockIdx.x % a.splits, P = blockIdx.x / a.splits;
+  const int jt0 = split * a.jt_per_split, jt1 = min(jt0 + a.jt_per_split, a.n_jtiles), n = jt1 - jt0;
+  if (n <= 0) return;
+
+  // ---- tile jt_ (clamped to this block's last one) -> LDS buffer b_, its 1/D_j values -> rdj_ring[b_]
+  const int st_row = lane >> 4;
+  const unsigned st_lane = (unsigned)(st_row * ROW_BYTES + 16 * ((lane & 15) ^ (st_row << 2)));
+  auto stage = [&](int jt_, int b_) {
+    const int j0 = min(jt_, jt1 - 1) * NX_BJ;
+    unsigned off = st_lane;
+    asm volatile("" : "+v"(off));
+    const int ws = __builtin_amdgcn_readfirstlane(wave);
+    if (j0 + NX_BJ <= M) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int q = ws * NG + g, slab = q >> 4;
+        const unsigned char* base = zn + (size_t)(j0 + 4 * (q & 15)) * ROW_BYTES + slab * 256;
+        unsigned char* dst = smem + b_ * TILE_BYTES + slab * (NX_BJ * 256) + (q & 15) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (off ^ (16u * (q & 3)))),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int q = ws * NG + g, slab = q >> 4, row = 4 * (q & 15) + st_row;
+        const int jr = min(j0 + row, M - 1);
+        const unsigned char* src = zn + (size_t)jr * ROW_BYTES + slab * 256 + ((off ^ (16u * (q & 3))) & 255u);
+        unsigned char* dst = smem + b_ * TILE_BYTES + slab * (NX_BJ * 256) + (q & 15) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+    if (ws == 0) {                                              // 64 floats: one 4-byte DMA of wave 0 (rows past M: masked later)
+      const float* src = a.rden + min(j0 + lane, M - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(rdj_ring + b_ * NX_BJ), 4, 0, 0);
+    }
+  };
+
+  // ---- anchor fragments of this wave's 32 rows
+  const int a_idx = P * PR + wave * 32 + l31;
+  const int i_glob = a_idx < a.n_anchor ? (a.anchors ? a.anchors[a_idx] : a_idx) : -1;
+  int mn = i_glob < 0 ? 0x7fffffff : i_glob, mx = i_glob;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    mn = min(mn, __shfl_xor(mn, o, 64));
+    mx = max(mx, __shfl_xor(mx, o, 64));
+  }
+  const int i_lo = __builtin_amdgcn_readfirstlane(mn), i_hi = __builtin_amdgcn_readfirstlane(mx);
+  uint4 zi[KF];
+#pragma unroll
+  for (int k = 0; k < KF; ++k) {
+    zi[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (i_glob >= 0) zi[k] = *reinterpret_cast<const uint4*>(zn + (size_t)i_glob * ROW_BYTES + (2 * k + lh) * 16);
+  }
+  const float rd_i = (i_glob >= 0) ? a.rden[i_glob] : 0.f;
+
+  const int tag31 = ((l31 & 3) << 2) | ((l31 >> 2) & 3);
+  const int row_lc = 256 * l31 + 16 * (tag31 ^ lh);
+  const int grp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, g1 = grp & 1, g2 = grp >> 1;
+  const int trL = 2 * g1 + (p4 >> 1), trQ = 64 * q4;
+  const int trC0 = 256 * (4 * g2 + q4) + 16 * (trL ^ (g2 & 3)) + 8 * (p4 & 1);
+  const int trC1 = 256 * (4 * g2 + q4) + 16 * (trL ^ ((g2 + 2) & 3)) + 8 * (p4 & 1) + 256 * 8;
+
+  nx_acc_t dz[HP];
+#pragma unroll
+  for (int t = 0; t < HP; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dz[t][r] = 0.f;
+
+  // S^T of the tile in buffer b_ (row reads of the T10 image)
+  auto gram = [&](int b_, nx_acc_t (&s)[2]) {
+    constexpr int RD = 3, RING = RD + 1;
+    uint4 ring[RING][2];
+    int lc = row_lc + b_ * TILE_BYTES;
+    asm("" : "+v"(lc));                                    // (not volatile: a volatile statement would fence the scheduler's region)
+    auto read_k = [&](int k, uint4 (&dst)[2]) {
+      const int at = (lc ^ (32 * (k & 7))) + 16384 * (k >> 3);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) dst[t] = *reinterpret_cast<const uint4*>(smem + at + t * 8192);
+    };
+#pragma unroll
+    for (int k = 0; k < RD && k < KF; ++k) read_k(k, ring[k % RING]);
+    const nx_acc_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+      if (k + RD < KF) read_k(k + RD, ring[(k + RD) % RING]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nx_bf16x8_t, ring[k % RING][t]),
+                                                       __builtin_bit_cast(nx_bf16x8_t, zi[k]), k == 0 ? zero16 : s[t], 0, 0, 0);
+    }
+  };
+  // W^T = exp2(S) (1/D_i + 1/D_j) as the four bf16 A fragments of the dZ product
+  auto weights = [&](const nx_acc_t (&s)[2], int slot_, nx_bf16x8_t (&wf)[4]) {
+    const float* rdj = rdj_ring + slot_ * NX_BJ + 4 * lh;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[t][r]) * (rd_i + rdj[32 * t + nx_acc_row(r, 0)]);
+        wf[2 * t + (r >> 3)][r & 7] = (__bf16)e;
+      }
+  };
+  // a tile that touches the diagonal or the boundary: the excluded pairs get S = -inf (exp2 -> 0) in a pass of their own,
+  // so that the pipelined region below exists once, without a per-element predicate
+  auto exclude = [&](nx_acc_t (&s)[2], int j0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jg = j0 + 32 * t + nx_acc_row(r, lh);
+        if (!(jg < M && i_glob >= 0 && jg != i_glob)) s[t][r] = -__builtin_inff();
+      }
+  };
+  // dZ += W Z_J over the tile in buffer b_ (transposed reads)
+  auto dzacc = [&](int b_, const nx_bf16x8_t (&wf)[4]) {
+    constexpr int N2 = 4 * HP, RD2 = 3, RING2 = RD2 + 1;
+    nx_s8_t bring[RING2];
+    int c0 = trC0 + b_ * TILE_BYTES, c1 = trC1 + b_ * TILE_BYTES;
+    asm("" : "+v"(c0), "+v"(c1));
+    auto read_b = [&](int i) {
+      const int ts = i / HP, ct = i % HP;
+      const int col = ((64 * (ct & 3)) ^ trQ) + 16384 * (ct >> 2) + 256 * (32 * (ts >> 1) + 16 * (ts & 1));
+      const nx_s4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) nx_s4_t*)(smem + c0 + col));
+      const nx_s4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) nx_s4_t*)(smem + c1 + col));
+      return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+#pragma unroll
+    for (int i = 0; i < RD2; ++i) bring[i % RING2] = read_b(i);
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+      if (i + RD2 < N2) bring[(i + RD2) % RING2] = read_b(i + RD2);
+      dz[i % HP] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i / HP], __builtin_bit_cast(nx_bf16x8_t, bring[i % RING2]),
+                                                           dz[i % HP], 0, 0, 0);
+    }
+  };
+  auto mask_of = [&](int jt_) {
+    const int j0 = jt_ * NX_BJ;
+    return (j0 + NX_BJ > M) || (P * PR + wave * 32 + 32 > a.n_anchor) || (j0 <= i_hi && j0 + NX_BJ > i_lo);
+  };
+
+  nx_acc_t sA[2], sB[2];
+  nx_bf16x8_t wA[4], wB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wA[q][e] = wB[q][e] = (__bf16)0.f;
+
+  // one iteration: tile t = jt0 + k; S(t) in sc, W(t - 1) in wp  ->  S(t + 1) in sn, W(t) in wc
+  auto step = [&](int k, nx_acc_t (&sc)[2], nx_acc_t (&sn)[2], nx_bf16x8_t (&wp)[4], nx_bf16x8_t (&wc)[4]) {
+    __syncthreads();                                       // tile t + 1 has landed; everybody is done with tile t - 2's buffer
+    stage(jt0 + k + 2, (k + 2) & (NB - 1));
+    const int jt = jt0 + k, bD = k == 0 ? 0 : (k - 1) & (NB - 1);
+    if (mask_of(jt)) exclude(sc, jt * NX_BJ);
+    __builtin_amdgcn_sched_barrier(0);
+    weights(sc, k & (NB - 1), wc);
+    gram((k + 1) & (NB - 1), sn);
+    dzacc(bD, wp);
+    // the issue order of the region: every MFMA followed by its share of the LDS reads and of the vector work (left to
+    // itself hipcc puts one step's 32 exp2 in front of the MFMAs and leaves the other step's MFMAs bare)
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, NX_PIPE_DS, 0);         // LDS reads
+      if (NX_PIPE_TRANS) __builtin_amdgcn_sched_group_barrier(0x400, NX_PIPE_TRANS, 0);   // exp2 (not part of the VALU class)
+      __builtin_amdgcn_sched_group_barrier(0x002, NX_PIPE_VALU, 0);       // vector instructions
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  stage(jt0, 0);
+  stage(jt0 + 1, 1);
+  __syncthreads();
+  gram(0, sA);
+  int k = 0;
+  for (; k + 1 < n; k += 2) {
+    step(k, sA, sB, wA, wB);
+    step(k + 1, sB, sA, wB, wA);
+  }
+  if (k < n) {                                             // odd count: one more step, then the last dZ from wB
+    step(k, sA, sB, wA, wB);
+    __syncthreads();
+    dzacc((n - 1) & (NB - 1), wB);
+  } else {
+    __syncthreads();
+    dzacc((n - 1) & (NB - 1), wA);
+  }
+
+  const int ib = P * PR + wave * 32;
+  float* out = a.dzpart + (size_t)split * a.n_anchor * HPAD;
+#pragma unroll
+  for (int ct = 0; ct < HP; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ia = ib + nx_acc_row(r, lh);
+      if (ia < a.n_anchor) out[(size_t)ia * HPAD + 32 * ct + l31] = dz[ct][r];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ small kernels
 // One wave per positive pair (i, i + N): F.normalize (x / max(|x|, 1e-12)), padded fp32 (+ bf16) images, positive dot.
 __global__ __launch_bounds__(256) void nx_prep_kernel(const float* __restrict__ h1, int64_t ld1,
@@ -1040,7 +1277,23 @@ static int nx_run_fwd(bool bf16, int hp, NxArgs a, int grid, hipStream_t s) {
   if (bf16 && NX_FWD16_X2) return hp <= 4 ? nx_launch_x2<4>(a, grid, s) : nx_launch_x2<8>(a, grid, s);
   NX_FWD_CASES(nx_launch, a, grid, s)
 }
-static int nx_run_bwd(bool bf16, int hp, NxArgs a, int grid, hipStream_t s) { NX_BWD_CASES(nx_launch, a, grid, s) }
+static NxPlan nx_plan_bwdp() {
+  const int smem = 4 * NX_BJ * 512 + 4 * NX_BJ * 4;
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute((const void*)ntx2_bwd16p_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    done = true;
+  }
+  return NxPlan{4, smem, 1};
+}
+static int nx_run_bwd(bool bf16, int hp, NxArgs a, int grid, hipStream_t s) {
+  if (bf16 && hp > 4 && NX_BWD16_PIPE) {
+    const NxPlan p = nx_plan_bwdp();
+    hipLaunchKernelGGL((ntx2_bwd16p_kernel<8>), dim3(grid), dim3(256), p.smem, s, a);
+    return check_launch("bkg_ntxent_backward");
+  }
+  NX_BWD_CASES(nx_launch, a, grid, s)
+}
 
 struct NxShape { int hpad, hp, pr, n_panels, n_jtiles, grid, splits, jt_per_split; long long n_items; };
 

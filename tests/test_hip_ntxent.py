@@ -34,7 +34,10 @@ def test_fp32_matches_oracle(n, h):
         assert err < 1e-5, err
 
 
-@pytest.mark.parametrize("n,h", [(3000, 128), (2000, 256), (513, 100)])
+# (h > 128 takes the software-pipelined backward and the 64-anchors-per-wave forward: the small sizes are its one-, two- and
+# three-tile blocks, odd and even tile counts, partial last tiles and panels)
+@pytest.mark.parametrize("n,h", [(3000, 128), (2000, 256), (513, 100), (20, 256), (40, 200), (65, 256), (97, 130), (129, 256),
+                                 (1111, 256)])
 def test_bf16_operands_track_the_exact_path(n, h):
     from biomedkg_amd import ops
     a, b = _pair(n, h, 7)
@@ -44,15 +47,17 @@ def test_bf16_operands_track_the_exact_path(n, h):
         loss = ops.ntxent_loss(ad, bd, 0.2, operands=mode)
         loss.backward()
         res[mode] = (float(loss), torch.cat([ad.grad, bd.grad]))
-    assert abs(res["bf16"][0] - res["fp32"][0]) <= 5e-5 * abs(res["fp32"][0]), (res["bf16"][0], res["fp32"][0])
+    # (the loss is a mean over 2 n rows: bf16 rounding of the operands averages out as 1 / sqrt(n))
+    tol = 5e-5 * max(1.0, (3000.0 / n) ** 0.5)
+    assert abs(res["bf16"][0] - res["fp32"][0]) <= tol * abs(res["fp32"][0]), (res["bf16"][0], res["fp32"][0])
     err = float((res["bf16"][1] - res["fp32"][1]).norm() / res["fp32"][1].norm())
     assert err < 1e-2, err
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_bitwise_repeatable(mode):
+@pytest.mark.parametrize("mode,h", [("fp32", 128), ("bf16", 128), ("bf16", 256)])
+def test_bitwise_repeatable(mode, h):
     from biomedkg_amd import ops
-    a, b = _pair(2500, 128, 3)
+    a, b = _pair(2500, h, 3)
     outs = []
     for _ in range(3):
         ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
