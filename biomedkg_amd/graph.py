@@ -70,7 +70,7 @@ class RowSplit:
         ``bkg_spmm_csr_f32`` walks finish them several per wave; the KGE kernels' tables stay one row per item."""
         dev = rowptr.device
         self._src = (rowptr, n_rows, nnz, chunk)
-        self._plain = None
+        self._plain, self._plain_asked = None, 0
         self.pack = bool(pack) and col is not None
         self.n_items_max = n_rows + nnz // chunk
         self.n_slots_max = 2 * (nnz // chunk) + 2
@@ -108,8 +108,12 @@ class RowSplit:
     def plain(self):
         """The same rows as one item each (no short-row table): rows of 64 sixteen-byte pieces or more already fill a
         wave, and finishing the short ones in the second launch costs more than it saves there (two-view GCN propagate,
-        d = 512 bf16: 331 vs 335 us per launch).  Built on first use, kept with this table."""
-        if not self.pack:
+        d = 512 bf16: 331 vs 335 us per launch).  Built when the table is asked for the 5th time -- a structure that lives
+        for one step (mini-batches, ``ms_per_step_fresh_structures``) never pays for a second table --, kept with this one."""
+        if not self.pack or not PLAIN_WIDE_ROWS:
+            return self
+        self._plain_asked += 1
+        if self._plain is None and self._plain_asked < 5:
             return self
         if self._plain is None:
             rowptr, n_rows, nnz, chunk = self._src
@@ -121,6 +125,7 @@ class RowSplit:
 
 
 PACK_SHORT_ROWS = __import__("os").environ.get("BKG_PACK_SHORT_ROWS", "1") != "0"
+PLAIN_WIDE_ROWS = __import__("os").environ.get("BKG_PLAIN_WIDE_ROWS", "1") != "0"
 
 
 def rowsplit_for(rowptr, n_rows, nnz, pack=False, col=None):

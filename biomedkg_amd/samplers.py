@@ -44,6 +44,7 @@ class NeighborSampler:
 
     def __init__(self, edge_index, num_nodes, num_neighbors=(30, 30, 30), seed=0):
         L.require_cuda(edge_index)
+        self.edge_index = edge_index          # (the structure cached on the tensor only holds it weakly)
         self.graph = graph_of(edge_index, num_nodes)
         self.num_nodes, self.num_neighbors, self.seed, self.calls = int(num_nodes), tuple(num_neighbors), int(seed), 0
 

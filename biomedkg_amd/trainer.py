@@ -148,7 +148,7 @@ class Trainer:
             # augmentation branch (biomedkg_amd/sampled_gcl.py)
             from .sampled_gcl import NeighborGraphedGcl
             sm = loader.sampler
-            loop = NeighborGraphedGcl(model, loader.x, sm.graph.edge_index, loader.batch_size, sm.num_neighbors, opt,
+            loop = NeighborGraphedGcl(model, loader.x, sm.edge_index, loader.batch_size, sm.num_neighbors, opt,
                                       clip=self.clip, seed=sm.seed, shuffle=loader.shuffle)
             step = loop.step
             step_fn = lambda: step()      # noqa: E731
