@@ -345,7 +345,7 @@ def ntxent_figures(dev):
                     "peak_TFLOPs": peak, "fwd_frac": tf_f / peak, "bwd_frac": tf_b / peak})
         del h1, h2, loss
     return {"note": "whole op by HIP events (normalise, Gram-tile kernel, fixed-order finish); TFLOP/s on EXECUTED flops: "
-                    "forward M^2 h (symmetric), backward 4 M^2 h, M = 2N; kernel-only times: profiles/r02_ntxent_*",
+                    "forward M^2 h (symmetric), backward 4 M^2 h, M = 2N; kernel-only times and counters: profiles/r03_ntxent_*",
             "cases": out}
 
 
