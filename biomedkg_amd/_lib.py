@@ -125,6 +125,7 @@ SIGNATURES = {
     # fusion.hip
     "bkg_attn_fuse_f32": (I32, [P, I64, I64, I32, I32, P, I64, P]),
     "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, U32, I64, P, I64, P]),
+    "bkg_redaf_fused_xw": (I32, [I64, I64, I64, P, I32, I64, P, I64, P, P, P, F32, U64, U32, P, I64, P]),
 }
 
 _lib = None

@@ -61,6 +61,12 @@ struct XwArgs {
   const int32_t* group_ptr; int G;
   int M, N, K;
   int persist;   // row-tile stride of the persistent loop (plain mode)
+  // ReDAF epilogue (gemm_xw_kernel<..., REDAF>): C is the fp32 [M / 2, N] fused output, rows 2n / 2n + 1 of the product are
+  // node n's two modality tokens
+  const float* rd_scale;       // [2][N]  modal_weights * zeta
+  const uint8_t* rd_keep;      // nullable [M][N] dropout keep mask (replayed draws); else the in-kernel Philox stream
+  float rd_p; uint64_t rd_seed; uint32_t rd_stream; int64_t rd_row0;
+  const uint32_t* rd_epoch;
 };
 
 // Two adjacent accumulator quads of one lane (columns 8q + 4lh + 0..3 and 8(q+1) + 4lh + 0..3 of a 16-column group).
@@ -97,7 +103,7 @@ __device__ __forceinline__ void xw_step(xw_acc_t (&acc)[XW_TN][XW_TM], const __b
     for (int j = 0; j < XW_TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[i], a[j], acc[i][j], 0, 0, 0);
 }
 
-template <typename AT, typename CT, bool GROUPED>
+template <typename AT, typename CT, bool GROUPED, bool REDAF = false>
 __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue ep) {
   __shared__ __attribute__((aligned(16))) __bf16 Bs[XW_BN][XW_LDB];
   __shared__ int s_g, s_m0;
@@ -209,6 +215,53 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
 
     // epilogue: acc[i][j][4q..4q+3] = C[m_base + 32 j + l31][n0 + 32 i + 8 q + 4 lh + 0..3]; one row pointer per j,
     // every piece at a compile-time offset from it (N % 32 == 0: a 32-column tile is in range or not as a whole)
+    if constexpr (REDAF) {
+      // ReDAF.forward behind the product (reference biomedkg/utils/fusion.py:49-90): t = relu(x W^T + b) is this lane's
+      // accumulator row; out[n] = mean_m relu(dropout(t[2n + m] * scale[m])) -- the two modality rows of a node are the
+      // lanes l31 and l31 ^ 1 (lane = row in this kernel), so the [2n, D] transform never leaves the registers.  The
+      // Philox stream is indexed exactly as bkg_redaf_combine_f32 indexes it: the same masks, the same bits out.
+      const int mrow = l31 & 1;
+      const float ks = (g.rd_keep || g.rd_p > 0.f) ? 1.0f / (1.0f - g.rd_p) : 1.0f;
+      const uint32_t thresh = (uint32_t)fminf(g.rd_p * 4294967296.0f, 4294967295.0f);
+      const uint32_t sid = with_epoch(g.rd_stream, g.rd_epoch);
+#pragma unroll
+      for (int j = 0; j < XW_TM; ++j) {
+        const int row = m_base + j * 32 + l31;
+        const bool live = row < m_hi;
+        float* __restrict__ orow = reinterpret_cast<float*>(g.C) + (int64_t)(row >> 1) * g.ldc + n0;
+#pragma unroll
+        for (int i = 0; i < XW_TN; ++i) {
+          if (n0 + i * 32 < g.N) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int off = i * 32 + q * 8 + lh * 4, col = n0 + off;
+              float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+              const float4 b = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+              const float4 sc = *reinterpret_cast<const float4*>(g.rd_scale + (int64_t)mrow * g.N + col);
+              v.x = fmaxf(v.x + b.x, 0.f) * sc.x; v.y = fmaxf(v.y + b.y, 0.f) * sc.y;
+              v.z = fmaxf(v.z + b.z, 0.f) * sc.z; v.w = fmaxf(v.w + b.w, 0.f) * sc.w;
+              if (g.rd_keep) {
+                uchar4 k = make_uchar4(0, 0, 0, 0);
+                if (live) k = *reinterpret_cast<const uchar4*>(g.rd_keep + (int64_t)row * g.N + col);
+                v.x = k.x ? v.x * ks : 0.f; v.y = k.y ? v.y * ks : 0.f; v.z = k.z ? v.z * ks : 0.f; v.w = k.w ? v.w * ks : 0.f;
+              } else if (g.rd_p > 0.f) {
+                const uint4 r = philox_keep4(g.rd_seed, (uint64_t)(g.rd_row0 + row) * g.N + col, sid);
+                v.x = r.x >= thresh ? v.x * ks : 0.f; v.y = r.y >= thresh ? v.y * ks : 0.f;
+                v.z = r.z >= thresh ? v.z * ks : 0.f; v.w = r.w >= thresh ? v.w * ks : 0.f;
+              }
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+              // modality 0 first, as the two-kernel form adds them (y = 0 + f(t_0) + f(t_1)): bit-equal
+              float4 o;
+              o.x = __shfl_xor(v.x, 1, 64); o.y = __shfl_xor(v.y, 1, 64); o.z = __shfl_xor(v.z, 1, 64); o.w = __shfl_xor(v.w, 1, 64);
+              if (live && mrow == 0)
+                *reinterpret_cast<float4*>(orow + off) = make_float4((v.x + o.x) * 0.5f, (v.y + o.y) * 0.5f, (v.z + o.z) * 0.5f,
+                                                                     (v.w + o.w) * 0.5f);
+            }
+          }
+        }
+      }
+      continue;
+    }
     const bool plain = !ep.bias && ep.act == 0 && !ep.gate && ep.beta == 0.f && ep.alpha == 1.f;
 #pragma unroll
     for (int j = 0; j < XW_TM; ++j) {
@@ -640,4 +693,33 @@ extern "C" int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const v
   else { if (c_is_bf16) BKG_XW(float, __bf16); else BKG_XW(float, float); }
 #undef BKG_XW
   return check_launch("bkg_gemm_xw");
+}
+
+// ReDAF.forward as ONE launch (reference biomedkg/utils/fusion.py:49-90; M = 2 modalities): out[n] = mean_m relu(dropout(
+// relu(x[n, m] W^T + b) * scale[m])), x rows 2n / 2n + 1 = node n's tokens.  keep (nullable): replayed dropout draws [rows][N].
+extern "C" int bkg_redaf_fused_xw(int64_t rows, int64_t N, int64_t K, const void* A, int32_t a_is_bf16, int64_t lda,
+                                  const void* Wt, int64_t ldw, const float* bias, const float* scale, const uint8_t* keep,
+                                  float drop_p, uint64_t seed, uint32_t stream_id, float* out, int64_t ldo, void* stream) {
+  BKG_ARG(rows >= 0 && rows % 2 == 0 && rows < (1ll << 31) && N > 0 && N % 32 == 0 && K > 0 && K % XW_KS == 0 &&
+              N * K <= (1ll << 22), "bkg_redaf_fused_xw: rows even, N % 32 == 0, K % 256 == 0, N * K <= 2^22");
+  const int a_el = a_is_bf16 ? 2 : 4;
+  BKG_ARG((uintptr_t)A % 16 == 0 && (lda * a_el) % 16 == 0 && (uintptr_t)Wt % 16 == 0 && (ldw * 2) % 16 == 0 &&
+              (uintptr_t)out % 16 == 0 && ldo % 4 == 0 && (uintptr_t)scale % 16 == 0 && (!bias || (uintptr_t)bias % 16 == 0) &&
+              (!keep || (uintptr_t)keep % 4 == 0),
+          "bkg_redaf_fused_xw: operands must allow 4-column vector access");
+  BKG_ARG(drop_p >= 0.f && drop_p < 1.f, "bkg_redaf_fused_xw: drop_p in [0,1)");
+  if (rows == 0) return 0;
+  GemmEpilogue ep{1.0f, 0.0f, bias, 1, nullptr, 0, 1.0f, 0};
+  const int n_tiles = ceil_div(N, XW_BN);
+  XwArgs g{A, lda, nullptr, reinterpret_cast<const __bf16*>(Wt), ldw, 0, out, ldo, nullptr, 0, (int)rows, (int)N, (int)K, 0,
+           scale, keep, drop_p, seed, stream_id, 0, rng_epoch_ptr()};
+  const int64_t m_tiles = ceil_div(rows, XW_BM);
+  int64_t lanes = std::max<int64_t>(BKG_XCDS, (2 * 256 / n_tiles) / BKG_XCDS * BKG_XCDS);
+  lanes = std::min<int64_t>(lanes, (m_tiles + BKG_XCDS - 1) / BKG_XCDS * BKG_XCDS);
+  g.persist = (int)lanes;
+  const unsigned grid = (unsigned)(lanes * n_tiles);
+  hipStream_t s = (hipStream_t)stream;
+  if (a_is_bf16) hipLaunchKernelGGL((gemm_xw_kernel<__bf16, float, false, true>), dim3(grid), dim3(256), 0, s, g, ep);
+  else hipLaunchKernelGGL((gemm_xw_kernel<float, float, false, true>), dim3(grid), dim3(256), 0, s, g, ep);
+  return check_launch("bkg_redaf_fused_xw");
 }

@@ -1498,6 +1498,9 @@ REDAF_CHUNK_NODES = int(__import__("os").environ.get("BKG_REDAF_CHUNK", "16384")
 #                            (4,096-node chunks: 1.47 ms per call at N = 130k -- products too small to fill the chip --, 16,384: 1.0)
 
 
+REDAF_ONE_LAUNCH = __import__("os").environ.get("BKG_REDAF_ONE_LAUNCH", "1") != "0"
+
+
 def _fusion_rows(x, n_out):
     """``x [n, M, D]`` as the ``[n M, D]`` operand of the fuser's product with an ``[n_out, D]`` weight: fp32, or -- bf16
     mode, constant input features, a shape the streaming product takes -- a bf16 copy cached on the tensor (that product
@@ -1554,6 +1557,13 @@ def redaf_fusion(x, w_t, b_t, scale, drop: Dropout = None):
         p, seed, sid = drop.p, drop.seed, drop.stream_id      # stream_id: the provider's per-call counter (fresh mask per call)
         if drop.keep is not None:
             keep = drop.keep.to(torch.uint8).contiguous()
+    if m == 2 and REDAF_ONE_LAUNCH and n > 0 and _xw_ok(x2, n * m, w_t.size(0), d) and w_t.size(0) == d:
+        # two modalities, bf16 mode, a shape the streaming product takes: the whole fuser is the product's epilogue
+        # (bkg_redaf_fused_xw) -- no [2n, D] transform anywhere, one launch per call; bit-equal with the chunked form below
+        wt16 = _weight_bf16(_f32c(w_t), False)
+        L.call("bkg_redaf_fused_xw", n * m, d, d, L.ptr(x2), int(x2.dtype == torch.bfloat16), x2.stride(0), L.ptr(wt16),
+               wt16.stride(0), L.ptr(_f32c(b_t)), L.ptr(scale), L.ptr(keep), p, seed, sid, L.ptr(out), out.stride(0), L.stream())
+        return out
     step = REDAF_CHUNK_NODES if n > 2 * REDAF_CHUNK_NODES else max(n, 1)
     t = None
     for lo in range(0, n, step):

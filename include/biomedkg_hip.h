@@ -416,6 +416,14 @@ int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int32_t M, int3
                           int64_t row0 /* index of t's first row in the whole [n_total * M, D] input: the Philox stream is
                                           keyed by the global element, so a chunked call draws the same mask */,
                           float* out, int64_t ldo, void* stream);
+/* ReDAF.forward (biomedkg/utils/fusion.py:49-90, two modalities) as ONE launch: the scale / dropout / ReLU / modality mean run
+ * in the epilogue of the product x W^T (the two token rows of a node are adjacent lanes of an accumulator tile), so the
+ * [2n, D] transform is never written.  A [rows, K] fp32 or bf16 (rows = 2 n, node-major), Wt the [N, K] bf16 weight image of
+ * bkg_weight_to_bf16, bias [N], scale [2, N]; dropout as in bkg_redaf_combine_f32 (keep mask [rows, N], or drop_p + the Philox
+ * stream (seed, stream_id) indexed by row * N + column: the same masks, bit-equal results); out fp32 [n, N]. */
+int bkg_redaf_fused_xw(int64_t rows, int64_t N, int64_t K, const void* A, int32_t a_is_bf16, int64_t lda, const void* Wt,
+                       int64_t ldw, const float* bias, const float* scale, const uint8_t* keep, float drop_p, uint64_t seed,
+                       uint32_t stream_id, float* out, int64_t ldo, void* stream);
 
 /* ---- the step tail: global-norm gradient clipping + Adam over a list of parameter tensors, two launches (csrc/optim.hip).
  *      Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) -- Lightning's gradient_clip_val = 1.0 of
