@@ -117,12 +117,13 @@ class NeighborGraphedGcl:
     eagerly (the bit-equality check of the tests).  One epoch = ``len(self)`` steps over a shuffled seed order."""
 
     def __init__(self, module, x, edge_index, batch_size=128, num_neighbors=(30, 30, 30), optimizer=None, clip=1.0, seed=0,
-                 shuffle=True, buckets=None, graphs=True):
+                 shuffle=True, buckets=None, graphs=True, max_graphs=16):
         L.require_cuda(x, edge_index)
         from .model.gcl import GGD
         if not isinstance(getattr(module, "model", None), GGD):
             raise ValueError("the padded NeighborLoader step is built for GGD")
         self.module, self.clip, self.graphs_on = module, clip, graphs
+        self.max_graphs = int(max_graphs)     # every captured graph keeps its step's intermediates in a pool of its own
         dev = x.device
         self.sampler = NeighborDeviceSampler(edge_index, x.size(0), num_neighbors, seed)
         self.n_cap, self.e_cap = self.sampler.num_nodes, self.sampler.edge_cap
@@ -259,6 +260,9 @@ class NeighborGraphedGcl:
             return self._padded_step(bucket, aug).detach()
         key = (bucket, aug)
         g = self.execs.get(key)
+        if g is None and len(self.execs) >= self.max_graphs:      # a regime that wanders over many buckets: the rest stay eager
+            self.stats["eager_padded"] += 1
+            return self._padded_step(bucket, aug).detach()
         if g is None:
             # first batch of this kind: one eager padded step (it IS this batch's training step; it also warms the
             # allocator and the kernel plans), then the capture pass, which records and does not execute

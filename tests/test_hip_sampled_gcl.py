@@ -142,7 +142,7 @@ def test_padded_step_is_the_reference_step_on_the_real_part(precision, aug):
         ops.set_matmul_precision(prev)
 
 
-def _run(graphs, steps, seed=0, precision="fp32"):
+def _run(graphs, steps, seed=0, precision="fp32", max_graphs=16):
     from biomedkg_amd import ops
     from biomedkg_amd.sampled_gcl import NeighborGraphedGcl
     ei, n = _graph()
@@ -153,7 +153,7 @@ def _run(graphs, steps, seed=0, precision="fp32"):
     try:
         mod = _module(fuse="attention").train()
         lp = NeighborGraphedGcl(mod, x, ei, batch_size=6, num_neighbors=(4, 3, 2), seed=seed, graphs=graphs,
-                                buckets=(64, 128, 192, 256, 384, 512, 1024, 24000))
+                                buckets=(64, 128, 192, 256, 384, 512, 1024, 24000), max_graphs=max_graphs)
         losses, sizes = [], []
         for _ in range(steps):
             losses.append(lp.step().clone())
@@ -178,6 +178,14 @@ def test_replayed_steps_equal_eager_padded_steps(precision):
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
     assert float(la[-5:].mean()) < float(la[:5].mean())                  # it trains
+
+
+def test_graph_count_is_capped():
+    """Past ``max_graphs`` captured (bucket, branch) pairs the remaining kinds of batch run the same padded step eagerly."""
+    la, sa, stats_a, pa = _run(True, 30, max_graphs=2)
+    lb, sb, stats_b, pb = _run(False, 30)
+    assert stats_a["captured"] == 2 and stats_a["eager_padded"] > 2 and stats_a["replayed"] > 0
+    assert torch.equal(la, lb) and all(torch.equal(a, b) for a, b in zip(pa, pb))
 
 
 def test_trainer_picks_the_graphed_loop():
