@@ -62,8 +62,20 @@ constexpr int NX_BJ = 64;   // rows of a j-tile
 #ifndef NX_PIPE_VALU
 #define NX_PIPE_VALU 4
 #endif
+#ifndef NX_PIPE_DMA_INSIDE
+#define NX_PIPE_DMA_INSIDE 0     // (1: the tile DMAs issued between the MFMAs of the region: 79 vs 66 ms -- hipcc then drains them early)
+#endif
 #ifndef NX_PIPE_TRANS
 #define NX_PIPE_TRANS 0         // (1: hipcc then puts the whole vector phase in front of the MFMAs: 69 -> slower)
+#endif
+#ifndef NX_PRIO_GRAM          // s_setprio at the start of a wave's matrix / vector phase in the x2 forward (-1: none)
+#define NX_PRIO_GRAM -1
+#endif
+#ifndef NX_PRIO_VP
+#define NX_PRIO_VP -1
+#endif
+#ifndef NX_LATE_RULE
+#define NX_LATE_RULE 0
 #endif
 #ifndef NX_PINGPONG
 #define NX_PINGPONG 1        // 8-wave bf16 forward: the two waves of a SIMD run half a tile apart (0: all waves in step; 2: fp32 too)
@@ -754,8 +766,14 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
+#if defined(NX_EXP_NOEXP)
+            const float e = s[b][t][r] * 1.0001f;
+#else
             const float e = __builtin_amdgcn_exp2f(s[b][t][r]);
+#endif
+#if !defined(NX_EXP_NOROWSUM)
             rowsum[b] += e;
+#endif
             s[b][t][r] = e;
           }
       }
@@ -793,7 +811,7 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
   //      h = 2k - 3, late ones at 2k - 2) are added over the waves, and tile k + 1 is sent to the buffer tile k - 1 was
   //      last read from at h = 2k - 1.
   const int n_it = (int)(x_end - x);
-  const bool late = wave >= NW / 2;
+  const bool late = NX_LATE_RULE == 0 ? wave >= NW / 2 : (NX_LATE_RULE == 1 ? (wave & 1) != 0 : ((wave >> 1) & 1) != 0);
   if (late && NX_PP_PRIO) __builtin_amdgcn_s_setprio(NX_PP_PRIO);
   int Pe = P, jte = jt;                                    // block timeline: item k at h = 2k
   bool p0 = false, p1 = false, p2 = false;                 // column-sum flags of items k, k - 1, k - 2
@@ -818,7 +836,9 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
       if (p2 && tid < NX_BJ) colreduce(slot_e == 0 ? 1 : (slot_e == 1 ? 2 : 0), x + k - 2);   // slot of k - 2 = (k + 1) mod 3
       if (k + 1 < n_it) {
         item_after(Pe, jte);
+#if !defined(NX_EXP_NODMA)
         stage(jte, (int)((k + 1) & 1));
+#endif
       }
       slot_e = slot_e == 2 ? 0 : slot_e + 1;
     }
@@ -826,9 +846,19 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
     if (hh < 0 || hh >= 2 * n_it) continue;
     const int j0 = jt * NX_BJ;
     if ((hh & 1) == 0) {
+      if (NX_PRIO_GRAM >= 0) __builtin_amdgcn_s_setprio(NX_PRIO_GRAM);
+#if !defined(NX_EXP_NOGRAM)
       gram(buf);
+#endif
     } else {
+      if (NX_PRIO_VP >= 0) __builtin_amdgcn_s_setprio(NX_PRIO_VP);
+#if defined(NX_EXP_NOVP)
+      rowsum[0] += s[0][0][0] + s[1][1][3];
+#elif defined(NX_EXP_NOCOL)
+      vector_phase(P, j0, mask_of(P, j0), false, slot);
+#else
       vector_phase(P, j0, mask_of(P, j0), !a.rect && jt >= (P + 1) * Q, slot);
+#endif
       int P_next = P, jt_next = jt;
       item_after(P_next, jt_next);
       const bool last = kw + 1 == n_it;
@@ -879,36 +909,34 @@ __global__ __launch_bounds__(256) void ntx2_bwd16p_kernel(NxArgs a) {
   // ---- tile jt_ (clamped to this block's last one) -> LDS buffer b_, its 1/D_j values -> rdj_ring[b_]
   const int st_row = lane >> 4;
   const unsigned st_lane = (unsigned)(st_row * ROW_BYTES + 16 * ((lane & 15) ^ (st_row << 2)));
-  auto stage = [&](int jt_, int b_) {
+  // (branch-free: the row index is clamped per lane, so that the DMAs can sit INSIDE the pipelined region, between its
+  // MFMAs -- issued in front of it they cost the wave 100-185 cycles each, MI355X_MICROARCH.md "LDS-DMA piece issue cost")
+  auto stage_tile = [&](int jt_, int b_) {
     const int j0 = min(jt_, jt1 - 1) * NX_BJ;
     unsigned off = st_lane;
-    asm volatile("" : "+v"(off));
+    asm("" : "+v"(off));
     const int ws = __builtin_amdgcn_readfirstlane(wave);
-    if (j0 + NX_BJ <= M) {
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int q = ws * NG + g, slab = q >> 4;
-        const unsigned char* base = zn + (size_t)(j0 + 4 * (q & 15)) * ROW_BYTES + slab * 256;
-        unsigned char* dst = smem + b_ * TILE_BYTES + slab * (NX_BJ * 256) + (q & 15) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (off ^ (16u * (q & 3)))),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int q = ws * NG + g, slab = q >> 4, row = 4 * (q & 15) + st_row;
-        const int jr = min(j0 + row, M - 1);
-        const unsigned char* src = zn + (size_t)jr * ROW_BYTES + slab * 256 + ((off ^ (16u * (q & 3))) & 255u);
-        unsigned char* dst = smem + b_ * TILE_BYTES + slab * (NX_BJ * 256) + (q & 15) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      }
+    for (int g = 0; g < NG; ++g) {
+      const int q = ws * NG + g, slab = q >> 4, row = 4 * (q & 15) + st_row;
+      const int jr = min(j0 + row, M - 1);
+      const unsigned char* src = zn + (size_t)jr * ROW_BYTES + slab * 256 + ((off ^ (16u * (q & 3))) & 255u);
+      unsigned char* dst = smem + b_ * TILE_BYTES + slab * (NX_BJ * 256) + (q & 15) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
-    if (ws == 0) {                                              // 64 floats: one 4-byte DMA of wave 0 (rows past M: masked later)
+  };
+  auto stage_rd = [&](int jt_, int b_) {                       // 64 floats: one 4-byte DMA of wave 0 (rows past M: masked later)
+    const int j0 = min(jt_, jt1 - 1) * NX_BJ;
+    if (__builtin_amdgcn_readfirstlane(wave) == 0) {
       const float* src = a.rden + min(j0 + lane, M - 1);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(rdj_ring + b_ * NX_BJ), 4, 0, 0);
     }
+  };
+  auto stage = [&](int jt_, int b_) {
+    stage_tile(jt_, b_);
+    stage_rd(jt_, b_);
   };
 
   // ---- anchor fragments of this wave's 32 rows
@@ -1024,10 +1052,12 @@ __global__ __launch_bounds__(256) void ntx2_bwd16p_kernel(NxArgs a) {
   // one iteration: tile t = jt0 + k; S(t) in sc, W(t - 1) in wp  ->  S(t + 1) in sn, W(t) in wc
   auto step = [&](int k, nx_acc_t (&sc)[2], nx_acc_t (&sn)[2], nx_bf16x8_t (&wp)[4], nx_bf16x8_t (&wc)[4]) {
     __syncthreads();                                       // tile t + 1 has landed; everybody is done with tile t - 2's buffer
-    stage(jt0 + k + 2, (k + 2) & (NB - 1));
+    stage_rd(jt0 + k + 2, (k + 2) & (NB - 1));
+    if (!NX_PIPE_DMA_INSIDE) stage_tile(jt0 + k + 2, (k + 2) & (NB - 1));
     const int jt = jt0 + k, bD = k == 0 ? 0 : (k - 1) & (NB - 1);
     if (mask_of(jt)) exclude(sc, jt * NX_BJ);
     __builtin_amdgcn_sched_barrier(0);
+    if (NX_PIPE_DMA_INSIDE) stage_tile(jt0 + k + 2, (k + 2) & (NB - 1));
     weights(sc, k & (NB - 1), wc);
     gram((k + 1) & (NB - 1), sn);
     dzacc(bD, wp);
@@ -1036,6 +1066,7 @@ __global__ __launch_bounds__(256) void ntx2_bwd16p_kernel(NxArgs a) {
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
+      if (NX_PIPE_DMA_INSIDE && (i & 7) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one of the 8 LDS-DMAs
       __builtin_amdgcn_sched_group_barrier(0x100, NX_PIPE_DS, 0);         // LDS reads
       if (NX_PIPE_TRANS) __builtin_amdgcn_sched_group_barrier(0x400, NX_PIPE_TRANS, 0);   // exp2 (not part of the VALU class)
       __builtin_amdgcn_sched_group_barrier(0x002, NX_PIPE_VALU, 0);       // vector instructions
