@@ -127,7 +127,10 @@ class NeighborGraphedGcl:
         dev = x.device
         self.sampler = NeighborDeviceSampler(edge_index, x.size(0), num_neighbors, seed)
         self.n_cap, self.e_cap = self.sampler.num_nodes, self.sampler.edge_cap
-        self.buckets = tuple(sorted(int(b) for b in (buckets or edge_buckets(self.e_cap))))
+        # (a ladder handed in is cut at the most edges a batch can hold: the sampler's buffers end there)
+        self.buckets = tuple(sorted({min(int(b), self.e_cap) for b in (buckets or edge_buckets(self.e_cap))}))
+        if self.buckets[-1] < self.e_cap:
+            self.buckets += (self.e_cap,)
         self.batch_size, self.shuffle = int(batch_size), shuffle
         self.x = x
         self.x_ext = torch.cat([x, x.new_zeros((1,) + tuple(x.shape[1:]))])           # + the zero row pad nodes read
