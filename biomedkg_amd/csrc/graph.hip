@@ -5,11 +5,16 @@
 // follows has a fixed, input-determined order (bitwise reproducible; no atomics anywhere here).
 #include <cstring>
 
+#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_merge_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
+
+#ifndef BKG_SMALL_SORT
+#define BKG_SMALL_SORT 1      // key sets of <= 8192 entries: one single-workgroup launch instead of a device sort
+#endif
 
 namespace bkg {
 
@@ -21,6 +26,37 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ lo, const int64_t* 
   keys[i] = (uint32_t)k;
   iota[i] = (uint32_t)i;
 }
+
+// Up to 1024 * IPT keys in ONE launch of one workgroup: keys made, sorted (stable LSD radix over the low `bits` bits, in
+// LDS) and written with their original positions.  The mini-batch steps sort seven key sets of a few thousand entries per
+// step; rocPRIM's device sorts are four to six launches each, and a replayed step is bound by its node count.  Any stable
+// sort yields the same (keys, permutation): bit-equal with the device sorts.  Pads (positions >= n) carry all-ones keys and
+// the highest positions, so they stay behind every real key.
+template <int IPT>
+__global__ __launch_bounds__(1024) void small_sort_kernel(const int64_t* __restrict__ lo, const int64_t* __restrict__ hi,
+                                                          int64_t n_lo, int n, int bits, uint32_t* __restrict__ sorted_keys,
+                                                          uint32_t* __restrict__ perm) {
+  using sort_t = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t>;
+  __shared__ typename sort_t::storage_type storage;
+  uint32_t keys[IPT], vals[IPT];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int idx = threadIdx.x * IPT + i;
+    keys[i] = 0xFFFFFFFFu;
+    vals[i] = (uint32_t)idx;
+    if (idx < n) keys[i] = (uint32_t)(lo[idx] + (hi ? hi[idx] * n_lo : 0));
+  }
+  sort_t().sort(keys, vals, storage, 0, bits);
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int idx = threadIdx.x * IPT + i;
+    if (idx < n) {
+      sorted_keys[idx] = keys[i];
+      perm[idx] = vals[i];
+    }
+  }
+}
+constexpr int SMALL_SORT_MAX = 8192;
 
 // out[s] = first position p in sorted[0..n) with sorted[p] >= s * stride   (s in [0, n_q))
 __global__ void lower_bound_kernel(const uint32_t* __restrict__ sorted, int64_t n, int64_t n_q, uint32_t stride,
@@ -189,10 +225,17 @@ extern "C" int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo
   BKG_ARG((double)n_lo * (double)n_hi < 4294967296.0, "bkg_sort_edges: key space exceeds 32 bits");
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(make_keys_kernel, grid1(n), dim3(256), 0, s, lo, hi, n_lo, keys_tmp, iota_tmp, n);
   uint64_t space = (uint64_t)n_lo * (uint64_t)n_hi;
   int bits = 1;
   while (bits < 32 && (1ull << bits) < space) ++bits;
+  if (n <= SMALL_SORT_MAX && BKG_SMALL_SORT) {
+    if (n <= 1024) hipLaunchKernelGGL(small_sort_kernel<1>, dim3(1), dim3(1024), 0, s, lo, hi, n_lo, (int)n, bits, sorted_keys, perm);
+    else if (n <= 2048) hipLaunchKernelGGL(small_sort_kernel<2>, dim3(1), dim3(1024), 0, s, lo, hi, n_lo, (int)n, bits, sorted_keys, perm);
+    else if (n <= 4096) hipLaunchKernelGGL(small_sort_kernel<4>, dim3(1), dim3(1024), 0, s, lo, hi, n_lo, (int)n, bits, sorted_keys, perm);
+    else hipLaunchKernelGGL(small_sort_kernel<8>, dim3(1), dim3(1024), 0, s, lo, hi, n_lo, (int)n, bits, sorted_keys, perm);
+    return check_launch("bkg_sort_edges(one workgroup)");
+  }
+  hipLaunchKernelGGL(make_keys_kernel, grid1(n), dim3(256), 0, s, lo, hi, n_lo, keys_tmp, iota_tmp, n);
   size_t bytes = (size_t)workspace_bytes;
   // While the stream is being captured into a hipGraph: the (equally stable) merge sort.  The radix sort's one-sweep
   // form zeroes its histograms with runtime memsets, and memset nodes re-execute wrongly on this stack (common.h):

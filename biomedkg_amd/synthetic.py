@@ -80,10 +80,13 @@ def gcl_small(num_nodes=5_000, num_edges=50_000, seed=42):
     """Single-type GCL graph (BASELINE configs 1-2): Chung-Lu, weights ~ rank^-0.8, no self loops,
     de-duplicated; ``edge_index int64 [2, <=E]``."""
     rng = np.random.default_rng(seed)
+    num_edges = min(int(num_edges), num_nodes * (num_nodes - 1))      # no more distinct ordered pairs than the graph has
     w = np.arange(1, num_nodes + 1, dtype=np.float64) ** (-0.8)
     w /= w.sum()
     got = np.empty((0, 2), dtype=np.int64)
-    while got.shape[0] < num_edges:
+    for _ in range(200):                                              # (a nearly complete tiny graph: settle for what came)
+        if got.shape[0] >= num_edges:
+            break
         need = int((num_edges - got.shape[0]) * 1.3) + 16
         cand = np.stack([rng.choice(num_nodes, need, p=w), rng.choice(num_nodes, need, p=w)], 1)
         cand = cand[cand[:, 0] != cand[:, 1]]

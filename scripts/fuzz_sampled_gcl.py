@@ -18,8 +18,8 @@ bad = 0
 
 
 def graph(kind, n, e, seed):
-    if kind == "random":
-        return synthetic.gcl_small(n, max(e, 1), seed=seed).to(dev)
+    if kind == "random":      # (the generator draws DISTINCT pairs: ask for no more than a small graph has)
+        return synthetic.gcl_small(n, max(min(e, n * (n - 1) // 4), 1), seed=seed).to(dev)
     if kind == "empty":
         return torch.zeros(2, 0, dtype=torch.int64, device=dev)
     if kind == "loops":
