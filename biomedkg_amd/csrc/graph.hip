@@ -32,12 +32,16 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ lo, const int64_t* 
 // step; rocPRIM's device sorts are four to six launches each, and a replayed step is bound by its node count.  Any stable
 // sort yields the same (keys, permutation): bit-equal with the device sorts.  Pads (positions >= n) carry all-ones keys and
 // the highest positions, so they stay behind every real key.
+// rowptr (nullable): rowptr[q] = first position with key >= q * stride, q < n_q -- the lower-bound pass that follows
+// every one of these sorts, over the sorted keys while they are still in LDS.
 template <int IPT>
 __global__ __launch_bounds__(1024) void small_sort_kernel(const int64_t* __restrict__ lo, const int64_t* __restrict__ hi,
                                                           int64_t n_lo, int n, int bits, uint32_t* __restrict__ sorted_keys,
-                                                          uint32_t* __restrict__ perm) {
+                                                          uint32_t* __restrict__ perm, int64_t n_q, uint32_t stride,
+                                                          int32_t* __restrict__ rowptr) {
   using sort_t = rocprim::block_radix_sort<uint32_t, 1024, IPT, uint32_t>;
   __shared__ typename sort_t::storage_type storage;
+  static_assert(sizeof(typename sort_t::storage_type) >= 1024 * IPT * sizeof(uint32_t), "the sorted keys are parked in the sort's LDS");
   uint32_t keys[IPT], vals[IPT];
 #pragma unroll
   for (int i = 0; i < IPT; ++i) {
@@ -54,6 +58,21 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(const int64_t* __restr
       sorted_keys[idx] = keys[i];
       perm[idx] = vals[i];
     }
+  }
+  if (rowptr == nullptr) return;
+  __syncthreads();                                          // everybody is out of the sort's storage
+  uint32_t* sk = reinterpret_cast<uint32_t*>(&storage);
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) sk[threadIdx.x * IPT + i] = keys[i];
+  __syncthreads();
+  for (int64_t q = threadIdx.x; q < n_q; q += 1024) {
+    const uint64_t want = (uint64_t)q * stride;
+    int a = 0, b = n;
+    while (a < b) {
+      const int mid = (a + b) >> 1;
+      if ((uint64_t)sk[mid] < want) a = mid + 1; else b = mid;
+    }
+    rowptr[q] = a;
   }
 }
 constexpr int SMALL_SORT_MAX = 8192;
@@ -218,21 +237,29 @@ extern "C" int64_t bkg_sort_workspace_bytes(int64_t n) {
 }
 
 // keys = lo[i] + hi[i] * n_lo (hi nullable); stable sort; outputs sorted keys + permutation.
-extern "C" int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n,
-                              uint32_t* keys_tmp, uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm,
-                              void* workspace, int64_t workspace_bytes, void* stream) {
+static int sort_edges_impl(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n,
+                           uint32_t* keys_tmp, uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm,
+                           void* workspace, int64_t workspace_bytes, int64_t n_q, uint32_t stride, int32_t* rowptr,
+                           void* stream) {
   BKG_ARG(n >= 0 && n_lo > 0 && n_hi > 0, "bkg_sort_edges: bad sizes");
   BKG_ARG((double)n_lo * (double)n_hi < 4294967296.0, "bkg_sort_edges: key space exceeds 32 bits");
-  if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    if (rowptr && n_q) fill_u32(rowptr, 0u, n_q, s);
+    return rowptr ? check_launch("bkg_sort_edges_rowptr") : 0;
+  }
   uint64_t space = (uint64_t)n_lo * (uint64_t)n_hi;
   int bits = 1;
   while (bits < 32 && (1ull << bits) < space) ++bits;
   if (n <= SMALL_SORT_MAX && BKG_SMALL_SORT) {
-    if (n <= 1024) hipLaunchKernelGGL(small_sort_kernel<1>, dim3(1), dim3(1024), 0, s, lo, hi, n_lo, (int)n, bits, sorted_keys, perm);
-    else if (n <= 2048) hipLaunchKernelGGL(small_sort_kernel<2>, dim3(1), dim3(1024), 0, s, lo, hi, n_lo, (int)n, bits, sorted_keys, perm);
-    else if (n <= 4096) hipLaunchKernelGGL(small_sort_kernel<4>, dim3(1), dim3(1024), 0, s, lo, hi, n_lo, (int)n, bits, sorted_keys, perm);
-    else hipLaunchKernelGGL(small_sort_kernel<8>, dim3(1), dim3(1024), 0, s, lo, hi, n_lo, (int)n, bits, sorted_keys, perm);
+#define BKG_SMALL_SORT_LAUNCH(IPT)                                                                                   \
+  hipLaunchKernelGGL(small_sort_kernel<IPT>, dim3(1), dim3(1024), 0, s, lo, hi, n_lo, (int)n, bits, sorted_keys, perm, \
+                     n_q, stride, rowptr)
+    if (n <= 1024) BKG_SMALL_SORT_LAUNCH(1);
+    else if (n <= 2048) BKG_SMALL_SORT_LAUNCH(2);
+    else if (n <= 4096) BKG_SMALL_SORT_LAUNCH(4);
+    else BKG_SMALL_SORT_LAUNCH(8);
+#undef BKG_SMALL_SORT_LAUNCH
     return check_launch("bkg_sort_edges(one workgroup)");
   }
   hipLaunchKernelGGL(make_keys_kernel, grid1(n), dim3(256), 0, s, lo, hi, n_lo, keys_tmp, iota_tmp, n);
@@ -248,7 +275,26 @@ extern "C" int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo
   else
     e = rocprim::radix_sort_pairs(workspace, bytes, keys_tmp, sorted_keys, iota_tmp, perm, (size_t)n, 0, bits, s);
   if (e != hipSuccess) { set_error("bkg_sort_edges: sort", e); return (int)e; }
+  if (rowptr && n_q)
+    hipLaunchKernelGGL(lower_bound_kernel, grid1(n_q), dim3(256), 0, s, sorted_keys, n, n_q, stride, rowptr);
   return check_launch("bkg_sort_edges");
+}
+
+extern "C" int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n,
+                              uint32_t* keys_tmp, uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+  return sort_edges_impl(lo, hi, n_lo, n_hi, n, keys_tmp, iota_tmp, sorted_keys, perm, workspace, workspace_bytes, 0, 1,
+                         nullptr, stream);
+}
+
+// bkg_sort_edges + bkg_lower_bound_u32(sorted_keys, n, n_queries, stride, rowptr) in one call (small key sets: one launch)
+extern "C" int bkg_sort_edges_rowptr(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n,
+                                     uint32_t* keys_tmp, uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm,
+                                     int64_t n_queries, uint32_t stride, int32_t* rowptr, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  BKG_ARG(n_queries >= 0 && rowptr, "bkg_sort_edges_rowptr: bad arguments");
+  return sort_edges_impl(lo, hi, n_lo, n_hi, n, keys_tmp, iota_tmp, sorted_keys, perm, workspace, workspace_bytes, n_queries,
+                         stride, rowptr, stream);
 }
 
 extern "C" int bkg_lower_bound_u32(const uint32_t* sorted, int64_t n, int64_t n_queries, uint32_t stride,

@@ -34,6 +34,21 @@ class _Sorter:
                L.ptr(sorted_keys), L.ptr(perm), L.ptr(ws), ws_bytes, L.stream())
         return sorted_keys, perm, ws
 
+    @staticmethod
+    def sort_rowptr(lo, hi, n_lo, n_hi, n_queries, stride=1):
+        """``sort`` + the row pointers ``rowptr[q] = first position with key >= q * stride`` in one library call (a key
+        set of a mini-batch: one launch)."""
+        L.require_cuda(lo, hi)
+        n = lo.numel()
+        dev = lo.device
+        ws_bytes = L.lib().bkg_sort_workspace_bytes(max(n, 1))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        keys_tmp, iota_tmp, sorted_keys, perm = (_i32(n, dev) for _ in range(4))
+        rowptr = _i32(n_queries, dev)
+        L.call("bkg_sort_edges_rowptr", L.ptr(lo), L.ptr(hi), n_lo, n_hi, n, L.ptr(keys_tmp), L.ptr(iota_tmp),
+               L.ptr(sorted_keys), L.ptr(perm), n_queries, stride, L.ptr(rowptr), L.ptr(ws), ws_bytes, L.stream())
+        return sorted_keys, perm, rowptr
+
 
 SPLIT_CHUNK = 256        # entries per work item of a long row (csrc/rowsplit.hip)
 SPLIT_MIN_NNZ = 1 << 15  # below this one wave per row is fine and the table is not worth building
@@ -148,9 +163,7 @@ class CSR:
         other = other.contiguous()
         dev = key.device
         self.n_rows, self.nnz = int(n_rows), key.numel()
-        self.sorted_keys, self.perm, _ = _Sorter.sort(key, None, n_rows, 1)
-        self.rowptr = _i32(n_rows + 1, dev)
-        L.call("bkg_lower_bound_u32", L.ptr(self.sorted_keys), self.nnz, n_rows + 1, 1, L.ptr(self.rowptr), L.stream())
+        self.sorted_keys, self.perm, self.rowptr = _Sorter.sort_rowptr(key, None, n_rows, 1, n_rows + 1)
         self.col = _i32(self.nnz, dev)
         L.call("bkg_gather_i64_to_i32", L.ptr(other), L.ptr(self.perm), L.ptr(self.col), self.nnz, L.stream())
 

@@ -1065,9 +1065,7 @@ class Incidence:
         from .graph import _Sorter, _i32
         ei = edge_index.contiguous()
         flat = ei.view(-1)                       # == cat(head, tail)
-        sorted_keys, self.perm, _ = _Sorter.sort(flat, None, num_nodes, 1)
-        self.rowptr = _i32(num_nodes + 1, ei.device)
-        L.call("bkg_lower_bound_u32", L.ptr(sorted_keys), flat.numel(), num_nodes + 1, 1, L.ptr(self.rowptr), L.stream())
+        sorted_keys, self.perm, self.rowptr = _Sorter.sort_rowptr(flat, None, num_nodes, 1, num_nodes + 1)
         from .graph import rowsplit_for
         # mini-batches (a few thousand nodes, a few 10^4 incidences): rows are short, the long-row table is 6 launches
         small = num_nodes <= 4096 and flat.numel() < (1 << 18)
@@ -1084,10 +1082,7 @@ def relation_order_of(edge_type, num_relations):
     from .graph import _cached, _Sorter, _i32
 
     def build():
-        sorted_keys, perm, _ = _Sorter.sort(edge_type, None, num_relations, 1)
-        rel_ptr = _i32(num_relations + 1, edge_type.device)
-        L.call("bkg_lower_bound_u32", L.ptr(sorted_keys), edge_type.numel(), num_relations + 1, 1, L.ptr(rel_ptr),
-               L.stream())
+        sorted_keys, perm, rel_ptr = _Sorter.sort_rowptr(edge_type, None, num_relations, 1, num_relations + 1)
         return perm, rel_ptr
     return _cached(edge_type, "rel_order", (int(num_relations),), build)
 

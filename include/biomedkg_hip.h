@@ -43,6 +43,11 @@ int64_t bkg_sort_workspace_bytes(int64_t n);
 int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n, uint32_t* keys_tmp,
                    uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm, void* workspace,
                    int64_t workspace_bytes, void* stream);
+/* bkg_sort_edges followed by bkg_lower_bound_u32(sorted_keys, n, n_queries, stride, rowptr) -- the row pointers of the CSR the
+ * sort is for -- in one call; key sets of <= 8192 entries: ONE single-workgroup launch (sort and search in LDS). */
+int bkg_sort_edges_rowptr(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n, uint32_t* keys_tmp,
+                          uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm, int64_t n_queries, uint32_t stride,
+                          int32_t* rowptr, void* workspace, int64_t workspace_bytes, void* stream);
 /* out[s] = lower_bound(sorted, s*stride), s in [0, n_queries) -- CSR row pointers from sorted keys */
 int bkg_lower_bound_u32(const uint32_t* sorted, int64_t n, int64_t n_queries, uint32_t stride, int32_t* out,
                         void* stream);
