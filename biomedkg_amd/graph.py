@@ -55,6 +55,7 @@ SPLIT_MIN_NNZ = 1 << 15  # below this one wave per row is fine and the table is 
 
 
 TIGHT_GRIDS = __import__("os").environ.get("BKG_TIGHT_GRIDS", "1") != "0"
+TIGHT_AFTER = int(__import__("os").environ.get("BKG_TIGHT_AFTER", "3"))      # launches over a table before its host read
 _AS_CAPTURED = 0
 
 
@@ -105,9 +106,16 @@ class RowSplit:
                                   self.totals.data_ptr(),
                                   self.n_items_max, self.n_slots_max, self.n_long_max, self.n_short_max)
 
-        self.exact = False
-        if TIGHT_GRIDS and not capturing():
+        self.exact, self._uses = False, 0
+
+    def use(self):
+        """Called by every launch over this table.  From the 3rd launch on the bounds are the table's counts
+        (``tighten``: one host read) -- a structure that lives for one or two launches (mini-batches; the bench's
+        ``ms_per_step_fresh_structures``) keeps its array-size bounds and never makes the host wait."""
+        self._uses += 1
+        if not self.exact and self._uses >= TIGHT_AFTER and TIGHT_GRIDS and not capturing():
             self.tighten()
+        return self
 
     def tighten(self):
         """Replace the launch bounds (array-size upper bounds: no host read needed to build the table) by the table's

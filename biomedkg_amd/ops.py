@@ -405,6 +405,8 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
         addend = (addend if addend.is_contiguous() else addend.contiguous()) if addend.dtype == torch.bfloat16 else _f32c(addend)
         if addend.dtype == torch.bfloat16 and (addend.stride(0) % 4 or addend.data_ptr() % 8):
             addend = addend.float()
+    if split is not None:
+        split.use()
     if split is not None and split.pack and d // (8 if is_bf16 else 4) >= 64 and split.exact:
         split = split.plain()          # wide rows: one wave per row already (RowSplit.plain)
     timing = KERNEL_TIMERS is not None and tag is not None
@@ -1113,7 +1115,7 @@ class _KgeScore(torch.autograd.Function):
                 l1 = torch.empty(n, dtype=torch.float32, device=z.device)
                 L.call("bkg_row_l1norm_f32", L.ptr(z), z.stride(0), n, d, L.ptr(l1), L.stream())
             dz = torch.empty_like(z)
-            sp = inc.split
+            sp = inc.split.use() if inc.split is not None else None
             partials = sp.partials(d, z.device) if sp is not None else None
             L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), 0, z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
                    L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), None, L.ptr(l1), L.ptr(inc.rowptr), L.ptr(inc.perm),
@@ -1296,7 +1298,7 @@ class _KgeBceLoss(torch.autograd.Function):
                 if ei.size(1) == 0:
                     continue
                 inc = incidence_of(ei, n)
-                sp = inc.split
+                sp = inc.split.use() if inc.split is not None else None
                 partials = sp.partials(d, z.device) if sp is not None else None
                 # algorithmic bytes: per incidence the OTHER endpoint's row + the 16-byte record + the incidence id; per
                 # node the fp32 gradient row (read back too when accumulating the second triplet set) + its row pointer

@@ -115,12 +115,19 @@ def test_spmm_row_classes(mix, tight, d, dtype):
     w = torch.rand(nnz, device=DEV, generator=gen)
     x = torch.randn(n_table, d, device=DEV, generator=gen).to(dtype)
     bias = torch.randn(d, device=DEV, generator=gen)
-    was = G.TIGHT_GRIDS
-    G.TIGHT_GRIDS = tight
+    was = (G.TIGHT_GRIDS, G.TIGHT_AFTER)
+    G.TIGHT_GRIDS, G.TIGHT_AFTER = tight, 1          # (the host read normally waits for a table's 3rd launch: RowSplit.use)
     try:
         sp = G.RowSplit(rowptr, rows, nnz, pack=True, col=col)
+        assert not sp.exact
+        _row_classes_body(sp, tight, lens, rows, d, dtype, rowptr, col, w, x, bias, nnz)
     finally:
-        G.TIGHT_GRIDS = was
+        G.TIGHT_GRIDS, G.TIGHT_AFTER = was
+
+
+def _row_classes_body(sp, tight, lens, rows, d, dtype, rowptr, col, w, x, bias, nnz):
+    from biomedkg_amd import ops
+    sp.use()
     assert sp.exact == tight
     n_items, _, n_long, n_short = sp.totals.tolist()
     assert n_short == int((lens <= 8).sum()) and n_long == int((lens > 256).sum())
