@@ -113,6 +113,8 @@ KERNEL_NAMES = {
     "gcn_propagate": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel: GCN A_hat (X W^T) gather/aggregate, d={d}",
     "gcn_propagate_views": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel: GCN A_hat (X W^T) gather/aggregate, two GGD "
                            "views side by side, d={d}",
+    "gcn_propagate_views_bwd": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel: the table gradient A_hat^T dOut of the two "
+                               "GGD views (bf16 dOut gathered over the out-edge CSR), d={d}",
     "kge_fused_bce": "kge_fused_bce_kernel<{t}>: DistMult scores + BCE terms + d score + d rel_emb partials, one triplet set, d={d}",
     "kge_bwd_nodes": "kge_bwd_nodes_kernel<{t}> + fixup: dz by per-node segment reduce over the triplet incidences, d={d}",
 }

@@ -36,6 +36,7 @@
 namespace bkg {
 
 typedef float nx_acc_t __attribute__((ext_vector_type(16)));
+typedef float nx_acc4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 nx_bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short nx_s4_t __attribute__((ext_vector_type(4)));
 typedef short nx_s8_t __attribute__((ext_vector_type(8)));
@@ -73,6 +74,12 @@ constexpr int NX_BJ = 64;   // rows of a j-tile
 #endif
 #ifndef NX_PRIO_VP
 #define NX_PRIO_VP -1
+#endif
+#ifndef NX_FWD16_Q
+#define NX_FWD16_Q 0          // 1: the bf16 forward on 16x16x32 tiles (ntx2_fwd16q_kernel: 16.1 - 16.3 ms at N = 130k against 15.7 - 15.9)
+#endif
+#ifndef NX_Q_RD
+#define NX_Q_RD 1
 #endif
 #ifndef NX_LATE_RULE
 #define NX_LATE_RULE 0
@@ -176,6 +183,37 @@ __device__ __forceinline__ float nx_transpose_reduce32_of(const nx_acc_t& e0, co
     }
   }
   const bool hi = l31 & 1;
+  const float keep = hi ? d[1] : d[0], send = hi ? d[0] : d[1];
+  return keep + nx_dpp<0xB1>(send);                            // quad_perm [1,0,3,2]
+}
+// 16 values per lane -> lane q of each 16-lane row returns the row's sum of value q (the levels 8, 4, 2, 1 of the above)
+__device__ __forceinline__ float nx_transpose_reduce16(const float (&a)[16], int l15) {
+  float b[8], c[4], d[2];
+  {
+    const bool hi = l15 & 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float keep = hi ? a[r + 8] : a[r], send = hi ? a[r] : a[r + 8];
+      b[r] = keep + nx_dpp<0x128>(send);                       // row_ror:8
+    }
+  }
+  {
+    const bool hi = l15 & 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float keep = hi ? b[r + 4] : b[r], send = hi ? b[r] : b[r + 4];
+      c[r] = keep + nx_dpp<0x141>(send);                       // row_half_mirror
+    }
+  }
+  {
+    const bool hi = l15 & 2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float keep = hi ? c[r + 2] : c[r], send = hi ? c[r] : c[r + 2];
+      d[r] = keep + nx_dpp<0x4E>(send);                        // quad_perm [2,3,0,1]
+    }
+  }
+  const bool hi = l15 & 1;
   const float keep = hi ? d[1] : d[0], send = hi ? d[0] : d[1];
   return keep + nx_dpp<0xB1>(send);                            // quad_perm [1,0,3,2]
 }
@@ -877,6 +915,262 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
   if (p1 && tid < NX_BJ) colreduce(slot_e == 0 ? 1 : (slot_e == 1 ? 2 : 0), x + n_it - 1);
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 forward, 16x16x32 tiles
+// ntx2_fwd16x2_kernel with the Gram tile of a wave (64 j x 64 anchors) made of 4 x 4 v_mfma_f32_16x16x32_bf16 tiles instead
+// of 2 x 2 32x32x16 ones: the same flops and cycles, a quarter of the LDS bytes per MFMA cycle, a column butterfly over 16
+// lanes instead of 32 -- and the clock: on random data the chip holds a higher one under the 16x16x32 shape
+// (MI355X_MICROARCH.md, "DVFS give-back" item 7).  Everything around the tile (work list, LDS-DMA staging, half-step loop,
+// column-sum buffers) is the kernel above.
+template <int HP>
+__global__ __launch_bounds__(512) void ntx2_fwd16q_kernel(NxArgs a) {
+  constexpr int NW = 8, IB = 4, JB = 4, HPAD = 32 * HP, PR = 16 * IB * NW, Q = PR / NX_BJ;
+  constexpr int ROW_BYTES = HPAD * 2, TILE_BYTES = NX_BJ * ROW_BYTES, KS = HPAD / 32;
+  constexpr int NG = TILE_BYTES / 1024 / NW;                     // LDS-DMA instructions per wave and tile (4 rows of a slab each)
+  static_assert(HP % 4 == 0 && NG >= 1, "bf16 image is made of 128-column slabs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto tile_at = [&](int b) { return smem + b * TILE_BYTES; };
+  float* aux = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);  // colbuf[3][NW][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wave = tid >> 6;      // (left in a VGPR on purpose: with scalar control flow hipcc's schedule of this loop spills 400 B)
+  const int M = a.M;
+  const unsigned char* zn = static_cast<const unsigned char*>(a.zn);
+
+  long long x = (long long)blockIdx.x * a.n_items / gridDim.x;
+  const long long x_end = (long long)(blockIdx.x + 1) * a.n_items / gridDim.x;
+  if (x >= x_end) return;
+  int P, jt;
+  if (a.rect) {
+    P = (int)(x / a.n_jtiles);
+    jt = (int)(x % a.n_jtiles);
+  } else {
+    P = nx_panel_of(x, a.n_panels, a.n_jtiles, Q);
+    jt = P * Q + (int)(x - nx_start(P, a.n_jtiles, Q));
+  }
+  auto item_after = [&](int& P_, int& jt_) {
+    ++jt_;
+    if (jt_ == a.n_jtiles) { ++P_; jt_ = a.rect ? 0 : P_ * Q; }
+  };
+
+  // ---- j-tile -> LDS image [slab][row][256 B], chunk c of a row at position c ^ tag(row); rows past M: row M - 1 (masked).
+  // DMA q = wave * NG + g of a tile writes rows 4 (q & 15) .. + 3 of slab q >> 4; lane: row 4 (q & 15) + (lane >> 4) -- whose
+  // tag is ((lane >> 4) << 2) | (q & 3) -- position lane & 15.  Per lane that is ONE offset, XORed with 16 (q & 3) per DMA
+  // (opaque to the optimiser on purpose: hoisted out of the tile loop, the NG variants would cost registers this kernel
+  // does not have)
+  const int st_row = lane >> 4;
+  const unsigned st_lane = (unsigned)(st_row * ROW_BYTES + 16 * ((lane & 15) ^ (st_row << 2)));
+  auto stage = [&](int jt_, int buf_) {
+    const int j0 = jt_ * NX_BJ;
+    unsigned off = st_lane;
+    asm volatile("" : "+v"(off));
+    const int ws = __builtin_amdgcn_readfirstlane(wave);     // scalar here: bases and LDS targets are SGPR arithmetic
+    if (j0 + NX_BJ <= M) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int q = ws * NG + g, slab = q >> 4;
+        const unsigned char* base = zn + (size_t)(j0 + 4 * (q & 15)) * ROW_BYTES + slab * 256;     // wave-uniform
+        unsigned char* dst = tile_at(buf_) + slab * (NX_BJ * 256) + (q & 15) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (off ^ (16u * (q & 3)))),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int q = ws * NG + g, slab = q >> 4, row = 4 * (q & 15) + st_row;
+        const int jr = min(j0 + row, M - 1);
+        const unsigned char* src = zn + (size_t)jr * ROW_BYTES + slab * 256 + ((off ^ (16u * (q & 3))) & 255u);
+        unsigned char* dst = tile_at(buf_) + slab * (NX_BJ * 256) + (q & 15) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- anchor fragments (B operands of v_mfma_f32_16x16x32_bf16: lane = column n = anchor, k = 8 (lane >> 4) + 0..7):
+  //      block ib of this wave = anchors P * PR + wave * 64 + 16 ib + l15
+  uint4 zi[IB][KS];
+  auto anchor_row = [&](int P_, int ib) {
+    const int a_idx = P_ * PR + wave * 64 + 16 * ib + l15;
+    return a_idx < a.n_anchor ? (a.anchors ? a.anchors[a_idx] : a_idx) : -1;
+  };
+  auto load_anchor = [&](int P_) {
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+      const int ig = anchor_row(P_, ib);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        zi[ib][ks] = make_uint4(0u, 0u, 0u, 0u);
+        if (ig >= 0) zi[ib][ks] = *reinterpret_cast<const uint4*>(zn + (size_t)ig * ROW_BYTES + (4 * ks + lg) * 16);
+      }
+    }
+  };
+
+  // A fragment of k-step ks, j-block jb: row 16 jb + l15 (its tag = the tag of l15), chunk 4 (ks & 3) + lg of slab ks >> 2 at
+  // position chunk ^ tag: ONE lane constant, XORed with 64 (ks & 3) per read; 16 rows x 4 chunks per read = all 64 banks
+  const int tag15 = ((l15 & 3) << 2) | ((l15 >> 2) & 3);
+  const int row_lc = 256 * l15 + 16 * (lg ^ tag15);
+
+  nx_acc4_t s[IB][JB];
+  float rowsum[IB] = {0.f, 0.f, 0.f, 0.f};
+
+  auto gram = [&](int buf_) {
+    constexpr int RD = NX_Q_RD, RING = RD + 1;
+    uint4 ring[RING][JB];
+    int lc = row_lc + buf_ * TILE_BYTES;
+    asm volatile("" : "+v"(lc));
+    auto read_k = [&](int ks, uint4 (&dst)[JB]) {
+      const int at = (lc ^ (64 * (ks & 3))) + 16384 * (ks >> 2);
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) dst[jb] = *reinterpret_cast<const uint4*>(smem + at + jb * 4096);
+    };
+#pragma unroll
+    for (int ks = 0; ks < RD && ks < KS; ++ks) read_k(ks, ring[ks % RING]);
+    const nx_acc4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + RD < KS) read_k(ks + RD, ring[(ks + RD) % RING]);
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+          s[ib][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(nx_bf16x8_t, ring[ks % RING][jb]),
+                                                              __builtin_bit_cast(nx_bf16x8_t, zi[ib][ks]),
+                                                              ks == 0 ? zero4 : s[ib][jb], 0, 0, 0);
+    }
+  };
+  // E = exp2(S) (both images carry sqrt(log2(e) / tau)), masked on the diagonal / at the boundary; row sums; with `col`
+  // the column sums over the wave's 64 anchors -> colbuf[slot_][wave].  s[ib][jb][r]: j = 16 jb + 4 lg + r, anchor 16 ib + l15
+  auto vector_phase = [&](int P_, int j0, bool need_mask, bool col, int slot_) {
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+      if (need_mask) {
+        const int ig = anchor_row(P_, ib);
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int jg = j0 + 16 * jb + 4 * lg + r;
+            float e = __builtin_amdgcn_exp2f(s[ib][jb][r]);
+            e = (jg < M && ig >= 0 && jg != ig) ? e : 0.f;
+            rowsum[ib] += e;
+            s[ib][jb][r] = e;
+          }
+      } else {
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(s[ib][jb][r]);
+            rowsum[ib] += e;
+            s[ib][jb][r] = e;
+          }
+      }
+    }
+    if (col) {
+      float c[16];                                         // value v = 4 jb + r: the tile's column j = 16 jb + 4 lg + r
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[4 * jb + r] = (s[0][jb][r] + s[1][jb][r]) + (s[2][jb][r] + s[3][jb][r]);
+      const float v = nx_transpose_reduce16(c, l15);       // lane l15 of each 16-lane row: the row's sum of value l15
+      aux[slot_ * (NW * NX_BJ) + wave * NX_BJ + 16 * (l15 >> 2) + 4 * lg + (l15 & 3)] = v;
+    }
+  };
+  auto colreduce = [&](int slot_, long long item_) {
+    const float* cb = aux + slot_ * (NW * NX_BJ);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += cb[w * NX_BJ + tid];
+    a.colitem[item_ * NX_BJ + tid] = v;
+  };
+  auto rowseg_write = [&](int P_) {
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+      float tot = rowsum[ib] + __shfl_xor(rowsum[ib], 16, 64);
+      tot += __shfl_xor(tot, 32, 64);
+      if (lg == 0) a.rowseg[((size_t)blockIdx.x + P_) * PR + wave * 64 + 16 * ib + l15] = tot;
+      rowsum[ib] = 0.f;
+    }
+  };
+  // does the tile touch the boundary (rows past M, anchors past n_anchor) or the wave's own diagonal?  (an anchor LIST
+  // -- the rectangular forward of a row-partitioned run -- has no range to test: always masked)
+  auto mask_of = [&](int P_, int j0) {
+    const int i0 = P_ * PR + wave * 64;
+    return (j0 + NX_BJ > M) || (i0 + 64 > a.n_anchor) || a.anchors != nullptr || (j0 < i0 + 64 && j0 + NX_BJ > i0);
+  };
+
+  // ---- the loop runs over HALF-steps h: a wave is in its matrix phase (gram) on the even ones and in its vector phase
+  //      on the odd ones of ITS OWN count hh = h - late, so that the two waves of a SIMD are always in different phases.
+  //      Block-level duties sit on the even half-steps h = 2k: the column sums of item k - 2 (early waves wrote them at
+  //      h = 2k - 3, late ones at 2k - 2) are added over the waves, and tile k + 1 is sent to the buffer tile k - 1 was
+  //      last read from at h = 2k - 1.
+  const int n_it = (int)(x_end - x);
+  const bool late = NX_LATE_RULE == 0 ? wave >= NW / 2 : (NX_LATE_RULE == 1 ? (wave & 1) != 0 : ((wave >> 1) & 1) != 0);
+  if (late && NX_PP_PRIO) __builtin_amdgcn_s_setprio(NX_PP_PRIO);
+  int Pe = P, jte = jt;                                    // block timeline: item k at h = 2k
+  bool p0 = false, p1 = false, p2 = false;                 // column-sum flags of items k, k - 1, k - 2
+  int slot_e = 0;
+  int kw = 0;                                              // this wave's own item (P, jt; the kw-th of the block), its buffer and colbuf slot
+  int buf = 0, slot = 0;
+  stage(jt, 0);
+  load_anchor(P);
+  for (int h = 0; h <= 2 * n_it; ++h) {
+    // even h: the full barrier (the compiler drains this wave's LDS-DMAs in front of it: tile k is complete); odd h: the
+    // waves only change phase -- a raw s_barrier, so that tile k + 1's DMAs stay in flight across it (NX_X2_ODD: 0 none,
+    // 1 raw, 2 full)
+    if ((h & 1) == 0 || NX_X2_ODD == 2) __syncthreads();
+    else if (NX_X2_ODD == 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if ((h & 1) == 0) {
+      const int k = h >> 1;
+      p2 = p1; p1 = p0;
+      p0 = k < n_it && !a.rect && jte >= (Pe + 1) * Q;
+      if (p2 && tid < NX_BJ) colreduce(slot_e == 0 ? 1 : (slot_e == 1 ? 2 : 0), x + k - 2);   // slot of k - 2 = (k + 1) mod 3
+      if (k + 1 < n_it) {
+        item_after(Pe, jte);
+#if !defined(NX_EXP_NODMA)
+        stage(jte, (int)((k + 1) & 1));
+#endif
+      }
+      slot_e = slot_e == 2 ? 0 : slot_e + 1;
+    }
+    const int hh = h - (late ? 1 : 0);
+    if (hh < 0 || hh >= 2 * n_it) continue;
+    const int j0 = jt * NX_BJ;
+    if ((hh & 1) == 0) {
+      if (NX_PRIO_GRAM >= 0) __builtin_amdgcn_s_setprio(NX_PRIO_GRAM);
+#if !defined(NX_EXP_NOGRAM)
+      gram(buf);
+#endif
+    } else {
+      if (NX_PRIO_VP >= 0) __builtin_amdgcn_s_setprio(NX_PRIO_VP);
+#if defined(NX_EXP_NOVP)
+      rowsum[0] += s[0][0][0] + s[1][1][3];
+#elif defined(NX_EXP_NOCOL)
+      vector_phase(P, j0, mask_of(P, j0), false, slot);
+#else
+      vector_phase(P, j0, mask_of(P, j0), !a.rect && jt >= (P + 1) * Q, slot);
+#endif
+      int P_next = P, jt_next = jt;
+      item_after(P_next, jt_next);
+      const bool last = kw + 1 == n_it;
+      if (P_next != P || last) {
+        rowseg_write(P);
+        if (!last) load_anchor(P_next);
+      }
+      P = P_next; jt = jt_next;
+      ++kw;
+      buf ^= 1;
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  }
+  __syncthreads();
+  // the last item (early waves wrote it at h = 2 n - 1, late ones at 2 n); slot_e = (n + 1) mod 3, the item's = (n - 1) mod 3
+  if (p1 && tid < NX_BJ) colreduce(slot_e == 0 ? 1 : (slot_e == 1 ? 2 : 0), x + n_it - 1);
+}
+
 // ------------------------------------------------------------------------------------------------ bf16 backward, software-pipelined
 // The backward of ntx2_kernel at h = 256 runs one wave per SIMD (444 registers), and a tile is a chain: Gram product (32
 // MFMAs) -> exp2 / (1/D_i + 1/D_j) / bf16 convert (~430 vector instructions) -> dZ product (32 MFMAs): nothing overlaps,
@@ -1284,10 +1578,10 @@ static NxPlan nx_plan_x2() {
   const int smem = 2 * NX_BJ * 64 * HP + 3 * 8 * NX_BJ * 4;
   static int occ_cache = -1;
   if (occ_cache < 0) {
-    hipFuncSetAttribute((const void*)ntx2_fwd16x2_kernel<HP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    const void* fn = NX_FWD16_Q ? (const void*)ntx2_fwd16q_kernel<HP> : (const void*)ntx2_fwd16x2_kernel<HP>;
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)ntx2_fwd16x2_kernel<HP>, 512, smem) != hipSuccess || occ < 1)
-      occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 512, smem) != hipSuccess || occ < 1) occ = 1;
     occ_cache = occ;
   }
   return NxPlan{8, smem, occ_cache};
@@ -1295,7 +1589,8 @@ static NxPlan nx_plan_x2() {
 template <int HP>
 static int nx_launch_x2(NxArgs a, int grid, hipStream_t s) {
   const NxPlan p = nx_plan_x2<HP>();
-  hipLaunchKernelGGL((ntx2_fwd16x2_kernel<HP>), dim3(grid), dim3(512), p.smem, s, a);
+  if (NX_FWD16_Q) hipLaunchKernelGGL((ntx2_fwd16q_kernel<HP>), dim3(grid), dim3(512), p.smem, s, a);
+  else hipLaunchKernelGGL((ntx2_fwd16x2_kernel<HP>), dim3(grid), dim3(512), p.smem, s, a);
   return check_launch("bkg_ntxent_forward");
 }
 

@@ -817,7 +817,8 @@ class _GcnConvViews(torch.autograd.Function):
                 comm.own_rows(full)[:n] = dxw
                 return full, None, db, None, None, None, None, None, None, None
         else:
-            dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split, out_dtype=torch.bfloat16)
+            dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split, out_dtype=torch.bfloat16,
+                       tag="gcn_propagate_views_bwd")
             if ctx.is_table:
                 return dxw.to(ctx.table_dtype), None, db, None, None, None, None, None, None, None
         d_in = weight.size(1)

@@ -15,7 +15,7 @@ def t(fn, reps=20):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
-for d in (128, 256, 512, 1024):
+for d in (64, 128, 256, 512, 1024):
     x = torch.randn(130_000, d, device=dev).bfloat16()
     us = t(lambda: ops.spmm(c.rowptr, c.col, gw.w_dst, x, 130_000, self_w=gw.self_w, split=c.split, out_dtype=torch.bfloat16))
     print(d, round(us, 1), "us", round(4e6 * d * 2 / us / 1e6, 2), "TB/s gathered")
