@@ -90,14 +90,15 @@ def pmc_traffic(tag, precision):
     try:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
-            hits = [k for k in json.load(open(path))["kernels"] if k.get("tag") == tag and k.get("precision") == precision]
+            hits = [k for k in json.load(open(path))["kernels"]
+                    if (k.get("tag") == tag or tag in (k.get("tags") or [])) and k.get("precision") == precision]
             if hits:
                 # a call = one launch of its main kernel (+ its second kernel); a tag may cover several shapes of the same
                 # call (the positive and the negative triplet set): bytes over all launches / number of calls
                 per_kernel = {}
                 for k in hits:
                     per_kernel[k["kernel"]] = per_kernel.get(k["kernel"], 0) + k["launches"]
-                calls = max(per_kernel.values())
+                calls = max(per_kernel.values())      # (a group shared by several tags -- "tags" -- averages over their calls)
                 total = sum(k["traffic_bytes_per_launch"] * k["launches"] for k in hits) / calls
                 h = sum(k.get("tcc_hit", 0) * k["launches"] for k in hits)
                 m = sum(k.get("tcc_miss", 0) * k["launches"] for k in hits)

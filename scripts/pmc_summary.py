@@ -39,26 +39,26 @@ def main(fetch_csv, write_csv, out_json, precision="fp32", bench_json=None, tcc_
         b = json.loads([ln for ln in open(bench_json) if ln.startswith("{")][-1])
         for r in [b.get("roofline")] + list(b.get("kernels") or []):
             if r and r.get("grid_size"):
-                tags[("spmm_items", int(r["grid_size"]), int(r["pieces"]))] = r["tag"]
+                tags.setdefault(("spmm_items", int(r["grid_size"]), int(r["pieces"])), []).append(r["tag"])
                 if r.get("grid_size_second_launch"):
-                    tags[("spmm_fixup", int(r["grid_size_second_launch"]), int(r["pieces"]))] = r["tag"]
+                    tags.setdefault(("spmm_fixup", int(r["grid_size_second_launch"]), int(r["pieces"])), []).append(r["tag"])
     out = []
     for key in sorted(f, key=lambda k: -sum(f[k])):
         fv, wv = f[key], w.get(key, [0.0])
         fetch = 2.0 * 1024 * sum(fv) / len(fv)
         write = 1024 * sum(wv) / len(wv)
-        tag = None
+        tag, also = None, []
         for kind in ("spmm_items", "spmm_fixup"):      # "spmm_items_kernel<__bf16, 64, 1>" or mangled "...IDF16bLi64ELi1E..."
             if kind in key[0]:
-                for (k2, grid, pieces), t in tags.items():
+                for (k2, grid, pieces), ts in tags.items():
                     lpr = min(pieces, 64)
                     if k2 == kind and grid == key[1] and (f", {lpr}, " in key[0] or f"Li{lpr}ELi" in key[0]):
-                        tag = t
+                        tag, also = ts[0], ts      # calls that launch the same kernel over the same grid share the group
         if "kge_bwd_nodes_kernel" in key[0] or "kge_bwd_nodes_fixup" in key[0]:
             tag = "kge_bwd_nodes"
         if "kge_fused_bce_kernel" in key[0]:
             tag = "kge_fused_bce"
-        rec = {"kernel": key[0], "grid_size": key[1], "precision": precision, "launches": len(fv), "tag": tag,
+        rec = {"kernel": key[0], "grid_size": key[1], "precision": precision, "launches": len(fv), "tag": tag, "tags": also,
                "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write}
         if key in hit or key in miss:
             rec["tcc_hit"] = sum(hit.get(key, [0.0])) / max(len(hit.get(key, [0.0])), 1)
