@@ -1065,7 +1065,7 @@ class Incidence:
     ``cat(head, tail)`` sorted by node.  Entry e < T: the node is the head of triplet e."""
 
     def __init__(self, edge_index, num_nodes):
-        from .graph import _Sorter, _i32
+        from .graph import _Sorter
         ei = edge_index.contiguous()
         flat = ei.view(-1)                       # == cat(head, tail)
         sorted_keys, self.perm, self.rowptr = _Sorter.sort_rowptr(flat, None, num_nodes, 1, num_nodes + 1)
@@ -1082,7 +1082,7 @@ def incidence_of(edge_index, num_nodes) -> Incidence:
 
 def relation_order_of(edge_type, num_relations):
     """Triplet ids grouped by relation (stable) + per-relation offsets, cached on ``edge_type``."""
-    from .graph import _cached, _Sorter, _i32
+    from .graph import _cached, _Sorter
 
     def build():
         sorted_keys, perm, rel_ptr = _Sorter.sort_rowptr(edge_type, None, num_relations, 1, num_relations + 1)
