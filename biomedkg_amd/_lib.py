@@ -123,6 +123,7 @@ SIGNATURES = {
     "bkg_clip_adam_max_tensors": (I64, []),
     "bkg_clip_adam_chunks": (I64, [P, I32]),
     "bkg_clip_adam_f32": (I32, [I32, P, P, P, P, P, F32, F32, P, F32, F32, F32, F32, P, P, I64, P, P]),
+    "bkg_clip_adam_images_f32": (I32, [I32, P, P, P, P, P, P, P, P, P, F32, F32, P, F32, F32, F32, F32, P, P, I64, P, P]),
     # fusion.hip
     "bkg_attn_fuse_f32": (I32, [P, I64, I64, I32, I32, P, I64, P]),
     "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, U32, I64, P, I64, P]),

@@ -32,6 +32,15 @@ struct OptTensors {
   int32_t count;
 };
 
+// bf16 images of the weights that the bf16-mode products read (bkg_weight_to_bf16: [batch][rows][cols] as stored and its
+// transpose [batch][cols][rows]), refreshed by the update itself: a weight changes exactly here, so the twelve conversion
+// launches at the top of the next step (one per weight) disappear.  w16[k] == nullptr: tensor k has no image.
+struct OptImages {
+  __bf16* w16[OPT_MAX_TENSORS];
+  __bf16* w16t[OPT_MAX_TENSORS];
+  int32_t rows[OPT_MAX_TENSORS], cols[OPT_MAX_TENSORS];
+};
+
 __device__ __forceinline__ int opt_tensor_of(const OptTensors& t, int chunk) {
   int lo = 0, hi = t.count;                   // first_chunk[lo] <= chunk < first_chunk[hi]
   while (hi - lo > 1) {
@@ -76,10 +85,12 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(OptTensors t, float* _
   if (threadIdx.x == 0) partial[chunk] = s;
 }
 
-__global__ __launch_bounds__(256) void clip_adam_kernel(OptTensors t, const float* __restrict__ partial, int n_partial,
-                                                        float max_norm, float lr, const float* __restrict__ lr_dev,
-                                                        float beta1, float beta2, float eps, float step,
-                                                        float* __restrict__ step_dev, float* __restrict__ norm_out) {
+template <bool IMAGES>
+__global__ __launch_bounds__(256) void clip_adam_kernel(OptTensors t, OptImages im, const float* __restrict__ partial,
+                                                        int n_partial, float max_norm, float lr,
+                                                        const float* __restrict__ lr_dev, float beta1, float beta2,
+                                                        float eps, float step, float* __restrict__ step_dev,
+                                                        float* __restrict__ norm_out) {
   __shared__ float sh[4];
   // the total in index order: every block computes the same sum (n_partial <= a few thousand floats, L2-resident)
   float acc = 0.f;
@@ -100,13 +111,24 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(OptTensors t, const floa
   const float* __restrict__ g = t.g[k];
   float* __restrict__ m = t.m[k];
   float* __restrict__ v = t.v[k];
+  __bf16* __restrict__ w16 = IMAGES ? im.w16[k] : nullptr;
+  __bf16* __restrict__ w16t = IMAGES ? im.w16t[k] : nullptr;
+  const int rows = IMAGES ? im.rows[k] : 1, cols = IMAGES ? im.cols[k] : 1;
   for (int64_t i = base + threadIdx.x; i < n && i < base + OPT_CHUNK; i += 256) {
     const float gi = g[i] * clip;
     const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
     m[i] = mi;
     v[i] = vi;
-    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    const float pi = p[i] - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    p[i] = pi;
+    if (IMAGES && w16) {
+      const __bf16 h = (__bf16)pi;
+      w16[i] = h;
+      const int64_t per = (int64_t)rows * cols, b = i / per, rem = i - b * per;
+      const int r = (int)(rem / cols), c = (int)(rem - (int64_t)r * cols);
+      w16t[b * per + (int64_t)c * rows + r] = h;           // (2-byte scattered stores into matrices that live in the L2)
+    }
   }
   if (chunk == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
 }
@@ -126,10 +148,11 @@ extern "C" int64_t bkg_clip_adam_chunks(const int64_t* numel, int32_t count) {
   return c;
 }
 
-extern "C" int bkg_clip_adam_f32(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
-                                 float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr,
-                                 const float* lr_dev, float beta1, float beta2, float eps, float step, float* step_dev,
-                                 float* partial, int64_t n_partial, float* norm_out, void* stream) {
+static int clip_adam_impl(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                          float* const* exp_avg_sq, const int64_t* numel, void* const* w16, void* const* w16t,
+                          const int32_t* rows, const int32_t* cols, float max_norm, float lr, const float* lr_dev,
+                          float beta1, float beta2, float eps, float step, float* step_dev, float* partial,
+                          int64_t n_partial, float* norm_out, void* stream) {
   BKG_ARG(count >= 0 && count <= OPT_MAX_TENSORS, "bkg_clip_adam_f32: at most 48 tensors per call");
   BKG_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, "bkg_clip_adam_f32: bad hyper-parameters");
   if (count == 0) return 0;
@@ -147,8 +170,44 @@ extern "C" int bkg_clip_adam_f32(int32_t count, float* const* params, const floa
   if (chunks == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(grad_sqnorm_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, partial);
-  hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, partial, (int)chunks, max_norm, lr, lr_dev,
-                     beta1, beta2, eps, step, step_dev, norm_out);
+  OptImages im;
+  bool any = false;
+  for (int i = 0; i < count; ++i) {
+    im.w16[i] = w16 ? reinterpret_cast<__bf16*>(w16[i]) : nullptr;
+    im.w16t[i] = w16t ? reinterpret_cast<__bf16*>(w16t[i]) : nullptr;
+    im.rows[i] = rows ? rows[i] : 1;
+    im.cols[i] = cols ? cols[i] : 1;
+    if (im.w16[i]) {
+      BKG_ARG(im.w16t[i] && im.rows[i] > 0 && im.cols[i] > 0 && numel[i] % ((int64_t)im.rows[i] * im.cols[i]) == 0,
+              "bkg_clip_adam_images_f32: an image needs both orientations and rows * cols dividing the tensor");
+      any = true;
+    }
+  }
+  if (any)
+    hipLaunchKernelGGL(clip_adam_kernel<true>, dim3((unsigned)chunks), dim3(256), 0, s, t, im, partial, (int)chunks, max_norm,
+                       lr, lr_dev, beta1, beta2, eps, step, step_dev, norm_out);
+  else
+    hipLaunchKernelGGL(clip_adam_kernel<false>, dim3((unsigned)chunks), dim3(256), 0, s, t, im, partial, (int)chunks, max_norm,
+                       lr, lr_dev, beta1, beta2, eps, step, step_dev, norm_out);
   if (step_dev) hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step_dev);
   return check_launch("bkg_clip_adam_f32");
+}
+
+extern "C" int bkg_clip_adam_f32(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                                 float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr,
+                                 const float* lr_dev, float beta1, float beta2, float eps, float step, float* step_dev,
+                                 float* partial, int64_t n_partial, float* norm_out, void* stream) {
+  return clip_adam_impl(count, params, grads, exp_avg, exp_avg_sq, numel, nullptr, nullptr, nullptr, nullptr, max_norm, lr,
+                        lr_dev, beta1, beta2, eps, step, step_dev, partial, n_partial, norm_out, stream);
+}
+
+// bkg_clip_adam_f32 that also refreshes the bf16 images of the weights it moves (bkg_weight_to_bf16's two orientations):
+// w16[i] / w16t[i] (nullable per tensor) = the [batch][rows][cols] and [batch][cols][rows] bf16 images of tensor i.
+extern "C" int bkg_clip_adam_images_f32(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                                        float* const* exp_avg_sq, const int64_t* numel, void* const* w16, void* const* w16t,
+                                        const int32_t* rows, const int32_t* cols, float max_norm, float lr,
+                                        const float* lr_dev, float beta1, float beta2, float eps, float step,
+                                        float* step_dev, float* partial, int64_t n_partial, float* norm_out, void* stream) {
+  return clip_adam_impl(count, params, grads, exp_avg, exp_avg_sq, numel, w16, w16t, rows, cols, max_norm, lr, lr_dev, beta1,
+                        beta2, eps, step, step_dev, partial, n_partial, norm_out, stream);
 }

@@ -101,19 +101,30 @@ def _weight_bf16(w, transpose):
     ``[N, K]``, its transpose when stored ``[K, N]``.  One tiny launch per weight version writes BOTH orientations
     (the forward needs one, the backward the other)."""
     cache = getattr(w, "_bkg_w16", None)
-    key = (w.data_ptr(), w._version, _REPLAY_GEN)
+    key = weight_image_key(w)
     if cache is None or cache[0] != key:
         w3 = w if w.dim() == 3 else w.unsqueeze(0)
         batch, rows, cols = w3.shape
-        plain = torch.empty(batch, rows, cols, dtype=torch.bfloat16, device=w.device)
-        trans = torch.empty(batch, cols, rows, dtype=torch.bfloat16, device=w.device)
-        L.call("bkg_weight_to_bf16", L.ptr(w3), w3.stride(1), w3.stride(0), rows, cols, batch, L.ptr(plain), plain.stride(1),
-               plain.stride(0), L.ptr(trans), trans.stride(1), trans.stride(0), L.stream())
-        if w.dim() == 2:
-            plain, trans = plain[0], trans[0]
+        # the images keep their addresses across versions of a weight (rewritten in place): the fused optimizer step
+        # refreshes them itself (optim.clip_adam_step), and a captured step may read them by address
+        if (cache is not None and cache[1].shape == w.shape and cache[1].device == w.device
+                and not torch.cuda.is_current_stream_capturing()):
+            plain, trans = cache[1], cache[2]
+            plain3, trans3 = (plain, trans) if w.dim() == 3 else (plain.unsqueeze(0), trans.unsqueeze(0))
+        else:
+            plain3 = torch.empty(batch, rows, cols, dtype=torch.bfloat16, device=w.device)
+            trans3 = torch.empty(batch, cols, rows, dtype=torch.bfloat16, device=w.device)
+            plain, trans = (plain3, trans3) if w.dim() == 3 else (plain3[0], trans3[0])
+        L.call("bkg_weight_to_bf16", L.ptr(w3), w3.stride(1), w3.stride(0), rows, cols, batch, L.ptr(plain3), plain3.stride(1),
+               plain3.stride(0), L.ptr(trans3), trans3.stride(1), trans3.stride(0), L.stream())
         cache = (key, plain, trans)
         w._bkg_w16 = cache
     return cache[2] if transpose else cache[1]
+
+
+def weight_image_key(w):
+    """What a cached bf16 image of ``w`` is valid for: this storage, this version, no graph replay since."""
+    return (w.data_ptr(), w._version, _REPLAY_GEN)
 
 
 _TALL_ROWS = 256    # fewest rows the streaming product is used for (a heuristic, not a kernel limit; a node-partitioned

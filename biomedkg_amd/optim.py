@@ -74,15 +74,52 @@ def clip_adam_step(opt, max_norm=None):
         scratch = _SCRATCH[key] = torch.empty(max(chunks + 1, 4096), dtype=torch.float32, device=dev)
     norm = torch.empty((), dtype=torch.float32, device=dev)
     b1, b2 = group["betas"]
-    L.call("bkg_clip_adam_f32", count, arr(*[p.data_ptr() for p in params]), arr(*[p.grad.data_ptr() for p in params]),
-           arr(*[opt.state[p]["exp_avg"].data_ptr() for p in params]),
-           arr(*[opt.state[p]["exp_avg_sq"].data_ptr() for p in params]), numel, float(max_norm or 0.0),
-           0.0 if lr_dev is not None else float(lr), L.ptr(lr_dev), float(b1), float(b2), float(group["eps"]), step_host,
-           L.ptr(step_dev), L.ptr(scratch), scratch.numel(), L.ptr(norm), L.stream())
+    # weights with bf16 images (ops._weight_bf16: the operands of the bf16-mode products): the update rewrites the images
+    # too, so the next step finds them current instead of launching one conversion per weight
+    images = [_image_of(p) for p in params] if FUSE_WEIGHT_IMAGES else [None] * count
+    if any(im is not None for im in images):
+        i32 = ctypes.c_int32 * count
+        L.call("bkg_clip_adam_images_f32", count, arr(*[p.data_ptr() for p in params]),
+               arr(*[p.grad.data_ptr() for p in params]), arr(*[opt.state[p]["exp_avg"].data_ptr() for p in params]),
+               arr(*[opt.state[p]["exp_avg_sq"].data_ptr() for p in params]), numel,
+               arr(*[im[0].data_ptr() if im else None for im in images]), arr(*[im[1].data_ptr() if im else None for im in images]),
+               i32(*[im[2] if im else 1 for im in images]), i32(*[im[3] if im else 1 for im in images]),
+               float(max_norm or 0.0), 0.0 if lr_dev is not None else float(lr), L.ptr(lr_dev), float(b1), float(b2),
+               float(group["eps"]), step_host, L.ptr(step_dev), L.ptr(scratch), scratch.numel(), L.ptr(norm), L.stream())
+    else:
+        L.call("bkg_clip_adam_f32", count, arr(*[p.data_ptr() for p in params]), arr(*[p.grad.data_ptr() for p in params]),
+               arr(*[opt.state[p]["exp_avg"].data_ptr() for p in params]),
+               arr(*[opt.state[p]["exp_avg_sq"].data_ptr() for p in params]), numel, float(max_norm or 0.0),
+               0.0 if lr_dev is not None else float(lr), L.ptr(lr_dev), float(b1), float(b2), float(group["eps"]), step_host,
+               L.ptr(step_dev), L.ptr(scratch), scratch.numel(), L.ptr(norm), L.stream())
     if step_dev is not None and len(steps) > 1:            # (one tiny multi-tensor copy; captured with the step)
         torch._foreach_copy_(steps[1:], [step_dev] * (len(steps) - 1))
     # the kernels wrote through raw pointers: tell autograd's version counters (everything cached per weight ``_version``
     # -- the bf16 weight images of ops._weight_bf16 -- must see the update, exactly as after an in-place torch op)
     for p in params:
         torch.autograd.graph.increment_version(p)
+    if any(im is not None for im in images):
+        from . import ops
+        for p, im in zip(params, images):
+            if im is not None:                 # the images are those of the NEW version
+                p._bkg_w16 = (ops.weight_image_key(p), im[0], im[1])
     return norm
+
+
+FUSE_WEIGHT_IMAGES = __import__("os").environ.get("BKG_FUSE_WEIGHT_IMAGES", "1") != "0"
+
+
+def _image_of(p):
+    """(plain, transposed, rows, cols) of a parameter's cached bf16 images, if it has them and they can be rewritten in
+    place: created by ``ops._weight_bf16`` for this very storage and shape, in bf16 mode."""
+    cache = getattr(p, "_bkg_w16", None)
+    if cache is None or p.dim() not in (2, 3):
+        return None
+    from . import ops
+    if not ops.bf16_storage():
+        return None
+    plain, trans = cache[1], cache[2]
+    if (cache[0][0] != p.data_ptr() or plain.shape != p.shape or plain.device != p.device or not plain.is_contiguous()
+            or not trans.is_contiguous()):
+        return None
+    return plain, trans, int(p.shape[-2]), int(p.shape[-1])

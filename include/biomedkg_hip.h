@@ -446,6 +446,15 @@ int bkg_clip_adam_f32(int32_t count, float* const* params, const float* const* g
                       float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, const float* lr_dev,
                       float beta1, float beta2, float eps, float step, float* step_dev, float* partial, int64_t n_partial,
                       float* norm_out, void* stream);
+/* The same step, which also refreshes the bf16 images the bf16-mode products read of the weights it moves (the two
+ * orientations bkg_weight_to_bf16 writes): w16[i] / w16t[i] (host arrays of device pointers, an entry nullable) = the
+ * [batch][rows[i]][cols[i]] image of tensor i as stored and its transpose.  A weight only changes here, so the conversion
+ * launch per weight at the top of the next step goes away. */
+int bkg_clip_adam_images_f32(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const int64_t* numel, void* const* w16, void* const* w16t,
+                             const int32_t* rows, const int32_t* cols, float max_norm, float lr, const float* lr_dev,
+                             float beta1, float beta2, float eps, float step, float* step_dev, float* partial,
+                             int64_t n_partial, float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }
