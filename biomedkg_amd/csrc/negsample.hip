@@ -319,7 +319,7 @@ extern "C" int bkg_randperm_dev(const int64_t* n_dev, int64_t cap, uint64_t seed
   BKG_ARG(cap >= 0 && n_dev, "bkg_randperm_dev: bad arguments");
   if (cap == 0) return 0;
   hipLaunchKernelGGL(randperm_dev_kernel, dim3(ceil_div(cap, 256)), dim3(256), 0, (hipStream_t)stream, n_dev, cap, seed,
-                     epoch, out);
+                     epoch ? epoch : rng_epoch_ptr(), out);      // (no counter given: the library-wide one of bkg_set_rng_epoch, if any)
   return check_launch("bkg_randperm_dev");
 }
 

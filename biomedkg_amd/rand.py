@@ -19,6 +19,9 @@ import torch
 from .ops import Dropout
 
 
+_PERM_SIZES = {}     # (n, device) -> the device scalar bkg_randperm_dev reads its extent from
+
+
 class DeviceRand:
     device_draws = True     # draws are made on the device in whatever order / shape the fast path needs (no tape)
 
@@ -45,7 +48,20 @@ class DeviceRand:
         return Dropout(p, keep=None, seed=self.seed, stream_id=self.counter & 0xFFFFFFFF)
 
     def perm(self, n, device):
-        return torch.randperm(n, device=device)
+        """``torch.randperm(n)`` of the corruption steps (reference gcl.py:22-24,70-71) as a keyed bijection of the index
+        range -- ONE launch (csrc/negsample.hip) instead of torch's random keys + radix sort (ten launches at n = 130 k);
+        under a captured step the library's replay counter re-keys it."""
+        device = torch.device(device)
+        if device.type != "cuda" or n == 0:
+            return torch.randperm(n, device=device)
+        from . import _lib as L
+        key = (n, str(device))
+        n_dev = _PERM_SIZES.get(key)
+        if n_dev is None:
+            n_dev = _PERM_SIZES[key] = torch.tensor([n], dtype=torch.int64, device=device)
+        out = torch.empty(n, dtype=torch.int64, device=device)
+        L.call("bkg_randperm_dev", L.ptr(n_dev), n, self._draw_seed(), None, L.ptr(out), L.stream())
+        return out
 
     def coin(self) -> float:
         return float(torch.rand(1).item())

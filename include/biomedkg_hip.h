@@ -389,7 +389,8 @@ int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int64_t n_cand
 int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t seed, int64_t* out, void* stream);
 /* torch.randperm over the REAL rows of a padded mini-batch (GGD's corruption, reference biomedkg/model/gcl.py:70-71, inside
  * a captured step): out[i] = pi(i) for i < n_dev[0] (device scalar), pi a bijection of [0, n_dev[0]) keyed by seed and the
- * device replay counter `epoch` (nullable); out[i] = i for n_dev[0] <= i < cap. */
+ * device replay counter `epoch` (NULL: the library-wide counter of bkg_set_rng_epoch, if one is set); out[i] = i for
+ * n_dev[0] <= i < cap.  With n_dev[0] = cap: x[torch.randperm(n)] of GGD / DGI's corruption without the sort behind randperm. */
 int bkg_randperm_dev(const int64_t* n_dev, int64_t cap, uint64_t seed, const uint32_t* epoch, int64_t* out, void* stream);
 /* The sampler of biomedkg/kge_module.py:86-102 for one PADDED mini-batch with every extent in device memory (sizes as
  * written by bkg_saint_batch; head / tail / type hold `rows` entries, the first sizes[1] are edges): hash set of the

@@ -189,3 +189,25 @@ def test_mismatched_triplet_arrays_are_refused_not_dereferenced():
     loss, _, _ = ops.kge_bce_loss(z, rel, pos, pt, neg, nt[:1], ops.KGE_DISTMULT, reg=1e-2)
     loss.backward()
     assert torch.isfinite(loss) and torch.isfinite(z.grad).all()
+
+
+def test_device_rand_perm_is_a_fresh_permutation_per_call():
+    """``DeviceRand.perm`` (GGD / DGI corruption, reference gcl.py:22-24,70-71): a keyed bijection of the index range, one
+    launch, new on every call, torch.randperm on the CPU."""
+    from biomedkg_amd import rand as R
+    r = R.DeviceRand(seed=7)
+    seen = []
+    for n in (1, 2, 1000, 130_001):
+        p = r.perm(n, DEV)
+        assert p.dtype == torch.int64 and p.device.type == "cuda"
+        assert torch.equal(torch.sort(p).values, torch.arange(n, device=DEV))
+        q = r.perm(n, DEV)
+        if n >= 1000:
+            assert not torch.equal(p, q)
+            assert int((p == torch.arange(n, device=DEV)).sum()) < 20        # nothing like the identity
+            seen.append(p)
+    again = R.DeviceRand(seed=7)                                             # same seed, same call number: same draw
+    for n in (1, 1, 2, 2):
+        again.perm(n, DEV)
+    assert again.perm(1000, DEV).equal(seen[0])
+    assert r.perm(5, "cpu").device.type == "cpu"
