@@ -127,6 +127,9 @@ SIGNATURES = {
     # fusion.hip
     "bkg_attn_fuse_f32": (I32, [P, I64, I64, I32, I32, P, I64, P]),
     "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, U32, I64, P, I64, P]),
+    "bkg_ggd_bce_partials": (I64, []),
+    "bkg_ggd_bce_f32": (I32, [P, I64, P, I64, I64, P, P, P, P]),
+    "bkg_ggd_bce_bwd_f32": (I32, [P, I64, P, I64, I64, P, P, P, I64, P, I64, P]),
     "bkg_redaf_fused_xw": (I32, [I64, I64, I64, P, I32, I64, P, I64, P, P, P, F32, U64, U32, P, I64, P]),
 }
 

@@ -160,6 +160,8 @@ class GGDModule(BaseGCL):
 
     def calculate_loss(self, x, edge_index):
         pos_h, neg_h = self.model(x, edge_index)
+        if ops.ggd_bce_ok(pos_h, neg_h):          # the same mean of softplus(-pos) and softplus(neg), one launch each way
+            return ops.ggd_bce(pos_h, neg_h)
         pred = torch.cat([pos_h, neg_h])
         gt = torch.cat([torch.ones_like(pos_h), torch.zeros_like(neg_h)])
         return F.binary_cross_entropy_with_logits(pred, gt)

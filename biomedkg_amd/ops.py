@@ -1507,6 +1507,43 @@ REDAF_CHUNK_NODES = int(__import__("os").environ.get("BKG_REDAF_CHUNK", "16384")
 #                            (4,096-node chunks: 1.47 ms per call at N = 130k -- products too small to fill the chip --, 16,384: 1.0)
 
 
+class _GgdBce(torch.autograd.Function):
+    """``binary_cross_entropy_with_logits(cat(pos, neg), cat(ones, zeros))`` (mean) for GGD's two score vectors, one
+    forward and one backward launch (csrc/gcl_loss.hip); ``n_dev``: the masked form of padded mini-batches."""
+
+    @staticmethod
+    def forward(ctx, pos, neg, n_dev):
+        L.require_cuda(pos, neg, n_dev)
+        n = pos.numel()
+        partial = torch.empty(int(L.lib().bkg_ggd_bce_partials()), dtype=torch.float32, device=pos.device)
+        out = torch.empty((), dtype=torch.float32, device=pos.device)
+        L.call("bkg_ggd_bce_f32", L.ptr(pos), pos.stride(0) if n else 1, L.ptr(neg), neg.stride(0) if n else 1, n,
+               L.ptr(n_dev), L.ptr(partial), L.ptr(out), L.stream())
+        ctx.save_for_backward(pos, neg, n_dev)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pos, neg, n_dev = ctx.saved_tensors
+        n = pos.numel()
+        d = torch.empty(n, 2, dtype=torch.float32, device=pos.device)       # [d pos | d neg]: the layout of the score table
+        g = _f32c(gout).reshape(1)
+        L.call("bkg_ggd_bce_bwd_f32", L.ptr(pos), pos.stride(0) if n else 1, L.ptr(neg), neg.stride(0) if n else 1, n,
+               L.ptr(n_dev), L.ptr(g), L.ptr(d), 2, L.ptr(d[:, 1]) if n else L.ptr(d), 2, L.stream())
+        return d[:, 0], d[:, 1], None
+
+
+def ggd_bce_ok(pos, neg):
+    return (pos.is_cuda and neg.is_cuda and pos.dim() == 1 and neg.shape == pos.shape and pos.dtype == torch.float32
+            and neg.dtype == torch.float32 and pos.numel() > 0)
+
+
+def ggd_bce(pos, neg, n_dev=None):
+    """GGD's loss over the positive / corrupted score vectors (any element stride); ``n_dev``: int64 device scalar, rows
+    below it count (padded mini-batches)."""
+    return _GgdBce.apply(pos, neg, n_dev)
+
+
 REDAF_ONE_LAUNCH = __import__("os").environ.get("BKG_REDAF_ONE_LAUNCH", "1") != "0"
 
 

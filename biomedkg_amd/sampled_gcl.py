@@ -198,6 +198,8 @@ class NeighborGraphedGcl:
         n_id, ei, real_n = self.padded_batch(e_b)
         x = m.fusion_fn(x=rows_of(self.x_ext, n_id))
         pos_h, neg_h = m.model(x, ei)
+        if ops.ggd_bce_ok(pos_h, neg_h):          # rows below sizes[1] count, the mean divides by 2 sizes[1] (csrc/gcl_loss.hip)
+            return ops.ggd_bce(pos_h, neg_h, self.v["sizes"][1:2])
         w = real_n.to(pos_h.dtype)
         inv = 0.5 / self.v["sizes"][1].to(pos_h.dtype)
         return (F.binary_cross_entropy_with_logits(pos_h, torch.ones_like(pos_h), weight=w, reduction="sum")

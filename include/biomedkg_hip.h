@@ -457,6 +457,18 @@ int bkg_clip_adam_images_f32(int32_t count, float* const* params, const float* c
                              float beta1, float beta2, float eps, float step, float* step_dev, float* partial,
                              int64_t n_partial, float* norm_out, void* stream);
 
+/* GGD's loss (biomedkg/gcl_module.py:229-234): binary_cross_entropy_with_logits(cat(pos, neg), cat(ones, zeros)), mean over
+ * the 2 n logits, forward (partial sums in a fixed order + a one-block finish) and gradient, one launch each; pos / neg /
+ * dpos / dneg: fp32 vectors with an element stride (the two columns of an [n, 2] score table).  n_dev (nullable DEVICE
+ * scalar): only rows below n_dev[0] count and the mean divides by 2 n_dev[0] (padded mini-batches); gradients of the other
+ * rows are 0.  partial: bkg_ggd_bce_partials() floats of scratch; gout: the upstream scalar on the device. */
+int64_t bkg_ggd_bce_partials(void);
+int bkg_ggd_bce_f32(const float* pos, int64_t stride_pos, const float* neg, int64_t stride_neg, int64_t n,
+                    const int64_t* n_dev, float* partial, float* out, void* stream);
+int bkg_ggd_bce_bwd_f32(const float* pos, int64_t stride_pos, const float* neg, int64_t stride_neg, int64_t n,
+                        const int64_t* n_dev, const float* gout, float* dpos, int64_t stride_dpos, float* dneg,
+                        int64_t stride_dneg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
