@@ -33,6 +33,7 @@ SIGNATURES = {
     # graph.hip
     "bkg_sort_workspace_bytes": (I64, [I64]),
     "bkg_sort_edges": (I32, [P, P, I64, I64, I64, P, P, P, P, P, I64, P]),
+    "bkg_keys_rowptr_presorted": (I32, [P, P, I64, I64, I64, P, P, I64, U32, P, P]),
     "bkg_sort_edges_rowptr": (I32, [P, P, I64, I64, I64, P, P, P, P, I64, U32, P, P, I64, P]),
     "bkg_lower_bound_u32": (I32, [P, I64, I64, U32, P, P]),
     "bkg_gather_i64_to_i32": (I32, [P, P, P, I64, P]),

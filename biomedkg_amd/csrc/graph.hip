@@ -287,6 +287,22 @@ extern "C" int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo
                          nullptr, stream);
 }
 
+// The same outputs for keys that ARE already in ascending order (the neighbour sampler emits a batch's edges target by
+// target in local-id order): sorted_keys = the keys, perm = 0 .. n - 1, the row pointers -- two launches, no sort.
+extern "C" int bkg_keys_rowptr_presorted(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n,
+                                         uint32_t* sorted_keys, uint32_t* perm, int64_t n_queries, uint32_t stride,
+                                         int32_t* rowptr, void* stream) {
+  BKG_ARG(n >= 0 && n_lo > 0 && n_hi > 0 && n_queries >= 0 && rowptr, "bkg_keys_rowptr_presorted: bad sizes");
+  BKG_ARG((double)n_lo * (double)n_hi < 4294967296.0, "bkg_keys_rowptr_presorted: key space exceeds 32 bits");
+  hipStream_t s = (hipStream_t)stream;
+  if (n) hipLaunchKernelGGL(make_keys_kernel, grid1(n), dim3(256), 0, s, lo, hi, n_lo, sorted_keys, perm, n);
+  if (n_queries) {
+    if (n) hipLaunchKernelGGL(lower_bound_kernel, grid1(n_queries), dim3(256), 0, s, sorted_keys, n, n_queries, stride, rowptr);
+    else fill_u32(rowptr, 0u, n_queries, s);
+  }
+  return check_launch("bkg_keys_rowptr_presorted");
+}
+
 // bkg_sort_edges + bkg_lower_bound_u32(sorted_keys, n, n_queries, stride, rowptr) in one call (small key sets: one launch)
 extern "C" int bkg_sort_edges_rowptr(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n,
                                      uint32_t* keys_tmp, uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm,

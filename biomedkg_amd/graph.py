@@ -35,6 +35,17 @@ class _Sorter:
         return sorted_keys, perm, ws
 
     @staticmethod
+    def presorted_rowptr(lo, hi, n_lo, n_hi, n_queries, stride=1):
+        """``sort_rowptr`` for keys that are already ascending (the caller vouches for it): no sort, two launches."""
+        L.require_cuda(lo, hi)
+        n, dev = lo.numel(), lo.device
+        sorted_keys, perm = _i32(n, dev), _i32(n, dev)
+        rowptr = _i32(n_queries, dev)
+        L.call("bkg_keys_rowptr_presorted", L.ptr(lo), L.ptr(hi), n_lo, n_hi, n, L.ptr(sorted_keys), L.ptr(perm), n_queries,
+               stride, L.ptr(rowptr), L.stream())
+        return sorted_keys, perm, rowptr
+
+    @staticmethod
     def sort_rowptr(lo, hi, n_lo, n_hi, n_queries, stride=1):
         """``sort`` + the row pointers ``rowptr[q] = first position with key >= q * stride`` in one library call (a key
         set of a mini-batch: one launch)."""
@@ -166,12 +177,14 @@ class CSR:
             self._split = rowsplit_for(self.rowptr, self.n_rows, self.nnz, pack=True, col=self.col)
         return self._split
 
-    def __init__(self, key, other, n_rows):
+    def __init__(self, key, other, n_rows, presorted=False):
+        """``presorted``: ``key`` is already ascending (rows in order, entries of a row in edge order)."""
         key = key.contiguous()
         other = other.contiguous()
         dev = key.device
         self.n_rows, self.nnz = int(n_rows), key.numel()
-        self.sorted_keys, self.perm, self.rowptr = _Sorter.sort_rowptr(key, None, n_rows, 1, n_rows + 1)
+        build = _Sorter.presorted_rowptr if presorted else _Sorter.sort_rowptr
+        self.sorted_keys, self.perm, self.rowptr = build(key, None, n_rows, 1, n_rows + 1)
         self.col = _i32(self.nnz, dev)
         L.call("bkg_gather_i64_to_i32", L.ptr(other), L.ptr(self.perm), L.ptr(self.col), self.nnz, L.stream())
 
@@ -225,9 +238,12 @@ class Graph(_EdgeHolder):
         L.require_cuda(edge_index)
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError("edge_index must be int64 [2, E]")
+        # a device NeighborLoader batch lists its edges target by target in local-id order and says so on the tensor
+        # (samplers.NeighborSampler, sampled_gcl): the target-side CSR then needs no sort
+        dst_sorted = bool(getattr(edge_index, "_bkg_dst_sorted", False))
         self._hold(edge_index.contiguous())
         self.num_nodes, self.num_edges = int(num_nodes), edge_index.size(1)
-        self.by_dst = CSR(self.dst, self.src, num_nodes)   # rows = targets, col = sources  (forward)
+        self.by_dst = CSR(self.dst, self.src, num_nodes, presorted=dst_sorted)   # rows = targets, col = sources  (forward)
         self.by_src = CSR(self.src, self.dst, num_nodes)   # rows = sources, col = targets  (backward)
         self._plain = None
         self._kept = None

@@ -12,9 +12,9 @@ gene/protein size a subgraph of ~25 k nodes and ~220 k edges per step.  Run eage
   (``biomedkg/model/gcl.py:74``: a host-side ``torch.rand(1).item()`` in the reference too); one graph per
   (bucket, augmented?) is captured lazily.
 * Inside the step nothing depends on a host-side size.  The node capacity is the graph's node count: pad NODES read the
-  zero row appended to the feature table and have no edges, so nothing gathers them; pad EDGES are self loops spread over
-  the nodes, which ``gcn_norm`` gives weight 0 (``add_remaining_self_loops`` replaces them by the unit loop every node
-  gets anyway); GGD's corruption permutes the real rows only (``bkg_randperm_dev``: a keyed bijection of ``[0, n_b)`` with
+  zero row appended to the feature table and have no edges, so nothing gathers them; pad EDGES are self loops, which ``gcn_norm`` gives weight 0 (``add_remaining_self_loops`` replaces them by the unit loop every node
+  gets anyway; they sit on the LAST node, behind the real edges, whose targets ascend: the target-side CSR of a batch
+  needs no sort); GGD's corruption permutes the real rows only (``bkg_randperm_dev``: a keyed bijection of ``[0, n_b)`` with
   ``n_b`` read on the device); the BCE sums over the real rows and divides by a device scalar, so the pad rows' logits
   get zero gradient and with them every pad row of every layer.
 
@@ -138,7 +138,7 @@ class NeighborGraphedGcl:
         self.v = self.sampler.views(self.cur)
         self.iota_n = torch.arange(self.n_cap, device=dev)
         self.iota_e = torch.arange(self.buckets[-1], device=dev)
-        self.spread = self.iota_e % self.n_cap                                          # pad edges: self loops, one per node in turn
+        self.last_node = torch.full((), self.n_cap - 1, dtype=torch.int64, device=dev)   # pad edges: its self loops
         self.pad_row = torch.full((), self.n_cap, dtype=torch.int64, device=dev)
         if optimizer is None:         # the optimizer of BaseGCL.configure_optimizers, without the trainer-bound scheduler
             optimizer = torch.optim.Adam(list(module.model.parameters()), lr=module.lr, fused=True)
@@ -187,8 +187,12 @@ class NeighborGraphedGcl:
         real_n = self.iota_n < v["sizes"][1]
         real_e = self.iota_e[:e_b] < v["sizes"][2]
         n_id = torch.where(real_n, v["n_id"], self.pad_row)
-        ei = torch.stack([torch.where(real_e, v["src"][:e_b], self.spread[:e_b]),
-                          torch.where(real_e, v["dst"][:e_b], self.spread[:e_b])])     # fresh tensor: no structure cached on it survives the step
+        # pads: self loops of the LAST node (weight 0 under gcn_norm for any node, real or pad) -- behind the real edges,
+        # whose targets ascend (the sampler expands frontier nodes in local-id order), so the whole list stays sorted by
+        # target and the target-side CSR needs no sort (graph.Graph, _bkg_dst_sorted)
+        ei = torch.stack([torch.where(real_e, v["src"][:e_b], self.last_node),
+                          torch.where(real_e, v["dst"][:e_b], self.last_node)])        # fresh tensor: no structure cached on it survives the step
+        ei._bkg_dst_sorted = True
         return n_id, ei, real_n
 
     def padded_loss(self, e_b):

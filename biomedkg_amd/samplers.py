@@ -72,7 +72,9 @@ class NeighborSampler:
             return self.sample_hop_by_hop(seeds)
         st = self.enqueue(seeds)
         _, nn, ne = st["ctr"].tolist()                                       # the one host read of the batch
-        return st["n_id"][:nn].clone(), torch.stack([st["e_src"][:ne], st["e_dst"][:ne]]), st["e_id"][:ne].clone()
+        ei = torch.stack([st["e_src"][:ne], st["e_dst"][:ne]])
+        ei._bkg_dst_sorted = True      # frontier nodes are expanded in local-id order, hop after hop: targets ascend (graph.Graph)
+        return st["n_id"][:nn].clone(), ei, st["e_id"][:ne].clone()
 
     def enqueue(self, seeds):
         """The batch of ``sample`` left in the fixed-capacity device state (``ctr[1]`` nodes in ``n_id``, ``ctr[2]`` edges

@@ -48,6 +48,11 @@ int bkg_sort_edges(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n
 int bkg_sort_edges_rowptr(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n, uint32_t* keys_tmp,
                           uint32_t* iota_tmp, uint32_t* sorted_keys, uint32_t* perm, int64_t n_queries, uint32_t stride,
                           int32_t* rowptr, void* workspace, int64_t workspace_bytes, void* stream);
+/* The outputs of bkg_sort_edges_rowptr for keys that are ALREADY ascending (a NeighborLoader batch lists its edges target by
+ * target in local-id order): sorted_keys = the keys, perm = identity, rowptr by binary search -- no sort.  The caller vouches
+ * for the order. */
+int bkg_keys_rowptr_presorted(const int64_t* lo, const int64_t* hi, int64_t n_lo, int64_t n_hi, int64_t n, uint32_t* sorted_keys,
+                              uint32_t* perm, int64_t n_queries, uint32_t stride, int32_t* rowptr, void* stream);
 /* out[s] = lower_bound(sorted, s*stride), s in [0, n_queries) -- CSR row pointers from sorted keys */
 int bkg_lower_bound_u32(const uint32_t* sorted, int64_t n, int64_t n_queries, uint32_t stride, int32_t* out,
                         void* stream);

@@ -46,6 +46,31 @@ def test_sync_free_sampler_equals_the_eager_device_sampler():
         assert torch.equal(v["src"][:e_b], sub[0]) and torch.equal(v["dst"][:e_b], sub[1])
 
 
+def test_batches_list_their_edges_in_target_order():
+    """What ``_bkg_dst_sorted`` vouches for: the device sampler expands frontier nodes in local-id order, hop after hop, so a
+    batch's targets ascend; the padded batch keeps that (pads = self loops of the last node), and the target-side CSR built
+    without a sort is the sorted one."""
+    from biomedkg_amd import graph as G
+    from biomedkg_amd.sampled_gcl import NeighborGraphedGcl
+    from biomedkg_amd.samplers import NeighborSampler
+    ei, n = _graph()
+    s = NeighborSampler(ei, n, (5, 4, 3), seed=11)
+    for trial in range(4):
+        seeds = torch.randint(0, n, (24,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(trial)).unique()
+        n_id, sub, _ = s.sample(seeds)
+        assert getattr(sub, "_bkg_dst_sorted", False) and bool((sub[1][1:] >= sub[1][:-1]).all())
+        fast, slow = G.Graph(sub, n_id.numel()).by_dst, G.CSR(sub[1], sub[0], n_id.numel())
+        assert torch.equal(fast.rowptr, slow.rowptr) and torch.equal(fast.col, slow.col) and torch.equal(fast.perm, slow.perm)
+    x = torch.randn(n, 2, 64, device=DEV) * 0.3
+    lp = NeighborGraphedGcl(_module(fuse="attention").train(), x, ei, batch_size=8, num_neighbors=(4, 3, 3), seed=5, graphs=False)
+    lp.sampler.draw(torch.arange(8, device=DEV))
+    n_b, e_b = lp.sampler.sizes()
+    lp.cur.copy_(lp.sampler.buf)
+    bucket = next(b for b in lp.buckets if b >= e_b)
+    _, pei, _ = lp.padded_batch(bucket)
+    assert pei._bkg_dst_sorted and bool((pei[1][1:] >= pei[1][:-1]).all()) and bool((pei[:, e_b:] == n - 1).all())
+
+
 def test_randperm_dev():
     from biomedkg_amd import _lib as L
     cap = 5000
