@@ -54,16 +54,19 @@ __global__ void rowsplit_fill_kernel(const int32_t* __restrict__ rowptr, int n_r
                                      int32_t* __restrict__ short_col, int32_t* __restrict__ totals) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int stride = n_rows + 1;
+  // ONE exclusive scan runs over the four counter arrays laid end to end: array k's prefix sums are its part of the scan
+  // minus what the arrays before it add up to (= the scan value at its first element)
+  const int b1 = scan[stride], b2 = scan[2 * stride], b3 = scan[3 * stride];
   if (r == n_rows) {
     totals[0] = scan[n_rows];
-    totals[1] = scan[stride + n_rows];
-    totals[2] = scan[2 * stride + n_rows];
-    totals[3] = scan[3 * stride + n_rows];
+    totals[1] = scan[stride + n_rows] - b1;
+    totals[2] = scan[2 * stride + n_rows] - b2;
+    totals[3] = scan[3 * stride + n_rows] - b3;
   }
   if (r >= n_rows) return;
   const int beg = rowptr[r], end = rowptr[r + 1], len = end - beg;
   if (pack && len <= SHORT_LEN) {
-    const int i = scan[3 * stride + r];
+    const int i = scan[3 * stride + r] - b3;
     reinterpret_cast<int4*>(short_desc)[i] = make_int4(r, beg, len, 0);
     int c[SHORT_LEN];
 #pragma unroll
@@ -77,7 +80,7 @@ __global__ void rowsplit_fill_kernel(const int32_t* __restrict__ rowptr, int n_r
     item_row[i0] = r; item_beg[i0] = beg; item_end[i0] = end; item_slot[i0] = -1;
     return;
   }
-  const int n = (len + chunk - 1) / chunk, s0 = scan[stride + r], l = scan[2 * stride + r];
+  const int n = (len + chunk - 1) / chunk, s0 = scan[stride + r] - b1, l = scan[2 * stride + r] - b2;
   long_row[l] = r; long_slot0[l] = s0; long_cnt[l] = n;
   for (int c = 0; c < n; ++c) {
     item_row[i0 + c] = r;
@@ -104,10 +107,13 @@ extern "C" int bkg_rowsplit_build(const int32_t* rowptr, int64_t n_rows, int64_t
   dim3 grid(ceil_div(n_rows + 1, 256)), block(256);
   hipLaunchKernelGGL(rowsplit_count_kernel, grid, block, 0, s, rowptr, n, chunk, pack ? 1 : 0, cnt_tmp);
   const size_t stride = (size_t)n_rows + 1;
-  for (int k = 0; k < 4; ++k) {
+  {   // the four counter arrays in one scan (two launches instead of eight: a mini-batch step builds two of these tables)
+    size_t need = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, need, cnt_tmp, scan_tmp, (int32_t)0, 4 * stride, rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) { set_error("bkg_rowsplit_build: exclusive_scan (size query)", e); return (int)e; }
+    BKG_ARG(need <= (size_t)workspace_bytes, "bkg_rowsplit_build: workspace too small for the scan");
     size_t bytes = (size_t)workspace_bytes;
-    hipError_t e = rocprim::exclusive_scan(workspace, bytes, cnt_tmp + k * stride, scan_tmp + k * stride, (int32_t)0,
-                                           stride, rocprim::plus<int32_t>(), s);
+    e = rocprim::exclusive_scan(workspace, bytes, cnt_tmp, scan_tmp, (int32_t)0, 4 * stride, rocprim::plus<int32_t>(), s);
     if (e != hipSuccess) { set_error("bkg_rowsplit_build: exclusive_scan", e); return (int)e; }
   }
   hipLaunchKernelGGL(rowsplit_fill_kernel, grid, block, 0, s, rowptr, n, chunk, pack ? 1 : 0, scan_tmp, item_row, item_beg,
