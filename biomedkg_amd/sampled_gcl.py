@@ -290,7 +290,7 @@ class NeighborGraphedGcl:
                 torch.cuda.synchronize()
                 self.graphs_on = False
                 self.optimizer.zero_grad(set_to_none=True)
-                print(f"[sampled-gcl] padded steps stay eager: {str(why).splitlines()[0]}", flush=True)
+                print(f"[sampled-gcl] padded steps stay eager: {str(why).splitlines()[0]}", file=__import__("sys").stderr, flush=True)
                 return loss
             self.execs[key] = g
             self.stats["captured"] += 1
