@@ -240,7 +240,7 @@ class Graph(_EdgeHolder):
             raise ValueError("edge_index must be int64 [2, E]")
         # a device NeighborLoader batch lists its edges target by target in local-id order and says so on the tensor
         # (samplers.NeighborSampler, sampled_gcl): the target-side CSR then needs no sort
-        dst_sorted = bool(getattr(edge_index, "_bkg_dst_sorted", False))
+        dst_sorted = getattr(edge_index, "_bkg_dst_sorted", None) == edge_index._version      # (vouched for THIS version of the tensor)
         self._hold(edge_index.contiguous())
         self.num_nodes, self.num_edges = int(num_nodes), edge_index.size(1)
         self.by_dst = CSR(self.dst, self.src, num_nodes, presorted=dst_sorted)   # rows = targets, col = sources  (forward)

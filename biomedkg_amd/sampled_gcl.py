@@ -192,7 +192,7 @@ class NeighborGraphedGcl:
         # target and the target-side CSR needs no sort (graph.Graph, _bkg_dst_sorted)
         ei = torch.stack([torch.where(real_e, v["src"][:e_b], self.last_node),
                           torch.where(real_e, v["dst"][:e_b], self.last_node)])        # fresh tensor: no structure cached on it survives the step
-        ei._bkg_dst_sorted = True
+        ei._bkg_dst_sorted = ei._version
         return n_id, ei, real_n
 
     def padded_loss(self, e_b):

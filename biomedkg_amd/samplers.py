@@ -73,7 +73,7 @@ class NeighborSampler:
         st = self.enqueue(seeds)
         _, nn, ne = st["ctr"].tolist()                                       # the one host read of the batch
         ei = torch.stack([st["e_src"][:ne], st["e_dst"][:ne]])
-        ei._bkg_dst_sorted = True      # frontier nodes are expanded in local-id order, hop after hop: targets ascend (graph.Graph)
+        ei._bkg_dst_sorted = ei._version      # frontier nodes are expanded in local-id order, hop after hop: targets ascend (graph.Graph)
         return st["n_id"][:nn].clone(), ei, st["e_id"][:ne].clone()
 
     def enqueue(self, seeds):

@@ -58,9 +58,14 @@ def test_batches_list_their_edges_in_target_order():
     for trial in range(4):
         seeds = torch.randint(0, n, (24,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(trial)).unique()
         n_id, sub, _ = s.sample(seeds)
-        assert getattr(sub, "_bkg_dst_sorted", False) and bool((sub[1][1:] >= sub[1][:-1]).all())
+        assert getattr(sub, "_bkg_dst_sorted", None) == sub._version and bool((sub[1][1:] >= sub[1][:-1]).all())
         fast, slow = G.Graph(sub, n_id.numel()).by_dst, G.CSR(sub[1], sub[0], n_id.numel())
         assert torch.equal(fast.rowptr, slow.rowptr) and torch.equal(fast.col, slow.col) and torch.equal(fast.perm, slow.perm)
+        shuffled = sub.clone()
+        shuffled._bkg_dst_sorted = shuffled._version
+        shuffled[:, :] = sub[:, torch.randperm(sub.size(1), device=DEV)]          # moved in place: the voucher is void
+        again = G.Graph(shuffled, n_id.numel()).by_dst
+        assert torch.equal(again.rowptr, slow.rowptr)
     x = torch.randn(n, 2, 64, device=DEV) * 0.3
     lp = NeighborGraphedGcl(_module(fuse="attention").train(), x, ei, batch_size=8, num_neighbors=(4, 3, 3), seed=5, graphs=False)
     lp.sampler.draw(torch.arange(8, device=DEV))
@@ -68,7 +73,7 @@ def test_batches_list_their_edges_in_target_order():
     lp.cur.copy_(lp.sampler.buf)
     bucket = next(b for b in lp.buckets if b >= e_b)
     _, pei, _ = lp.padded_batch(bucket)
-    assert pei._bkg_dst_sorted and bool((pei[1][1:] >= pei[1][:-1]).all()) and bool((pei[:, e_b:] == n - 1).all())
+    assert pei._bkg_dst_sorted == pei._version and bool((pei[1][1:] >= pei[1][:-1]).all()) and bool((pei[:, e_b:] == n - 1).all())
 
 
 def test_randperm_dev():
