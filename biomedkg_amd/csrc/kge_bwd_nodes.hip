@@ -17,6 +17,12 @@ namespace bkg {
 
 enum { KN_DISTMULT = 0, KN_TRANSE = 1 };
 constexpr float KN_EPS = 1e-12f;
+#ifndef KN_REL_LDS
+#define KN_REL_LDS 1          // the relation table staged in LDS, persistent workgroups (0: rows from the caches)
+#endif
+#ifndef KN_PERSIST_BLOCKS
+#define KN_PERSIST_BLOCKS 2048  // workgroups of the persistent form (256 CUs x 8)
+#endif
 #ifndef KN_U4
 #define KN_U4 2      // incidences in flight per lane group at four accumulator quads (experiment knob)
 #endif
@@ -88,30 +94,40 @@ __device__ __forceinline__ void kn_finish(float4* acc, const float4* self, float
 }
 
 // SPLIT: one wave per row-split item instead of one wave per node
-template <typename T, int KIND, int LPR, int VPL, bool SPLIT>
+// REL_LDS: the relation table (n_rel rows + a zero row for the pad relation id of padded steps, <= 64 KB) is staged in LDS
+// once per workgroup, and a workgroup walks a strided share of the items instead of four.  Measured neutral at the bench
+// size (0.737 ms per launch either way; with the relation factor taken out altogether -- KN_EXP_NOREL -- 0.60): the row
+// comes out of LDS as slowly as out of the L1, what costs is the chain entry id -> record -> (row, relation row).
+template <typename T, int KIND, int LPR, int VPL, bool SPLIT, bool REL_LDS>
 __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict__ z, int64_t ldz, int n_nodes,
                                                             KnTriplets tr, const float* __restrict__ rel_emb,
-                                                            int64_t ldr, const float* __restrict__ gscore,
+                                                            int64_t ldr, int n_rel, const float* __restrict__ gscore,
                                                             const float* __restrict__ l1,
                                                             const int32_t* __restrict__ inc_rowptr,
                                                             const int32_t* __restrict__ inc_perm,
                                                             float* __restrict__ dz, int64_t lddz, bkg_rowsplit rs,
                                                             float* __restrict__ partials, int accumulate) {
-  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q;
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, D = EPL * LPR * VPL;
+  extern __shared__ __attribute__((aligned(16))) float rel_lds[];
   const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
+  if (REL_LDS) {
+    for (int i = threadIdx.x; i < (n_rel + 1) * (D / 4); i += 256) {      // (+ a zero row: the pad relation id of padded steps)
+      const int r = i / (D / 4), c = i % (D / 4);
+      reinterpret_cast<float4*>(rel_lds)[i] = r < n_rel ? kn_ld4(rel_emb + (int64_t)r * ldr + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+  }
+  const int n_work = SPLIT ? rs.totals[0] : n_nodes;
+  for (int work = blockIdx.x * 4 + (threadIdx.x >> 6); work < n_work; work += gridDim.x * 4) {
   int node, start, end, slot = -1;
   if (SPLIT) {
-    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= rs.totals[0]) return;
-    item = __builtin_amdgcn_readfirstlane(item);
+    const int item = __builtin_amdgcn_readfirstlane(work);
     node = __builtin_amdgcn_readfirstlane(rs.item_row[item]);
     start = __builtin_amdgcn_readfirstlane(rs.item_beg[item]);
     end = __builtin_amdgcn_readfirstlane(rs.item_end[item]);
     slot = __builtin_amdgcn_readfirstlane(rs.item_slot[item]);
   } else {
-    node = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (node >= n_nodes) return;
-    node = __builtin_amdgcn_readfirstlane(node);
+    node = __builtin_amdgcn_readfirstlane(work);
     start = __builtin_amdgcn_readfirstlane(inc_rowptr[node]);
     end = __builtin_amdgcn_readfirstlane(inc_rowptr[node + 1]);
   }
@@ -181,7 +197,12 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict_
       const float sg = is_head[u] ? -g[u] : g[u], io = inv_o[u];
 #pragma unroll
       for (int q = 0; q < VQ; ++q) {
-        const float4 r = kn_ld4(rel_emb + ri[u] * ldr + piece_col<T, LPR>(lig, q));  // <= R rows: cache resident
+#if defined(KN_EXP_NOREL)
+        const float4 r = make_float4(1.f, 1.f, 1.f, 1.f);
+#else
+        const float4 r = REL_LDS ? *reinterpret_cast<const float4*>(rel_lds + (int)ri[u] * D + piece_col<T, LPR>(lig, q))
+                                 : kn_ld4(rel_emb + (n_rel > 0 ? min(ri[u], (int64_t)n_rel - 1) : ri[u]) * ldr + piece_col<T, LPR>(lig, q));   // (the pad relation id of a padded step: a finite row times g = 0)
+#endif
         if (KIND == KN_DISTMULT) {
           acc[q].x = fmaf(g[u] * r.x, o[q].x, acc[q].x); acc[q].y = fmaf(g[u] * r.y, o[q].y, acc[q].y);
           acc[q].z = fmaf(g[u] * r.z, o[q].z, acc[q].z); acc[q].w = fmaf(g[u] * r.w, o[q].w, acc[q].w);
@@ -210,16 +231,19 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict_
         acc[q].z += __shfl_xor(acc[q].z, o, 64); acc[q].w += __shfl_xor(acc[q].w, o, 64);
       }
   }
-  if (grp != 0) return;  // after the cross-group combine every group holds the full sum
+  // after the cross-group combine every group holds the full sum: group 0 writes it
   if (SPLIT && slot >= 0) {
-    constexpr int d = EPL * LPR * VPL;
+    if (grp == 0) {
 #pragma unroll
-    for (int q = 0; q < VQ; ++q)
-      *reinterpret_cast<float4*>(partials + (int64_t)slot * d + piece_col<T, LPR>(lig, q)) = acc[q];
-    return;
+      for (int q = 0; q < VQ; ++q)
+        *reinterpret_cast<float4*>(partials + (int64_t)slot * D + piece_col<T, LPR>(lig, q)) = acc[q];
+    }
+    continue;
   }
+  // (TransE: the normalisation's dot product runs over the lanes of a group, every group has the same values)
   kn_finish<T, KIND, LPR, VPL>(acc, self, inv_self, KIND == KN_TRANSE ? (l1[node] > KN_EPS) : true, node, lig, dz, lddz,
-                               accumulate, true);
+                               accumulate, grp == 0);
+  }
 }
 
 // long incidence lists: add the node's partial slots in chunk order, then the TransE epilogue
@@ -272,7 +296,7 @@ using namespace bkg;
 
 extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes,
                                      int32_t d, const int64_t* head, const int64_t* tail, const int64_t* rel,
-                                     int64_t T, const float* rel_emb, int64_t ldr, const float* gscore,
+                                     int64_t T, const float* rel_emb, int64_t ldr, int64_t n_rel, const float* gscore,
                                      const void* rec, const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm, float* dz,
                                      int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
                                      void* stream) {
@@ -287,24 +311,35 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_b
   hipStream_t s = (hipStream_t)stream;
   dim3 block(256);
   bkg_rowsplit none{};
+  /* relation table in LDS (and a strided walk over the items) when it fits 64 KB and there is enough work to amortise   \
+     the staging; else one block per four items, rows from the caches */                                               \
+  const bool rel_lds = KN_REL_LDS && n_rel > 0 && (int64_t)(n_rel + 1) * d * 4 <= 65536;                                     \
+  const size_t smem = rel_lds ? (size_t)(n_rel + 1) * d * 4 : 0;
+#define KN_GRID(work) dim3((unsigned)std::max<int64_t>(1, rel_lds ? std::min<int64_t>(ceil_div(work, 4), KN_PERSIST_BLOCKS) \
+                                                                   : ceil_div(work, 4)))
+#define KN_LAUNCH2(TT, K, SP, RL, work, RS)                                                                            \
+  hipLaunchKernelGGL((kge_bwd_nodes_kernel<TT, K, LPR, VPL, SP, RL>), KN_GRID(work), block, RL ? smem : 0, s,          \
+                     (const TT*)z, ldz, (int)n_nodes, tr, rel_emb, ldr, (int)n_rel, gscore, l1, inc_rowptr, inc_perm,  \
+                     dz, lddz, RS, partials, accumulate)
 #define KN_LAUNCH(TT, K)                                                                                               \
   if (split) {                                                                                                         \
-    if (split->n_items_max > 0)                                                                                        \
-    hipLaunchKernelGGL((kge_bwd_nodes_kernel<TT, K, LPR, VPL, true>), dim3(ceil_div(split->n_items_max, 4)), block, 0, \
-                       s, (const TT*)z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz,    \
-                       lddz, *split, partials, accumulate);                                                            \
+    if (split->n_items_max > 0) {                                                                                      \
+      if (rel_lds) KN_LAUNCH2(TT, K, true, true, split->n_items_max, *split);                                          \
+      else KN_LAUNCH2(TT, K, true, false, split->n_items_max, *split);                                                 \
+    }                                                                                                                  \
     if (split->n_long_max > 0)   /* (bounds cut to the table's actual counts may be zero) */                          \
     hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, K, LPR, VPL>), dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), \
                        block, 0, s, *split, (const TT*)z, ldz, l1, partials, dz, lddz, accumulate);                    \
   } else {                                                                                                             \
-    hipLaunchKernelGGL((kge_bwd_nodes_kernel<TT, K, LPR, VPL, false>), dim3(ceil_div(n_nodes, 4)), block, 0, s,        \
-                       (const TT*)z, ldz, (int)n_nodes, tr, rel_emb, ldr, gscore, l1, inc_rowptr, inc_perm, dz, lddz,  \
-                       none, partials, accumulate);                                                                    \
+    if (rel_lds) KN_LAUNCH2(TT, K, false, true, n_nodes, none);                                                        \
+    else KN_LAUNCH2(TT, K, false, false, n_nodes, none);                                                               \
   }
   BKG_PIECE_DISPATCH_(d / epl, 16, 16, {
     if (z_is_bf16) { if (kind == KN_DISTMULT) { KN_LAUNCH(__bf16, KN_DISTMULT) } else { KN_LAUNCH(__bf16, KN_TRANSE) } }
     else { if (kind == KN_DISTMULT) { KN_LAUNCH(float, KN_DISTMULT) } else { KN_LAUNCH(float, KN_TRANSE) } }
   })
 #undef KN_LAUNCH
+#undef KN_LAUNCH2
+#undef KN_GRID
   return check_launch("bkg_kge_bwd_nodes_f32");
 }

@@ -1130,7 +1130,8 @@ class _KgeScore(torch.autograd.Function):
             sp = inc.split.use() if inc.split is not None else None
             partials = sp.partials(d, z.device) if sp is not None else None
             L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), 0, z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
-                   L.ptr(rel_emb), rel_emb.stride(0), L.ptr(gscore), None, L.ptr(l1), L.ptr(inc.rowptr), L.ptr(inc.perm),
+                   L.ptr(rel_emb), rel_emb.stride(0), rel_emb.size(0), L.ptr(gscore), None, L.ptr(l1), L.ptr(inc.rowptr),
+                   L.ptr(inc.perm),
                    L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None), L.ptr(partials), 0, L.stream())
         if ctx.needs_input_grad[1]:
             drel = torch.zeros_like(rel_emb)
@@ -1317,7 +1318,8 @@ class _KgeBceLoss(torch.autograd.Function):
                 with _Timed("kge_bwd_nodes" if not ctx.padded else None,
                             2 * ei.size(1) * (d * zt.element_size() + 16 + 4) + n * (4 * d * (1 if first else 2) + 4), d=d):
                     L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]),
-                           L.ptr(et), ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), L.ptr(g), L.ptr(rec), L.ptr(l1),
+                           L.ptr(et), ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), rel_emb.size(0), L.ptr(g), L.ptr(rec),
+                           L.ptr(l1),
                            L.ptr(inc.rowptr),
                            L.ptr(inc.perm), L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None),
                            L.ptr(partials), 0 if first else 1, L.stream())

@@ -188,6 +188,8 @@ int bkg_row_l1norm_f32(const float* z, int64_t ldz, int64_t n, int32_t d, float*
 int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z /* fp32 or bf16 table */, int32_t z_is_bf16, int64_t ldz,
                           int64_t n_nodes, int32_t d, const int64_t* head,
                           const int64_t* tail, const int64_t* rel, int64_t T, const float* rel_emb, int64_t ldr,
+                          int64_t n_rel /* rows of rel_emb (relation ids < n_rel): staged in LDS when n_rel * d * 4 <= 64 KB;
+                                           0: read from the caches */,
                           const float* gscore,
                           const void* rec /* nullable int32[T][4] {head, tail, rel, bits(g)} from the fused pass: replaces
                                              head / tail / rel / gscore (one 16-byte gather per incidence) */,
