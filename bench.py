@@ -117,7 +117,8 @@ KERNEL_NAMES = {
     "gcn_propagate_views_bwd": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel: the table gradient A_hat^T dOut of the two "
                                "GGD views (bf16 dOut gathered over the out-edge CSR), d={d}",
     "kge_fused_bce": "kge_fused_bce_kernel<{t}>: DistMult scores + BCE terms + d score + d rel_emb partials, one triplet set, d={d}",
-    "kge_bwd_nodes": "kge_bwd_nodes_kernel<{t}> + fixup: dz by per-node segment reduce over the triplet incidences, d={d}",
+    "kge_bwd_nodes": "kge_incidence_streams_kernel + kge_bwd_stream_kernel<{t}> + fixup: dz by per-node segment reduce over the "
+                     "triplet incidences (their other-endpoint / relation / g streams in list order), d={d}",
 }
 
 

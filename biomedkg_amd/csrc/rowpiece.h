@@ -53,6 +53,56 @@ __device__ __forceinline__ void zero4(float4 (&acc)[N]) {
   for (int v = 0; v < N; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ---- entry batches.  An item's entry range is wave-uniform (its bounds come through readfirstlane), so when the wave
+// has one or two lane groups the indices and weights of a batch of NB consecutive entries are read with SCALAR loads
+// into SGPRs: no vector registers, no texture-addresser cycles (a wave-wide 4-byte load with two distinct addresses
+// occupies the addresser like a full one), and -- on their own counter (lgkmcnt) -- the NEXT batch's indices arrive
+// while this batch's rows are in flight.  Lane group g of the G = 64 / LPR groups takes entries g, g + G, ... of the
+// batch (a v_cndmask between two SGPRs).  With four or more groups a batch would not fit the scalar register file:
+// those widths (d <= 128 bf16 / d <= 64 fp32) keep per-lane loads.
+template <int G, int UT>
+struct EntryIdx {
+  static constexpr bool SCALAR = G <= 2;
+  int v[SCALAR ? UT * G : UT];
+  __device__ __forceinline__ void load(int e, int last, const int32_t* __restrict__ col, int grp) {
+    if constexpr (SCALAR) {
+#pragma unroll
+      for (int j = 0; j < UT * G; ++j) v[j] = col[min(e + j, last)];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UT; ++u) v[u] = col[min(e + u * G + grp, last)];
+    }
+  }
+  __device__ __forceinline__ int mine(int u, int grp) const {
+    if constexpr (!SCALAR) return v[u];
+    else if constexpr (G == 1) return v[u];
+    else return grp ? v[u * G + 1] : v[u * G];
+  }
+};
+template <int G, int UT, bool HAS_W>
+struct EntryWt {
+  static constexpr bool SCALAR = G <= 2;
+  float v[HAS_W ? (SCALAR ? UT * G : UT) : 1];
+  __device__ __forceinline__ void load(int e, int last, const float* __restrict__ w, int grp) {
+    if constexpr (HAS_W) {
+      if constexpr (SCALAR) {
+#pragma unroll
+        for (int j = 0; j < UT * G; ++j) v[j] = w[min(e + j, last)];
+      } else {
+#pragma unroll
+        for (int u = 0; u < UT; ++u) v[u] = w[min(e + u * G + grp, last)];
+      }
+    }
+  }
+  __device__ __forceinline__ float mine(int u, int grp) const {
+    if constexpr (!HAS_W) return 1.0f;
+    else if constexpr (!SCALAR || G == 1) return v[u];
+    else return grp ? v[u * G + 1] : v[u * G];
+  }
+};
+constexpr int NO_CLAMP = 0x7fffffff;
+
+
 // d -> (LPR, VPL) instantiations shared by the launchers: PIECES = d / EPL sixteen-byte pieces per row.
 // (L32, L64: lanes per row for the two widths of the d = 256 tables -- 32 bf16 pieces / 64 fp32 pieces.  The
 // segment-reduce SpMM uses one piece per lane; the KGE kernels do scalar work per triplet (score reduction, sigmoid,

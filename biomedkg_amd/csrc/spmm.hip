@@ -40,55 +40,8 @@ struct SpmmEpilogue {
   const uint32_t* epoch;    // replay epoch of a captured step (common.h with_epoch) or null
 };
 
-// ---- entry batches.  An item's entry range is wave-uniform (its bounds come through readfirstlane), so when the wave
-// has one or two lane groups the indices and weights of a batch of NB consecutive entries are read with SCALAR loads
-// into SGPRs: no vector registers, no texture-addresser cycles (a wave-wide 4-byte load with two distinct addresses
-// occupies the addresser like a full one), and -- on their own counter (lgkmcnt) -- the NEXT batch's indices arrive
-// while this batch's rows are in flight.  Lane group g of the G = 64 / LPR groups takes entries g, g + G, ... of the
-// batch (a v_cndmask between two SGPRs).  With four or more groups a batch would not fit the scalar register file:
-// those widths (d <= 128 bf16 / d <= 64 fp32) keep per-lane loads.
-template <int G, int UT>
-struct EntryIdx {
-  static constexpr bool SCALAR = G <= 2;
-  int v[SCALAR ? UT * G : UT];
-  __device__ __forceinline__ void load(int e, int last, const int32_t* __restrict__ col, int grp) {
-    if constexpr (SCALAR) {
-#pragma unroll
-      for (int j = 0; j < UT * G; ++j) v[j] = col[min(e + j, last)];
-    } else {
-#pragma unroll
-      for (int u = 0; u < UT; ++u) v[u] = col[min(e + u * G + grp, last)];
-    }
-  }
-  __device__ __forceinline__ int mine(int u, int grp) const {
-    if constexpr (!SCALAR) return v[u];
-    else if constexpr (G == 1) return v[u];
-    else return grp ? v[u * G + 1] : v[u * G];
-  }
-};
-template <int G, int UT, bool HAS_W>
-struct EntryWt {
-  static constexpr bool SCALAR = G <= 2;
-  float v[HAS_W ? (SCALAR ? UT * G : UT) : 1];
-  __device__ __forceinline__ void load(int e, int last, const float* __restrict__ w, int grp) {
-    if constexpr (HAS_W) {
-      if constexpr (SCALAR) {
-#pragma unroll
-        for (int j = 0; j < UT * G; ++j) v[j] = w[min(e + j, last)];
-      } else {
-#pragma unroll
-        for (int u = 0; u < UT; ++u) v[u] = w[min(e + u * G + grp, last)];
-      }
-    }
-  }
-  __device__ __forceinline__ float mine(int u, int grp) const {
-    if constexpr (!HAS_W) return 1.0f;
-    else if constexpr (!SCALAR || G == 1) return v[u];
-    else return grp ? v[u * G + 1] : v[u * G];
-  }
-};
-constexpr int NO_CLAMP = 0x7fffffff;
-
+// (entry batches -- EntryIdx / EntryWt, scalar loads for one or two lane groups -- live in rowpiece.h: the KGE backward's
+// stream kernel walks its incidence lists the same way)
 template <typename T, int LPR, int VPL, int UT>
 __device__ __forceinline__ void gather_rows(Piece<T> (&val)[UT][VPL], const EntryIdx<64 / LPR, UT>& idx,
                                             const T* __restrict__ x, int64_t ldx, int grp, int lig) {

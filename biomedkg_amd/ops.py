@@ -1069,6 +1069,7 @@ def grouped_linear(h, weight, group_ptr):
 
 # ----------------------------------------------------------------------------- KGE scorer
 KGE_DISTMULT, KGE_TRANSE = 0, 1
+KGE_BWD_STREAMS = __import__("os").environ.get("BKG_KGE_BWD_STREAMS", "1") != "0"
 
 
 class Incidence:
@@ -1079,7 +1080,7 @@ class Incidence:
         from .graph import _Sorter
         ei = edge_index.contiguous()
         flat = ei.view(-1)                       # == cat(head, tail)
-        sorted_keys, self.perm, self.rowptr = _Sorter.sort_rowptr(flat, None, num_nodes, 1, num_nodes + 1)
+        _, self.perm, self.rowptr = _Sorter.sort_rowptr(flat, None, num_nodes, 1, num_nodes + 1)
         from .graph import rowsplit_for
         # mini-batches (a few thousand nodes, a few 10^4 incidences): rows are short, the long-row table is 6 launches
         small = num_nodes <= 4096 and flat.numel() < (1 << 18)
@@ -1315,6 +1316,31 @@ class _KgeBceLoss(torch.autograd.Function):
                 partials = sp.partials(d, z.device) if sp is not None else None
                 # algorithmic bytes: per incidence the OTHER endpoint's row + the 16-byte record + the incidence id; per
                 # node the fp32 gradient row (read back too when accumulating the second triplet set) + its row pointer
+                stream = (KGE_BWD_STREAMS and kind == KGE_DISTMULT and sp is not None and rec is not None
+                          and (rel_emb.size(0) + 1) * d * 4 <= 65536 and n < (1 << 31))
+                if stream:
+                    # the lists' streams in list order: other endpoint and relation id once per structure (cached on it:
+                    # the positives keep theirs, fresh negatives build them with their g), g every step -- then the list
+                    # reduce runs like the SpMM's (csrc/kge_bwd_nodes.hip, "stream form")
+                    n_inc = 2 * ei.size(1)
+                    gs = torch.empty(n_inc, dtype=torch.float32, device=z.device)
+                    # (priced like the one-pass form: the streams' extra 16 bytes per incidence are this form's own traffic)
+                    with _Timed("kge_bwd_nodes" if not ctx.padded else None,
+                                2 * ei.size(1) * (d * zt.element_size() + 16 + 4) + n * (4 * d * (1 if first else 2) + 4), d=d):
+                        of = (et.data_ptr(), et._version)
+                        fresh = getattr(inc, "streams_of", None) != of
+                        if fresh:
+                            inc.other = torch.empty(n_inc, dtype=torch.int32, device=z.device)
+                            inc.relid = torch.empty(n_inc, dtype=torch.int32, device=z.device)
+                            inc.streams_of = of
+                        L.call("bkg_kge_incidence_streams", L.ptr(inc.perm), n_inc, ei.size(1), None, None, None, L.ptr(rec),
+                               None, L.ptr(inc.other) if fresh else None, L.ptr(inc.relid) if fresh else None, L.ptr(gs),
+                               L.stream())
+                        L.call("bkg_kge_bwd_stream_f32", L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(rel_emb),
+                               rel_emb.stride(0), rel_emb.size(0), L.ptr(inc.other), L.ptr(inc.relid), L.ptr(gs), L.ptr(dz),
+                               dz.stride(0), L.sref(sp.c), L.ptr(partials), 0 if first else 1, L.stream())
+                    first = False
+                    continue
                 with _Timed("kge_bwd_nodes" if not ctx.padded else None,
                             2 * ei.size(1) * (d * zt.element_size() + 16 + 4) + n * (4 * d * (1 if first else 2) + 4), d=d):
                     L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]),

@@ -196,6 +196,18 @@ int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z /* fp32 or bf16 table */, 
                           const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm,
                           float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
                           void* stream);
+/* The same DistMult backward over per-incidence STREAMS in list order (what makes it a weighted segment reduce like
+ * bkg_spmm_csr_f32: no entry id -> record -> row chain): bkg_kge_incidence_streams writes other[e] (the other endpoint),
+ * relid[e] and g[e] = d score for the 2T entries in inc_perm order (other / relid nullable: a cached structure whose g alone
+ * changes; rec: the fused pass's records instead of head / tail / rel / gscore); bkg_kge_bwd_stream_f32 then computes
+ * dz[i] (+)= sum_e g[e] rel_emb[relid[e]] (*) z[other[e]] over node i's list (split: the row table of the lists, required;
+ * the relation table, n_rel rows + a zero row for id n_rel, must fit 64 KB). */
+int bkg_kge_incidence_streams(const int32_t* perm, int64_t n_inc, int64_t T, const int64_t* head, const int64_t* tail,
+                              const int64_t* rel, const void* rec, const float* gscore, int32_t* other, int32_t* relid,
+                              float* g, void* stream);
+int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes, int32_t d, const float* rel_emb,
+                           int64_t ldr, int64_t n_rel, const int32_t* other, const int32_t* relid, const float* g, float* dz,
+                           int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate, void* stream);
 /* Fused training pass for one label (1 = positives, 0 = negatives): score[T], g[T] = (sigmoid(s) - label) *
  * inv_total, per-wave BCE-with-logits partial sums loss_part[W] and per-wave partial rows drel[W, lddr] of the
  * relation-side gradient (W = bkg_kge_fused_bce_waves(T, n_rel); relation r owns ceil(cnt_r / 64) consecutive waves;

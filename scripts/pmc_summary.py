@@ -54,7 +54,8 @@ def main(fetch_csv, write_csv, out_json, precision="fp32", bench_json=None, tcc_
                     lpr = min(pieces, 64)
                     if k2 == kind and grid == key[1] and (f", {lpr}, " in key[0] or f"Li{lpr}ELi" in key[0]):
                         tag, also = ts[0], ts      # calls that launch the same kernel over the same grid share the group
-        if "kge_bwd_nodes_kernel" in key[0] or "kge_bwd_nodes_fixup" in key[0]:
+        if any(k in key[0] for k in ("kge_bwd_nodes_kernel", "kge_bwd_nodes_fixup", "kge_bwd_stream_kernel",
+                                     "kge_incidence_streams_kernel")):
             tag = "kge_bwd_nodes"
         if "kge_fused_bce_kernel" in key[0]:
             tag = "kge_fused_bce"
