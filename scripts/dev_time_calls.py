@@ -1,5 +1,5 @@
 """Dev: every library call of one bench step timed on its own (events around the call, a sync per call), with its integer
-arguments -- which entry points carry the step, at which shapes.  usage: dev_time_calls.py [bf16|fp32]"""
+arguments -- which entry points carry the step, at which shapes.  usage: dev_time_calls.py [bf16|fp32] [fresh]"""
 import collections, sys, types
 sys.path.insert(0, ".")
 import torch
@@ -35,8 +35,13 @@ for m in (ops, __import__("biomedkg_amd.graph", fromlist=["x"]), __import__("bio
           __import__("biomedkg_amd.sampling", fromlist=["x"]), __import__("biomedkg_amd.rand", fromlist=["x"])):
     if hasattr(m, "L"):
         m.L.call = timed
+fresh = len(sys.argv) > 2 and sys.argv[2] == "fresh"      # a new edge_index per step, as bench.py's fresh-structures figure
 for rep in range(3):
     rows.clear()
+    if fresh:
+        ei = step_k.batch.edge_index.clone()
+        step_k.batch.edge_index = step_g.batch.edge_index = ei
+        step_k.batch.edge_type = step_k.batch.edge_type.clone()
     which[0] = "gcl"; step_g()
     which[0] = "kge"; step_k()
 torch.cuda.synchronize()

@@ -204,3 +204,50 @@ def test_deterministic_split_k_products_match_the_atomic_ones(precision):
     finally:
         ops.set_deterministic(False)
         ops.set_matmul_precision("fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,n,d,r,hubs", [("bf16", 5000, 256, 30, 2), ("bf16", 20000, 64, 1, 0), ("fp32", 9001, 128, 60, 1),
+                                             ("fp32", 4100, 32, 7, 3), ("bf16", 66000, 128, 2, 0)])
+def test_kge_bwd_stream_form_matches_one_pass_form(prec, n, d, r, hubs):
+    """DistMult's node-side backward (reference decoder.py:45-49 through autograd) in the stream form -- list-order
+    endpoint / relation / g streams, then a weighted segment reduce -- against the one-pass form the goldens pin: hub nodes
+    (lists cut into slices + fix-up), nodes without triplets, widths 32..256, one relation and many, both table types."""
+    from biomedkg_amd import ops
+    dev, t = "cuda", 300_001
+    old_prec, old_streams = ops.get_matmul_precision(), ops.KGE_BWD_STREAMS
+    launches = []
+    call = ops.L.call
+    try:
+        ops.set_matmul_precision(prec)
+        ops.L.call = lambda name, *a: (launches.append(name), call(name, *a))[1]
+
+        def triplets(seed):
+            g = torch.Generator(device=dev).manual_seed(seed)
+            ei = torch.randint(0, n // 2 if seed % 2 else n, (2, t), device=dev, generator=g)
+            if hubs:
+                m = torch.rand(t, device=dev, generator=g) < 0.33
+                ei[seed % 2][m] = torch.randint(0, hubs, (int(m.sum()),), device=dev, generator=g)
+            return ei, torch.randint(0, r, (t,), device=dev, generator=g)
+        (pe, pt), (ne, nt) = triplets(2), triplets(3)
+        z0, rel0 = torch.randn(n, d, device=dev) * 0.3, torch.randn(r, d, device=dev) * 0.3
+        got = []
+        for streams in (False, True):
+            ops.KGE_BWD_STREAMS = streams
+            z, rel = z0.clone().requires_grad_(), rel0.clone().requires_grad_()
+            loss = ops.kge_bce_loss(z, rel, pe.clone(), pt.clone(), ne.clone(), nt.clone(), ops.KGE_DISTMULT, reg=1e-2)[0]
+            loss.backward()
+            got.append((float(loss.detach()), z.grad.clone(), rel.grad.clone()))
+        assert launches.count("bkg_kge_bwd_stream_f32") == 2 and launches.count("bkg_kge_bwd_nodes_f32") == 2
+        (l0, gz0, gr0), (l1, gz1, gr1) = got
+        assert l0 == l1 and torch.equal(gr0, gr1)
+        assert float((gz0 - gz1).norm() / gz0.norm()) < 2e-6          # the same products, summed in another order
+        rows = torch.zeros(n, dtype=torch.bool, device=dev)
+        rows[pe.flatten()] = True
+        rows[ne.flatten()] = True
+        reg_only = 2e-2 * z0 / (n * d)                                # rows without triplets carry the L2 term alone
+        assert torch.allclose(gz1[~rows], reg_only[~rows], rtol=1e-6, atol=0)
+    finally:
+        ops.L.call = call
+        ops.KGE_BWD_STREAMS = old_streams
+        ops.set_matmul_precision(old_prec)
