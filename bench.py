@@ -705,7 +705,18 @@ def launch_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this stack
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+    out = None
+    while out is None:                              # a rank that dies early leaves the others waiting in a collective:
+        try:                                        # end them instead of waiting for the caller's own limit
+            out, _ = procs[0].communicate(timeout=2)
+        except subprocess.TimeoutExpired:
+            dead = [p.returncode for p in procs[1:] if p.poll() not in (None, 0)]
+            if dead:
+                sys.stderr.write(f"bench.py --gpus {n}: a rank exited with {dead[0]}; ending the others\n")
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                out, _ = procs[0].communicate()
     codes = [procs[0].returncode]
     deadline = time.time() + 120
     for p in procs[1:]:
@@ -749,6 +760,8 @@ def main():
         if forced:
             kw.update(rank=0, world_size=1)
         torch.distributed.init_process_group(backend, **kw)
+        if os.environ.get("BKG_BENCH_FAIL_RANK") == str(rank):      # fault injection (tests): a rank that dies after rendezvous
+            os._exit(7)
 
     from biomedkg_amd import ops
     mode = args.mode if args.mode != "auto" else ("partition" if world > 1 else "single")

@@ -303,3 +303,21 @@ def test_bench_starts_its_own_ranks():
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo"
     assert line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["parallelism"] == "np2"
+
+
+def test_bench_ends_the_job_when_a_rank_dies():
+    """A rank that dies after the rendezvous (BKG_BENCH_FAIL_RANK: fault injection) must not leave the launcher waiting on
+    rank 0's collective until the caller's own limit: the other ranks are ended and a non-zero code comes back promptly."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BKG_BENCH_ONE_DEVICE="1", BKG_BENCH_BACKEND="gloo", BKG_BENCH_FAIL_RANK="1")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert time.time() - t0 < 300
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
