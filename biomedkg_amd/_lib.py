@@ -78,7 +78,7 @@ SIGNATURES = {
     "bkg_ntxent_bf16_scale": (F32, [F32]),
     "bkg_ntxent_prepare": (I32, [P, I64, P, I64, I64, I32, I32, F32, P, P, P, P, P]),
     "bkg_ntxent_forward_workspace_floats": (I64, [I64, I32, I32]),
-    "bkg_ntxent_forward": (I32, [P, I32, I64, I32, F32, P, P, P, P, P, P]),
+    "bkg_ntxent_forward": (I32, [P, I32, I64, I32, F32, P, P, P, P, P, P, P]),
     "bkg_ntxent_backward_workspace_floats": (I64, [I64, I32, I32]),
     "bkg_ntxent_backward": (I32, [P, I32, P, P, P, P, I64, I32, F32, P, P, I64, P, I64, P]),
     "bkg_ntxent_rows_forward_workspace_floats": (I64, [I64, I64, I32, I32]),

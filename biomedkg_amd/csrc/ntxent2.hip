@@ -103,6 +103,7 @@ struct NxArgs {
   long long n_items;   // flattened (panel, j-tile) items
   float* rowseg;       // [(grid + n_panels)][PR]   row sums per (block, panel) segment, slot = block + panel
   float* colitem;      // [n_items][64]             column sums per item (diagonal-panel items: not written, not read)
+  unsigned int* ticket;  // nullable: zeroed by the forward launch for the loss reduce inside the finish launch
   // backward
   const float* rden;   // [M] 1 / D
   float* dzpart;       // [splits][M][HPAD]
@@ -232,6 +233,7 @@ __device__ __forceinline__ int nx_off16(int row, int ch) {
 // BF16: operand type; HP = padded width / 32; NW waves; BWD.
 template <bool BF16, int HP, int NW, bool BWD>
 __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
+  if (a.ticket && blockIdx.x == 0 && threadIdx.x == 0) *a.ticket = 0u;   // (forward launches; the backward leaves it NULL)
   constexpr int HPAD = 32 * HP, PR = 32 * NW, NT = 64 * NW, Q = PR / NX_BJ;
   constexpr int HS = HPAD + 4;                                   // fp32 image: padded row (floats)
   // bf16 images: the forward only reads rows (ds_read_b128): rows padded by 16 B (conflict-free, every address a lane
@@ -667,6 +669,7 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
 // column-sum butterfly over the SUM of its two blocks' tiles).
 template <int HP>
 __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
+  if (a.ticket && blockIdx.x == 0 && threadIdx.x == 0) *a.ticket = 0u;   // (forward launches; the backward leaves it NULL)
   constexpr int NW = 8, AB = 2, HPAD = 32 * HP, PR = 32 * NW * AB, Q = PR / NX_BJ;
   constexpr int ROW_BYTES = HPAD * 2, TILE_BYTES = NX_BJ * ROW_BYTES, KF = HPAD / 16;
   constexpr int NG = TILE_BYTES / 1024 / NW;                     // LDS-DMA instructions per wave and tile (4 rows of a slab each)
@@ -923,6 +926,7 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
 // column-sum buffers) is the kernel above.
 template <int HP>
 __global__ __launch_bounds__(512) void ntx2_fwd16q_kernel(NxArgs a) {
+  if (a.ticket && blockIdx.x == 0 && threadIdx.x == 0) *a.ticket = 0u;   // (forward launches; the backward leaves it NULL)
   constexpr int NW = 8, IB = 4, JB = 4, HPAD = 32 * HP, PR = 16 * IB * NW, Q = PR / NX_BJ;
   constexpr int ROW_BYTES = HPAD * 2, TILE_BYTES = NX_BJ * ROW_BYTES, KS = HPAD / 32;
   constexpr int NG = TILE_BYTES / 1024 / NW;                     // LDS-DMA instructions per wave and tile (4 rows of a slab each)
@@ -1444,28 +1448,80 @@ __global__ __launch_bounds__(256) void nx_prep_kernel(const float* __restrict__ 
 }
 
 // D_i = (row segments of i's panel, in block order) + (column items of i's j-tile, in panel order); 1/D; loss term.
-// rect (anchor subset): row segments only.
+// rect (anchor subset): row segments only.  With `loss`: the terms are added in a fixed order inside this launch -- a
+// tree per block (double), then the block that takes the last ticket adds the blocks' sums in block order and writes
+// loss = sum / n_anchor (the ticket was zeroed by the Gram launch in front; slots: one double per block).
 __global__ __launch_bounds__(256) void nx_fwd_finish_kernel(const float* __restrict__ rowseg, const float* __restrict__ colitem,
                                                             const float* __restrict__ posdot, int n_anchor, int N, int PR,
                                                             int n_panels, int n_jtiles, long long n_items, long long grid,
                                                             int rect, float inv_tau, float* __restrict__ den,
-                                                            float* __restrict__ rden, double* __restrict__ term) {
+                                                            float* __restrict__ rden, double* __restrict__ term,
+                                                            double* __restrict__ slots, unsigned int* __restrict__ ticket,
+                                                            float* __restrict__ loss) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_anchor) return;
-  const int q = PR / NX_BJ, P = i / PR, jt = i / NX_BJ;
-  float d = 0.f;
-  const long long s0 = rect ? (long long)P * n_jtiles : nx_start(P, n_jtiles, q);
-  const long long s1 = rect ? (long long)(P + 1) * n_jtiles : nx_start(P + 1, n_jtiles, q);
-  const long long b0 = nx_block_of(s0, n_items, grid), b1 = nx_block_of(s1 - 1, n_items, grid);
-  for (long long b = b0; b <= b1; ++b) d += rowseg[(size_t)(b + P) * PR + i % PR];
-  if (!rect) {
-    const int p_end = min(n_panels, jt / q);          // panels strictly left of this j-tile's own panel columns
-    for (int Pc = 0; Pc < p_end; ++Pc)
-      d += colitem[(size_t)(nx_start(Pc, n_jtiles, q) + jt - Pc * q) * NX_BJ + i % NX_BJ];
+  double t = 0.0;
+  if (i < n_anchor) {
+    const int q = PR / NX_BJ, P = i / PR, jt = i / NX_BJ;
+    const long long s0 = rect ? (long long)P * n_jtiles : nx_start(P, n_jtiles, q);
+    const long long s1 = rect ? (long long)(P + 1) * n_jtiles : nx_start(P + 1, n_jtiles, q);
+    const long long b0 = nx_block_of(s0, n_items, grid), b1 = nx_block_of(s1 - 1, n_items, grid);
+    // the same left-to-right sums as ever, the loads four ahead of the adds (a thread's chain is 20-odd dependent loads
+    // at the small sizes where this launch shows)
+    float d = 0.f;
+    const float* rs = rowseg + (size_t)(b0 + P) * PR + i % PR;
+    const int nb = (int)(b1 - b0) + 1;
+    int b = 0;
+    for (; b + 4 <= nb; b += 4) {
+      const float v0 = rs[(size_t)b * PR], v1 = rs[(size_t)(b + 1) * PR], v2 = rs[(size_t)(b + 2) * PR], v3 = rs[(size_t)(b + 3) * PR];
+      d += v0; d += v1; d += v2; d += v3;
+    }
+    for (; b < nb; ++b) d += rs[(size_t)b * PR];
+    if (!rect) {
+      const int p_end = min(n_panels, jt / q);          // panels strictly left of this j-tile's own panel columns
+      const float* ci = colitem + i % NX_BJ;
+      int Pc = 0;
+      for (; Pc + 4 <= p_end; Pc += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ci[(size_t)(nx_start(Pc + u, n_jtiles, q) + jt - (Pc + u) * q) * NX_BJ];
+        d += v[0]; d += v[1]; d += v[2]; d += v[3];
+      }
+      for (; Pc < p_end; ++Pc) d += ci[(size_t)(nx_start(Pc, n_jtiles, q) + jt - Pc * q) * NX_BJ];
+    }
+    den[i] = d;
+    if (rden) rden[i] = 1.0f / d;
+    if (term || loss) t = log((double)d) - (i < N ? 2.0 * (double)posdot[i] * (double)inv_tau : 0.0);
+    if (term) term[i] = t;
   }
-  den[i] = d;
-  if (rden) rden[i] = 1.0f / d;
-  if (term) term[i] = log((double)d) - (i < N ? 2.0 * (double)posdot[i] * (double)inv_tau : 0.0);
+  if (!loss) return;
+  __shared__ double red[256];
+  __shared__ bool last;
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    slots[blockIdx.x] = red[0];
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double acc = 0.0;                                    // thread k: blocks k, k + 256, ... in order; then the same tree
+  for (unsigned bb = threadIdx.x; bb < gridDim.x; bb += 256) acc += __builtin_nontemporal_load(slots + bb);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[0] = (float)(red[0] / (double)n_anchor);
+    *ticket = 0u;
+  }
 }
 
 // dh = ((sum_s part_s - 2 z_p(i)) * g * inv_m_tau  projected through x / |x|) for one anchor row per wave.
@@ -1666,6 +1722,7 @@ extern "C" int bkg_ntxent_prepare(const float* h1, int64_t ld1, const float* h2,
   return check_launch("bkg_ntxent_prepare");
 }
 
+static int64_t nx_loss_tail_floats(int64_t M) { return 2 * (ceil_div(M, 256) + 1) + 2; }
 static bool nx_args_ok(int64_t M, int64_t n_anchor, int32_t h, float tau) {
   return M > 0 && M % 2 == 0 && M < (1ll << 30) && h > 0 && h <= 256 && tau > 0.f && n_anchor <= M;
 }
@@ -1673,7 +1730,8 @@ static bool nx_args_ok(int64_t M, int64_t n_anchor, int32_t h, float tau) {
 extern "C" int64_t bkg_ntxent_rows_forward_workspace_floats(int64_t M, int64_t n_anchor, int32_t h, int32_t bf16) {
   if (M <= 0 || h <= 0 || h > 256 || n_anchor == 0) return -1;
   const NxShape sh = nx_shape(M, n_anchor, h, bf16 != 0, false);
-  return (int64_t)(sh.grid + sh.n_panels) * sh.pr + (n_anchor < 0 ? sh.n_items * NX_BJ : 0);
+  // + the loss reduce of the whole-problem forward: one double per finish block and the ticket (8-byte aligned tail)
+  return (int64_t)(sh.grid + sh.n_panels) * sh.pr + (n_anchor < 0 ? sh.n_items * NX_BJ + nx_loss_tail_floats(M) : 0);
 }
 extern "C" int64_t bkg_ntxent_forward_workspace_floats(int64_t M, int32_t h, int32_t bf16) {
   return bkg_ntxent_rows_forward_workspace_floats(M, -1, h, bf16);
@@ -1681,7 +1739,7 @@ extern "C" int64_t bkg_ntxent_forward_workspace_floats(int64_t M, int32_t h, int
 
 static int nx_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau, const int32_t* anchors,
                       int64_t n_anchor, const float* posdot, float* workspace, float* den, float* rden, double* term,
-                      hipStream_t s) {
+                      float* loss, hipStream_t s) {
   const NxShape sh = nx_shape(M, n_anchor, h, bf16 != 0, false);
   const bool rect = n_anchor >= 0;
   NxArgs a{};
@@ -1690,19 +1748,26 @@ static int nx_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float 
   a.anchors = anchors; a.n_anchor = (int)(rect ? n_anchor : M); a.rect = rect;
   a.rowseg = workspace;
   a.colitem = workspace + (size_t)(sh.grid + sh.n_panels) * sh.pr;
+  double* slots = nullptr;
+  if (loss) {                                         // the tail of the workspace, on an 8-byte boundary
+    uintptr_t tail = reinterpret_cast<uintptr_t>(a.colitem + (size_t)sh.n_items * NX_BJ);
+    slots = reinterpret_cast<double*>((tail + 7) & ~(uintptr_t)7);
+    a.ticket = reinterpret_cast<unsigned int*>(slots + ceil_div(M, 256));
+  }
   int rc = nx_run_fwd(bf16 != 0, sh.hp, a, sh.grid, s);
   if (rc) return rc;
   hipLaunchKernelGGL(nx_fwd_finish_kernel, dim3(ceil_div(a.n_anchor, 256)), dim3(256), 0, s, a.rowseg, a.colitem, posdot,
                      a.n_anchor, (int)(M / 2), sh.pr, sh.n_panels, sh.n_jtiles, sh.n_items, (long long)sh.grid, (int)rect,
-                     1.0f / tau, den, rden, term);
+                     1.0f / tau, den, rden, term, slots, a.ticket, loss);
   return check_launch("bkg_ntxent_forward(finish)");
 }
 
-// den[M], rden[M] = 1/D, term[M] (double) = log D_i - (i < N) * 2 z_i.z_(i+N) / tau;  loss = sum(term) / M
+// den[M], rden[M] = 1/D, term[M] (double, nullable) = log D_i - (i < N) * 2 z_i.z_(i+N) / tau, loss[1] (nullable) =
+// sum(term) / M added in a fixed order inside the finish launch
 extern "C" int bkg_ntxent_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau, const float* posdot,
-                                  float* workspace, float* den, float* rden, double* term, void* stream) {
+                                  float* workspace, float* den, float* rden, double* term, float* loss, void* stream) {
   BKG_ARG(nx_args_ok(M, M, h, tau), "bkg_ntxent_forward: bad arguments (h <= 256)");
-  return nx_forward(zn, bf16, M, h, tau, nullptr, -1, posdot, workspace, den, rden, term, (hipStream_t)stream);
+  return nx_forward(zn, bf16, M, h, tau, nullptr, -1, posdot, workspace, den, rden, term, loss, (hipStream_t)stream);
 }
 
 // den[n_anchor] = D of the anchor rows zn[anchors[a]] against ALL M rows (row-partitioned multi-GPU forward)
@@ -1710,7 +1775,8 @@ extern "C" int bkg_ntxent_rows_forward(const void* zn, int32_t bf16, int64_t M, 
                                        const int32_t* anchors, int64_t n_anchor, float* workspace, float* den,
                                        void* stream) {
   BKG_ARG(nx_args_ok(M, n_anchor, h, tau) && n_anchor > 0 && anchors, "bkg_ntxent_rows_forward: bad arguments (h <= 256)");
-  return nx_forward(zn, bf16, M, h, tau, anchors, n_anchor, nullptr, workspace, den, nullptr, nullptr, (hipStream_t)stream);
+  return nx_forward(zn, bf16, M, h, tau, anchors, n_anchor, nullptr, workspace, den, nullptr, nullptr, nullptr,
+                    (hipStream_t)stream);
 }
 
 extern "C" int64_t bkg_ntxent_rows_backward_workspace_floats(int64_t M, int64_t n_anchor, int32_t h, int32_t bf16) {

@@ -1415,7 +1415,7 @@ def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_
 # ----------------------------------------------------------------------------- NT-Xent
 class _NtXent(torch.autograd.Function):
     """GRACE loss: DualBranchContrast(InfoNCE(tau), L2L, intraview_negs=True)(h1, h2) -- reference
-    gcl_module.py:171-173,186-190.  Four launches forward (normalise, Gram tiles, fixed-order finish, sum), two
+    gcl_module.py:171-173,186-190.  Three launches forward (normalise, Gram tiles, fixed-order finish with the loss sum), two
     backward (csrc/ntxent2.hip); ``operands``: "fp32" = exact fp32 MFMA, "bf16" = bf16 MFMA operands with fp32
     exp / sums (the matmul precision mode picks it)."""
 
@@ -1434,12 +1434,12 @@ class _NtXent(torch.autograd.Function):
                L.ptr(norm), L.ptr(posdot), L.stream())
         ws = torch.empty(L.lib().bkg_ntxent_forward_workspace_floats(m, h, bf16), dtype=torch.float32, device=dev)
         den = torch.empty(2, m, dtype=torch.float32, device=dev)          # D and 1 / D
-        term = torch.empty(m, dtype=torch.float64, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)             # sum(term) / m, added inside the finish launch
         L.call("bkg_ntxent_forward", L.ptr(zn16 if bf16 else zn), bf16, m, h, tau, L.ptr(posdot), L.ptr(ws), L.ptr(den[0]),
-               L.ptr(den[1]), L.ptr(term), L.stream())
+               L.ptr(den[1]), None, L.ptr(loss), L.stream())
         ctx.tau, ctx.n, ctx.h, ctx.bf16 = tau, n, h, bf16
         ctx.save_for_backward(zn, zn16, norm, den)
-        return (term.sum() / m).float()
+        return loss.view(())
 
     @staticmethod
     def backward(ctx, g):

@@ -258,8 +258,9 @@ int bkg_kge_bwd_rel_f32(int32_t kind, const float* z, int64_t ldz, int32_t d, co
  *        images, the row norms [2N] and the positive-pair dots [N].
  *      bkg_ntxent_forward: D over the Gram tiles on the matrix cores (bf16 = 0: exact fp32 MFMA on the fp32 image;
  *        1: bf16 operands from the bf16 image, fp32 exp / sums), using the symmetry of the Gram (upper-triangular
- *        tiles, row + column sums, fixed-order reduction: bitwise repeatable).  Outputs den[M], rden[M] = 1/D and
- *        term[M] (double) = log D_i - (i < N) 2 z_i.z_(i+N)/tau, so that loss = sum(term) / M.
+ *        tiles, row + column sums, fixed-order reduction: bitwise repeatable).  Outputs den[M], rden[M] = 1/D,
+ *        term[M] (double, nullable) = log D_i - (i < N) 2 z_i.z_(i+N)/tau and loss[1] (nullable) = sum(term) / M, the
+ *        terms added in double in a fixed order inside the last launch (no reduction left to the caller).
  *      bkg_ntxent_backward: dL/dh1, dL/dh2 [N, h] (times the upstream scalar *gout, a DEVICE float), tiles recomputed.
  *      Workspaces (floats) by the *_workspace_floats queries; every function is stream-ordered, no host sync. */
 int32_t bkg_ntxent_hpad(int32_t h, int32_t bf16);
@@ -270,7 +271,7 @@ int bkg_ntxent_prepare(const float* h1, int64_t ld1, const float* h2, int64_t ld
                        float tau, float* zn, void* zn_bf16, float* norm, float* posdot, void* stream);
 int64_t bkg_ntxent_forward_workspace_floats(int64_t M, int32_t h, int32_t bf16);
 int bkg_ntxent_forward(const void* zn, int32_t bf16, int64_t M, int32_t h, float tau, const float* posdot,
-                       float* workspace, float* den, float* rden, double* term, void* stream);
+                       float* workspace, float* den, float* rden, double* term, float* loss, void* stream);
 int64_t bkg_ntxent_backward_workspace_floats(int64_t M, int32_t h, int32_t bf16);
 int bkg_ntxent_backward(const void* zn, int32_t bf16, const float* zn_f32, const float* norm, const float* rden,
                         const float* gout, int64_t M, int32_t h, float tau, float* workspace, float* dh1, int64_t ld1,
