@@ -38,7 +38,29 @@ struct SpmmEpilogue {
   uint32_t stream_id;
   int out_bf16;             // 1: `out` is a bf16 [n_rows, ldo] table (a result only GEMMs / gathers read)
   const uint32_t* epoch;    // replay epoch of a captured step (common.h with_epoch) or null
+  // column halves (bkg_spmm_csr_f32 col_halves = 2): the launch runs TWO problems of half the width side by side, the
+  // blocks of XCDs 0-3 (blockIdx % 8 < 4: workgroups go round-robin over the eight XCDs) on columns [0, d), those of XCDs
+  // 4-7 on [d, 2 d) -- an L2 then holds 512-byte pieces of HALF the table's rows' bytes instead of whole 1 KB rows.
+  // col0: first column of this block's half (set in the kernel); d_full: the row width the dropout mask is indexed by
+  // (0: the kernel's own d); part_stride: floats between the two halves' partial-slot buffers
+  int halves, col0, d_full;
+  int64_t part_stride;
 };
+
+// block id inside its half; `half` (0 / 1) tells the kernel which columns and which partial-slot buffer are its own
+// (halves == 1: the block id itself, half 0)
+template <int D>
+__device__ __forceinline__ unsigned spmm_half_of(SpmmEpilogue& ep, unsigned& half) {
+  unsigned bid = blockIdx.x;
+  half = 0u;
+  if (ep.halves > 1) {                                  // 2 or 4 column parts: 4 or 2 XCDs each
+    const unsigned xcd = bid & 7u, per = 8u / (unsigned)ep.halves;
+    half = xcd / per;
+    bid = (bid >> 3) * per + xcd % per;
+    ep.col0 = (int)half * D;
+  }
+  return bid;
+}
 
 // (entry batches -- EntryIdx / EntryWt, scalar loads for one or two lane groups -- live in rowpiece.h: the KGE backward's
 // stream kernel walks its incidence lists the same way)
@@ -152,12 +174,13 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
   }
   const float scale = (ep.keep || ep.drop_p > 0.f) ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
   const uint32_t thresh = (uint32_t)fminf(ep.drop_p * 4294967296.0f, 4294967295.0f);
+  const int64_t dm = ep.d_full ? ep.d_full : d;                   // row width of the dropout mask
   uint2 lo = make_uint2(0u, 0u);
 #pragma unroll
   for (int v = 0; v < VPL; ++v)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const int c = EPL * (lig + v * LPR) + 4 * q;
+      const int c = EPL * (lig + v * LPR) + 4 * q + ep.col0;      // the column in out / addend / bias / the mask
       float4 a = acc[v * Q + q];
       if (ep.addend) {
         if (ep.add_bf16) {
@@ -177,11 +200,11 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
         a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
       }
       if (ep.keep) {
-        const uchar4 k = *reinterpret_cast<const uchar4*>(ep.keep + (int64_t)row * d + c);
+        const uchar4 k = *reinterpret_cast<const uchar4*>(ep.keep + (int64_t)row * dm + c);
         a.x = k.x ? a.x * scale : 0.f; a.y = k.y ? a.y * scale : 0.f;
         a.z = k.z ? a.z * scale : 0.f; a.w = k.w ? a.w * scale : 0.f;
       } else if (ep.drop_p > 0.f) {
-        const uint4 r = philox_keep4(ep.seed, (uint64_t)row * d + c, with_epoch(ep.stream_id, ep.epoch));
+        const uint4 r = philox_keep4(ep.seed, (uint64_t)row * dm + c, with_epoch(ep.stream_id, ep.epoch));
         a.x = r.x >= thresh ? a.x * scale : 0.f; a.y = r.y >= thresh ? a.y * scale : 0.f;
         a.z = r.z >= thresh ? a.z * scale : 0.f; a.w = r.w >= thresh ? a.w * scale : 0.f;
       }
@@ -271,7 +294,10 @@ __global__ __launch_bounds__(256) void spmm_items_kernel(bkg_rowsplit rs, const 
                                                          int64_t ldx, float* __restrict__ out, int64_t ldo,
                                                          float* __restrict__ partials, SpmmEpilogue ep) {
   constexpr int Q = Piece<T>::Q, EPL = Piece<T>::EPL;
-  const int bi = blockIdx.x;
+  unsigned half;
+  const int bi = (int)spmm_half_of<EPL * LPR * VPL>(ep, half);
+  x += half * (EPL * LPR * VPL);
+  partials += half * ep.part_stride;
   const int lane = threadIdx.x & 63;
   int item = bi * 4 + (threadIdx.x >> 6);
   if (item >= rs.totals[0]) return;
@@ -308,15 +334,19 @@ template <typename T, int LPR, int VPL, int LS, int VS>
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(bkg_rowsplit rs, const float* __restrict__ w,
                                                          const T* __restrict__ x, int64_t ldx,
                                                          float* __restrict__ out, int64_t ldo,
-                                                         const float* __restrict__ partials, SpmmEpilogue ep) {
+                                                         float* __restrict__ partials, SpmmEpilogue ep) {
   constexpr int G = 64 / LPR, NG = 4 * G, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, d = EPL * LPR * VPL;
   __shared__ __attribute__((aligned(16))) float red[NG * d];
-  if (blockIdx.x >= (unsigned)rs.n_long_max) {      // block-uniform
-    const int i = ((int)blockIdx.x - (int)rs.n_long_max) * (256 / LS) + (int)threadIdx.x / LS;
+  unsigned half;
+  const unsigned bid = spmm_half_of<d>(ep, half);
+  x += half * d;
+  partials += half * ep.part_stride;
+  if (bid >= (unsigned)rs.n_long_max) {      // block-uniform
+    const int i = ((int)bid - (int)rs.n_long_max) * (256 / LS) + (int)threadIdx.x / LS;
     spmm_short_rows<T, LS, VS>(i, rs.totals[3], rs.short_desc, rs.short_col, w, x, ldx, out, ldo, ep, (int)threadIdx.x % LS);
     return;
   }
-  const int l = blockIdx.x;
+  const int l = bid;
   if (l >= rs.totals[2]) return;    // block-uniform
   const int lane = threadIdx.x & 63, lig = lane % LPR, gi = (threadIdx.x >> 6) * G + lane / LPR;
   const int row = rs.long_row[l], s0 = rs.long_slot0[l], n = rs.long_cnt[l];
@@ -408,13 +438,15 @@ static void launch_spmm(const SpmmArgs<T>& a) {
   if (a.split) {
     using SS = ShortShape<LPR, VPL>;
     static_assert(SS::LS * SS::VS == LPR * VPL && 64 % SS::LS == 0, "short-row shape");
+    // column halves: two problems per launch, four blocks of each per group of eight (spmm_half_of)
+    auto grid_of = [&](int64_t nb) { return (unsigned)(a.ep.halves > 1 ? ceil_div(nb, 8 / a.ep.halves) * 8 : nb); };
     const int nb_items = ceil_div(a.split->n_items_max, 4);
     const int64_t nb_short = a.split->short_desc ? ceil_div(a.split->n_short_max, 256 / SS::LS) : 0;
     if (nb_items > 0)
-      hipLaunchKernelGGL((spmm_items_kernel<T, LPR, VPL>), dim3(nb_items), dim3(256), 0, a.s, *a.split, a.col, a.w, a.x,
-                         a.ldx, a.out, a.ldo, a.partials, a.ep);
+      hipLaunchKernelGGL((spmm_items_kernel<T, LPR, VPL>), dim3(grid_of(nb_items)), dim3(256), 0, a.s, *a.split, a.col, a.w,
+                         a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
     if (a.split->n_long_max + nb_short > 0)
-      hipLaunchKernelGGL((spmm_fixup_kernel<T, LPR, VPL, SS::LS, SS::VS>), dim3((unsigned)(a.split->n_long_max + nb_short)),
+      hipLaunchKernelGGL((spmm_fixup_kernel<T, LPR, VPL, SS::LS, SS::VS>), dim3(grid_of(a.split->n_long_max + nb_short)),
                          dim3(256), 0, a.s, *a.split, a.w, a.x, a.ldx, a.out, a.ldo, a.partials, a.ep);
   } else {
     hipLaunchKernelGGL((spmm_csr_kernel<T, LPR, VPL>), dim3(ceil_div(a.n_rows, 4)), dim3(256), 0, a.s, a.rowptr, a.col,
@@ -447,15 +479,24 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
                                 int64_t n_rows, int32_t d, const float* self_w, const void* addend, int32_t addend_is_bf16,
                                 int64_t ld_add, const float* bias,
                                 int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
-                                uint32_t stream_id, const bkg_rowsplit* split, float* partials, void* stream) {
+                                uint32_t stream_id, const bkg_rowsplit* split, float* partials, int32_t col_halves,
+                                void* stream) {
   using namespace bkg;
   BKG_ARG(n_rows >= 0 && d > 0, "bkg_spmm_csr_f32: bad shape");
+  BKG_ARG(col_halves == 1 || ((col_halves == 2 || col_halves == 4) && split && x_is_bf16 && d % (8 * col_halves) == 0),
+          "bkg_spmm_csr_f32: col_halves = 2 | 4 needs a row table, a bf16 table and d % (8 col_halves) == 0");
   BKG_ARG(drop_p >= 0.f && drop_p < 1.f, "bkg_spmm_csr_f32: drop_p must be in [0,1)");
   BKG_ARG(!split || partials, "bkg_spmm_csr_f32: row splitting needs a partials buffer");
   if (n_rows == 0) return 0;
   float* out = reinterpret_cast<float*>(out_);
   SpmmEpilogue ep{self_w, bias, reinterpret_cast<const float*>(addend), ld_add, addend_is_bf16 ? 1 : 0, relu, keep, drop_p, seed,
-                  stream_id, out_is_bf16 ? 1 : 0, rng_epoch_ptr()};
+                  stream_id, out_is_bf16 ? 1 : 0, rng_epoch_ptr(), 1, 0, 0, 0};
+  if (col_halves > 1) {            // the kernels run at a part's width; the mask keeps the whole row's indexing
+    ep.halves = col_halves;
+    ep.d_full = d;
+    d /= col_halves;
+    ep.part_stride = (int64_t)split->n_slots_max * d;
+  }
   const int epl = x_is_bf16 ? 8 : 4;
   const bool vec_ok = (d % epl == 0) && (ldx % epl == 0) && (ldo % 4 == 0) && (((uintptr_t)x | (uintptr_t)out) % 16 == 0) &&
                       (!bias || ((uintptr_t)bias % 16 == 0)) && (!keep || ((uintptr_t)keep % 4 == 0)) &&

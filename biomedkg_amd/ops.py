@@ -418,7 +418,11 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
             addend = addend.float()
     if split is not None:
         split.use()
-    if split is not None and split.pack and d // (8 if is_bf16 else 4) >= 64 and split.exact:
+    # two-view tables (1 KB rows): the launch runs the two 256-column halves as two problems, each on four of the eight
+    # XCDs -- an L2 caches 512-byte pieces of half the table's bytes (csrc/spmm.hip, col_halves)
+    halves = 2 if (SPMM_COL_HALVES and is_bf16 and d == 512 and split is not None and split.pack and n_rows >= 4096
+                   and x.stride(0) % 8 == 0) else 1
+    if split is not None and split.pack and (d // halves) // (8 if is_bf16 else 4) >= 64 and split.exact:
         split = split.plain()          # wide rows: one wave per row already (RowSplit.plain)
     timing = KERNEL_TIMERS is not None and tag is not None
     if timing:
@@ -429,19 +433,29 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
            int(out_dtype == torch.bfloat16), out.stride(0), n_rows, d, L.ptr(self_w), L.ptr(addend),
            int(addend is not None and addend.dtype == torch.bfloat16), addend.stride(0) if addend is not None else 0,
            L.ptr(bias), int(relu), L.ptr(keep), p, seed, sid, L.sref(split.c if split is not None else None),
-           L.ptr(partials), L.stream())
+           L.ptr(partials), halves, L.stream())
     if timing:
         ev1.record()
         rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None,
                                                                              2 if is_bf16 else 4, out.element_size()),
-                                             "d": d,       # rocprofv3's Grid_Size of the two launches (threads)
-                                             "grid": ((split.n_items_max if split is not None else n_rows) + 3) // 4 * 256,
-                                             "grid2": _spmm_second_grid(split, d, is_bf16)})
+                                             "d": d, "col_halves": halves,
+                                             # rocprofv3's Grid_Size of the two launches (threads)
+                                             "grid": _spmm_grid(((split.n_items_max if split is not None else n_rows) + 3) // 4,
+                                                                halves),
+                                             "grid2": _spmm_second_grid(split, d // halves, is_bf16, halves)})
         rec["events"].append((ev0, ev1))
     return out
 
 
-def _spmm_second_grid(split, d, is_bf16):
+SPMM_COL_HALVES = __import__("os").environ.get("BKG_SPMM_COL_HALVES", "1") != "0"
+
+
+def _spmm_grid(blocks, halves):
+    """Threads of a launch of ``blocks`` workgroups (column halves: two problems, four blocks of each per group of eight)."""
+    return ((blocks + 3) // 4 * 8 if halves == 2 else blocks) * 256
+
+
+def _spmm_second_grid(split, d, is_bf16, halves=1):
     """Grid_Size (threads) of bkg_spmm_csr_f32's second launch -- long-row fix-up blocks + short-row blocks
     (csrc/spmm.hip launch_spmm / ShortShape) -- so that a PMC pass can be attributed to the tagged call."""
     if split is None:
@@ -451,7 +465,7 @@ def _spmm_second_grid(split, d, is_bf16):
     c = pieces // 2
     ls = c if (pieces % 2 == 0 and 4 <= c <= 64 and 64 % c == 0) else lpr
     short_blocks = (split.n_short_max + 256 // ls - 1) // (256 // ls) if split.pack else 0
-    return (split.n_long_max + short_blocks) * 256
+    return _spmm_grid(split.n_long_max + short_blocks, halves)
 
 
 def _table(x):

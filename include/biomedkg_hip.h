@@ -127,7 +127,11 @@ int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, 
                      int32_t out_is_bf16, int64_t ldo, int64_t n_rows, int32_t d, const float* self_w,
                      const void* addend /* fp32, or bf16 when addend_is_bf16: RGCNConv's root term */, int32_t addend_is_bf16,
                      int64_t ld_add, const float* bias, int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
-                     uint32_t stream_id, const bkg_rowsplit* split, float* partials, void* stream);
+                     uint32_t stream_id, const bkg_rowsplit* split, float* partials,
+                     int32_t col_halves /* 1; 2 (bf16 table, split given, d % 16 == 0): the launch runs the two d / 2-column
+                                           halves as two problems, each on four of the eight XCDs (an L2 then caches pieces
+                                           of half the table's bytes); same sums per column, same dropout mask */,
+                     void* stream);
 
 /* ---- exact-fp32 MFMA GEMM: C = epi(alpha op(A) op(B)), epi = (+bias[col]) -> act (0 none, 1 relu, 2 elu) ->
  *      (* gate>0 ? gate_scale : 0) -> (+ beta C).  Replaces torch Linear inside GCNConv.lin, the GRACE/GGD/DGI heads
