@@ -483,8 +483,8 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
                                 void* stream) {
   using namespace bkg;
   BKG_ARG(n_rows >= 0 && d > 0, "bkg_spmm_csr_f32: bad shape");
-  BKG_ARG(col_halves == 1 || ((col_halves == 2 || col_halves == 4) && split && x_is_bf16 && d % (8 * col_halves) == 0),
-          "bkg_spmm_csr_f32: col_halves = 2 | 4 needs a row table, a bf16 table and d % (8 col_halves) == 0");
+  BKG_ARG(col_halves == 1 || ((col_halves == 2 || col_halves == 4) && split && d % (8 * col_halves) == 0),
+          "bkg_spmm_csr_f32: col_halves = 2 | 4 needs a row table and d % (8 col_halves) == 0");
   BKG_ARG(drop_p >= 0.f && drop_p < 1.f, "bkg_spmm_csr_f32: drop_p must be in [0,1)");
   BKG_ARG(!split || partials, "bkg_spmm_csr_f32: row splitting needs a partials buffer");
   if (n_rows == 0) return 0;

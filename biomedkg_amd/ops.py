@@ -418,10 +418,16 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
             addend = addend.float()
     if split is not None:
         split.use()
-    # two-view tables (1 KB rows): the launch runs the two 256-column halves as two problems, each on four of the eight
-    # XCDs -- an L2 caches 512-byte pieces of half the table's bytes (csrc/spmm.hip, col_halves)
-    halves = 2 if (SPMM_COL_HALVES and is_bf16 and d == 512 and split is not None and split.pack and n_rows >= 4096
-                   and x.stride(0) % 8 == 0) else 1
+    # rows of 1 KB (the two-view bf16 tables, the exact mode's fp32 tables) or 2 KB: the launch runs the row's 512-byte column
+    # parts as two / four problems, each on four / two of the eight XCDs -- an L2 then caches pieces of a half / a quarter of
+    # the table's bytes (csrc/spmm.hip, col_halves; measured on the bench graph: bf16 d = 512 352 -> 310 us, fp32 d = 512
+    # 805 -> 588; 512-byte rows gain nothing from 256-byte parts)
+    halves = 1
+    if SPMM_COL_HALVES and split is not None and split.pack and n_rows >= 4096:
+        row_bytes = d * x.element_size()
+        halves = 4 if row_bytes >= 2048 else (2 if row_bytes >= 1024 else 1)
+        if halves > 1 and (d % (8 * halves) or (d // halves) // (8 if is_bf16 else 4) not in (4, 8, 16, 32, 64)):
+            halves = 1
     if split is not None and split.pack and (d // halves) // (8 if is_bf16 else 4) >= 64 and split.exact:
         split = split.plain()          # wide rows: one wave per row already (RowSplit.plain)
     timing = KERNEL_TIMERS is not None and tag is not None

@@ -61,3 +61,17 @@ def call2(halves):
 a1 = t(lambda: call2(1)); r2 = out2.clone()
 a2 = t(lambda: call2(2))
 print("d = 256: one launch", round(a1, 1), "us; halves by XCD", round(a2, 1), "us; max diff", float((r2.float() - out2.float()).abs().max()))
+
+xf = x.float()
+outf = torch.empty(n, 512, device=dev)
+def callf(halves):
+    sp = c.split
+    if 512 // halves // 4 >= 64 and sp.exact and sp.pack:
+        sp = sp.plain()
+    partials = sp.partials(512, dev)
+    L.call("bkg_spmm_csr_f32", L.ptr(c.rowptr), L.ptr(c.col), L.ptr(gw.w_dst), L.ptr(xf), 0, xf.stride(0), L.ptr(outf), 0, outf.stride(0),
+           n, 512, L.ptr(gw.self_w), None, 0, 0, None, 0, None, 0.0, 0, 0, L.sref(sp.c), L.ptr(partials), halves, L.stream())
+f1 = t(lambda: callf(1)); rf = outf.clone()
+f2 = t(lambda: callf(2)); d2 = float((rf - outf).abs().max())
+f4 = t(lambda: callf(4)); d4 = float((rf - outf).abs().max())
+print("fp32 d = 512: one launch", round(f1, 1), "us; halves", round(f2, 1), "us; quarters", round(f4, 1), "us; max diff", d2, d4)
