@@ -457,8 +457,9 @@ SPMM_COL_HALVES = __import__("os").environ.get("BKG_SPMM_COL_HALVES", "1") != "0
 
 
 def _spmm_grid(blocks, halves):
-    """Threads of a launch of ``blocks`` workgroups (column halves: two problems, four blocks of each per group of eight)."""
-    return ((blocks + 3) // 4 * 8 if halves == 2 else blocks) * 256
+    """Threads of a launch of ``blocks`` workgroups (column parts: 2 | 4 problems, 4 | 2 blocks of each per group of eight)."""
+    per = 8 // halves
+    return ((blocks + per - 1) // per * 8 if halves > 1 else blocks) * 256
 
 
 def _spmm_second_grid(split, d, is_bf16, halves=1):
