@@ -921,6 +921,24 @@ def main():
         finally:
             ops.rowsum_linear_ok = ok_fn
 
+    ms_shuffled_types = None
+    if world == 1 and mode == "single" and not args.no_extras:
+        # the same step with the negatives' relation ids in the reference's literal form, repeat(..)[randperm(..)], instead
+        # of grouped by relation (biomedkg_amd/ops.py grouped_types: the same distribution of typed negatives)
+        from biomedkg_amd import kge_module as _km
+        was = _km.GROUPED_NEG_TYPES
+        _km.GROUPED_NEG_TYPES = False
+        try:
+            for _ in range(2):
+                step_g(); step_k()
+            sync(); t1 = time.perf_counter()
+            for _ in range(5):
+                step_g(); step_k()
+            sync()
+            ms_shuffled_types = (time.perf_counter() - t1) / 5 * 1e3
+        finally:
+            _km.GROUPED_NEG_TYPES = was
+
     ms_fp32 = None
     if world == 1 and not args.no_extras and args.precision == "bf16":
         ops.set_matmul_precision("fp32")                # the exact parity mode on the same modules / graph
@@ -973,7 +991,7 @@ def main():
             "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_max": per_step[-1],
             "ms_per_step_slowest_index": per_step_raw.index(per_step[-1]),
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
-            "ms_per_step_linear_ggd_head": ms_linear_head,
+            "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_shuffled_neg_types": ms_shuffled_types,
             "ms_per_step_fresh_structures": ms_fresh,
             "roofline": roof, "kernels": others, "exchange": exchange,
             "cpu_baseline": None,

@@ -16,6 +16,10 @@ from .factory import FusionFactory, KGEModelFactory
 from .gcl_module import _get_scheduler
 from .utils.metrics import AUROC, AveragePrecision, BootStrapper, EdgeWisePrecision, F1Score, MetricCollection
 
+# negatives' relation ids grouped by relation instead of shuffled (ops.grouped_types: the same distribution of typed
+# negatives, no permutation launch and no sort per step); 0: the reference's literal repeat(..)[randperm(..)]
+GROUPED_NEG_TYPES = __import__("os").environ.get("BKG_GROUPED_NEG_TYPES", "1") != "0"
+
 
 class KGEModule(LightningModule):
     def __init__(self, encoder_name: str, decoder_name: str, in_dim: int, hidden_dim: int, out_dim: int,
@@ -55,7 +59,13 @@ class KGEModule(LightningModule):
         num_neg_samples = self.neg_ratio * edge_index.size(-1) if self.neg_ratio else None
         neg_edge_index = r.neg_edges(edge_index, num_neg_samples)
         if self.neg_ratio:
-            neg_edge_type = r.shuffle(edge_type.repeat(self.neg_ratio))   # == repeat(..)[randperm(..)]
+            neg_edge_type = None
+            rel = getattr(getattr(self.model, "decoder", None), "rel_emb", None)
+            if GROUPED_NEG_TYPES and rel is not None and hasattr(r, "grouped_types"):
+                # device randomness: the same multiset of ids in relation order -- a uniformly random pairing all the same
+                neg_edge_type = r.grouped_types(edge_type, self.neg_ratio, rel.size(0))
+            if neg_edge_type is None:
+                neg_edge_type = r.shuffle(edge_type.repeat(self.neg_ratio))   # == repeat(..)[randperm(..)]
         else:
             neg_edge_type = edge_type
         return neg_edge_index, neg_edge_type

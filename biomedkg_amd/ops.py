@@ -1123,6 +1123,30 @@ def relation_order_of(edge_type, num_relations):
     return _cached(edge_type, "rel_order", (int(num_relations),), build)
 
 
+def grouped_types(edge_type, repeat, num_relations):
+    """``edge_type.repeat(repeat)[randperm(...)]`` (reference kge_module.py:97-100) delivered GROUPED BY RELATION: the
+    multiset of the positives' relation ids, ``repeat`` times, in relation order.  The negatives it is paired with come out of
+    the sampler in exchangeable order (the first K survivors of a keyed random permutation of the candidate range,
+    sampling.negative_sampling), so ANY fixed arrangement of the ids is a uniformly random pairing -- the set of typed
+    negatives has the reference's distribution -- and this one is the arrangement the fused scorer wants: its relation
+    order is the identity (no permutation launch, no sort, head / tail ids read in place).  Cached on ``edge_type``
+    together with its own relation order."""
+    from .graph import _cached
+    t = edge_type.numel() * int(repeat)
+    if edge_type.dim() != 1 or edge_type.dtype != torch.int64 or not edge_type.is_cuda or t == 0 or t >= (1 << 31):
+        return None
+
+    def build():
+        _, rel_ptr = relation_order_of(edge_type, num_relations)
+        cnt = (rel_ptr[1:] - rel_ptr[:-1]).long() * int(repeat)
+        types = torch.repeat_interleave(torch.arange(num_relations, dtype=torch.int64, device=edge_type.device), cnt,
+                                        output_size=t)
+        ptr = (rel_ptr.long() * int(repeat)).to(torch.int32)
+        types._bkg_cache = {"rel_order": ((types._version, int(num_relations)), (_iota32(t, edge_type.device), ptr))}
+        return types
+    return _cached(edge_type, "grouped_types", (int(repeat), int(num_relations)), build)
+
+
 class _KgeScore(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, rel_emb, edge_index, edge_type, kind):

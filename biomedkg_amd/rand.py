@@ -81,6 +81,14 @@ class DeviceRand:
         L.call("bkg_permute_gather_i64", L.ptr(src), src.numel(), self._draw_seed(), L.ptr(out), L.stream())
         return out
 
+    def grouped_types(self, edge_type, repeat, num_relations):
+        """The relation ids of ``repeat`` negatives per positive, grouped by relation (``ops.grouped_types``: a uniformly
+        random pairing with this provider's negatives, whose order is exchangeable); None where that form does not
+        apply.  Takes the draw ``shuffle`` would have taken, so the streams behind it do not move."""
+        from . import ops
+        self._draw_seed()
+        return ops.grouped_types(edge_type, repeat, num_relations)
+
     def neg_edges(self, edge_index, num_neg_samples):
         from .sampling import negative_sampling
         return negative_sampling(edge_index, num_neg_samples=num_neg_samples, seed=self._draw_seed())

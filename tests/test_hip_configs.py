@@ -190,6 +190,10 @@ def test_c3_as_timed_bf16_path_against_fp64_with_the_same_rounding_points():
             drawn["neg_type"] = super().shuffle(src)
             return drawn["neg_type"]
 
+        def grouped_types(self, edge_type, repeat, num_relations):     # (the form the timed step takes)
+            drawn["neg_type"] = super().grouped_types(edge_type, repeat, num_relations)
+            return drawn["neg_type"]
+
     ops.set_matmul_precision("bf16")
     try:
         got = {}

@@ -147,6 +147,65 @@ def test_kge_module_uses_device_sampler():
     assert torch.isfinite(loss)
 
 
+def test_grouped_negative_types_are_the_same_typed_negatives():
+    """The negatives' relation ids grouped by relation (ops.grouped_types) instead of ``repeat(k)[randperm]`` (reference
+    kge_module.py:97-100): the same multiset of ids; its own relation order is the identity with the positives' counts
+    times k; the fused step over it equals the unfused decode + BCE route over the SAME tensors; the pairing with the
+    sampler's negatives is uniform -- here: over many draws every (cell, relation) combination of a small graph turns up
+    with the frequency the independent shuffle gives it; and the literal form is still there behind the flag."""
+    from types import SimpleNamespace
+    from biomedkg_amd import kge_module as KM, ops, rand as R, synthetic
+    g = synthetic.primekg_like(3000, 40_000, 8, seed=1)
+    ei, et = g["edge_index"].to(DEV), g["edge_type"].to(DEV)
+    m = KM.KGEModule("rgcn", "dismult", 32, 32, 32, 2, 8, 1, "cosine", 1e-3, 0.1, "none", 3, "random").to(DEV)
+    with R.use(R.DeviceRand(seed=2)):
+        nei, net = m.sample_neg_edges(ei, et)
+    assert torch.equal(net, torch.sort(et.repeat(3)).values)
+    order, ptr = ops.relation_order_of(net, 8)
+    assert torch.equal(order.long(), torch.arange(net.numel(), device=DEV))
+    assert torch.equal(ptr.long(), torch.cat([torch.zeros(1, dtype=torch.long, device=DEV),
+                                              torch.cumsum(3 * torch.bincount(et, minlength=8), 0)]))
+    with R.use(R.DeviceRand(seed=2)):
+        nei2, net2 = m.sample_neg_edges(ei, et)
+    assert net2 is net and torch.equal(nei2, nei)            # cached on the positives' ids; the sampler's draw did not move
+    # fused route == unfused route on these tensors
+    z = torch.randn(3000, 32, device=DEV)
+    rel = m.model.decoder.rel_emb.detach()
+    loss, pp, npred = ops.kge_bce_loss(z, rel, ei, et, nei, net, ops.KGE_DISTMULT, reg=0.0)
+    sp = (z[ei[0]] * rel[et] * z[ei[1]]).sum(1)
+    sn = (z[nei[0]] * rel[net] * z[nei[1]]).sum(1)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(torch.cat([sp, sn]), torch.cat([torch.ones_like(sp), torch.zeros_like(sn)]))
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert torch.allclose(npred, sn, rtol=1e-4, atol=1e-5)
+    # the literal form behind the flag
+    was = KM.GROUPED_NEG_TYPES
+    KM.GROUPED_NEG_TYPES = False
+    try:
+        with R.use(R.DeviceRand(seed=2)):
+            _, net3 = m.sample_neg_edges(ei, et)
+    finally:
+        KM.GROUPED_NEG_TYPES = was
+    assert not torch.equal(net3, net) and torch.equal(torch.sort(net3).values, net)
+    # uniform pairing: ids 0..9, two relations with 3 + 6 positives; negatives of relation 0 must be spread over the free
+    # cells like those of relation 1 (a position-dependent sampler would put relation 0 -- always first -- on fixed cells)
+    n = 12
+    pe = torch.tensor([[0, 1, 2, 3, 4, 5, 6, 7, 8], [1, 2, 3, 4, 5, 6, 7, 8, 9]], device=DEV)
+    pt = torch.tensor([0, 0, 0, 1, 1, 1, 1, 1, 1], device=DEV)
+    hits = torch.zeros(2, n * n, dtype=torch.float64, device=DEV)
+    draws = 3000
+    with R.use(R.DeviceRand(seed=5)):
+        m2 = KM.KGEModule("rgcn", "dismult", 8, 8, 8, 2, 2, 1, "cosine", 1e-3, 0.1, "none", 1, "random").to(DEV)
+        for _ in range(draws):
+            a, b = m2.sample_neg_edges(pe, pt)
+            hits.view(-1).index_add_(0, b * (n * n) + a[0] * n + a[1], torch.ones(a.size(1), dtype=torch.float64, device=DEV))
+    free = hits.sum(0) > 0
+    assert int(free.sum()) == 10 * 9 - 9                      # N is inferred as max id + 1 = 10 (PyG), minus the positives
+    for r, cnt in ((0, 3), (1, 6)):
+        p = hits[r][free] / (draws * cnt)                       # probability of a free cell for one negative of relation r
+        want = 1.0 / int(free.sum())
+        assert float((p - want).abs().max()) < 6 * (want / (draws * cnt)) ** 0.5 + 1e-9
+
+
 def test_degenerate_inputs():
     from biomedkg_amd import rand as R, sampling
     empty = torch.empty(2, 0, dtype=torch.int64, device=DEV)
