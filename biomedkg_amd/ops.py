@@ -1138,11 +1138,11 @@ def grouped_types(edge_type, repeat, num_relations):
 
     def build():
         _, rel_ptr = relation_order_of(edge_type, num_relations)
-        cnt = (rel_ptr[1:] - rel_ptr[:-1]).long() * int(repeat)
-        types = torch.repeat_interleave(torch.arange(num_relations, dtype=torch.int64, device=edge_type.device), cnt,
-                                        output_size=t)
-        ptr = (rel_ptr.long() * int(repeat)).to(torch.int32)
-        types._bkg_cache = {"rel_order": ((types._version, int(num_relations)), (_iota32(t, edge_type.device), ptr))}
+        ptr = rel_ptr * int(repeat)                                      # (int32; t < 2^31)
+        iota = _iota32(t, edge_type.device)
+        # id of position i = number of group ends <= i (one launch; torch.repeat_interleave walks each group serially)
+        types = torch.searchsorted(ptr[1:], iota, right=True)
+        types._bkg_cache = {"rel_order": ((types._version, int(num_relations)), (iota, ptr))}
         return types
     return _cached(edge_type, "grouped_types", (int(repeat), int(num_relations)), build)
 
