@@ -28,7 +28,7 @@ constexpr float KN_EPS = 1e-12f;
 #define KN_REL_LDS 1          // the relation table staged in LDS, persistent workgroups (0: rows from the caches)
 #endif
 #ifndef KN_PERSIST_BLOCKS
-#define KN_PERSIST_BLOCKS 2048  // workgroups of the persistent form (256 CUs x 8)
+#define KN_PERSIST_BLOCKS 8192  // workgroups of the persistent form (swept on the bench graph: 1024 0.699, 2048 0.693, 4096 0.688, 8192 0.677, 16384 0.682, 32768 0.701 ms per tagged call)
 #endif
 #ifndef KN_U4
 #define KN_U4 2      // incidences in flight per lane group at four accumulator quads (experiment knob)

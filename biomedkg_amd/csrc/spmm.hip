@@ -23,6 +23,10 @@
 #include "common.h"
 #include "rowpiece.h"
 
+#ifndef SPMM_U1
+#define SPMM_U1 8    // entries in flight per lane group, one piece per lane (swept: see DESIGN 9-5)
+#endif
+
 namespace bkg {
 
 struct SpmmEpilogue {
@@ -105,7 +109,7 @@ __device__ __forceinline__ void spmm_accumulate_w(float4* acc, int beg, int end,
                                                   const float* __restrict__ w, const T* __restrict__ x, int64_t ldx,
                                                   int grp, int lig) {
   constexpr int G = 64 / LPR, Q = Piece<T>::Q;
-  constexpr int U = (VPL == 1) ? 8 : 4;  // entries in flight per lane group
+  constexpr int U = (VPL == 1) ? SPMM_U1 : 4;  // entries in flight per lane group
   constexpr int NB = U * G;
   int e = beg;
   if (e + NB <= end) {

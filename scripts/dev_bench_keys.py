@@ -1,3 +1,5 @@
-import json,sys
-d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(d["ms_per_step"], d["ms_per_step_median"], d["ms_per_step_fresh_structures"], d["sampled_regime"]["graphed_steps_per_s"], d["ms_gcl_step"], d["ms_kge_step"])
+"""Dev: the step time and the tagged calls' launch times of a bench line (file argument)."""
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+tags = {k["tag"]: round(k["avg_launch_ms"], 4) for k in [d["roofline"]] + d["kernels"]}
+print(round(d["ms_per_step"], 3), round(d["ms_gcl_step"], 3), round(d["ms_kge_step"], 3), tags)
