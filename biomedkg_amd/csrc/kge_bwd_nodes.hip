@@ -21,6 +21,9 @@ constexpr float KN_EPS = 1e-12f;
 #define KS_RUNS 0             // 1: the relation row applied once per run of equal ids (pays only on relation-ordered lists;
                               // measured equal on the north-star graph, so the lists stay in entry order)
 #endif
+#ifndef KS_L32
+#define KS_L32 16     // lanes per row of a 32-piece table (d = 256 bf16) in the stream form (swept: 8 0.775, 16 0.662, 32 0.676 ms per tagged call)
+#endif
 #ifndef KS_ATTR
 #define KS_ATTR
 #endif
@@ -568,7 +571,7 @@ extern "C" int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t 
     hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, KN_DISTMULT, LPR, VPL>),                                        \
                        dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), block, 0, s, *split, (const TT*)z, ldz,      \
                        (const float*)nullptr, partials, dz, lddz, accumulate);
-  BKG_PIECE_DISPATCH_(d / epl, 32, 64, {
+  BKG_PIECE_DISPATCH_(d / epl, KS_L32, 64, {
     if (z_is_bf16) { KS_LAUNCH(__bf16) } else { KS_LAUNCH(float) }
   })
 #undef KS_LAUNCH

@@ -20,6 +20,10 @@
 #include "common.h"
 #include "rowpiece.h"
 
+#ifndef KF_L32
+#define KF_L32 8     // lanes per row of a 32-piece table (d = 256 bf16) in the fused scorer (swept: DESIGN 9-4)
+#endif
+
 namespace bkg {
 
 enum { KF_DISTMULT = 0, KF_TRANSE = 1 };
@@ -360,7 +364,7 @@ extern "C" int bkg_kge_fused_bce_dev_f32(int32_t kind, const void* z, int32_t z_
   hipLaunchKernelGGL((kge_fused_bce_kernel<TT, K, LPR, VPL>), grid, block, 0, s, (const TT*)z, ldz, head, tail, T, \
                      label, inv_total, inv_total_dev, rel_emb, ldr, n_rel, order, rel_ptr, CH, score, g, reinterpret_cast<int4*>(rec), loss_part,  \
                      drel, lddr)
-  BKG_PIECE_DISPATCH_(d / epl, 8, 16, {
+  BKG_PIECE_DISPATCH_(d / epl, KF_L32, 16, {
     if (z_is_bf16) { if (kind == KF_DISTMULT) KF_LAUNCH(__bf16, KF_DISTMULT); else KF_LAUNCH(__bf16, KF_TRANSE); }
     else { if (kind == KF_DISTMULT) KF_LAUNCH(float, KF_DISTMULT); else KF_LAUNCH(float, KF_TRANSE); }
   })
