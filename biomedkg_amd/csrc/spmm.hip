@@ -23,6 +23,9 @@
 #include "common.h"
 #include "rowpiece.h"
 
+#ifndef SPMM_L32
+#define SPMM_L32 32   // lanes per row of a 32-piece row (512 bytes) in the item kernel (swept: DESIGN 9-5)
+#endif
 #ifndef SPMM_U1
 #define SPMM_U1 8    // entries in flight per lane group, one piece per lane (swept: see DESIGN 9-5)
 #endif
@@ -466,7 +469,7 @@ static bool dispatch_spmm(int d, const SpmmArgs<T>& a) {
     case 4: launch_spmm<T, 4, 1>(a); return true;
     case 8: launch_spmm<T, 8, 1>(a); return true;
     case 16: launch_spmm<T, 16, 1>(a); return true;
-    case 32: launch_spmm<T, 32, 1>(a); return true;
+    case 32: launch_spmm<T, SPMM_L32, 32 / SPMM_L32>(a); return true;
     case 64: launch_spmm<T, 64, 1>(a); return true;
     case 96: launch_spmm<T, 32, 3>(a); return true;
     case 128: launch_spmm<T, 64, 2>(a); return true;
