@@ -20,6 +20,9 @@
 #include "common.h"
 #include "rowpiece.h"
 
+#ifndef KF_CH
+#define KF_CH 64     // triplets per wave (biomedkg_amd/ops.py _FUSED_CHUNK must agree: bkg_kge_fused_chunk)
+#endif
 #ifndef KF_L32
 #define KF_L32 8     // lanes per row of a 32-piece table (d = 256 bf16) in the fused scorer (swept: DESIGN 9-4)
 #endif
@@ -338,8 +341,9 @@ extern "C" int bkg_relation_wave_ptr(const int32_t* rel_ptr, int32_t n_rel, int3
   return check_launch("bkg_relation_wave_ptr");
 }
 
+extern "C" int32_t bkg_kge_fused_chunk() { return KF_CH; }
 extern "C" int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel) {
-  return ((T + 63) / 64 + n_rel + 3) / 4 * 4;
+  return ((T + KF_CH - 1) / KF_CH + n_rel + 3) / 4 * 4;
 }
 
 // `inv_total_dev` (nullable): read 1 / total from device memory instead of the scalar argument.  Triplets whose
@@ -358,7 +362,7 @@ extern "C" int bkg_kge_fused_bce_dev_f32(int32_t kind, const void* z, int32_t z_
   hipStream_t s = (hipStream_t)stream;
   // triplets per wave: small enough that T / CH waves oversubscribe the chip several times (each wave walks its
   // slice serially through a 3-deep dependent-load chain), large enough that the 1-KiB atomic flush stays rare
-  constexpr int CH = 64;
+  constexpr int CH = KF_CH;
   dim3 grid((unsigned)(bkg_kge_fused_bce_waves(T, n_rel) / 4)), block(256);
 #define KF_LAUNCH(TT, K)                                                                                            \
   hipLaunchKernelGGL((kge_fused_bce_kernel<TT, K, LPR, VPL>), grid, block, 0, s, (const TT*)z, ldz, head, tail, T, \

@@ -1199,7 +1199,17 @@ def kge_score(z, rel_emb, edge_index, edge_type, kind):
 
 
 _KGE_PIECES = (2, 4, 6, 8, 12, 16, 24, 32, 64, 96, 128, 192)   # csrc/rowpiece.h BKG_PIECE_DISPATCH
-_FUSED_CHUNK = 64   # triplets per wave of csrc/kge_fused.hip
+class _FusedChunk:
+    """Triplets per wave of csrc/kge_fused.hip, asked of the library at first use."""
+    value = None
+
+    def __int__(self):
+        if _FusedChunk.value is None:
+            _FusedChunk.value = int(L.lib().bkg_kge_fused_chunk())
+        return _FusedChunk.value
+
+
+_FUSED_CHUNK_OF = _FusedChunk()
 
 
 _FEW_WAVES = 1 << 14     # below this the per-relation reduce of the waves' rows needs no long-row table
@@ -1213,7 +1223,7 @@ def _iota32(n, device):
 def _relation_waves_small(rel_ptr, num_relations, n_waves):
     """The same wave CSR for a mini-batch's few waves: one launch, no long-row table, nothing cached."""
     wave_ptr = torch.empty(num_relations + 1, dtype=torch.int32, device=rel_ptr.device)
-    L.call("bkg_relation_wave_ptr", L.ptr(rel_ptr), num_relations, _FUSED_CHUNK, L.ptr(wave_ptr), L.stream())
+    L.call("bkg_relation_wave_ptr", L.ptr(rel_ptr), num_relations, int(_FUSED_CHUNK_OF), L.ptr(wave_ptr), L.stream())
     return wave_ptr, _iota32(n_waves, rel_ptr.device), None
 
 
@@ -1224,7 +1234,8 @@ def _relation_waves(edge_type, rel_ptr, num_relations, n_waves):
 
     def build():
         cnt = (rel_ptr[1:] - rel_ptr[:-1]).long()
-        nw = (cnt + _FUSED_CHUNK - 1) // _FUSED_CHUNK
+        ch = int(_FUSED_CHUNK_OF)
+        nw = (cnt + ch - 1) // ch
         wave_ptr = torch.cat([nw.new_zeros(1), torch.cumsum(nw, 0)]).to(torch.int32)
         iota = torch.arange(n_waves, dtype=torch.int32, device=edge_type.device)
         return wave_ptr, iota, RowSplit(wave_ptr, num_relations, n_waves)

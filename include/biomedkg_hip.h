@@ -217,6 +217,7 @@ int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_
  * relation-side gradient (W = bkg_kge_fused_bce_waves(T, n_rel); relation r owns ceil(cnt_r / 64) consecutive waves;
  * the caller segment-reduces them), in one sweep over the triplets' rows visited in relation-sorted order.
  * Replaces decode + cat + binary_cross_entropy_with_logits of biomedkg/kge_module.py:121-127 and their autograd. */
+int32_t bkg_kge_fused_chunk(void);   /* triplets per wave of the fused pass (the wave tables of its callers are cut by it) */
 int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel);
 /* The scalar tail of a mini-batch step, one launch each (a captured step is bound by its launch count):
  * loss[0] = inv_total * sum(part[0..n_part)) + reg * (mean over rows < n_real of z^2 + mean of rel^2), the reference's
