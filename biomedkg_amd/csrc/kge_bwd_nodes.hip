@@ -24,6 +24,9 @@ constexpr float KN_EPS = 1e-12f;
 #ifndef KS_L32
 #define KS_L32 16     // lanes per row of a 32-piece table (d = 256 bf16) in the stream form (swept: 8 0.775, 16 0.662, 32 0.676 ms per tagged call)
 #endif
+#ifndef KS_U2
+#define KS_U2 4       // entries in flight per lane group at two pieces per lane (swept: DESIGN 9-5)
+#endif
 #ifndef KS_ATTR
 #define KS_ATTR
 #endif
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256) KS_ATTR void kge_bwd_stream_kernel(const T* __
                                                              float* __restrict__ dz, int64_t lddz, bkg_rowsplit rs,
                                                              float* __restrict__ partials, int accumulate) {
   constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, D = EPL * LPR * VPL;
-  constexpr int U = (VPL == 1) ? 8 : 4, NB = U * G;
+  constexpr int U = (VPL == 1) ? 8 : KS_U2, NB = U * G;
   extern __shared__ __attribute__((aligned(16))) float rel_lds[];
   const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
   for (int i = threadIdx.x; i < (n_rel + 1) * (D / 4); i += 256) {
