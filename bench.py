@@ -14,9 +14,10 @@ Adam (clip + update fused: biomedkg_amd/optim.py), inputs resident in HBM.  ``va
 although both sub-steps consume it), whole job.
 
 N = 1 runs the whole graph on the GPU.  N > 1 (``--mode auto`` -> ``partition``, BASELINE configs[3] / north_star):
-ONE graph, its nodes partitioned over the ranks (biomedkg_amd/partition.py): all-gather of the gather table per conv
-layer, reduce-scatter in backward, the scorer over each rank's share of the triplets, flat-bucket gradient all-reduce;
-the total work is fixed, so ``"scaling": "strong"``.  ``--mode replicas`` is the reference's own regime (Lightning DDP:
+ONE graph, its nodes partitioned over the ranks (biomedkg_amd/partition.py): per conv layer a gather of the table rows a
+rank's in-edges read (forward) and of the output-gradient rows its out-edges point at (backward), every triplet scored by
+the owners of both its endpoints (no gradient rows cross the wire), flat-bucket gradient all-reduce; the total work is
+fixed, so ``"scaling": "strong"``.  ``--mode replicas`` is the reference's own regime (Lightning DDP:
 one graph per rank, gradient all-reduce only, weak scaling) and is opt-in.
 Default ``--precision bf16`` = BASELINE's "bf16 storage / fp32 accumulate" configuration; ``--precision fp32``
 is the exact parity mode (its step time is reported on the same line as ``ms_per_step_fp32``).
@@ -235,6 +236,15 @@ def build_partitioned_steps(args, rank, world, dev):
     n, e, r, h = g["num_nodes"], g["edge_index"].size(1), g["num_relations"], args.hidden
     ei, et = g["edge_index"].to(dev), g["edge_type"].to(dev)
     part = P.NodePartition(ei, n, rank, world)
+    # refuse early, with a message, what would otherwise die inside a step: the gathered tables live in the padded slot
+    # space [world * n_max, d] -- per conv layer a forward table and a gathered output gradient, two views wide for GGD,
+    # plus the activations saved for the backward (a generous bound: fp32, every layer resident at once)
+    need = part.world * part.n_max * (2 * h) * 4 * 2 * 4 * 2
+    free, _ = torch.cuda.mem_get_info(dev)
+    if need > 0.9 * free:
+        raise SystemExit(f"bench.py: rank {rank} would need ~{need / 2**30:.1f} GiB for the gathered tables of {world} x "
+                         f"{part.n_max} slots x {2 * h} columns but the device has {free / 2**30:.1f} GiB free "
+                         "(BKG_BENCH_ONE_DEVICE shares one GPU among all ranks: use a smaller --nodes / --edges there)")
     torch.manual_seed(42)
     xk = part.shard(torch.randn(n, h, device=dev)).contiguous()                     # each rank keeps only its rows
     xg = part.shard(torch.randn(n, 768, device=dev)).contiguous()
@@ -244,15 +254,14 @@ def build_partitioned_steps(args, rank, world, dev):
     kge.train(); gcl.train()
     pg = P.PartitionedGraph(part, ei, P.HipBackend)
     prg = P.PartitionedRelGraph(part, ei, et, r, P.HipBackend)
-    share = slice(rank, None, world)                          # this rank's positives (strided: every relation on every rank)
-    pos_ei, pos_et = ei[:, share].contiguous(), et[share].contiguous()
+    # both-owner scoring (partition.TripletShare): the rank scores every triplet that touches one of its nodes -- counted
+    # by the owner of its head -- and reduces the embedding gradient of its own rows; no dz ever crosses the wire
+    pos = P.TripletShare(part, ei, et)
+    neg_sampler = sampling.BlockNegativeSampler(ei, et, part.bounds, rank, args.neg_ratio * e)
     shared = torch.Generator(device=dev).manual_seed(7)       # replicated draws: identical on every rank
-    shared_host = torch.Generator().manual_seed(7)            # ... the augmentation coin: a host draw, no device round trip
-    pos_slots = part.slots(pos_ei).contiguous()               # the positives' rows of the gathered table
+    shared_host = torch.Generator().manual_seed(7)            # ... the augmentation coin / the negatives' seed: host draws
     own = torch.Generator().manual_seed(1000 + rank)          # per-rank seeds for the in-kernel streams
     counter = [0]
-    from biomedkg_amd import rand as R
-    shuffler = R.DeviceRand(seed=4242 + rank)
 
     def own_seed():
         return int(torch.randint(0, 1 << 31, (1,), generator=own))
@@ -285,12 +294,39 @@ def build_partitioned_steps(args, rank, world, dev):
         return P.ggd_loss_partitioned(gcl.model, x, pg, P.HipBackend, perm, dropout_of, keep=keep)
 
     def kge_loss():
-        k = args.neg_ratio * pos_ei.size(1)
-        neg = sampling.negative_sampling(ei, n, k, seed=own_seed() * world + rank)
-        nt = shuffler.shuffle(pos_et.repeat(args.neg_ratio))       # == repeat(..)[randperm(k)] without the sort behind it
-        return P.kge_loss_partitioned(kge.model, xk, prg, P.HipBackend, pos_ei, pos_et, neg, nt, kge.model.decoder.kind,
-                                      dropout_of, n_pos_global=e, n_neg_global=args.neg_ratio * e, pos_slots=pos_slots)
+        # reference kge_module.py:86-102 over a partition: every rank draws the blocks of the cell grid that touch its
+        # nodes from the step's SHARED seed (the two owners of a block get the same triplets), relation ids =
+        # edge_type.repeat(k)[randperm] per global position
+        seed = int(torch.randint(0, 1 << 62, (1,), generator=shared_host))
+        idx, types, n_own = neg_sampler.draw(seed)
+        neg = P.TripletShare(part, idx, types, n_own=n_own, entries=neg_sampler.entries)
+        return P.kge_loss_partitioned(kge.model, xk, prg, P.HipBackend, pos, neg, kge.model.decoder.kind, dropout_of,
+                                      n_pos_global=e, n_neg_global=args.neg_ratio * e)
 
+    def check_losses():
+        """The two losses on FIXED draws (one corruption permutation, one edge mask, world-independent negatives), exact
+        fp32, dropout off, at the initial weights: the same numbers at every world size (tests compare N ranks with one)."""
+        was = ops.get_matmul_precision()
+        ops.set_matmul_precision("fp32")
+        gcl.eval(); kge.eval()
+        try:
+            gen = torch.Generator().manual_seed(99)
+            perm = torch.randperm(n, generator=gen).to(dev)
+            keep = (torch.rand(e, generator=gen) >= 0.4).to(dev)
+            nt = et[torch.randperm(e, generator=gen).to(dev)]
+            with torch.no_grad():
+                lg = P.ggd_loss_partitioned(gcl.model, xg, P.PartitionedGraph(part, ei, P.HipBackend), P.HipBackend, perm,
+                                            None, keep=keep)
+                neg = sampling.negative_sampling(ei, n, e, seed=99)
+                lk = P.kge_loss_partitioned(kge.model, xk, prg, P.HipBackend, pos, P.TripletShare(part, neg, nt),
+                                            kge.model.decoder.kind, None, n_pos_global=e, n_neg_global=e)
+            return {"ggd": float(P.loss_value(lg, world)), "kge": float(P.loss_value(lk, world)),
+                    "note": "exact fp32, dropout off, fixed draws, initial weights: independent of the world size"}
+        finally:
+            ops.set_matmul_precision(was)
+            gcl.train(); kge.train()
+
+    check = check_losses()
     # both outcomes of GGD's augmentation coin and the KGE step once, untimed: whichever comes first inside the timed
     # region then finds its buffers in the caching allocator (a first-time hipMalloc costs ~100 ms)
     for loss_fn in (lambda: ggd_loss(True), lambda: ggd_loss(False), kge_loss, kge_loss):
@@ -299,6 +335,7 @@ def build_partitioned_steps(args, rank, world, dev):
         p.grad = None
     step_g, step_k = make(list(gcl.model.parameters()), ggd_loss), make(list(kge.model.parameters()), kge_loss)
     step_g.part = part
+    step_g.check_loss = check
     return step_g, step_k, n, e, r
 
 
@@ -719,21 +756,26 @@ def launch_ranks(args):
     with socket.socket() as s:                      # a free rendezvous port on the loop-back interface
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    import tempfile
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BKG_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this stack
+        # every rank's stderr goes to a file of its own: when one fails, ITS last lines are shown under its rank number
+        # (eight interleaved tracebacks of ranks that were merely killed in a collective say nothing)
+        logs.append(tempfile.TemporaryFile(mode="w+b"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = None
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=logs[-1]))
+    out, first_dead = None, None
     while out is None:                              # a rank that dies early leaves the others waiting in a collective:
         try:                                        # end them instead of waiting for the caller's own limit
             out, _ = procs[0].communicate(timeout=2)
         except subprocess.TimeoutExpired:
-            dead = [p.returncode for p in procs[1:] if p.poll() not in (None, 0)]
+            dead = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
             if dead:
-                sys.stderr.write(f"bench.py --gpus {n}: a rank exited with {dead[0]}; ending the others\n")
+                first_dead = dead[0]
+                sys.stderr.write(f"bench.py --gpus {n}: rank {dead[0][0]} exited with {dead[0][1]}; ending the others\n")
                 for p in procs:
                     if p.poll() is None:
                         p.kill()
@@ -746,9 +788,21 @@ def launch_ranks(args):
         except subprocess.TimeoutExpired:           # rank 0 is gone and this one is stuck in a collective
             p.kill()
             codes.append(p.wait() or 1)
+    bad = [c for c in codes if c != 0]
+
+    def tail(r, lines=40):
+        logs[r].seek(0)
+        text = logs[r].read().decode(errors="replace").splitlines()
+        return "\n".join(text[-lines:])
+    if bad:
+        # the rank that failed FIRST (the others' errors are the collective timing out or the kill), else every bad one
+        show = [first_dead[0]] if first_dead else [r for r, c in enumerate(codes) if c != 0]
+        for r in show:
+            sys.stderr.write(f"---- bench.py rank {r} (exit code {codes[r]}), last lines of its stderr ----\n{tail(r)}\n")
+    else:
+        sys.stderr.write(tail(0, lines=200) + ("\n" if tail(0, 1) else ""))     # rank 0's warnings (RCCL's banner etc.)
     sys.stdout.write(out.decode())
     sys.stdout.flush()
-    bad = [c for c in codes if c != 0]
     raise SystemExit(max(abs(c) for c in bad) if bad else 0)
 
 
@@ -780,6 +834,10 @@ def main():
         kw = {"device_id": dev} if backend == "nccl" else {}
         if forced:
             kw.update(rank=0, world_size=1)
+        # a rank that never arrives must not hold the others until the caller's limit: the rendezvous and every collective
+        # give up after BKG_BENCH_TIMEOUT_S (default 5 minutes) with an error naming the call
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ.get("BKG_BENCH_TIMEOUT_S", "300")))
         torch.distributed.init_process_group(backend, **kw)
         if os.environ.get("BKG_BENCH_FAIL_RANK") == str(rank):      # fault injection (tests): a rank that dies after rendezvous
             os._exit(7)
@@ -870,9 +928,11 @@ def main():
                     "halo": {k: {"used": comm.patterns.get(k) is not None, "max_share_of_remote_rows_read": v}
                              for k, v in part.halo_fraction.items()},
                     "rows": {"n_local": part.n_local, "n_max": part.n_max, "bounds": part.bounds},
-                    "note": "rank 0's counts; gathers only (forward tables and the backward's gated output gradients, bf16 "
-                            "in bf16 mode) + the scorer's table gather and dz reduce-scatter + the flat gradient all-reduce "
-                            "(not counted here)"}
+                    "padded_over_real_rows": part.padding_waste,
+                    "note": "rank 0's counts; gathers only: forward tables and the backward's gated output gradients (bf16 in "
+                            "bf16 mode), the scorer's embedding table -- its gradient needs no exchange (both-owner scoring) -- "
+                            "the first R-GCN layer's constant input gathered once per graph, not per step; the flat gradient "
+                            "all-reduce is not counted here"}
     n_neg = args.neg_ratio * e
     strong = mode == "partition"
     total_edges = e if strong or world == 1 else world * e
@@ -959,8 +1019,9 @@ def main():
 
     if rank == 0:
         what = {"single": "the whole graph on one GPU",
-                "partition": f"ONE graph, nodes partitioned over {world} ranks (all-gather of the gather table per conv "
-                             "layer, reduce-scatter in backward, scorer over each rank's share of the triplets)",
+                "partition": f"ONE graph, nodes partitioned over {world} ranks (gathers of the rows a rank's edges read, "
+                             "forward tables and output gradients alike; every triplet scored by the owners of both its "
+                             "endpoints; no reduce-scatter anywhere)",
                 "replicas": "one graph per rank, gradient all-reduce only (the reference's DDP regime)"}[mode]
         out = {
             "metric": "edges/sec, GCL (GGD) step + KGE (R-GCN+DistMult) step, PrimeKG++ scale",
@@ -1000,6 +1061,7 @@ def main():
             "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_shuffled_neg_types": ms_shuffled_types,
             "ms_per_step_fresh_structures": ms_fresh,
             "roofline": roof, "kernels": others, "exchange": exchange,
+            "check_loss": getattr(step_g, "check_loss", None),
             "cpu_baseline": None,
         }
         def extra(fn, *a):      # the side figures never cost the headline line: a failure is reported in its place

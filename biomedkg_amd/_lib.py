@@ -64,7 +64,7 @@ SIGNATURES = {
     "bkg_row_l1norm_f32": (I32, [P, I64, I64, I32, P, P]),
     "bkg_kge_incidence_streams": (I32, [P, I64, I64, P, P, P, P, P, P, P, P, P]),
     "bkg_kge_bwd_stream_f32": (I32, [P, I32, I64, I64, I32, P, I64, I64, P, P, P, P, I64, P, P, I32, P]),
-    "bkg_kge_bwd_nodes_f32": (I32, [I32, P, I32, I64, I64, I32, P, P, P, I64, P, I64, I64, P, P, P, P, P, P, I64, P, P, I32, P]),
+    "bkg_kge_bwd_nodes_f32": (I32, [I32, P, I32, I64, I64, I32, P, P, P, I64, P, I64, I64, P, P, P, P, P, P, I64, P, P, I32, I64, P]),
     "bkg_kge_fused_chunk": (I32, []),
     "bkg_kge_fused_bce_waves": (I64, [I64, I32]),
     "bkg_kge_fused_bce_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
@@ -118,6 +118,8 @@ SIGNATURES = {
     "bkg_hashset_insert_offdiag": (I32, [P, P, I64, I64, P, I64, P]),
     "bkg_negative_sample_workspace_bytes": (I64, [I64]),
     "bkg_negative_sample": (I32, [I64, I64, I64, U64, P, I64, P, P, P, P, P, I64, I64, P, P, I64, P]),
+    "bkg_negative_blocks_struct_bytes": (I64, []),
+    "bkg_negative_sample_blocks": (I32, [P, I32, I64, I64, U64, I64, P, I64, P, I64, P, P, P, P, P, P, P, P, I64, P]),
     "bkg_permute_gather_i64": (I32, [P, I64, U64, P, P]),
     "bkg_randperm_dev": (I32, [P, I64, U64, P, P, P]),
     "bkg_negative_sample_dev_candidates": (I64, [I64]),

@@ -112,10 +112,11 @@ __device__ __forceinline__ void kn_finish(float4* acc, const float4* self, float
 // size (0.737 ms per launch either way; with the relation factor taken out altogether -- KN_EXP_NOREL -- 0.60): the row
 // comes out of LDS as slowly as out of the L1, what costs is the chain entry id -> record -> (row, relation row).
 template <typename T, int KIND, int LPR, int VPL, bool SPLIT, bool REL_LDS>
-__global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict__ z, int64_t ldz, int n_nodes,
+__global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict__ z, const T* __restrict__ z_self,
+                                                            int64_t ldz, int n_nodes,
                                                             KnTriplets tr, const float* __restrict__ rel_emb,
                                                             int64_t ldr, int n_rel, const float* __restrict__ gscore,
-                                                            const float* __restrict__ l1,
+                                                            const float* __restrict__ l1, const float* __restrict__ l1_self,
                                                             const int32_t* __restrict__ inc_rowptr,
                                                             const int32_t* __restrict__ inc_perm,
                                                             float* __restrict__ dz, int64_t lddz, bkg_rowsplit rs,
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict_
   float inv_self = 0.f;
   zero4(acc);
   if (KIND == KN_TRANSE) {
-    inv_self = 1.0f / fmaxf(l1[node], KN_EPS);
-    kn_load_self<T, LPR, VPL>(z, ldz, node, lig, inv_self, self);
+    inv_self = 1.0f / fmaxf(l1_self[node], KN_EPS);
+    kn_load_self<T, LPR, VPL>(z_self, ldz, node, lig, inv_self, self);
   }
   // Batches of U incidences per lane group through a three-stage software pipeline: with the rows of batch i the
   // triplet fields of batch i+1 and the entry ids of batch i+2 are in flight (issued before the rows, so the one
@@ -254,15 +255,15 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_kernel(const T* __restrict_
     continue;
   }
   // (TransE: the normalisation's dot product runs over the lanes of a group, every group has the same values)
-  kn_finish<T, KIND, LPR, VPL>(acc, self, inv_self, KIND == KN_TRANSE ? (l1[node] > KN_EPS) : true, node, lig, dz, lddz,
+  kn_finish<T, KIND, LPR, VPL>(acc, self, inv_self, KIND == KN_TRANSE ? (l1_self[node] > KN_EPS) : true, node, lig, dz, lddz,
                                accumulate, grp == 0);
   }
 }
 
 // long incidence lists: add the node's partial slots in chunk order, then the TransE epilogue
 template <typename T, int KIND, int LPR, int VPL>
-__global__ __launch_bounds__(256) void kge_bwd_nodes_fixup_kernel(bkg_rowsplit rs, const T* __restrict__ z, int64_t ldz,
-                                                                  const float* __restrict__ l1,
+__global__ __launch_bounds__(256) void kge_bwd_nodes_fixup_kernel(bkg_rowsplit rs, const T* __restrict__ z /* self rows */,
+                                                                  int64_t ldz, const float* __restrict__ l1 /* of the self rows */,
                                                                   const float* __restrict__ partials,
                                                                   float* __restrict__ dz, int64_t lddz,
                                                                   int accumulate) {
@@ -490,8 +491,12 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_b
                                      int64_t T, const float* rel_emb, int64_t ldr, int64_t n_rel, const float* gscore,
                                      const void* rec, const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm, float* dz,
                                      int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
-                                     void* stream) {
+                                     int64_t self_row0, void* stream) {
   BKG_ARG(kind == KN_DISTMULT || kind == KN_TRANSE, "bkg_kge_bwd_nodes_f32: bad kind");
+  BKG_ARG(self_row0 >= 0, "bkg_kge_bwd_nodes_f32: bad self_row0");
+  // incidence row i is node `self_row0 + i` of the table z / l1 (0 for a whole graph; a node-partitioned rank reduces the
+  // lists of ITS nodes only, whose rows of the gathered table start at its first slot): TransE reads the node's own row
+  const float* l1_self = l1 ? l1 + self_row0 : nullptr;
   BKG_ARG(kind == KN_DISTMULT || l1 != nullptr, "bkg_kge_bwd_nodes_f32: TransE needs the row L1 norms");
   const int epl = z_is_bf16 ? 8 : 4;
   BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) &&
@@ -510,7 +515,8 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_b
                                                                    : ceil_div(work, 4)))
 #define KN_LAUNCH2(TT, K, SP, RL, work, RS)                                                                            \
   hipLaunchKernelGGL((kge_bwd_nodes_kernel<TT, K, LPR, VPL, SP, RL>), KN_GRID(work), block, RL ? smem : 0, s,          \
-                     (const TT*)z, ldz, (int)n_nodes, tr, rel_emb, ldr, (int)n_rel, gscore, l1, inc_rowptr, inc_perm,  \
+                     (const TT*)z, (const TT*)z + self_row0 * ldz, ldz, (int)n_nodes, tr, rel_emb, ldr, (int)n_rel, gscore, l1, \
+                     l1_self, inc_rowptr, inc_perm,                                                                    \
                      dz, lddz, RS, partials, accumulate)
 #define KN_LAUNCH(TT, K)                                                                                               \
   if (split) {                                                                                                         \
@@ -520,7 +526,7 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_b
     }                                                                                                                  \
     if (split->n_long_max > 0)   /* (bounds cut to the table's actual counts may be zero) */                          \
     hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, K, LPR, VPL>), dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), \
-                       block, 0, s, *split, (const TT*)z, ldz, l1, partials, dz, lddz, accumulate);                    \
+                       block, 0, s, *split, (const TT*)z + self_row0 * ldz, ldz, l1_self, partials, dz, lddz, accumulate); \
   } else {                                                                                                             \
     if (rel_lds) KN_LAUNCH2(TT, K, false, true, n_nodes, none);                                                        \
     else KN_LAUNCH2(TT, K, false, false, n_nodes, none);                                                               \

@@ -256,6 +256,106 @@ __global__ __launch_bounds__(256) void padded_loss_inputs_kernel(const int64_t* 
   out_type[i] = valid ? type[i] : pad_rel;
 }
 
+
+// ---- block-structured sampling for node-partitioned training (biomedkg_amd/partition.py, both-owner scoring).  The
+// off-diagonal cell grid is cut into world x world blocks (head owner a, tail owner b); block (a, b) draws its share
+// k_ab = K * free_ab / free of the K negatives -- free = cells that are not positives, counted once per graph, so the
+// union is K distinct uniform non-edges stratified by block with proportional allocation -- from ITS OWN keyed
+// permutation of the block's cells, seeded by (seed, a, b).  Every rank can therefore produce any block: rank r draws the
+// 2 world - 1 blocks that touch its nodes (row band r: it owns the heads; column band r: it owns the tails), the two
+// owners of a block get identical triplets, and no triplet, score or gradient row ever crosses the wire.  The relation id
+// of the negative at global position p (blocks laid out one after the other in block-id order) is
+// type[sigma(p) % E], sigma a keyed bijection of [0, K): the reference's edge_type.repeat(k)[randperm(K)].
+struct NegBlock {
+  int64_t row_lo, n_rows, col_lo, n_cols;   // the block's cells; a diagonal block has row_lo == col_lo, n_rows == n_cols
+  int64_t population;                       // n_rows * n_cols, or n (n - 1) on the diagonal
+  int64_t cand0, n_cand;                    // its candidates: [cand0, cand0 + n_cand) of the launch, cand0 % 256 == 0
+  int64_t out0, k;                          // its survivors go to out[out0 .. out0 + k)
+  int64_t gpos0;                            // global position of its first negative (relation ids)
+  int64_t id;                               // a * world + b (seeds its permutation)
+};
+
+__device__ __forceinline__ int neg_block_of(const NegBlock* __restrict__ blocks, int n_blocks, int64_t i) {
+  int b = 0;
+  for (int j = 1; j < n_blocks; ++j) b = (i >= blocks[j].cand0) ? j : b;     // (cand0 ascending; <= 2 world - 1 entries)
+  return b;
+}
+
+__global__ __launch_bounds__(256) void negative_candidates_blocks_kernel(const NegBlock* __restrict__ blocks, int n_blocks,
+                                                                         uint64_t seed, uint64_t n_nodes,
+                                                                         const unsigned long long* __restrict__ pos_tab,
+                                                                         uint64_t pos_mask, uint64_t* __restrict__ keys,
+                                                                         int32_t* __restrict__ flag) {
+  __shared__ Feistel pi;
+  __shared__ NegBlock blk;
+  if (threadIdx.x == 0) {
+    blk = blocks[neg_block_of(blocks, n_blocks, (int64_t)blockIdx.x * 256)];
+    pi = make_feistel((uint64_t)blk.population, hs_mix(seed ^ ((uint64_t)(blk.id + 1) * 0xD1B54A32D192ED03ull)));
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = i - blk.cand0;
+  if (j >= blk.n_cand) { flag[i] = 0; keys[i] = 0; return; }
+  const uint64_t code = pi((uint64_t)j);
+  uint64_t r, c;
+  if (blk.row_lo == blk.col_lo) {          // diagonal block: its own off-diagonal cells, PyG's coding inside the block
+    const uint64_t n1 = (uint64_t)blk.n_rows - 1;
+    r = code / n1; c = code % n1; c += (r <= c ? 1 : 0);
+  } else {
+    r = code / (uint64_t)blk.n_cols; c = code % (uint64_t)blk.n_cols;
+  }
+  r += (uint64_t)blk.row_lo; c += (uint64_t)blk.col_lo;
+  const uint64_t key = r * (n_nodes - 1) + c - (r < c ? 1 : 0);     // the graph-wide off-diagonal code (hash set, output)
+  keys[i] = key;
+  flag[i] = hs_contains(pos_tab, pos_mask, key) ? 0 : 1;
+}
+
+__global__ __launch_bounds__(256) void negative_scatter_blocks_kernel(const NegBlock* __restrict__ blocks, int n_blocks,
+                                                                      const uint64_t* __restrict__ keys,
+                                                                      const int32_t* __restrict__ flag,
+                                                                      const int32_t* __restrict__ offs, uint64_t n_nodes,
+                                                                      uint64_t seed, int64_t k_global,
+                                                                      const int64_t* __restrict__ pos_type, int64_t n_pos,
+                                                                      int64_t* __restrict__ out_head, int64_t* __restrict__ out_tail,
+                                                                      int64_t* __restrict__ out_type, int32_t* __restrict__ count) {
+  __shared__ Feistel sigma;
+  __shared__ NegBlock blk;
+  __shared__ int bi;
+  if (threadIdx.x == 0) {
+    bi = neg_block_of(blocks, n_blocks, (int64_t)blockIdx.x * 256);
+    blk = blocks[bi];
+    sigma = make_feistel((uint64_t)k_global, hs_mix(seed ^ 0x2545F4914F6CDD1Dull));
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t j = i - blk.cand0;
+  const int64_t base = offs[blk.cand0];
+  const int64_t last = blk.cand0 + blk.n_cand - 1;
+  const int64_t survivors = (int64_t)offs[last] + flag[last] - base;
+  const int64_t have = survivors < blk.k ? survivors : blk.k;
+  auto put = [&](int64_t p, int64_t r, int64_t c) {
+    out_head[blk.out0 + p] = r;
+    out_tail[blk.out0 + p] = c;
+    if (out_type) out_type[blk.out0 + p] = pos_type[sigma((uint64_t)(blk.gpos0 + p)) % (uint64_t)n_pos];
+  };
+  if (j < blk.n_cand && flag[i]) {
+    const int64_t rank = (int64_t)offs[i] - base;
+    if (rank < blk.k) {                    // vector_to_edge_index: re-open the diagonal
+      const int64_t r = (int64_t)(keys[i] / (n_nodes - 1));
+      int64_t c = (int64_t)(keys[i] % (n_nodes - 1));
+      c += (r <= c ? 1 : 0);
+      put(rank, r, c);
+    }
+  }
+  if (j >= have && j < blk.k) {            // a shortfall (never, in practice: the candidate count carries six sigma; it is
+    const int64_t r = blk.row_lo + j % blk.n_rows;     // reported through count): cells of the block all the same, so that
+    int64_t c = blk.col_lo + (j + 1) % blk.n_cols;     // the incidence lists built over the block layout stay valid
+    if (r == c) c = blk.col_lo + (j + 2) % blk.n_cols;
+    put(j, r, c);
+  }
+  if (j == 0) count[bi] = (int32_t)have;
+}
+
 }  // namespace bkg
 
 using namespace bkg;
@@ -304,6 +404,37 @@ extern "C" int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int
   hipLaunchKernelGGL(negative_scatter_kernel, dim3(ceil_div(n_candidates, 256)), dim3(256), 0, s, keys_tmp, flag_tmp,
                      offs_tmp, n_candidates, (uint64_t)n_nodes, out_offset, max_out, out_head, out_tail, count);
   return check_launch("bkg_negative_sample");
+}
+
+extern "C" int64_t bkg_negative_blocks_struct_bytes(void) { return (int64_t)sizeof(NegBlock); }
+
+// Block-structured negative sampling (see NegBlock): `blocks` is a DEVICE array of n_blocks descriptors (11 int64 each:
+// row_lo, n_rows, col_lo, n_cols, population, cand0, n_cand, out0, k, gpos0, id; cand0 ascending multiples of 256),
+// n_cand_total the padded candidate count (a multiple of 256).  out_head / out_tail / out_type: sum of k entries;
+// pos_type: the n_pos positives' relation ids (out_type nullable); count[n_blocks]: survivors kept per block (== k unless
+// a block fell short).
+extern "C" int bkg_negative_sample_blocks(const void* blocks, int32_t n_blocks, int64_t n_cand_total, int64_t n_nodes,
+                                          uint64_t seed, int64_t k_global, const uint64_t* pos_table, int64_t pos_capacity,
+                                          const int64_t* pos_type, int64_t n_pos, uint64_t* keys_tmp, int32_t* flag_tmp,
+                                          int32_t* offs_tmp, int64_t* out_head, int64_t* out_tail, int64_t* out_type,
+                                          int32_t* count, void* workspace, int64_t workspace_bytes, void* stream) {
+  BKG_ARG(n_blocks >= 0 && n_blocks <= 4096 && n_cand_total >= 0 && n_cand_total % 256 == 0 && n_cand_total < (1ll << 31) &&
+              n_nodes > 1 && n_nodes < (1ll << 31) && k_global > 0, "bkg_negative_sample_blocks: bad sizes");
+  BKG_ARG(pow2(pos_capacity) && (!out_type || (pos_type && n_pos > 0)), "bkg_negative_sample_blocks: bad tables");
+  if (n_blocks == 0 || n_cand_total == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const NegBlock* b = reinterpret_cast<const NegBlock*>(blocks);
+  hipLaunchKernelGGL(negative_candidates_blocks_kernel, dim3(n_cand_total / 256), dim3(256), 0, s, b, (int)n_blocks, seed,
+                     (uint64_t)n_nodes, reinterpret_cast<const unsigned long long*>(pos_table), (uint64_t)pos_capacity - 1,
+                     keys_tmp, flag_tmp);
+  size_t bytes = (size_t)workspace_bytes;
+  hipError_t e = rocprim::exclusive_scan(workspace, bytes, flag_tmp, offs_tmp, 0, (size_t)n_cand_total,
+                                         rocprim::plus<int32_t>(), s);
+  if (e != hipSuccess) { set_error("bkg_negative_sample_blocks: scan", e); return (int)e; }
+  hipLaunchKernelGGL(negative_scatter_blocks_kernel, dim3(n_cand_total / 256), dim3(256), 0, s, b, (int)n_blocks, keys_tmp,
+                     flag_tmp, offs_tmp, (uint64_t)n_nodes, seed, k_global, pos_type, n_pos, out_head, out_tail, out_type,
+                     count);
+  return check_launch("bkg_negative_sample_blocks");
 }
 
 extern "C" int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t seed, int64_t* out, void* stream) {

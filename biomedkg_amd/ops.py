@@ -3,6 +3,8 @@ requires CUDA (HIP) tensors and raises otherwise.  fp32 throughout in this file.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -619,15 +621,21 @@ def _dims(graph):
     return getattr(graph, "n_out", n), getattr(graph, "n_table", n), comm
 
 
-def _exchanged_product(comm, n_rows, d_out, dtype, device, make_rows):
+def _exchanged_product(comm, n_rows, d_out, dtype, device, make_rows, min_rows=0):
     """A node-partitioned layer's gather table: ``make_rows(lo, hi, out)`` writes rows ``[lo, hi)`` of the rank's product
     into ``out``; every finished row chunk leaves for its readers while the next one is computed (halo patterns; the
     plain all-gather moves the whole shard after the last chunk).  -> the ``[world * n_max, d_out]`` table."""
     buf = comm.shard_buffer(d_out, dtype, device)
     chunks = comm.chunks("in")
+    # a chunk the producer's kernel does not take on its own (fp32 rows below the streaming product's floor: a rank that
+    # owns hub nodes holds few rows, and a quarter of them fewer still): the whole shard as ONE product, then the chunked
+    # exchange all the same (every rank must issue the same collectives)
+    whole = any(0 < hi - lo < min_rows for lo, hi in chunks)
+    if whole and n_rows > 0:
+        make_rows(0, n_rows, buf[:n_rows])
     pending = []
     for c, (lo, hi) in enumerate(chunks):
-        if hi > lo:
+        if hi > lo and not whole:
             make_rows(lo, hi, buf[lo:hi])
         pending.append(comm.exchange_begin(buf, "in", chunk=c if len(chunks) > 1 else None))
     table = None
@@ -652,7 +660,8 @@ class _GcnConv(torch.autograd.Function):
         if bf16_storage() and _bf16_ok(d_out) and _xw_ok(x, n_rows, d_out, d_in):
             if comm is not None:          # row chunks of the product leave for their readers while the next one runs
                 xw = _exchanged_product(comm, n_rows, d_out, torch.bfloat16, x.device,
-                                        lambda lo, hi, out: gemm(x[lo:hi], weight, trans_b=True, out_dtype=torch.bfloat16, out=out))
+                                        lambda lo, hi, out: gemm(x[lo:hi], weight, trans_b=True, out_dtype=torch.bfloat16, out=out),
+                                        min_rows=0 if x.dtype == torch.bfloat16 else _TALL_ROWS)
             else:
                 xw = gemm(x, weight, trans_b=True, out_dtype=torch.bfloat16)      # only ever read as the gather table
         else:
@@ -808,7 +817,8 @@ class _GcnConvViews(torch.autograd.Function):
                 table = _exchanged_product(comm, n, views * d_out, torch.bfloat16, x2.device,
                                            lambda lo, hi, out: gemm(xr[views * lo:views * hi], weight, trans_b=True,
                                                                     out_dtype=torch.bfloat16,
-                                                                    out=out.view(views * (hi - lo), d_out)))
+                                                                    out=out.view(views * (hi - lo), d_out)),
+                                           min_rows=0 if x2.dtype == torch.bfloat16 else (_TALL_ROWS + views - 1) // views)
             else:
                 table = gemm(x2.view(views * n, d_in), weight, trans_b=True, out_dtype=torch.bfloat16).view(n, views * d_out)
         c = graph.by_dst
@@ -888,12 +898,17 @@ class _RgcnConv(torch.autograd.Function):
     def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop, hidden):
         n, n_table, comm = _dims(rg)
         d_in, d_out = weight.size(1), weight.size(2)
+        x_given = x                        # (the caller's tensor object: what a remembered table is valid for)
         if x.dtype == torch.bfloat16 and not _xw_ok(x, n, d_out, d_in):
             x = x.float()
+        remember = False
         if comm is None:
             table = _table(x)
             pending = None
+        elif not ctx.needs_input_grad[0] and comm.constant_table(rg, x_given, ("in", _PRECISION)) is not None:
+            table, pending = comm.constant_table(rg, x_given, ("in", _PRECISION)), None      # the node features: the same rows every step, gathered once
         else:
+            remember = not ctx.needs_input_grad[0]
             pending = comm.exchange_begin(_table(x), "in")                           # crosses xGMI ...
         # ... under the [N, out] root term: a bf16 table where the layer's own output is one (a hidden layer of bf16 mode:
         # every value of the sum is rounded to bf16 right after it), fp32 for the encoder's output layer
@@ -901,6 +916,8 @@ class _RgcnConv(torch.autograd.Function):
         xr = gemm(x, root, out_dtype=torch.bfloat16) if xr16 else gemm(x, root)
         if pending is not None:
             table = comm.exchange_end(pending)
+            if remember:
+                comm.remember_table(rg, x_given, ("in", _PRECISION), table)
         h16 = bf16_storage() and _bf16_ok(d_in) and _bf16_operand_ok(rg.num_segments, d_out, d_in)
         h = spmm(rg.seg_ptr, rg.src_sorted, rg.inv_cnt, table, rg.num_segments, tag="rgcn_segment_mean",
                  split=rg.seg_split, out_dtype=torch.bfloat16 if h16 else torch.float32)   # [S, in]  segment means
@@ -1108,6 +1125,48 @@ class Incidence:
         self.split = None if small else rowsplit_for(self.rowptr, num_nodes, flat.numel())
 
 
+class LocalIncidence:
+    """The incidence lists of a node-partitioned rank's OWN nodes over the triplets it scores (``slot_index [2, T]``: table
+    slots of head / tail): the entries of ``cat(head, tail)`` whose node is one of the rank's ``n_local`` rows starting at
+    slot ``row0``, sorted by local row.  ``perm`` holds positions in the 2T-entry list (entry e < T: the node is the
+    head of triplet e), exactly what the whole-graph ``Incidence`` holds -- so the same kernels reduce these lists into a
+    ``[n_local, d]`` gradient: a triplet is scored by the owners of BOTH its endpoints, nothing is reduce-scattered.
+    ``entries`` (optional, int64): the positions of the local entries when the caller knows them by construction (fresh
+    negatives drawn block by block: no mask, no count read)."""
+
+    def __init__(self, slot_index, row0, n_local, entries=None):
+        from .graph import _Sorter, rowsplit_for
+        flat = slot_index.contiguous().view(-1)
+        if entries is None:
+            entries = torch.nonzero((flat >= row0) & (flat < row0 + n_local)).squeeze(1)     # (one host read: static sets)
+        keys = (flat[entries] - row0).contiguous()
+        _, perm, self.rowptr = _Sorter.sort_rowptr(keys, None, max(n_local, 1), 1, n_local + 1)
+        self.perm = entries.to(torch.int32)[perm.long()].contiguous()
+        self.n_inc, self.n_rows, self.row0 = int(entries.numel()), int(n_local), int(row0)
+        small = n_local <= 4096 and self.n_inc < (1 << 18)
+        self.split = None if small else rowsplit_for(self.rowptr, n_local, self.n_inc)
+
+
+class OwnedTriplets:
+    """One label's triplets as a node-partitioned rank scores them (biomedkg_amd/partition.py, both-owner scoring):
+    ``own`` -- the head is one of the rank's nodes: scored, counted in the loss and in d rel_emb -- then ``foreign`` --
+    the tail is local, the head is not: scored for d score only (the head's owner counts them).  Indices are table slots.
+    ``incidence``: the rank's nodes' lists over ``cat(own, foreign)``."""
+
+    def __init__(self, own_index, own_type, foreign_index, foreign_type, row0, n_local, entries=None):
+        self.own_index, self.own_type = own_index.contiguous(), own_type.contiguous()
+        self.foreign_index, self.foreign_type = foreign_index.contiguous(), foreign_type.contiguous()
+        self.n_own, self.n_foreign = int(own_index.size(1)), int(foreign_index.size(1))
+        self.row0, self.n_local, self._entries, self._inc = int(row0), int(n_local), entries, None
+
+    @property
+    def incidence(self):
+        if self._inc is None:
+            both = torch.cat([self.own_index, self.foreign_index], dim=1)
+            self._inc = LocalIncidence(both, self.row0, self.n_local, self._entries)
+        return self._inc
+
+
 def incidence_of(edge_index, num_nodes) -> Incidence:
     from .graph import _cached
     return _cached(edge_index, "incidence", (int(num_nodes),), lambda: Incidence(edge_index, num_nodes))
@@ -1178,7 +1237,7 @@ class _KgeScore(torch.autograd.Function):
             L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(z), 0, z.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(et), t,
                    L.ptr(rel_emb), rel_emb.stride(0), rel_emb.size(0), L.ptr(gscore), None, L.ptr(l1), L.ptr(inc.rowptr),
                    L.ptr(inc.perm),
-                   L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None), L.ptr(partials), 0, L.stream())
+                   L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None), L.ptr(partials), 0, 0, L.stream())
         if ctx.needs_input_grad[1]:
             drel = torch.zeros_like(rel_emb)
             order, rel_ptr = relation_order_of(et, rel_emb.size(0)) if t >= (1 << 15) else (None, None)
@@ -1266,14 +1325,17 @@ class _KgeBceLoss(torch.autograd.Function):
     """``binary_cross_entropy_with_logits(cat(decode(pos), decode(neg)), cat(1, 0))`` of the reference's
     ``KGEModule.training_step`` (kge_module.py:121-127) as ONE op: the forward sweeps each triplet set once
     (scores, loss terms, d loss / d score, d rel_emb -- csrc/kge_fused.hip), the backward is the per-node
-    segment reduce for dz.  Returns ``(loss, pos_pred, neg_pred)``; the preds are detached outputs."""
+    segment reduce for dz.  Returns ``(loss, pos_pred, neg_pred)``; the preds are detached outputs.
+
+    ``owned`` (node-partitioned training, biomedkg_amd/partition.py): ``(OwnedTriplets of the positives, of the
+    negatives)`` in table slots -- the rank scores every triplet that touches one of its nodes; the ones whose HEAD it
+    owns count in the loss and in d rel_emb, the others (tail local, head remote) are scored for d score alone, and dz is
+    reduced over the rank's own nodes' lists only: ``[n_local, d]``, no reduce-scatter."""
 
     @staticmethod
-    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total, reg, inv_total, rows, reg_rows=None):
+    def forward(ctx, z, rel_emb, pos_ei, pos_et, neg_ei, neg_et, kind, comm, total, reg, inv_total, rows, reg_rows=None,
+                owned=None):
         d, r = z.size(1), rel_emb.size(0)
-        t_pos, t_neg = pos_ei.size(1), neg_ei.size(1)
-        if total is None:
-            total = t_pos + t_neg
         # padded mini-batches (biomedkg_amd/sampled.py): ``inv_total`` is a DEVICE scalar, pad triplets carry the
         # relation id ``r`` -- one group past the real ones, which no wave visits -- and their records stay zero
         padded = inv_total is not None
@@ -1281,26 +1343,39 @@ class _KgeBceLoss(torch.autograd.Function):
         # bf16 mode: both passes gather the node rows from a bf16 copy of z (half the bytes; fp32 accumulate)
         zt = to_bf16(z) if (bf16_storage() and d % 8 == 0 and (d // 8) in _KGE_PIECES) else z
         if comm is not None:              # node-partitioned: the scorer reads the all-gathered table (triplet ids = slots)
+            if owned is None:
+                raise ValueError("a node-partitioned scorer takes its triplets as OwnedTriplets (kge_bce_loss_owned)")
             zt = comm.all_gather(zt)
         n = zt.size(0)
         zt_bf16 = int(zt.dtype == torch.bfloat16)
-        scores, grads, recs, drel = [], [], [], None
+        # triplet sets (index, type, label, counted) in groups: one group = one incidence structure of the backward
+        if owned is None:
+            sets = ((pos_ei, pos_et, 1.0, True, 0), (neg_ei, neg_et, 0.0, True, 1))
+        else:
+            po, ne = owned
+            sets = ((po.own_index, po.own_type, 1.0, True, 0), (po.foreign_index, po.foreign_type, 1.0, False, 0),
+                    (ne.own_index, ne.own_type, 0.0, True, 1), (ne.foreign_index, ne.foreign_type, 0.0, False, 1))
+        t_all = sum(ei.size(1) for ei, _, _, _, _ in sets)
+        if total is None:
+            total = sum(ei.size(1) for ei, _, _, counted, _ in sets if counted)
         # packed {head, tail, rel, g} per triplet for the node-side backward (ids fit int32; one gather instead of four)
         pack = bool(ctx.needs_input_grad[0]) and n < (1 << 31) and r < (1 << 31)
         if padded and not pack:
             raise ValueError("padded triplets need the packed gradient records (z must require grad)")
-        sets = ((pos_ei, pos_et, 1.0), (neg_ei, neg_et, 0.0))
-        n_waves = [L.lib().bkg_kge_fused_bce_waves(ei.size(1), r) if ei.size(1) else 0 for ei, _, _ in sets]
+        if owned is not None and ctx.needs_input_grad[0] and not pack:
+            raise ValueError("both-owner scoring needs the packed gradient records (table rows and relations < 2^31)")
+        n_waves = [L.lib().bkg_kge_fused_bce_waves(ei.size(1), r) if ei.size(1) else 0 for ei, _, _, _, _ in sets]
         part = torch.empty(sum(n_waves), dtype=torch.float32, device=dev)      # every wave of a launch writes its slot
         new = torch.zeros if padded else torch.empty
-        rec_all = new(t_pos + t_neg, 4, dtype=torch.int32, device=dev) if pack else None
+        rec_all = new(t_all, 4, dtype=torch.int32, device=dev) if pack else None
+        scores, grads, drel = [], [], None
+        counted_parts = []
         w0 = t0 = 0
-        for (ei, et, label), waves in zip(sets, n_waves):
+        for (ei, et, label, counted, _), waves in zip(sets, n_waves):
             t = ei.size(1)
             s = torch.empty(t, dtype=torch.float32, device=dev)
             rec = rec_all[t0:t0 + t] if (pack and t) else None
             g = torch.empty(t if rec is None else 0, dtype=torch.float32, device=dev)   # g travels inside rec when packed
-            recs.append(rec)
             if t:
                 order, rel_ptr = relation_order_of(et, r + 1 if padded else r)
                 if padded:
@@ -1317,9 +1392,11 @@ class _KgeBceLoss(torch.autograd.Function):
                            t, label, 1.0 / total, L.ptr(inv_total), L.ptr(rel_emb), rel_emb.stride(0), r, L.ptr(order),
                            L.ptr(rel_ptr), L.ptr(s), L.ptr(g) if rec is None else None, L.ptr(rec),
                            L.ptr(part[w0:w0 + waves]), L.ptr(drel_part), drel_part.stride(0), L.stream())
-                # per-relation sum of the waves' partial rows (consecutive waves; fixed order; no atomics)
-                dr = spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
-                drel = dr if drel is None else drel + dr
+                if counted:
+                    # per-relation sum of the waves' partial rows (consecutive waves; fixed order; no atomics)
+                    dr = spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
+                    drel = dr if drel is None else drel + dr
+                    counted_parts.append(part[w0:w0 + waves])
             scores.append(s)
             grads.append(g)
             w0, t0 = w0 + waves, t0 + t
@@ -1327,29 +1404,44 @@ class _KgeBceLoss(torch.autograd.Function):
             drel = torch.zeros_like(rel_emb)
         ctx.kind, ctx.comm, ctx.reg = kind, comm, float(reg)
         ctx.reg_rows = reg_rows
-        ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
+        ctx.owned = owned
         ctx.n_real = rows
         ctx.padded = padded
-        ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel, recs[0], recs[1], z if (reg or padded) else None)
-        ctx.mark_non_differentiable(scores[0], scores[1])
+        if owned is None:
+            ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
+            ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel,
+                                  rec_all[:pos_ei.size(1)] if (pack and pos_ei.size(1)) else None,
+                                  rec_all[pos_ei.size(1):] if (pack and neg_ei.size(1)) else None,
+                                  z if (reg or padded) else None)
+            pos_scores, neg_scores = scores[0], scores[1]
+        else:
+            t_pos = owned[0].n_own + owned[0].n_foreign
+            ctx.graphs = None
+            ctx.save_for_backward(zt, rel_emb, None, None, drel, rec_all[:t_pos] if (pack and t_pos) else None,
+                                  rec_all[t_pos:] if (pack and t_all > t_pos) else None, z if reg else None)
+            pos_scores, neg_scores = scores[0], scores[2]           # (the sets the rank counts)
+        ctx.mark_non_differentiable(pos_scores, neg_scores)
         if padded:   # BCE mean + L2 over the real rows in ONE launch (a captured mini-batch step is bound by its launch count)
             out = torch.empty((), dtype=torch.float32, device=dev)
             L.call("bkg_kge_loss_finish_f32", L.ptr(part), part.numel(), 0.0, L.ptr(inv_total), L.ptr(z), z.stride(0),
                    z.size(0), d, L.ptr(rows), L.ptr(rel_emb), rel_emb.stride(0), r, float(reg),
                    L.ptr(_finish_scratch(dev)), L.ptr(out), L.stream())
-            return out, scores[0], scores[1]
-        loss = part.sum(dtype=torch.float64) / total
+            return out, pos_scores, neg_scores
+        if owned is None:
+            loss = part.sum(dtype=torch.float64) / total
+        else:
+            loss = sum((p_.sum(dtype=torch.float64) for p_ in counted_parts),
+                       torch.zeros((), dtype=torch.float64, device=dev)) / total
         if reg:      # + reg * (mean(z^2) + mean(rel_emb^2)), reference kge_module.py:128-129: two one-launch norms
             z_rows = z.size(0) if reg_rows is None else reg_rows        # a partitioned step: the mean over N / world rows
             loss = loss + reg * (torch.linalg.vector_norm(z).double().pow(2) / (z_rows * z.size(1))
                                  + torch.linalg.vector_norm(rel_emb).double().pow(2) / rel_emb.numel())
-        return loss.float(), scores[0], scores[1]
+        return loss.float(), pos_scores, neg_scores
 
     @staticmethod
     def backward(ctx, gloss, _gp, _gn):
         zt, rel_emb, g_pos, g_neg, drel, rec_pos, rec_neg, z_reg = ctx.saved_tensors
-        pos_ei, pos_et, neg_ei, neg_et = ctx.graphs
-        kind = ctx.kind
+        kind, owned = ctx.kind, ctx.owned
         n, d = zt.size(0), zt.size(1)
         zt_bf16 = int(zt.dtype == torch.bfloat16)
         z = zt
@@ -1362,54 +1454,65 @@ class _KgeBceLoss(torch.autograd.Function):
                 else:
                     l1 = torch.empty(n, dtype=torch.float32, device=z.device)
                     L.call("bkg_row_l1norm_f32", L.ptr(z), z.stride(0), n, d, L.ptr(l1), L.stream())
-            dz = torch.empty(n, d, dtype=torch.float32, device=z.device)
+            # the incidence structures: (edge_index, edge_type, g, rec, incidence, triplets, rows of dz, first table row)
+            if owned is None:
+                pos_ei, pos_et, neg_ei, neg_et = ctx.graphs
+                groups = [(ei, et, g, rec, (incidence_of(ei, n) if ei.size(1) else None), ei.size(1), n, 0)
+                          for ei, et, g, rec in ((pos_ei, pos_et, g_pos, rec_pos), (neg_ei, neg_et, g_neg, rec_neg))]
+            else:
+                groups = [(None, ts.own_type, None, rec, (ts.incidence if ts.n_own + ts.n_foreign else None),
+                           ts.n_own + ts.n_foreign, ts.n_local, ts.row0)
+                          for ts, rec in ((owned[0], rec_pos), (owned[1], rec_neg))]
+            n_rows = groups[0][6]
+            dz = torch.empty(n_rows, d, dtype=torch.float32, device=z.device)
             first = True
-            for ei, et, g, rec in ((pos_ei, pos_et, g_pos, rec_pos), (neg_ei, neg_et, g_neg, rec_neg)):
-                if ei.size(1) == 0:
+            for ei, et, g, rec, inc, t, _, row0 in groups:
+                if t == 0 or inc is None:
                     continue
-                inc = incidence_of(ei, n)
+                n_inc = 2 * t if owned is None else inc.n_inc
+                if n_inc == 0:
+                    continue
                 sp = inc.split.use() if inc.split is not None else None
                 partials = sp.partials(d, z.device) if sp is not None else None
                 # algorithmic bytes: per incidence the OTHER endpoint's row + the 16-byte record + the incidence id; per
                 # node the fp32 gradient row (read back too when accumulating the second triplet set) + its row pointer
+                by = n_inc * (d * zt.element_size() + 16 + 4) + n_rows * (4 * d * (1 if first else 2) + 4)
                 stream = (KGE_BWD_STREAMS and kind == KGE_DISTMULT and sp is not None and rec is not None
                           and (rel_emb.size(0) + 1) * d * 4 <= 65536 and n < (1 << 31))
                 if stream:
                     # the lists' streams in list order: other endpoint and relation id once per structure (cached on it:
                     # the positives keep theirs, fresh negatives build them with their g), g every step -- then the list
                     # reduce runs like the SpMM's (csrc/kge_bwd_nodes.hip, "stream form")
-                    n_inc = 2 * ei.size(1)
                     gs = torch.empty(n_inc, dtype=torch.float32, device=z.device)
                     # (priced like the one-pass form: the streams' extra 16 bytes per incidence are this form's own traffic)
-                    with _Timed("kge_bwd_nodes" if not ctx.padded else None,
-                                2 * ei.size(1) * (d * zt.element_size() + 16 + 4) + n * (4 * d * (1 if first else 2) + 4), d=d):
-                        of = (et.data_ptr(), et._version)
-                        fresh = getattr(inc, "streams_of", None) != of
+                    with _Timed("kge_bwd_nodes" if not ctx.padded else None, by, d=d):
+                        # the two fixed streams belong to (this incidence structure, this relation-id tensor OBJECT at this
+                        # version): an id tensor re-allocated at the same address (fix_edge_id's full_like every step) is
+                        # another object and rebuilds them
+                        held = getattr(inc, "streams_of", None)
+                        fresh = held is None or held[0]() is not et or held[1] != et._version
                         if fresh:
                             inc.other = torch.empty(n_inc, dtype=torch.int32, device=z.device)
                             inc.relid = torch.empty(n_inc, dtype=torch.int32, device=z.device)
-                            inc.streams_of = of
-                        L.call("bkg_kge_incidence_streams", L.ptr(inc.perm), n_inc, ei.size(1), None, None, None, L.ptr(rec),
+                            inc.streams_of = (weakref.ref(et), et._version)
+                        L.call("bkg_kge_incidence_streams", L.ptr(inc.perm), n_inc, t, None, None, None, L.ptr(rec),
                                None, L.ptr(inc.other) if fresh else None, L.ptr(inc.relid) if fresh else None, L.ptr(gs),
                                L.stream())
-                        L.call("bkg_kge_bwd_stream_f32", L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(rel_emb),
+                        L.call("bkg_kge_bwd_stream_f32", L.ptr(zt), zt_bf16, zt.stride(0), n_rows, d, L.ptr(rel_emb),
                                rel_emb.stride(0), rel_emb.size(0), L.ptr(inc.other), L.ptr(inc.relid), L.ptr(gs), L.ptr(dz),
                                dz.stride(0), L.sref(sp.c), L.ptr(partials), 0 if first else 1, L.stream())
                     first = False
                     continue
-                with _Timed("kge_bwd_nodes" if not ctx.padded else None,
-                            2 * ei.size(1) * (d * zt.element_size() + 16 + 4) + n * (4 * d * (1 if first else 2) + 4), d=d):
-                    L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(ei[0]), L.ptr(ei[1]),
-                           L.ptr(et), ei.size(1), L.ptr(rel_emb), rel_emb.stride(0), rel_emb.size(0), L.ptr(g), L.ptr(rec),
-                           L.ptr(l1),
-                           L.ptr(inc.rowptr),
+                with _Timed("kge_bwd_nodes" if not ctx.padded else None, by, d=d):
+                    L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), n_rows, d,
+                           L.ptr(ei[0]) if ei is not None else None, L.ptr(ei[1]) if ei is not None else None,
+                           L.ptr(et) if ei is not None else None, t, L.ptr(rel_emb), rel_emb.stride(0), rel_emb.size(0),
+                           L.ptr(g) if g is not None else None, L.ptr(rec), L.ptr(l1), L.ptr(inc.rowptr),
                            L.ptr(inc.perm), L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None),
-                           L.ptr(partials), 0 if first else 1, L.stream())
+                           L.ptr(partials), 0 if first else 1, row0, L.stream())
                 first = False
             if first:
                 dz.zero_()
-            if ctx.comm is not None:
-                dz = ctx.comm.reduce_scatter(dz)          # the owners' sums of every rank's triplet share
             if ctx.padded:       # dz * gloss + the L2 term's 2 reg z / (real rows * d) on the real rows: one launch
                 gl = gloss.reshape(1).contiguous()
                 L.call("bkg_scale_add_rows_f32", L.ptr(dz), dz.stride(0), L.ptr(z_reg), z_reg.stride(0), n, d, L.ptr(gl),
@@ -1439,13 +1542,25 @@ class _KgeBceLoss(torch.autograd.Function):
                 drel_out = drel * gloss
                 if ctx.reg:
                     drel_out = torch.addcmul(drel_out, rel_emb, gloss * (2.0 * ctx.reg / rel_emb.numel()))
-        return dz, drel_out, None, None, None, None, None, None, None, None, None, None, None
+        return dz, drel_out, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind, comm=None, total=None,
+def kge_bce_loss_owned(z_local, rel_emb, pos: OwnedTriplets, neg: OwnedTriplets, kind, comm, total, reg=0.0, reg_rows=None):
+    """The same op over a node-partitioned rank's triplets (``_KgeBceLoss`` with ``owned``): ``z_local`` is the rank's
+    shard, the triplets are table slots, ``total`` the count the BCE sum is divided by (global count / world)."""
+    L.require_cuda(z_local, rel_emb)
+    if reg and reg_rows is None:
+        raise ValueError("the L2 term of a partitioned step needs reg_rows = N / world (the rows its mean runs over)")
+    if comm is not None and not comm.live:
+        comm = None
+    e2 = torch.empty(2, 0, dtype=torch.int64, device=z_local.device)
+    return _KgeBceLoss.apply(_f32c(z_local), _f32c(rel_emb), e2, e2[0], e2, e2[0], kind, comm, total, float(reg), None,
+                             None, reg_rows, (pos, neg))
+
+
+def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind, total=None,
                  reg=0.0, inv_total=None, rows=None, reg_rows=None):
-    """``comm`` (node-partitioned training, biomedkg_amd/partition.py): ``z`` is the rank's shard, the triplet ids are
-    slots of the all-gathered table; ``total``: the count the BCE sum is divided by (default: this call's triplets);
+    """(Node-partitioned training: ``kge_bce_loss_owned``.)  ``total``: the count the BCE sum is divided by (default: this call's triplets);
     ``reg``: adds ``reg * (mean(z^2) + mean(rel_emb^2))`` (the reference's L2 term) inside the same op.
     ``inv_total`` / ``rows`` (padded mini-batches of a captured step, biomedkg_amd/sampled.py): the BCE sum is multiplied
     by the DEVICE scalar ``inv_total``, triplets with relation id ``R`` (one past the real ones) are pads, and the mean
@@ -1457,14 +1572,11 @@ def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_
             # (the reference fails here too -- a broadcast error in decode -- e.g. when negative_sampling comes back
             # with fewer pairs than neg_ratio * E on a tiny dense batch; the kernels index one by the other)
             raise ValueError(f"{what} triplets: edge_index {tuple(ei.shape)} and edge_type {tuple(et.shape)} do not match")
-    if reg and comm is not None and reg_rows is None:
-        raise ValueError("the L2 term of a partitioned step needs reg_rows = N / world (the rows its mean runs over)")
-    if inv_total is not None and (comm is not None or inv_total.dtype != torch.float32 or rows is None
-                                  or rows.dtype != torch.int64):
+    if inv_total is not None and (inv_total.dtype != torch.float32 or rows is None or rows.dtype != torch.int64):
         raise ValueError("inv_total (padded mini-batches): a float32 device scalar together with rows = the real row "
-                         "count as an int64 device scalar; no comm on that path")
+                         "count as an int64 device scalar")
     return _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
-                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, comm, total, float(reg),
+                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, None, total, float(reg),
                              inv_total, rows, reg_rows)
 
 

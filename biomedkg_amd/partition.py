@@ -99,6 +99,7 @@ class HaloPattern:
 
 
 HALO_THRESHOLD = float(os.environ.get("BKG_HALO_THRESHOLD", "0.75"))   # halo exchange when every rank reads <= this share
+EXACT_GATHER_WASTE = float(os.environ.get("BKG_EXACT_GATHER_WASTE", "1.1"))   # padded / real rows above which "all" is exact
 
 
 class Comm:
@@ -206,6 +207,19 @@ class Comm:
     def exchange(self, shard, pattern="in"):
         return self.exchange_end(self.exchange_begin(shard, pattern))
 
+    # ---- tables of constant inputs (the first R-GCN layer gathers the node features: the same rows every step)
+    def constant_table(self, holder, shard, pattern="in"):
+        """The gathered table of ``shard`` remembered on ``holder`` (a graph structure), or None.  Valid for this tensor
+        object at this version; the holder keeps the shard alive, so its address cannot be handed to another tensor."""
+        hit = getattr(holder, "_bkg_const_table", None)
+        if (hit is not None and hit[0] is shard and hit[1] == shard._version and hit[2] == pattern
+                and hit[3].device == shard.device):
+            return hit[3]
+        return None
+
+    def remember_table(self, holder, shard, pattern, table):
+        holder._bkg_const_table = (shard, shard._version, pattern, table)
+
     def _count(self, received, sent):
         self.stats["bytes_received"] += int(received)
         self.stats["bytes_sent"] += int(sent)
@@ -222,22 +236,10 @@ class Comm:
         self._waits = []
         return out
 
-    # ---- the two whole-table collectives that remain (small or once per step)
+    # ---- whole-table exchange (once per step: the scorer's embedding table, NT-Xent's rows, GGD's shared first product)
     def all_gather(self, shard):
-        """Every row to every rank (NT-Xent's normalised rows; the scorer's embedding table)."""
+        """Every row to every rank: the plain all-gather for equal shards, exact per-peer counts otherwise (pattern "all")."""
         return self.exchange(shard, pattern="all")
-
-    def reduce_scatter(self, dtable):
-        """``dtable [world * n_max, d]`` (this rank's contribution to every owner) -> the rank's summed ``[n_local, d]``
-        (the scorer's ``dz``: a rank's triplets touch other ranks' nodes)."""
-        if not self.live:
-            return dtable[: self.n_local]
-        dtable = dtable if dtable.is_contiguous() else dtable.contiguous()
-        out = torch.empty(self.n_max, dtable.size(1), dtype=dtable.dtype, device=dtable.device)
-        dist.reduce_scatter_tensor(out, dtable, op=dist.ReduceOp.SUM, group=self.group)
-        el = dtable.element_size() * dtable.size(1) * self.n_max * (self.world - 1)
-        self._count(el, el)
-        return out[: self.n_local]
 
     def all_gather_vector(self, v_local, fill=0.0):
         """``[n_local]`` (or ``[k, n_local]``) per rank -> ``[k, world * n_max]`` in slot order."""
@@ -249,25 +251,6 @@ class Comm:
         out = torch.empty(self.world * v.size(0), self.n_max, dtype=v.dtype, device=v.device)
         dist.all_gather_into_tensor(out, buf, group=self.group)
         return out.view(self.world, v.size(0), self.n_max).permute(1, 0, 2).reshape(v.size(0), self.world * self.n_max)
-
-
-class _GatherRows(torch.autograd.Function):
-    """forward: every rank's rows to every rank (``pattern``); backward: reduce-scatter (sum) of the table gradient.
-    Only for tables whose READERS are not a sparse structure of the graph (the scorer's embedding table)."""
-
-    @staticmethod
-    def forward(ctx, shard, comm):
-        ctx.comm, ctx.dtype = comm, shard.dtype
-        return comm.all_gather(shard)
-
-    @staticmethod
-    def backward(ctx, dtable):
-        # partial tables are summed in fp32 whatever the table's own precision
-        return ctx.comm.reduce_scatter(dtable.float().contiguous()).to(ctx.dtype), None
-
-
-def all_gather_rows(shard, comm):
-    return _GatherRows.apply(shard, comm)
 
 
 # ----------------------------------------------------------------------------- partition
@@ -299,7 +282,20 @@ class NodePartition:
         self.comm = Comm(world, self.n_local, self.n_max, rank=rank)
         self._valid = None
         self.halo_fraction = {}
+        self.padding_waste = 1.0
         if world > 1:
+            # whole-table exchanges (the scorer's embedding table, GGD's paired first product, NT-Xent's rows): the padded
+            # all-gather moves (world - 1) n_max rows to every rank whatever its peers really own -- on the bench graph at
+            # 8 ranks 204,638 rows where the other ranks hold 100,766..125,908 (load-balanced shards of 4,092..29,234
+            # rows).  When that padding is worth more than 10 % somewhere, "every row" becomes a pattern of its own
+            # (exact per-peer counts through the same all-to-all as the halo rows); equal shards keep the all-gather.
+            sizes = [b - a for a, b in zip(bounds[:-1], bounds[1:])]
+            self.padding_waste = (world - 1) * self.n_max / max(self.num_nodes - max(sizes), 1)
+            exact = self.padding_waste > EXACT_GATHER_WASTE if halo is not False else False
+            everything = None
+            if exact:
+                everything = HaloPattern(self, torch.ones(world, self.num_nodes, dtype=torch.bool, device=dev))
+            self.comm.patterns["all"] = everything
             src, dst = edge_index[0], edge_index[1]
             own_s = torch.bucketize(src, self._bounds_t[1:-1], right=True)
             own_d = torch.bucketize(dst, self._bounds_t[1:-1], right=True)
@@ -309,9 +305,10 @@ class NodePartition:
                 pat = HaloPattern(self, needed)
                 self.halo_fraction[name] = pat.max_fraction
                 # every rank takes the same decision (max_fraction is a global quantity): halo rows only when that saves
-                # a clear share of the table, else the plain all-gather (no pack / unpack); halo=True / False forces it
+                # a clear share of the table, else every row (no pack / unpack when the shards are equal: the plain
+                # all-gather); halo=True / False forces it
                 use = pat.max_fraction <= HALO_THRESHOLD if halo is None else bool(halo)
-                self.comm.patterns[name] = pat if use else None
+                self.comm.patterns[name] = pat if use else everything
 
     @staticmethod
     def load_of(edge_index, num_nodes, node_weight):
@@ -490,7 +487,11 @@ class _PartRgcn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_local, weight, root, bias, prg, backend, relu, drop):
         comm, f = prg.part.comm, prg.fwd
-        table = comm.exchange(x_local, "in")
+        table = None if ctx.needs_input_grad[0] else comm.constant_table(prg, x_local)
+        if table is None:
+            table = comm.exchange(x_local, "in")
+            if not ctx.needs_input_grad[0]:                 # a constant input (the node features): gathered once
+                comm.remember_table(prg, x_local, "in", table)
         h = backend.spmm_epilogue(f.seg, f.seg_w, table, f.num_segments, None, None, False, None)
         y = backend.grouped_linear(h, weight, f.rel_ptr)
         out = backend.spmm_epilogue(f.rows, None, y, x_local.size(0), backend.matmul(x_local, root), bias, relu, drop)
@@ -504,14 +505,17 @@ class _PartRgcn(torch.autograd.Function):
         prg, be = ctx.prg, ctx.backend
         comm, f, b = prg.part.comm, prg.fwd, prg.bwd
         dout = be.gate(dout, out, ctx.relu, ctx.drop).contiguous()
-        pending = comm.exchange_begin(dout, "out")                          # crosses the wire under the local products
+        need_dx = ctx.needs_input_grad[0]
+        pending = comm.exchange_begin(dout, "out") if need_dx else None      # crosses the wire under the local products
         dweight = be.grouped_outer(h, dout[f.seg_node], f.rel_ptr, weight.size(0))        # dW_r = H_r^T dY_r
-        droot = x_local.t() @ dout
+        droot = be.matmul_tn(x_local, dout)                                  # x^T dOut, through the backend like every product
         db = dout.sum(0)
-        dtable = comm.exchange_end(pending)
-        t = be.spmm_epilogue(b.seg, b.seg_w, dtable, b.num_segments, None, None, False, None)
-        dxs = be.grouped_linear(t, weight.transpose(1, 2), b.rel_ptr)
-        dx = be.spmm_epilogue(b.rows, None, dxs, x_local.size(0), dout @ root.t(), None, False, None)
+        dx = None
+        if need_dx:
+            dtable = comm.exchange_end(pending)
+            t = be.spmm_epilogue(b.seg, b.seg_w, dtable, b.num_segments, None, None, False, None)
+            dxs = be.grouped_linear(t, weight.transpose(1, 2), b.rel_ptr)
+            dx = be.spmm_epilogue(b.rows, None, dxs, x_local.size(0), be.matmul_nt(dout, root), None, False, None)
         return dx, dweight, droot, db, None, None, None, None
 
 
@@ -561,12 +565,6 @@ def rgcn_encoder_partitioned(encoder, x_local, prg: PartitionedRelGraph, backend
     return _run_stack(encoder.graph_layers, x_local, conv, encoder.training, encoder.drop_out, dropout_of)
 
 
-def gather_embeddings(z_local, part: NodePartition):
-    """Full ``[world * n_max, d]`` table of the final embeddings (autograd: reduce-scatter of dz) for the KGE
-    scorer; index it with ``part.slots(node_ids)``."""
-    return all_gather_rows(z_local, part.comm)
-
-
 # ----------------------------------------------------------------------------- backends
 class HipBackend:
     """The product arithmetic: csrc kernels through ``biomedkg_amd.ops`` / ``graph`` -- the fused single-GPU layers,
@@ -610,6 +608,18 @@ class HipBackend:
     def matmul(x, w):
         from . import ops
         return ops.gemm(x, w)
+
+    @staticmethod
+    def matmul_tn(a, b):
+        """``a^T b`` (weight-gradient shape: the rows are contracted)"""
+        from . import ops
+        return ops.gemm(ops._as_f32(a), ops._as_f32(b), trans_a=True)
+
+    @staticmethod
+    def matmul_nt(a, b):
+        """``a b^T``"""
+        from . import ops
+        return ops.gemm(ops._as_f32(a), ops._as_f32(b), trans_b=True)
 
     @staticmethod
     def gcn_conv(x_local, weight, bias, pg, gw, relu=False, drop=None):
@@ -781,28 +791,104 @@ class _TableView(torch.autograd.Function):
         return out, None, None
 
 
-def kge_loss_partitioned(model, x_local, prg: PartitionedRelGraph, backend, pos_ei, pos_et, neg_ei, neg_et, kind,
-                         dropout_of=None, n_pos_global=None, n_neg_global=None, pos_slots=None):
-    """``KGEModule.training_step``'s loss (reference kge_module.py:110-129) with the encoder over the rank's shard
-    and the scorer over the rank's share of the triplets (``pos_* / neg_*``: global node ids).  The BCE terms are
-    normalised by the GLOBAL triplet count over ``world`` (``n_*_global``; default: equal shares), so the bucket's
-    average is the whole-graph mean.  The scorer reads the all-gathered embedding table (bf16 on the wire in bf16 mode)
-    through slot indices; its gradient comes back through the reduce-scatter."""
-    from . import ops
+class TripletShare:
+    """A rank's share of a triplet list every rank holds (``index [2, T]`` global node ids, ``types [T]``) under
+    both-owner scoring: ``own`` -- the head is one of the rank's nodes: the rank scores it, counts it in the loss and in
+    d rel_emb -- and ``foreign`` -- the tail is local, the head is not: scored again here, for d score only, so that the
+    gradient of the rank's OWN embedding rows is complete without anything coming back over the wire (every triplet is
+    scored by the owner of its head and, when that is another rank, by the owner of its tail; counted once).
+    ``n_own`` first; ``entries``: positions in ``cat(head, tail)`` of the incidences with a local node when the caller
+    knows them by construction (sampling.BlockNegativeSampler), else found with one mask + host read (static positives)."""
+
+    def __init__(self, part, index, types, n_own=None, entries=None):
+        if n_own is None:
+            h_loc, t_loc = part.is_local(index[0]), part.is_local(index[1])
+            own = torch.nonzero(h_loc).squeeze(1)
+            foreign = torch.nonzero(t_loc & ~h_loc).squeeze(1)
+            order = torch.cat([own, foreign])
+            index, types, n_own = index[:, order], types[order], int(own.numel())
+        self.part, self.n_own = part, int(n_own)
+        self.index, self.types = index.contiguous(), types.contiguous()
+        self.slots = part.slots(self.index).contiguous()
+        self.entries = entries
+        self._owned = None
+
+    def owned(self):
+        """The ``ops.OwnedTriplets`` of the fused scorer (built once per share: its incidence lists are cached on it)."""
+        if self._owned is None:
+            from . import ops
+            k, part = self.n_own, self.part
+            self._owned = ops.OwnedTriplets(self.slots[:, :k], self.types[:k], self.slots[:, k:], self.types[k:],
+                                            part.rank * part.n_max if part.comm.live else 0, part.n_local, self.entries)
+        return self._owned
+
+
+class _GatherRowsOwnGrad(torch.autograd.Function):
+    """forward: every rank's rows to every rank; backward: the rank's OWN rows of the table gradient, nothing else --
+    for consumers that complete the gradient of the rank's rows locally (both-owner scoring)."""
+
+    @staticmethod
+    def forward(ctx, shard, comm):
+        ctx.comm, ctx.n = comm, shard.size(0)
+        return comm.all_gather(shard)
+
+    @staticmethod
+    def backward(ctx, dtable):
+        comm = ctx.comm
+        own = comm.own_rows(dtable) if comm.live else dtable
+        return own[: ctx.n], None
+
+
+def _score(table_h, rel_r, table_t, kind):
+    """DistMult / TransE logits (reference decoder.py:45-49 / 31-38) in torch -- the composable form's scorer."""
+    if kind in (0, "dismult", "distmult"):
+        return (table_h * rel_r * table_t).sum(1)
+    hn = table_h / table_h.abs().sum(1, keepdim=True).clamp_min(1e-12)
+    tn = table_t / table_t.abs().sum(1, keepdim=True).clamp_min(1e-12)
+    return -(hn + rel_r - tn).abs().sum(1)
+
+
+def kge_bce_partitioned(z_local, rel, pos: TripletShare, neg: TripletShare, kind, part, total, reg, backend):
+    """BCE over the rank's counted triplets + its nodes' share of the L2 terms (reference kge_module.py:121-129), with the
+    gradients of both-owner scoring: d rel_emb from the counted (head-owned) triplets, dz of the rank's rows from EVERY
+    triplet that touches them.  ``total`` = global triplet count / world; the returned scalar's mean over ranks is the
+    whole-graph loss and the bucket's gradient average the whole-graph gradient.  HipBackend: ONE fused op
+    (``ops.kge_bce_loss_owned``); else the composable torch form."""
+    if backend.fused:
+        from . import ops
+        loss, _, _ = ops.kge_bce_loss_owned(z_local, rel, pos.owned(), neg.owned(), kind, part.comm, total, reg=reg,
+                                            reg_rows=part.num_nodes / part.world)
+        return loss
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    table = _GatherRowsOwnGrad.apply(z_local, part.comm)                     # autograd: own rows only
+    table_d, rel_d = table.detach(), rel.detach()
+    value, for_z = 0.0, 0.0
+    for share, label in ((pos, 1.0), (neg, 0.0)):
+        h, t, r, k = share.slots[0], share.slots[1], share.types, share.n_own
+        if h.numel() == 0:
+            continue
+        y = torch.full((h.numel(),), label, dtype=z_local.dtype, device=z_local.device)
+        # every incident triplet, gradient into the rank's own rows only (the gather hands back nothing else)
+        for_z = for_z + bce(_score(table[h], rel_d[r], table[t], kind), y, reduction="sum")
+        # the counted ones, gradient into the relation table
+        value = value + bce(_score(table_d[h[:k]], rel[r[:k]], table_d[t[:k]], kind), y[:k], reduction="sum")
+    loss = (value + (for_z - for_z.detach() if torch.is_tensor(for_z) else 0.0)) / total
+    if reg:
+        loss = loss + reg * (z_local.pow(2).sum() / (part.num_nodes / part.world * z_local.size(1)) + rel.pow(2).mean())
+    return loss
+
+
+def kge_loss_partitioned(model, x_local, prg: PartitionedRelGraph, backend, pos: TripletShare, neg: TripletShare, kind,
+                         dropout_of=None, n_pos_global=None, n_neg_global=None):
+    """``KGEModule.training_step``'s loss (reference kge_module.py:110-129) with the encoder over the rank's shard and
+    the scorer over the triplets that touch the rank's nodes (``TripletShare``: both-owner scoring).  The BCE terms are
+    normalised by the GLOBAL triplet count over ``world``, so the bucket's average is the whole-graph mean.  The scorer
+    reads the all-gathered embedding table (bf16 on the wire in bf16 mode) through slot indices; its gradient needs no
+    exchange: each rank reduces the lists of its own nodes (round 3 reduce-scattered an fp32 ``[N, d]`` table here)."""
     part = prg.part
     z_local = rgcn_encoder_partitioned(model.encoder, x_local, prg, backend, dropout_of)
-    # (``pos_slots``: the positives' table slots, computed once by a caller whose positives do not change)
-    ps = pos_slots if pos_slots is not None else part.slots(pos_ei)
-    ns = part.slots(neg_ei)
-    rel = model.decoder.rel_emb
-    total = None
-    if n_pos_global is not None:
-        total = (n_pos_global + n_neg_global) / part.world
-    # BCE + the L2 terms in ONE op: every rank adds its nodes' share of mean(z^2) -- sum over its rows / (N / world) rows,
-    # i.e. x world for the gradient average -- and the full rel term (kge_bce_loss(reg_rows=...))
-    loss, _, _ = ops.kge_bce_loss(z_local, rel, ps, pos_et, ns, neg_et, kind, comm=part.comm, total=total, reg=1e-2,
-                                  reg_rows=part.num_nodes / part.world)
-    return loss
+    total = (n_pos_global + n_neg_global) / part.world
+    return kge_bce_partitioned(z_local, model.decoder.rel_emb, pos, neg, kind, part, total, 1e-2, backend)
 
 
 # ----------------------------------------------------------------------------- NT-Xent, rows partitioned

@@ -179,3 +179,109 @@ def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None, seed=Non
             break
     row, col = neg // (n - 1), neg % (n - 1)         # vector_to_edge_index: re-open the diagonal
     return torch.stack([row, col + (row <= col).to(col.dtype)], dim=0)
+
+
+# ----------------------------------------------------------------------------- node-partitioned training
+class BlockNegativeSampler:
+    """Negatives for a node-partitioned KGE step (biomedkg_amd/partition.py, both-owner scoring; csrc/negsample.hip
+    ``bkg_negative_sample_blocks``).  The N x N cell grid is cut by the partition's node ranges into world x world blocks
+    (head owner a, tail owner b).  Block (a, b) draws ``k_ab`` of the ``k`` negatives -- proportional to its FREE cells
+    (off-diagonal cells that are not positives; counted here, once per graph, from the edge list every rank holds), so
+    the union over the blocks is k distinct non-edges, uniform over the free cells, stratified by block with proportional
+    allocation (PyG draws a simple random sample: same marginals) -- from its own keyed permutation seeded by
+    ``(seed, a, b)``.  Rank r draws the blocks of its row band (it owns the heads: these triplets count in its loss) and
+    of its column band (tails local, heads remote: scored for the gradient of its own rows only); the other owner of a
+    block draws the very same triplets, so the scorer's backward needs no exchange at all.  Relation ids: the reference's
+    ``edge_type.repeat(neg_ratio)[randperm(k)]`` (kge_module.py:97-100) evaluated per global position.
+
+    ``draw(seed)`` -> ``(index [2, k_r] global ids, types [k_r], n_own)`` in the fixed layout [block (r, r) | blocks (r, b != r)
+    | blocks (a != r, r)]; ``entries``: positions in ``cat(head, tail)`` of the incidences with a local node (known by
+    construction: no mask, no count read inside the step).  All ranks must pass the same seed."""
+
+    def __init__(self, edge_index, edge_type, bounds, rank, k):
+        L.require_cuda(edge_index, edge_type)
+        dev = edge_index.device
+        world = len(bounds) - 1
+        n = int(bounds[-1])
+        self.n, self.k, self.rank, self.world = n, int(k), int(rank), world
+        self.edge_type = edge_type.contiguous()
+        self.table = _positive_table(edge_index, n)
+        sizes = [bounds[i + 1] - bounds[i] for i in range(world)]
+        # free cells per block: population minus the distinct loop-free positives inside it
+        bt = torch.tensor(bounds[1:-1], device=dev, dtype=torch.int64)
+        keys = _positive_keys(edge_index, n)                                  # distinct off-diagonal codes, sorted
+        row = keys // (n - 1)
+        col = keys % (n - 1)
+        col = col + (row <= col).to(col.dtype)
+        blk = torch.bucketize(row, bt, right=True) * world + torch.bucketize(col, bt, right=True)
+        used = torch.bincount(blk, minlength=world * world).tolist()          # (one host read, once per graph)
+        pop = [sizes[a] * (sizes[b] - 1 if a == b else sizes[b]) for a in range(world) for b in range(world)]
+        free = [p - u for p, u in zip(pop, used)]
+        total_free = sum(free)
+        if self.k > total_free:
+            raise ValueError(f"{self.k} negatives asked of a graph with {total_free} non-edges")
+        # proportional allocation, largest remainders (every rank computes the same table)
+        quota = [self.k * f // total_free for f in free]
+        rem = sorted(range(world * world), key=lambda i: (-(self.k * free[i] % total_free), i))
+        for i in rem[: self.k - sum(quota)]:
+            quota[i] += 1
+        gpos, acc = [], 0
+        for q in quota:
+            gpos.append(acc)
+            acc += q
+        r = self.rank
+        order = [r * world + r] + [r * world + b for b in range(world) if b != r] + [a * world + r for a in range(world) if a != r]
+        rows, cand0, out0 = [], 0, 0
+        self.n_own = 0
+        layout = []                                           # (block id, out0, k) of the rank's blocks, in output order
+        for bid in order:
+            a, b = divmod(bid, world)
+            kq = quota[bid]
+            if kq == 0:
+                layout.append((bid, out0, 0))
+                continue
+            p = free[bid] / pop[bid]
+            # candidates: enough that fewer than kq survivors is a six-sigma event (hypergeometric, variance below the
+            # binomial's); the whole block when that is most of it anyway
+            m = int((kq + 6.0 * (kq * max(1.0 - p, 0.0)) ** 0.5 + 8.0) / p) + 1
+            m = min(max(m, kq), pop[bid])
+            rows.append([bounds[a], sizes[a], bounds[b], sizes[b], pop[bid], cand0, m, out0, kq, gpos[bid], bid])
+            layout.append((bid, out0, kq))
+            cand0 += -(-m // 256) * 256
+            out0 += kq
+            if a == r:
+                self.n_own += kq
+        self.layout, self.k_rank, self.n_cand = layout, out0, cand0
+        self.n_blocks = len(rows)
+        assert L.lib().bkg_negative_blocks_struct_bytes() == 11 * 8
+        self.blocks = torch.tensor(rows if rows else [[0] * 11], dtype=torch.int64, device=dev)
+        self.ws_bytes = L.lib().bkg_negative_sample_workspace_bytes(max(cand0, 1))
+        # incidences with a local node, by construction: heads of the own blocks, tails of block (r, r), tails of the
+        # foreign blocks -- positions in cat(head [k_r], tail [k_r])
+        k_rr = quota[r * world + r]
+        ar = lambda lo, hi: torch.arange(lo, hi, device=dev, dtype=torch.int64)          # noqa: E731
+        self.entries = torch.cat([ar(0, self.n_own), self.k_rank + ar(0, k_rr), self.k_rank + ar(self.n_own, self.k_rank)])
+        self.count = None
+
+    def draw(self, seed, with_types=True):
+        dev = self.blocks.device
+        kr = self.k_rank
+        out = torch.empty(2, kr, dtype=torch.int64, device=dev)
+        types = torch.empty(kr, dtype=torch.int64, device=dev) if with_types else None
+        self.count = torch.zeros(max(self.n_blocks, 1), dtype=torch.int32, device=dev)
+        if self.n_blocks and self.n_cand:
+            keys = torch.empty(self.n_cand, dtype=torch.int64, device=dev)
+            flag = torch.empty(2, self.n_cand, dtype=torch.int32, device=dev)
+            ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+            L.call("bkg_negative_sample_blocks", L.ptr(self.blocks), self.n_blocks, self.n_cand, self.n, int(seed) & ((1 << 64) - 1),
+                   self.k, L.ptr(self.table), self.table.numel(), L.ptr(self.edge_type), self.edge_type.numel(), L.ptr(keys),
+                   L.ptr(flag[0]), L.ptr(flag[1]), L.ptr(out[0]), L.ptr(out[1]), L.ptr(types), L.ptr(self.count), L.ptr(ws),
+                   ws.numel(), L.stream())
+        return out, types, self.n_own
+
+    def shortfall(self):
+        """Negatives the last draw's blocks fell short by (a host read: tests / diagnostics only)."""
+        if self.count is None or not self.n_blocks:
+            return 0
+        want = self.blocks[:, 8].to(torch.int32)
+        return int((want - self.count[: self.n_blocks]).clamp_min(0).sum().item())

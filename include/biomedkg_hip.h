@@ -199,6 +199,8 @@ int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z /* fp32 or bf16 table */, 
                                              head / tail / rel / gscore (one 16-byte gather per incidence) */,
                           const float* l1, const int32_t* inc_rowptr, const int32_t* inc_perm,
                           float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
+                          int64_t self_row0 /* incidence row i is node self_row0 + i of z / l1 (0: a whole graph; a
+                                               node-partitioned rank reduces its own nodes' lists over the gathered table) */,
                           void* stream);
 /* The same DistMult backward over per-incidence STREAMS in list order (what makes it a weighted segment reduce like
  * bkg_spmm_csr_f32: no entry id -> record -> row chain): bkg_kge_incidence_streams writes other[e] (the other endpoint),
@@ -411,6 +413,19 @@ int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int64_t n_cand
                         const uint64_t* pos_table, int64_t pos_capacity, uint64_t* keys_tmp, int32_t* flag_tmp,
                         int32_t* offs_tmp, int64_t* out_head, int64_t* out_tail, int64_t out_offset, int64_t max_out,
                         int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
+/* Block-structured negative sampling for node-partitioned training (biomedkg_amd/partition.py; replaces the per-rank
+ * call of PyG negative_sampling, reference biomedkg/kge_module.py:93, when a graph's nodes are partitioned): the cell grid
+ * is cut into (head owner, tail owner) blocks, each with its own keyed permutation and its share of the K negatives, so the
+ * two owners of a block draw identical triplets and nothing crosses the wire.  blocks: device array of n_blocks
+ * descriptors of bkg_negative_blocks_struct_bytes() bytes (11 int64: row_lo, n_rows, col_lo, n_cols, population, cand0,
+ * n_cand, out0, k, gpos0, id).  out_type[p] = pos_type[sigma(gpos0 + rank) % n_pos]: edge_type.repeat(k)[randperm]
+ * (kge_module.py:97-100) evaluated position by position. */
+int64_t bkg_negative_blocks_struct_bytes(void);
+int bkg_negative_sample_blocks(const void* blocks, int32_t n_blocks, int64_t n_cand_total, int64_t n_nodes, uint64_t seed,
+                               int64_t k_global, const uint64_t* pos_table, int64_t pos_capacity, const int64_t* pos_type,
+                               int64_t n_pos, uint64_t* keys_tmp, int32_t* flag_tmp, int32_t* offs_tmp, int64_t* out_head,
+                               int64_t* out_tail, int64_t* out_type, int32_t* count, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t seed, int64_t* out, void* stream);
 /* torch.randperm over the REAL rows of a padded mini-batch (GGD's corruption, reference biomedkg/model/gcl.py:70-71, inside
  * a captured step): out[i] = pi(i) for i < n_dev[0] (device scalar), pi a bijection of [0, n_dev[0]) keyed by seed and the

@@ -44,6 +44,8 @@ class TorchBackend:
     permute = staticmethod(lambda csr, values: values[csr.perm])
     linear = staticmethod(lambda x, weight, bias=None: F.linear(x, weight, bias))
     matmul = staticmethod(lambda x, w: x @ w)
+    matmul_tn = staticmethod(lambda a, b: a.t() @ b)
+    matmul_nt = staticmethod(lambda a, b: a @ b.t())
 
     @staticmethod
     def spmm_epilogue(csr, w, table, n_out, addend, bias, relu, drop):

@@ -87,7 +87,9 @@ def test_partitioned_training_losses_world1_match_the_modules():
     neg = sampling.negative_sampling(ei, n, ei.size(1), seed=3)
     nt = et[torch.randperm(et.numel(), device=DEV)]
     prg = P.PartitionedRelGraph(part, ei, et, r, P.HipBackend)
-    loss_p = P.kge_loss_partitioned(kge.model, part.shard(x), prg, P.HipBackend, ei, et, neg, nt, kge.model.decoder.kind)
+    loss_p = P.kge_loss_partitioned(kge.model, part.shard(x), prg, P.HipBackend, P.TripletShare(part, ei, et),
+                                    P.TripletShare(part, neg, nt), kge.model.decoder.kind,
+                                    n_pos_global=ei.size(1), n_neg_global=neg.size(1))
     loss_p.backward()
     grads_p = [p.grad.clone() for p in kge.model.parameters()]
     kge.model.zero_grad()
@@ -152,7 +154,9 @@ def test_partitioned_step_world1_in_bf16_mode_runs_the_fused_views_path():
         neg = sampling.negative_sampling(ei, n, ei.size(1), seed=3)
         nt = et[torch.randperm(et.numel(), device=DEV)]
         prg = P.PartitionedRelGraph(part, ei, et, r, P.HipBackend)
-        loss_p = P.kge_loss_partitioned(kge.model, x, prg, P.HipBackend, ei, et, neg, nt, kge.model.decoder.kind)
+        loss_p = P.kge_loss_partitioned(kge.model, x, prg, P.HipBackend, P.TripletShare(part, ei, et),
+                                        P.TripletShare(part, neg, nt), kge.model.decoder.kind,
+                                        n_pos_global=ei.size(1), n_neg_global=neg.size(1))
         loss_p.backward()
         grads_p = [p.grad.clone() for p in kge.model.parameters()]
         kge.model.zero_grad()
@@ -224,9 +228,9 @@ def _two_rank_worker(rank, world, port, outdir):
     neg = sampling.negative_sampling(ei, n, ei.size(1), seed=3)
     nt = et[torch.randperm(et.numel(), generator=torch.Generator().manual_seed(3)).to(DEV)]
     prg = P.PartitionedRelGraph(part, ei, et, r, P.HipBackend)
-    sh = slice(rank, None, world)
-    loss = P.kge_loss_partitioned(kge.model, part.shard(x), prg, P.HipBackend, ei[:, sh].contiguous(), et[sh].contiguous(),
-                                  neg[:, sh].contiguous(), nt[sh].contiguous(), kge.model.decoder.kind,
+    # both-owner scoring: every rank takes, from the SAME global triplet lists, the ones that touch its nodes
+    loss = P.kge_loss_partitioned(kge.model, part.shard(x), prg, P.HipBackend, P.TripletShare(part, ei, et),
+                                  P.TripletShare(part, neg, nt), kge.model.decoder.kind,
                                   n_pos_global=ei.size(1), n_neg_global=neg.size(1))
     loss.backward()
     grads = [p.grad.clone() for p in kge.model.parameters()]
@@ -321,3 +325,236 @@ def test_bench_ends_the_job_when_a_rank_dies():
     assert out.returncode != 0
     assert time.time() - t0 < 300
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+# ------------------------------------------------------------------------------------------- round 4: both-owner scoring
+def _slot_table(part, full):
+    """[N, d] -> the [world * n_max, d] table in slot space (what an all-gather of the shards produces)."""
+    table = torch.zeros(part.world * part.n_max, full.size(1), dtype=full.dtype, device=full.device)
+    table[part.node_slots()] = full
+    return table
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_block_negative_sampler_is_pyg_negative_sampling_cut_by_owner_blocks(world):
+    """sampling.BlockNegativeSampler (csrc/negsample.hip bkg_negative_sample_blocks): over all ranks the counted (head-owned)
+    negatives are K distinct off-diagonal non-edges -- PyG negative_sampling's contract, reference kge_module.py:93 --
+    allotted to the (head owner, tail owner) blocks in proportion to their free cells; the two owners of a block draw the
+    SAME triplets and relation ids; the ids over all K positions are edge_type.repeat(k)[a permutation] (kge_module.py:97-
+    100); the incidence positions handed to the scorer are exactly the entries with a local node; another seed gives
+    other negatives."""
+    from biomedkg_amd import partition as P, sampling, synthetic
+    g = synthetic.primekg_like(3000, 60_000, 8, seed=2)
+    ei, et, n = g["edge_index"].to(DEV), g["edge_type"].to(DEV), g["num_nodes"]
+    ratio = 2
+    k = ratio * ei.size(1)
+    pos_codes = set((ei[0] * n + ei[1]).tolist())
+    blocks, counted = {}, []
+    for rank in range(world):
+        part = P.NodePartition(ei, n, rank, world)
+        smp = sampling.BlockNegativeSampler(ei, et, part.bounds, rank, k)
+        idx, types, n_own = smp.draw(seed=77)
+        assert smp.shortfall() == 0
+        assert idx.shape == (2, smp.k_rank) and types.shape == (smp.k_rank,) and n_own == smp.n_own
+        h_loc, t_loc = part.is_local(idx[0]), part.is_local(idx[1])
+        assert bool(h_loc[:n_own].all()) and not bool(h_loc[n_own:].any()) and bool(t_loc[n_own:].all())
+        # the incidences with a local node, as the sampler lists them by construction
+        flat = idx.reshape(-1)
+        want = torch.nonzero(part.is_local(flat)).squeeze(1)
+        assert torch.equal(torch.sort(smp.entries).values, want)
+        bt = torch.tensor(part.bounds[1:-1], device=DEV)
+        for bid, out0, kq in smp.layout:
+            a, b = divmod(bid, world)
+            h, t = idx[0, out0:out0 + kq], idx[1, out0:out0 + kq]
+            assert bool((torch.bucketize(h, bt, right=True) == a).all()) and bool((torch.bucketize(t, bt, right=True) == b).all())
+            triple = torch.stack([h, t, types[out0:out0 + kq]]).cpu()
+            if bid in blocks:
+                assert torch.equal(blocks[bid], triple), f"the two owners of block {bid} drew different triplets"
+            blocks[bid] = triple
+        counted.append(torch.cat([idx[:, :n_own], types[None, :n_own]]).cpu())
+        again = smp.draw(seed=77)
+        assert torch.equal(again[0], idx) and torch.equal(again[1], types)            # a pure function of (graph, seed)
+        other = smp.draw(seed=78)[0]
+        assert not torch.equal(other, idx)
+    assert len(blocks) == world * world
+    allneg = torch.cat(counted, dim=1)
+    assert allneg.size(1) == k
+    codes = (allneg[0] * n + allneg[1]).tolist()
+    assert len(set(codes)) == k and not (set(codes) & pos_codes)
+    assert bool((allneg[0] != allneg[1]).all())
+    # relation ids: a permutation of edge_type.repeat(ratio) over the K global positions
+    assert torch.equal(torch.sort(allneg[2]).values, torch.sort(et.repeat(ratio)).values.cpu())
+    # quotas follow the blocks' free cells (proportional allocation: within one of the exact share)
+    part = P.NodePartition(ei, n, 0, world)
+    sizes = [b - a for a, b in zip(part.bounds[:-1], part.bounds[1:])]
+    bt = torch.tensor(part.bounds[1:-1], device=DEV)
+    loop_free = ei[:, ei[0] != ei[1]]
+    cells = torch.unique(loop_free[0] * n + loop_free[1])
+    used = torch.bincount(torch.bucketize(cells // n, bt, right=True) * world + torch.bucketize(cells % n, bt, right=True),
+                          minlength=world * world).tolist()
+    free = [sizes[a] * (sizes[b] - (a == b)) - used[a * world + b] for a in range(world) for b in range(world)]
+    for bid in range(world * world):
+        assert abs(blocks[bid].size(1) - k * free[bid] / sum(free)) <= 1.0
+
+
+def test_block_negative_sampler_in_a_block_that_is_mostly_edges():
+    """A dense block (a 60-node clique region: 70 % of its cells are positives) next to sparse ones: its quota follows its
+    FREE cells, its candidates cover the shortfall risk (here: the whole block), nothing is a positive, nothing repeats."""
+    from biomedkg_amd import partition as P, sampling
+    gen = torch.Generator().manual_seed(0)
+    n = 600
+    dense = torch.nonzero(torch.rand(60, 60, generator=gen) < 0.7).t()
+    sparse = torch.randint(0, n, (2, 3000), generator=gen)
+    ei = torch.cat([dense, sparse], dim=1).to(DEV)
+    et = torch.randint(0, 3, (ei.size(1),), generator=gen).to(DEV)
+    pos_codes = set((ei[0] * n + ei[1]).tolist())
+    k = ei.size(1)
+    seen = []
+    for rank in range(4):
+        part = P.NodePartition(ei, n, rank, 4)
+        smp = sampling.BlockNegativeSampler(ei, et, part.bounds, rank, k)
+        idx, types, n_own = smp.draw(seed=5)
+        assert smp.shortfall() == 0
+        seen.append(idx[:, :n_own].cpu())
+    allneg = torch.cat(seen, dim=1)
+    codes = (allneg[0] * n + allneg[1]).tolist()
+    assert allneg.size(1) == k and len(set(codes)) == k and not (set(codes) & pos_codes)
+    assert bool((allneg[0] != allneg[1]).all())
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("decoder", ["dismult", "transe"])
+@pytest.mark.parametrize("size", ["small", "large"])
+def test_both_owner_scoring_equals_the_whole_graph_scorer(mode, decoder, size):
+    """ops.kge_bce_loss_owned over the shards of 1, 3 and 5 simulated ranks (the all-gather replaced by the table it would
+    deliver) against ops.kge_bce_loss on the whole graph: the counted losses add up to the whole loss, every rank's dz is
+    the whole dz of its rows (from its own nodes' incidence lists -- nothing is summed across ranks), the d rel_emb add
+    up.  "large": shards above 4,096 rows (long-row tables, the stream form for DistMult); "small": the one-wave-per-row
+    kernels."""
+    from biomedkg_amd import ops, partition as P, sampling, synthetic
+    n, e = (24_000, 400_000) if size == "large" else (1200, 15_000)
+    g = synthetic.primekg_like(n, e, 8, seed=9)
+    ei, et, r = g["edge_index"].to(DEV), g["edge_type"].to(DEV), g["num_relations"]
+    kind = ops.KGE_DISTMULT if decoder == "dismult" else ops.KGE_TRANSE
+    d = 256
+    torch.manual_seed(3)
+    z = torch.randn(n, d, device=DEV) * 0.3
+    rel = torch.randn(r, d, device=DEV) * 0.3
+    neg = sampling.negative_sampling(ei, n, ei.size(1), seed=11)
+    nt = et[torch.randperm(et.numel(), device=DEV)]
+    ops.set_matmul_precision(mode)
+    try:
+        zw, rw = z.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+        whole, _, _ = ops.kge_bce_loss(zw, rw, ei, et, neg, nt, kind, reg=1e-2)
+        whole.backward()
+        for world in ((1, 3) if size == "large" else (1, 3, 5)):
+            losses, drel = [], torch.zeros_like(rel)
+            dz = torch.zeros_like(z)
+            for rank in range(world):
+                part = P.NodePartition(ei, n, rank, world)
+                zfull = z
+                part.comm.all_gather = lambda shard, part=part: _slot_table(part, zfull.to(shard.dtype))
+                pos_s, neg_s = P.TripletShare(part, ei, et), P.TripletShare(part, neg, nt)
+                zl = part.shard(z).clone().requires_grad_(True)
+                rl = rel.clone().requires_grad_(True)
+                total = (ei.size(1) + neg.size(1)) / world
+                loss = P.kge_bce_partitioned(zl, rl, pos_s, neg_s, kind, part, total, 1e-2, P.HipBackend)
+                loss.backward()
+                losses.append(float(loss))
+                dz[part.lo:part.hi] = zl.grad / world
+                drel += rl.grad / world
+            tol = 1e-5 if mode == "fp32" else 2e-4
+            assert abs(sum(losses) / world - float(whole)) <= tol * abs(float(whole)), (world, losses, float(whole))
+            err_z = float((dz - zw.grad).norm() / zw.grad.norm())
+            err_r = float((drel - rw.grad).norm() / rw.grad.norm())
+            # TransE's gradient is a sum of signs: an element within rounding of zero flips one (as in the single-GPU tests)
+            lim = (1e-5 if mode == "fp32" else 2e-3) if decoder == "dismult" else 5e-3
+            assert err_z < lim and err_r < lim, (world, err_z, err_r)
+    finally:
+        ops.set_matmul_precision("fp32")
+
+
+def _small_shard_worker(rank, world, port, outdir):
+    """bf16 mode, halo exchange forced, shards of a few hundred rows: every row chunk of the first layer's fp32 product is
+    below the streaming kernel's floor (this raised TypeError inside _exchanged_product)."""
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from biomedkg_amd import ops, partition as P, synthetic
+    from biomedkg_amd.model.encoder import GCNEncoder
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops.set_matmul_precision("bf16")
+    g = synthetic.primekg_like(1400, 20_000, 4, seed=8)
+    ei, n = g["edge_index"].to(DEV), g["num_nodes"]
+    part = P.NodePartition(ei, n, rank, world, halo=True)
+    assert 256 <= part.n_local < 1024 and len(part.comm.chunks("in")) == 4
+    torch.manual_seed(0)
+    x = torch.randn(n, 256, device=DEV)
+    enc = GCNEncoder(256, 256, 256, 1).to(DEV).eval()
+    pg = P.PartitionedGraph(part, ei, P.HipBackend)
+    out = P.gcn_encoder_partitioned(enc, part.shard(x).contiguous(), pg, P.HipBackend)
+    out.float().pow(2).sum().backward()
+    grads = [p.grad.clone() for p in enc.parameters()]
+    for t in grads:
+        dist.all_reduce(t)
+    torch.save({"out": out.float().cpu(), "grads": [t.cpu() for t in grads], "lo": part.lo, "hi": part.hi},
+               os.path.join(outdir, f"s{world}_r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_small_shards_with_chunked_halo_exchange_in_bf16_mode(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    from biomedkg_amd import ops, synthetic
+    from biomedkg_amd.model.encoder import GCNEncoder
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_small_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    parts = [torch.load(tmp_path / f"s2_r{i}.pt") for i in range(2)]
+    g = synthetic.primekg_like(1400, 20_000, 4, seed=8)
+    ei, n = g["edge_index"].to(DEV), g["num_nodes"]
+    ops.set_matmul_precision("bf16")
+    try:
+        torch.manual_seed(0)
+        x = torch.randn(n, 256, device=DEV)
+        enc = GCNEncoder(256, 256, 256, 1).to(DEV).eval()
+        ref = enc(x, ei)
+        ref.float().pow(2).sum().backward()
+        got = torch.cat([p["out"] for p in parts]).to(DEV)
+        assert float((got - ref.float()).norm() / ref.float().norm()) < 2e-2
+        for a, p in zip(parts[0]["grads"], enc.parameters()):
+            assert float((a.to(DEV) - p.grad).norm() / p.grad.norm().clamp_min(1e-12)) < 3e-2
+    finally:
+        ops.set_matmul_precision("fp32")
+
+
+@pytest.mark.parametrize("ranks", [4, 8])
+def test_bench_partitioned_on_four_and_eight_ranks_of_one_device(ranks):
+    """``python3 bench.py --gpus 4`` / ``--gpus 8`` exactly as the driver's SCALE run issues it, with the ranks sharing
+    this box's one GPU over gloo (BKG_BENCH_ONE_DEVICE / BKG_BENCH_BACKEND): skewed load-balanced shards, row chunks with
+    empty per-peer lists, uneven and zero all-to-all counts, both-owner scoring with the block sampler -- and the exact-
+    fp32 check losses of the N-rank run equal the one-rank run's (same graph, same weights, same draws)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BKG_BENCH_ONE_DEVICE="1", BKG_BENCH_BACKEND="gloo")
+    common = ["--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"]
+    lines = {}
+    for n in (1, ranks):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--mode", "partition"] + common,
+                             env=env, capture_output=True, text=True, timeout=1500)
+        assert out.returncode == 0, out.stderr[-3000:]
+        got = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(got) == 1, out.stdout[-2000:]
+        lines[n] = json.loads(got[0])
+    line = lines[ranks]
+    assert line["n_gpus"] == ranks and line["ranks"] == ranks and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["parallelism"] == f"np{ranks}"
+    ex = line["exchange"]
+    assert ex is not None and ex["wire_bytes_received_per_step"] > 0 and ex["exchanges_per_step"] > 0
+    assert len(ex["rows"]["bounds"]) == ranks + 1
+    for key in ("ggd", "kge"):
+        a, b = lines[1]["check_loss"][key], line["check_loss"][key]
+        assert abs(a - b) <= 1e-5 * abs(a), (key, a, b)
