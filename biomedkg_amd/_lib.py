@@ -87,14 +87,14 @@ SIGNATURES = {
     "bkg_ntxent_rows_backward_workspace_floats": (I64, [I64, I64, I32, I32]),
     "bkg_ntxent_rows_backward": (I32, [P, I32, P, P, P, P, I64, I32, F32, P, I64, I64, F32, P, P, I64, P, I64, P]),
     # sample.hip
-    "bkg_random_walk": (I32, [P, P, P, I64, I32, U64, P, P]),
-    "bkg_sample_neighbors": (I32, [P, P, I64, I32, U64, U32, P, P]),
+    "bkg_random_walk": (I32, [P, P, P, I64, I32, U64, P, P, P]),
+    "bkg_sample_neighbors": (I32, [P, P, I64, I32, U64, U32, P, P, P]),
     "bkg_neighbor_workspace_bytes": (I64, [I64, I32]),
     "bkg_neighbor_begin": (I32, [P, I64, I64, P, P, P, P]),
-    "bkg_neighbor_hop": (I32, [P, P, P, I64, I32, U64, U32, P, P, P, P, P, P, P, P, I64, P, P, P, P, I64, P]),
+    "bkg_neighbor_hop": (I32, [P, P, P, I64, I32, U64, U32, P, P, P, P, P, P, P, P, P, I64, P, P, P, P, I64, P]),
     "bkg_neighbor_finish": (I32, [I64, P, P, P, I64, P, P, P]),
     "bkg_saint_batch_workspace_bytes": (I64, [I64, I64]),
-    "bkg_saint_batch": (I32, [P, P, P, I64, I32, U64, P, P, P, P, P, I64, I64, P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P,
+    "bkg_saint_batch": (I32, [P, P, P, I64, I32, U64, P, P, P, P, P, P, I64, I64, P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P,
                               P, P, I64, P]),
     # rank.hip
     "bkg_rank_true_score_f32": (I32, [P, I64, P, I64, P, I64, I32, P, P]),

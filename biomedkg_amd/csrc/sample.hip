@@ -6,6 +6,10 @@
 // Here the graph's CSRs already live in HBM, so sampling is two small kernels and the batch never leaves
 // the device.  Randomness: Philox4x32-7 keyed by (seed, draw id) -- reproducible per seed, not bit-equal to
 // the host RNG streams of the upstream loaders (their streams cannot be reproduced on a device).
+// Replay (parity tests, oracle/samplers.py): every entry point takes an optional TAPE of raw 32-bit words that replaces
+// the Philox stream -- walks: word [w, step]; neighbour picks: word [node id, Floyd step] (keyed by the NODE, not by its
+// position in the frontier: a node is expanded once, so the tape means the same to a sampler that orders its frontier
+// differently) -- mapped to an index by the same multiply-shift.  The CPU oracle consumes the same tape.
 #include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
@@ -18,15 +22,18 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t ctr, uint32_
 }
 
 // uniform integer in [0, n) without modulo bias worth speaking of (n <= 2^31): multiply-shift
+__device__ __forceinline__ uint32_t below(uint32_t word, uint32_t n) { return (uint32_t)(((uint64_t)word * n) >> 32); }
 __device__ __forceinline__ uint32_t rng_below(uint64_t seed, uint64_t ctr, uint32_t lane, uint32_t n) {
-  return (uint32_t)(((uint64_t)rng_u32(seed, ctr, lane) * n) >> 32);
+  return below(rng_u32(seed, ctr, lane), n);
 }
+constexpr int TAPE_STRIDE = 64;      // words per node of a neighbour-pick tape (= the largest fan-out)
 
 // walks[w, 0] = start[w]; walks[w, s+1] = a uniformly chosen out-neighbour of walks[w, s] (stays put on a sink),
 // over the SOURCE-sorted CSR (rowptr/col).  torch-sparse random_walk semantics.
 __global__ void random_walk_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                    const int64_t* __restrict__ start, int64_t n_walks, int walk_length, uint64_t seed,
-                                   const uint32_t* __restrict__ epoch, int64_t n_nodes, int64_t* __restrict__ walks) {
+                                   const uint32_t* __restrict__ epoch, int64_t n_nodes, const uint32_t* __restrict__ tape,
+                                   int64_t* __restrict__ walks) {
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_walks) return;
   if (epoch) seed += (uint64_t)epoch[0] * 0x9E3779B97F4A7C15ull;   // captured replays: a fresh stream per replay
@@ -35,7 +42,9 @@ __global__ void random_walk_kernel(const int32_t* __restrict__ rowptr, const int
   walks[w * (walk_length + 1)] = cur;
   for (int s = 0; s < walk_length; ++s) {
     const int beg = rowptr[cur], deg = rowptr[cur + 1] - beg;
-    if (deg > 0) cur = col[beg + rng_below(seed, (uint64_t)w, (uint32_t)s, (uint32_t)deg)];
+    if (deg > 0)
+      cur = col[beg + (tape ? below(tape[w * walk_length + s], (uint32_t)deg)
+                            : rng_below(seed, (uint64_t)w, (uint32_t)s, (uint32_t)deg))];
     walks[w * (walk_length + 1) + s + 1] = cur;
   }
 }
@@ -46,7 +55,7 @@ __global__ void random_walk_kernel(const int32_t* __restrict__ rowptr, const int
 template <int MAXF>
 __global__ void sample_neighbors_kernel(const int32_t* __restrict__ rowptr, const int64_t* __restrict__ frontier,
                                         int64_t n_frontier, int fanout, uint64_t seed, uint32_t hop,
-                                        int32_t* __restrict__ out_pos) {
+                                        const uint32_t* __restrict__ tape, int32_t* __restrict__ out_pos) {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_frontier) return;
   const int64_t v = frontier[f];
@@ -59,7 +68,9 @@ __global__ void sample_neighbors_kernel(const int32_t* __restrict__ rowptr, cons
   int picked[MAXF];
   int n = 0;
   for (int j = deg - fanout; j < deg; ++j) {   // Floyd: t uniform in [0, j]; take t, or j if t was taken
-    int t = (int)rng_below(seed, (uint64_t)f * 64 + (uint64_t)(j - (deg - fanout)), hop, (uint32_t)(j + 1));
+    const int step = j - (deg - fanout);
+    int t = (int)(tape ? below(tape[v * TAPE_STRIDE + step], (uint32_t)(j + 1))
+                       : rng_below(seed, (uint64_t)f * 64 + (uint64_t)step, hop, (uint32_t)(j + 1)));
     bool seen = false;
     for (int q = 0; q < n; ++q) seen |= picked[q] == t;
     picked[n++] = seen ? j : t;
@@ -138,7 +149,7 @@ __global__ void nb_begin_kernel(const int64_t* __restrict__ seeds, int64_t n_see
 template <int MAXF>
 __global__ void nb_sample_kernel(const int32_t* __restrict__ rowptr, const int64_t* __restrict__ n_id,
                                  const int64_t* __restrict__ ctr, int fanout, uint64_t seed, uint32_t hop,
-                                 int32_t* __restrict__ out_pos) {
+                                 const uint32_t* __restrict__ tape, int32_t* __restrict__ out_pos) {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t lo = ctr[0], cnt = ctr[1] - ctr[0];
   if (f >= cnt) return;
@@ -152,7 +163,9 @@ __global__ void nb_sample_kernel(const int32_t* __restrict__ rowptr, const int64
   int picked[MAXF];
   int n = 0;
   for (int j = deg - fanout; j < deg; ++j) {   // Floyd, as sample_neighbors_kernel
-    int t = (int)rng_below(seed, (uint64_t)f * 64 + (uint64_t)(j - (deg - fanout)), hop, (uint32_t)(j + 1));
+    const int step = j - (deg - fanout);
+    int t = (int)(tape ? below(tape[v * TAPE_STRIDE + step], (uint32_t)(j + 1))
+                       : rng_below(seed, (uint64_t)f * 64 + (uint64_t)step, hop, (uint32_t)(j + 1)));
     bool taken = false;
     for (int q = 0; q < n; ++q) taken |= picked[q] == t;
     picked[n++] = taken ? j : t;
@@ -236,11 +249,11 @@ __global__ void nb_relabel_kernel(const int32_t* __restrict__ lut, const int64_t
 using namespace bkg;
 
 extern "C" int bkg_random_walk(const int32_t* rowptr, const int32_t* col, const int64_t* start, int64_t n_walks,
-                               int32_t walk_length, uint64_t seed, int64_t* walks, void* stream) {
+                               int32_t walk_length, uint64_t seed, const uint32_t* tape, int64_t* walks, void* stream) {
   BKG_ARG(n_walks >= 0 && walk_length >= 0, "bkg_random_walk: bad sizes");
   if (n_walks == 0) return 0;
   hipLaunchKernelGGL(random_walk_kernel, dim3(ceil_div(n_walks, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col,
-                     start, n_walks, walk_length, seed, (const uint32_t*)nullptr, (int64_t)0, walks);
+                     start, n_walks, walk_length, seed, (const uint32_t*)nullptr, (int64_t)0, tape, walks);
   return check_launch("bkg_random_walk");
 }
 
@@ -254,7 +267,8 @@ extern "C" int64_t bkg_saint_batch_workspace_bytes(int64_t n_nodes, int64_t n_ed
 // One GraphSAINT random-walk batch, entirely on the device (see the kernels above).  node_flag / node_offs / lut:
 // int32[n_nodes] scratch (lut = local id or -1 survives the call); edge_flag / edge_offs: int32[n_edges] scratch.
 extern "C" int bkg_saint_batch(const int32_t* rowptr, const int32_t* col, const int64_t* start, int64_t n_walks,
-                               int32_t walk_length, uint64_t seed, const uint32_t* epoch, int64_t* walks,
+                               int32_t walk_length, uint64_t seed, const uint32_t* epoch, const uint32_t* tape,
+                               int64_t* walks,
                                const int64_t* src, const int64_t* dst, const int64_t* type, int64_t n_nodes,
                                int64_t n_edges, int32_t* node_flag, int32_t* node_offs, int32_t* lut, int32_t* edge_flag,
                                int32_t* edge_offs, int64_t node_cap, int64_t edge_cap, int64_t pad_node, int64_t pad_types, int64_t* n_id,
@@ -264,8 +278,9 @@ extern "C" int bkg_saint_batch(const int32_t* rowptr, const int32_t* col, const 
               n_nodes < (1ll << 31) && n_edges < (1ll << 31), "bkg_saint_batch: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_entries = n_walks * (walk_length + 1);
+  BKG_ARG(!tape || start, "bkg_saint_batch: a replayed tape needs explicit roots");
   hipLaunchKernelGGL(random_walk_kernel, dim3(ceil_div(n_walks, 256)), dim3(256), 0, s, rowptr, col, start, n_walks,
-                     walk_length, seed, epoch, n_nodes, walks);
+                     walk_length, seed, epoch, n_nodes, tape, walks);
   fill_u32(node_flag, 0u, n_nodes, s);
   hipError_t e = hipSuccess;
   hipLaunchKernelGGL(saint_mark_kernel, dim3(ceil_div(n_entries, 256)), dim3(256), 0, s, walks, n_entries, node_flag);
@@ -287,11 +302,11 @@ extern "C" int bkg_saint_batch(const int32_t* rowptr, const int32_t* col, const 
 }
 
 extern "C" int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* frontier, int64_t n_frontier, int32_t fanout,
-                                    uint64_t seed, uint32_t hop, int32_t* out_pos, void* stream) {
+                                    uint64_t seed, uint32_t hop, const uint32_t* tape, int32_t* out_pos, void* stream) {
   BKG_ARG(n_frontier >= 0 && fanout > 0 && fanout <= 64, "bkg_sample_neighbors: 1 <= fanout <= 64");
   if (n_frontier == 0) return 0;
   hipLaunchKernelGGL(sample_neighbors_kernel<64>, dim3(ceil_div(n_frontier, 256)), dim3(256), 0, (hipStream_t)stream,
-                     rowptr, frontier, n_frontier, fanout, seed, hop, out_pos);
+                     rowptr, frontier, n_frontier, fanout, seed, hop, tape, out_pos);
   return check_launch("bkg_sample_neighbors");
 }
 
@@ -316,7 +331,8 @@ extern "C" int bkg_neighbor_begin(const int64_t* seeds, int64_t n_seeds, int64_t
 }
 
 extern "C" int bkg_neighbor_hop(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t n_nodes,
-                                int32_t fanout, uint64_t seed, uint32_t hop, int32_t* seen, int64_t* n_id, int64_t* ctr,
+                                int32_t fanout, uint64_t seed, uint32_t hop, const uint32_t* tape, int32_t* seen,
+                                int64_t* n_id, int64_t* ctr,
                                 int32_t* pos, int32_t* new_flag, int32_t* node_offs, int32_t* eflag, int32_t* edge_offs,
                                 int64_t edge_cap, int64_t* e_src, int64_t* e_dst, int64_t* e_id, void* workspace,
                                 int64_t workspace_bytes, void* stream) {
@@ -324,7 +340,7 @@ extern "C" int bkg_neighbor_hop(const int32_t* rowptr, const int32_t* col, const
   hipStream_t s = (hipStream_t)stream;
   const int64_t slots = n_nodes * fanout;
   hipLaunchKernelGGL(nb_sample_kernel<64>, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, rowptr, n_id, ctr, fanout, seed,
-                     hop, pos);
+                     hop, tape, pos);
   fill_u32(new_flag, 0u, n_nodes, s);
   hipError_t e = hipSuccess;
   hipLaunchKernelGGL(nb_flags_kernel, dim3(ceil_div(slots, 256)), dim3(256), 0, s, pos, col, ctr, fanout, slots, seen,

@@ -106,7 +106,7 @@ class SaintDeviceSampler:
         csr = self.graph.by_src
         L.call("bkg_saint_batch", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(self.start) if start is not None else None,
                self.batch_size, self.walk_length,
-               self.seed, L.ptr(self.epoch) if use_epoch else None, L.ptr(self.walks), L.ptr(self.edge_index[0]),
+               self.seed, L.ptr(self.epoch) if use_epoch else None, None, L.ptr(self.walks), L.ptr(self.edge_index[0]),
                L.ptr(self.edge_index[1]), L.ptr(self.edge_type), self.num_nodes, self.num_edges, L.ptr(self._node[0]),
                L.ptr(self._node[1]), L.ptr(self._node[2]), L.ptr(self._edge[0]), L.ptr(self._edge[1]), self.node_cap,
                self.edge_cap, self.pad_node, self.pad_types, L.ptr(v["n_id"]), L.ptr(v["src"]), L.ptr(v["dst"]), L.ptr(v["type"]),

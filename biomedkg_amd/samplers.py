@@ -31,6 +31,16 @@ def rows_of(table, n_id):
     return x
 
 
+def _tape_words(tape, shape):
+    """A replay tape as the kernels read it: contiguous 32-bit words on the device (None stays None)."""
+    if tape is None:
+        return None
+    L.require_cuda(tape)
+    if tape.element_size() != 4 or tuple(tape.shape) != tuple(shape) or tape.is_floating_point():
+        raise ValueError(f"replay tape: expected {tuple(shape)} 32-bit integer words, got {tuple(tape.shape)} {tape.dtype}")
+    return tape.contiguous()
+
+
 def _relabel(n_id, num_nodes, *ids):
     lut = torch.full((num_nodes,), -1, dtype=torch.int64, device=n_id.device)
     lut[n_id] = torch.arange(n_id.numel(), device=n_id.device)
@@ -65,18 +75,20 @@ class NeighborSampler:
     def one_read_ok(self):
         return self.num_nodes * max(min(k if k > 0 else 64, 64) for k in self.num_neighbors) < (1 << 31)
 
-    def sample(self, seeds):
+    def sample(self, seeds, tape=None):
         """One host read per batch (node and edge counts) instead of three per hop; the same batch, draw for draw, as
-        ``sample_hop_by_hop``."""
+        ``sample_hop_by_hop``.  ``tape`` (parity tests): ``[num_nodes, 64]`` raw 32-bit words (int32 / uint32 storage)
+        that replace the Philox stream -- node v's Floyd step s reads ``tape[v, s]`` (oracle/samplers.py reads the same)."""
+        tape = _tape_words(tape, (self.num_nodes, 64))
         if not self.one_read_ok() or seeds.numel() == 0:
-            return self.sample_hop_by_hop(seeds)
-        st = self.enqueue(seeds)
+            return self.sample_hop_by_hop(seeds, tape)
+        st = self.enqueue(seeds, tape)
         _, nn, ne = st["ctr"].tolist()                                       # the one host read of the batch
         ei = torch.stack([st["e_src"][:ne], st["e_dst"][:ne]])
         ei._bkg_dst_sorted = ei._version      # frontier nodes are expanded in local-id order, hop after hop: targets ascend (graph.Graph)
         return st["n_id"][:nn].clone(), ei, st["e_id"][:ne].clone()
 
-    def enqueue(self, seeds):
+    def enqueue(self, seeds, tape=None):
         """The batch of ``sample`` left in the fixed-capacity device state (``ctr[1]`` nodes in ``n_id``, ``ctr[2]`` edges
         in ``e_src / e_dst / e_id``, already relabelled) -- no host read; biomedkg_amd/sampled_gcl.py trains on it as is."""
         st, csr = self._state(seeds.device), self.graph.by_dst
@@ -87,7 +99,7 @@ class NeighborSampler:
         for hop, k in enumerate(self.num_neighbors):
             fan = min(k if k > 0 else 64, 64)
             L.call("bkg_neighbor_hop", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(csr.perm), self.num_nodes, fan,
-                   self.seed * 1_000_003 + self.calls, hop, L.ptr(st["seen"]), L.ptr(st["n_id"]), L.ptr(st["ctr"]),
+                   self.seed * 1_000_003 + self.calls, hop, L.ptr(tape), L.ptr(st["seen"]), L.ptr(st["n_id"]), L.ptr(st["ctr"]),
                    L.ptr(st["pos"]), L.ptr(st["new_flag"]), L.ptr(st["node_offs"]), L.ptr(st["eflag"]),
                    L.ptr(st["edge_offs"]), st["cap"], L.ptr(st["e_src"]), L.ptr(st["e_dst"]), L.ptr(st["e_id"]),
                    L.ptr(st["ws"]), st["ws"].numel(), L.stream())
@@ -95,7 +107,7 @@ class NeighborSampler:
                L.ptr(st["e_src"]), L.ptr(st["e_dst"]), L.stream())
         return st
 
-    def sample_hop_by_hop(self, seeds):
+    def sample_hop_by_hop(self, seeds, tape=None):
         g, dev = self.graph, seeds.device
         csr = g.by_dst
         self.calls += 1
@@ -109,7 +121,7 @@ class NeighborSampler:
             fan = min(k if k > 0 else 64, 64)
             pos = torch.empty(frontier.numel(), fan, dtype=torch.int32, device=dev)
             L.call("bkg_sample_neighbors", L.ptr(csr.rowptr), L.ptr(frontier), frontier.numel(), fan,
-                   self.seed * 1_000_003 + self.calls, hop, L.ptr(pos), L.stream())
+                   self.seed * 1_000_003 + self.calls, hop, L.ptr(tape), L.ptr(pos), L.stream())
             valid = pos >= 0
             p = pos[valid].long()
             src = csr.col[p].long()
@@ -138,12 +150,13 @@ class SaintRandomWalkSampler:
         self.num_nodes, self.batch_size, self.walk_length = int(num_nodes), int(batch_size), int(walk_length)
         self.seed, self.calls = int(seed), 0
 
-    def walks(self, start):
+    def walks(self, start, tape=None):
         csr = self.graph.by_src
         self.calls += 1
+        tape = _tape_words(tape, (start.numel(), self.walk_length))
         out = torch.empty(start.numel(), self.walk_length + 1, dtype=torch.int64, device=start.device)
         L.call("bkg_random_walk", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(start), start.numel(), self.walk_length,
-               self.seed * 1_000_003 + self.calls, L.ptr(out), L.stream())
+               self.seed * 1_000_003 + self.calls, L.ptr(tape), L.ptr(out), L.stream())
         return out
 
     _EDGE_CAP = 1 << 22      # induced edges the one-call path holds (more: the torch-glue path below)
@@ -161,19 +174,24 @@ class SaintRandomWalkSampler:
                                  ws=torch.empty(L.lib().bkg_saint_batch_workspace_bytes(n, e), dtype=torch.uint8, device=dev))
         return st
 
-    def sample(self, start=None):
+    def sample(self, start=None, tape=None):
         """Walks, node set, induced edges and relabelling in ONE library call (csrc/sample.hip: bkg_saint_batch) and
-        one host read of the two sizes; the same batch as ``sample_with_torch_glue``."""
+        one host read of the two sizes; the same batch as ``sample_with_torch_glue``.  ``tape`` (parity tests; needs
+        ``start``): ``[walks, walk_length]`` raw 32-bit words replacing the Philox stream (oracle/samplers.py)."""
         dev = self.edge_index.device
+        if tape is not None and start is None:
+            raise ValueError("a replayed tape needs explicit roots")
         if self.edge_index.size(1) == 0 or self.num_nodes >= (1 << 31):
-            return self.sample_with_torch_glue(start)
+            return self.sample_with_torch_glue(start, tape)
+        if tape is not None:
+            tape = _tape_words(tape, (start.numel(), self.walk_length))
         if start is None:
             start = torch.randint(0, self.num_nodes, (self.batch_size,), device=dev)
         st, csr = self._state(dev), self.graph.by_src
         self.calls += 1
         start = start.contiguous()
         L.call("bkg_saint_batch", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(start), start.numel(), self.walk_length,
-               self.seed * 1_000_003 + self.calls, None, L.ptr(st["walks"]), L.ptr(self.edge_index[0]),
+               self.seed * 1_000_003 + self.calls, None, L.ptr(tape), L.ptr(st["walks"]), L.ptr(self.edge_index[0]),
                L.ptr(self.edge_index[1]), None, self.num_nodes, self.edge_index.size(1), L.ptr(st["node"][0]),
                L.ptr(st["node"][1]), L.ptr(st["node"][2]), L.ptr(st["edge"][0]), L.ptr(st["edge"][1]), st["ncap"], st["cap"],
                st["ncap"] - 1, 1, L.ptr(st["n_id"]), L.ptr(st["out"][0]), L.ptr(st["out"][1]), L.ptr(st["out"][2]),
@@ -181,14 +199,14 @@ class SaintRandomWalkSampler:
         nn, ne, _ = st["sizes"].tolist()                                     # the one host read of the batch
         if ne > st["cap"]:
             self.calls -= 1
-            return self.sample_with_torch_glue(start)
+            return self.sample_with_torch_glue(start, tape)
         return (st["n_id"][:nn].clone(), torch.stack([st["out"][0][:ne], st["out"][1][:ne]]), st["out"][3][:ne].clone())
 
-    def sample_with_torch_glue(self, start=None):
+    def sample_with_torch_glue(self, start=None, tape=None):
         dev = self.edge_index.device
         if start is None:
             start = torch.randint(0, self.num_nodes, (self.batch_size,), device=dev)
-        n_id = torch.unique(self.walks(start))
+        n_id = torch.unique(self.walks(start, tape))
         mask = torch.zeros(self.num_nodes, dtype=torch.bool, device=dev)
         mask[n_id] = True
         src, dst = self.edge_index[0], self.edge_index[1]

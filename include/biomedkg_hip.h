@@ -301,10 +301,14 @@ int bkg_ntxent_rows_backward(const void* zn, int32_t bf16, const float* zn_f32, 
  *      bkg_random_walk: walks[w, 0..L] over the source-sorted CSR, uniform out-neighbour per step (sinks stay put).
  *      bkg_sample_neighbors: out_pos[f, 0..fanout) = CSR positions (destination-sorted CSR) of up to `fanout`
  *      distinct uniformly chosen in-edges of frontier[f], -1 padded; fanout <= 64.  Philox keyed by (seed, draw). */
+/*      tape (nullable, every sampler entry point): raw 32-bit words that REPLACE the Philox stream -- the draw of an index
+ *      below n is (word * n) >> 32 either way -- so that the CPU restatement of the two loaders (oracle/samplers.py) and
+ *      these kernels can be fed the same draws: walks read tape[w * walk_length + step]; neighbour picks read
+ *      tape[node * 64 + Floyd step] (keyed by the node, which is expanded once, not by its place in the frontier). */
 int bkg_random_walk(const int32_t* rowptr, const int32_t* col, const int64_t* start, int64_t n_walks,
-                    int32_t walk_length, uint64_t seed, int64_t* walks, void* stream);
+                    int32_t walk_length, uint64_t seed, const uint32_t* tape, int64_t* walks, void* stream);
 int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* frontier, int64_t n_frontier, int32_t fanout,
-                         uint64_t seed, uint32_t hop, int32_t* out_pos, void* stream);
+                         uint64_t seed, uint32_t hop, const uint32_t* tape, int32_t* out_pos, void* stream);
 /* NeighborLoader(num_neighbors=[..]) batches (biomedkg/data_module.py:89-99) with ONE host read at the end instead of
  * three per hop: begin (seeds -> n_id[0..n_seeds), seen flags, ctr = {frontier start, nodes, edges}), one hop call per
  * fan-out (up to `fanout` distinct uniformly chosen in-edges per frontier node; new sources appended to n_id in
@@ -317,7 +321,7 @@ int64_t bkg_neighbor_workspace_bytes(int64_t n_nodes, int32_t max_fanout);
 int bkg_neighbor_begin(const int64_t* seeds, int64_t n_seeds, int64_t n_nodes, int32_t* seen, int64_t* n_id, int64_t* ctr,
                        void* stream);
 int bkg_neighbor_hop(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t n_nodes, int32_t fanout,
-                     uint64_t seed, uint32_t hop, int32_t* seen, int64_t* n_id, int64_t* ctr, int32_t* pos,
+                     uint64_t seed, uint32_t hop, const uint32_t* tape, int32_t* seen, int64_t* n_id, int64_t* ctr, int32_t* pos,
                      int32_t* new_flag, int32_t* node_offs, int32_t* eflag, int32_t* edge_offs, int64_t edge_cap,
                      int64_t* e_src, int64_t* e_dst, int64_t* e_id, void* workspace, int64_t workspace_bytes, void* stream);
 int bkg_neighbor_finish(int64_t n_nodes, const int64_t* n_id, const int64_t* ctr, int32_t* lut, int64_t edge_cap,
@@ -334,7 +338,7 @@ int bkg_neighbor_finish(int64_t n_nodes, const int64_t* n_id, const int64_t* ctr
  * int32[n_edges], workspace of bkg_saint_batch_workspace_bytes. */
 int64_t bkg_saint_batch_workspace_bytes(int64_t n_nodes, int64_t n_edges);
 int bkg_saint_batch(const int32_t* rowptr, const int32_t* col, const int64_t* start, int64_t n_walks,
-                    int32_t walk_length, uint64_t seed, const uint32_t* epoch, int64_t* walks, const int64_t* src,
+                    int32_t walk_length, uint64_t seed, const uint32_t* epoch, const uint32_t* tape, int64_t* walks, const int64_t* src,
                     const int64_t* dst, const int64_t* type /* nullable */, int64_t n_nodes, int64_t n_edges,
                     int32_t* node_flag, int32_t* node_offs, int32_t* lut, int32_t* edge_flag, int32_t* edge_offs,
                     int64_t node_cap, int64_t edge_cap, int64_t pad_node, int64_t pad_types, int64_t* n_id, int64_t* out_src,

@@ -165,3 +165,85 @@ def test_mini_batch_structures_die_with_their_batch():
     base = run(15)
     grown = run(60) - base
     assert grown < 8 * 2 ** 20, f"{grown / 2 ** 20:.1f} MiB left behind by 60 more steps"
+
+
+# ------------------------------------------------------------------------------------------- round 4: against the oracle
+def _oracle_graphs():
+    """(name, edge_index, num_nodes, seeds): a hub + a node without in-edges + a sink + isolated nodes; a graph whose every
+    in-degree is below the fan-out; a PrimeKG-like synthetic graph."""
+    from biomedkg_amd import synthetic
+    g = torch.Generator().manual_seed(11)
+    n = 600
+    ei = torch.randint(0, n - 20, (2, 24_000), generator=g)           # nodes n-20 .. n-1 stay isolated
+    ei[1, :3000] = 7                                                  # hub: ~3,000 in-edges
+    ei[0, ei[0] == 13] = 14                                           # 13: a sink (no out-edges)
+    ei[1, ei[1] == 21] = 22                                           # 21: no in-edges (a seed that expands to nothing)
+    out = [("hub_sink_isolated", ei, n, torch.tensor([7, 21, 13, 590, 3, 250]))]
+    ei2 = torch.randint(0, 400, (2, 2400), generator=g)               # mean in-degree 6: fan-out 30 is above every degree
+    assert int(torch.bincount(ei2[1], minlength=400).max()) < 30
+    out.append(("fanout_above_every_degree", ei2, 400, torch.tensor([1, 2, 3, 399])))
+    pk = synthetic.primekg_like(3000, 90_000, 8, seed=3)
+    out.append(("primekg_like", pk["edge_index"], pk["num_nodes"], torch.arange(0, 3000, 47)))
+    return out
+
+
+@pytest.mark.parametrize("case", range(3))
+@pytest.mark.parametrize("fanouts", [(30, 30, 30), (5, 3)])
+def test_neighbor_sampler_equals_the_oracle_on_the_same_tape(case, fanouts):
+    """NeighborLoader(num_neighbors=[30] * 3) (reference data_module.py:93-99): the device sampler and oracle/samplers.py
+    (pyg-lib's neighbor_sample restated) fed the SAME tape of raw draws give the same batch: seeds first, the same nodes
+    discovered in every hop, the same sampled edges (global source, global target, edge id), the relabelled edge_index
+    consistent with n_id.  The two order a hop's new nodes differently (discovery order upstream, ascending ids on the
+    device): a relabelling of the same batch.  Both device forms (one host read; hop by hop) are held to it."""
+    from biomedkg_amd.samplers import NeighborSampler
+    from oracle import samplers as S
+    name, ei, n, seeds = _oracle_graphs()[case]
+    tape = S.make_tape(n, S.TAPE_STRIDE, seed=5 + case)
+    want = S.neighbor_sample(ei, n, seeds, list(fanouts), tape)
+    w_nodes, w_sub, w_eid = want["n_id"], want["edge_index"], want["e_id"]
+    w_triples = sorted(zip(w_nodes[w_sub[0]].tolist(), w_nodes[w_sub[1]].tolist(), w_eid.tolist()))
+    samp = NeighborSampler(ei.to(DEV), n, fanouts, seed=123)
+    for form in (samp.sample, samp.sample_hop_by_hop):
+        n_id, sub, e_id = (t.cpu() for t in form(seeds.to(DEV), tape.to(DEV)))
+        assert n_id[: seeds.numel()].tolist() == seeds.tolist(), name
+        assert n_id.unique().numel() == n_id.numel()
+        assert sorted(n_id.tolist()) == sorted(w_nodes.tolist()), name
+        # hop by hop: the device appends a hop's discoveries in ascending id order
+        at = 0
+        for hop, nodes in enumerate(want["hops"]):
+            got = n_id[at:at + len(nodes)].tolist()
+            assert got == (nodes if hop == 0 else sorted(nodes)), (name, hop)
+            at += len(nodes)
+        triples = sorted(zip(n_id[sub[0]].tolist(), n_id[sub[1]].tolist(), e_id.tolist()))
+        assert triples == w_triples, name
+        assert torch.equal(n_id[sub[0]], ei[0, e_id]) and torch.equal(n_id[sub[1]], ei[1, e_id])
+    # without a tape the sampler draws from its own stream: another batch (the hub has 3,000 in-edges to choose from)
+    if case == 0:
+        _, _, e_free = samp.sample(seeds.to(DEV))
+        assert sorted(e_free.cpu().tolist()) != sorted(w_eid.tolist())
+
+
+@pytest.mark.parametrize("case", range(3))
+def test_saint_random_walk_sampler_equals_the_oracle_on_the_same_tape(case):
+    """GraphSAINTRandomWalkSampler(walk_length=10) (reference data_module.py:101-107): same roots + same tape -> the same
+    walks step for step (sinks and isolated roots stay put), the same node set (ascending), the same induced edges and the
+    same relabelled edge_index as oracle/samplers.py (torch-sparse random_walk + saint_subgraph restated), for the one-call
+    device batch and the torch-glue form alike."""
+    from biomedkg_amd.samplers import SaintRandomWalkSampler
+    from oracle import samplers as S
+    name, ei, n, seeds = _oracle_graphs()[case]
+    g = torch.Generator().manual_seed(case)
+    start = torch.cat([seeds, torch.randint(0, n, (64 - seeds.numel(),), generator=g)])[:64]
+    tape = S.make_tape(start.numel(), 10, seed=17 + case)
+    want = S.saint_random_walk_batch(ei, n, start, 10, tape)
+    samp = SaintRandomWalkSampler(ei.to(DEV), n, batch_size=start.numel(), walk_length=10, seed=9)
+    walks = samp.walks(start.to(DEV), tape.to(DEV)).cpu()
+    assert torch.equal(walks, want["walks"]), name
+    for form in (samp.sample, samp.sample_with_torch_glue):
+        n_id, sub, e_id = (t.cpu() for t in form(start.to(DEV), tape.to(DEV)))
+        assert torch.equal(n_id, want["n_id"]), name
+        order = torch.argsort(e_id)
+        assert torch.equal(e_id[order], want["e_id"]), name
+        assert torch.equal(sub[:, order], want["edge_index"]), name
+    with pytest.raises(ValueError):
+        samp.sample(None, tape.to(DEV))
