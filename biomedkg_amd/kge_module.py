@@ -61,8 +61,13 @@ class KGEModule(LightningModule):
         if self.neg_ratio:
             neg_edge_type = None
             rel = getattr(getattr(self.model, "decoder", None), "rel_emb", None)
-            if GROUPED_NEG_TYPES and rel is not None and hasattr(r, "grouped_types"):
-                # device randomness: the same multiset of ids in relation order -- a uniformly random pairing all the same
+            if (GROUPED_NEG_TYPES and rel is not None and hasattr(r, "grouped_types")
+                    and getattr(neg_edge_index, "_bkg_exchangeable", False)
+                    and neg_edge_index.size(1) == num_neg_samples):
+                # device randomness: the same multiset of ids in relation order -- a uniformly random pairing all the same,
+                # BECAUSE the negatives come out of the keyed-permutation sampler in exchangeable order (the sampler says
+                # so on the tensor).  The dense fallback of tiny / dense batches enumerates the population in (head, tail)
+                # order: there the ids are shuffled, as the reference does
                 neg_edge_type = r.grouped_types(edge_type, self.neg_ratio, rel.size(0))
             if neg_edge_type is None:
                 neg_edge_type = r.shuffle(edge_type.repeat(self.neg_ratio))   # == repeat(..)[randperm(..)]

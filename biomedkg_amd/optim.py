@@ -8,8 +8,8 @@ single param group and keeps the state in the optimizer's own ``state`` dict und
 ``exp_avg_sq``), so ``state_dict()`` / ``load_state_dict()`` / LR schedulers / checkpoints are torch's.  Differences to
 ``clip_grad_norm_`` + ``step()``: the gradients are not scaled in place (the clip factor is applied inside the update),
 and the squared norm is summed in a fixed block order (bitwise repeatable).  Configurations it does not cover (several
-param groups, amsgrad, weight decay, maximize, non-fp32 or non-contiguous tensors, more than 48 tensors) take torch's
-path.  A capturable optimizer (device ``step`` / ``lr``: hipGraph-captured steps, biomedkg_amd/graphs.py) is updated
+param groups, amsgrad, weight decay, maximize, non-fp32 or non-contiguous tensors, more than 48 tensors, an optimizer
+with step hooks registered -- the fused path never calls ``step()``, so hooks would not run) take torch's path.  A capturable optimizer (device ``step`` / ``lr``: hipGraph-captured steps, biomedkg_amd/graphs.py) is updated
 through its device scalars."""
 from __future__ import annotations
 
@@ -39,10 +39,17 @@ def clip_adam_step(opt, max_norm=None):
     gradient norm as a device scalar when the fused path ran, else whatever torch's clip returns (or None)."""
     group = opt.param_groups[0]
     params = [p for p in group["params"] if p.grad is not None]
-    if not _supported(opt, params):
+    # step hooks (optimizer.register_step_pre_hook / _post_hook, the global ones, a profiler's): this path never calls
+    # opt.step(), so an optimizer that carries any takes torch's path, where they run
+    hooked = bool(getattr(opt, "_optimizer_step_pre_hooks", None) or getattr(opt, "_optimizer_step_post_hooks", None)
+                  or getattr(torch.optim.optimizer, "_global_optimizer_pre_hooks", None)
+                  or getattr(torch.optim.optimizer, "_global_optimizer_post_hooks", None))
+    if hooked or not _supported(opt, params):
         norm = torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"]], max_norm) if max_norm else None
         opt.step()
         return norm
+    # what LRScheduler's patch of ``step`` records: schedulers check it to warn about "scheduler before optimizer"
+    opt._opt_called = True
     dev = params[0].device
     capturable = bool(group.get("capturable"))
     for p in params:

@@ -128,6 +128,7 @@ def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
                L.ptr(flag[0]), L.ptr(flag[1]), L.ptr(out[0]), L.ptr(out[1]), 0, k, L.ptr(count), L.ptr(ws), ws.numel(),
                L.stream())
         _watch_shortfall(count, k)
+        out._bkg_exchangeable = True                 # the first k survivors of a keyed permutation: any order is as likely
         return out
     for _ in range(3):                               # PyG: at most three over-sampling rounds
         keys = torch.empty(draw, dtype=torch.int64, device=dev)
@@ -139,6 +140,7 @@ def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
         have = min(have + int(count.item()), k)      # the one host sync of the sampler
         first += draw
         if have >= k:
+            out._bkg_exchangeable = True
             return out
         draw = min(int(1.1 * (k - have) / prob) + 64, population - first)   # later rounds continue the permutation's prefix
         if draw <= 0:

@@ -206,6 +206,30 @@ def test_grouped_negative_types_are_the_same_typed_negatives():
         assert float((p - want).abs().max()) < 6 * (want / (draws * cnt)) ** 0.5 + 1e-9
 
 
+def test_dense_batches_shuffle_their_negative_types():
+    """on a tiny dense batch PyG's sample size exceeds the population and the sampler enumerates the cells in
+    (head, tail) order -- NOT an exchangeable order, so relation-grouped ids would pair relation id with head id
+    monotonically.  There the ids are shuffled (reference kge_module.py:97-100), whatever GROUPED_NEG_TYPES says."""
+    from biomedkg_amd import kge_module as KM, rand as R
+    pe = torch.tensor([[0, 1, 2, 3], [1, 2, 3, 0]], device=DEV)      # 4 nodes: 12 off-diagonal cells, 4 positives, 8 free
+    pt = torch.tensor([0, 0, 1, 1], device=DEV)
+    m = KM.KGEModule("rgcn", "dismult", 8, 8, 8, 2, 2, 1, "cosine", 1e-3, 0.1, "none", 2, "random").to(DEV)
+    assert KM.GROUPED_NEG_TYPES
+    monotone = 0
+    heads_of_rel0 = torch.zeros(4, device=DEV)
+    with R.use(R.DeviceRand(seed=3)):
+        for _ in range(200):
+            nei, net = m.sample_neg_edges(pe, pt)                    # k = 8, sample size int(1.1 * 8 / (2/3)) = 13 > 12
+            assert not getattr(nei, "_bkg_exchangeable", False)
+            assert nei.size(1) == 8 == net.numel()
+            assert bool((nei[0, 1:] >= nei[0, :-1]).all())           # the enumeration order: heads ascend
+            assert sorted(net.tolist()) == [0, 0, 0, 0, 1, 1, 1, 1]
+            monotone += int(torch.equal(net, torch.sort(net).values))
+            heads_of_rel0 += torch.bincount(nei[0][net == 0], minlength=4).float()
+    assert monotone < 20                                             # grouped ids would be monotone every time (1 / 70 by chance)
+    assert bool((heads_of_rel0 > 50).all())                          # relation 0 meets every head (grouped: heads 0 and 1 only)
+
+
 def test_degenerate_inputs():
     from biomedkg_amd import rand as R, sampling
     empty = torch.empty(2, 0, dtype=torch.int64, device=DEV)

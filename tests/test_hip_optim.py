@@ -144,3 +144,25 @@ def test_fused_step_refreshes_the_bf16_weight_images():
             L.call = orig
     finally:
         ops.set_matmul_precision(prev)
+
+
+def test_schedulers_and_step_hooks_see_the_fused_step():
+    """the fused tail never calls ``optimizer.step()`` -- the LRScheduler's "scheduler before optimizer"
+    check reads ``_opt_called``, which the fused path now sets; an optimizer with step hooks takes torch's path so that
+    the hooks run."""
+    import warnings
+    from biomedkg_amd.optim import clip_adam_step
+    p = torch.nn.Parameter(torch.randn(64, 64, device=DEV))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 0.5 ** e)
+    p.grad = torch.randn_like(p)
+    clip_adam_step(opt, 1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        sched.step()                                   # no "lr_scheduler.step() before optimizer.step()" warning
+    calls = []
+    opt.register_step_post_hook(lambda *a, **k: calls.append(1))
+    before = p.detach().clone()
+    p.grad = torch.randn_like(p)
+    clip_adam_step(opt, 1.0)
+    assert calls == [1] and not torch.equal(before, p.detach())
