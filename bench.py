@@ -103,10 +103,32 @@ def pmc_traffic(tag, precision):
                 total = sum(k["traffic_bytes_per_launch"] * k["launches"] for k in hits) / calls
                 h = sum(k.get("tcc_hit", 0) * k["launches"] for k in hits)
                 m = sum(k.get("tcc_miss", 0) * k["launches"] for k in hits)
-                return total, (h / (h + m) if (h + m) else None), os.path.basename(path)
+                # the call's duration from the --kernel-trace pass of the same command (scripts/pmc_summary.py): its
+                # launches' mean durations, summed -- the figure the live HIP-event time must agree with
+                traced = None
+                if all("avg_duration_us" in k for k in hits):
+                    per = {}
+                    for k in hits:
+                        per[k["kernel"]] = per.get(k["kernel"], 0) + k["launches_traced"]
+                    traced = sum(k["avg_duration_us"] * k["launches_traced"] for k in hits) / max(per.values()) / 1e3
+                return total, (h / (h + m) if (h + m) else None), os.path.basename(path), traced
     except Exception:  # noqa: BLE001 - reporting only
-        return None, None, None
-    return None, None, None
+        return None, None, None, None
+    return None, None, None, None
+
+
+def step_accounting(precision):
+    """The step-level object of the newest committed PMC / trace summary (profiles/*pmc_traffic.json ``step``): traced ms
+    per step, the tagged calls' share and the untagged remainder by kernel family."""
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+            step = (json.load(open(path)).get("step") or {}).get(precision)
+            if step and "error" not in step:
+                return dict(step, source=os.path.basename(path))
+    except Exception:  # noqa: BLE001 - reporting only
+        pass
+    return None
 
 
 KERNEL_NAMES = {
@@ -130,41 +152,51 @@ def roofline_of(tag, rec, precision):
     What the memory side sees is ``traffic`` = the bytes that left the XCD L2s (PMC FETCH_SIZE x 2 + WRITE_SIZE per
     call); MI355X_MICROARCH.md "HBM" (l. 297): those counters are the L2's fabric-side requests and Infinity-Cache hits
     ARE counted in them, so ``l2_miss_GBs = traffic / time`` is L2-miss traffic served by Infinity Cache + HBM together,
-    not HBM alone.  It is reported against both ceilings: ``frac_hbm_spec`` (/ 8 TB/s, the figure north_star's "HBM
-    roofline" names; = ``frac``) and ``frac_mall_gather`` (/ 8.6 TB/s, the guide's measured row-gather rate out of the
-    Infinity Cache)."""
+    not HBM alone.
+
+    The model behind ``frac`` (round 4): a row gather moves two streams that overlap in time -- ALL gathered bytes
+    through the XCD L2s (the guide's L2 gather rate, 16.8 TB/s) and the L2 MISSES through the fabric out of the Infinity
+    Cache (its gather rate out of the Infinity Cache, 8.6 TB/s) -- so the fastest this call could run at the measured hit
+    rate is ``t_min = max(algorithmic / 16.8 TB/s, l2_miss_bytes / 8.6 TB/s)`` and ``frac = t_min / t``.  The three
+    component fractions are kept: ``frac_l2_gather``, ``frac_mall_gather``, ``frac_hbm_spec`` (L2-miss traffic against
+    the 8 TB/s HBM spec, north_star's "HBM roofline": an upper bound of the true HBM fraction)."""
     durs = [a.elapsed_time(b) for a, b in rec["events"]]
     avg_ms = sum(durs) / len(durs)
     gbs = rec["bytes"] / (avg_ms * 1e-3) / 1e9
-    traffic, l2_hit, source = pmc_traffic(tag, precision)
+    traffic, l2_hit, source, traced_ms = pmc_traffic(tag, precision)
     miss_gbs = (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None
     d = rec.get("d", 0)
     halves = rec.get("col_halves", 1)       # 2: the launch runs the two column halves as two problems (csrc/spmm.hip)
     pieces = max(d // halves // 8, 1) if precision == "bf16" else max(d // 4, 1)
     name = KERNEL_NAMES.get(tag, tag).format(t="__bf16" if precision == "bf16" else "float", p=min(pieces, 64), d=d)
-    # a row gather answers to two ceilings at once: the bytes that miss the XCD L2s against the fabric (8 TB/s HBM spec; the
-    # guide measures 8.6 TB/s for gathers out of the Infinity Cache) and ALL gathered bytes against what the L2s deliver to
-    # gathers (the guide's 16.8 TB/s).  `frac` is the larger of the two fractions -- the ceiling that binds; both are kept
-    # (a launch that turns misses into L2 hits lowers frac_hbm_spec while it gets faster: r03 v27's column parts)
     f_hbm = (miss_gbs / HBM_PEAK_GBS) if miss_gbs else None
+    f_mall = (miss_gbs / MALL_GATHER_GBS) if miss_gbs else None
     f_l2 = gbs / L2_GATHER_GBS
+    t_l2 = rec["bytes"] / (L2_GATHER_GBS * 1e9) * 1e3                       # ms: every gathered byte through the L2s
+    t_mall = (traffic / (MALL_GATHER_GBS * 1e9) * 1e3) if traffic else None   # ms: the misses out of the Infinity Cache
+    t_min = max(t_l2, t_mall) if t_mall is not None else None
     return {"bound": "hbm", "kernel": name, "tag": tag, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": max(f_hbm, f_l2) if f_hbm is not None else None, "traffic": traffic,
-            "bound_by": (None if f_hbm is None else ("l2_miss_traffic_vs_hbm_spec" if f_hbm >= f_l2 else "gathered_bytes_vs_l2_gather_rate")),
-            "l2_miss_GBs": miss_gbs, "frac_hbm_spec": f_hbm, "frac_l2_gather": f_l2,
-            "frac_mall_gather": (miss_gbs / MALL_GATHER_GBS) if miss_gbs else None,
+            "frac": (t_min / avg_ms) if t_min is not None else None, "traffic": traffic,
+            "t_min_ms": t_min, "t_min_l2_ms": t_l2, "t_min_mall_ms": t_mall,
+            "bound_by": (None if t_min is None else ("l2_misses_vs_infinity_cache_gather_rate" if t_mall >= t_l2
+                                                     else "gathered_bytes_vs_l2_gather_rate")),
+            "l2_miss_GBs": miss_gbs, "frac_hbm_spec": f_hbm, "frac_l2_gather": f_l2, "frac_mall_gather": f_mall,
             "algorithmic_over_hbm": gbs / HBM_PEAK_GBS, "reuse": (rec["bytes"] / traffic) if traffic else None,
             "l2_hit_rate": l2_hit, "pmc_source": source,
-            "avg_launch_ms": avg_ms, "launches": len(durs), "ms_total": sum(durs), "bytes_per_launch": rec["bytes"],
+            "avg_launch_ms": avg_ms, "avg_launch_ms_traced": traced_ms,
+            "traced_over_live": (traced_ms / avg_ms) if traced_ms else None,
+            "launches": len(durs), "ms_total": sum(durs), "bytes_per_launch": rec["bytes"],
             "grid_size": rec.get("grid"), "grid_size_second_launch": rec.get("grid2"), "pieces": pieces, "col_halves": halves,
             "guide_GBs": {"hbm_spec": HBM_PEAK_GBS, "hbm_achievable": 6300.0, "infinity_cache_gather": MALL_GATHER_GBS,
                           "l2_gather": L2_GATHER_GBS},
-            "frac_definition": "frac = max(frac_hbm_spec, frac_l2_gather).  frac_hbm_spec = (PMC bytes that left the XCD L2s "
-                               "per call / HIP-event time) / 8 TB/s; those bytes include Infinity-Cache hits (guide l. 297), "
-                               "so this is L2-miss traffic against the HBM spec, an upper bound of the HBM fraction.  "
-                               "frac_l2_gather = algorithmic bytes / time / 16.8 TB/s (the guide's L2 gather rate): the "
-                               "ceiling of a gather whose rows mostly hit L2.  achieved / peak = algorithmic_over_hbm is NOT a "
-                               "fraction (cache reuse); frac is null when no PMC pass of this call is committed under profiles/"}
+            "frac_definition": "frac = t_min / t with t_min = max(algorithmic bytes / 16.8 TB/s [every gathered byte through "
+                               "the XCD L2s: the guide's L2 gather rate], L2-miss bytes / 8.6 TB/s [PMC FETCH_SIZE x 2 + "
+                               "WRITE_SIZE per call out of the Infinity Cache: the guide's gather rate; those bytes include "
+                               "Infinity-Cache hits, guide l. 297]) and t = the call's HIP-event time (avg_launch_ms; "
+                               "avg_launch_ms_traced = the same call in the committed --kernel-trace pass).  Components: "
+                               "frac_l2_gather = t_min_l2 / t, frac_mall_gather = t_min_mall / t, frac_hbm_spec = L2-miss "
+                               "rate / 8 TB/s.  achieved / peak = algorithmic_over_hbm is NOT a fraction (cache reuse); frac "
+                               "is null when no PMC pass of this call is committed under profiles/"}
 
 
 # tagged calls that launch the SAME kernel over the same grid (the forward and the backward propagate of the GGD views): the
@@ -667,10 +699,41 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_full_step(nodes, edges, relations, hidden, neg_ratio, threads, steps=1):
+    """One GGD + one R-GCN/DistMult TRAINING step (fwd + bwd + clip + Adam) of the CPU oracle at the given size with
+    ``threads`` threads, through ``oracle/lean.py`` -- the oracle's arithmetic with its ``[E, d]`` / per-relation ``[N, d]``
+    temporaries recomputed in the backward instead of stored (the plain form needs > 62 GB at the bench size; proven equal
+    on the 5,000-node graph: tests/test_oracle_lean.py).  -> seconds per step (each step timed, the fastest reported:
+    the first one also pays the allocator's first touch of ~10 GB)."""
+    from biomedkg_amd import synthetic
+    from oracle import lean, ref_modules as R
+    torch.set_num_threads(threads)
+    g = synthetic.primekg_like(nodes, edges, relations, seed=42)
+    torch.manual_seed(0)
+    xk, xg = torch.randn(nodes, hidden), torch.randn(nodes, 768)
+    kge = R.make_kge_model("rgcn", "dismult", hidden, hidden, hidden, 2, g["num_relations"])
+    ggd = R.GGD(R.GCNEncoder(768, hidden, hidden, 2), hidden, 1, 0.5)
+    ok, og = torch.optim.Adam(kge.parameters(), lr=1e-3), torch.optim.Adam(ggd.parameters(), lr=1e-3)
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        og.zero_grad(); lean.ggd_loss(ggd, xg, g["edge_index"]).backward()
+        torch.nn.utils.clip_grad_norm_(ggd.parameters(), 1.0); og.step()
+        t1 = time.perf_counter()
+        ok.zero_grad(); lean.kge_step(kge, xk, g["edge_index"], g["edge_type"], neg_ratio)[0].backward()
+        torch.nn.utils.clip_grad_norm_(kge.parameters(), 1.0); ok.step()
+        times.append((time.perf_counter() - t0, t1 - t0))
+    return min(times)
+
+
 def cpu_baseline(args):
-    """CPU oracle (kind "port": the torch restatement of the reference's PyG/PyGCL path) on a
-    1/cpu_scale graph with the same N:E:R ratios; one KGE + one GCL step like the GPU step; all cores, then one thread
-    on a 4x smaller sample (SURVEY 8d asks for both)."""
+    """CPU oracle (kind "port": the torch restatement of the reference's PyG/PyGCL path -- PyG itself cannot be installed
+    here) timed on this box's host cores.  ``value``: ONE full training step (GGD + R-GCN/DistMult, fwd + bwd + clip +
+    Adam) on the FULL bench graph with all cores, through the memory-lean form of the oracle (``cpu_full_step``).  A
+    bounded probe on a 1/cpu_scale graph runs first (the plain oracle; reported as ``scaled_sample``); when it says the
+    full step would take more than ~4 minutes the scaled figure is the value instead and says so.  ``threads1``: the
+    same full step on ONE thread, measured once per round by ``scripts/cpu_baseline_full.py`` on the GPU box (it takes
+    minutes: not part of the default run) and read from profiles/."""
     from biomedkg_amd import synthetic
     from oracle import ref_modules as R
     # the cores this process may actually run on (a cgroup-limited box reports more in cpu_count())
@@ -701,41 +764,46 @@ def cpu_baseline(args):
         dt = (time.perf_counter() - t0) / reps
         return n, e, g["num_relations"], reps, dt
 
-    n, e, r, reps, dt = run(args.cpu_scale, cores, 15.0)
-    n1, e1, _, reps1, dt1 = run(args.cpu_scale * 4, 1, 8.0)
-
-    def forward_full():
-        """the naive oracle's TRAINING step does not fit the host at G-full (> 62 GB of PyG-style temporaries),
-        its FORWARD does: one GGD forward (two encoder passes + head + loss) and one KGE forward (R-GCN + DistMult scores
-        of positives and negatives + loss) on the full-size graph, no autograd."""
-        torch.set_num_threads(cores)
-        g = synthetic.primekg_like(args.nodes, args.edges, args.relations, seed=42)
-        torch.manual_seed(0)
-        xk, xg = torch.randn(args.nodes, args.hidden), torch.randn(args.nodes, 768)
-        kge = R.make_kge_model("rgcn", "dismult", args.hidden, args.hidden, args.hidden, 2, g["num_relations"])
-        ggd = R.GGD(R.GCNEncoder(768, args.hidden, args.hidden, 2), args.hidden, 1, 0.5)
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            R.ggd_loss(ggd, xg, g["edge_index"])
-            R.kge_step(kge, xk, g["edge_index"], g["edge_type"], args.neg_ratio)
-            return time.perf_counter() - t0
-    fwd = None
-    if dt * args.cpu_scale < 120.0:          # bounded: skipped on a host where the scaled-up step says it would take minutes
+    n, e, r, reps, dt = run(args.cpu_scale, cores, 8.0)
+    scaled = {"value": e / dt, "unit": "edges/s", "cores": cores,
+              "sample": f"plain oracle, 1/{args.cpu_scale}-scale graph (N={n}, E={e}, R={r}), {reps} steps, {dt:.2f} s/step"}
+    full = None
+    if dt * args.cpu_scale < 240.0:          # bounded: skipped on a host where the scaled-up step says it would take too long
         try:
-            fwd = forward_full()
-        except Exception:                    # noqa: BLE001  (e.g. not enough host memory)
-            fwd = None
-    return {"value": e / dt, "unit": "edges/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "forward_only_full_graph": None if fwd is None else {
-                "value": args.edges / fwd, "unit": "edges/s", "seconds": fwd,
-                "sample": f"forward only (no autograd) of the same two sub-steps on the FULL graph (N={args.nodes}, "
-                          f"E={args.edges}), {cores} threads: the naive oracle's training step does not fit the host at this size"},
-            "sample": f"CPU oracle (torch restatement of the reference's PyG path), GGD + R-GCN/DistMult step on a "
-                      f"1/{args.cpu_scale}-scale graph (N={n}, E={e}, R={r}), {reps} steps, "
-                      f"{dt:.2f} s/step, {cores} threads",
-            "threads1": {"value": e1 / dt1, "unit": "edges/s", "cores": 1,
-                         "sample": f"same step, 1 thread, 1/{args.cpu_scale * 4}-scale graph (N={n1}, E={e1}), {reps1} steps, "
-                                   f"{dt1:.2f} s/step"}}
+            sec, sec_ggd = cpu_full_step(args.nodes, args.edges, args.relations, args.hidden, args.neg_ratio, cores)
+            full = {"seconds_per_step": sec, "seconds_ggd": sec_ggd, "seconds_kge": sec - sec_ggd}
+        except Exception as why:             # noqa: BLE001  (e.g. not enough host memory)
+            full = {"error": f"{type(why).__name__}: {why}"[:200]}
+    # the one-thread figure of the same full step (and the all-core one of that run): measured by scripts/cpu_baseline_full.py
+    offline = None
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_baseline_full.json")), reverse=True):
+            offline = dict(json.load(open(path)), source=os.path.basename(path))
+            break
+    except Exception:  # noqa: BLE001
+        offline = None
+    if full and "seconds_per_step" in full:
+        sec = full["seconds_per_step"]
+        out = {"value": args.edges / sec, "unit": "edges/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+               "seconds_per_step": sec, "seconds_ggd_step": full["seconds_ggd"], "seconds_kge_step": full["seconds_kge"],
+               "sample": f"CPU oracle (torch restatement of the reference's PyG path, memory-lean form: oracle/lean.py), ONE "
+                         f"full training step -- GGD + R-GCN/DistMult, fwd + bwd + clip + Adam -- on the FULL bench graph "
+                         f"(N={args.nodes}, E={args.edges}, R={args.relations}, neg_ratio={args.neg_ratio}), {cores} threads, "
+                         f"{sec:.1f} s"}
+    else:
+        out = {"value": e / dt, "unit": "edges/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+               "sample": f"CPU oracle on a 1/{args.cpu_scale}-scale graph (N={n}, E={e}, R={r}), {reps} steps, {dt:.2f} s/step, "
+                         f"{cores} threads -- the full-size step was not run here ({full})"}
+    out["scaled_sample"] = scaled
+    out["threads1"] = (None if not offline else
+                       {"value": offline.get("edges_per_s_1_thread"), "unit": "edges/s", "cores": 1,
+                        "seconds_per_step": offline.get("seconds_1_thread"),
+                        "same_run_all_cores_seconds": offline.get("seconds_all_cores"),
+                        "thread_scaling": offline.get("thread_scaling"), "source": offline.get("source"),
+                        "sample": "the same full-size step on ONE thread, measured by scripts/cpu_baseline_full.py on a GPU "
+                                  "box of this pool (minutes per step: not part of the default bench run)"})
+    return out
 
 
 # ----------------------------------------------------------------------------------------------- main
@@ -1061,9 +1129,23 @@ def main():
             "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_shuffled_neg_types": ms_shuffled_types,
             "ms_per_step_fresh_structures": ms_fresh,
             "roofline": roof, "kernels": others, "exchange": exchange,
+            "step_accounting": None,
             "check_loss": getattr(step_g, "check_loss", None),
             "cpu_baseline": None,
         }
+        if world == 1:
+            live = [roof] + others if roof else []
+            out["step_accounting"] = {
+                "live": {"tagged_bytes_per_step": sum(r["bytes_per_launch"] * r["launches"] for r in live) / args.steps,
+                         "tagged_ms_per_step": sum(r["ms_total"] for r in live) / args.steps,
+                         "ms_per_step": ms,
+                         "tagged_GBs_over_the_step": (sum(r["bytes_per_launch"] * r["launches"] for r in live) / args.steps
+                                                      / (ms * 1e-3) / 1e9) if live else None,
+                         "note": "HIP events of this run: the tagged gather / aggregate / scorer calls' algorithmic bytes and "
+                                 "time per step; the remainder of the step (products, casts, sorts, optimizer, glue) is "
+                                 "broken down by kernel family in `traced`"},
+                "traced": step_accounting(args.precision)}
+
         def extra(fn, *a):      # the side figures never cost the headline line: a failure is reported in its place
             try:
                 return fn(*a)

@@ -20,8 +20,10 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   rocprofv3 --pmc $pass --output-format csv -d /tmp/pmc_$name -o p -- python3 bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline \
       > /tmp/pmc_$name.json 2>/dev/null
 done
+# (the kernel trace of the bf16 --kernel-trace --stats run above gives the per-(kernel, grid) durations and the step object)
 python3 scripts/pmc_summary.py $(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv") $(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv") \
-    $out/${tag}_pmc_traffic.json bf16 $out/${tag}_bench.json $(find /tmp/pmc_TCC_HIT_sum -name "*counter_collection.csv") > $out/${tag}_pmc_summary.txt 2>&1
+    $out/${tag}_pmc_traffic.json bf16 $out/${tag}_bench.json $(find /tmp/pmc_TCC_HIT_sum -name "*counter_collection.csv") \
+    $(find /tmp/ks_bf16 -name "*kernel_trace.csv" | head -1) 2 5 > $out/${tag}_pmc_summary.txt 2>&1
 # the sampled GCL regime as replayed graphs: kernel stats and the busy fraction of the trace
 rm -rf /tmp/gclg
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gclg -o g -- python3 scripts/dev_gcl_graphed_loop.py fp32 100 1 > $out/${tag}_gcl_graphed.txt 2>/dev/null
