@@ -624,7 +624,7 @@ def sampled_gcl_figures(dev, n=27_000, e=640_000, seeds=128, steps=40):
     host's time to ENQUEUE a step (no synchronisation inside the loop) against the step's wall time: a launch-bound loop has
     the two equal (the GPU waits for the host), a GPU-bound one has the host run ahead.  The kernel-trace busy fraction of
     the same loop: scripts/busy_fraction.py over a rocprofv3 --kernel-trace of scripts/dev_gcl_sampled.py (profiles/)."""
-    from biomedkg_amd import ops, synthetic
+    from biomedkg_amd import gcl_module as GM, ops, synthetic
     from biomedkg_amd.gcl_module import GGDModule
     from biomedkg_amd.samplers import NeighborBatchLoader
     prec = ops.get_matmul_precision()
@@ -637,7 +637,7 @@ def sampled_gcl_figures(dev, n=27_000, e=640_000, seeds=128, steps=40):
         params = list(m.model.parameters())
         opt = torch.optim.Adam(params, lr=1e-3, fused=True)
 
-        def loop(k):
+        def loop(k, m=m, opt=opt):
             it = iter(NeighborBatchLoader(x, ei, None, seeds, (30, 30, 30), True, seed=3))
             torch.cuda.synchronize(); t0 = time.perf_counter()
             nodes = edges = 0
@@ -662,12 +662,12 @@ def sampled_gcl_figures(dev, n=27_000, e=640_000, seeds=128, steps=40):
         # branch) -- biomedkg_amd/sampled_gcl.py; the first batches of each kind are captured before the timed loop
         from biomedkg_amd.sampled_gcl import NeighborGraphedGcl
 
-        def graphed(precision):
+        def graphed(precision, cls=GGDModule, steps=steps, warm=3):
             ops.set_matmul_precision(precision)
             torch.manual_seed(0)
-            mg = GGDModule(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="attention").to(dev).train()
+            mg = cls(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="attention").to(dev).train()
             lp = NeighborGraphedGcl(mg, x, ei, seeds, (30, 30, 30), clip=1.0, seed=3)
-            for _ in range(3 * steps):                      # capture what the regime uses
+            for _ in range(warm * steps):                   # capture what the regime uses
                 lp.step()
             torch.cuda.synchronize()
             before = dict(lp.stats)
@@ -684,6 +684,23 @@ def sampled_gcl_figures(dev, n=27_000, e=640_000, seeds=128, steps=40):
         out["graphed"] = graphed("fp32")
         out["graphed_bf16"] = graphed("bf16")
         out["speedup"] = round(out["graphed"]["steps_per_s"] / out["eager_steps_per_s"], 2)
+        # the other two GCL models of train_gcl.py:15-38 over the same batches (round 4: masked readout / JSD for DGI, masked
+        # NT-Xent for GRACE -- on ~25k-node batches GRACE's step is its 51k x 51k NT-Xent, whatever launches it)
+        for name, cls, k in (("dgi", GM.DGIModule, 20), ("grace", GM.GRACEModule, 8)):
+            try:
+                ops.set_matmul_precision("fp32")
+                torch.manual_seed(0)
+                me = cls(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="attention").to(dev).train()
+                oe = torch.optim.Adam(list(me.model.parameters()), lr=1e-3, fused=True)
+                loop(2, me, oe)
+                _, t_wall_e, _, _ = loop(k, me, oe)
+                del me, oe
+                out[name] = {"eager_steps_per_s": round(1.0 / t_wall_e, 1), "graphed": graphed("fp32", cls, k, 2),
+                             "graphed_bf16": graphed("bf16", cls, k, 2)}
+                out[name]["speedup"] = round(out[name]["graphed"]["steps_per_s"] / out[name]["eager_steps_per_s"], 2)
+            except Exception as why:      # noqa: BLE001  (a side figure)
+                torch.cuda.synchronize()
+                out[name] = {"error": f"{type(why).__name__}: {why}"[:300]}
         return out
     finally:
         ops.set_matmul_precision(prec)

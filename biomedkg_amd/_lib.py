@@ -132,6 +132,7 @@ SIGNATURES = {
     "bkg_clip_adam_images_f32": (I32, [I32, P, P, P, P, P, P, P, P, P, F32, F32, P, F32, F32, F32, F32, P, P, I64, P, P]),
     # fusion.hip
     "bkg_attn_fuse_f32": (I32, [P, I64, I64, I32, I32, P, I64, P]),
+    "bkg_attn_scores_combine_bf16": (I32, [P, I64, P, I64, I64, I32, P, P, F32, P, I64, P]),
     "bkg_redaf_combine_f32": (I32, [P, I64, I64, I32, I32, P, P, F32, U64, U32, I64, P, I64, P]),
     "bkg_ggd_bce_partials": (I64, []),
     "bkg_ggd_bce_f32": (I32, [P, I64, P, I64, I64, P, P, P, P]),

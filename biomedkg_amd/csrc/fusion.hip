@@ -107,6 +107,95 @@ __global__ __launch_bounds__(256) void redaf_combine_kernel(const float* __restr
   *reinterpret_cast<float4*>(out + (int64_t)node * ldo + c) = y;
 }
 
+
+// ---- AttentionFusion in projected form (bf16 mode, two modalities; biomedkg_amd/ops.py attention_fusion):
+//   s_ab = q_a . k_b = x_a^T (Wq^T Wk) x_b + (Wq^T bk) . x_a + (Wk^T bq) . x_b + bq . bk          (the fuser is frozen:
+//   y    = sum_b c_b v_b = Wv (sum_b c_b x_b) + bv,   c_b = 1/2 sum_a softmax_b(s_ab / sqrt(D)), sum_b c_b = 1   Wq^T Wk is a
+// constant of the run) -- so the three [2n, D] x [D, D] projections of reference fusion.py:22-26 become ONE [2n, D] product
+// T = X (Wq^T Wk) and one [n, D] product with Wv over the COMBINED rows.  This kernel sits between them: per node the four
+// scores from T and X (two rows each, bf16), the 2 x 2 softmax, the modality mean's coefficients, and the combined row
+// xc = c_0 x_0 + c_1 x_1 in bf16.  One wave per node, 16-byte pieces, wave-shuffle reductions.
+__device__ __forceinline__ void bf16x8_to_f32(const uint4 v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+template <int PASSES>      // D = PASSES * 512 at most (64 lanes x 8 elements per pass)
+__global__ __launch_bounds__(256) void attn_scores_combine_kernel(const __bf16* __restrict__ t, int64_t ldt,
+                                                                  const __bf16* __restrict__ x, int64_t ldx, int n, int D,
+                                                                  const float* __restrict__ u /* Wk^T bq */,
+                                                                  const float* __restrict__ w /* Wq^T bk */, float c0,
+                                                                  __bf16* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= n) return;
+  const __bf16* t0 = t + (int64_t)(2 * node) * ldt;
+  const __bf16* x0 = x + (int64_t)(2 * node) * ldx;
+  uint4 xr[PASSES][2];
+  float s[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, lin_u[2] = {0.f, 0.f}, lin_w[2] = {0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int c = (p * 64 + lane) * 8;
+    const bool ok = c < D;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    xr[p][0] = ok ? *reinterpret_cast<const uint4*>(x0 + c) : z;
+    xr[p][1] = ok ? *reinterpret_cast<const uint4*>(x0 + ldx + c) : z;
+    const uint4 ta = ok ? *reinterpret_cast<const uint4*>(t0 + c) : z;
+    const uint4 tb = ok ? *reinterpret_cast<const uint4*>(t0 + ldt + c) : z;
+    float fx[2][8], ft[2][8], fu[8], fw[8];
+    bf16x8_to_f32(xr[p][0], fx[0]); bf16x8_to_f32(xr[p][1], fx[1]);
+    bf16x8_to_f32(ta, ft[0]); bf16x8_to_f32(tb, ft[1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float4 a = ok ? *reinterpret_cast<const float4*>(u + c + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b = ok ? *reinterpret_cast<const float4*>(w + c + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+      fu[4 * h] = a.x; fu[4 * h + 1] = a.y; fu[4 * h + 2] = a.z; fu[4 * h + 3] = a.w;
+      fw[4 * h] = b.x; fw[4 * h + 1] = b.y; fw[4 * h + 2] = b.z; fw[4 * h + 3] = b.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) s[a][b] = fmaf(ft[a][e], fx[b][e], s[a][b]);
+        lin_u[a] = fmaf(fu[e], fx[a][e], lin_u[a]);
+        lin_w[a] = fmaf(fw[e], fx[a][e], lin_w[a]);
+      }
+    }
+  }
+  const float scale = 1.0f / sqrtf((float)D);
+  float coef[2] = {0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 2; ++a) lin_w[a] = wave_sum(lin_w[a]);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) lin_u[b] = wave_sum(lin_u[b]);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    float sc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) sc[b] = (wave_sum(s[a][b]) + lin_w[a] + lin_u[b] + c0) * scale;
+    const float mx = fmaxf(sc[0], sc[1]);
+    const float e0 = expf(sc[0] - mx), e1 = expf(sc[1] - mx);
+    const float inv = 0.5f / (e0 + e1);
+    coef[0] += e0 * inv;
+    coef[1] += e1 * inv;
+  }
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int c = (p * 64 + lane) * 8;
+    if (c >= D) continue;
+    float f0[8], f1[8];
+    bf16x8_to_f32(xr[p][0], f0); bf16x8_to_f32(xr[p][1], f1);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaf(coef[1], f1[e], coef[0] * f0[e]);
+    *reinterpret_cast<bf16x8*>(out + (int64_t)node * ldo + c) = o;
+  }
+}
+
 }  // namespace bkg
 
 using namespace bkg;
@@ -126,6 +215,24 @@ extern "C" int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_
     default: hipLaunchKernelGGL(attn_fuse_kernel<4>, grid, block, 0, s, qkv, ld, (int)n, D, out, ldo); break;
   }
   return check_launch("bkg_attn_fuse_f32");
+}
+
+// The node-wise middle of the projected AttentionFusion (see attn_scores_combine_kernel): t = X (Wq^T Wk) and x as
+// [2 n, D] bf16 tables (rows 2 i, 2 i + 1 = the two modality tokens of node i), u = Wk^T bq, w = Wq^T bk, c0 = bq . bk ->
+// out[i] = c_0 x_{i,0} + c_1 x_{i,1} (bf16), the rows the V projection then runs over.
+extern "C" int bkg_attn_scores_combine_bf16(const void* t, int64_t ldt, const void* x, int64_t ldx, int64_t n, int32_t D,
+                                            const float* u, const float* w, float c0, void* out, int64_t ldo, void* stream) {
+  BKG_ARG(D % 8 == 0 && D <= 2048 && ldt % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)t % 16 == 0) &&
+              ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)u % 16 == 0) && ((uintptr_t)w % 16 == 0),
+          "bkg_attn_scores_combine_bf16: D a multiple of 8 up to 2048, 16-byte aligned rows");
+  if (n == 0) return 0;
+  dim3 grid(ceil_div(n, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define BKG_ASC(P) hipLaunchKernelGGL(attn_scores_combine_kernel<P>, grid, block, 0, s, (const __bf16*)t, ldt, (const __bf16*)x, \
+                                      ldx, (int)n, D, u, w, c0, (__bf16*)out, ldo)
+  if (D <= 512) BKG_ASC(1); else if (D <= 1024) BKG_ASC(2); else if (D <= 1536) BKG_ASC(3); else BKG_ASC(4);
+#undef BKG_ASC
+  return check_launch("bkg_attn_scores_combine_bf16");
 }
 
 extern "C" int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int32_t M, int32_t D, const float* scale,

@@ -28,7 +28,10 @@ class DGI(torch.nn.Module):
     def summary(z):
         return torch.sigmoid(z.mean(dim=0, keepdim=True))
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, summary=None):
+        """``summary``: the readout in place of ``self.summary`` (a padded mini-batch averages its real rows only,
+        biomedkg_amd/sampled_gcl.py)."""
+        summary = summary or self.summary
         if ops.features_bf16_ok(x) and x.is_cuda:
             x = ops.cached_bf16(x)
         r = _rand.current()
@@ -40,9 +43,9 @@ class DGI(torch.nn.Module):
             h2 = enc.forward_views(ops.pair_rows(xw, r.perm(x.size(0), x.device)), edge_index, 2)
             d = h2.size(1) // 2
             z, zn = h2[:, :d], h2[:, d:]
-            return z, ops.linear(self.summary(z), self.project.weight, self.project.bias), zn
+            return z, ops.linear(summary(z), self.project.weight, self.project.bias), zn
         z = self.encoder(x, edge_index)
-        g = ops.linear(self.summary(z), self.project.weight, self.project.bias)
+        g = ops.linear(summary(z), self.project.weight, self.project.bias)
         zn = self.encoder(*self.corruption(x, edge_index))
         return z, g, zn
 

@@ -20,8 +20,16 @@ gene/protein size a subgraph of ~25 k nodes and ~220 k edges per step.  Run eage
 
 Arithmetic: the padded step computes ``GGDModule.training_step`` (``biomedkg/gcl_module.py:52-56,229-234``) on the real
 part of the batch -- ``tests/test_hip_sampled_gcl.py`` holds it against the ordinary step on the unpadded batch with the
-same draws, and a replayed graph against the same padded step run eagerly (bit-equal).  Only GGD is built this way (DGI's
-summary and GRACE's NT-Xent would need their own masked forms); the other modules keep the eager loop.
+same draws, and a replayed graph against the same padded step run eagerly (bit-equal).
+
+All three GCL models of ``train_gcl.py:15-38`` train this way (round 4).  **DGI** (``gcl_module.py:140-143``): the readout
+averages the real rows (a masked column sum over a device count), the corruption permutes the real rows, the JSD terms of
+the pad rows are multiplied by zero.  **GRACE** (``gcl_module.py:186-190``): the projected rows of the pads are zeroed
+before the NT-Xent, so a pad COLUMN is the zero vector and adds exactly ``exp(0) = 1`` to every real row's denominator --
+subtracted again as ``2 (n_cap - n_b)``, a device scalar -- and contributes nothing to any gradient (``E_ij z_j = 0``);
+pad ROWS get ``1 / D = 0`` and their gradient rows are cleared (``_MaskedNtXent``: the row-partitioned NT-Xent kernels of
+csrc/ntxent2.hip over all ``2 n_cap`` anchors).  GRACE draws two feature masks and two edge masks per step (in-kernel
+Philox / the device generator: graph-safe) and has no host coin: one graph per edge bucket.
 """
 from __future__ import annotations
 
@@ -109,8 +117,37 @@ class _StepRand(R.DeviceRand):
         return out
 
 
+class _MaskedNtXent(torch.autograd.Function):
+    """NT-Xent (reference gcl_module.py:171-173: DualBranchContrast(InfoNCE(tau), L2L, intraview_negs)) over the REAL rows of
+    a padded batch.  ``h1 / h2 [n_cap, h]`` arrive with their pad rows zeroed; ``w [n_cap]`` (1.0 real, 0.0 pad) and the
+    real row count ``n_dev`` (int64 device scalar) say which.  Every size the kernels see is the capacity."""
+
+    @staticmethod
+    def forward(ctx, h1, h2, w, n_dev, tau, kernels):
+        n = h1.size(0)
+        zn, norm, posdot = kernels.normalize(h1, h2)                        # pad rows: the zero vector
+        anchors = torch.arange(2 * n, dtype=torch.int32, device=h1.device)
+        den = kernels.row_sums(zn, anchors, tau)                            # [2 n]: real columns + exp(0) per pad column
+        n_b = n_dev.to(torch.float32)
+        w2 = torch.cat([w, w])
+        den = torch.where(w2 > 0, den - 2.0 * (n - n_b), torch.full_like(den, float("inf")))
+        terms = (torch.log(den.double()) * w2.double()).nan_to_num(posinf=0.0).sum() - 2.0 * (posdot.double() * w.double()).sum() / tau
+        ctx.tau, ctx.kernels, ctx.n = tau, kernels, n
+        ctx.save_for_backward(zn, norm, den, anchors, w2, n_b)
+        return (terms / (2.0 * n_b.double())).float().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        zn, norm, den, anchors, w2, n_b = ctx.saved_tensors
+        scale = g.reshape(1).float() / (2.0 * n_b * ctx.tau)
+        dh = ctx.kernels.row_grads(zn, anchors, den, norm, ctx.tau, scale, ctx.n)           # [2 n, h]
+        dh = torch.where(w2[:, None] > 0, dh, torch.zeros_like(dh))          # (a pad row's normalisation divides by eps)
+        return dh[: ctx.n], dh[ctx.n:], None, None, None, None
+
+
 class NeighborGraphedGcl:
-    """``GGDModule`` training steps over NeighborLoader batches, one hipGraph replay each (see the module docstring).
+    """``GGDModule`` / ``DGIModule`` / ``GRACEModule`` training steps over NeighborLoader batches, one hipGraph replay each
+    (see the module docstring).
 
     ``step()`` = sample (one batch ahead) + zero_grad + forward + loss + backward + clip + Adam; returns the loss as a
     device scalar (the replay's static output; read it before the next step).  ``graphs=False`` runs the same padded step
@@ -119,9 +156,11 @@ class NeighborGraphedGcl:
     def __init__(self, module, x, edge_index, batch_size=128, num_neighbors=(30, 30, 30), optimizer=None, clip=1.0, seed=0,
                  shuffle=True, buckets=None, graphs=True, max_graphs=16):
         L.require_cuda(x, edge_index)
-        from .model.gcl import GGD
-        if not isinstance(getattr(module, "model", None), GGD):
-            raise ValueError("the padded NeighborLoader step is built for GGD")
+        from .model.gcl import DGI, GGD, GRACE
+        kinds = {GGD: "ggd", DGI: "dgi", GRACE: "grace"}
+        self.kind = kinds.get(type(getattr(module, "model", None)))
+        if self.kind is None:
+            raise ValueError("the padded NeighborLoader step is built for the GGD, DGI and GRACE modules")
         self.module, self.clip, self.graphs_on = module, clip, graphs
         self.max_graphs = int(max_graphs)     # every captured graph keeps its step's intermediates in a pool of its own
         dev = x.device
@@ -196,11 +235,16 @@ class NeighborGraphedGcl:
         return n_id, ei, real_n
 
     def padded_loss(self, e_b):
-        """``GGDModule.training_step`` (fusion -> GGD -> BCE with logits, mean over the 2 n_b real logits) over the batch
-        in ``self.cur`` padded to ``n_cap`` nodes / ``e_b`` edges."""
+        """The module's ``training_step`` over the batch in ``self.cur`` padded to ``n_cap`` nodes / ``e_b`` edges: GGD --
+        fusion -> GGD -> BCE with logits, mean over the 2 n_b real logits; DGI -- masked readout, JSD over the real rows;
+        GRACE -- two augmented views, projector, NT-Xent over the real rows."""
         m = self.module
         n_id, ei, real_n = self.padded_batch(e_b)
         x = m.fusion_fn(x=rows_of(self.x_ext, n_id))
+        if self.kind == "dgi":
+            return self._dgi_loss(m, x, ei, real_n)
+        if self.kind == "grace":
+            return self._grace_loss(m, x, ei, real_n)
         pos_h, neg_h = m.model(x, ei)
         if ops.ggd_bce_ok(pos_h, neg_h):          # rows below sizes[1] count, the mean divides by 2 sizes[1] (csrc/gcl_loss.hip)
             return ops.ggd_bce(pos_h, neg_h, self.v["sizes"][1:2])
@@ -208,6 +252,26 @@ class NeighborGraphedGcl:
         inv = 0.5 / self.v["sizes"][1].to(pos_h.dtype)
         return (F.binary_cross_entropy_with_logits(pos_h, torch.ones_like(pos_h), weight=w, reduction="sum")
                 + F.binary_cross_entropy_with_logits(neg_h, torch.zeros_like(neg_h), weight=w, reduction="sum")) * inv
+
+    def _dgi_loss(self, m, x, ei, real_n):
+        """``DGIModule.calculate_loss`` (reference gcl_module.py:140-143, gcl.py:23-27) on the real rows."""
+        import math
+        w = real_n.to(torch.float32)
+        n_b = self.v["sizes"][1].to(torch.float32)
+        z, g, zn = m.model(x, ei, summary=lambda t: torch.sigmoid((t.float() * w[:, None]).sum(0, keepdim=True) / n_b))
+        sim_pos = ops.linear(z, g).squeeze(1)
+        sim_neg = ops.linear(zn, g).squeeze(1)
+        log2 = math.log(2.0)
+        e_pos = ((log2 - F.softplus(-sim_pos)) * w).sum() / n_b
+        e_neg = ((F.softplus(-sim_neg) + sim_neg - log2) * w).sum() / n_b
+        return e_neg - e_pos
+
+    def _grace_loss(self, m, x, ei, real_n):
+        """``GRACEModule.calculate_loss`` (reference gcl_module.py:186-190) on the real rows."""
+        w = real_n.to(torch.float32)
+        z1, z2 = m.model.views(x, ei)
+        h1, h2 = [m.model.project(z).float() * w[:, None] for z in (z1, z2)]
+        return _MaskedNtXent.apply(h1, h2, w, self.v["sizes"][1:2], float(m.contrast_model.tau), ops.NtXentKernels())
 
     def _padded_step(self, e_b, aug):
         with as_captured():               # eager or recorded: the same kernels over the same (untightened) tables
@@ -263,7 +327,8 @@ class NeighborGraphedGcl:
         self.copied.record(main)                                           # the next batch is drawn UNDER this step
         self._draw_ahead(main)
         bucket = next(b for b in self.buckets if b >= max(e_b, 1))
-        aug = self.last_aug = self.coins.random() < self.module.model.p
+        # GGD's augmentation coin (host side in the reference too); DGI and GRACE have none: one graph per bucket
+        aug = self.last_aug = (self.coins.random() < self.module.model.p) if self.kind == "ggd" else False
         if not self.graphs_on:
             self.stats["eager_padded"] += 1
             return self._padded_step(bucket, aug).detach()

@@ -141,8 +141,8 @@ class Trainer:
             step_fn.loop, step_fn.owns_batches, step_fn.warmup_steps = loop, True, 0
             return step_fn
         from .samplers import NeighborBatchLoader
-        from .model.gcl import GGD
-        if isinstance(loader, NeighborBatchLoader) and isinstance(getattr(model, "model", None), GGD) \
+        from .model.gcl import DGI, GGD, GRACE
+        if isinstance(loader, NeighborBatchLoader) and isinstance(getattr(model, "model", None), (GGD, DGI, GRACE)) \
                 and loader.sampler.one_read_ok() and loader.x.size(0) > 0:
             # the reference's GCL regime (NeighborLoader batches): padded sync-free batches, one graph per edge bucket and
             # augmentation branch (biomedkg_amd/sampled_gcl.py)

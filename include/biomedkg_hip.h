@@ -459,6 +459,13 @@ int bkg_padded_loss_inputs(const int64_t* sizes, const int64_t* count, const int
 /* ---- modality fusion epilogues (biomedkg/utils/fusion.py:17-31 AttentionFusion, :49-90 ReDAF) */
 int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_t D, float* out, int64_t ldo,
                       void* stream);
+/* AttentionFusion in projected form (bf16 mode; reference biomedkg/utils/fusion.py:17-31 evaluated through two exact
+ * identities of its arithmetic -- q_a . k_b = x_a^T (Wq^T Wk) x_b + (Wq^T bk) . x_a + (Wk^T bq) . x_b + bq . bk, and
+ * sum_b c_b (Wv x_b + bv) = Wv (sum_b c_b x_b) + bv since the attention weights of a row sum to one): t = X (Wq^T Wk) and
+ * x as [2 n, D] bf16 tables -> the four scores per node, the 2 x 2 softmax, the modality-mean coefficients c_b and the
+ * combined row out[i] = c_0 x_{i,0} + c_1 x_{i,1} (bf16), over which the V projection then runs. */
+int bkg_attn_scores_combine_bf16(const void* t, int64_t ldt, const void* x, int64_t ldx, int64_t n, int32_t D,
+                                 const float* u, const float* w, float c0, void* out, int64_t ldo, void* stream);
 /* ReDAF dropout: `keep` (explicit mask, [n*M, D] bytes) or, when NULL and drop_p > 0, an in-kernel Philox stream keyed by
  * (seed, stream_id) -- the caller advances stream_id on every call, as nn.Dropout draws a fresh mask per forward. */
 int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int32_t M, int32_t D, const float* scale,

@@ -554,3 +554,51 @@ def test_dgi_two_views_side_by_side_equal_two_passes():
     assert abs(la - lb) <= 2e-3 * abs(la), (la, lb)
     for a, b in zip(ga, gb):
         assert float((a - b).norm() / a.norm().clamp_min(1e-12)) < 2e-2
+
+
+@pytest.mark.parametrize("d", [768, 256])
+def test_projected_attention_fusion_tracks_the_exact_path(d):
+    """bf16 mode evaluates AttentionFusion (reference fusion.py:17-31) in its projected form -- T = X (Wq^T Wk), the four
+    scores per node as row dots, V over the combined rows (ops._attention_fusion_projected) -- two identities of the
+    reference's arithmetic.  Held to the CPU oracle's AttentionFusion in float64 (the reference's literal form) and to the
+    build's exact-fp32 mode; the literal bf16 form (BKG_PROJECTED_ATTENTION=0 semantics) is the yardstick for what bf16
+    operands alone cost."""
+    from biomedkg_amd import ops, synthetic
+    from biomedkg_amd.utils.fusion import AttentionFusion
+    from oracle import ref_modules as O
+    n = 6000
+    x = synthetic.lm_features(n, 2, d, seed=3)
+    torch.manual_seed(2)
+    f = AttentionFusion(d).to(DEV).eval()
+    with torch.no_grad():
+        for p in (f.q_proj.bias, f.k_proj.bias, f.v_proj.bias):
+            p.uniform_(-0.3, 0.3)                                    # the bias terms of the identity must matter
+    o = O.AttentionFusion(d).double()
+    o.load_state_dict({k: v.double().cpu() for k, v in f.state_dict().items()})
+    want = o(x.double())
+    xd = x.to(DEV)
+    exact = f(xd).double().cpu()
+    assert float((exact - want).norm() / want.norm()) < 1e-5
+    ops.set_matmul_precision("bf16")
+    try:
+        calls = []
+        real = ops.L.call
+        ops.L.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        try:
+            got = f(xd).double().cpu()
+        finally:
+            ops.L.call = real
+        assert "bkg_attn_scores_combine_bf16" in calls and "bkg_attn_fuse_f32" not in calls
+        was = ops.PROJECTED_ATTENTION
+        ops.PROJECTED_ATTENTION = False
+        try:
+            xd2 = xd.clone()
+            literal = f(xd2).double().cpu()
+        finally:
+            ops.PROJECTED_ATTENTION = was
+    finally:
+        ops.set_matmul_precision("fp32")
+    err_proj = float((got - want).norm() / want.norm())
+    err_lit = float((literal - want).norm() / want.norm())
+    assert err_proj < 1e-2, err_proj
+    assert err_proj < 3.0 * err_lit + 1e-3, (err_proj, err_lit)     # no worse than bf16 operands make the literal form

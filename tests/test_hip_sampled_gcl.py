@@ -22,11 +22,12 @@ def _graph(n=3000, e=24000, seed=3):
     return synthetic.gcl_small(n, e, seed=seed).to(DEV), n
 
 
-def _module(in_dim=64, hidden=32, seed=0, fuse=None):
-    from biomedkg_amd.gcl_module import GGDModule
+def _module(in_dim=64, hidden=32, seed=0, fuse=None, kind="ggd"):
+    from biomedkg_amd import gcl_module as M
     torch.manual_seed(seed)
-    return GGDModule(in_dim=in_dim, hidden_dim=hidden, out_dim=hidden, num_hidden_layers=2, learning_rate=1e-3,
-                     fuse_method=fuse).to(DEV)
+    cls = {"ggd": M.GGDModule, "dgi": M.DGIModule, "grace": M.GRACEModule}[kind]
+    return cls(in_dim=in_dim, hidden_dim=hidden, out_dim=hidden, num_hidden_layers=2, learning_rate=1e-3,
+               fuse_method=fuse).to(DEV)
 
 
 def test_sync_free_sampler_equals_the_eager_device_sampler():
@@ -172,7 +173,86 @@ def test_padded_step_is_the_reference_step_on_the_real_part(precision, aug):
         ops.set_matmul_precision(prev)
 
 
-def _run(graphs, steps, seed=0, precision="fp32", max_graphs=16):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("kind", ["dgi", "grace"])
+def test_padded_dgi_and_grace_steps_are_the_reference_steps_on_the_real_part(kind, precision):
+    """Round 4: DGI (masked readout + masked JSD) and GRACE (zeroed pad rows + the pad columns' exp(0) taken out of every
+    denominator) in the padded form equal ``DGIModule`` / ``GRACEModule.training_step`` (reference gcl_module.py:140-143,
+    186-190) on the unpadded batch with the SAME draws: loss and every parameter gradient."""
+    from biomedkg_amd import rand as R, _lib as L, ops
+    from biomedkg_amd.sampled_gcl import NeighborGraphedGcl
+    ei, n = _graph()
+    x = torch.randn(n, 2, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 0.3
+    prev = ops.get_matmul_precision()
+    ops.set_matmul_precision(precision)
+    try:
+        mod = _module(fuse="attention", kind=kind).train()
+        lp = NeighborGraphedGcl(mod, x, ei, batch_size=8, num_neighbors=(4, 3, 3), seed=5, graphs=False)
+        seeds = torch.arange(40, 48, device=DEV)
+        lp.sampler.draw(seeds)
+        n_b, e_b = lp.sampler.sizes()
+        lp.last_sizes = (n_b, e_b)
+        lp.cur.copy_(lp.sampler.buf)
+        assert 8 < n_b < n and 0 < e_b
+        bucket = next(b for b in lp.buckets if b >= e_b)
+        tape = {"feat": [], "edge": [], "perm": []}
+
+        class Padded(type(lp.rand)):                 # the padded step, its draws kept in order
+            def feat_keep(self, x, p):
+                tape["feat"].append(super().feat_keep(x, p))
+                return tape["feat"][-1]
+
+            def masked(self, x, p):
+                return x * self.feat_keep(x, p)
+
+            def edge_keep(self, num_edges, p, device):
+                tape["edge"].append(super().edge_keep(num_edges, p, device))
+                return tape["edge"][-1]
+
+            def perm(self, n, device):
+                tape["perm"].append(super().perm(n, device))
+                return tape["perm"][-1]
+
+        class Same(Padded):                          # the ordinary step on the unpadded batch with the SAME draws
+            def feat_keep(self, x, p):
+                return tape["feat"].pop(0)[:x.size(0)]
+
+            def edge_keep(self, num_edges, p, device):
+                return tape["edge"].pop(0)[:num_edges].clone()
+
+            def perm(self, n, device):
+                self.counter += 1
+                return tape["perm"].pop(0)[:n].clone()
+
+        L.call("bkg_set_rng_epoch", L.ptr(lp.epoch))
+        try:
+            padded = Padded(lp.rand.seed, lp.rand.n_dev, lp.rand.epoch)
+            with R.use(padded):
+                padded.begin_step(False)
+                mod.zero_grad(set_to_none=True)
+                loss = lp.padded_loss(bucket)
+                loss.backward()
+                got = [p.grad.clone() for p in mod.model.parameters()]
+            assert len(tape["perm"]) == (1 if kind == "dgi" else 0) and len(tape["feat"]) == (2 if kind == "grace" else 0)
+            same = Same(lp.rand.seed, lp.rand.n_dev, lp.rand.epoch)
+            with R.use(same):
+                same.begin_step(False)
+                mod.zero_grad(set_to_none=True)
+                ref = mod.training_step(lp.unpadded_batch())
+                ref.backward()
+        finally:
+            L.call("bkg_set_rng_epoch", None)
+        assert torch.isfinite(loss) and all(torch.isfinite(g).all() for g in got)
+        tol = dict(rtol=2e-5, atol=1e-6) if precision == "fp32" else dict(rtol=3e-3, atol=3e-4)
+        torch.testing.assert_close(loss, ref, **tol)
+        for a, p in zip(got, mod.model.parameters()):
+            err = float((a - p.grad).norm() / p.grad.norm().clamp_min(1e-12))
+            assert err < (5e-4 if precision == "fp32" else 5e-2), err
+    finally:
+        ops.set_matmul_precision(prev)
+
+
+def _run(graphs, steps, seed=0, precision="fp32", max_graphs=16, kind="ggd"):
     from biomedkg_amd import ops
     from biomedkg_amd.sampled_gcl import NeighborGraphedGcl
     ei, n = _graph()
@@ -181,7 +261,7 @@ def _run(graphs, steps, seed=0, precision="fp32", max_graphs=16):
     ops.set_matmul_precision(precision)
     ops.set_deterministic(True)      # bitwise claims need the fixed-order weight-gradient sums (Trainer(deterministic=True))
     try:
-        mod = _module(fuse="attention").train()
+        mod = _module(fuse="attention", kind=kind).train()
         lp = NeighborGraphedGcl(mod, x, ei, batch_size=6, num_neighbors=(4, 3, 2), seed=seed, graphs=graphs,
                                 buckets=(64, 128, 192, 256, 384, 512, 1024, 24000), max_graphs=max_graphs)
         losses, sizes = [], []
@@ -208,6 +288,19 @@ def test_replayed_steps_equal_eager_padded_steps(precision):
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
     assert float(la[-5:].mean()) < float(la[:5].mean())                  # it trains
+
+
+@pytest.mark.parametrize("kind", ["dgi", "grace"])
+def test_replayed_dgi_and_grace_steps_equal_eager_padded_steps(kind):
+    steps = 30
+    la, sa, stats_a, pa = _run(True, steps, kind=kind)
+    lb, sb, stats_b, pb = _run(False, steps, kind=kind)
+    assert sa == sb and len({s[:2] for s in sa}) > 5
+    assert stats_a["captured"] >= 2 and stats_a["replayed"] >= steps // 3 and stats_b["eager_padded"] == steps
+    assert torch.isfinite(la).all()
+    assert torch.equal(la, lb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
 
 
 def test_graph_count_is_capped():
