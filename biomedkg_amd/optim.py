@@ -15,10 +15,13 @@ from __future__ import annotations
 
 import ctypes
 
+import importlib
+
 import torch
 
 from . import _lib as L
 
+_torch_optimizer = importlib.import_module("torch.optim.optimizer")     # (torch.optim deletes the attribute after import)
 _SCRATCH = {}
 
 
@@ -42,8 +45,8 @@ def clip_adam_step(opt, max_norm=None):
     # step hooks (optimizer.register_step_pre_hook / _post_hook, the global ones, a profiler's): this path never calls
     # opt.step(), so an optimizer that carries any takes torch's path, where they run
     hooked = bool(getattr(opt, "_optimizer_step_pre_hooks", None) or getattr(opt, "_optimizer_step_post_hooks", None)
-                  or getattr(torch.optim.optimizer, "_global_optimizer_pre_hooks", None)
-                  or getattr(torch.optim.optimizer, "_global_optimizer_post_hooks", None))
+                  or getattr(_torch_optimizer, "_global_optimizer_pre_hooks", None)
+                  or getattr(_torch_optimizer, "_global_optimizer_post_hooks", None))
     if hooked or not _supported(opt, params):
         norm = torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"]], max_norm) if max_norm else None
         opt.step()

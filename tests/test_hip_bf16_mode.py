@@ -575,8 +575,9 @@ def test_projected_attention_fusion_tracks_the_exact_path(d):
             p.uniform_(-0.3, 0.3)                                    # the bias terms of the identity must matter
     o = O.AttentionFusion(d).double()
     o.load_state_dict({k: v.double().cpu() for k, v in f.state_dict().items()})
-    want = o(x.double())
+    want = o(x.double()).detach()
     xd = x.to(DEV)
+    ops.set_matmul_precision("fp32")                 # (this file's fixture puts every test in bf16 mode)
     exact = f(xd).double().cpu()
     assert float((exact - want).norm() / want.norm()) < 1e-5
     ops.set_matmul_precision("bf16")
