@@ -27,8 +27,8 @@ averages the real rows (a masked column sum over a device count), the corruption
 the pad rows are multiplied by zero.  **GRACE** (``gcl_module.py:186-190``): the projected rows of the pads are zeroed
 before the NT-Xent, so a pad COLUMN is the zero vector and adds exactly ``exp(0) = 1`` to every real row's denominator --
 subtracted again as ``2 (n_cap - n_b)``, a device scalar -- and contributes nothing to any gradient (``E_ij z_j = 0``);
-pad ROWS get ``1 / D = 0`` and their gradient rows are cleared (``_MaskedNtXent``: the row-partitioned NT-Xent kernels of
-csrc/ntxent2.hip over all ``2 n_cap`` anchors).  GRACE draws two feature masks and two edge masks per step (in-kernel
+pad ROWS get ``1 / D = 0`` and their gradient rows are cleared (``_MaskedNtXent``: the symmetric NT-Xent kernels of
+csrc/ntxent2.hip over the ``2 n_cap`` rows, the same executed flops as the whole-batch loss).  GRACE draws two feature masks and two edge masks per step (in-kernel
 Philox / the device generator: graph-safe) and has no host coin: one graph per edge bucket.
 """
 from __future__ import annotations
@@ -119,30 +119,53 @@ class _StepRand(R.DeviceRand):
 
 class _MaskedNtXent(torch.autograd.Function):
     """NT-Xent (reference gcl_module.py:171-173: DualBranchContrast(InfoNCE(tau), L2L, intraview_negs)) over the REAL rows of
-    a padded batch.  ``h1 / h2 [n_cap, h]`` arrive with their pad rows zeroed; ``w [n_cap]`` (1.0 real, 0.0 pad) and the
-    real row count ``n_dev`` (int64 device scalar) say which.  Every size the kernels see is the capacity."""
+    a padded batch, through the SYMMETRIC matrix-core kernels of the whole-batch loss (csrc/ntxent2.hip: the same executed
+    flops as the unpadded step).  ``h1 / h2 [n_cap, h]`` arrive with their pad rows zeroed; ``w [n_cap]`` (1.0 real, 0.0
+    pad) and the real row count ``n_dev`` (int64 device scalar) say which.  A pad column is the zero vector: it adds
+    exactly exp(0) = 1 to every row's D -- taken out again as ``2 (n_cap - n_b)`` -- and nothing to any gradient; pad rows
+    get 1 / D = 0 and their gradient rows are cleared.  Every size the kernels see is the capacity."""
 
     @staticmethod
-    def forward(ctx, h1, h2, w, n_dev, tau, kernels):
-        n = h1.size(0)
-        zn, norm, posdot = kernels.normalize(h1, h2)                        # pad rows: the zero vector
-        anchors = torch.arange(2 * n, dtype=torch.int32, device=h1.device)
-        den = kernels.row_sums(zn, anchors, tau)                            # [2 n]: real columns + exp(0) per pad column
+    def forward(ctx, h1, h2, w, n_dev, tau, bf16):
+        h1, h2 = h1.contiguous(), h2.contiguous()
+        n, h = h1.shape
+        m, dev = 2 * n, h1.device
+        hpad = L.lib().bkg_ntxent_hpad(h, bf16)
+        if hpad < 0:
+            raise ValueError(f"ntxent: embedding width {h} > 256 is not supported")
+        zn = torch.empty(m, hpad, dtype=torch.float32, device=dev)
+        zn16 = torch.empty(m, hpad, dtype=torch.bfloat16, device=dev) if bf16 else None
+        norm = torch.empty(m, dtype=torch.float32, device=dev)
+        posdot = torch.empty(n, dtype=torch.float32, device=dev)
+        L.call("bkg_ntxent_prepare", L.ptr(h1), h1.stride(0), L.ptr(h2), h2.stride(0), n, h, hpad, tau, L.ptr(zn), L.ptr(zn16),
+               L.ptr(norm), L.ptr(posdot), L.stream())
+        ws = torch.empty(L.lib().bkg_ntxent_forward_workspace_floats(m, h, bf16), dtype=torch.float32, device=dev)
+        den = torch.empty(2, m, dtype=torch.float32, device=dev)
+        L.call("bkg_ntxent_forward", L.ptr(zn16 if bf16 else zn), bf16, m, h, tau, L.ptr(posdot), L.ptr(ws), L.ptr(den[0]),
+               L.ptr(den[1]), None, None, L.stream())
         n_b = n_dev.to(torch.float32)
         w2 = torch.cat([w, w])
-        den = torch.where(w2 > 0, den - 2.0 * (n - n_b), torch.full_like(den, float("inf")))
-        terms = (torch.log(den.double()) * w2.double()).nan_to_num(posinf=0.0).sum() - 2.0 * (posdot.double() * w.double()).sum() / tau
-        ctx.tau, ctx.kernels, ctx.n = tau, kernels, n
-        ctx.save_for_backward(zn, norm, den, anchors, w2, n_b)
+        real = w2 > 0
+        d_real = torch.where(real, den[0] - 2.0 * (n - n_b), torch.ones_like(den[0]))       # (pads: log 1 = 0)
+        rden = torch.where(real, 1.0 / d_real, torch.zeros_like(d_real)).contiguous()
+        terms = torch.log(d_real.double()).sum() - 2.0 * (posdot.double() * w.double()).sum() / tau
+        ctx.tau, ctx.n, ctx.h, ctx.bf16 = tau, n, h, bf16
+        ctx.save_for_backward(zn, zn16, norm, rden, real, n_b)
         return (terms / (2.0 * n_b.double())).float().reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        zn, norm, den, anchors, w2, n_b = ctx.saved_tensors
-        scale = g.reshape(1).float() / (2.0 * n_b * ctx.tau)
-        dh = ctx.kernels.row_grads(zn, anchors, den, norm, ctx.tau, scale, ctx.n)           # [2 n, h]
-        dh = torch.where(w2[:, None] > 0, dh, torch.zeros_like(dh))          # (a pad row's normalisation divides by eps)
-        return dh[: ctx.n], dh[ctx.n:], None, None, None, None
+        zn, zn16, norm, rden, real, n_b = ctx.saved_tensors
+        n, h, tau, bf16 = ctx.n, ctx.h, ctx.tau, ctx.bf16
+        m, dev = 2 * n, zn.device
+        # the kernel's own mean runs over all 2 n_cap rows: rescale to the 2 n_b real ones (a device scalar)
+        gout = (g.reshape(1).float() * (float(n) / n_b)).contiguous()
+        ws = torch.empty(L.lib().bkg_ntxent_backward_workspace_floats(m, h, bf16), dtype=torch.float32, device=dev)
+        dh = torch.empty(2, n, h, dtype=torch.float32, device=dev)
+        L.call("bkg_ntxent_backward", L.ptr(zn16 if bf16 else zn), bf16, L.ptr(zn), L.ptr(norm), L.ptr(rden), L.ptr(gout), m, h,
+               tau, L.ptr(ws), L.ptr(dh[0]), h, L.ptr(dh[1]), h, L.stream())
+        dh = torch.where(real.view(2, n, 1), dh, torch.zeros_like(dh))       # (a pad row's normalisation divides by eps)
+        return dh[0], dh[1], None, None, None, None
 
 
 class NeighborGraphedGcl:
@@ -271,7 +294,8 @@ class NeighborGraphedGcl:
         w = real_n.to(torch.float32)
         z1, z2 = m.model.views(x, ei)
         h1, h2 = [m.model.project(z).float() * w[:, None] for z in (z1, z2)]
-        return _MaskedNtXent.apply(h1, h2, w, self.v["sizes"][1:2], float(m.contrast_model.tau), ops.NtXentKernels())
+        return _MaskedNtXent.apply(h1, h2, w, self.v["sizes"][1:2], float(m.contrast_model.tau),
+                                   int(ops.get_matmul_precision() == "bf16"))
 
     def _padded_step(self, e_b, aug):
         with as_captured():               # eager or recorded: the same kernels over the same (untightened) tables
