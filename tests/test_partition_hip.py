@@ -237,6 +237,19 @@ def _two_rank_worker(rank, world, port, outdir):
     for t in grads:
         dist.all_reduce(t); t /= world
     out["kge"] = (P.loss_value(loss, world).cpu(), [t.cpu() for t in grads])
+    # the DPI fine-tune's decoder (BASELINE configs[4]: TransE, every relation id forced to 1) over the same partition
+    torch.manual_seed(6)
+    dpi = KGEModule("rgcn", "transe", 256, 256, 256, 2, r, 1, "cosine", 1e-3, 0.1, "none", 1, "random").to(DEV).eval()
+    one = torch.full_like(et, 1)
+    prg1 = P.PartitionedRelGraph(part, ei, one, r, P.HipBackend)
+    loss = P.kge_loss_partitioned(dpi.model, part.shard(x), prg1, P.HipBackend, P.TripletShare(part, ei, one),
+                                  P.TripletShare(part, neg, torch.full_like(nt, 1)), dpi.model.decoder.kind,
+                                  n_pos_global=ei.size(1), n_neg_global=neg.size(1))
+    loss.backward()
+    grads = [p.grad.clone() for p in dpi.model.parameters()]
+    for t in grads:
+        dist.all_reduce(t); t /= world
+    out["dpi_transe"] = (P.loss_value(loss, world).cpu(), [t.cpu() for t in grads])
     # GRACE head on the rank's rows: encoder over the shard (no augmentation), projector, row-partitioned NT-Xent
     z = P.gcn_encoder_partitioned(grace.model.encoder, part.shard(x), pg, P.HipBackend)
     h1 = grace.model.project(z)
@@ -259,13 +272,15 @@ def test_fused_partitioned_steps_two_ranks_on_one_gpu_match_one_rank(tmp_path):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         mp.spawn(_two_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
         res[world] = torch.load(tmp_path / f"w{world}_r0.pt")
-    for key in ("ggd", "kge", "grace"):
+    for key in ("ggd", "kge", "dpi_transe", "grace"):
         l1, g1 = res[1][key]
         l2, g2 = res[2][key]
         assert abs(float(l1) - float(l2)) <= 2e-3 * abs(float(l1)), (key, float(l1), float(l2))
         for a, b in zip(g1, g2):
+            if float(a.norm()) == 0.0 and float(b.norm()) == 0.0:
+                continue                                 # (relation rows no triplet uses under fix_edge_id)
             err = float((a - b).norm() / a.norm().clamp_min(1e-12))
-            assert err < 3e-2, (key, err)
+            assert err < (3e-2 if key != "dpi_transe" else 6e-2), (key, err)   # TransE: a sum of signs (ties flip)
 
 
 def test_collectives_of_the_partitioned_step_over_a_one_rank_rccl_group():
