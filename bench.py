@@ -289,11 +289,14 @@ def build_partitioned_steps(args, rank, world, dev):
     # both-owner scoring (partition.TripletShare): the rank scores every triplet that touches one of its nodes -- counted
     # by the owner of its head -- and reduces the embedding gradient of its own rows; no dz ever crosses the wire
     pos = P.TripletShare(part, ei, et)
-    neg_sampler = sampling.BlockNegativeSampler(ei, et, part.bounds, rank, args.neg_ratio * e)
+    neg_sampler = sampling.BlockNegativeSampler(ei, et, part.bounds, rank, args.neg_ratio * e, num_relations=r,
+                                                n_max=part.n_max)
     shared = torch.Generator(device=dev).manual_seed(7)       # replicated draws: identical on every rank
     shared_host = torch.Generator().manual_seed(7)            # ... the augmentation coin / the negatives' seed: host draws
     own = torch.Generator().manual_seed(1000 + rank)          # per-rank seeds for the in-kernel streams
     counter = [0]
+    from biomedkg_amd import rand as R
+    shared_rand = R.DeviceRand(seed=777)                      # replicated device draws (GGD's corruption permutation)
 
     def own_seed():
         return int(torch.randint(0, 1 << 31, (1,), generator=own))
@@ -322,16 +325,17 @@ def build_partitioned_steps(args, rank, world, dev):
         if coin if force_aug is None else force_aug:
             x = ops.masked_bf16(xg, 0.4, own_seed(), rank) if ops.bf16_storage() else xg * (torch.rand_like(xg) >= 0.4)
             keep = torch.rand(e, generator=shared, device=dev) >= 0.4
-        perm = torch.randperm(n, generator=shared, device=dev)
+        perm = shared_rand.perm(n, dev)            # a keyed bijection, the same key on every rank (one launch, no sort)
         return P.ggd_loss_partitioned(gcl.model, x, pg, P.HipBackend, perm, dropout_of, keep=keep)
 
     def kge_loss():
         # reference kge_module.py:86-102 over a partition: every rank draws the blocks of the cell grid that touch its
-        # nodes from the step's SHARED seed (the two owners of a block get the same triplets), relation ids =
-        # edge_type.repeat(k)[randperm] per global position
+        # nodes from the step's SHARED seed (the two owners of a block get the same triplets); the relation ids --
+        # edge_type.repeat(k), dealt to the blocks once, relation-grouped inside a block -- are constants of the partition
         seed = int(torch.randint(0, 1 << 62, (1,), generator=shared_host))
-        idx, types, n_own = neg_sampler.draw(seed)
-        neg = P.TripletShare(part, idx, types, n_own=n_own, entries=neg_sampler.entries)
+        smp = neg_sampler
+        neg = P.TripletShare(part, None, smp.types, n_own=smp.n_own, entries=smp.entries, slots=smp.draw(seed),
+                             types_own=smp.types_own, types_foreign=smp.types_foreign)
         return P.kge_loss_partitioned(kge.model, xk, prg, P.HipBackend, pos, neg, kge.model.decoder.kind, dropout_of,
                                       n_pos_global=e, n_neg_global=args.neg_ratio * e)
 

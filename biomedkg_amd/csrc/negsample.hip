@@ -273,6 +273,7 @@ struct NegBlock {
   int64_t out0, k;                          // its survivors go to out[out0 .. out0 + k)
   int64_t gpos0;                            // global position of its first negative (relation ids)
   int64_t id;                               // a * world + b (seeds its permutation)
+  int64_t row_shift, col_shift;             // added to the head / tail id on the way out (node id -> slot of the gathered table)
 };
 
 __device__ __forceinline__ int neg_block_of(const NegBlock* __restrict__ blocks, int n_blocks, int64_t i) {
@@ -334,8 +335,8 @@ __global__ __launch_bounds__(256) void negative_scatter_blocks_kernel(const NegB
   const int64_t survivors = (int64_t)offs[last] + flag[last] - base;
   const int64_t have = survivors < blk.k ? survivors : blk.k;
   auto put = [&](int64_t p, int64_t r, int64_t c) {
-    out_head[blk.out0 + p] = r;
-    out_tail[blk.out0 + p] = c;
+    out_head[blk.out0 + p] = r + blk.row_shift;
+    out_tail[blk.out0 + p] = c + blk.col_shift;
     if (out_type) out_type[blk.out0 + p] = pos_type[sigma((uint64_t)(blk.gpos0 + p)) % (uint64_t)n_pos];
   };
   if (j < blk.n_cand && flag[i]) {
@@ -408,8 +409,9 @@ extern "C" int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int
 
 extern "C" int64_t bkg_negative_blocks_struct_bytes(void) { return (int64_t)sizeof(NegBlock); }
 
-// Block-structured negative sampling (see NegBlock): `blocks` is a DEVICE array of n_blocks descriptors (11 int64 each:
-// row_lo, n_rows, col_lo, n_cols, population, cand0, n_cand, out0, k, gpos0, id; cand0 ascending multiples of 256),
+// Block-structured negative sampling (see NegBlock): `blocks` is a DEVICE array of n_blocks descriptors (13 int64 each:
+// row_lo, n_rows, col_lo, n_cols, population, cand0, n_cand, out0, k, gpos0, id, row_shift, col_shift; cand0 ascending
+// multiples of 256; the shifts turn node ids into slots of a rank's gathered table on the way out),
 // n_cand_total the padded candidate count (a multiple of 256).  out_head / out_tail / out_type: sum of k entries;
 // pos_type: the n_pos positives' relation ids (out_type nullable); count[n_blocks]: survivors kept per block (== k unless
 // a block fell short).

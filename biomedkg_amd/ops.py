@@ -1139,9 +1139,17 @@ class LocalIncidence:
         flat = slot_index.contiguous().view(-1)
         if entries is None:
             entries = torch.nonzero((flat >= row0) & (flat < row0 + n_local)).squeeze(1)     # (one host read: static sets)
-        keys = (flat[entries] - row0).contiguous()
-        _, perm, self.rowptr = _Sorter.sort_rowptr(keys, None, max(n_local, 1), 1, n_local + 1)
-        self.perm = entries.to(torch.int32)[perm.long()].contiguous()
+        if entries.numel() == flat.numel():              # every entry is local (one rank): the whole-graph incidence lists
+            keys = flat if row0 == 0 else flat - row0
+            _, self.perm, self.rowptr = _Sorter.sort_rowptr(keys.contiguous(), None, max(n_local, 1), 1, n_local + 1)
+        else:
+            keys = (flat[entries] - row0).contiguous()
+            _, perm, self.rowptr = _Sorter.sort_rowptr(keys, None, max(n_local, 1), 1, n_local + 1)
+            e32 = entries if entries.dtype == torch.int32 else getattr(entries, "_bkg_i32", None)
+            if e32 is None:                              # (a static position list keeps its int32 form)
+                e32 = entries._bkg_i32 = entries.to(torch.int32)
+            self.perm = torch.empty_like(perm)
+            L.call("bkg_gather_i32", L.ptr(e32), L.ptr(perm), L.ptr(self.perm), perm.numel(), L.stream())
         self.n_inc, self.n_rows, self.row0 = int(entries.numel()), int(n_local), int(row0)
         small = n_local <= 4096 and self.n_inc < (1 << 18)
         self.split = None if small else rowsplit_for(self.rowptr, n_local, self.n_inc)
@@ -1153,17 +1161,22 @@ class OwnedTriplets:
     the tail is local, the head is not: scored for d score only (the head's owner counts them).  Indices are table slots.
     ``incidence``: the rank's nodes' lists over ``cat(own, foreign)``."""
 
-    def __init__(self, own_index, own_type, foreign_index, foreign_type, row0, n_local, entries=None):
-        self.own_index, self.own_type = own_index.contiguous(), own_type.contiguous()
-        self.foreign_index, self.foreign_type = foreign_index.contiguous(), foreign_type.contiguous()
+    def __init__(self, own_index, own_type, foreign_index, foreign_type, row0, n_local, entries=None, both=None):
+        """``both`` (optional): ``cat(own_index, foreign_index, dim=1)`` when the caller already holds it (the two index
+        tensors are then usually its column ranges: rows contiguous, which is all the kernels need)."""
+        rows_ok = lambda t: t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()       # noqa: E731
+        self.own_index, self.own_type = rows_ok(own_index), own_type.contiguous()
+        self.foreign_index, self.foreign_type = rows_ok(foreign_index), foreign_type.contiguous()
         self.n_own, self.n_foreign = int(own_index.size(1)), int(foreign_index.size(1))
         self.row0, self.n_local, self._entries, self._inc = int(row0), int(n_local), entries, None
+        self._both = both
 
     @property
     def incidence(self):
         if self._inc is None:
-            both = torch.cat([self.own_index, self.foreign_index], dim=1)
+            both = self._both if self._both is not None else torch.cat([self.own_index, self.foreign_index], dim=1)
             self._inc = LocalIncidence(both, self.row0, self.n_local, self._entries)
+            self._both = None
         return self._inc
 
 

@@ -738,7 +738,10 @@ def ggd_loss_partitioned(ggd, x_local, pg: PartitionedGraph, backend, perm, drop
             if ops.features_bf16_ok(x_local):
                 x_local = ops.cached_bf16(x_local)
             xw = ops.xw_table(x_local, layer0.lin.weight)                   # [n_local, h] bf16
-            h = _PairedTable.apply(xw, perm_slots, part.comm, ops.pair_rows)    # slot j: [xw_j | xw_perm(j)], whole table
+            if part.comm.live:
+                h = _PairedTable.apply(xw, perm_slots, part.comm, ops.pair_rows)    # slot j: [xw_j | xw_perm(j)], whole table
+            else:                                   # one rank: nothing to gather -- the single-GPU pairing and its one-launch backward
+                h = ops.pair_rows(xw, perm)
             for i, layer in enumerate(enc.graph_layers):
                 drop = None
                 if i != last and enc.drop_out and enc.training and dropout_of is not None:
@@ -753,6 +756,8 @@ def ggd_loss_partitioned(ggd, x_local, pg: PartitionedGraph, backend, perm, drop
                 s = ops.linear_rowsum(hh, head.weight, head.bias).view(n_loc, 2)
             else:
                 s = ops.linear(hh, head.weight, head.bias).sum(1).view(n_loc, 2)
+            if ops.ggd_bce_ok(s[:, 0], s[:, 1]):          # mean over the 2 n_loc local logits, one launch each way
+                return ops.ggd_bce(s[:, 0], s[:, 1]) * (2.0 * n_loc * part.world / total)
             pred = torch.cat([s[:, 0], s[:, 1]])
             gt = torch.cat([torch.ones_like(s[:, 0]), torch.zeros_like(s[:, 1])])
             return torch.nn.functional.binary_cross_entropy_with_logits(pred, gt, reduction="sum") * (part.world / total)
@@ -800,7 +805,10 @@ class TripletShare:
     ``n_own`` first; ``entries``: positions in ``cat(head, tail)`` of the incidences with a local node when the caller
     knows them by construction (sampling.BlockNegativeSampler), else found with one mask + host read (static positives)."""
 
-    def __init__(self, part, index, types, n_own=None, entries=None):
+    def __init__(self, part, index, types, n_own=None, entries=None, slots=None, types_own=None, types_foreign=None):
+        """``slots``: the triplets' table slots when the producer already wrote them (``BlockNegativeSampler`` with
+        ``n_max``: ``index`` is then not needed and may be None); ``types_own / types_foreign``: persistent tensors of the
+        two id ranges (their relation order is cached ON the tensor object: a fresh slice per step would re-sort)."""
         if n_own is None:
             h_loc, t_loc = part.is_local(index[0]), part.is_local(index[1])
             own = torch.nonzero(h_loc).squeeze(1)
@@ -808,9 +816,13 @@ class TripletShare:
             order = torch.cat([own, foreign])
             index, types, n_own = index[:, order], types[order], int(own.numel())
         self.part, self.n_own = part, int(n_own)
-        self.index, self.types = index.contiguous(), types.contiguous()
-        self.slots = part.slots(self.index).contiguous()
+        self.index = index.contiguous() if index is not None else None
+        self.types = types.contiguous()
+        self.slots = slots if slots is not None else part.slots(self.index).contiguous()
         self.entries = entries
+        k = self.n_own
+        self.types_own = types_own if types_own is not None else self.types[:k].contiguous()
+        self.types_foreign = types_foreign if types_foreign is not None else self.types[k:].contiguous()
         self._owned = None
 
     def owned(self):
@@ -818,8 +830,9 @@ class TripletShare:
         if self._owned is None:
             from . import ops
             k, part = self.n_own, self.part
-            self._owned = ops.OwnedTriplets(self.slots[:, :k], self.types[:k], self.slots[:, k:], self.types[k:],
-                                            part.rank * part.n_max if part.comm.live else 0, part.n_local, self.entries)
+            self._owned = ops.OwnedTriplets(self.slots[:, :k], self.types_own, self.slots[:, k:], self.types_foreign,
+                                            part.rank * part.n_max if part.comm.live else 0, part.n_local, self.entries,
+                                            both=self.slots)
         return self._owned
 
 

@@ -193,20 +193,32 @@ class BlockNegativeSampler:
     allocation (PyG draws a simple random sample: same marginals) -- from its own keyed permutation seeded by
     ``(seed, a, b)``.  Rank r draws the blocks of its row band (it owns the heads: these triplets count in its loss) and
     of its column band (tails local, heads remote: scored for the gradient of its own rows only); the other owner of a
-    block draws the very same triplets, so the scorer's backward needs no exchange at all.  Relation ids: the reference's
-    ``edge_type.repeat(neg_ratio)[randperm(k)]`` (kge_module.py:97-100) evaluated per global position.
+    block draws the very same triplets, so the scorer's backward needs no exchange at all.
 
-    ``draw(seed)`` -> ``(index [2, k_r] global ids, types [k_r], n_own)`` in the fixed layout [block (r, r) | blocks (r, b != r)
-    | blocks (a != r, r)]; ``entries``: positions in ``cat(head, tail)`` of the incidences with a local node (known by
-    construction: no mask, no count read inside the step).  All ranks must pass the same seed."""
+    Relation ids (the reference's ``edge_type.repeat(neg_ratio)[randperm(k)]``, kge_module.py:97-100): the multiset
+    ``edge_type.repeat(neg_ratio)`` is dealt to the blocks ONCE, by a fixed low-discrepancy bijection of the k positions
+    (global position p holds the ``(p * stride) mod k``-th id of the relation-sorted list, stride ~ 0.618 k coprime to k:
+    every block's contiguous range samples all relations in proportion), and laid out relation-grouped inside a block.
+    The negatives a block pairs them with arrive in exchangeable order (the first survivors of a keyed permutation of the
+    block's cells), so this fixed arrangement IS a uniformly random pairing within the block -- the argument of
+    ``ops.grouped_types`` block by block -- the exact multiset over all blocks, and every rank derives the same table.
+    What it buys: the ids, their relation order and the scorer's wave tables are constants of the (partition, k) pair --
+    no per-step permutation, no per-step sort.
 
-    def __init__(self, edge_index, edge_type, bounds, rank, k):
+    ``draw(seed)`` -> ``index [2, k_r]`` (node ids, or table SLOTS when the sampler was given ``n_max``) in the fixed
+    layout [block (r, r) | blocks (r, b != r) | blocks (a != r, r)]; ``types`` / ``types_own`` / ``types_foreign``: the
+    static ids of that layout; ``entries``: positions in ``cat(head, tail)`` of the incidences with a local node (known
+    by construction: no mask, no count read inside the step).  All ranks must pass the same seed."""
+
+    def __init__(self, edge_index, edge_type, bounds, rank, k, num_relations=None, n_max=None):
         L.require_cuda(edge_index, edge_type)
         dev = edge_index.device
         world = len(bounds) - 1
         n = int(bounds[-1])
         self.n, self.k, self.rank, self.world = n, int(k), int(rank), world
-        self.edge_type = edge_type.contiguous()
+        e = int(edge_type.numel())
+        if self.k <= 0 or e == 0 or self.k % e:
+            raise ValueError("k must be a positive multiple of the positives' count (neg_ratio * E)")
         self.table = _positive_table(edge_index, n)
         sizes = [bounds[i + 1] - bounds[i] for i in range(world)]
         # free cells per block: population minus the distinct loop-free positives inside it
@@ -236,6 +248,7 @@ class BlockNegativeSampler:
         rows, cand0, out0 = [], 0, 0
         self.n_own = 0
         layout = []                                           # (block id, out0, k) of the rank's blocks, in output order
+        shift = (lambda owner: owner * int(n_max) - bounds[owner]) if (n_max is not None and world > 1) else (lambda owner: 0)
         for bid in order:
             a, b = divmod(bid, world)
             kq = quota[bid]
@@ -247,7 +260,7 @@ class BlockNegativeSampler:
             # binomial's); the whole block when that is most of it anyway
             m = int((kq + 6.0 * (kq * max(1.0 - p, 0.0)) ** 0.5 + 8.0) / p) + 1
             m = min(max(m, kq), pop[bid])
-            rows.append([bounds[a], sizes[a], bounds[b], sizes[b], pop[bid], cand0, m, out0, kq, gpos[bid], bid])
+            rows.append([bounds[a], sizes[a], bounds[b], sizes[b], pop[bid], cand0, m, out0, kq, gpos[bid], bid, shift(a), shift(b)])
             layout.append((bid, out0, kq))
             cand0 += -(-m // 256) * 256
             out0 += kq
@@ -255,8 +268,9 @@ class BlockNegativeSampler:
                 self.n_own += kq
         self.layout, self.k_rank, self.n_cand = layout, out0, cand0
         self.n_blocks = len(rows)
-        assert L.lib().bkg_negative_blocks_struct_bytes() == 11 * 8
-        self.blocks = torch.tensor(rows if rows else [[0] * 11], dtype=torch.int64, device=dev)
+        self.slots = n_max is not None
+        assert L.lib().bkg_negative_blocks_struct_bytes() == 13 * 8
+        self.blocks = torch.tensor(rows if rows else [[0] * 13], dtype=torch.int64, device=dev)
         self.ws_bytes = L.lib().bkg_negative_sample_workspace_bytes(max(cand0, 1))
         # incidences with a local node, by construction: heads of the own blocks, tails of block (r, r), tails of the
         # foreign blocks -- positions in cat(head [k_r], tail [k_r])
@@ -264,22 +278,45 @@ class BlockNegativeSampler:
         ar = lambda lo, hi: torch.arange(lo, hi, device=dev, dtype=torch.int64)          # noqa: E731
         self.entries = torch.cat([ar(0, self.n_own), self.k_rank + ar(0, k_rr), self.k_rank + ar(self.n_own, self.k_rank)])
         self.count = None
+        # ---- the relation ids of the rank's blocks: constants of (partition, k)
+        et = edge_type.contiguous()
+        nrel = int(num_relations) if num_relations is not None else int(et.max().item()) + 1
+        self.num_relations = nrel
+        sorted_ids = torch.sort(et).values                                   # the relation-sorted positives' ids ...
+        ratio = self.k // e                                                  # ... each standing for `ratio` consecutive entries
+        stride = int(self.k * 0.6180339887498949) | 1
+        from math import gcd
+        while gcd(stride, self.k) != 1:
+            stride += 2
+        parts = []
+        for bid, o0, kq in layout:
+            if kq == 0:
+                continue
+            p = gpos[bid] + ar(0, kq)
+            parts.append(torch.sort(sorted_ids[((p * stride) % self.k) // ratio]).values)
+        self.types = torch.cat(parts) if parts else et.new_empty(0)
+        self.types_own = self.types[: self.n_own].clone()
+        self.types_foreign = self.types[self.n_own:].clone()
+        for t in (self.types_own, self.types_foreign):                       # their relation order, computed once
+            if t.numel():
+                perm = torch.argsort(t, stable=True).to(torch.int32)
+                ptr = torch.searchsorted(t[perm.long()].contiguous(), torch.arange(nrel + 1, device=dev)).to(torch.int32)
+                t._bkg_cache = {"rel_order": ((t._version, nrel), (perm, ptr))}
 
-    def draw(self, seed, with_types=True):
+    def draw(self, seed):
         dev = self.blocks.device
         kr = self.k_rank
         out = torch.empty(2, kr, dtype=torch.int64, device=dev)
-        types = torch.empty(kr, dtype=torch.int64, device=dev) if with_types else None
         self.count = torch.zeros(max(self.n_blocks, 1), dtype=torch.int32, device=dev)
         if self.n_blocks and self.n_cand:
             keys = torch.empty(self.n_cand, dtype=torch.int64, device=dev)
             flag = torch.empty(2, self.n_cand, dtype=torch.int32, device=dev)
             ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
             L.call("bkg_negative_sample_blocks", L.ptr(self.blocks), self.n_blocks, self.n_cand, self.n, int(seed) & ((1 << 64) - 1),
-                   self.k, L.ptr(self.table), self.table.numel(), L.ptr(self.edge_type), self.edge_type.numel(), L.ptr(keys),
-                   L.ptr(flag[0]), L.ptr(flag[1]), L.ptr(out[0]), L.ptr(out[1]), L.ptr(types), L.ptr(self.count), L.ptr(ws),
+                   self.k, L.ptr(self.table), self.table.numel(), None, 0, L.ptr(keys),
+                   L.ptr(flag[0]), L.ptr(flag[1]), L.ptr(out[0]), L.ptr(out[1]), None, L.ptr(self.count), L.ptr(ws),
                    ws.numel(), L.stream())
-        return out, types, self.n_own
+        return out
 
     def shortfall(self):
         """Negatives the last draw's blocks fell short by (a host read: tests / diagnostics only)."""

@@ -421,9 +421,11 @@ int bkg_negative_sample(int64_t n_nodes, int64_t first_candidate, int64_t n_cand
  * call of PyG negative_sampling, reference biomedkg/kge_module.py:93, when a graph's nodes are partitioned): the cell grid
  * is cut into (head owner, tail owner) blocks, each with its own keyed permutation and its share of the K negatives, so the
  * two owners of a block draw identical triplets and nothing crosses the wire.  blocks: device array of n_blocks
- * descriptors of bkg_negative_blocks_struct_bytes() bytes (11 int64: row_lo, n_rows, col_lo, n_cols, population, cand0,
- * n_cand, out0, k, gpos0, id).  out_type[p] = pos_type[sigma(gpos0 + rank) % n_pos]: edge_type.repeat(k)[randperm]
- * (kge_module.py:97-100) evaluated position by position. */
+ * descriptors of bkg_negative_blocks_struct_bytes() bytes (13 int64: row_lo, n_rows, col_lo, n_cols, population, cand0,
+ * n_cand, out0, k, gpos0, id, row_shift, col_shift -- the shifts are added to head / tail on the way out: node id -> slot
+ * of the rank's gathered table).  out_type (nullable) [p] = pos_type[sigma(gpos0 + rank) % n_pos]: edge_type.repeat(k)
+ * [randperm] (kge_module.py:97-100) evaluated position by position; callers that allot the ids to the blocks themselves
+ * (sampling.BlockNegativeSampler: relation-grouped inside every block) pass NULL. */
 int64_t bkg_negative_blocks_struct_bytes(void);
 int bkg_negative_sample_blocks(const void* blocks, int32_t n_blocks, int64_t n_cand_total, int64_t n_nodes, uint64_t seed,
                                int64_t k_global, const uint64_t* pos_table, int64_t pos_capacity, const int64_t* pos_type,

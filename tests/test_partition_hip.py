@@ -356,8 +356,9 @@ def test_block_negative_sampler_is_pyg_negative_sampling_cut_by_owner_blocks(wor
     negatives are K distinct off-diagonal non-edges -- PyG negative_sampling's contract, reference kge_module.py:93 --
     allotted to the (head owner, tail owner) blocks in proportion to their free cells; the two owners of a block draw the
     SAME triplets and relation ids; the ids over all K positions are edge_type.repeat(k)[a permutation] (kge_module.py:97-
-    100); the incidence positions handed to the scorer are exactly the entries with a local node; another seed gives
-    other negatives."""
+    100) -- dealt to the blocks once, relation-grouped inside a block, every relation in every block in proportion; the
+    incidence positions handed to the scorer are exactly the entries with a local node; another seed gives other
+    negatives."""
     from biomedkg_amd import partition as P, sampling, synthetic
     g = synthetic.primekg_like(3000, 60_000, 8, seed=2)
     ei, et, n = g["edge_index"].to(DEV), g["edge_type"].to(DEV), g["num_nodes"]
@@ -368,8 +369,18 @@ def test_block_negative_sampler_is_pyg_negative_sampling_cut_by_owner_blocks(wor
     for rank in range(world):
         part = P.NodePartition(ei, n, rank, world)
         smp = sampling.BlockNegativeSampler(ei, et, part.bounds, rank, k)
-        idx, types, n_own = smp.draw(seed=77)
+        idx, types, n_own = smp.draw(seed=77), smp.types, smp.n_own
         assert smp.shortfall() == 0
+        assert torch.equal(torch.cat([smp.types_own, smp.types_foreign]), types)
+        # the ids of the two ranges come with their relation order (computed once, cached on the tensors)
+        from biomedkg_amd import ops
+        for t in (smp.types_own, smp.types_foreign):
+            if t.numel():
+                order, ptr = ops.relation_order_of(t, smp.num_relations)
+                assert bool((t[order.long()][1:] >= t[order.long()][:-1]).all()) and int(ptr[-1]) == t.numel()
+        # with n_max the same draw comes out in table slots
+        slot_smp = sampling.BlockNegativeSampler(ei, et, part.bounds, rank, k, n_max=part.n_max)
+        assert torch.equal(slot_smp.draw(seed=77), part.slots(idx))
         assert idx.shape == (2, smp.k_rank) and types.shape == (smp.k_rank,) and n_own == smp.n_own
         h_loc, t_loc = part.is_local(idx[0]), part.is_local(idx[1])
         assert bool(h_loc[:n_own].all()) and not bool(h_loc[n_own:].any()) and bool(t_loc[n_own:].all())
@@ -387,10 +398,8 @@ def test_block_negative_sampler_is_pyg_negative_sampling_cut_by_owner_blocks(wor
                 assert torch.equal(blocks[bid], triple), f"the two owners of block {bid} drew different triplets"
             blocks[bid] = triple
         counted.append(torch.cat([idx[:, :n_own], types[None, :n_own]]).cpu())
-        again = smp.draw(seed=77)
-        assert torch.equal(again[0], idx) and torch.equal(again[1], types)            # a pure function of (graph, seed)
-        other = smp.draw(seed=78)[0]
-        assert not torch.equal(other, idx)
+        assert torch.equal(smp.draw(seed=77), idx)                                    # a pure function of (graph, seed)
+        assert not torch.equal(smp.draw(seed=78), idx)
     assert len(blocks) == world * world
     allneg = torch.cat(counted, dim=1)
     assert allneg.size(1) == k
@@ -408,8 +417,13 @@ def test_block_negative_sampler_is_pyg_negative_sampling_cut_by_owner_blocks(wor
     used = torch.bincount(torch.bucketize(cells // n, bt, right=True) * world + torch.bucketize(cells % n, bt, right=True),
                           minlength=world * world).tolist()
     free = [sizes[a] * (sizes[b] - (a == b)) - used[a * world + b] for a in range(world) for b in range(world)]
+    share = torch.bincount(et, minlength=8).double().cpu() / et.numel()
     for bid in range(world * world):
         assert abs(blocks[bid].size(1) - k * free[bid] / sum(free)) <= 1.0
+        kb = blocks[bid].size(1)
+        if kb >= 2000:                      # every relation turns up in every block in proportion (low-discrepancy deal)
+            got = torch.bincount(blocks[bid][2], minlength=8).double() / kb
+            assert float((got - share).abs().max()) < 0.02, (bid, got, share)
 
 
 def test_block_negative_sampler_in_a_block_that_is_mostly_edges():
@@ -428,7 +442,7 @@ def test_block_negative_sampler_in_a_block_that_is_mostly_edges():
     for rank in range(4):
         part = P.NodePartition(ei, n, rank, 4)
         smp = sampling.BlockNegativeSampler(ei, et, part.bounds, rank, k)
-        idx, types, n_own = smp.draw(seed=5)
+        idx, n_own = smp.draw(seed=5), smp.n_own
         assert smp.shortfall() == 0
         seen.append(idx[:, :n_own].cpu())
     allneg = torch.cat(seen, dim=1)
