@@ -305,30 +305,92 @@ def build_partitioned_steps(args, rank, world, dev):
         counter[0] += 1
         return ops.Dropout(0.2, keep=None, seed=own_seed(), stream_id=counter[0] & 0xFFFFFFFF)
 
-    def make(params, loss_fn):
-        opt = torch.optim.Adam(params, lr=1e-3, fused=True)
-        bucket = GradBucket(params, world)
+    # BKG_BENCH_PARTITION_GRAPH=1 (RCCL only): each sub-step -- zero_grad, loss, backward, the gradient all-reduce, clip,
+    # Adam, every exchange in between -- is captured once per host-side branch (GGD's augmentation coin) as ONE hipGraph
+    # and replayed: one host call per sub-step instead of ~350 launches (at one rank the host needs 3.6 ms to enqueue an
+    # eager partitioned step: a rank whose share of the kernels is shorter than that -- P >= 4 -- is launch-bound).  What
+    # makes it capturable: every extent is static (patterns, block-structured negatives), no host read inside a step, the
+    # in-kernel random streams are re-keyed by the library's device replay counter, torch's device draws come from a
+    # generator registered with the graph.  Falls back to the eager step if the capture raises.
+    graph_mode = (os.environ.get("BKG_BENCH_PARTITION_GRAPH") == "1" and torch.distributed.is_initialized()
+                  and torch.distributed.get_backend() == "nccl")
+    graph_stats = {"captured": 0, "replayed": 0, "eager": 0, "refused": None}
 
-        def step():
+    def make(params, loss_fn, draw_key):
+        from biomedkg_amd import _lib as L
+        from biomedkg_amd.graph import as_captured
+        opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+        if graph_mode:
+            from biomedkg_amd.graphs import make_capturable
+            opt = make_capturable(opt)
+        bucket = GradBucket(params, world)
+        epoch = torch.zeros(1, dtype=torch.int32, device=dev)
+        graphs, losses = {}, {}
+        side = torch.cuda.Stream() if graph_mode else None
+        state = {"on": graph_mode}
+
+        def body(key):
+            if graph_mode:
+                epoch.add_(1)
             opt.zero_grad(set_to_none=True)
-            loss = loss_fn()
+            loss = loss_fn(key)
             loss.backward()
             bucket.all_reduce()
             clip_adam_step(opt, 1.0)
             return loss
+
+        def step():
+            key = draw_key()
+            if not state["on"] or step.force_eager:
+                graph_stats["eager"] += 1
+                return body(key)
+            L.call("bkg_set_rng_epoch", L.ptr(epoch))
+            outer = torch.cuda.current_stream()
+            side.wait_stream(outer)
+            try:
+                with torch.cuda.stream(side):
+                    g = graphs.get(key)
+                    if g is None:
+                        with as_captured():
+                            loss = body(key).detach().clone()       # this kind's first step, eagerly (it also warms the pools)
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        g.register_generator_state(shared)
+                        try:
+                            with as_captured(), torch.cuda.graph(g, stream=side):
+                                losses[key] = body(key).detach()
+                        except Exception as why:                    # noqa: BLE001
+                            torch.cuda.synchronize()
+                            state["on"] = False
+                            graph_stats["refused"] = f"{type(why).__name__}: {why}"[:300]
+                            opt.zero_grad(set_to_none=True)
+                            return loss
+                        graphs[key] = g
+                        graph_stats["captured"] += 1
+                        return loss
+                    g.replay()
+                    ops.note_graph_replay()
+                    graph_stats["replayed"] += 1
+                    return losses[key]
+            finally:
+                outer.wait_stream(side)
+                L.call("bkg_set_rng_epoch", None)
         step.finish = lambda: None
+        step.force_eager = False
         return step
 
-    def ggd_loss(force_aug=None):
+    def ggd_key():
+        return float(torch.rand(1, generator=shared_host)) < gcl.model.p             # reference gcl.py:75-76 (a host coin)
+
+    def ggd_loss(aug):
         x, keep = xg, None
-        coin = float(torch.rand(1, generator=shared_host)) < gcl.model.p             # reference gcl.py:75-76
-        if coin if force_aug is None else force_aug:
+        if aug:
             x = ops.masked_bf16(xg, 0.4, own_seed(), rank) if ops.bf16_storage() else xg * (torch.rand_like(xg) >= 0.4)
             keep = torch.rand(e, generator=shared, device=dev) >= 0.4
         perm = shared_rand.perm(n, dev)            # a keyed bijection, the same key on every rank (one launch, no sort)
         return P.ggd_loss_partitioned(gcl.model, x, pg, P.HipBackend, perm, dropout_of, keep=keep)
 
-    def kge_loss():
+    def kge_loss(_key=None):
         # reference kge_module.py:86-102 over a partition: every rank draws the blocks of the cell grid that touch its
         # nodes from the step's SHARED seed (the two owners of a block get the same triplets); the relation ids --
         # edge_type.repeat(k), dealt to the blocks once, relation-grouped inside a block -- are constants of the partition
@@ -369,9 +431,12 @@ def build_partitioned_steps(args, rank, world, dev):
         loss_fn().backward()
     for p in list(gcl.model.parameters()) + list(kge.model.parameters()):
         p.grad = None
-    step_g, step_k = make(list(gcl.model.parameters()), ggd_loss), make(list(kge.model.parameters()), kge_loss)
+    step_g = make(list(gcl.model.parameters()), ggd_loss, ggd_key)
+    step_k = make(list(kge.model.parameters()), kge_loss, lambda: None)
     step_g.part = part
     step_g.check_loss = check
+    step_g.check_fn = check_losses
+    step_g.graph_stats = graph_stats if graph_mode else None
     return step_g, step_k, n, e, r
 
 
@@ -836,43 +901,40 @@ def cpu_baseline(args):
 
 
 # ----------------------------------------------------------------------------------------------- main
-def launch_ranks(args):
-    """``python3 bench.py --gpus N`` with no launcher around it: this process becomes the launcher -- it never touches
-    the GPU (nothing before this point does: ``import torch`` and ``torch.cuda.device_count()`` do not initialise HIP on
-    this image) -- and starts N fresh interpreters on this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the
-    way Lightning starts the reference's ranks from one ``python train_gcl.py`` (reference train_gcl.py:63-68,
-    configs/gcl.yaml:11).  Rank 0's stdout (the single JSON line) is relayed; the exit code is the worst child's."""
+def _run_ranks(args, extra_env, limit_s):
+    """Start N fresh interpreters on this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and wait for them.
+    -> (rank 0's stdout, exit codes, text for stderr).  ``limit_s``: end every rank when the attempt takes longer."""
     import socket
     import subprocess
+    import tempfile
     n = args.gpus
-    one_device = os.environ.get("BKG_BENCH_ONE_DEVICE") == "1"
-    have = torch.cuda.device_count()
-    if have < n and not one_device:
-        raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s) (BKG_BENCH_ONE_DEVICE=1 + "
-                         "BKG_BENCH_BACKEND=gloo is the functional single-device check)")
     with socket.socket() as s:                      # a free rendezvous port on the loop-back interface
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    import tempfile
     procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BKG_BENCH_SPAWNED="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BKG_BENCH_SPAWNED="1", **extra_env)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this stack
         # every rank's stderr goes to a file of its own: when one fails, ITS last lines are shown under its rank number
         # (eight interleaved tracebacks of ranks that were merely killed in a collective say nothing)
         logs.append(tempfile.TemporaryFile(mode="w+b"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=logs[-1]))
-    out, first_dead = None, None
+    out, first_dead, note = None, None, ""
+    t0 = time.time()
     while out is None:                              # a rank that dies early leaves the others waiting in a collective:
         try:                                        # end them instead of waiting for the caller's own limit
             out, _ = procs[0].communicate(timeout=2)
         except subprocess.TimeoutExpired:
             dead = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
-            if dead:
-                first_dead = dead[0]
-                sys.stderr.write(f"bench.py --gpus {n}: rank {dead[0][0]} exited with {dead[0][1]}; ending the others\n")
+            late = limit_s is not None and time.time() - t0 > limit_s
+            if dead or late:
+                if dead:
+                    first_dead = dead[0]
+                    note += f"bench.py --gpus {n}: rank {dead[0][0]} exited with {dead[0][1]}; ending the others\n"
+                else:
+                    note += f"bench.py --gpus {n}: no result after {limit_s:.0f} s; ending the ranks\n"
                 for p in procs:
                     if p.poll() is None:
                         p.kill()
@@ -895,11 +957,46 @@ def launch_ranks(args):
         # the rank that failed FIRST (the others' errors are the collective timing out or the kill), else every bad one
         show = [first_dead[0]] if first_dead else [r for r, c in enumerate(codes) if c != 0]
         for r in show:
-            sys.stderr.write(f"---- bench.py rank {r} (exit code {codes[r]}), last lines of its stderr ----\n{tail(r)}\n")
+            note += f"---- bench.py rank {r} (exit code {codes[r]}), last lines of its stderr ----\n{tail(r)}\n"
     else:
-        sys.stderr.write(tail(0, lines=200) + ("\n" if tail(0, 1) else ""))     # rank 0's warnings (RCCL's banner etc.)
-    sys.stdout.write(out.decode())
+        note += tail(0, lines=200) + ("\n" if tail(0, 1) else "")     # rank 0's warnings (RCCL's banner etc.)
+    return out.decode(), codes, note
+
+
+def launch_ranks(args):
+    """``python3 bench.py --gpus N`` with no launcher around it: this process becomes the launcher -- it never touches
+    the GPU (nothing before this point does: ``import torch`` and ``torch.cuda.device_count()`` do not initialise HIP on
+    this image) -- and starts N fresh interpreters on this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the
+    way Lightning starts the reference's ranks from one ``python train_gcl.py`` (reference train_gcl.py:63-68,
+    configs/gcl.yaml:11).  Rank 0's stdout (the single JSON line) is relayed; the exit code is the worst child's.
+
+    Node-partitioned runs over RCCL try the GRAPHED sub-steps first (BKG_BENCH_PARTITION_GRAPH=1: every sub-step one
+    hipGraph replay -- an eager partitioned step costs the host 3.6-5 ms to enqueue, more than a rank's kernels take from
+    four ranks on); captured collectives have only ever run on a one-rank RCCL group here (no multi-GPU box), so if that
+    attempt fails or yields nothing within BKG_BENCH_GRAPH_ATTEMPT_S (default 420 s) the ranks are started again with
+    the eager step, and the line says which form ran (``exchange.graphed_sub_steps``)."""
+    n = args.gpus
+    one_device = os.environ.get("BKG_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not one_device:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s) (BKG_BENCH_ONE_DEVICE=1 + "
+                         "BKG_BENCH_BACKEND=gloo is the functional single-device check)")
+    backend = os.environ.get("BKG_BENCH_BACKEND", "nccl")
+    try_graphs = ("BKG_BENCH_PARTITION_GRAPH" not in os.environ and backend == "nccl" and args.mode in ("auto", "partition"))
+    if try_graphs:
+        limit = float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "420"))
+        out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "1"}, limit)
+        if all(c == 0 for c in codes) and any(l.startswith("{") for l in out.splitlines()):
+            sys.stderr.write(note)
+            sys.stdout.write(out)
+            sys.stdout.flush()
+            raise SystemExit(0)
+        sys.stderr.write(note + f"bench.py --gpus {n}: the graphed attempt failed (exit codes {codes}); running the eager step\n")
+    out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "0"} if try_graphs else {}, None)
+    sys.stderr.write(note)
+    sys.stdout.write(out)
     sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
     raise SystemExit(max(abs(c) for c in bad) if bad else 0)
 
 
@@ -1005,23 +1102,53 @@ def main():
         comm = part.comm
         reps = 3
 
+        graphed = getattr(step_g, "graph_stats", None) is not None
+        host_graphed = None
+        if graphed:                      # the host's time per step in the mode the timed loop ran in (replays)
+            sync(); t = time.perf_counter()
+            for _ in range(reps):
+                step_g(); step_k()
+            host_graphed = (time.perf_counter() - t) / reps * 1e3
+            sync()
+        step_g.force_eager = step_k.force_eager = True      # the wire counters and waits below are those of the eager step
+
         def measure(serial):
             comm.serial, comm.timed = serial, True
             comm.take_stats()
             sync(); t = time.perf_counter()
             for _ in range(reps):
                 step_g(); step_k()
+            host = (time.perf_counter() - t) / reps * 1e3       # everything ENQUEUED (no synchronisation inside a step)
             sync()
             wall = (time.perf_counter() - t) / reps * 1e3
             rx, tx, count, exposed = comm.take_stats()
             comm.serial, comm.timed = False, False
-            return wall, rx / reps, tx / reps, count / reps, exposed / reps
-        wall_o, rx, tx, count, exposed_o = measure(False)
-        wall_s, _, _, _, exposed_s = measure(True)
+            return wall, rx / reps, tx / reps, count / reps, exposed / reps, host
+        wall_o, rx, tx, count, exposed_o, host_o = measure(False)
+        wall_s, _, _, _, exposed_s, _ = measure(True)
+        launches = [0]
+        from biomedkg_amd import _lib as _L
+        real_call = _L.call
+
+        def counting(name, *a):
+            launches[0] += 1
+            return real_call(name, *a)
+        _L.call = ops.L.call = counting
+        try:
+            step_g(); step_k()
+        finally:
+            _L.call = ops.L.call = real_call
+        sync()
+        step_g.force_eager = step_k.force_eager = False
         exchange = {"wire_bytes_received_per_step": rx, "wire_bytes_sent_per_step": tx, "exchanges_per_step": count,
                     "exchange_exposed_ms": exposed_o, "exchange_serial_ms": exposed_s,
                     "exposed_fraction": (exposed_o / exposed_s) if exposed_s else None,
                     "ms_per_step_overlapped": wall_o, "ms_per_step_serial": wall_s,
+                    "host_enqueue_ms_per_step": host_o, "library_calls_per_step": launches[0],
+                    "graphed_sub_steps": getattr(step_g, "graph_stats", None),
+                    "host_enqueue_ms_per_step_graphed": host_graphed,
+                    "host_note": "host_enqueue_ms_per_step: the host's time to enqueue one step (no synchronisation inside it); a "
+                                 "rank whose share of the kernels is shorter than that is launch-bound, whatever the wire does",
                     "halo": {k: {"used": comm.patterns.get(k) is not None, "max_share_of_remote_rows_read": v}
                              for k, v in part.halo_fraction.items()},
                     "rows": {"n_local": part.n_local, "n_max": part.n_max, "bounds": part.bounds},
@@ -1030,6 +1157,8 @@ def main():
                             "bf16 mode), the scorer's embedding table -- its gradient needs no exchange (both-owner scoring) -- "
                             "the first R-GCN layer's constant input gathered once per graph, not per step; the flat gradient "
                             "all-reduce is not counted here"}
+    # the same two losses after the run's optimizer steps (every rank: collectives inside): training moved them
+    check_after = step_g.check_fn() if mode == "partition" else None
     n_neg = args.neg_ratio * e
     strong = mode == "partition"
     total_edges = e if strong or world == 1 else world * e
@@ -1159,7 +1288,7 @@ def main():
             "ms_per_step_fresh_structures": ms_fresh,
             "roofline": roof, "kernels": others, "exchange": exchange,
             "step_accounting": None,
-            "check_loss": getattr(step_g, "check_loss", None),
+            "check_loss": getattr(step_g, "check_loss", None), "check_loss_after": check_after,
             "cpu_baseline": None,
         }
         if world == 1:

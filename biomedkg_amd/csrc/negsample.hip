@@ -283,7 +283,8 @@ __device__ __forceinline__ int neg_block_of(const NegBlock* __restrict__ blocks,
 }
 
 __global__ __launch_bounds__(256) void negative_candidates_blocks_kernel(const NegBlock* __restrict__ blocks, int n_blocks,
-                                                                         uint64_t seed, uint64_t n_nodes,
+                                                                         uint64_t seed, const uint32_t* __restrict__ epoch,
+                                                                         uint64_t n_nodes,
                                                                          const unsigned long long* __restrict__ pos_tab,
                                                                          uint64_t pos_mask, uint64_t* __restrict__ keys,
                                                                          int32_t* __restrict__ flag) {
@@ -291,7 +292,10 @@ __global__ __launch_bounds__(256) void negative_candidates_blocks_kernel(const N
   __shared__ NegBlock blk;
   if (threadIdx.x == 0) {
     blk = blocks[neg_block_of(blocks, n_blocks, (int64_t)blockIdx.x * 256)];
-    pi = make_feistel((uint64_t)blk.population, hs_mix(seed ^ ((uint64_t)(blk.id + 1) * 0xD1B54A32D192ED03ull)));
+    // (a captured step's kernel arguments are frozen: the library's device replay counter re-keys the draw -- the same
+    // counter value on every rank, which all replay once per step, so the two owners of a block still agree)
+    const uint64_t s_eff = epoch ? seed ^ ((uint64_t)epoch[0] * 0x9E3779B97F4A7C15ull) : seed;
+    pi = make_feistel((uint64_t)blk.population, hs_mix(s_eff ^ ((uint64_t)(blk.id + 1) * 0xD1B54A32D192ED03ull)));
   }
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -427,7 +431,7 @@ extern "C" int bkg_negative_sample_blocks(const void* blocks, int32_t n_blocks, 
   hipStream_t s = (hipStream_t)stream;
   const NegBlock* b = reinterpret_cast<const NegBlock*>(blocks);
   hipLaunchKernelGGL(negative_candidates_blocks_kernel, dim3(n_cand_total / 256), dim3(256), 0, s, b, (int)n_blocks, seed,
-                     (uint64_t)n_nodes, reinterpret_cast<const unsigned long long*>(pos_table), (uint64_t)pos_capacity - 1,
+                     rng_epoch_ptr(), (uint64_t)n_nodes, reinterpret_cast<const unsigned long long*>(pos_table), (uint64_t)pos_capacity - 1,
                      keys_tmp, flag_tmp);
   size_t bytes = (size_t)workspace_bytes;
   hipError_t e = rocprim::exclusive_scan(workspace, bytes, flag_tmp, offs_tmp, 0, (size_t)n_cand_total,

@@ -587,3 +587,65 @@ def test_bench_partitioned_on_four_and_eight_ranks_of_one_device(ranks):
     for key in ("ggd", "kge"):
         a, b = lines[1]["check_loss"][key], line["check_loss"][key]
         assert abs(a - b) <= 1e-5 * abs(a), (key, a, b)
+
+
+def test_block_sampler_is_rekeyed_by_the_replay_counter():
+    """A captured step freezes the sampler's seed argument: the library's device replay counter (bkg_set_rng_epoch) re-keys
+    the draw, so every replay gets fresh negatives -- and ranks that replay in lockstep (the same counter value) still draw
+    the same blocks."""
+    from biomedkg_amd import _lib as L, partition as P, sampling, synthetic
+    g = synthetic.primekg_like(2000, 30_000, 5, seed=1)
+    ei, et, n = g["edge_index"].to(DEV), g["edge_type"].to(DEV), g["num_nodes"]
+    part = P.NodePartition(ei, n, 1, 3)
+    smp = sampling.BlockNegativeSampler(ei, et, part.bounds, 1, ei.size(1))
+    plain = smp.draw(seed=5)
+    epoch = torch.zeros(1, dtype=torch.int32, device=DEV)
+    L.call("bkg_set_rng_epoch", L.ptr(epoch))
+    try:
+        e0 = smp.draw(seed=5)
+        epoch.add_(1)
+        e1 = smp.draw(seed=5)
+        e1_again = smp.draw(seed=5)
+        other_rank = sampling.BlockNegativeSampler(ei, et, part.bounds, 0, ei.size(1))
+        o1 = other_rank.draw(seed=5)
+    finally:
+        L.call("bkg_set_rng_epoch", None)
+    assert torch.equal(e0, plain)                       # counter 0: the un-keyed draw
+    assert not torch.equal(e1, e0) and torch.equal(e1, e1_again)
+    # block (0, 1): rank 0 owns its heads, rank 1 its tails -- the same triplets at the same counter value
+    b01 = 0 * 3 + 1
+    lo_a, k_a = [(o, k) for b, o, k in other_rank.layout if b == b01][0]
+    lo_b, k_b = [(o, k) for b, o, k in smp.layout if b == b01][0]
+    assert k_a == k_b and torch.equal(o1[:, lo_a:lo_a + k_a], e1[:, lo_b:lo_b + k_b])
+
+
+def test_partitioned_sub_steps_replay_as_hipgraphs_over_rccl():
+    """BKG_BENCH_PARTITION_GRAPH=1 on a one-rank RCCL group with every collective of the N-rank path issued for real
+    (BKG_PARTITION_FORCE_COLLECTIVES=1): each sub-step -- exchanges, gradient all-reduce, clip, Adam -- is captured once
+    per host-side branch and replayed; the host's time per step drops several-fold; the run trains like the eager one
+    (the fixed-draw check losses fall, and by about as much)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, BKG_PARTITION_FORCE_COLLECTIVES="1", BKG_BENCH_PARTITION_GRAPH=mode, MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29541")
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "partition", "--steps",
+                              "12", "--warmup", "3", "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    eager, graphed = lines["0"], lines["1"]
+    gs = graphed["exchange"]["graphed_sub_steps"]
+    assert eager["exchange"]["graphed_sub_steps"] is None
+    assert gs["refused"] is None and gs["captured"] == 3 and gs["replayed"] >= 20        # GGD with / without augmentation, KGE
+    assert graphed["exchange"]["host_enqueue_ms_per_step_graphed"] < 0.5 * eager["exchange"]["host_enqueue_ms_per_step"]
+    for line in (eager, graphed):
+        for key in ("ggd", "kge"):
+            assert line["check_loss_after"][key] < line["check_loss"][key], (key, line["check_loss"], line["check_loss_after"])
+    for key in ("ggd", "kge"):          # the same number of optimizer steps from the same weights, other random draws
+        drop_e = eager["check_loss"][key] - eager["check_loss_after"][key]
+        drop_g = graphed["check_loss"][key] - graphed["check_loss_after"][key]
+        assert abs(drop_e - drop_g) < 0.35 * abs(drop_e) + 1e-3, (key, drop_e, drop_g)
