@@ -354,10 +354,15 @@ def build_partitioned_steps(args, rank, world, dev):
                         with as_captured():
                             loss = body(key).detach().clone()       # this kind's first step, eagerly (it also warms the pools)
                         torch.cuda.synchronize()
+                        # the process group's watchdog thread polls the end events of the eager collectives just issued; let
+                        # it retire them before a capture begins (an event query from that thread while this one captures
+                        # ends the process: hipErrorCapturedEvent, seen once in four runs without the pause), and capture in
+                        # thread-local mode so that its later calls are none of this capture's business
+                        time.sleep(0.5)
                         g = torch.cuda.CUDAGraph()
                         g.register_generator_state(shared)
                         try:
-                            with as_captured(), torch.cuda.graph(g, stream=side):
+                            with as_captured(), torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                                 losses[key] = body(key).detach()
                         except Exception as why:                    # noqa: BLE001
                             torch.cuda.synchronize()
@@ -1025,6 +1030,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         backend = os.environ.get("BKG_BENCH_BACKEND", "nccl")
+        if os.environ.get("BKG_BENCH_PARTITION_GRAPH") == "1":
+            # captured collectives: no pooled events (an event of the pool may be handed from a finished eager collective to
+            # a captured one while the watchdog still looks at it)
+            os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
         kw = {"device_id": dev} if backend == "nccl" else {}
         if forced:
             kw.update(rank=0, world_size=1)
