@@ -1,0 +1,10 @@
+export TMPDIR=/tmp
+rm -rf /tmp/ks
+rocprofv3 --kernel-trace --output-format csv -d /tmp/ks -o k -- python3 bench.py --precision bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
+python3 - <<'PY'
+import glob, json, sys
+sys.path.insert(0, "scripts")
+import pmc_summary as P
+g, step = P.load_trace(glob.glob("/tmp/ks/**/*kernel_trace.csv", recursive=True)[0], 2, 5)
+print(json.dumps({k: step[k] for k in ("kernel_ms_per_step", "launches_per_step", "library_share_of_kernel_time", "not_library_kernels")}, indent=0))
+PY

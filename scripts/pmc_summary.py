@@ -72,11 +72,16 @@ def load_trace(path, warmup, steps):
     window = [r for r in rows if r[0] >= t0 and r[1] <= t1]
     groups = collections.defaultdict(list)
     fam = collections.defaultdict(float)
+    foreign = collections.defaultdict(lambda: [0, 0.0])      # kernels that are not the library's: launches, ms per step
     busy, cur = 0, t0
     for a, b, name, grid in window:
         short = name.split("(")[0].replace("void ", "")
         groups[(short, grid)].append(b - a)
         fam[family_of(name)] += (b - a) / 1e6 / steps
+        if "bkg" not in name:
+            rec = foreign[short[:96]]
+            rec[0] += 1
+            rec[1] += (b - a) / 1e6 / steps
         a2 = max(a, cur)
         if b > a2:
             busy += b - a2
@@ -85,6 +90,9 @@ def load_trace(path, warmup, steps):
             "gpu_busy_ms_per_step": busy / 1e6 / steps, "kernel_ms_per_step": sum(fam.values()),
             "launches_per_step": len(window) / steps,
             "by_family_ms_per_step": dict(sorted(fam.items(), key=lambda kv: -kv[1])),
+            "library_share_of_kernel_time": 1.0 - sum(v[1] for v in foreign.values()) / max(sum(fam.values()), 1e-30),
+            "not_library_kernels": [{"kernel": k, "launches_per_step": v[0] / steps, "ms_per_step": v[1]}
+                                    for k, v in sorted(foreign.items(), key=lambda kv: -kv[1][1])[:25]],
             "note": "window = the timed steps of a rocprofv3 --kernel-trace run of bench.py (between clip_adam launches); "
                     "kernel_ms_per_step sums durations (kernels on two queues may overlap: gpu_busy is their union)"}
     return groups, step
