@@ -139,6 +139,10 @@ KERNEL_NAMES = {
                            "views side by side, d={d} (one launch pair; each view's 256 columns on four of the eight XCDs)",
     "gcn_propagate_views_bwd": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel: the table gradient A_hat^T dOut of the two "
                                "GGD views (bf16 dOut gathered over the out-edge CSR), d={d}",
+    "gcn_propagate_views_kept": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel: the two GGD views of an AUGMENTED step "
+                                "(dropout_edge p = 0.4): the propagate over the view's kept edges only (bkg_csr_compact), d={d}",
+    "gcn_propagate_views_bwd_kept": "spmm_items_kernel<{t},{p},1> + spmm_fixup_kernel: the table gradient of an augmented "
+                                    "step's two views over the kept out-edges, d={d}",
     "kge_fused_bce": "kge_fused_bce_kernel<{t}>: DistMult scores + BCE terms + d score + d rel_emb partials, one triplet set, d={d}",
     "kge_bwd_nodes": "kge_incidence_streams_kernel + kge_bwd_stream_kernel<{t}> + fixup: dz by per-node segment reduce over the "
                      "triplet incidences (their other-endpoint / relation / g streams in list order), d={d}",
@@ -160,8 +164,10 @@ def roofline_of(tag, rec, precision):
     rate is ``t_min = max(algorithmic / 16.8 TB/s, l2_miss_bytes / 8.6 TB/s)`` and ``frac = t_min / t``.  The three
     component fractions are kept: ``frac_l2_gather``, ``frac_mall_gather``, ``frac_hbm_spec`` (L2-miss traffic against
     the 8 TB/s HBM spec, north_star's "HBM roofline": an upper bound of the true HBM fraction)."""
+    from biomedkg_amd import ops
     durs = [a.elapsed_time(b) for a, b in rec["events"]]
     avg_ms = sum(durs) / len(durs)
+    ops.timer_bytes(rec)                    # (a dropout_edge view's launches: bytes of the entries it kept)
     gbs = rec["bytes"] / (avg_ms * 1e-3) / 1e9
     traffic, l2_hit, source, traced_ms = pmc_traffic(tag, precision)
     miss_gbs = (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None
@@ -201,7 +207,8 @@ def roofline_of(tag, rec, precision):
 
 # tagged calls that launch the SAME kernel over the same grid (the forward and the backward propagate of the GGD views): the
 # dominant kernel is picked by their summed time, the call with the larger share stands for it
-SAME_KERNEL = {"gcn_propagate_views_bwd": "gcn_propagate_views"}
+SAME_KERNEL = {"gcn_propagate_views_bwd": "gcn_propagate_views", "gcn_propagate_views_kept": "gcn_propagate_views",
+               "gcn_propagate_views_bwd_kept": "gcn_propagate_views"}
 
 
 def rooflines(timers, precision):

@@ -89,13 +89,22 @@ def capturing():
     return _AS_CAPTURED > 0 or torch.cuda.is_current_stream_capturing()
 
 
+VIEW_GRID_MARK = 16
+
+
 class RowSplit:
     """Device work-item table cutting rows longer than ``SPLIT_CHUNK`` entries (``bkg_rowsplit``)."""
 
-    def __init__(self, rowptr, n_rows, nnz, chunk=SPLIT_CHUNK, pack=False, col=None):
+    def __init__(self, rowptr, n_rows, nnz, chunk=SPLIT_CHUNK, pack=False, col=None, ephemeral=False, superset=None):
         """``pack``: rows of <= 8 entries leave the item list for ``short_desc`` (csrc/rowsplit.hip) -- the tables
-        ``bkg_spmm_csr_f32`` walks finish them several per wave; the KGE kernels' tables stay one row per item."""
+        ``bkg_spmm_csr_f32`` walks finish them several per wave; the KGE kernels' tables stay one row per item.
+        ``ephemeral``: a table that lives for ONE step however many launches walk it (a ``dropout_edge`` view's CSR,
+        ``KeptCSR``): it keeps its array-size bounds -- ``nnz`` may itself be a bound -- and never reads its counts.
+        ``superset``: the table of a CSR over the same rows whose every row is AT LEAST as long (the graph a view's kept
+        entries come from), same ``chunk`` / ``pack``: a row here cuts into no more items, slots or long rows than there,
+        and a short row there is short here -- once that table knows its counts they bound this one's launches too."""
         dev = rowptr.device
+        self.ephemeral = bool(ephemeral)
         self._src = (rowptr, n_rows, nnz, chunk)
         self._plain, self._plain_asked = None, 0
         self.pack = bool(pack) and col is not None
@@ -118,12 +127,20 @@ class RowSplit:
                                   self.n_items_max, self.n_slots_max, self.n_long_max, self.n_short_max)
 
         self.exact, self._uses = False, 0
+        if superset is not None and superset.exact and superset.pack == self.pack and superset._src[3] == chunk:
+            # (+ VIEW_GRID_MARK items: four empty workgroups more than the graph's own launches, so that a counter pass --
+            # rocprofv3 rows carry kernel name and grid, nothing else -- can tell a view's launches from the graph's)
+            self.n_items_max = self.c.n_items_max = min(self.n_items_max, superset.n_items_max + VIEW_GRID_MARK)
+            self.n_slots_max = self.c.n_slots_max = min(self.n_slots_max, superset.n_slots_max)
+            self.n_long_max = self.c.n_long_max = min(self.n_long_max, superset.n_long_max)
 
     def use(self):
         """Called by every launch over this table.  From the 3rd launch on the bounds are the table's counts
         (``tighten``: one host read) -- a structure that lives for one or two launches (mini-batches; the bench's
         ``ms_per_step_fresh_structures``) keeps its array-size bounds and never makes the host wait."""
         self._uses += 1
+        if self.ephemeral:
+            return self
         if not self.exact and self._uses >= TIGHT_AFTER and TIGHT_GRIDS and not capturing():
             self.tighten()
         return self
@@ -195,13 +212,45 @@ class CSR:
         return out
 
 
+class KeptCSR:
+    """The entries of ``csr`` whose weight is not zero as a CSR of its own (``bkg_csr_compact``): what a ``dropout_edge``
+    view propagates over -- reference biomedkg/model/gcl.py:42-43,76: PyG hands GCNConv ``edge_index[:, keep]``, the
+    dropped edges' rows are never gathered.  The arrays keep the full length (``count``, on the device, says how many
+    entries are live: nothing here waits for the host); the work-item table keeps its bounds (``RowSplit`` ephemeral)."""
+
+    __slots__ = ("rowptr", "col", "w", "count", "n_rows", "nnz", "split")
+
+    def __init__(self, csr, w):
+        dev = w.device
+        n, nnz = csr.n_rows, csr.nnz
+        self.n_rows, self.nnz = n, nnz
+        self.rowptr, self.col = _i32(n + 1, dev), _i32(nnz, dev)
+        self.w = torch.empty(nnz, dtype=torch.float32, device=dev)
+        self.count = _i32(1, dev)
+        flag, offs = _i32(nnz, dev), _i32(nnz, dev)
+        ws_bytes = L.lib().bkg_csr_compact_workspace_bytes(nnz)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.call("bkg_csr_compact", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(w), n, nnz, L.ptr(flag), L.ptr(offs),
+               L.ptr(self.rowptr), L.ptr(self.col), L.ptr(self.w), L.ptr(self.count), L.ptr(ws), ws_bytes, L.stream())
+        self.split = (RowSplit(self.rowptr, n, nnz, pack=PACK_SHORT_ROWS, col=self.col, ephemeral=True, superset=csr.split)
+                      if nnz >= SPLIT_MIN_NNZ else None)
+
+
+# a dropout_edge view of a graph of this many edges or more propagates over its kept entries only (KeptCSR): two
+# compactions + two work-item tables per mask (~0.1 ms on the bench graph) against 40 % of the gathered rows of the eight
+# propagates of a step.  Mini-batch graphs stay on the masked weights (launch-bound: the extra launches cost more).
+KEPT_CSR_MIN_EDGES = int(__import__("os").environ.get("BKG_KEPT_CSR_MIN_EDGES", str(1 << 20)))
+
+
 class GcnWeights:
-    """gcn_norm result for one (graph, keep mask): weights in both CSR orders + self-loop weight."""
+    """gcn_norm result for one (graph, keep mask): weights in both CSR orders + self-loop weight.  ``dst`` / ``src``: the
+    view's own CSRs (``KeptCSR``) when the mask was compacted -- ``w_dst`` / ``w_src`` are then THEIR weights."""
 
-    __slots__ = ("w_dst", "w_src", "self_w")
+    __slots__ = ("w_dst", "w_src", "self_w", "dst", "src")
 
-    def __init__(self, w_dst, w_src, self_w):
+    def __init__(self, w_dst, w_src, self_w, dst=None, src=None):
         self.w_dst, self.w_src, self.self_w = w_dst, w_src, self_w
+        self.dst, self.src = dst, src
 
 
 class _EdgeHolder:
@@ -269,7 +318,12 @@ class Graph(_EdgeHolder):
         if keep is not None and self._kept is not None and self._kept[0] is keep and self._kept[1] == keep._version:
             return self._kept[2]      # every layer (and both GGD views) of a step passes the same mask tensor
         w_edge, self_w = self.gcn_norm_raw(keep)
-        out = GcnWeights(self.by_dst.permute_f32(w_edge), self.by_src.permute_f32(w_edge), self_w)
+        w_dst, w_src = self.by_dst.permute_f32(w_edge), self.by_src.permute_f32(w_edge)
+        if keep is not None and self.num_edges >= KEPT_CSR_MIN_EDGES:
+            kd, ks = KeptCSR(self.by_dst, w_dst), KeptCSR(self.by_src, w_src)
+            out = GcnWeights(kd.w, ks.w, self_w, dst=kd, src=ks)
+        else:
+            out = GcnWeights(w_dst, w_src, self_w)
         if keep is None:
             self._plain = out
         else:

@@ -8,7 +8,7 @@ import weakref
 import torch
 
 from . import _lib as L
-from .graph import CSR, Graph, GcnWeights, RelGraph
+from .graph import CSR, Graph, GcnWeights, KeptCSR, RelGraph
 
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 
@@ -329,6 +329,14 @@ def _spmm_bytes(nnz, n_rows, d, has_w, elem=4, out_elem=4):
     return nnz * (d * elem + 4 + (4 if has_w else 0)) + n_rows * (d * out_elem + 4)
 
 
+def timer_bytes(rec):
+    """Algorithmic bytes per launch of a ``KERNEL_TIMERS`` record; a call over a compacted view (``live``: the device
+    count of its entries, the last launch's) is priced on the entries it walks.  Reads the device: after the timed loop."""
+    if rec.get("live") is not None:
+        rec["bytes"], rec["live"] = _spmm_bytes(int(rec["live"].item()), *rec["bytes_of"]), None
+    return rec["bytes"]
+
+
 def to_bf16(x, gate=None, gate_scale=1.0):
     """bf16 gather table of ``x`` (csrc/spmm.hip ``bkg_gate_cast_bf16``), optionally through the ReLU/dropout
     backward gate ``gate > 0 ? x * gate_scale : 0``.  ``x`` and ``gate`` may each be fp32 or bf16."""
@@ -396,9 +404,10 @@ def bf16_storage() -> bool:
 
 
 def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=False, drop: Dropout = None, tag=None,
-         split=None, out_dtype=torch.float32):
+         split=None, out_dtype=torch.float32, live=None):
     """``out[i] = epi(sum_k w[k] x[col[k]] (+ self_w[i] x[i]) (+ addend[i]))`` (csrc/spmm.hip).
-    ``x`` is an fp32 or a bf16 table; the result is fp32."""
+    ``x`` is an fp32 or a bf16 table; the result is fp32.  ``live``: device int32 count of the entries ``rowptr`` spans
+    when ``col`` / ``w`` are longer than that (graph.KeptCSR) -- only the byte accounting of a tagged call reads it."""
     L.require_cuda(rowptr, col, w, x, self_w, addend, bias)
     if x.dtype == torch.bfloat16:
         x = x if x.is_contiguous() else x.contiguous()
@@ -446,6 +455,9 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
         ev1.record()
         rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None,
                                                                              2 if is_bf16 else 4, out.element_size()),
+                                             # (entries by a device count: resolved after the timed loop, timer_bytes)
+                                             "live": live, "bytes_of": (n_rows, d, w is not None, 2 if is_bf16 else 4,
+                                                                        out.element_size()),
                                              "d": d, "col_halves": halves,
                                              # rocprofv3's Grid_Size of the two launches (threads)
                                              "grid": _spmm_grid(((split.n_items_max if split is not None else n_rows) + 3) // 4,
@@ -644,6 +656,17 @@ def _exchanged_product(comm, n_rows, d_out, dtype, device, make_rows, min_rows=0
     return table
 
 
+def _view_csr(gw, side):
+    """The ``dropout_edge`` view's own CSR (graph.KeptCSR) when the mask was compacted, else None (the graph's CSR with
+    the view's weights: partitioned graphs, mini-batches, no mask)."""
+    return getattr(gw, side, None)
+
+
+def _view_tag(tag, csr):
+    """Launches over a view's kept entries are timed apart from the full graph's (other bytes per launch, other grid)."""
+    return tag + "_kept" if isinstance(csr, KeptCSR) else tag
+
+
 class _GcnConv(torch.autograd.Function):
     """``dropout(relu(A_hat (x W^T) + b))`` -- PyG GCNConv + the encoder's ReLU/dropout
     (reference biomedkg/model/encoder.py:153-162) fused into the aggregation epilogue.  ``x`` is fp32 or (a hidden
@@ -668,10 +691,11 @@ class _GcnConv(torch.autograd.Function):
             xw = _table(gemm(x, weight, trans_b=True))
             if comm is not None:
                 xw = comm.exchange(xw, "in")
-        c = graph.by_dst
+        c = _view_csr(gw, "dst") or graph.by_dst
         out16 = hidden and _hidden_bf16_ok(n_rows, d_out)
         out = spmm(c.rowptr, c.col, gw.w_dst, xw, n_rows, self_w=gw.self_w, bias=bias, relu=relu, drop=drop,
-                   tag="gcn_propagate", split=c.split, out_dtype=torch.bfloat16 if out16 else torch.float32)
+                   tag=_view_tag("gcn_propagate", c), split=c.split, out_dtype=torch.bfloat16 if out16 else torch.float32,
+                   live=getattr(c, "count", None))
         ctx.graph, ctx.gw, ctx.relu = graph, gw, relu
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
@@ -697,7 +721,7 @@ class _GcnConv(torch.autograd.Function):
             dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * ctx.keep * ctx.scale
         else:
             dout = _as_f32(dout)
-        c = g.by_src
+        c = _view_csr(gw, "src") or g.by_src
         # dXW feeds only the two products below: keep it as a bf16 table when both can take one
         d_out, d_in = weight.size(0), weight.size(1)
         x16 = x.dtype == torch.bfloat16
@@ -821,9 +845,10 @@ class _GcnConvViews(torch.autograd.Function):
                                            min_rows=0 if x2.dtype == torch.bfloat16 else (_TALL_ROWS + views - 1) // views)
             else:
                 table = gemm(x2.view(views * n, d_in), weight, trans_b=True, out_dtype=torch.bfloat16).view(n, views * d_out)
-        c = graph.by_dst
+        c = _view_csr(gw, "dst") or graph.by_dst
         out = spmm(c.rowptr, c.col, gw.w_dst, table, n, self_w=gw.self_w, bias=bias.repeat(views), relu=relu, drop=drop,
-                   tag="gcn_propagate_views", split=c.split, out_dtype=torch.bfloat16 if hidden else torch.float32)
+                   tag=_view_tag("gcn_propagate_views", c), split=c.split, out_dtype=torch.bfloat16 if hidden else torch.float32,
+                   live=getattr(c, "count", None))
         ctx.graph, ctx.gw, ctx.relu, ctx.views, ctx.is_table = graph, gw, relu, views, is_table
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
@@ -846,7 +871,7 @@ class _GcnConvViews(torch.autograd.Function):
                 dout = to_bf16(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
         else:
             dout = to_bf16(_as_f32(dout) * ctx.keep * ctx.scale)
-        c = g.by_src
+        c = _view_csr(gw, "src") or g.by_src
         d_out = dout.size(1) // v
         db = None
         if ctx.needs_input_grad[2]:        # the views share the bias: their column sums added
@@ -860,7 +885,7 @@ class _GcnConvViews(torch.autograd.Function):
                 return full, None, db, None, None, None, None, None, None, None
         else:
             dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split, out_dtype=torch.bfloat16,
-                       tag="gcn_propagate_views_bwd")
+                       tag=_view_tag("gcn_propagate_views_bwd", c), live=getattr(c, "count", None))
             if ctx.is_table:
                 return dxw.to(ctx.table_dtype), None, db, None, None, None, None, None, None, None
         d_in = weight.size(1)
