@@ -220,32 +220,65 @@ __global__ void segment_prefill_kernel(int64_t n, int32_t n_nodes, int32_t last_
 static inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
 
 
-// ---- a dropout_edge view as a CSR of its own (reference biomedkg/model/gcl.py:42-43,76: PyG dropout_edge returns
-// edge_index[:, keep], so GCNConv runs over the KEPT edges only).  The masked form -- the same CSR, weight 0 on dropped
-// entries -- gathers every dropped edge's row all the same (40 % of a propagate's bytes at p = 0.4); this compacts one
-// CSR's entries with a non-zero weight (dropped edges and pre-existing self loops both carry 0): flag -> exclusive scan ->
-// scatter, entries in their row order, row pointers read off the scan.  Buffers keep the full size (no host read).
-__global__ __launch_bounds__(256) void csr_flag_kernel(const float* __restrict__ w, int64_t nnz, int32_t* __restrict__ flag) {
+// ---- a dropout_edge view as CSRs of its own (reference biomedkg/model/gcl.py:42-43,76: PyG dropout_edge returns
+// edge_index[:, keep], so GCNConv -- gcn_norm and the propagate -- runs over the KEPT edges only).  The masked form (the
+// graph's CSRs, weight 0 on dropped entries) gathers every dropped edge's row all the same: 40 % of a propagate's bytes at
+// p = 0.4.  Here both CSRs of the graph (rows = targets, rows = sources) are compacted to the view's entries -- kept and
+// not a self loop (add_remaining_self_loops replaces those by the unit loop) -- and weighted in ONE pass: flags of both
+// laid end to end -> one exclusive scan -> row pointers read off the scan, whose differences ARE the view's in-degrees
+// (deg^-1/2, the loop weight) -> scatter of the column ids with w = deg^-1/2[row] deg^-1/2[col].  No host read; arrays
+// keep the graph's length.
+__global__ __launch_bounds__(256) void gcn_view_flag_kernel(const int32_t* __restrict__ col_d, const int32_t* __restrict__ perm_d,
+                                                            const int32_t* __restrict__ row_d, const int32_t* __restrict__ col_s,
+                                                            const int32_t* __restrict__ perm_s, const int32_t* __restrict__ row_s,
+                                                            const uint8_t* __restrict__ keep, int64_t nnz,
+                                                            int32_t* __restrict__ flag) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < nnz) flag[i] = w[i] != 0.f ? 1 : 0;
+  if (i >= 2 * nnz) return;
+  const bool second = i >= nnz;
+  const int64_t k = second ? i - nnz : i;
+  const int32_t* col = second ? col_s : col_d;
+  const int32_t* perm = second ? perm_s : perm_d;
+  const int32_t* row = second ? row_s : row_d;
+  flag[i] = (keep[perm[k]] && col[k] != row[k]) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void csr_compact_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                          const float* __restrict__ w, int64_t n_rows, int64_t nnz,
-                                                          const int32_t* __restrict__ flag, const int32_t* __restrict__ offs,
-                                                          int32_t* __restrict__ rowptr_out, int32_t* __restrict__ col_out,
-                                                          float* __restrict__ w_out, int32_t* __restrict__ count) {
+__global__ __launch_bounds__(256) void gcn_view_rows_kernel(const int32_t* __restrict__ rowptr_d, const int32_t* __restrict__ rowptr_s,
+                                                            const int32_t* __restrict__ flag, const int32_t* __restrict__ offs,
+                                                            int n, int64_t nnz, int32_t* __restrict__ rowptr_out_d,
+                                                            int32_t* __restrict__ rowptr_out_s, float* __restrict__ dis,
+                                                            float* __restrict__ self_w, int32_t* __restrict__ counts) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r > n) return;
+  const int32_t total = nnz ? offs[2 * nnz - 1] + flag[2 * nnz - 1] : 0;
+  const int32_t base = nnz ? offs[nnz] : 0;                       // entries the first (target-side) CSR keeps
+  auto at_d = [&](int q) { const int32_t p = rowptr_d[q]; return p < nnz ? offs[p] : base; };
+  auto at_s = [&](int q) { const int32_t p = rowptr_s[q]; return (p < nnz ? offs[nnz + p] : total) - base; };
+  const int32_t beg = at_d(r);
+  rowptr_out_d[r] = beg;
+  rowptr_out_s[r] = at_s(r);
+  if (r < n) {
+    const float d = 1.0f / sqrtf((float)(at_d(r + 1) - beg + 1));  // kept in-edges + the unit loop (as gcn_degree_finish_kernel)
+    dis[r] = d;
+    self_w[r] = d * d;
+  }
+  if (r == 0) { counts[0] = base; counts[1] = total - base; }
+}
+
+__global__ __launch_bounds__(256) void gcn_view_scatter_kernel(const int32_t* __restrict__ col_d, const int32_t* __restrict__ row_d,
+                                                               const int32_t* __restrict__ col_s, const int32_t* __restrict__ row_s,
+                                                               const int32_t* __restrict__ flag, const int32_t* __restrict__ offs,
+                                                               const float* __restrict__ dis, int64_t nnz,
+                                                               int32_t* __restrict__ col_out_d, float* __restrict__ w_out_d,
+                                                               int32_t* __restrict__ col_out_s, float* __restrict__ w_out_s) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int32_t total = nnz ? offs[nnz - 1] + flag[nnz - 1] : 0;
-  if (i < nnz && flag[i]) {
-    col_out[offs[i]] = col[i];
-    w_out[offs[i]] = w[i];
-  }
-  if (i <= n_rows) {
-    const int32_t r = rowptr[i];
-    rowptr_out[i] = r < nnz ? offs[r] : total;
-  }
-  if (i == 0) *count = total;
+  if (i >= 2 * nnz || !flag[i]) return;
+  const bool second = i >= nnz;
+  const int64_t k = second ? i - nnz : i;
+  const int32_t c = second ? col_s[k] : col_d[k], r = second ? row_s[k] : row_d[k];
+  const int32_t pos = offs[i] - (second ? offs[nnz] : 0);
+  const float w = dis[r] * dis[c];
+  if (second) { col_out_s[pos] = c; w_out_s[pos] = w; } else { col_out_d[pos] = c; w_out_d[pos] = w; }
 }
 
 }  // namespace bkg
@@ -367,31 +400,40 @@ extern "C" int bkg_gather_f32(const float* src, const int32_t* idx, float* out, 
   return check_launch("bkg_gather_f32");
 }
 
-extern "C" int64_t bkg_csr_compact_workspace_bytes(int64_t nnz) {
+extern "C" int64_t bkg_gcn_view_workspace_bytes(int64_t nnz) {
   size_t bytes = 0;
-  rocprim::exclusive_scan(nullptr, bytes, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)(nnz > 0 ? nnz : 1),
+  rocprim::exclusive_scan(nullptr, bytes, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)(nnz > 0 ? 2 * nnz : 1),
                           rocprim::plus<int32_t>());
   return (int64_t)bytes + 256;
 }
 
-// The entries of a CSR whose weight is not zero, as a CSR of its own over the same rows (see csr_flag_kernel): rowptr_out
-// [n_rows + 1], col_out / w_out [nnz] (the first *count entries are meaningful), count (device) = entries kept.
-// flag_tmp / offs_tmp: int32[nnz] scratch; workspace of bkg_csr_compact_workspace_bytes(nnz).
-extern "C" int bkg_csr_compact(const int32_t* rowptr, const int32_t* col, const float* w, int64_t n_rows, int64_t nnz,
-                               int32_t* flag_tmp, int32_t* offs_tmp, int32_t* rowptr_out, int32_t* col_out, float* w_out,
-                               int32_t* count, void* workspace, int64_t workspace_bytes, void* stream) {
-  BKG_ARG(n_rows >= 0 && nnz >= 0 && nnz < (1ll << 31) && n_rows < (1ll << 31), "bkg_csr_compact: bad sizes");
+// The two CSRs and gcn_norm weights of a dropout_edge view (see gcn_view_flag_kernel).  In: the graph's CSR by target
+// (rowptr_d [n + 1], col_d = sources, perm_d = original edge of each entry, row_d = its target: the sorted keys) and by
+// source (..._s), keep [nnz] in edge order.  Out: dis-free results -- self_w [n] (the unit loop's weight 1 / deg), the
+// view's CSRs rowptr_out_* [n + 1], col_out_* / w_out_* [nnz] (the first counts[0] / counts[1] entries are meaningful).
+// dis [n], flag_tmp / offs_tmp [2 nnz]: scratch; workspace of bkg_gcn_view_workspace_bytes(nnz).
+extern "C" int bkg_gcn_view(const int32_t* rowptr_d, const int32_t* col_d, const int32_t* perm_d, const int32_t* row_d,
+                            const int32_t* rowptr_s, const int32_t* col_s, const int32_t* perm_s, const int32_t* row_s,
+                            const uint8_t* keep, int64_t n_nodes, int64_t nnz, int32_t* flag_tmp, int32_t* offs_tmp, float* dis,
+                            float* self_w, int32_t* rowptr_out_d, int32_t* col_out_d, float* w_out_d, int32_t* rowptr_out_s,
+                            int32_t* col_out_s, float* w_out_s, int32_t* counts, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+  BKG_ARG(n_nodes >= 0 && nnz >= 0 && 2 * nnz < (1ll << 31) && n_nodes < (1ll << 31), "bkg_gcn_view: bad sizes");
+  BKG_ARG(nnz == 0 || keep, "bkg_gcn_view: a view needs its keep mask");
   hipStream_t s = (hipStream_t)stream;
   if (nnz) {
-    hipLaunchKernelGGL(csr_flag_kernel, grid1(nnz), dim3(256), 0, s, w, nnz, flag_tmp);
+    hipLaunchKernelGGL(gcn_view_flag_kernel, grid1(2 * nnz), dim3(256), 0, s, col_d, perm_d, row_d, col_s, perm_s, row_s, keep, nnz,
+                       flag_tmp);
     size_t bytes = (size_t)workspace_bytes;
-    hipError_t e = rocprim::exclusive_scan(workspace, bytes, flag_tmp, offs_tmp, 0, (size_t)nnz, rocprim::plus<int32_t>(), s);
-    if (e != hipSuccess) { set_error("bkg_csr_compact: scan", e); return (int)e; }
+    hipError_t e = rocprim::exclusive_scan(workspace, bytes, flag_tmp, offs_tmp, 0, (size_t)(2 * nnz), rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) { set_error("bkg_gcn_view: scan", e); return (int)e; }
   }
-  const int64_t span = nnz > n_rows + 1 ? nnz : n_rows + 1;
-  hipLaunchKernelGGL(csr_compact_kernel, grid1(span), dim3(256), 0, s, rowptr, col, w, n_rows, nnz, flag_tmp, offs_tmp,
-                     rowptr_out, col_out, w_out, count);
-  return check_launch("bkg_csr_compact");
+  hipLaunchKernelGGL(gcn_view_rows_kernel, grid1(n_nodes + 1), dim3(256), 0, s, rowptr_d, rowptr_s, flag_tmp, offs_tmp, (int)n_nodes,
+                     nnz, rowptr_out_d, rowptr_out_s, dis, self_w, counts);
+  if (nnz)
+    hipLaunchKernelGGL(gcn_view_scatter_kernel, grid1(2 * nnz), dim3(256), 0, s, col_d, row_d, col_s, row_s, flag_tmp, offs_tmp, dis,
+                       nnz, col_out_d, w_out_d, col_out_s, w_out_s);
+  return check_launch("bkg_gcn_view");
 }
 
 // ----------------------------------------------------------------------------- GCN norm

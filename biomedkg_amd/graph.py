@@ -213,31 +213,24 @@ class CSR:
 
 
 class KeptCSR:
-    """The entries of ``csr`` whose weight is not zero as a CSR of its own (``bkg_csr_compact``): what a ``dropout_edge``
-    view propagates over -- reference biomedkg/model/gcl.py:42-43,76: PyG hands GCNConv ``edge_index[:, keep]``, the
-    dropped edges' rows are never gathered.  The arrays keep the full length (``count``, on the device, says how many
-    entries are live: nothing here waits for the host); the work-item table keeps its bounds (``RowSplit`` ephemeral)."""
+    """One of the two CSRs of a ``dropout_edge`` view (``Graph.gcn_view`` / ``bkg_gcn_view``): the graph's entries the view
+    keeps, with their gcn_norm weights -- reference biomedkg/model/gcl.py:42-43,76: PyG hands GCNConv
+    ``edge_index[:, keep]``, the dropped edges' rows are never gathered.  The arrays keep the graph's length (``count``,
+    on the device, says how many entries are live: nothing here waits for the host); the work-item table keeps its bounds
+    (``RowSplit`` ephemeral, bounded by the graph's own table once that one knows its counts)."""
 
     __slots__ = ("rowptr", "col", "w", "count", "n_rows", "nnz", "split")
 
-    def __init__(self, csr, w):
-        dev = w.device
-        n, nnz = csr.n_rows, csr.nnz
-        self.n_rows, self.nnz = n, nnz
-        self.rowptr, self.col = _i32(n + 1, dev), _i32(nnz, dev)
-        self.w = torch.empty(nnz, dtype=torch.float32, device=dev)
-        self.count = _i32(1, dev)
-        flag, offs = _i32(nnz, dev), _i32(nnz, dev)
-        ws_bytes = L.lib().bkg_csr_compact_workspace_bytes(nnz)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        L.call("bkg_csr_compact", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(w), n, nnz, L.ptr(flag), L.ptr(offs),
-               L.ptr(self.rowptr), L.ptr(self.col), L.ptr(self.w), L.ptr(self.count), L.ptr(ws), ws_bytes, L.stream())
-        self.split = (RowSplit(self.rowptr, n, nnz, pack=PACK_SHORT_ROWS, col=self.col, ephemeral=True, superset=csr.split)
-                      if nnz >= SPLIT_MIN_NNZ else None)
+    def __init__(self, rowptr, col, w, count, csr):
+        self.rowptr, self.col, self.w, self.count = rowptr, col, w, count
+        self.n_rows, self.nnz = csr.n_rows, csr.nnz
+        self.split = (RowSplit(rowptr, csr.n_rows, csr.nnz, pack=PACK_SHORT_ROWS, col=col, ephemeral=True, superset=csr.split)
+                      if csr.nnz >= SPLIT_MIN_NNZ else None)
 
 
 # a dropout_edge view of a graph of this many edges or more propagates over its kept entries only (KeptCSR): two
-# compactions + two work-item tables per mask (~0.1 ms on the bench graph) against 40 % of the gathered rows of the eight
+# CSRs + two work-item tables per mask (~0.2 ms on the bench graph, less than the masked form's gcn_norm + two weight
+# permutations) against 40 % of the gathered rows of the eight
 # propagates of a step.  Mini-batch graphs stay on the masked weights (launch-bound: the extra launches cost more).
 KEPT_CSR_MIN_EDGES = int(__import__("os").environ.get("BKG_KEPT_CSR_MIN_EDGES", str(1 << 20)))
 
@@ -311,19 +304,39 @@ class Graph(_EdgeHolder):
                L.ptr(keep), self.num_nodes, self.num_edges, L.ptr(dis), L.ptr(self_w), L.ptr(w_edge), L.stream())
         return w_edge, self_w
 
+    def gcn_view(self, keep) -> GcnWeights:
+        """The ``dropout_edge`` view ``keep`` (uint8 / bool ``[E]``, edge order) as CSRs of its own with their gcn_norm
+        weights (``bkg_gcn_view``: flags, one scan, row pointers + degrees, scatter -- five launches, no host read)."""
+        dev = self.edge_index.device
+        n, e = self.num_nodes, self.num_edges
+        keep = keep.to(torch.uint8).contiguous()
+        d, s = self.by_dst, self.by_src
+        flag, offs = _i32(2 * e, dev), _i32(2 * e, dev)
+        dis = torch.empty(n, dtype=torch.float32, device=dev)
+        self_w = torch.empty_like(dis)
+        rp_d, rp_s, col_d, col_s = _i32(n + 1, dev), _i32(n + 1, dev), _i32(e, dev), _i32(e, dev)
+        w_d, w_s = (torch.empty(e, dtype=torch.float32, device=dev) for _ in range(2))
+        counts = _i32(2, dev)
+        ws_bytes = L.lib().bkg_gcn_view_workspace_bytes(e)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.call("bkg_gcn_view", L.ptr(d.rowptr), L.ptr(d.col), L.ptr(d.perm), L.ptr(d.sorted_keys), L.ptr(s.rowptr), L.ptr(s.col),
+               L.ptr(s.perm), L.ptr(s.sorted_keys), L.ptr(keep), n, e, L.ptr(flag), L.ptr(offs), L.ptr(dis), L.ptr(self_w),
+               L.ptr(rp_d), L.ptr(col_d), L.ptr(w_d), L.ptr(rp_s), L.ptr(col_s), L.ptr(w_s), L.ptr(counts), L.ptr(ws), ws_bytes,
+               L.stream())
+        kd, ks = KeptCSR(rp_d, col_d, w_d, counts[0:1], d), KeptCSR(rp_s, col_s, w_s, counts[1:2], s)
+        return GcnWeights(w_d, w_s, self_w, dst=kd, src=ks)
+
     def gcn_weights(self, keep=None) -> GcnWeights:
         """``keep``: optional uint8/bool ``[E]`` dropout_edge mask in original edge order."""
         if keep is None and self._plain is not None:
             return self._plain
         if keep is not None and self._kept is not None and self._kept[0] is keep and self._kept[1] == keep._version:
             return self._kept[2]      # every layer (and both GGD views) of a step passes the same mask tensor
-        w_edge, self_w = self.gcn_norm_raw(keep)
-        w_dst, w_src = self.by_dst.permute_f32(w_edge), self.by_src.permute_f32(w_edge)
         if keep is not None and self.num_edges >= KEPT_CSR_MIN_EDGES:
-            kd, ks = KeptCSR(self.by_dst, w_dst), KeptCSR(self.by_src, w_src)
-            out = GcnWeights(kd.w, ks.w, self_w, dst=kd, src=ks)
+            out = self.gcn_view(keep)
         else:
-            out = GcnWeights(w_dst, w_src, self_w)
+            w_edge, self_w = self.gcn_norm_raw(keep)
+            out = GcnWeights(self.by_dst.permute_f32(w_edge), self.by_src.permute_f32(w_edge), self_w)
         if keep is None:
             self._plain = out
         else:

@@ -59,14 +59,19 @@ int bkg_lower_bound_u32(const uint32_t* sorted, int64_t n, int64_t n_queries, ui
 int bkg_gather_i64_to_i32(const int64_t* src, const uint32_t* idx, int32_t* out, int64_t n, void* stream);
 int bkg_gather_i32(const int32_t* src, const int32_t* idx, int32_t* out, int64_t n, void* stream);
 int bkg_gather_f32(const float* src, const int32_t* idx, float* out, int64_t n, void* stream);
-/* A dropout_edge view as a CSR of its own (biomedkg/model/gcl.py:42-43,76: PyG dropout_edge hands GCNConv the KEPT edges
- * only): the entries of a CSR whose weight is not zero (dropped edges and pre-existing self loops carry 0 after
- * bkg_gcn_norm), in their row order -- the propagate then gathers 60 % of the rows at p = 0.4 instead of all of them.
- * rowptr_out [n_rows + 1], col_out / w_out [nnz] (the first *count entries are meaningful; no host read). */
-int64_t bkg_csr_compact_workspace_bytes(int64_t nnz);
-int bkg_csr_compact(const int32_t* rowptr, const int32_t* col, const float* w, int64_t n_rows, int64_t nnz, int32_t* flag_tmp,
-                    int32_t* offs_tmp, int32_t* rowptr_out, int32_t* col_out, float* w_out, int32_t* count, void* workspace,
-                    int64_t workspace_bytes, void* stream);
+/* A dropout_edge view as CSRs of its own (biomedkg/model/gcl.py:42-43,76: PyG dropout_edge hands GCNConv the KEPT edges
+ * only): both CSRs of the graph compacted to the view's entries (kept, not a self loop) with their gcn_norm weights
+ * deg^-1/2[row] deg^-1/2[col] (degrees of the view: kept in-edges + the unit loop; self_w = 1 / deg) -- the propagates of
+ * an augmented step then gather 60 % of the rows at p = 0.4 instead of all of them.  ..._d: the CSR by target (col =
+ * sources, perm = original edge of each entry, row = its target), ..._s: by source.  rowptr_out_* [n + 1], col_out_* /
+ * w_out_* [nnz] (the first counts[0] / counts[1] entries are meaningful; no host read); dis [n], flag_tmp / offs_tmp
+ * [2 nnz]: scratch. */
+int64_t bkg_gcn_view_workspace_bytes(int64_t nnz);
+int bkg_gcn_view(const int32_t* rowptr_d, const int32_t* col_d, const int32_t* perm_d, const int32_t* row_d,
+                 const int32_t* rowptr_s, const int32_t* col_s, const int32_t* perm_s, const int32_t* row_s, const uint8_t* keep,
+                 int64_t n_nodes, int64_t nnz, int32_t* flag_tmp, int32_t* offs_tmp, float* dis, float* self_w,
+                 int32_t* rowptr_out_d, int32_t* col_out_d, float* w_out_d, int32_t* rowptr_out_s, int32_t* col_out_s,
+                 float* w_out_s, int32_t* counts, void* workspace, int64_t workspace_bytes, void* stream);
 /* PyG gcn_norm (add_remaining_self_loops + deg^-1/2 by target) over the dst-sorted CSR; keep = optional
  * dropout_edge mask [E] in edge order (biomedkg/model/gcl.py:42-43,76).  Outputs dis[N], self_w[N], w_edge[E]. */
 int bkg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int64_t* src,

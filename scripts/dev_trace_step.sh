@@ -8,3 +8,4 @@ import pmc_summary as P
 g, step = P.load_trace(glob.glob("/tmp/ks/**/*kernel_trace.csv", recursive=True)[0], 2, 5)
 print(json.dumps({k: step[k] for k in ("kernel_ms_per_step", "launches_per_step", "library_share_of_kernel_time", "not_library_kernels")}, indent=0))
 PY
+cp $(find /tmp/ks -name "*kernel_trace.csv" | head -1) gpurun_out/last_kernel_trace.csv 2>/dev/null

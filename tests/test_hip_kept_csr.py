@@ -1,58 +1,12 @@
-"""A ``dropout_edge`` view as a CSR of its own (``bkg_csr_compact`` / graph.KeptCSR): reference biomedkg/model/gcl.py:42-43,76
--- PyG ``dropout_edge`` hands GCNConv ``edge_index[:, keep]``.  The compaction against a numpy restatement, the propagates
-over it against the oracle's gcn_norm on the kept edges, and a whole augmented GGD / GRACE step against the same step over
-the masked weights (the form every graph below ``KEPT_CSR_MIN_EDGES`` keeps).  Needs an MI355X."""
-import numpy as np
+"""A ``dropout_edge`` view as CSRs of its own (``bkg_gcn_view`` / graph.KeptCSR): reference biomedkg/model/gcl.py:42-43,76
+-- PyG ``dropout_edge`` hands GCNConv ``edge_index[:, keep]``.  The view's CSRs and weights against the oracle's gcn_norm
+of the kept edges entry by entry, the propagates over them, and a whole augmented GGD / GRACE step against the same step
+over the masked weights (the form every graph below ``KEPT_CSR_MIN_EDGES`` keeps).  Needs an MI355X."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-
-
-def _compact_np(rowptr, col, w):
-    live = w != 0
-    counts = np.add.reduceat(np.concatenate([live, [False]]).astype(np.int64), rowptr[:-1]) if len(col) else np.zeros(len(rowptr) - 1, np.int64)
-    counts[rowptr[1:] == rowptr[:-1]] = 0          # (reduceat of an empty row returns the next entry)
-    rp = np.zeros(len(rowptr), np.int64)
-    rp[1:] = np.cumsum(counts)
-    return rp, col[live], w[live]
-
-
-def _run_compact(rowptr, col, w):
-    from biomedkg_amd import _lib as L
-    n, nnz = len(rowptr) - 1, len(col)
-    dev = torch.device(DEV)
-    rp, c, wt = (torch.from_numpy(a).to(dev) for a in (rowptr.astype(np.int32), col.astype(np.int32), w.astype(np.float32)))
-    flag, offs = (torch.empty(max(nnz, 1), dtype=torch.int32, device=dev) for _ in range(2))
-    rp_o = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    c_o = torch.full((max(nnz, 1),), -7, dtype=torch.int32, device=dev)
-    w_o = torch.full((max(nnz, 1),), -7.0, dtype=torch.float32, device=dev)
-    cnt = torch.full((1,), -1, dtype=torch.int32, device=dev)
-    ws_bytes = L.lib().bkg_csr_compact_workspace_bytes(nnz)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    L.call("bkg_csr_compact", L.ptr(rp), L.ptr(c), L.ptr(wt), n, nnz, L.ptr(flag), L.ptr(offs), L.ptr(rp_o), L.ptr(c_o),
-           L.ptr(w_o), L.ptr(cnt), L.ptr(ws), ws_bytes, L.stream())
-    k = int(cnt.item())
-    return rp_o.cpu().numpy(), c_o[:k].cpu().numpy(), w_o[:k].cpu().numpy(), c_o[k:].cpu().numpy()
-
-
-@pytest.mark.parametrize("n,nnz,p_zero", [(1, 0, 0.0), (0, 0, 0.0), (5, 3, 0.5), (7, 40, 1.0), (7, 40, 0.0), (1000, 50_000, 0.4),
-                                          (130_000, 1_000_003, 0.4), (3, 700_000, 0.4)])
-def test_compaction_is_the_kept_entries_in_row_order(n, nnz, p_zero):
-    rng = np.random.default_rng(n * 31 + nnz)
-    rows = np.sort(rng.integers(0, max(n, 1), nnz)) if n else np.zeros(0, np.int64)
-    if n > 10:
-        rows = np.sort(np.where(rows >= n - 3, 0, rows))           # trailing empty rows + a long first one
-    rowptr = np.searchsorted(rows, np.arange(n + 1)).astype(np.int64)
-    col = rng.integers(0, max(n, 1), nnz)
-    w = rng.random(nnz).astype(np.float32) + 0.5
-    w[rng.random(nnz) < p_zero] = 0.0
-    rp, c, wk, tail = _run_compact(rowptr, col, w)
-    rp_ref, c_ref, w_ref = _compact_np(rowptr, col, w)
-    assert np.array_equal(rp, rp_ref)
-    assert np.array_equal(c, c_ref) and np.array_equal(wk, w_ref)
-    assert (tail == -7).all()                                       # nothing written past the count
 
 
 def _hub_graph(n, e, seed=0):
@@ -63,6 +17,36 @@ def _hub_graph(n, e, seed=0):
     ei[0, hub:2 * hub] = 11
     ei[:, -50:] = torch.arange(50).repeat(2, 1)                     # self loops already in the edge list
     return ei[:, torch.randperm(e, generator=g)]
+
+
+@pytest.mark.parametrize("n,e,p_drop", [(1, 0, 0.4), (5, 3, 0.5), (7, 40, 1.0), (7, 40, 0.0), (1000, 50_000, 0.4), (130_000, 1_000_003, 0.4),
+                                        (3, 70_000, 0.4)])
+def test_the_views_csrs_are_gcn_norm_of_the_kept_edges_entry_by_entry(n, e, p_drop):
+    """Both CSRs of the view: rows in order, the entries of a row in edge order (the graph's stable order), weights
+    ``deg^-1/2[s] deg^-1/2[d]`` of the KEPT edges' degrees, existing self loops gone, the unit loop's weight ``1 / deg``."""
+    from biomedkg_amd import graph as G
+    from oracle import pyg_ops as P
+    g = torch.Generator().manual_seed(n * 31 + e)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if n > 10:
+        ei[1, : e // 3] = 0                                         # a long first row; the last rows stay (nearly) empty
+        ei[:, e // 3:] %= max(n - 3, 1)
+    keep = torch.rand(e, generator=g) >= p_drop
+    gr = G.Graph(ei.to(DEV), n)
+    gw = gr.gcn_view(keep.to(DEV))
+    kept = keep & (ei[0] != ei[1])
+    e2, w = P.gcn_norm(ei[:, keep], n)                              # (kept non-loop edges in order, then one loop per node)
+    m = int(kept.sum())
+    assert torch.equal(e2[:, :m], ei[:, kept])
+    torch.testing.assert_close(gw.self_w.cpu(), w[m:], rtol=1e-6, atol=0)
+    for view, row_of, col_of in ((gw.dst, 1, 0), (gw.src, 0, 1)):
+        assert int(view.count) == m
+        order = torch.argsort(e2[row_of, :m], stable=True)           # rows ascending, edge order inside a row
+        rowptr = torch.zeros(n + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(torch.bincount(e2[row_of, :m], minlength=n), 0)
+        assert torch.equal(view.rowptr.cpu().long(), rowptr)
+        assert torch.equal(view.col[:m].cpu().long(), e2[col_of, :m][order])
+        torch.testing.assert_close(view.w[:m].cpu(), w[:m][order], rtol=1e-6, atol=0)
 
 
 @pytest.mark.parametrize("tight_parent", [False, True])
