@@ -72,8 +72,9 @@ SIGNATURES = {
     "bkg_kge_fused_bce_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
     "bkg_kge_fused_bce_dev_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
     "bkg_kge_loss_finish_scratch_bytes": (I64, []),
-    "bkg_kge_loss_finish_f32": (I32, [P, I32, F32, P, P, I64, I32, I32, P, P, I64, I32, F32, P, P, P]),
+    "bkg_kge_loss_finish_f32": (I32, [P, I32, F32, P, P, I64, I32, I32, P, I64, P, I64, I32, F32, P, P, P]),
     "bkg_scale_add_rows_f32": (I32, [P, I64, P, I64, I32, I32, P, F32, P, P]),
+    "bkg_scale_add_rows_out_f32": (I32, [P, I64, P, I64, I32, I32, P, F32, P, I64, P]),
     "bkg_relation_wave_ptr": (I32, [P, I32, I32, P, P]),
     "bkg_kge_bwd_rel_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, I32, P, I64, P, P, P]),
     # ntxent.hip

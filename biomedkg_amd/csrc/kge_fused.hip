@@ -210,23 +210,24 @@ __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
   return r;
 }
 
-// loss = inv_total * sum(part) + reg * (mean_{rows < n_real}(z^2) + mean(rel^2)).  FIN_BLOCKS blocks add their
-// slices (fixed thread -> element mapping, fixed-order tree) into slots of `scratch`; the block that takes the last
-// ticket adds the slots in slot order and writes the loss -- one launch, repeatable.  scratch: 3 * FIN_BLOCKS doubles
-// + one uint32 ticket (zero before the first use; the kernel leaves it zero).
-constexpr int FIN_BLOCKS = 64;
+// loss = inv_total * sum(part) + reg * (sum_{rows < n_real}(z^2) / (mean_rows d) + mean(rel^2)).  The launch's blocks
+// (FIN_BLOCKS for a mini-batch, up to FIN_BLOCKS_MAX for a whole graph's z) add their slices (fixed thread -> element
+// mapping, fixed-order tree) into slots of `scratch`; the block that takes the last ticket adds the slots (one per
+// thread, the same tree) and writes the loss -- one launch, repeatable.  scratch: 3 * FIN_BLOCKS_MAX doubles + one uint32
+// ticket (zero before the first use; the kernel leaves it zero).
+constexpr int FIN_BLOCKS = 64, FIN_BLOCKS_MAX = 1024;
 
 __global__ __launch_bounds__(1024) void kge_loss_finish_kernel(const float* __restrict__ part, int n_part, float inv_total,
                                                                const float* __restrict__ inv_total_dev,
                                                                const float* __restrict__ z, int64_t ldz, int n_cap, int d,
-                                                               const int64_t* __restrict__ n_real_dev,
+                                                               const int64_t* __restrict__ n_real_dev, int64_t mean_rows,
                                                                const float* __restrict__ rel, int64_t ldr, int n_rel,
                                                                float reg, double* __restrict__ scratch,
                                                                unsigned int* __restrict__ ticket, float* __restrict__ loss) {
   __shared__ double sh[1024];
   __shared__ bool last;
-  const int t = threadIdx.x, b = blockIdx.x;
-  const int64_t gt = (int64_t)b * 1024 + t, stride = (int64_t)FIN_BLOCKS * 1024;
+  const int t = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
+  const int64_t gt = (int64_t)b * 1024 + t, stride = (int64_t)nb * 1024;
   double a = 0.0, zz = 0.0, rr = 0.0;
   for (int64_t i = gt; i < n_part; i += stride) a += (double)part[i];
   int n_rows = n_cap;
@@ -247,20 +248,21 @@ __global__ __launch_bounds__(1024) void kge_loss_finish_kernel(const float* __re
   zz = block_sum_1024(zz, sh);
   rr = block_sum_1024(rr, sh);
   if (t == 0) {
-    scratch[b] = a; scratch[FIN_BLOCKS + b] = zz; scratch[2 * FIN_BLOCKS + b] = rr;
+    scratch[b] = a; scratch[FIN_BLOCKS_MAX + b] = zz; scratch[2 * FIN_BLOCKS_MAX + b] = rr;
     __threadfence();
-    last = atomicAdd(ticket, 1u) == (unsigned)(FIN_BLOCKS - 1);
+    last = atomicAdd(ticket, 1u) == (unsigned)(nb - 1);
   }
   __syncthreads();
-  if (!last || t != 0) return;
+  if (!last) return;
   __threadfence();
-  double sa = 0.0, sz = 0.0, sr = 0.0;
-  for (int k = 0; k < FIN_BLOCKS; ++k) {
-    sa += scratch[k]; sz += scratch[FIN_BLOCKS + k]; sr += scratch[2 * FIN_BLOCKS + k];
-  }
+  const double sa = block_sum_1024(t < nb ? scratch[t] : 0.0, sh);
+  const double sz = block_sum_1024(t < nb ? scratch[FIN_BLOCKS_MAX + t] : 0.0, sh);
+  const double sr = block_sum_1024(t < nb ? scratch[2 * FIN_BLOCKS_MAX + t] : 0.0, sh);
+  if (t != 0) return;
   const double it = inv_total_dev ? (double)inv_total_dev[0] : (double)inv_total;
   double out = sa * it;
-  if (reg != 0.f) out += (double)reg * (sz / ((double)max(n_rows, 1) * d) + sr / ((double)n_rel * d));
+  const double rows_of_mean = mean_rows > 0 ? (double)mean_rows : (double)max(n_rows, 1);
+  if (reg != 0.f) out += (double)reg * (sz / (rows_of_mean * d) + sr / ((double)n_rel * d));
   loss[0] = (float)out;
   *ticket = 0u;
 }
@@ -302,23 +304,39 @@ __global__ __launch_bounds__(256) void scale_add_rows_kernel(float* __restrict__
   dst[(int64_t)row * ldd + col] = v;
 }
 
+// out[row, :] = base[row, :] * g + src[row, :] * (g * coef / n): the out-of-place form (base is a tensor the autograd graph
+// saved: the relation embeddings' gradient partials, a few dozen rows)
+__global__ __launch_bounds__(256) void scale_add_rows_out_kernel(const float* __restrict__ base, int64_t ldb,
+                                                                 const float* __restrict__ src, int64_t lds, int n, int d,
+                                                                 const float* __restrict__ gloss, float coef,
+                                                                 float* __restrict__ out, int64_t ldo) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)n * d) return;
+  const int row = (int)(e / d), col = (int)(e % d);
+  const float g = gloss[0];
+  out[(int64_t)row * ldo + col] = fmaf(src[(int64_t)row * lds + col], g * (coef / (float)max(n, 1)), base[(int64_t)row * ldb + col] * g);
+}
+
 }  // namespace bkg
 
 using namespace bkg;
 
-extern "C" int64_t bkg_kge_loss_finish_scratch_bytes() { return 3 * FIN_BLOCKS * sizeof(double) + 16; }
+extern "C" int64_t bkg_kge_loss_finish_scratch_bytes() { return 3 * FIN_BLOCKS_MAX * sizeof(double) + 16; }
 
 extern "C" int bkg_kge_loss_finish_f32(const float* part, int32_t n_part, float inv_total, const float* inv_total_dev,
                                        const float* z, int64_t ldz, int32_t n_cap, int32_t d, const int64_t* n_real_dev,
-                                       const float* rel, int64_t ldr, int32_t n_rel, float reg, void* scratch, float* loss,
-                                       void* stream) {
-  BKG_ARG(n_part >= 0 && n_cap >= 0 && d > 0 && n_rel > 0, "bkg_kge_loss_finish_f32: bad sizes");
+                                       int64_t mean_rows, const float* rel, int64_t ldr, int32_t n_rel, float reg,
+                                       void* scratch, float* loss, void* stream) {
+  BKG_ARG(n_part >= 0 && n_cap >= 0 && d > 0 && n_rel > 0 && mean_rows >= 0, "bkg_kge_loss_finish_f32: bad sizes");
   BKG_ARG(d % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && (uintptr_t)z % 16 == 0 && (uintptr_t)rel % 16 == 0 &&
               (uintptr_t)scratch % 8 == 0, "bkg_kge_loss_finish_f32: 16-byte aligned rows, d % 4 == 0");
   double* slots = reinterpret_cast<double*>(scratch);
-  unsigned int* ticket = reinterpret_cast<unsigned int*>(slots + 3 * FIN_BLOCKS);
-  hipLaunchKernelGGL(kge_loss_finish_kernel, dim3(FIN_BLOCKS), dim3(1024), 0, (hipStream_t)stream, part, n_part, inv_total,
-                     inv_total_dev, z, ldz, n_cap, d, n_real_dev, rel, ldr, n_rel, reg, slots, ticket, loss);
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(slots + 3 * FIN_BLOCKS_MAX);
+  // ~8 sixteen-byte pieces per thread: 64 blocks for a mini-batch, the whole chip for a full graph's z
+  const int64_t work = std::max<int64_t>(n_part, reg != 0.f ? (int64_t)n_cap * (d / 4) : 0);
+  const int blocks = (int)std::min<int64_t>(FIN_BLOCKS_MAX, std::max<int64_t>(FIN_BLOCKS, ceil_div(work, (int64_t)1024 * 8)));
+  hipLaunchKernelGGL(kge_loss_finish_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, part, n_part, inv_total,
+                     inv_total_dev, z, ldz, n_cap, d, n_real_dev, mean_rows, rel, ldr, n_rel, reg, slots, ticket, loss);
   return check_launch("bkg_kge_loss_finish_f32");
 }
 
@@ -383,4 +401,13 @@ extern "C" int bkg_kge_fused_bce_f32(int32_t kind, const void* z, int32_t z_is_b
                                      void* rec, float* loss_part, float* drel, int64_t lddr, void* stream) {
   return bkg_kge_fused_bce_dev_f32(kind, z, z_is_bf16, ldz, d, head, tail, T, label, inv_total, nullptr, rel_emb, ldr, n_rel,
                                    order, rel_ptr, score, g, rec, loss_part, drel, lddr, stream);
+}
+
+extern "C" int bkg_scale_add_rows_out_f32(const float* base, int64_t ldb, const float* src, int64_t lds, int32_t n, int32_t d,
+                                          const float* gloss, float coef, float* out, int64_t ldo, void* stream) {
+  BKG_ARG(n >= 0 && d > 0, "bkg_scale_add_rows_out_f32: bad sizes");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scale_add_rows_out_kernel, dim3(ceil_div((int64_t)n * d, 256)), dim3(256), 0, (hipStream_t)stream, base, ldb,
+                     src, lds, n, d, gloss, coef, out, ldo);
+  return check_launch("bkg_scale_add_rows_out_f32");
 }

@@ -1133,6 +1133,7 @@ def grouped_linear(h, weight, group_ptr):
 # ----------------------------------------------------------------------------- KGE scorer
 KGE_DISTMULT, KGE_TRANSE = 0, 1
 KGE_BWD_STREAMS = __import__("os").environ.get("BKG_KGE_BWD_STREAMS", "1") != "0"
+KGE_LOSS_FINISH = __import__("os").environ.get("BKG_KGE_LOSS_FINISH", "1") != "0"     # 0: the loss tail as torch expressions
 
 
 class Incidence:
@@ -1404,12 +1405,20 @@ class _KgeBceLoss(torch.autograd.Function):
             raise ValueError("both-owner scoring needs the packed gradient records (table rows and relations < 2^31)")
         n_waves = [L.lib().bkg_kge_fused_bce_waves(ei.size(1), r) if ei.size(1) else 0 for ei, _, _, _, _ in sets]
         part = torch.empty(sum(n_waves), dtype=torch.float32, device=dev)      # every wave of a launch writes its slot
+        # the sets the loss counts take the first slots: ONE contiguous sum (the others' slots follow)
+        n_counted = sum(w for w, st in zip(n_waves, sets) if st[3])
+        slot_c, slot_u, slot0 = 0, n_counted, []
+        for w, st in zip(n_waves, sets):
+            slot0.append(slot_c if st[3] else slot_u)
+            if st[3]:
+                slot_c += w
+            else:
+                slot_u += w
         new = torch.zeros if padded else torch.empty
         rec_all = new(t_all, 4, dtype=torch.int32, device=dev) if pack else None
         scores, grads, drel = [], [], None
-        counted_parts = []
-        w0 = t0 = 0
-        for (ei, et, label, counted, _), waves in zip(sets, n_waves):
+        t0 = 0
+        for (ei, et, label, counted, _), waves, w0 in zip(sets, n_waves, slot0):
             t = ei.size(1)
             s = torch.empty(t, dtype=torch.float32, device=dev)
             rec = rec_all[t0:t0 + t] if (pack and t) else None
@@ -1434,10 +1443,9 @@ class _KgeBceLoss(torch.autograd.Function):
                     # per-relation sum of the waves' partial rows (consecutive waves; fixed order; no atomics)
                     dr = spmm(wave_ptr, wave_iota, None, drel_part, r, split=wave_split)
                     drel = dr if drel is None else drel + dr
-                    counted_parts.append(part[w0:w0 + waves])
             scores.append(s)
             grads.append(g)
-            w0, t0 = w0 + waves, t0 + t
+            t0 += t
         if drel is None:
             drel = torch.zeros_like(rel_emb)
         ctx.kind, ctx.comm, ctx.reg = kind, comm, float(reg)
@@ -1462,14 +1470,18 @@ class _KgeBceLoss(torch.autograd.Function):
         if padded:   # BCE mean + L2 over the real rows in ONE launch (a captured mini-batch step is bound by its launch count)
             out = torch.empty((), dtype=torch.float32, device=dev)
             L.call("bkg_kge_loss_finish_f32", L.ptr(part), part.numel(), 0.0, L.ptr(inv_total), L.ptr(z), z.stride(0),
-                   z.size(0), d, L.ptr(rows), L.ptr(rel_emb), rel_emb.stride(0), r, float(reg),
+                   z.size(0), d, L.ptr(rows), 0, L.ptr(rel_emb), rel_emb.stride(0), r, float(reg),
                    L.ptr(_finish_scratch(dev)), L.ptr(out), L.stream())
             return out, pos_scores, neg_scores
-        if owned is None:
-            loss = part.sum(dtype=torch.float64) / total
-        else:
-            loss = sum((p_.sum(dtype=torch.float64) for p_ in counted_parts),
-                       torch.zeros((), dtype=torch.float64, device=dev)) / total
+        if (KGE_LOSS_FINISH and d % 4 == 0 and z.stride(0) % 4 == 0 and rel_emb.stride(0) % 4 == 0 and z.stride(1) == 1
+                and rel_emb.stride(1) == 1 and z.data_ptr() % 16 == 0 and rel_emb.data_ptr() % 16 == 0 and z.size(0) < (1 << 31)):
+            # BCE mean + the L2 term in ONE launch (fp64 sums in a fixed order), as the padded mini-batch steps do
+            out = torch.empty((), dtype=torch.float32, device=dev)
+            L.call("bkg_kge_loss_finish_f32", L.ptr(part), n_counted, 1.0 / total, None, L.ptr(z), z.stride(0), z.size(0), d,
+                   None, 0 if reg_rows is None else int(reg_rows), L.ptr(rel_emb), rel_emb.stride(0), r, float(reg),
+                   L.ptr(_finish_scratch(dev)), L.ptr(out), L.stream())
+            return out, pos_scores, neg_scores
+        loss = part[:n_counted].sum(dtype=torch.float64) / total
         if reg:      # + reg * (mean(z^2) + mean(rel_emb^2)), reference kge_module.py:128-129: two one-launch norms
             z_rows = z.size(0) if reg_rows is None else reg_rows        # a partitioned step: the mean over N / world rows
             loss = loss + reg * (torch.linalg.vector_norm(z).double().pow(2) / (z_rows * z.size(1))
@@ -1576,6 +1588,11 @@ class _KgeBceLoss(torch.autograd.Function):
                 gl = gloss.reshape(1).contiguous()
                 L.call("bkg_scale_add_rows_f32", L.ptr(drel_out), drel_out.stride(0), L.ptr(rel_emb), rel_emb.stride(0),
                        rel_emb.size(0), d, L.ptr(gl), 2.0 * ctx.reg / d, None, L.stream())
+            elif KGE_LOSS_FINISH and gloss.numel() == 1 and drel.is_contiguous():
+                drel_out = torch.empty_like(drel)            # drel * gloss + (2 reg / numel) * gloss * rel_emb: one launch
+                gl = gloss.reshape(1).float().contiguous()
+                L.call("bkg_scale_add_rows_out_f32", L.ptr(drel), drel.stride(0), L.ptr(rel_emb), rel_emb.stride(0),
+                       rel_emb.size(0), d, L.ptr(gl), 2.0 * ctx.reg / d, L.ptr(drel_out), drel_out.stride(0), L.stream())
             else:
                 drel_out = drel * gloss
                 if ctx.reg:
