@@ -286,10 +286,21 @@ __global__ __launch_bounds__(256) void gcn_view_scatter_kernel(const int32_t* __
 using namespace bkg;
 
 // ----------------------------------------------------------------------------- sort
+// The one-sweep radix sort as tuned on gfx950 for this library's (uint32 key, uint32 position) pairs
+// (scripts/dev_sort_configs.hip; 8 M pairs of 17-bit keys -- the fresh negatives' incidence lists: 227 -> 142 us):
+// 9-bit digits (node ids of the bench graph take 17 bits: TWO passes instead of three of 8), 1024 x 8 items per block with
+// the match ranking, and rocPRIM's merge sort only below 128 k pairs (its default hands everything up to 1 M pairs to the
+// merge sort: 162 us for 1 M pairs against 52 us here, 116 against 43 us for 300 k -- the mini-batch structures' sizes).
+using SortConfig = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 9,
+                                        rocprim::block_radix_rank_algorithm::match>,
+    131072>;
+
 extern "C" int64_t bkg_sort_workspace_bytes(int64_t n) {
   size_t bytes = 0, merge_bytes = 0;
   uint32_t* p = nullptr;
-  rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)n, 0, 32, (hipStream_t)0);
+  rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, p, p, p, p, (size_t)n, 0, 32, (hipStream_t)0);
   rocprim::merge_sort(nullptr, merge_bytes, p, p, p, p, (size_t)n, rocprim::less<uint32_t>(), (hipStream_t)0);
   bytes = bytes > merge_bytes ? bytes : merge_bytes;
   size_t scan_bytes = 0;
@@ -335,7 +346,7 @@ static int sort_edges_impl(const int64_t* lo, const int64_t* hi, int64_t n_lo, i
   if (capturing == hipStreamCaptureStatusActive)
     e = rocprim::merge_sort(workspace, bytes, keys_tmp, sorted_keys, iota_tmp, perm, (size_t)n, rocprim::less<uint32_t>(), s);
   else
-    e = rocprim::radix_sort_pairs(workspace, bytes, keys_tmp, sorted_keys, iota_tmp, perm, (size_t)n, 0, bits, s);
+    e = rocprim::radix_sort_pairs<SortConfig>(workspace, bytes, keys_tmp, sorted_keys, iota_tmp, perm, (size_t)n, 0, bits, s);
   if (e != hipSuccess) { set_error("bkg_sort_edges: sort", e); return (int)e; }
   if (rowptr && n_q)
     hipLaunchKernelGGL(lower_bound_kernel, grid1(n_q), dim3(256), 0, s, sorted_keys, n, n_q, stride, rowptr);

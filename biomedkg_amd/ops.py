@@ -1473,7 +1473,7 @@ class _KgeBceLoss(torch.autograd.Function):
                    z.size(0), d, L.ptr(rows), 0, L.ptr(rel_emb), rel_emb.stride(0), r, float(reg),
                    L.ptr(_finish_scratch(dev)), L.ptr(out), L.stream())
             return out, pos_scores, neg_scores
-        if (KGE_LOSS_FINISH and d % 4 == 0 and z.stride(0) % 4 == 0 and rel_emb.stride(0) % 4 == 0 and z.stride(1) == 1
+        if (KGE_LOSS_FINISH and total > 0 and d % 4 == 0 and z.stride(0) % 4 == 0 and rel_emb.stride(0) % 4 == 0 and z.stride(1) == 1
                 and rel_emb.stride(1) == 1 and z.data_ptr() % 16 == 0 and rel_emb.data_ptr() % 16 == 0 and z.size(0) < (1 << 31)):
             # BCE mean + the L2 term in ONE launch (fp64 sums in a fixed order), as the padded mini-batch steps do
             out = torch.empty((), dtype=torch.float32, device=dev)
