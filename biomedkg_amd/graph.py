@@ -194,14 +194,21 @@ class CSR:
             self._split = rowsplit_for(self.rowptr, self.n_rows, self.nnz, pack=True, col=self.col)
         return self._split
 
-    def __init__(self, key, other, n_rows, presorted=False):
-        """``presorted``: ``key`` is already ascending (rows in order, entries of a row in edge order)."""
+    def __init__(self, key, other, n_rows, presorted=False, shared=None):
+        """``presorted``: ``key`` is already ascending (rows in order, entries of a row in edge order).
+        ``shared = (tensor, slot)``: the sort of ``key`` is kept on that tensor under that slot and taken from there when
+        it is already known -- the GCN structure's by-source CSR and the R-GCN structure's source side sort the same row of
+        the same ``edge_index`` (a training run over both modules, the bench: one sort instead of two)."""
         key = key.contiguous()
         other = other.contiguous()
         dev = key.device
         self.n_rows, self.nnz = int(n_rows), key.numel()
         build = _Sorter.presorted_rowptr if presorted else _Sorter.sort_rowptr
-        self.sorted_keys, self.perm, self.rowptr = build(key, None, n_rows, 1, n_rows + 1)
+        if shared is not None and shared[0] is not None:
+            self.sorted_keys, self.perm, self.rowptr = _cached(shared[0], shared[1], (self.n_rows,),
+                                                               lambda: build(key, None, n_rows, 1, n_rows + 1))
+        else:
+            self.sorted_keys, self.perm, self.rowptr = build(key, None, n_rows, 1, n_rows + 1)
         self.col = _i32(self.nnz, dev)
         L.call("bkg_gather_i64_to_i32", L.ptr(other), L.ptr(self.perm), L.ptr(self.col), self.nnz, L.stream())
 
@@ -232,6 +239,7 @@ class KeptCSR:
 # CSRs + two work-item tables per mask (~0.2 ms on the bench graph, less than the masked form's gcn_norm + two weight
 # permutations) against 40 % of the gathered rows of the eight
 # propagates of a step.  Mini-batch graphs stay on the masked weights (launch-bound: the extra launches cost more).
+PLANT_RELATION_ORDER = __import__("os").environ.get("BKG_PLANT_RELATION_ORDER", "1") != "0"
 KEPT_CSR_MIN_EDGES = int(__import__("os").environ.get("BKG_KEPT_CSR_MIN_EDGES", str(1 << 20)))
 
 
@@ -286,7 +294,7 @@ class Graph(_EdgeHolder):
         self._hold(edge_index.contiguous())
         self.num_nodes, self.num_edges = int(num_nodes), edge_index.size(1)
         self.by_dst = CSR(self.dst, self.src, num_nodes, presorted=dst_sorted)   # rows = targets, col = sources  (forward)
-        self.by_src = CSR(self.src, self.dst, num_nodes)   # rows = sources, col = targets  (backward)
+        self.by_src = CSR(self.src, self.dst, num_nodes, shared=(self.edge_index, "sort_by_source"))   # rows = sources, col = targets  (backward)
         self._plain = None
         self._kept = None
 
@@ -371,6 +379,15 @@ class RelGraph(_EdgeHolder):
         src, dst = self.src, self.dst
         sorted_keys, perm, ws = _Sorter.sort(dst, self.edge_type, n, r)
         self.perm = perm
+        if PLANT_RELATION_ORDER and e and num_nodes * (r + 1) < (1 << 32):
+            # this sort IS a grouping of the triplets by relation (keys = relation * n + target): the scorer's relation
+            # order (ops.relation_order_of, cached on the id tensor) needs no sort of its own while the structure is young
+            # (a mini-batch, a graph rebuilt every step); a graph that stays gets the stable order on its third step --
+            # triplet ids ascending inside a relation: the scorer's id reads and record writes then run forward in memory
+            # (the full-graph positives: 0.519 against 0.527 ms per launch)
+            rel_edge_ptr = _i32(r + 1, dev)
+            L.call("bkg_lower_bound_u32", L.ptr(sorted_keys), e, r + 1, n, L.ptr(rel_edge_ptr), L.stream())
+            _cached(self.edge_type, "rel_order_planted", (r,), lambda: [perm, rel_edge_ptr, 0])
         self.src_sorted = _i32(e, dev)
         L.call("bkg_gather_i64_to_i32", L.ptr(src), L.ptr(perm), L.ptr(self.src_sorted), e, L.stream())
         flag, scan = _i32(e, dev), _i32(e, dev)
@@ -411,7 +428,7 @@ class RelGraph(_EdgeHolder):
         w_edge = torch.empty(e, dtype=torch.float32, device=dev)
         L.call("bkg_rgcn_edge_order", L.ptr(self.perm), L.ptr(self.seg_of), L.ptr(self.inv_cnt), e, L.ptr(seg_of_edge),
                L.ptr(w_edge), L.stream())
-        self.src_csr = CSR(self.edge_index[0], seg_of_edge, self._n_src)
+        self.src_csr = CSR(self.edge_index[0], seg_of_edge, self._n_src, shared=(self.edge_index, "sort_by_source"))
         self.src_w = self.src_csr.permute_f32(w_edge)
 
 

@@ -1218,7 +1218,17 @@ def relation_order_of(edge_type, num_relations):
     def build():
         sorted_keys, perm, rel_ptr = _Sorter.sort_rowptr(edge_type, None, num_relations, 1, num_relations + 1)
         return perm, rel_ptr
+    tag = getattr(edge_type, "_bkg_cache", None)
+    if tag is not None:
+        key = (edge_type._version, int(num_relations))
+        own, planted = tag.get("rel_order"), tag.get("rel_order_planted")
+        if (own is None or own[0] != key) and planted is not None and planted[0] == key and planted[1][2] < _PLANTED_ORDER_USES:
+            planted[1][2] += 1           # the R-GCN structure's (relation, target) sort, while the structure is young
+            return planted[1][0], planted[1][1]
     return _cached(edge_type, "rel_order", (int(num_relations),), build)
+
+
+_PLANTED_ORDER_USES = 2     # steps a graph's triplets are walked in the R-GCN structure's order before they get their own
 
 
 def grouped_types(edge_type, repeat, num_relations):

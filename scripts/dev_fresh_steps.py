@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""The bench's `ms_per_step_fresh_structures` figure on its own (a NEW edge_index tensor every step: every structure is
+rebuilt inside the step), for a kernel trace:   rocprofv3 --kernel-trace ... -- python3 scripts/dev_fresh_steps.py [steps]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+sys.argv = sys.argv[:1]
+args = bench.parse()
+dev = torch.device("cuda:0")
+from biomedkg_amd import ops  # noqa: E402
+ops.set_matmul_precision("bf16")
+step_g, step_k, n, e, r = bench.build_replica_steps(args, 0, 1, dev)
+
+
+def fresh():
+    ei = step_k.batch.edge_index.clone()
+    step_k.batch.edge_index = step_g.batch.edge_index = ei
+    step_k.batch.edge_type = step_k.batch.edge_type.clone()
+    step_g(); step_k()
+
+
+for _ in range(3):
+    fresh()
+step_k.finish()
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(steps):
+    fresh()
+step_k.finish()
+torch.cuda.synchronize()
+print("ms per fresh step", (time.perf_counter() - t) / steps * 1e3)
