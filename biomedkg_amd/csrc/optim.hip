@@ -85,6 +85,18 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(OptTensors t, float* _
   if (threadIdx.x == 0) partial[chunk] = s;
 }
 
+// One element of the update (torch.optim.Adam, no amsgrad / decay) -- the same operations in the same order whichever
+// path below loads it.
+__device__ __forceinline__ float adam_element(float g, float clip, float& m, float& v, float p, float beta1, float beta2,
+                                              float step_size, float inv_sqrt_bc2, float eps) {
+  const float gi = g * clip;
+  m = beta1 * m + (1.0f - beta1) * gi;
+  v = beta2 * v + (1.0f - beta2) * gi * gi;
+  return p - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+}
+
+constexpr int OPT_TILE_PAD = 2;          // bf16 elements between the rows of a chunk staged for its transposed image
+
 template <bool IMAGES>
 __global__ __launch_bounds__(256) void clip_adam_kernel(OptTensors t, OptImages im, const float* __restrict__ partial,
                                                         int n_partial, float max_norm, float lr,
@@ -92,6 +104,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(OptTensors t, OptImages 
                                                         float eps, float step, float* __restrict__ step_dev,
                                                         float* __restrict__ norm_out) {
   __shared__ float sh[4];
+  __shared__ __bf16 tile[IMAGES ? OPT_CHUNK + 64 * OPT_TILE_PAD : 1];
   // the total in index order: every block computes the same sum (n_partial <= a few thousand floats, L2-resident)
   float acc = 0.f;
   for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
@@ -114,13 +127,68 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(OptTensors t, OptImages 
   __bf16* __restrict__ w16 = IMAGES ? im.w16[k] : nullptr;
   __bf16* __restrict__ w16t = IMAGES ? im.w16t[k] : nullptr;
   const int rows = IMAGES ? im.rows[k] : 1, cols = IMAGES ? im.cols[k] : 1;
+  if (chunk == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+  // A whole chunk of sixteen-byte aligned tensors: four elements per thread and pass (the R-GCN weights are 97 % of the
+  // bench step's parameters).  With images, when the chunk is a band of whole rows of ONE matrix (cols divides the chunk,
+  // the matrix a whole number of chunks): the band is staged in LDS and leaves for the transposed image with 4096 / cols
+  // consecutive rows per column -- 32 bytes per 16 lanes at cols = 256 -- instead of one 2-byte store per cache line
+  // (8 M scattered stores for the bench's R-GCN weights: the update ran at 1.1 TB/s, 228 us).
+  const bool vec = base + OPT_CHUNK <= n && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  if (vec) {
+    const bool band = IMAGES && w16 && cols >= 64 && OPT_CHUNK % cols == 0 && ((int64_t)rows * cols) % OPT_CHUNK == 0 &&
+                      (((uintptr_t)w16 & 7) == 0);
+    const int band_rows = band ? OPT_CHUNK / cols : 1;
+#pragma unroll
+    for (int it = 0; it < OPT_CHUNK / 1024; ++it) {
+      const int local = it * 1024 + threadIdx.x * 4;
+      const int64_t i = base + local;
+      const float4 g4 = *reinterpret_cast<const float4*>(g + i);
+      float4 m4 = *reinterpret_cast<const float4*>(m + i);
+      float4 v4 = *reinterpret_cast<const float4*>(v + i);
+      float4 p4 = *reinterpret_cast<const float4*>(p + i);
+      p4.x = adam_element(g4.x, clip, m4.x, v4.x, p4.x, beta1, beta2, step_size, inv_sqrt_bc2, eps);
+      p4.y = adam_element(g4.y, clip, m4.y, v4.y, p4.y, beta1, beta2, step_size, inv_sqrt_bc2, eps);
+      p4.z = adam_element(g4.z, clip, m4.z, v4.z, p4.z, beta1, beta2, step_size, inv_sqrt_bc2, eps);
+      p4.w = adam_element(g4.w, clip, m4.w, v4.w, p4.w, beta1, beta2, step_size, inv_sqrt_bc2, eps);
+      *reinterpret_cast<float4*>(m + i) = m4;
+      *reinterpret_cast<float4*>(v + i) = v4;
+      *reinterpret_cast<float4*>(p + i) = p4;
+      if (IMAGES && w16) {
+        const __bf16 h[4] = {(__bf16)p4.x, (__bf16)p4.y, (__bf16)p4.z, (__bf16)p4.w};
+        if (band) {
+          *reinterpret_cast<uint2*>(w16 + i) = *reinterpret_cast<const uint2*>(h);
+          const int r = local / cols, c = local - r * cols;          // (cols % 4 == 0: the four share a row)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tile[r * (cols + OPT_TILE_PAD) + c + e] = h[e];
+        } else {
+          const int64_t per = (int64_t)rows * cols;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int64_t ie = i + e, b = ie / per, rem = ie - b * per;
+            const int r = (int)(rem / cols), c = (int)(rem - (int64_t)r * cols);
+            w16[ie] = h[e];
+            w16t[b * per + (int64_t)c * rows + r] = h[e];
+          }
+        }
+      }
+    }
+    if (band) {
+      __syncthreads();
+      const int64_t per = (int64_t)rows * cols, b = base / per;
+      const int r0 = (int)((base - b * per) / cols);
+      __bf16* __restrict__ out = w16t + b * per + r0;
+      for (int j = threadIdx.x; j < OPT_CHUNK; j += 256) {
+        const int c = j / band_rows, dr = j - c * band_rows;
+        out[(int64_t)c * rows + dr] = tile[dr * (cols + OPT_TILE_PAD) + c];
+      }
+    }
+    return;
+  }
   for (int64_t i = base + threadIdx.x; i < n && i < base + OPT_CHUNK; i += 256) {
-    const float gi = g[i] * clip;
-    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    float mi = m[i], vi = v[i];
+    const float pi = adam_element(g[i], clip, mi, vi, p[i], beta1, beta2, step_size, inv_sqrt_bc2, eps);
     m[i] = mi;
     v[i] = vi;
-    const float pi = p[i] - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     p[i] = pi;
     if (IMAGES && w16) {
       const __bf16 h = (__bf16)pi;
@@ -130,7 +198,6 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(OptTensors t, OptImages 
       w16t[b * per + (int64_t)c * rows + r] = h;           // (2-byte scattered stores into matrices that live in the L2)
     }
   }
-  if (chunk == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
 }
 
 // the device step counter is bumped by its own one-thread launch AFTER the update (a block of the update kernel doing it
