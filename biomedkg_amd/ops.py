@@ -1231,6 +1231,49 @@ def relation_order_of(edge_type, num_relations):
 _PLANTED_ORDER_USES = 2     # steps a graph's triplets are walked in the R-GCN structure's order before they get their own
 
 
+SORTED_POSITIVES = __import__("os").environ.get("BKG_SORTED_POSITIVES", "1") != "0"
+_SORTED_MIN_TRIPLETS = 1 << 20
+
+
+class _SortedTriplets:
+    """A graph's positives stored in (relation, target) order -- the R-GCN structure's sort (graph.RelGraph) -- for the
+    scorer of a graph that STAYS (full-graph training): the ids are read in place, the tails of consecutive triplets are
+    the same or neighbouring rows of ``z`` (every tail row leaves the L2 once per (relation, target) segment instead of
+    once per triplet), scores and gradient records are written front to back, and the tail half of every node's incidence
+    list is a handful of runs of consecutive records.  ``index`` / ``types``: the triplets in that order (their relation
+    order planted as the identity); ``inverse``: position of the caller's triplet in it (scores go back through it)."""
+
+    __slots__ = ("index", "types", "inverse")
+
+    def __init__(self, edge_index, edge_type, perm, rel_ptr, num_relations):
+        p64 = perm.long()
+        self.index = edge_index.index_select(1, p64).contiguous()
+        self.types = edge_type.index_select(0, p64).contiguous()
+        self.inverse = torch.empty_like(p64)
+        self.inverse[p64] = torch.arange(p64.numel(), device=p64.device)
+        self.types._bkg_cache = {"rel_order": ((self.types._version, int(num_relations)),
+                                               (_iota32(p64.numel(), p64.device), rel_ptr))}
+
+
+def sorted_positives_of(edge_index, edge_type, num_relations):
+    """``_SortedTriplets`` of a triplet set whose R-GCN structure has outlived its young steps (``relation_order_of``: the
+    planted order was used up), else None.  Cached on ``edge_type`` (keyed on the index tensor and both versions)."""
+    from .graph import _cached
+    t = edge_type.numel()
+    if not SORTED_POSITIVES or t < _SORTED_MIN_TRIPLETS or t >= (1 << 31):
+        return None
+    tag = getattr(edge_type, "_bkg_cache", None)
+    planted = tag.get("rel_order_planted") if tag is not None else None
+    key = (edge_type._version, int(num_relations))
+    if planted is None or planted[0] != key or planted[1][2] < _PLANTED_ORDER_USES:
+        return None
+    perm, rel_ptr = planted[1][0], planted[1][1]
+    if perm.numel() != t or edge_index.size(1) != t:
+        return None
+    return _cached(edge_type, "sorted_triplets", (int(num_relations), edge_index.data_ptr(), edge_index._version),
+                   lambda: _SortedTriplets(edge_index, edge_type, perm, rel_ptr, num_relations))
+
+
 def grouped_types(edge_type, repeat, num_relations):
     """``edge_type.repeat(repeat)[randperm(...)]`` (reference kge_module.py:97-100) delivered GROUPED BY RELATION: the
     multiset of the positives' relation ids, ``repeat`` times, in relation order.  The negatives it is paired with come out of
@@ -1398,7 +1441,12 @@ class _KgeBceLoss(torch.autograd.Function):
         n = zt.size(0)
         zt_bf16 = int(zt.dtype == torch.bfloat16)
         # triplet sets (index, type, label, counted) in groups: one group = one incidence structure of the backward
+        resort = None
         if owned is None:
+            if not padded and comm is None:
+                resort = sorted_positives_of(pos_ei, pos_et, r)
+                if resort is not None:             # the positives of a graph that stays: walked in (relation, target) order
+                    pos_ei, pos_et = resort.index, resort.types
             sets = ((pos_ei, pos_et, 1.0, True, 0), (neg_ei, neg_et, 0.0, True, 1))
         else:
             po, ne = owned
@@ -1470,6 +1518,8 @@ class _KgeBceLoss(torch.autograd.Function):
                                   rec_all[pos_ei.size(1):] if (pack and neg_ei.size(1)) else None,
                                   z if (reg or padded) else None)
             pos_scores, neg_scores = scores[0], scores[1]
+            if resort is not None:
+                pos_scores = pos_scores.index_select(0, resort.inverse)      # back in the caller's order
         else:
             t_pos = owned[0].n_own + owned[0].n_foreign
             ctx.graphs = None

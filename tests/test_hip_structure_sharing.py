@@ -89,3 +89,42 @@ def test_gcn_and_rgcn_structures_share_the_by_source_sort():
     again = G.CSR(ei[0], ei[1], n, shared=(ei, "sort_by_source"))
     assert again.perm is not g.by_src.perm
     assert torch.equal(again.perm.cpu().long(), torch.argsort(ei[0].cpu(), stable=True))
+
+
+def test_positives_of_a_graph_that_stays_are_scored_in_their_sorted_frame(monkeypatch):
+    """From the step after the planted order is used up, the scorer walks a copy of the positives stored in (relation,
+    target) order: same loss, same gradients, scores handed back in the caller's order."""
+    from biomedkg_amd import graph as G, ops
+    monkeypatch.setattr(ops, "_SORTED_MIN_TRIPLETS", 1000)
+    n, e, r, d = 3000, 60_000, 7, 128
+    ei, et = _graph(n, e, r, 5)
+    g = torch.Generator().manual_seed(6)
+    z0 = torch.randn(n, d, generator=g).to(DEV)
+    rel0 = torch.randn(r, d, generator=g).to(DEV)
+    neg = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    neg_t = torch.randint(0, r - 1, (e,), generator=g).to(DEV)
+    G.RelGraph(ei, et, n, r)
+    res, framed = [], []
+    for step in range(4):
+        z, rel = z0.clone().requires_grad_(True), rel0.clone().requires_grad_(True)
+        loss, pos, _ = ops.kge_bce_loss(z, rel, ei, et, neg, neg_t, ops.KGE_DISTMULT, reg=1e-2)
+        loss.backward()
+        framed.append("sorted_triplets" in et._bkg_cache)
+        res.append((float(loss.detach()), z.grad.clone(), rel.grad.clone(), pos.clone()))
+    assert framed == [False, False, True, True]
+    frame = et._bkg_cache["sorted_triplets"][1]
+    assert torch.equal(frame.index[:, frame.inverse], ei) and torch.equal(frame.types[frame.inverse], et)
+    keys = frame.types * n + frame.index[1]
+    assert bool((keys[1:] >= keys[:-1]).all())                    # (relation, target) order
+    l0, z0g, r0g, p0 = res[0]
+    for l, zg, rg, p in res[1:]:
+        assert abs(l - l0) <= 1e-6 * abs(l0)
+        assert torch.equal(p, p0)                                  # the caller's order, the same scores
+        torch.testing.assert_close(zg, z0g, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(rg, r0g, rtol=1e-4, atol=1e-7)
+    # an id tensor edited in place drops the frame with everything else cached on it
+    et[:5] = 2
+    loss, pos, _ = ops.kge_bce_loss(z0.clone().requires_grad_(True), rel0, ei, et, neg, neg_t, ops.KGE_DISTMULT)
+    ref = ops.kge_score(z0, rel0, ei, et, ops.KGE_DISTMULT).detach()        # (exact fp32 rows; the loss reads a bf16 table)
+    assert float((pos - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    assert float((pos[:5] - p0[:5]).abs().max()) > 1e-3                   # ... and they are the edited triplets' scores
