@@ -139,4 +139,4 @@ class GGD(torch.nn.Module):
             s = ops.linear_rowsum(h, last.weight, last.bias).view(n, 2)      # (W h + b).sum(1) = h . W.sum(0) + b.sum()
         else:
             s = ops.linear(h, last.weight, last.bias).sum(1).view(n, 2)
-        return s[:, 0], s[:, 1]
+        return ops.columns_of_pair(s)

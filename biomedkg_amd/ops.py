@@ -592,6 +592,43 @@ class _RowDot(torch.autograd.Function):
         return dx, dw
 
 
+class _ColumnsOfPair(torch.autograd.Function):
+    """``s [n, 2] -> (s[:, 0], s[:, 1])``.  Autograd's own column selects hand back two zero-filled ``[n, 2]`` tables, two
+    copies and their sum; the loss behind (``ggd_bce``) writes ``[d pos | d neg]`` as ONE ``[n, 2]`` table already -- its
+    two columns arrive here and that table is the gradient (no launch), anything else is stacked (one)."""
+
+    @staticmethod
+    def forward(ctx, s):
+        return s[:, 0], s[:, 1]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        b = g0._base
+        if (b is not None and b is g1._base and b.dim() == 2 and b.size(1) == 2 and b.is_contiguous() and b.dtype == g0.dtype
+                and g0.stride() == (2,) and g1.stride() == (2,) and g0.storage_offset() == b.storage_offset()
+                and g1.storage_offset() == b.storage_offset() + 1 and g0.numel() == b.size(0)):
+            return b
+        return torch.stack((g0, g1), dim=1)
+
+
+def columns_of_pair(s):
+    """The two columns of an ``[n, 2]`` score table (GGD: positive | corrupted) as separate vectors."""
+    return _ColumnsOfPair.apply(s)
+
+
+class _ColSumOfWeight(torch.autograd.Function):
+    """``weight.sum(0)`` of a small parameter through the library's column sum (the gradient: every row gets it)."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        ctx.rows = weight.size(0)
+        return colsum(weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.unsqueeze(0).expand(ctx.rows, g.numel())
+
+
 def rowsum_linear_ok(x, weight):
     """Can ``linear(x, weight, bias).sum(-1)`` run as one dot product per row (:func:`linear_rowsum`)?"""
     epl = 8 if x.dtype == torch.bfloat16 else 4
@@ -607,7 +644,7 @@ def linear_rowsum(x, weight, bias=None):
     the fp32 additions (so the exact-fp32 parity path keeps the product); the gradients reach ``weight`` and ``bias``
     through autograd of the two small sums."""
     L.require_cuda(x, weight, bias)
-    s = _RowDot.apply(x if x.is_contiguous() else x.contiguous(), weight.sum(0))
+    s = _RowDot.apply(x if x.is_contiguous() else x.contiguous(), _ColSumOfWeight.apply(weight))
     return s if bias is None else s + bias.sum()
 
 
