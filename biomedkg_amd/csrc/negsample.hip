@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void negative_scatter_kernel(const uint64_t* _
       out_tail[p] = (int64_t)(c + (r <= c ? 1 : 0));
     }
   }
-  if (i == n_cand - 1) *count = offs[i] + flag[i];
+  // slots the survivors did not reach hold (0, 0) -- never whatever the buffer held (the one-round caller does not read
+  // the count: a shortfall, ~1e-9 per call, must not leave stale ids); a later round of the caller writes over them
+  const int64_t total = (int64_t)offs[n_cand - 1] + flag[n_cand - 1], q = out_offset + total + i;
+  if (q < max_out) { out_head[q] = 0; out_tail[q] = 0; }
+  if (i == n_cand - 1) *count = (int32_t)total;
 }
 
 __global__ __launch_bounds__(256) void permute_gather_kernel(const int64_t* __restrict__ src, int64_t n, Feistel pi,

@@ -1286,8 +1286,8 @@ class _SortedTriplets:
         p64 = perm.long()
         self.index = edge_index.index_select(1, p64).contiguous()
         self.types = edge_type.index_select(0, p64).contiguous()
-        self.inverse = torch.empty_like(p64)
-        self.inverse[p64] = torch.arange(p64.numel(), device=p64.device)
+        self.inverse = torch.empty_like(perm)                                  # int32 (t < 2^31)
+        self.inverse[p64] = _iota32(p64.numel(), p64.device)
         self.types._bkg_cache = {"rel_order": ((self.types._version, int(num_relations)),
                                                (_iota32(p64.numel(), p64.device), rel_ptr))}
 
@@ -1556,7 +1556,9 @@ class _KgeBceLoss(torch.autograd.Function):
                                   z if (reg or padded) else None)
             pos_scores, neg_scores = scores[0], scores[1]
             if resort is not None:
-                pos_scores = pos_scores.index_select(0, resort.inverse)      # back in the caller's order
+                back = torch.empty_like(pos_scores)                           # back in the caller's order
+                L.call("bkg_gather_f32", L.ptr(pos_scores), L.ptr(resort.inverse), L.ptr(back), back.numel(), L.stream())
+                pos_scores = back
         else:
             t_pos = owned[0].n_own + owned[0].n_foreign
             ctx.graphs = None

@@ -114,10 +114,11 @@ def _negative_sampling_hashed(edge_index, n, k, sample_size, prob, seed):
     pos_table = _positive_table(edge_index, n)
     # PyG's first round keeps ~1.1 k of its int(1.1 k / prob) candidates (binomial, sigma^2 <= 1.1 k (1 - prob)).  When
     # that 10 % margin is worth six sigma the round cannot fall short of k in practice, and the survivor count need not
-    # be READ: no host round trip in the middle of the step (zero-filled result: a shortfall -- ~1e-9 per call -- would
-    # leave (0, 0) pairs, never stale memory).  Otherwise: count, and go on to rounds two and three like PyG.
+    # be READ: no host round trip in the middle of the step (the kernel zeroes the slots its survivors do not reach: a
+    # shortfall -- ~1e-9 per call -- leaves (0, 0) pairs, never stale memory).  Otherwise: count, and go on to rounds two
+    # and three like PyG.
     sure = sample_size <= population and 0.1 * k >= 6.0 * (1.1 * k * max(1.0 - prob, 0.0)) ** 0.5 and prob > 0.9
-    out = (torch.zeros if sure else torch.empty)(2, k, dtype=torch.int64, device=dev)
+    out = torch.empty(2, k, dtype=torch.int64, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
     have, first, draw = 0, 0, min(sample_size, population)
     if sure:

@@ -425,7 +425,8 @@ int bkg_gate_f32(const float* dout, const float* gate, float scale, int64_t nume
  *      bkg_negative_sample: candidate c is pi(c), pi a bijection of [0, N*(N-1)) keyed by seed (candidates are distinct by
  *      construction = random.sample); candidates [first, first + n) that are not in pos_table are written, in candidate
  *      order, as (head, tail) pairs (vector_to_edge_index: tail += (head <= tail)) at out_offset + rank while < max_out;
- *      *count (device) = survivors of this call.  Bitwise repeatable, no atomics.
+ *      *count (device) = survivors of this call; the slots behind the survivors (as far as n_candidates reaches, below
+ *      max_out) are set to (0, 0).  Bitwise repeatable, no atomics.
  *      keys_tmp / flag_tmp / offs_tmp: [n_candidates] scratch.  bkg_permute_gather_i64: out[i] = src[pi(i)], pi a keyed
  *      bijection of [0, n) (x[randperm(n)] without the sort). */
 int bkg_hashset_insert_offdiag(const int64_t* head, const int64_t* tail, int64_t n_nodes, int64_t n, uint64_t* table,

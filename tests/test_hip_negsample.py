@@ -249,3 +249,26 @@ def test_degenerate_inputs():
     full = torch.cartesian_prod(torch.arange(4), torch.arange(4)).t().contiguous().to(DEV)
     assert sampling.negative_sampling(full[:, full[0] != full[1]]).shape == (2, 0)   # all 12 off-diagonal cells taken
     assert R.DeviceRand(seed=1).shuffle(torch.empty(0, dtype=torch.int64, device=DEV)).numel() == 0
+
+
+def test_a_round_that_falls_short_leaves_zero_pairs_not_stale_ids():
+    """The one-round caller never reads the survivor count: the slots its survivors do not reach must hold (0, 0), whatever
+    the (uninitialised) output buffer held before -- and nothing is written past ``max_out`` or past the candidates' reach."""
+    from biomedkg_amd import _lib as L, sampling
+    n, draw, max_out = 60, 300, 500
+    ei = _graph(n, 2500, 9)                                          # dense: most candidates are positives
+    table = sampling._positive_table(ei, n)
+    keys = torch.empty(draw, dtype=torch.int64, device=DEV)
+    flag = torch.empty(2, draw, dtype=torch.int32, device=DEV)
+    out = torch.full((2, max_out + 50), -7, dtype=torch.int64, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(L.lib().bkg_negative_sample_workspace_bytes(draw), dtype=torch.uint8, device=DEV)
+    L.call("bkg_negative_sample", n, 0, draw, 4321, L.ptr(table), table.numel(), L.ptr(keys), L.ptr(flag[0]), L.ptr(flag[1]),
+           L.ptr(out[0]), L.ptr(out[1]), 0, max_out, L.ptr(count), L.ptr(ws), ws.numel(), L.stream())
+    kept = int(count)
+    assert 0 < kept < draw
+    got = out.cpu()
+    assert int(got[:, :kept].min()) >= 0 and not bool((got[0, :kept] == got[1, :kept]).any())
+    reach = min(max_out, kept + draw)
+    assert bool((got[:, kept:reach] == 0).all())                     # the shortfall: (0, 0) pairs
+    assert bool((got[:, reach:] == -7).all())                        # nothing beyond

@@ -113,7 +113,8 @@ def test_positives_of_a_graph_that_stays_are_scored_in_their_sorted_frame(monkey
         res.append((float(loss.detach()), z.grad.clone(), rel.grad.clone(), pos.clone()))
     assert framed == [False, False, True, True]
     frame = et._bkg_cache["sorted_triplets"][1]
-    assert torch.equal(frame.index[:, frame.inverse], ei) and torch.equal(frame.types[frame.inverse], et)
+    inv = frame.inverse.long()
+    assert torch.equal(frame.index[:, inv], ei) and torch.equal(frame.types[inv], et)
     keys = frame.types * n + frame.index[1]
     assert bool((keys[1:] >= keys[:-1]).all())                    # (relation, target) order
     l0, z0g, r0g, p0 = res[0]
