@@ -39,6 +39,8 @@ SIGNATURES = {
     "bkg_gather_i64_to_i32": (I32, [P, P, P, I64, P]),
     "bkg_gather_i32": (I32, [P, P, P, I64, P]),
     "bkg_gather_f32": (I32, [P, P, P, I64, P]),
+    "bkg_csr_compact_workspace_bytes": (I64, [I64]),
+    "bkg_csr_compact": (I32, [P, P, P, I64, I64, P, P, P, P, P, P, P, I64, P]),
     "bkg_gcn_view_workspace_bytes": (I64, [I64]),
     "bkg_gcn_view": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, P, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
     "bkg_gcn_norm": (I32, [P, P, P, P, P, P, I64, I64, P, P, P, P]),

@@ -281,6 +281,32 @@ __global__ __launch_bounds__(256) void gcn_view_scatter_kernel(const int32_t* __
   if (second) { col_out_s[pos] = c; w_out_s[pos] = w; } else { col_out_d[pos] = c; w_out_d[pos] = w; }
 }
 
+// ---- the entries of ONE weighted CSR whose weight is not zero, as a CSR of its own over the same rows (a dropout_edge view
+// of a node-partitioned graph: its CSRs list table slots and carry the self loops as entries, the weights come from the
+// global degrees -- biomedkg_amd/partition.py --, so the view is cut out of the weighted form instead of built from a mask)
+__global__ __launch_bounds__(256) void csr_flag_kernel(const float* __restrict__ w, int64_t nnz, int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nnz) flag[i] = w[i] != 0.f ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void csr_compact_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          const float* __restrict__ w, int64_t n_rows, int64_t nnz,
+                                                          const int32_t* __restrict__ flag, const int32_t* __restrict__ offs,
+                                                          int32_t* __restrict__ rowptr_out, int32_t* __restrict__ col_out,
+                                                          float* __restrict__ w_out, int32_t* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int32_t total = nnz ? offs[nnz - 1] + flag[nnz - 1] : 0;
+  if (i < nnz && flag[i]) {
+    col_out[offs[i]] = col[i];
+    w_out[offs[i]] = w[i];
+  }
+  if (i <= n_rows) {
+    const int32_t r = rowptr[i];
+    rowptr_out[i] = r < nnz ? offs[r] : total;
+  }
+  if (i == 0) *count = total;
+}
+
 }  // namespace bkg
 
 using namespace bkg;
@@ -409,6 +435,32 @@ extern "C" int bkg_gather_f32(const float* src, const int32_t* idx, float* out, 
   if (n == 0) return 0;
   hipLaunchKernelGGL(gather_f32_kernel, grid1(n), dim3(256), 0, (hipStream_t)stream, src, idx, out, n);
   return check_launch("bkg_gather_f32");
+}
+
+extern "C" int64_t bkg_csr_compact_workspace_bytes(int64_t nnz) {
+  size_t bytes = 0;
+  rocprim::exclusive_scan(nullptr, bytes, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)(nnz > 0 ? nnz : 1),
+                          rocprim::plus<int32_t>());
+  return (int64_t)bytes + 256;
+}
+
+// rowptr_out [n_rows + 1], col_out / w_out [nnz] (the first *count entries are meaningful), count (device) = entries kept.
+// flag_tmp / offs_tmp: int32 [nnz] scratch; workspace of bkg_csr_compact_workspace_bytes(nnz).  No host read.
+extern "C" int bkg_csr_compact(const int32_t* rowptr, const int32_t* col, const float* w, int64_t n_rows, int64_t nnz,
+                               int32_t* flag_tmp, int32_t* offs_tmp, int32_t* rowptr_out, int32_t* col_out, float* w_out,
+                               int32_t* count, void* workspace, int64_t workspace_bytes, void* stream) {
+  BKG_ARG(n_rows >= 0 && nnz >= 0 && nnz < (1ll << 31) && n_rows < (1ll << 31), "bkg_csr_compact: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (nnz) {
+    hipLaunchKernelGGL(csr_flag_kernel, grid1(nnz), dim3(256), 0, s, w, nnz, flag_tmp);
+    size_t bytes = (size_t)workspace_bytes;
+    hipError_t e = rocprim::exclusive_scan(workspace, bytes, flag_tmp, offs_tmp, 0, (size_t)nnz, rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) { set_error("bkg_csr_compact: scan", e); return (int)e; }
+  }
+  const int64_t span = nnz > n_rows + 1 ? nnz : n_rows + 1;
+  hipLaunchKernelGGL(csr_compact_kernel, grid1(span), dim3(256), 0, s, rowptr, col, w, n_rows, nnz, flag_tmp, offs_tmp,
+                     rowptr_out, col_out, w_out, count);
+  return check_launch("bkg_csr_compact");
 }
 
 extern "C" int64_t bkg_gcn_view_workspace_bytes(int64_t nnz) {

@@ -234,6 +234,20 @@ class KeptCSR:
         self.split = (RowSplit(rowptr, csr.n_rows, csr.nnz, pack=PACK_SHORT_ROWS, col=col, ephemeral=True, superset=csr.split)
                       if csr.nnz >= SPLIT_MIN_NNZ else None)
 
+    @classmethod
+    def of_weights(cls, csr, w):
+        """The entries of ``csr`` with a non-zero weight ``w`` (``bkg_csr_compact``): a view of a CSR that already carries the
+        view's weights -- a node-partitioned graph's (table slots as columns, self loops as entries, global degrees)."""
+        dev, n, nnz = w.device, csr.n_rows, csr.nnz
+        rowptr, col, count = _i32(n + 1, dev), _i32(nnz, dev), _i32(1, dev)
+        w_out = torch.empty(nnz, dtype=torch.float32, device=dev)
+        flag, offs = _i32(nnz, dev), _i32(nnz, dev)
+        ws_bytes = L.lib().bkg_csr_compact_workspace_bytes(nnz)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.call("bkg_csr_compact", L.ptr(csr.rowptr), L.ptr(csr.col), L.ptr(w), n, nnz, L.ptr(flag), L.ptr(offs), L.ptr(rowptr),
+               L.ptr(col), L.ptr(w_out), L.ptr(count), L.ptr(ws), ws_bytes, L.stream())
+        return cls(rowptr, col, w_out, count, csr)
+
 
 # a dropout_edge view of a graph of this many edges or more propagates over its kept entries only (KeptCSR): two
 # CSRs + two work-item tables per mask (~0.2 ms on the bench graph, less than the masked form's gcn_norm + two weight

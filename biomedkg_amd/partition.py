@@ -348,7 +348,9 @@ class PartitionedGraph:
     targets (backward: ``dXW = by_src @ gathered dOut``: every rank sums the table gradient of its own rows, nothing is
     reduce-scattered).  Carries what the fused layers read off a graph (``by_dst`` / ``by_src`` / ``n_out`` / ``n_table``
     / ``comm``); ``gcn_weights(keep)`` re-weights the same CSRs for a ``dropout_edge`` view -- global degrees from the full
-    edge list, no communication, nothing re-sorted."""
+    edge list, no communication, nothing re-sorted -- and, on the product backend for a shard of ``KEPT_CSR_MIN_EDGES``
+    entries or more, cuts the view's own CSRs out of them (``graph.KeptCSR.of_weights``: the dropped edges' rows are then
+    never gathered, as in the single-GPU ``Graph.gcn_view``)."""
 
     def __init__(self, part: NodePartition, edge_index, backend, keep=None):
         self.part, self.backend, n = part, backend, part.num_nodes
@@ -368,10 +370,10 @@ class PartitionedGraph:
         self.num_nodes = self.n_out = part.n_local
         self.n_table = part.world * part.n_max
         self.comm = part.comm
-        self.fwd, self.bwd = self.by_dst, self.by_src
         self._weights = {}
         self._default_keep = keep
         gw = self.gcn_weights(keep)
+        self.fwd, self.bwd = gw.dst or self.by_dst, gw.src or self.by_src      # (the composable form's pair: CSR + its weights)
         self.w_fwd, self.w_bwd = gw.w_dst, gw.w_src
 
     def gcn_weights(self, keep=None):
@@ -384,10 +386,21 @@ class PartitionedGraph:
             return hit[1]
         w_edge, self_w = self.backend.gcn_norm(self.edge_index, self.part.num_nodes, keep)
         w = torch.cat([w_edge, self_w])
-        out = GcnWeights(self.backend.permute(self.by_dst, w[self._entry_in]),
-                         self.backend.permute(self.by_src, w[self._entry_out]), None)
+        w_dst = self.backend.permute(self.by_dst, w[self._entry_in])
+        w_src = self.backend.permute(self.by_src, w[self._entry_out])
+        kept = getattr(self.backend, "kept_csr", None)
+        if keep is not None and kept is not None and min(self.by_dst.nnz, self.by_src.nnz) >= _kept_floor():
+            kd, ks = kept(self.by_dst, w_dst), kept(self.by_src, w_src)
+            out = GcnWeights(kd.w, ks.w, None, dst=kd, src=ks)
+        else:
+            out = GcnWeights(w_dst, w_src, None)
         self._weights["kept" if keep is not None else "plain"] = (key, out, keep)   # (keep kept alive: id() stays unique)
         return out
+
+
+def _kept_floor():
+    from . import graph
+    return graph.KEPT_CSR_MIN_EDGES
 
 
 class _PartSpmm(torch.autograd.Function):
@@ -427,7 +440,8 @@ def gcn_conv_partitioned(x_local, weight, bias, pg: PartitionedGraph, backend, r
     """``dropout(relu(A_hat[local rows] @ gather(x_local W^T) + b))`` -> ``[n_local, out]`` (composable form)."""
     gw = gw if gw is not None else pg.gcn_weights()
     xw = backend.linear(x_local, weight)                                     # transform BEFORE the exchange:
-    return part_spmm(xw, pg.comm, backend, pg.by_dst, pg.by_src, gw.w_dst, gw.w_src, bias=bias, relu=relu, drop=drop)
+    return part_spmm(xw, pg.comm, backend, gw.dst or pg.by_dst, gw.src or pg.by_src, gw.w_dst, gw.w_src, bias=bias, relu=relu,
+                     drop=drop)
 
 
 class _RelSide:
@@ -582,6 +596,11 @@ class HipBackend:
         return csr.permute_f32(values.to(torch.float32).contiguous())
 
     @staticmethod
+    def kept_csr(csr, w):
+        from .graph import KeptCSR
+        return KeptCSR.of_weights(csr, w)
+
+    @staticmethod
     def gcn_norm(edge_index, num_nodes, keep):
         from .graph import graph_of
         return graph_of(edge_index, num_nodes).gcn_norm_raw(keep)
@@ -628,7 +647,8 @@ class HipBackend:
 
     @staticmethod
     def table_conv(table, bias, pg, gw, relu=False, drop=None):
-        return _TableConv.apply(table, bias, pg.comm, HipBackend, pg.by_dst, pg.by_src, gw.w_dst, gw.w_src, relu, drop)
+        return _TableConv.apply(table, bias, pg.comm, HipBackend, gw.dst or pg.by_dst, gw.src or pg.by_src, gw.w_dst, gw.w_src,
+                                relu, drop)
 
     @staticmethod
     def spmm_epilogue(csr, w, table, n_out, addend, bias, relu, drop):

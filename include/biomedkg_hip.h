@@ -67,6 +67,13 @@ int bkg_gather_f32(const float* src, const int32_t* idx, float* out, int64_t n, 
  * w_out_* [nnz] (the first counts[0] / counts[1] entries are meaningful; no host read); dis [n], flag_tmp / offs_tmp
  * [2 nnz]: scratch. */
 int64_t bkg_gcn_view_workspace_bytes(int64_t nnz);
+/* The same cut for ONE CSR that already carries the view's weights (a node-partitioned graph's CSRs: columns are table
+ * slots, the self loops are entries, weights from the global degrees -- biomedkg_amd/partition.py): the entries whose
+ * weight is not zero as a CSR of its own over the same rows. */
+int64_t bkg_csr_compact_workspace_bytes(int64_t nnz);
+int bkg_csr_compact(const int32_t* rowptr, const int32_t* col, const float* w, int64_t n_rows, int64_t nnz, int32_t* flag_tmp,
+                    int32_t* offs_tmp, int32_t* rowptr_out, int32_t* col_out, float* w_out, int32_t* count, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 int bkg_gcn_view(const int32_t* rowptr_d, const int32_t* col_d, const int32_t* perm_d, const int32_t* row_d,
                  const int32_t* rowptr_s, const int32_t* col_s, const int32_t* perm_s, const int32_t* row_s, const uint8_t* keep,
                  int64_t n_nodes, int64_t nnz, int32_t* flag_tmp, int32_t* offs_tmp, float* dis, float* self_w,

@@ -11,10 +11,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def test_partitioned_gcn_and_rgcn_world1_match_fused_layers():
-    from biomedkg_amd import ops, partition as P, synthetic
+@pytest.mark.parametrize("kept_views", [False, True])
+def test_partitioned_gcn_and_rgcn_world1_match_fused_layers(monkeypatch, kept_views):
+    """``kept_views``: the dropout_edge view as CSRs of its own on BOTH sides (graph.KEPT_CSR_MIN_EDGES = 0: the
+    partitioned graph cuts them out of its weighted CSRs, the whole graph builds them from the mask)."""
+    from biomedkg_amd import graph as G, ops, partition as P, synthetic
     from biomedkg_amd.graph import graph_of, rel_graph_of
     from biomedkg_amd.model.encoder import GCNEncoder, RGCN
+    monkeypatch.setattr(G, "KEPT_CSR_MIN_EDGES", 0 if kept_views else 1 << 60)
     g = synthetic.primekg_like(3000, 60_000, 8, seed=2)
     ei, et, n = g["edge_index"].to(DEV), g["edge_type"].to(DEV), g["num_nodes"]
     torch.manual_seed(0)
@@ -25,6 +29,10 @@ def test_partitioned_gcn_and_rgcn_world1_match_fused_layers():
     enc = GCNEncoder(64, 32, 32, 2).to(DEV).eval()
     x = torch.randn(n, 64, device=DEV)
     pg = P.PartitionedGraph(part, ei, P.HipBackend, keep=keep)
+    assert isinstance(pg.fwd, G.KeptCSR) == kept_views and isinstance(pg.bwd, G.KeptCSR) == kept_views
+    if kept_views:      # kept edges that are no self loops + one unit loop per node, on both sides
+        live = int((keep & (ei[0] != ei[1])).sum()) + n
+        assert int(pg.fwd.count) == live == int(pg.bwd.count)
     out_p = P.gcn_encoder_partitioned(enc, x, pg, P.HipBackend)
     out_p.pow(2).sum().backward()
     grads_p = [p.grad.clone() for p in enc.parameters()]
@@ -104,11 +112,14 @@ def test_partitioned_training_losses_world1_match_the_modules():
         torch.testing.assert_close(a, p.grad, rtol=2e-3, atol=1e-4)
 
 
-def test_partitioned_step_world1_in_bf16_mode_runs_the_fused_views_path():
+@pytest.mark.parametrize("kept_views", [False, True])
+def test_partitioned_step_world1_in_bf16_mode_runs_the_fused_views_path(monkeypatch, kept_views):
     """bf16 mode at a size that engages the side-by-side GGD views and the bf16 tables: the partitioned losses and
     gradients (exchange degenerate at one rank) against the whole-graph modules in the same mode, same permutation,
-    same edge mask, same negatives."""
-    from biomedkg_amd import ops, partition as P, rand as R, sampling, synthetic
+    same edge mask, same negatives.  ``kept_views``: the partitioned side propagates over the view's own CSRs, the module
+    over the masked weights."""
+    from biomedkg_amd import graph as G, ops, partition as P, rand as R, sampling, synthetic
+    monkeypatch.setattr(G, "KEPT_CSR_MIN_EDGES", 1 << 60)
     from biomedkg_amd.gcl_module import GGDModule
     from biomedkg_amd.kge_module import KGEModule
     g = synthetic.primekg_like(6000, 120_000, 8, seed=6)
@@ -126,9 +137,12 @@ def test_partitioned_step_world1_in_bf16_mode_runs_the_fused_views_path():
         orig = ops.gcn_conv_views
         ops.gcn_conv_views = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
         try:
+            G.KEPT_CSR_MIN_EDGES = 0 if kept_views else 1 << 60
             loss_p = P.ggd_loss_partitioned(gcl.model, x, pg, P.HipBackend, perm, keep=keep)
+            assert isinstance(pg.gcn_weights(keep).dst, G.KeptCSR) == kept_views
         finally:
             ops.gcn_conv_views = orig
+            G.KEPT_CSR_MIN_EDGES = 1 << 60
         assert len(calls) == 4                                           # the fused side-by-side path was taken
         loss_p.backward()
         grads_p = [p.grad.clone() for p in gcl.model.parameters()]
@@ -572,8 +586,11 @@ def test_bench_partitioned_on_four_and_eight_ranks_of_one_device(ranks):
     common = ["--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"]
     lines = {}
     for n in (1, ranks):
+        # the N-rank run cuts its dropout_edge views' own CSRs (a 300 k-edge graph stays below the product's floor), the
+        # one-rank run keeps the masked weights: the check losses must not tell
+        run_env = dict(env, BKG_KEPT_CSR_MIN_EDGES="0") if n > 1 else env
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--mode", "partition"] + common,
-                             env=env, capture_output=True, text=True, timeout=1500)
+                             env=run_env, capture_output=True, text=True, timeout=1500)
         assert out.returncode == 0, out.stderr[-3000:]
         got = [l for l in out.stdout.splitlines() if l.startswith("{")]
         assert len(got) == 1, out.stdout[-2000:]
