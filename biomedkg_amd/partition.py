@@ -833,6 +833,10 @@ class TripletShare:
             h_loc, t_loc = part.is_local(index[0]), part.is_local(index[1])
             own = torch.nonzero(h_loc).squeeze(1)
             foreign = torch.nonzero(t_loc & ~h_loc).squeeze(1)
+            # a static set (the positives): each range stored in (relation, tail) order -- the scorer then reads the ids
+            # in place (their relation order is the identity), consecutive triplets share or neighbour a tail row, and the
+            # tail half of a node's incidence list is a few runs of consecutive records (ops._SortedTriplets on one GPU)
+            own, foreign = (sel[torch.argsort(types[sel] * part.num_nodes + index[1][sel], stable=True)] for sel in (own, foreign))
             order = torch.cat([own, foreign])
             index, types, n_own = index[:, order], types[order], int(own.numel())
         self.part, self.n_own = part, int(n_own)
