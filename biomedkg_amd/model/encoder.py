@@ -101,8 +101,12 @@ class GCNEncoder(_Stack):
     def views_ok(self, n_rows, views=2):
         """Can ``views`` inputs over one graph go through the stack side by side (``forward_views``)?"""
         layers = self.graph_layers
-        return (len(layers) >= 2 and all(ops.views_ok(n_rows, l.in_channels, l.out_channels, views) for l in layers[1:])
-                and ops.views_ok(n_rows, 256, layers[0].out_channels, views))
+        if len(layers) < 2:
+            return False
+        if ops.bf16_storage():
+            return (all(ops.views_ok(n_rows, l.in_channels, l.out_channels, views) for l in layers[1:])
+                    and ops.views_ok(n_rows, 256, layers[0].out_channels, views))
+        return all(ops.views_ok_f32(n_rows, l.in_channels, l.out_channels, views) for l in layers)     # (exact mode)
 
     def forward_views(self, xw2, edge_index, views, edge_keep=None, out_bf16=False):
         """The stack over ``views`` inputs of the SAME graph at once (bf16 mode; GGD's positive + corrupted pass).

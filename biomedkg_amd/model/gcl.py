@@ -36,7 +36,7 @@ class DGI(torch.nn.Module):
             x = ops.cached_bf16(x)
         r = _rand.current()
         enc = self.encoder
-        if (getattr(r, "device_draws", False) and ops.bf16_storage() and x.is_cuda and x.dim() == 2 and not x.requires_grad
+        if (getattr(r, "device_draws", False) and x.is_cuda and x.dim() == 2 and not x.requires_grad
                 and hasattr(enc, "forward_views") and x.size(1) % 256 == 0 and enc.views_ok(x.size(0))):
             # both passes side by side, the first layer's product shared (see GGD._views_ok)
             xw = ops.xw_table(x, enc.graph_layers[0].lin.weight)
@@ -120,7 +120,7 @@ class GGD(torch.nn.Module):
         corruption is a row permutation, ``x[perm] W^T = (x W^T)[perm]`` -- the first layer's product, so they run
         side by side through every kernel (``GCNEncoder.forward_views``).  Same arithmetic per view."""
         enc = self.encoder
-        return (getattr(r, "device_draws", False) and ops.bf16_storage() and x.is_cuda and x.dim() == 2 and not x.requires_grad
+        return (getattr(r, "device_draws", False) and x.is_cuda and x.dim() == 2 and not x.requires_grad
                 and hasattr(enc, "forward_views") and x.size(1) % 256 == 0 and enc.views_ok(x.size(0)))
 
     def _forward_views(self, x, edge_index, edge_keep, r):
@@ -135,7 +135,7 @@ class GGD(torch.nn.Module):
         for layer in self.mlp[:-1]:
             h = ops.linear(h, layer.weight, layer.bias, act=ops.ACT_RELU)
         last = self.mlp[-1]
-        if ops.rowsum_linear_ok(h, last.weight):
+        if ops.bf16_storage() and ops.rowsum_linear_ok(h, last.weight):      # (the exact mode keeps the reference's product + sum)
             s = ops.linear_rowsum(h, last.weight, last.bias).view(n, 2)      # (W h + b).sum(1) = h . W.sum(0) + b.sum()
         else:
             s = ops.linear(h, last.weight, last.bias).sum(1).view(n, 2)

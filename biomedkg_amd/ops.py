@@ -805,6 +805,8 @@ class _XwTable(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        if not bf16_storage():          # exact mode: an fp32 table (each row's product does not depend on where the row sits)
+            return gemm(x, weight, trans_b=True)
         return gemm(x, weight, trans_b=True, out_dtype=torch.bfloat16)
 
     @staticmethod
@@ -856,6 +858,66 @@ def views_ok(n_rows, d_in, d_out, views=2):
     """Shapes for which V views of one graph run through a conv layer as ONE launch per kernel (bf16 mode)."""
     return (bf16_storage() and n_rows >= 4096 and d_in % 256 == 0 and d_out % 256 == 0 and _bf16_ok(views * d_out)
             and _bf16_operand_ok(views * n_rows, d_out, d_in) and _bf16_operand_ok(views * n_rows, d_in, d_out))
+
+
+FP32_VIEWS = __import__("os").environ.get("BKG_FP32_VIEWS", "1") != "0"
+
+
+def views_ok_f32(n_rows, d_in, d_out, views=2):
+    """Exact-fp32 mode: V views of one graph through a conv layer side by side (``_GcnConvViewsF32``) -- the row widths the
+    fp32 aggregation kernels take (``views * d_out / 4`` sixteen-byte pieces, in column parts above 1 KB rows)."""
+    d = views * d_out
+    return (FP32_VIEWS and _PRECISION == 0 and n_rows >= 4096 and d_in % 4 == 0 and d % 16 == 0
+            and (d // 4 in (4, 8, 16, 32, 64, 96, 128, 192, 256) or (d % 64 == 0 and d // 16 in (4, 8, 16, 32, 64))))
+
+
+class _GcnConvViewsF32(torch.autograd.Function):
+    """``_GcnConvViews`` in the exact-fp32 mode (whole graphs and mini-batches on one GPU): the V views' rows of a node side
+    by side in fp32 tables -- one product over ``[V N, in]`` rows, one aggregation launch over ``V * out``-wide rows (its
+    index / weight stream read once), one gate and one pair of gradient products per layer instead of V.  Every row's
+    arithmetic is what the one-view layer does to it (the products are row-independent, the aggregation sums a row's
+    entries column by column), so the corrupted view's first product ``x[perm] W^T = (x W^T)[perm]`` is shared exactly."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias, graph: Graph, gw: GcnWeights, relu, drop, views, is_table):
+        n, n_table, comm = _dims(graph)
+        if comm is not None:
+            raise ValueError("the fp32 side-by-side layer runs whole graphs (a partitioned exact-mode step keeps one view per pass)")
+        x2 = _f32c(x2)
+        if is_table:
+            table = x2
+        else:
+            d_in, d_out = weight.size(1), weight.size(0)
+            table = gemm(x2.view(views * n, d_in), weight, trans_b=True).view(n, views * d_out)
+        c = _view_csr(gw, "dst") or graph.by_dst
+        out = spmm(c.rowptr, c.col, gw.w_dst, table, n, self_w=gw.self_w, bias=bias.repeat(views), relu=relu, drop=drop,
+                   split=c.split)
+        ctx.graph, ctx.gw, ctx.relu, ctx.views, ctx.is_table = graph, gw, relu, views, is_table
+        ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
+        ctx.gated = relu or ctx.scale != 1.0
+        ctx.keep = _plain_dropout_keep(relu, drop)
+        ctx.save_for_backward(None if is_table else x2, weight, out if ctx.gated else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, weight, out = ctx.saved_tensors
+        g, gw, v = ctx.graph, ctx.gw, ctx.views
+        n, n_table, _ = _dims(g)
+        dout = _f32c(dout)
+        if ctx.gated:
+            dout = _gate(dout, out, ctx.scale) if ctx.relu else dout * ctx.keep * ctx.scale
+        d_out = dout.size(1) // v
+        db = colsum(dout.view(v * n, d_out)) if ctx.needs_input_grad[2] else None       # the views share the bias
+        c = _view_csr(gw, "src") or g.by_src
+        dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split)
+        if ctx.is_table:
+            return dxw, None, db, None, None, None, None, None, None
+        d_in = weight.size(1)
+        rows = dxw.view(v * n, d_out)
+        dx = gemm(rows, weight).view(n, v * d_in) if ctx.needs_input_grad[0] else None
+        dw = gemm(rows, x2.view(v * n, d_in), trans_a=True) if ctx.needs_input_grad[1] else None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class _GcnConvViews(torch.autograd.Function):
@@ -934,6 +996,8 @@ class _GcnConvViews(torch.autograd.Function):
 
 def gcn_conv_views(x2, weight, bias, graph, gw, views, relu=False, drop=None, hidden=False, is_table=False):
     L.require_cuda(x2, weight, bias)
+    if not bf16_storage():          # exact mode: fp32 tables throughout (``hidden`` asks for bf16 results: not here)
+        return _GcnConvViewsF32.apply(x2, weight, bias, graph, gw, relu, drop, views, is_table)
     return _GcnConvViews.apply(x2, weight, bias, graph, gw, relu, drop, hidden, views, is_table)
 
 
