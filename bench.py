@@ -1290,7 +1290,9 @@ def main():
                        "identities": "bf16 mode evaluates two expressions of the reference in an algebraically equal form, "
                                      "nothing is skipped: the corrupted view's first product x[perm] W^T as (x W^T)[perm], "
                                      "and GGD's head (W h + b).sum(1) as h . W.sum(0) + b.sum() (every gradient included; "
-                                     "the exact-fp32 mode keeps the reference's form).  Both modes: the negatives' relation "
+                                     "the exact-fp32 mode shares the first product too -- there the identity holds bit for "
+                                     "bit, rows of a product do not depend on their position -- and keeps the reference's "
+                                     "head).  Both modes: the negatives' relation "
                                      "ids -- the reference's edge_type.repeat(k)[randperm] -- are delivered grouped by relation; "
                                      "the negatives they are paired with come out of the sampler in exchangeable order, so the "
                                      "typed negatives have the same distribution (ms_per_step_shuffled_neg_types times the "
