@@ -31,12 +31,19 @@ __global__ __launch_bounds__(512) void gemm_xw32_kernel(Xw32Args g, GemmEpilogue
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, kh = lane >> 5;
   const int n0 = wave * 32;
   const int m_tiles = (g.M + X32_BM - 1) / X32_BM, stride = gridDim.x;
+  // Work items: the tiles of the full rounds, then -- when the last round would leave more than half of the blocks idle --
+  // its tiles as two 32-row halves each (803 tiles on 256 blocks: 3 rounds + 35 tiles -> 70 halves: 3.5 tile-times
+  // instead of 4).  Item t -> first row and whether it is a half (block-uniform).
+  const int full_items = (m_tiles / stride) * stride, rest = m_tiles - full_items;
+  const bool split_rest = 2 * rest <= stride;
+  const int n_items = full_items + (split_rest ? 2 * rest : rest);
+  auto row0_of = [&](int t) { return t < full_items || !split_rest ? t * X32_BM : full_items * X32_BM + (t - full_items) * 32; };
 
   // DMA pieces of this lane: rows wave * 8 + j of a tile (one row per wave-instruction), slot lane
   int t_issue = blockIdx.x;
   auto issue = [&](int slot) {
     unsigned char* base = ring + slot * X32_STAGE + wave * (8 * 1024);
-    const int m0 = t_issue * X32_BM;
+    const int m0 = row0_of(t_issue);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int row = wave * 8 + j;
@@ -69,7 +76,9 @@ __global__ __launch_bounds__(512) void gemm_xw32_kernel(Xw32Args g, GemmEpilogue
   const float bias = ep.bias ? ep.bias[n0 + l31] : 0.f;
 
   int slot = 0;
-  for (int t = blockIdx.x; t < m_tiles; t += stride) {
+  for (int t = blockIdx.x; t < n_items; t += stride) {
+    const bool half = split_rest && t >= full_items;          // a 32-row item: the second row block is not computed
+    const int m_row0 = row0_of(t), m_end = min(g.M, m_row0 + (half ? 32 : X32_BM));
     // this wave's DMAs of tile t have landed (older stores too); everyone's after the barrier, and the other slot is free
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -82,14 +91,24 @@ __global__ __launch_bounds__(512) void gemm_xw32_kernel(Xw32Args g, GemmEpilogue
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     // A[row][k] sits at row * 1024 + ((k / 4) ^ (row & 31)) * 16 + (k % 4) * 4; row & 31 = l31 for both row blocks
     const unsigned char* arow = tile + l31 * 1024;
+    if (!half) {
 #pragma unroll
-    for (int ks = 0; ks < X32_K / 2; ++ks) {
-      const int k = 2 * ks;                                   // this lane reads k + kh: same 16-byte chunk (k even)
-      const int off = (((k >> 2) ^ l31) << 4) + ((k & 3) + kh) * 4;
+      for (int ks = 0; ks < X32_K / 2; ++ks) {
+        const int k = 2 * ks;                                 // this lane reads k + kh: same 16-byte chunk (k even)
+        const int off = (((k >> 2) ^ l31) << 4) + ((k & 3) + kh) * 4;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float a = *reinterpret_cast<const float*>(arow + j * (32 * 1024) + off);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[ks], acc[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          const float a = *reinterpret_cast<const float*>(arow + j * (32 * 1024) + off);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[ks], acc[j], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < X32_K / 2; ++ks) {
+        const int k = 2 * ks;
+        const int off = (((k >> 2) ^ l31) << 4) + ((k & 3) + kh) * 4;
+        const float a = *reinterpret_cast<const float*>(arow + off);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[ks], acc[0], 0, 0, 0);
       }
     }
     // D = A_tile x W: lane holds column n0 + l31 of rows (r & 3) + 8 (r >> 2) + 4 kh
@@ -97,8 +116,8 @@ __global__ __launch_bounds__(512) void gemm_xw32_kernel(Xw32Args g, GemmEpilogue
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = t * X32_BM + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row < g.M) {
+        const int row = m_row0 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < m_end) {
           float v = ep.alpha * acc[j][r] + bias;
           if (ep.act == 1) v = fmaxf(v, 0.f);
           else if (ep.act == 2) v = v > 0.f ? v : expm1f(v);

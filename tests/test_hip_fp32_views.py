@@ -93,3 +93,25 @@ def test_fp32_views_train_with_dropout_and_augmentation():
             opt.step()
             losses.append(float(loss.detach()))
     assert all(torch.isfinite(torch.tensor(losses))) and min(losses[-3:]) < losses[0]
+
+
+@pytest.mark.parametrize("m", [16384, 16385 + 64 * 3, 51_402, 25_691, 16384 + 64 * 130 + 7, 130_000])
+def test_tall_fp32_products_with_a_split_last_round(m):
+    """``gemm_xw32_kernel``: when the last round of 64-row tiles would leave more than half of the 256 blocks idle its tiles
+    go out as 32-row halves (51 k rows: 803 tiles = 3 rounds + 35 -> 70 halves).  Every row against fp64, whatever item
+    computed it; trans_w both ways; with bias + ReLU."""
+    from biomedkg_amd import ops
+    g = torch.Generator().manual_seed(m)
+    a = torch.randn(m, 256, generator=g).to(DEV)
+    w = (torch.randn(256, 256, generator=g) * 0.1).to(DEV)
+    b = torch.randn(256, generator=g).to(DEV)
+    ref = a.double() @ w.double().t()
+    got = ops.gemm(a, w, trans_b=True)
+    torch.testing.assert_close(got.double(), ref, rtol=1e-5, atol=1e-4)
+    got2 = ops.gemm(a, w.t().contiguous())
+    assert torch.equal(got, got2) or float((got - got2).abs().max()) < 1e-4
+    lin = ops.linear(a, w, b, act=ops.ACT_RELU)
+    torch.testing.assert_close(lin.double(), (ref + b.double()).relu(), rtol=1e-5, atol=1e-4)
+    # rows of a product do not depend on where they sit (what the shared first product of the views relies on)
+    perm = torch.randperm(m, device=DEV)
+    assert torch.equal(ops.gemm(a[perm].contiguous(), w, trans_b=True), got[perm])
