@@ -2,7 +2,7 @@
 """Differential sweep of round 4's structure changes: random graphs (isolated nodes, self loops, duplicate edges, empty
 relations, hubs), a few Adam steps of the GGD step (augmentation always on) and of the KGE step (R-GCN + DistMult / TransE),
 WITH the dropout_edge views' own CSRs (graph.KeptCSR), the planted relation order and the sorted frame of the positives
-against the same build with all three switched off.  Exact-fp32 mode, fixed draws: every step's losses agree to 2e-5;
+against the same build with all three switched off.  Exact-fp32 mode, fixed draws: the first step's losses agree to 2e-6, every step's to 2e-4;
 the parameters after four Adam steps to 5e-3 (Adam divides by sqrt(v): an entry whose tiny gradient changes sign with the
 summation order moves by the learning rate either way).
 python scripts/fuzz_views_frames.py [cases]   (MI355X)"""
@@ -67,10 +67,14 @@ for it in range(cases):
         out[on] = (losses, [p.detach().clone() for p in list(gcl.model.parameters()) + list(kge.model.parameters())])
     ops.set_deterministic(False)
     (la, pa), (lb, pb) = out[False], out[True]
-    dl = max(abs(a - b) / max(abs(a), 1e-6) for x, y in zip(la, lb) for a, b in zip(x, y))
+    rel = [max(abs(a - b) / max(abs(a), 1e-6) for a, b in zip(x, y)) for x, y in zip(la, lb)]     # per step
+    dl, d1 = max(rel), rel[0]
     dp = max(float((a - b).norm() / a.norm().clamp_min(1e-12)) for a, b in zip(pa, pb))
-    flag = "" if (dl <= 2e-5 and dp <= 5e-3) else "   <-- MISMATCH"
+    # the first step differs by summation order alone; later steps carry what Adam makes of it (it divides by sqrt(v): an
+    # entry whose tiny gradient changes sign with the order moves by the learning rate either way)
+    flag = "" if (d1 <= 2e-6 and dl <= 2e-4 and dp <= 5e-3) else "   <-- MISMATCH"
     bad += bool(flag)
-    print(f"case {it}: n={n} e={e} r={r} {dec}: loss rel diff {dl:.2e}, param rel diff {dp:.2e}{flag}", flush=True)
+    print(f"case {it}: n={n} e={e} r={r} {dec}: loss rel diff first step {d1:.2e}, worst of 4 {dl:.2e}, param rel diff {dp:.2e}{flag}",
+          flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
