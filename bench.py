@@ -4,7 +4,8 @@
     python bench.py --gpus 1 --steps 10 --warmup 3
     python bench.py --gpus N --steps K --warmup W          # starts its own N ranks (launch_ranks), one per GPU, RCCL
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W   # ... or takes the ranks an outer launcher started
+        --master-port P bench.py --gpus N --steps K --warmup W   # ... under an outer launcher: its rank 0 does the same
+                                                                  # (take_over_from_outer_launcher), the other workers leave
 
 One *step* = one GCL training step (GGD, the reference's default ``model_name``; 4-layer GCN
 768->256) + one KGE training step (4-layer R-GCN d=256 + DistMult, ``neg_ratio`` negatives per
@@ -1012,10 +1013,38 @@ def launch_ranks(args):
     raise SystemExit(max(abs(c) for c in bad) if bad else 0)
 
 
+# what an outer launcher (torch.distributed.run) puts into its workers' environment
+_OUTER_RANK_KEYS = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                    "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT")
+
+
+def take_over_from_outer_launcher(args):
+    """``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` (the driver's SCALE form): N copies of this
+    file arrive with RANK / WORLD_SIZE set.  Running the step in THOSE processes would mean the eager partitioned step --
+    host-bound from four ranks on (3.6-5 ms to enqueue against 1.4-2.8 ms of kernels) -- with no way back if the graphed
+    form failed: a rank cannot restart itself.  So the outer launcher's rank 0, which has not touched the GPU (nothing
+    before this point does), becomes bench.py's OWN launcher exactly as if it had been started bare -- ``launch_ranks``:
+    N fresh ranks on a rendezvous port of their own, the graphed sub-steps first, the eager step if that attempt fails
+    or stalls -- and relays its rank 0's single JSON line; the outer launcher's other workers leave at once with exit
+    code 0.  ``BKG_BENCH_OUTER_RANKS=1`` keeps the outer launcher's processes as the ranks (the eager step, or the
+    graphed one with ``BKG_BENCH_PARTITION_GRAPH=1``)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {os.environ.get('WORLD_SIZE')} rank(s)")
+    if int(os.environ.get("RANK", "0")) != 0:
+        raise SystemExit(0)
+    for key in list(os.environ):
+        if key in _OUTER_RANK_KEYS or key.startswith("TORCHELASTIC_"):
+            del os.environ[key]
+    launch_ranks(args)                              # does not return
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)                          # does not return
+    if (args.gpus > 1 and os.environ.get("BKG_BENCH_SPAWNED") != "1" and os.environ.get("BKG_BENCH_OUTER_RANKS") != "1"
+            and args.mode in ("auto", "partition")):
+        take_over_from_outer_launcher(args)         # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

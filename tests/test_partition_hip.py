@@ -314,6 +314,36 @@ def test_collectives_of_the_partitioned_step_over_a_one_rank_rccl_group():
     assert line["scaling"] == "strong" and line["value"] > 0 and line["n_gpus"] == 1
 
 
+@pytest.mark.parametrize("keep_outer_ranks", [False, True])
+def test_bench_under_torch_distributed_run(keep_outer_ranks):
+    """The other form the driver may use: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...``.  By default the outer launcher's rank 0 becomes bench.py's own
+    launcher (graphed sub-steps first over RCCL, eager fallback; here: gloo on the one GPU) and the other worker leaves;
+    ``BKG_BENCH_OUTER_RANKS=1`` keeps the outer launcher's processes as the ranks.  Either way: exit code 0, ONE JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BKG_BENCH_ONE_DEVICE="1", BKG_BENCH_BACKEND="gloo")
+    if keep_outer_ranks:
+        env["BKG_BENCH_OUTER_RANKS"] = "1"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo" and line["scaling"] == "strong"
+    assert line["exchange"] is not None and line["value"] > 0
+
+
 def test_bench_starts_its_own_ranks():
     """``python3 bench.py --gpus 2`` with NO launcher around it (the driver's SCALE command form; the reference's users
     run one command too: train_gcl.py:63-68, Lightning starts the ranks): the parent spawns two fresh rank processes
