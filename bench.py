@@ -986,7 +986,7 @@ def launch_ranks(args):
     Node-partitioned runs over RCCL try the GRAPHED sub-steps first (BKG_BENCH_PARTITION_GRAPH=1: every sub-step one
     hipGraph replay -- an eager partitioned step costs the host 3.6-5 ms to enqueue, more than a rank's kernels take from
     four ranks on); captured collectives have only ever run on a one-rank RCCL group here (no multi-GPU box), so if that
-    attempt fails or yields nothing within BKG_BENCH_GRAPH_ATTEMPT_S (default 420 s) the ranks are started again with
+    attempt fails or yields nothing within BKG_BENCH_GRAPH_ATTEMPT_S (default 300 s) the ranks are started again with
     the eager step, and the line says which form ran (``exchange.graphed_sub_steps``)."""
     n = args.gpus
     one_device = os.environ.get("BKG_BENCH_ONE_DEVICE") == "1"
@@ -997,7 +997,7 @@ def launch_ranks(args):
     backend = os.environ.get("BKG_BENCH_BACKEND", "nccl")
     try_graphs = ("BKG_BENCH_PARTITION_GRAPH" not in os.environ and backend == "nccl" and args.mode in ("auto", "partition"))
     if try_graphs:
-        limit = float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "420"))
+        limit = float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "300"))
         out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "1"}, limit)
         if all(c == 0 for c in codes) and any(l.startswith("{") for l in out.splitlines()):
             sys.stderr.write(note)
