@@ -324,34 +324,88 @@ def build_partitioned_steps(args, rank, world, dev):
                   and torch.distributed.get_backend() == "nccl")
     graph_stats = {"captured": 0, "replayed": 0, "eager": 0, "refused": None}
 
-    def make(params, loss_fn, draw_key):
+    def make(params, loss_fn, draw_key, defer_update=False):
+        """``defer_update`` (graphed mode, the KGE sub-step): its 32.5 MB gradient bucket -- the one message of the step that
+        does not shrink with P -- is reduced on a stream and a communicator of its own WHILE the next GGD sub-step runs, and
+        the update (scale, clip, Adam) lands at the top of this sub-step's next call, before its parameters are read again:
+        three graphs (loss + backward + pack | all-reduce | update) instead of one, the arithmetic of the loop unchanged
+        (what ``make_step(overlap=True)`` does for the replicated runs)."""
         from biomedkg_amd import _lib as L
         from biomedkg_amd.graph import as_captured
         opt = torch.optim.Adam(params, lr=1e-3, fused=True)
         if graph_mode:
             from biomedkg_amd.graphs import make_capturable
             opt = make_capturable(opt)
-        bucket = GradBucket(params, world)
+        defer = bool(defer_update and graph_mode and os.environ.get("BKG_BENCH_DEFER_UPDATE", "1") != "0")
+        group = torch.distributed.new_group() if defer else None      # (every rank makes it: the same call order everywhere)
+        bucket = GradBucket(params, world, group=group)
+        defer = defer and bucket.live
         epoch = torch.zeros(1, dtype=torch.int32, device=dev)
         graphs, losses = {}, {}
         side = torch.cuda.Stream() if graph_mode else None
-        state = {"on": graph_mode}
+        comm_stream = torch.cuda.Stream() if defer else None
+        state = {"on": graph_mode, "pending": False}
+        tail = {}                                       # the deferred update's two graphs: "reduce", "update"
 
-        def body(key):
+        def body(key, whole=True):
             if graph_mode:
                 epoch.add_(1)
             opt.zero_grad(set_to_none=True)
             loss = loss_fn(key)
             loss.backward()
-            bucket.all_reduce()
-            clip_adam_step(opt, 1.0)
+            if whole:
+                bucket.all_reduce()
+                clip_adam_step(opt, 1.0)
+            else:
+                bucket.pack()                           # (the reduce and the update follow as graphs of their own)
             return loss
+
+        def reduce_body():
+            torch.distributed.all_reduce(bucket._flat, group=group)
+
+        def update_body():
+            bucket._flat.div_(world)
+            for p_, v_ in zip(bucket.params, bucket._views):
+                p_.grad = v_                            # the update reads the averaged bucket in place
+            clip_adam_step(opt, 1.0)
+
+        def run_tail(name, fn, stream):
+            """One of the deferred update's two pieces on ``stream``: eagerly the first time, captured the second, replayed
+            from then on (the same ladder as the sub-steps' own graphs)."""
+            with torch.cuda.stream(stream):
+                g = tail.get(name)
+                if g is None:
+                    fn()
+                    tail[name] = False                  # seen once: capture next time
+                elif g is False:
+                    torch.cuda.synchronize()
+                    time.sleep(0.5)                     # (the watchdog and the eager collectives just issued: see below)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                        fn()
+                    tail[name] = g
+                    g.replay()
+                else:
+                    g.replay()
+
+        def finish_pending():
+            if not state["pending"]:
+                return
+            state["pending"] = False
+            outer = torch.cuda.current_stream()
+            side.wait_stream(comm_stream)               # the averaged bucket has arrived
+            side.wait_stream(outer)
+            run_tail("update", update_body, side)
+            outer.wait_stream(side)
 
         def step():
             key = draw_key()
             if not state["on"] or step.force_eager:
+                finish_pending()
                 graph_stats["eager"] += 1
                 return body(key)
+            if defer:
+                finish_pending()                        # the previous call's update, before the parameters are read
             L.call("bkg_set_rng_epoch", L.ptr(epoch))
             outer = torch.cuda.current_stream()
             side.wait_stream(outer)
@@ -360,7 +414,7 @@ def build_partitioned_steps(args, rank, world, dev):
                     g = graphs.get(key)
                     if g is None:
                         with as_captured():
-                            loss = body(key).detach().clone()       # this kind's first step, eagerly (it also warms the pools)
+                            loss = body(key, whole=not defer).detach().clone()   # this kind's first step, eagerly (it also warms the pools)
                         torch.cuda.synchronize()
                         # the process group's watchdog thread polls the end events of the eager collectives just issued; let
                         # it retire them before a capture begins (an event query from that thread while this one captures
@@ -371,24 +425,37 @@ def build_partitioned_steps(args, rank, world, dev):
                         g.register_generator_state(shared)
                         try:
                             with as_captured(), torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                                losses[key] = body(key).detach()
+                                losses[key] = body(key, whole=not defer).detach()
                         except Exception as why:                    # noqa: BLE001
                             torch.cuda.synchronize()
                             state["on"] = False
                             graph_stats["refused"] = f"{type(why).__name__}: {why}"[:300]
+                            if defer:                               # the eager step just run stopped at the pack: finish it
+                                bucket.all_reduce_packed()
+                                update_body()
                             opt.zero_grad(set_to_none=True)
                             return loss
                         graphs[key] = g
                         graph_stats["captured"] += 1
+                        if defer:
+                            start_reduce()
                         return loss
                     g.replay()
                     ops.note_graph_replay()
                     graph_stats["replayed"] += 1
+                    if defer:
+                        start_reduce()
                     return losses[key]
             finally:
                 outer.wait_stream(side)
                 L.call("bkg_set_rng_epoch", None)
-        step.finish = lambda: None
+
+        def start_reduce():
+            comm_stream.wait_stream(side)               # the packed bucket is complete
+            run_tail("reduce", reduce_body, comm_stream)
+            state["pending"] = True
+            graph_stats["deferred_updates"] = graph_stats.get("deferred_updates", 0) + 1
+        step.finish = finish_pending
         step.force_eager = False
         return step
 
@@ -445,7 +512,7 @@ def build_partitioned_steps(args, rank, world, dev):
     for p in list(gcl.model.parameters()) + list(kge.model.parameters()):
         p.grad = None
     step_g = make(list(gcl.model.parameters()), ggd_loss, ggd_key)
-    step_k = make(list(kge.model.parameters()), kge_loss, lambda: None)
+    step_k = make(list(kge.model.parameters()), kge_loss, lambda: None, defer_update=True)
     step_g.part = part
     step_g.check_loss = check
     step_g.check_fn = check_losses

@@ -40,18 +40,18 @@ def init_from_env(backend=None):
 class GradBucket:
     """Averages the gradients of ``params`` across ranks with one flat all-reduce per call."""
 
-    def __init__(self, params, world=None):
+    def __init__(self, params, world=None, group=None):
+        """``group``: the process group the all-reduce runs on (a bucket reduced on a stream of its own while another
+        communicator's collectives are in flight -- bench.py's graphed partitioned steps -- needs a group of its own)."""
         self.params = [p for p in params if p.requires_grad]
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.group = group
         self._flat = None
         # (BKG_PARTITION_FORCE_COLLECTIVES=1: a 1-rank group still issues its all-reduce -- functional check of the calls)
         self.live = self.world > 1 or (os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
 
-    def begin(self):
-        """Pack the gradients into the flat bucket and start the all-reduce (asynchronously: the collective runs on
-        the backend's own stream / thread).  ``finish`` must be called before the gradients are used."""
-        if not self.live:
-            return
+    def pack(self):
+        """The gradients copied into the flat bucket (``views``: the bucket seen through each parameter's shape)."""
         for p in self.params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -64,7 +64,14 @@ class GradBucket:
                 self._views.append(self._flat[off:off + g.numel()].view(g.shape))
                 off += g.numel()
         torch._foreach_copy_(self._views, grads)  # one fused pack instead of a copy_ launch per parameter
-        self._work = dist.all_reduce(self._flat, async_op=True)
+
+    def begin(self):
+        """Pack the gradients into the flat bucket and start the all-reduce (asynchronously: the collective runs on
+        the backend's own stream / thread).  ``finish`` must be called before the gradients are used."""
+        if not self.live:
+            return
+        self.pack()
+        self._work = dist.all_reduce(self._flat, async_op=True, group=self.group)
 
     def finish(self):
         """Wait for the collective started by ``begin`` and write the averaged gradients back."""
@@ -78,6 +85,11 @@ class GradBucket:
     def all_reduce(self):
         self.begin()
         self.finish()
+
+    def all_reduce_packed(self):
+        """The all-reduce of a bucket that ``pack`` filled (synchronous on the current stream); ``views`` hold the sums."""
+        if self.live:
+            dist.all_reduce(self._flat, group=self.group)
 
 
 def broadcast_parameters(module, src=0):

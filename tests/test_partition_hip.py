@@ -676,9 +676,9 @@ def test_partitioned_sub_steps_replay_as_hipgraphs_over_rccl():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = {}
-    for mode in ("0", "1"):
-        env = dict(os.environ, BKG_PARTITION_FORCE_COLLECTIVES="1", BKG_BENCH_PARTITION_GRAPH=mode, MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT="29541")
+    for mode in ("0", "1", "1-inline"):
+        env = dict(os.environ, BKG_PARTITION_FORCE_COLLECTIVES="1", BKG_BENCH_PARTITION_GRAPH=mode[0], MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29541", BKG_BENCH_DEFER_UPDATE="0" if mode.endswith("inline") else "1")
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "partition", "--steps",
                               "12", "--warmup", "3", "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"],
                              env=env, capture_output=True, text=True, timeout=900)
@@ -688,10 +688,19 @@ def test_partitioned_sub_steps_replay_as_hipgraphs_over_rccl():
     gs = graphed["exchange"]["graphed_sub_steps"]
     assert eager["exchange"]["graphed_sub_steps"] is None
     assert gs["refused"] is None and gs["captured"] == 3 and gs["replayed"] >= 20        # GGD with / without augmentation, KGE
+    # the KGE sub-step's gradient bucket is reduced on a stream and a communicator of its own under the next GGD sub-step,
+    # its update lands at the top of the next KGE call: one deferred update per KGE step of the graphed form
+    assert gs.get("deferred_updates", 0) >= 12
     assert graphed["exchange"]["host_enqueue_ms_per_step_graphed"] < 0.5 * eager["exchange"]["host_enqueue_ms_per_step"]
-    for line in (eager, graphed):
+    inline = lines["1-inline"]            # the graphed form with the bucket reduced inside the sub-step's own graph
+    assert inline["exchange"]["graphed_sub_steps"].get("deferred_updates", 0) == 0
+    for line in (eager, graphed, inline):
         for key in ("ggd", "kge"):
             assert line["check_loss_after"][key] < line["check_loss"][key], (key, line["check_loss"], line["check_loss_after"])
+    # deferred or inline: the same updates in the same order on the same draws (the replay counter keys them)
+    for key in ("ggd", "kge"):
+        a, b = graphed["check_loss_after"][key], inline["check_loss_after"][key]
+        assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, (key, a, b)
     for key in ("ggd", "kge"):          # the same number of optimizer steps from the same weights, other random draws
         drop_e = eager["check_loss"][key] - eager["check_loss_after"][key]
         drop_g = graphed["check_loss"][key] - graphed["check_loss_after"][key]
