@@ -32,6 +32,11 @@ RGCN_PRODUCTS_MS = 1.35              # grouped / root / weight-gradient products
 GCN_PRODUCTS_MS = 0.8                # x W products + weight gradients of the 4 GCN layers (two views)
 NEG_STRUCT_MS = 0.62                 # the fresh negatives' sampler + incidence structure
 
+# the one message that does not shrink with P: the flat gradient buckets (fp32), all-reduced every step -- the R-GCN + DistMult
+# parameters (4 x (30 + 1) x 256 x 256 + biases + 30 x 256) and the GGD stack's (768 x 256 + 3 x 256 x 256 + 2 MLP layers)
+KGE_GRAD_MB = (4 * (R + 1) * H * H + 4 * H + R * H) * 4 / 1e6
+GGD_GRAD_MB = (768 * H + 3 * H * H + 2 * H * H + 6 * H) * 4 / 1e6
+
 g = synthetic.primekg_like(N, E, R, seed=42)
 ei = g["edge_index"]
 rows_out = []
@@ -94,6 +99,17 @@ for world in (2, 4, 8):
         "scorer: the embedding table, every row (its gradient: nothing, both-owner scoring)": NEG_STRUCT_MS * share * (2 - 1 / world),
     }
     exposed = sum(max(ms(by) - hide.get(name, 0.0), 0.0) for grp in (ggd, kge) for name, by in grp.items())
+    # gradient all-reduce (ring: 2 (P - 1) / P of the bucket per rank; one ring = one link, RCCL's multi-ring forms approach
+    # seven): the GGD bucket is reduced inside its sub-step's graph; the KGE bucket on a stream and communicator of its own
+    # UNDER the next GGD sub-step (bench.py make(defer_update=True)), exposed only where it outlasts that sub-step
+    ring = 2.0 * (world - 1) / world
+    ar_kge_1, ar_kge_7 = ring * KGE_GRAD_MB / LINK_GBS, ring * KGE_GRAD_MB / (LINK_GBS * LINKS)
+    ar_ggd_7 = ring * GGD_GRAD_MB / (LINK_GBS * LINKS)
+    ggd_compute = GGD_MS * share
+    ar_exposed_7 = ar_ggd_7 + max(ar_kge_7 - ggd_compute, 0.0)
+    ar_exposed_1 = ring * GGD_GRAD_MB / LINK_GBS + max(ar_kge_1 - ggd_compute, 0.0)
+    ar_inline_7 = ar_ggd_7 + ar_kge_7                              # (both buckets inside their sub-steps' graphs: round 4 before)
+    exposed += ar_exposed_7
     as_coded = comp + exposed
     interleaved = max(comp, t7) + 0.05                        # the two sub-steps on two streams: each hides the other's waits
     single = GGD_MS + KGE_MS
@@ -101,12 +117,18 @@ for world in (2, 4, 8):
     fr_out = max(r_ / (N - n_) for r_, n_ in zip(recv["out"], rows))
     print(f"| {world} | {min(rows)}..{max(rows)} | {waste:.2f} | {fr_in:.2f} / {fr_out:.2f} | {worst:.0f} ({worst_old3:.0f}; {old2:.0f}) | "
           f"{t1:.2f} .. {t7:.2f} | {comp:.2f} | {exposed:.2f} | {as_coded:.2f} .. {interleaved:.2f} | "
-          f"{single / as_coded:.1f}x .. {single / interleaved:.1f}x |")
+          f"{single / as_coded:.1f}x .. {single / interleaved:.1f}x |   grad all-reduce {KGE_GRAD_MB:.1f} + {GGD_GRAD_MB:.1f} MB: KGE bucket "
+          f"{ar_kge_1:.2f} .. {ar_kge_7:.3f} ms (one ring .. seven) under a GGD sub-step of {ggd_compute:.2f} ms: exposed "
+          f"{ar_exposed_1:.2f} .. {ar_exposed_7:.3f} ms (inline: {ar_inline_7:.3f} at seven)")
     rows_out.append({"world": world, "rows_min": min(rows), "rows_max": max(rows), "padded_over_real": waste,
                      "halo_in": fr_in, "halo_out": fr_out, "wire_MB": worst, "wire_MB_round3": worst_old3,
                      "wire_MB_round2": old2, "wire_ms_one_link": t1, "wire_ms_seven_links": t7, "compute_ms": comp,
                      "exposed_ms_as_coded": exposed, "step_ms_as_coded": as_coded, "step_ms_interleaved": interleaved,
                      "speedup_as_coded": single / as_coded, "speedup_interleaved": single / interleaved,
+                     "grad_allreduce": {"kge_MB": KGE_GRAD_MB, "ggd_MB": GGD_GRAD_MB, "kge_ms_one_ring": ar_kge_1,
+                                        "kge_ms_seven_rings": ar_kge_7, "exposed_ms_seven_rings": ar_exposed_7,
+                                        "exposed_ms_one_ring": ar_exposed_1, "inline_ms_seven_rings": ar_inline_7,
+                                        "ggd_substep_compute_ms": ggd_compute},
                      "bytes": {"ggd": {k: v / 1e6 for k, v in ggd.items()}, "kge": {k: v / 1e6 for k, v in kge.items()}}})
 if JSON_OUT:
     json.dump({"single_gpu_ms": {"ggd": GGD_MS, "kge": KGE_MS}, "link_GBs": LINK_GBS, "links": LINKS, "ranks": rows_out},
