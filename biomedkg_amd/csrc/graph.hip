@@ -5,12 +5,33 @@
 // follows has a fixed, input-determined order (bitwise reproducible; no atomics anywhere here).
 #include <cstring>
 
+#include "common.h"
+
+// rocPRIM's one-sweep radix sort zeroes its digit histograms and look-back states with hipMemsetAsync, and a memset node of
+// a hipGraph re-executes wrongly on this stack (common.h: stale words from the second replay on; a captured 1.5 M-key
+// radix sort page-faulted on its second replay).  rocPRIM is header-only: inside THIS translation unit its two memsets are
+// routed to the library's fill kernel -- a kernel node replays like any other -- so captured steps sort with the radix sort
+// too (a NeighborLoader batch's 221 k-edge by-source sort: ~6 graph nodes and 43 us instead of the merge sort's ~20 and
+// 116).  (hip_runtime_api.h is already in: the macro meets only rocPRIM's calls.)
+namespace bkg {
+inline hipError_t fill_bytes_async(void* dst, int value, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  if (bytes % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0) {
+    const uint32_t b = (uint32_t)(value & 0xff), v = b | (b << 8) | (b << 16) | (b << 24);
+    fill_u32(dst, v, (int64_t)(bytes / 4), s);
+    return hipGetLastError();
+  }
+  return (hipMemsetAsync)(dst, value, bytes, s);      // (not a shape rocPRIM's sorts and scans ask for)
+}
+}  // namespace bkg
+#define hipMemsetAsync(dst, value, bytes, stream) ::bkg::fill_bytes_async((dst), (value), (bytes), (stream))
+
 #include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_merge_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
-#include "common.h"
+#undef hipMemsetAsync
 
 #ifndef BKG_SMALL_SORT
 #define BKG_SMALL_SORT 1      // key sets of <= 8192 entries: one single-workgroup launch instead of a device sort
@@ -363,12 +384,15 @@ static int sort_edges_impl(const int64_t* lo, const int64_t* hi, int64_t n_lo, i
   }
   hipLaunchKernelGGL(make_keys_kernel, grid1(n), dim3(256), 0, s, lo, hi, n_lo, keys_tmp, iota_tmp, n);
   size_t bytes = (size_t)workspace_bytes;
-  // While the stream is being captured into a hipGraph: the (equally stable) merge sort.  The radix sort's one-sweep
-  // form zeroes its histograms with runtime memsets, and memset nodes re-execute wrongly on this stack (common.h):
-  // a captured 1.5 M-key radix sort page-faults on its second replay, 0.7 M (already a merge sort inside) and 6 M do not.
+  // (captured or not: the radix sort -- its memsets are fill kernels in this translation unit, see the top of the file;
+  // BKG_CAPTURED_MERGE_SORT=1 brings back the merge sort of rounds 2-3 for a stream that is being captured)
+  static const bool merge_when_captured = [] { const char* v = getenv("BKG_CAPTURED_MERGE_SORT"); return v && v[0] == '1'; }();
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-  hipError_t e = hipStreamIsCapturing(s, &capturing);
-  if (e != hipSuccess) { set_error("bkg_sort_edges: hipStreamIsCapturing", e); return (int)e; }
+  hipError_t e = hipSuccess;
+  if (merge_when_captured) {
+    e = hipStreamIsCapturing(s, &capturing);
+    if (e != hipSuccess) { set_error("bkg_sort_edges: hipStreamIsCapturing", e); return (int)e; }
+  }
   if (capturing == hipStreamCaptureStatusActive)
     e = rocprim::merge_sort(workspace, bytes, keys_tmp, sorted_keys, iota_tmp, perm, (size_t)n, rocprim::less<uint32_t>(), s);
   else

@@ -249,12 +249,14 @@ def test_grace_replays_with_other_work_in_between():
         assert torch.equal(a, p.detach())
 
 
-@pytest.mark.parametrize("n,hi", [(3000, 1409), (700_000, 1409), (1_500_000, 60_000), (3_000_000, 130_000)])
+@pytest.mark.parametrize("n,hi", [(3000, 1409), (150_000, 27_000), (221_000, 27_000), (700_000, 1409), (1_500_000, 60_000),
+                                  (3_000_000, 130_000), (8_000_000, 130_000)])
 def test_captured_sorts_survive_replay(n, hi):
     """The library's key sort inside a captured step (the triplet orders and incidence lists of the padded KGE loop):
     replayed over changing keys it must stay a stable sort.  (The radix sort's one-sweep form zeroes histograms with
-    runtime memsets -- broken as graph nodes on ROCm 7.2: a captured 1.5 M-key sort page-faulted on its second replay;
-    under capture the library uses the merge sort.)"""
+    runtime memsets -- broken as graph nodes on ROCm 7.2: a captured 1.5 M-key sort page-faulted on its second replay.
+    Rounds 2-3 used the merge sort under capture; since round 4 rocPRIM's two memsets are routed to the library's fill
+    kernel inside csrc/graph.hip and captured steps run the radix sort too.)"""
     from biomedkg_amd.graph import _Sorter
     keys = torch.randint(0, hi, (n,), device=DEV)
 
@@ -266,7 +268,7 @@ def test_captured_sorts_survive_replay(n, hi):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         sk, perm, ws = body()
-    for _ in range(3):
+    for _ in range(5):
         g.replay()
         torch.cuda.synchronize()
         ref = torch.sort(keys, stable=True)
