@@ -130,6 +130,7 @@ SIGNATURES = {
     "bkg_negative_sample_dev_candidates": (I64, [I64]),
     "bkg_negative_sample_dev": (I32, [P, I64, P, P, P, I64, U64, P, P, I64, P, P, P, I64, I64, P, P, P, P, P, I64, P]),
     "bkg_padded_loss_inputs": (I32, [P, P, P, P, P, I64, I64, I64, P, P, P, P, P]),
+    "bkg_padded_gcl_batch": (I32, [P, P, P, P, I64, I64, I64, I64, P, P, P, P, P]),
     # optim.hip
     "bkg_clip_adam_max_tensors": (I64, []),
     "bkg_clip_adam_chunks": (I64, [P, I32]),

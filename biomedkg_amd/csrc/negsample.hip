@@ -243,6 +243,31 @@ __global__ __launch_bounds__(256) void randperm_dev_kernel(const int64_t* __rest
 // The loss-side view of a padded batch in one launch: pad positives get the relation id `pad_rel` (one past the real
 // ones: no scorer wave visits it) and endpoints spread over the local ids (zero gradient records, no long incidence
 // list); inv_total = 1 / (edges + negatives).
+// The padded view of a device NeighborLoader batch (biomedkg_amd/sampled_gcl.py): node ids past the batch's node count
+// read the zero row `pad_row`, edges past its edge count become self loops of `last_node` (weight 0 under gcn_norm; behind
+// the real edges, whose targets ascend, so the list stays sorted by target), real[i] = i < nodes.  One launch for what
+// was six torch expressions inside every captured step.
+__global__ __launch_bounds__(256) void padded_gcl_batch_kernel(const int64_t* __restrict__ sizes,
+                                                               const int64_t* __restrict__ n_id,
+                                                               const int64_t* __restrict__ src,
+                                                               const int64_t* __restrict__ dst, int64_t n_cap, int64_t e_b,
+                                                               int64_t pad_row, int64_t last_node,
+                                                               int64_t* __restrict__ out_n_id, int64_t* __restrict__ out_src,
+                                                               int64_t* __restrict__ out_dst, uint8_t* __restrict__ real) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nodes = sizes[1], edges = sizes[2];
+  if (i < n_cap) {
+    const bool live = i < nodes;
+    out_n_id[i] = live ? n_id[i] : pad_row;
+    real[i] = live ? 1 : 0;
+  }
+  if (i < e_b) {
+    const bool live = i < edges;
+    out_src[i] = live ? src[i] : last_node;
+    out_dst[i] = live ? dst[i] : last_node;
+  }
+}
+
 __global__ __launch_bounds__(256) void padded_loss_inputs_kernel(const int64_t* __restrict__ sizes,
                                                                  const int64_t* __restrict__ count,
                                                                  const int64_t* __restrict__ src,
@@ -506,4 +531,15 @@ extern "C" int bkg_padded_loss_inputs(const int64_t* sizes, const int64_t* count
   hipLaunchKernelGGL(padded_loss_inputs_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, sizes, count,
                      src, dst, type, rows, node_cap, pad_rel, out_src, out_dst, out_type, inv_total);
   return check_launch("bkg_padded_loss_inputs");
+}
+
+extern "C" int bkg_padded_gcl_batch(const int64_t* sizes, const int64_t* n_id, const int64_t* src, const int64_t* dst,
+                                    int64_t n_cap, int64_t e_b, int64_t pad_row, int64_t last_node, int64_t* out_n_id,
+                                    int64_t* out_src, int64_t* out_dst, uint8_t* real, void* stream) {
+  BKG_ARG(n_cap >= 0 && e_b >= 0 && sizes, "bkg_padded_gcl_batch: bad sizes");
+  const int64_t span = n_cap > e_b ? n_cap : e_b;
+  if (span == 0) return 0;
+  hipLaunchKernelGGL(padded_gcl_batch_kernel, dim3(ceil_div(span, 256)), dim3(256), 0, (hipStream_t)stream, sizes, n_id, src, dst,
+                     n_cap, e_b, pad_row, last_node, out_n_id, out_src, out_dst, real);
+  return check_launch("bkg_padded_gcl_batch");
 }

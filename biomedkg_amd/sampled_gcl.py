@@ -246,14 +246,16 @@ class NeighborGraphedGcl:
     # ---- the padded step (captured once per edge bucket and augmentation branch)
     def padded_batch(self, e_b):
         v = self.v
-        real_n = self.iota_n < v["sizes"][1]
-        real_e = self.iota_e[:e_b] < v["sizes"][2]
-        n_id = torch.where(real_n, v["n_id"], self.pad_row)
-        # pads: self loops of the LAST node (weight 0 under gcn_norm for any node, real or pad) -- behind the real edges,
-        # whose targets ascend (the sampler expands frontier nodes in local-id order), so the whole list stays sorted by
-        # target and the target-side CSR needs no sort (graph.Graph, _bkg_dst_sorted)
-        ei = torch.stack([torch.where(real_e, v["src"][:e_b], self.last_node),
-                          torch.where(real_e, v["dst"][:e_b], self.last_node)])        # fresh tensor: no structure cached on it survives the step
+        dev = self.x.device
+        # pads: node ids past the count read the zero row; edges past the count are self loops of the LAST node (weight 0
+        # under gcn_norm for any node, real or pad) -- behind the real edges, whose targets ascend (the sampler expands
+        # frontier nodes in local-id order), so the whole list stays sorted by target and the target-side CSR needs no
+        # sort (graph.Graph, _bkg_dst_sorted).  One launch (it was six torch expressions in every captured step).
+        n_id = torch.empty(self.n_cap, dtype=torch.int64, device=dev)
+        ei = torch.empty(2, e_b, dtype=torch.int64, device=dev)            # fresh tensor: no structure cached on it survives the step
+        real_n = torch.empty(self.n_cap, dtype=torch.bool, device=dev)
+        L.call("bkg_padded_gcl_batch", L.ptr(v["sizes"]), L.ptr(v["n_id"]), L.ptr(v["src"]), L.ptr(v["dst"]), self.n_cap, e_b,
+               self.n_cap, self.n_cap - 1, L.ptr(n_id), L.ptr(ei[0]), L.ptr(ei[1]), L.ptr(real_n), L.stream())
         ei._bkg_dst_sorted = ei._version
         return n_id, ei, real_n
 

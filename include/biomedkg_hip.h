@@ -483,6 +483,13 @@ int bkg_negative_sample_dev(const int64_t* sizes, int64_t neg_ratio, const int64
 int bkg_padded_loss_inputs(const int64_t* sizes, const int64_t* count, const int64_t* src, const int64_t* dst,
                            const int64_t* type, int64_t rows, int64_t node_cap, int64_t pad_rel, int64_t* out_src,
                            int64_t* out_dst, int64_t* out_type, float* inv_total, void* stream);
+/* The padded view of a device NeighborLoader batch (the reference's GCL loader, biomedkg/data_module.py:93-99, as a
+ * sync-free captured step): sizes[1] / sizes[2] = the batch's node / edge counts (device); out_n_id[n_cap] = n_id or
+ * pad_row past the count, out_src / out_dst[e_b] = the edges or self loops of last_node past the count, real[n_cap] = 1
+ * for the batch's own nodes. */
+int bkg_padded_gcl_batch(const int64_t* sizes, const int64_t* n_id, const int64_t* src, const int64_t* dst, int64_t n_cap,
+                         int64_t e_b, int64_t pad_row, int64_t last_node, int64_t* out_n_id, int64_t* out_src,
+                         int64_t* out_dst, uint8_t* real, void* stream);
 
 /* ---- modality fusion epilogues (biomedkg/utils/fusion.py:17-31 AttentionFusion, :49-90 ReDAF) */
 int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_t D, float* out, int64_t ldo,
