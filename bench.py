@@ -1163,19 +1163,26 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    # everything the timed loop needs is made BEFORE the warm-up steps -- the per-step marks, the tagged calls' events, the
+    # cycle collection -- so that nothing but the bracket's synchronisation stands between the last warm-up step and the
+    # first timed one
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step GPU times (no sync inside)
+    for ev in marks:                                    # (created for real here, not inside the timed loop)
+        ev.record()
+    ops.reserve_events(64 * args.steps + 64)            # ... and the tagged calls' events (~50 per step)
+    import gc
+    gc.collect()                                        # the interpreter's cycle collector stays out of the timed loop (a full
+    gc.disable()                                        # collection over the warm-up's tensors showed up as one 21 ms step)
+    # ... and out of the gap between warm-up and timed loop: a collection THERE hands the warm-up's cyclic garbage (buffers
+    # of the last steps) back to the caching allocator, the first timed step then finds another block layout and runs
+    # 1.0-1.3 ms long (10.9-11.2 against 9.75 ms, every run; scripts/dev_first_step_syncs.py takes the loop apart).  So:
+    # collect what the set-up left, switch the collector off, THEN warm up -- the timed steps see the allocator the warm-up
+    # steps left
     for _ in range(args.warmup):
         step_g(); step_k()
     step_k.finish()
     sync()
     ops.KERNEL_TIMERS = None if os.environ.get("BKG_BENCH_NO_KERNEL_TIMERS") == "1" else {}
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step GPU times (no sync inside)
-    for ev in marks:                                    # (created for real here, not inside the timed loop)
-        ev.record()
-    ops.reserve_events(64 * args.steps + 64)            # ... and the tagged calls' events (~50 per step)
-    sync()
-    import gc
-    gc.collect()                                        # the interpreter's cycle collector stays out of the timed loop (a full
-    gc.disable()                                        # collection over the warm-up's tensors showed up as one 21 ms step)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -1396,6 +1403,7 @@ def main():
             "triplets_per_sec_kge_step": (total_edges + (n_neg if strong or world == 1 else world * n_neg)) / (ms_k * 1e-3),
             "edges_per_sec_gcl_step": total_edges / (ms_g * 1e-3),
             "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_max": per_step[-1],
+            "ms_per_step_each": [round(v, 3) for v in per_step_raw],
             "ms_per_step_slowest_index": per_step_raw.index(per_step[-1]),
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
             "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_shuffled_neg_types": ms_shuffled_types,
