@@ -60,6 +60,56 @@ def test_gcn_norm_full_size(kg):
     assert abs(float(gw.w_dst.double().sum() - gw.w_src.double().sum())) < 1e-6 * float(gw.w_dst.double().sum())
 
 
+def test_dropout_edge_view_full_size(kg):
+    """The view builder as the bench runs it (4 M edges: above the product's floor, no patching): both CSRs of a
+    ``dropout_edge`` view are the kept non-loop edges in row order with PyG's gcn_norm weights of the KEPT graph, and the
+    two-view propagate over them equals an fp64 restatement (row chunks) of ``A_hat_kept @ table`` with its epilogue."""
+    from biomedkg_amd import graph as G, ops
+    ei, _ = kg
+    src, dst = ei
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    keep = torch.rand(E, device=DEV, generator=gen) >= 0.4
+    gr = G.graph_of(ei, N)
+    for _ in range(4):
+        gr.by_dst.split.use(); gr.by_src.split.use()            # (the graph's tables know their counts, as after a step)
+    gw = gr.gcn_weights(keep)
+    assert isinstance(gw.dst, G.KeptCSR) and isinstance(gw.src, G.KeptCSR)
+    live = keep & (src != dst)
+    m = int(live.sum())
+    assert int(gw.dst.count) == m == int(gw.src.count)
+    deg = torch.bincount(dst[live], minlength=N).double() + 1.0
+    dis = deg.pow(-0.5)
+    torch.testing.assert_close(gw.self_w.double(), dis * dis, rtol=1e-6, atol=0)
+    for view, key, other in ((gw.dst, dst, src), (gw.src, src, dst)):
+        rp = view.rowptr.long()
+        assert rp[0] == 0 and rp[-1] == m and bool((rp[1:] >= rp[:-1]).all())
+        assert torch.equal(rp[1:] - rp[:-1], torch.bincount(key[live], minlength=N))             # row lengths of the view
+        rows = torch.repeat_interleave(torch.arange(N, device=DEV), rp[1:] - rp[:-1])
+        col = view.col[:m].long()
+        torch.testing.assert_close(view.w[:m].double(), dis[rows] * dis[col], rtol=1e-6, atol=0)
+        # the same multiset of (row, col) pairs as the kept edges (checksums of both orders and of their product)
+        assert int(rows.sum()) == int(key[live].sum()) and int(col.sum()) == int(other[live].sum())
+        assert int((rows * 7 + col * 13).remainder(1_000_003).sum()) == int((key[live] * 7 + other[live] * 13).remainder(1_000_003).sum())
+    # the two-view propagate (bf16 table, column halves by XCD, bias + ReLU epilogue) over the view
+    ops.set_matmul_precision("bf16")
+    try:
+        table = _x(3, d=2 * D).to(torch.bfloat16)
+        bias = _x(4, rows=1, d=2 * D)[0]
+        c = gw.dst
+        out = ops.spmm(c.rowptr, c.col, gw.w_dst, table, N, self_w=gw.self_w, bias=bias, relu=True, split=c.split, live=c.count)
+        tf = table.double()
+        es, ed, ew = src[live], dst[live], (dis[src] * dis[dst])[live]
+        for lo in range(0, N, 26_000):
+            hi = min(lo + 26_000, N)
+            sel = (ed >= lo) & (ed < hi)
+            ref = torch.zeros(hi - lo, 2 * D, dtype=torch.float64, device=DEV)
+            ref.index_add_(0, ed[sel] - lo, tf[es[sel]] * ew[sel, None])
+            ref += tf[lo:hi] * (dis[lo:hi] ** 2)[:, None] + bias.double()
+            torch.testing.assert_close(out[lo:hi].double(), ref.relu(), rtol=1e-4, atol=1e-4)
+    finally:
+        ops.set_matmul_precision("fp32")
+
+
 def test_spmm_full_size(kg):
     from biomedkg_amd import graph as G, ops
     ei, _ = kg
