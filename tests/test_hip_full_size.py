@@ -218,6 +218,36 @@ def test_kge_loss_full_size(kg, kind):
         assert err < (1e-5 if kind == 0 else 2e-3), (name, err)   # TransE: sign(0) ties of |.|' differ at fp32 roundoff
 
 
+def test_kge_loss_full_size_in_the_sorted_frame(kg):
+    """The positives of a graph that stays are scored in their (relation, target) frame from the step after the R-GCN
+    structure's planted order is used up (ops._SortedTriplets; 4 M triplets: above the product's floor, as shipped): the
+    same loss, scores and gradients as the first call's plain form, against the fp64 restatement."""
+    from biomedkg_amd import graph as G, ops, sampling
+    ei0, et0 = kg
+    ei, et = ei0.clone(), et0.clone()                          # (structures are cached on the tensors)
+    G.rel_graph_of(ei, et, N, R)                               # what the encoder builds: plants the relation order
+    torch.manual_seed(5)
+    neg = sampling.negative_sampling(ei, N, E)
+    nt = et[torch.randperm(E, device=DEV)]
+    z0, rel0 = _x(6) * 0.3, torch.randn(R, D, device=DEV) * 0.3
+    res = []
+    for call in range(4):
+        z, rel = z0.clone().requires_grad_(), rel0.clone().requires_grad_()
+        loss, pos_s, neg_s = ops.kge_bce_loss(z, rel, ei, et, neg, nt, 0)
+        loss.backward()
+        res.append((float(loss.detach()), pos_s.clone(), z.grad.clone(), rel.grad.clone(), "sorted_triplets" in et._bkg_cache))
+    assert [r[4] for r in res] == [False, False, True, True]      # two asks on the planted order, then the frame
+    zd, rd = z0.double().requires_grad_(), rel0.double().requires_grad_()
+    all_ei, all_et = torch.cat([ei, neg], 1), torch.cat([et, nt])
+    label = torch.cat([torch.ones(E, dtype=torch.float64, device=DEV), torch.zeros(E, dtype=torch.float64, device=DEV)])
+    ref_loss, ref_s = _kge_ref(0, zd, rd, all_ei, all_et, label)
+    for loss, pos_s, dz, drel, _ in res:
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+        torch.testing.assert_close(pos_s.double(), ref_s[:E], rtol=1e-4, atol=1e-4)      # the caller's order
+        assert float((dz.double() - zd.grad).norm() / zd.grad.norm()) < 1e-5
+        assert float((drel.double() - rd.grad).norm() / rd.grad.norm()) < 1e-5
+
+
 def _ntxent_ref(h1, h2, tau, chunk=4096):
     """fp64 dual-branch InfoNCE with intra-view negatives in row chunks (never the [2N, 2N] matrix)."""
     n = h1.size(0)
