@@ -235,9 +235,17 @@ __global__ __launch_bounds__(1024) void kge_loss_finish_kernel(const float* __re
   if (reg != 0.f) {
     const int d4 = d >> 2;                     // rows are read as float4 (d % 4 == 0, 16-byte aligned rows: host check)
     const int64_t nz = (int64_t)n_rows * d4, nr = (int64_t)n_rel * d4;
-    for (int64_t e = gt; e < nz; e += stride) {
-      const float4 v = *reinterpret_cast<const float4*>(z + (e / d4) * ldz + (e % d4) * 4);
-      zz += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    if (ldz == d) {                            // contiguous rows (a whole graph's z): one flat stream, no 64-bit division per piece
+      const float4* zf = reinterpret_cast<const float4*>(z);
+      for (int64_t e = gt; e < nz; e += stride) {
+        const float4 v = zf[e];
+        zz += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+      }
+    } else {
+      for (int64_t e = gt; e < nz; e += stride) {
+        const float4 v = *reinterpret_cast<const float4*>(z + (e / d4) * ldz + (e % d4) * 4);
+        zz += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+      }
     }
     for (int64_t e = gt; e < nr; e += stride) {
       const float4 v = *reinterpret_cast<const float4*>(rel + (e / d4) * ldr + (e % d4) * 4);

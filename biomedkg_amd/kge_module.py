@@ -108,10 +108,24 @@ class KGEModule(LightningModule):
         z = self.model.encode(x, batch.edge_index, batch.edge_type)
         neg_edge_index, neg_edge_type = self.sample_neg_edges(batch.edge_index, batch.edge_type)
         dec = self.model.decoder
-        loss, pos_pred, neg_pred = ops.kge_bce_loss(z, dec.rel_emb, batch.edge_index, batch.edge_type, neg_edge_index,
-                                                    neg_edge_type, dec.kind, reg=1e-2)     # BCE + 1e-2 (mean z^2 + mean rel^2)
-        self._last_scores = (z.detach(), pos_pred, neg_pred)      # (detached: must not keep the step's autograd graph alive)
+        loss, pos_pred, neg_pred, inverse = ops.kge_bce_loss(z, dec.rel_emb, batch.edge_index, batch.edge_type, neg_edge_index,
+                                                             neg_edge_type, dec.kind, reg=1e-2,      # BCE + 1e-2 (mean z^2 + mean rel^2)
+                                                             lazy_scores=True)
+        # (detached: must not keep the step's autograd graph alive; the positives' scores may still be in the order of the
+        # scorer's sorted frame: ``_last_scores`` puts them in the batch's order when somebody reads them)
+        self._scores_of_last_step = (z.detach(), pos_pred, neg_pred, inverse)
         return loss
+
+    @property
+    def _last_scores(self):
+        """``(z, pos_pred, neg_pred)`` of the last fused training step, the predictions in the batch's triplet order."""
+        from . import ops
+        z, pos_pred, neg_pred, inverse = self._scores_of_last_step
+        if inverse is not None:
+            pos_pred = ops.scores_in_order(pos_pred, inverse)
+            self._scores_of_last_step = (z, pos_pred, neg_pred, None)
+        return z, pos_pred, neg_pred
+
 
     def training_step(self, batch, batch_idx=None):
         if getattr(self.model.decoder, "kind", None) is not None:

@@ -1345,6 +1345,21 @@ SORTED_POSITIVES = __import__("os").environ.get("BKG_SORTED_POSITIVES", "1") != 
 _SORTED_MIN_TRIPLETS = 1 << 20
 
 
+# how the positives' scores leave a call that ran in the sorted frame: put back in the caller's order by the op (default), or
+# left in frame order with the inverse permutation handed over beside them ("lazy": a training step stores the scores for
+# whoever may ask -- metrics, tests -- and pays the 4 M-float gather only then)
+_FRAME = {"lazy": False, "inverse": None}
+
+
+def scores_in_order(scores, inverse):
+    """Scores of a call in the sorted frame (``_SortedTriplets``) in the caller's triplet order."""
+    if inverse is None:
+        return scores
+    back = torch.empty_like(scores)
+    L.call("bkg_gather_f32", L.ptr(scores), L.ptr(inverse), L.ptr(back), back.numel(), L.stream())
+    return back
+
+
 class _SortedTriplets:
     """A graph's positives stored in (relation, target) order -- the R-GCN structure's sort (graph.RelGraph) -- for the
     scorer of a graph that STAYS (full-graph training): the ids are read in place, the tails of consecutive triplets are
@@ -1629,10 +1644,11 @@ class _KgeBceLoss(torch.autograd.Function):
                                   rec_all[pos_ei.size(1):] if (pack and neg_ei.size(1)) else None,
                                   z if (reg or padded) else None)
             pos_scores, neg_scores = scores[0], scores[1]
-            if resort is not None:
-                back = torch.empty_like(pos_scores)                           # back in the caller's order
-                L.call("bkg_gather_f32", L.ptr(pos_scores), L.ptr(resort.inverse), L.ptr(back), back.numel(), L.stream())
-                pos_scores = back
+            _FRAME["inverse"] = None
+            if resort is not None and _FRAME["lazy"]:
+                _FRAME["inverse"] = resort.inverse            # the caller puts them in order if anybody asks (scores_in_order)
+            elif resort is not None:
+                pos_scores = scores_in_order(pos_scores, resort.inverse)
         else:
             t_pos = owned[0].n_own + owned[0].n_foreign
             ctx.graphs = None
@@ -1787,13 +1803,15 @@ def kge_bce_loss_owned(z_local, rel_emb, pos: OwnedTriplets, neg: OwnedTriplets,
 
 
 def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, kind, total=None,
-                 reg=0.0, inv_total=None, rows=None, reg_rows=None):
+                 reg=0.0, inv_total=None, rows=None, reg_rows=None, lazy_scores=False):
     """(Node-partitioned training: ``kge_bce_loss_owned``.)  ``total``: the count the BCE sum is divided by (default: this call's triplets);
     ``reg``: adds ``reg * (mean(z^2) + mean(rel_emb^2))`` (the reference's L2 term) inside the same op.
     ``inv_total`` / ``rows`` (padded mini-batches of a captured step, biomedkg_amd/sampled.py): the BCE sum is multiplied
     by the DEVICE scalar ``inv_total``, triplets with relation id ``R`` (one past the real ones) are pads, and the mean
     of ``z^2`` runs over the first ``rows`` rows (an int64 DEVICE scalar).  ``reg_rows`` (partitioned steps): the number
-    of rows the mean of ``z^2`` is taken over when ``z`` is a shard (N / world: the bucket average is the whole mean)."""
+    of rows the mean of ``z^2`` is taken over when ``z`` is a shard (N / world: the bucket average is the whole mean).
+    ``lazy_scores``: a fourth value comes back -- None, or the inverse permutation of the sorted frame the positives' scores
+    were left in (``scores_in_order`` puts them in the caller's order: a training step only does when somebody asks)."""
     L.require_cuda(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_edge_type, inv_total)
     for ei, et, what in ((pos_edge_index, pos_edge_type, "positive"), (neg_edge_index, neg_edge_type, "negative")):
         if ei.dim() != 2 or ei.size(0) != 2 or et.dim() != 1 or et.numel() != ei.size(1):
@@ -1803,9 +1821,17 @@ def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_
     if inv_total is not None and (inv_total.dtype != torch.float32 or rows is None or rows.dtype != torch.int64):
         raise ValueError("inv_total (padded mini-batches): a float32 device scalar together with rows = the real row "
                          "count as an int64 device scalar")
-    return _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
-                             neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, None, total, float(reg),
-                             inv_total, rows, reg_rows)
+    _FRAME["lazy"] = bool(lazy_scores)
+    try:
+        out = _KgeBceLoss.apply(_f32c(z), _f32c(rel_emb), pos_edge_index.contiguous(), pos_edge_type.contiguous(),
+                                neg_edge_index.contiguous(), neg_edge_type.contiguous(), kind, None, total, float(reg),
+                                inv_total, rows, reg_rows)
+    finally:
+        _FRAME["lazy"] = False
+    if lazy_scores:        # (loss, positives' scores possibly in frame order, negatives' scores, the inverse permutation or None)
+        inverse, _FRAME["inverse"] = _FRAME["inverse"], None
+        return out + (inverse,)
+    return out
 
 
 # ----------------------------------------------------------------------------- NT-Xent
