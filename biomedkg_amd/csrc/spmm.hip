@@ -582,7 +582,8 @@ extern "C" int bkg_gate_cast_bf16(const void* src, int32_t src_is_bf16, const vo
 // ---- feature masking of the GCL augmentations (reference biomedkg/model/gcl.py:42,76: x * (rand >= p), no
 //      rescale) fused with the bf16 table cast: dst = bf16(philox(seed, stream, i) >= p ? src[i] : 0); p = 0: plain cast
 namespace bkg {
-__global__ __launch_bounds__(256) void mask_cast_bf16_kernel(const float* __restrict__ src, float p, uint64_t seed,
+template <typename ST>
+__global__ __launch_bounds__(256) void mask_cast_bf16_kernel(const ST* __restrict__ src, float p, uint64_t seed,
                                                              uint32_t stream_id, __bf16* __restrict__ dst, int64_t n8,
                                                              const uint32_t* __restrict__ epoch) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -606,14 +607,18 @@ __global__ __launch_bounds__(256) void mask_cast_bf16_kernel(const float* __rest
 }
 }  // namespace bkg
 
-extern "C" int bkg_mask_cast_bf16(const float* src, float p, uint64_t seed, uint32_t stream_id, void* dst, int64_t n,
-                                  void* stream) {
+extern "C" int bkg_mask_cast_bf16(const void* src, int32_t src_is_bf16, float p, uint64_t seed, uint32_t stream_id,
+                                  void* dst, int64_t n, void* stream) {
   using namespace bkg;
   BKG_ARG(n >= 0 && n % 8 == 0 && p >= 0.f && p < 1.f, "bkg_mask_cast_bf16: n must be a multiple of 8, p in [0,1)");
   BKG_ARG(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "bkg_mask_cast_bf16: 16-byte alignment");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(mask_cast_bf16_kernel, dim3(ceil_div(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, src, p, seed,
-                     stream_id, (__bf16*)dst, n / 8, rng_epoch_ptr());
+  if (src_is_bf16)      // (the cached bf16 copy of constant features: bf16(mask ? x : 0) = mask ? bf16(x) : 0, half the bytes read)
+    hipLaunchKernelGGL(mask_cast_bf16_kernel<__bf16>, dim3(ceil_div(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)src, p, seed, stream_id, (__bf16*)dst, n / 8, rng_epoch_ptr());
+  else
+    hipLaunchKernelGGL(mask_cast_bf16_kernel<float>, dim3(ceil_div(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, p, seed, stream_id, (__bf16*)dst, n / 8, rng_epoch_ptr());
   return check_launch("bkg_mask_cast_bf16");
 }
 

@@ -139,7 +139,8 @@ int bkg_cast_f32_bf16(const float* src, const float* gate, float gate_scale, voi
 /*      typed form: src and gate may each be fp32 or bf16 (bf16 hidden activations / gradients of the bf16 mode) */
 /*      feature masking of the GCL augmentations (biomedkg/model/gcl.py:42,76: x * (rand >= p), no rescale) fused with
  *      the cast: dst = bf16(Philox(seed, stream_id, i) >= p ? src[i] : 0) */
-int bkg_mask_cast_bf16(const float* src, float p, uint64_t seed, uint32_t stream_id, void* dst, int64_t n, void* stream);
+int bkg_mask_cast_bf16(const void* src, int32_t src_is_bf16, float p, uint64_t seed, uint32_t stream_id, void* dst, int64_t n,
+                       void* stream);   /* src: fp32, or the bf16 copy of the same features (the same result, half the bytes) */
 int bkg_gate_cast_bf16(const void* src, int32_t src_is_bf16, const void* gate, int32_t gate_is_bf16, float gate_scale,
                        void* dst, int64_t n, void* stream);
 int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, const void* x, int32_t x_is_bf16,
