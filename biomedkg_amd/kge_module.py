@@ -120,7 +120,10 @@ class KGEModule(LightningModule):
     def _last_scores(self):
         """``(z, pos_pred, neg_pred)`` of the last fused training step, the predictions in the batch's triplet order."""
         from . import ops
-        z, pos_pred, neg_pred, inverse = self._scores_of_last_step
+        last = getattr(self, "_scores_of_last_step", None)
+        if last is None:
+            return None                              # no fused training step has run yet
+        z, pos_pred, neg_pred, inverse = last
         if inverse is not None:
             pos_pred = ops.scores_in_order(pos_pred, inverse)
             self._scores_of_last_step = (z, pos_pred, neg_pred, None)
