@@ -23,13 +23,18 @@ one graph per rank, gradient all-reduce only, weak scaling) and is opt-in.
 Default ``--precision bf16`` = BASELINE's "bf16 storage / fp32 accumulate" configuration; ``--precision fp32``
 is the exact parity mode (its step time is reported on the same line as ``ms_per_step_fp32``).
 
-Also on the same JSON line (rank 0, N = 1): ``roofline`` for the kernel with the most GPU time among the gather /
+In the full record (rank 0, N = 1): ``roofline`` for the kernel with the most GPU time among the gather /
 aggregate launches (HIP events on the launch stream inside the timed region; see ``roofline_of``), ``kernels`` for the
 others, ``grace_step`` (BASELINE configs[1]: GRACE / GCN d=128 on the 5k/50k graph, fp32) and ``ntxent`` (the NT-Xent
 matrix-core kernels against the fp32 / bf16 MFMA peaks), ``fusion`` (the modality projection), ``sampled_regime`` (the
 reference's own GraphSAINT mini-batch KGE loop: eager steps/s vs one hipGraph replay per step), and ``cpu_baseline``
-(the CPU oracle -- a torch restatement of the reference's PyG path -- timed on this box's host cores on a bounded
-down-scaled sample).
+(the CPU oracle -- a torch restatement of the reference's PyG path -- timed live on this box's host cores: full training
+steps on a 1/8-scale graph for ~15 s; the full-size step, 100-110 s on 64 cores, is measured once per round and read from
+profiles/).
+
+stdout's LAST line is a compact (< 8 KB) strict-JSON object -- the contract's keys, ``roofline``, ``cpu_baseline``,
+``exchange`` for N > 1 (``compact_line``); the full record (the other kernels, step accounting, every side figure) is written
+to ``bench_detail.json`` next to this file.
 """
 import argparse
 import json
@@ -57,6 +62,20 @@ MFMA_F32_TFLOPS = 155.0      # v_mfma_f32_32x32x2_f32, measured
 MFMA_BF16_TFLOPS = 2500.0    # dense bf16
 
 
+# what ``frac`` means, once (bench_detail.json ``roofline_model``), not per kernel
+ROOFLINE_MODEL = {
+    "guide_GBs": {"hbm_spec": HBM_PEAK_GBS, "hbm_achievable": 6300.0, "infinity_cache_gather": MALL_GATHER_GBS,
+                  "l2_gather": L2_GATHER_GBS},
+    "frac_definition": "frac = t_min / t with t_min = max(algorithmic bytes / 16.8 TB/s [every gathered byte through "
+                       "the XCD L2s: the guide's L2 gather rate], L2-miss bytes / 8.6 TB/s [PMC FETCH_SIZE x 2 + "
+                       "WRITE_SIZE per call out of the Infinity Cache: the guide's gather rate; those bytes include "
+                       "Infinity-Cache hits, guide l. 297]) and t = the call's HIP-event time (avg_launch_ms; "
+                       "avg_launch_ms_traced = the same call in the committed --kernel-trace pass).  Components: "
+                       "frac_l2_gather = t_min_l2 / t, frac_mall_gather = t_min_mall / t, frac_hbm_spec = L2-miss "
+                       "rate / 8 TB/s.  achieved / peak = algorithmic_over_hbm is NOT a fraction (cache reuse); frac "
+                       "is null when no PMC pass of this call is committed under profiles/"}
+
+
 class Batch:
     pass
 
@@ -78,7 +97,10 @@ def parse():
                          "replicas: one graph per rank, gradient all-reduce only (weak scaling, the reference's DDP regime)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 step / GRACE / NT-Xent / fusion figures")
-    ap.add_argument("--cpu-scale", type=int, default=16, help="CPU baseline runs on a 1/scale graph")
+    ap.add_argument("--cpu-scale", type=int, default=8, help="the live CPU baseline probe runs on a 1/scale graph")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (kernels, step accounting, NT-Xent / fusion / sampled-regime figures); "
+                         "stdout's last line is the compact (< 8 KB) strict-JSON line")
     return ap.parse_args()
 
 
@@ -194,16 +216,7 @@ def roofline_of(tag, rec, precision):
             "traced_over_live": (traced_ms / avg_ms) if traced_ms else None,
             "launches": len(durs), "ms_total": sum(durs), "bytes_per_launch": rec["bytes"],
             "grid_size": rec.get("grid"), "grid_size_second_launch": rec.get("grid2"), "pieces": pieces, "col_halves": halves,
-            "guide_GBs": {"hbm_spec": HBM_PEAK_GBS, "hbm_achievable": 6300.0, "infinity_cache_gather": MALL_GATHER_GBS,
-                          "l2_gather": L2_GATHER_GBS},
-            "frac_definition": "frac = t_min / t with t_min = max(algorithmic bytes / 16.8 TB/s [every gathered byte through "
-                               "the XCD L2s: the guide's L2 gather rate], L2-miss bytes / 8.6 TB/s [PMC FETCH_SIZE x 2 + "
-                               "WRITE_SIZE per call out of the Infinity Cache: the guide's gather rate; those bytes include "
-                               "Infinity-Cache hits, guide l. 297]) and t = the call's HIP-event time (avg_launch_ms; "
-                               "avg_launch_ms_traced = the same call in the committed --kernel-trace pass).  Components: "
-                               "frac_l2_gather = t_min_l2 / t, frac_mall_gather = t_min_mall / t, frac_hbm_spec = L2-miss "
-                               "rate / 8 TB/s.  achieved / peak = algorithmic_over_hbm is NOT a fraction (cache reuse); frac "
-                               "is null when no PMC pass of this call is committed under profiles/"}
+            }
 
 
 # tagged calls that launch the SAME kernel over the same grid (the forward and the backward propagate of the GGD views): the
@@ -222,6 +235,137 @@ def rooflines(timers, precision):
         r["ms_total_of_kernel"] = group[SAME_KERNEL.get(r["tag"], r["tag"])]
     out.sort(key=lambda r: (-r["ms_total_of_kernel"], -r["ms_total"]))
     return (out[0] if out else None), out[1:]
+
+
+
+# ----------------------------------------------------------------------------------------------- the line the driver reads
+LINE_LIMIT = 8192          # the driver keeps an 8 KB tail of stdout: the LAST line must fit it with room to spare
+_ROOFLINE_KEYS = ("bound", "tag", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms",
+                  "avg_launch_ms_traced", "l2_hit_rate", "l2_miss_GBs", "frac_hbm_spec", "frac_l2_gather", "frac_mall_gather",
+                  "launches", "pmc_source")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "cpu_model", "seconds_per_step", "sample", "full_size", "threads1")
+_EXCHANGE_KEYS = ("wire_bytes_received_per_step", "wire_bytes_sent_per_step", "exchanges_per_step", "exchange_exposed_ms",
+                  "exchange_serial_ms", "exposed_fraction", "ms_per_step_overlapped", "ms_per_step_serial",
+                  "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_graphed", "library_calls_per_step",
+                  "padded_over_real_rows", "rows", "form")
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "ranks", "backend", "steps", "warmup", "ms_per_step", "higher_is_better",
+             "scaling", "vs_baseline", "dtype", "data")
+_SIDE_KEYS = ("triplets_per_sec_kge_step", "edges_per_sec_gcl_step", "ms_per_step_median", "ms_per_step_max", "ms_gcl_step",
+              "ms_kge_step", "ms_per_step_fp32", "ms_per_step_shuffled_neg_types", "ms_kge_step_neg10",
+              "triplets_per_sec_kge_step_neg10")
+
+
+def _strict(o, digits=6):
+    """JSON the strictest reader takes: non-finite floats -> null, floats to ``digits`` significant digits, tuples ->
+    lists, anything else that json cannot carry -> its str()."""
+    import math
+    if isinstance(o, bool) or o is None or isinstance(o, (int, str)):
+        return o
+    if isinstance(o, float):
+        if not math.isfinite(o):
+            return None
+        return float(f"{o:.{digits}g}")
+    if isinstance(o, dict):
+        return {str(k): _strict(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_strict(v, digits) for v in o]
+    if hasattr(o, "item"):
+        try:
+            return _strict(o.item(), digits)
+        except Exception:      # noqa: BLE001
+            pass
+    return str(o)
+
+
+def _short(text, limit):
+    text = " ".join(str(text).split())
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def _pick(d, keys, text_limit=160):
+    if not isinstance(d, dict):
+        return None
+    out = {}
+    for k in keys:
+        if k in d:
+            v = d[k]
+            out[k] = _short(v, text_limit) if isinstance(v, str) else v
+    return out
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line the driver parses (a 26 KB line came back ``parsed: null``): the contract's keys, the
+    dominant kernel's ``roofline`` and ``cpu_baseline`` as numbers plus short labels, ``exchange`` numbers for N > 1, a few
+    headline side figures.  Everything else -- the other kernels, the step accounting, NT-Xent / fusion / sampled-regime
+    figures, the prose definitions -- lives in ``bench_detail.json`` (``detail``).  -> a strict-JSON string, always shorter
+    than LINE_LIMIT (the optional parts are dropped in order if a future field pushes it over)."""
+    line = {k: out.get(k) for k in _TOP_KEYS}
+    cfg = out.get("config") or {}
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 360), "parallelism": cfg.get("parallelism")}
+    roof = _pick(out.get("roofline"), _ROOFLINE_KEYS, 200)
+    line["roofline"] = roof
+    cpu = out.get("cpu_baseline")
+    if isinstance(cpu, dict) and "error" in cpu:
+        line["cpu_baseline"] = {"error": _short(cpu["error"], 200)}
+    else:
+        cpu = _pick(cpu, _CPU_KEYS, 260)
+        if cpu:
+            for k in ("full_size", "threads1"):
+                if isinstance(cpu.get(k), dict):
+                    cpu[k] = {a: b for a, b in cpu[k].items() if not isinstance(b, (str, dict, list)) or a == "source"}
+        line["cpu_baseline"] = cpu
+    if out.get("exchange"):
+        ex = _pick(out["exchange"], _EXCHANGE_KEYS)
+        gs = out["exchange"].get("graphed_sub_steps")
+        if isinstance(gs, dict):
+            ex["graphed_sub_steps"] = {k: (_short(v, 120) if isinstance(v, str) else v) for k, v in gs.items()}
+        line["exchange"] = ex
+    for k in _SIDE_KEYS:
+        if out.get(k) is not None:
+            line[k] = out[k]
+    for key in ("check_loss", "check_loss_after"):
+        if out.get(key):
+            line[key] = {k: v for k, v in out[key].items() if not isinstance(v, str)}
+    line["detail"] = detail_path
+    line = _strict(line)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    for drop in ("check_loss_after", "check_loss", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_shuffled_neg_types",
+                 "ms_per_step_fp32", "exchange.graphed_sub_steps", "cpu_baseline.threads1", "cpu_baseline.full_size"):
+        if len(text) < LINE_LIMIT - 1024:
+            break
+        head, _, leaf = drop.partition(".")
+        if leaf:
+            if isinstance(line.get(head), dict):
+                line[head].pop(leaf, None)
+        else:
+            line.pop(head, None)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:      # cannot happen with the fields above; never print a line the driver cannot read
+        line = {k: line.get(k) for k in _TOP_KEYS + ("config",)}
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    return text
+
+
+def emit(out, detail_path):
+    """Write the full record to ``detail_path`` (and to gpurun_out/ when that directory exists: it is what travels back
+    from a GPU box), then print the compact line LAST on stdout."""
+    detail = _strict(out, digits=9)
+    wrote = None
+    for path in [detail_path] + ([os.path.join(ROOT, "gpurun_out", os.path.basename(detail_path))]
+                                  if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else []):
+        try:
+            with open(path, "w") as f:
+                json.dump(detail, f, allow_nan=False, indent=1)
+            wrote = wrote or os.path.relpath(path, ROOT)
+        except OSError as why:
+            sys.stderr.write(f"bench.py: could not write {path}: {why}\n")
+    try:      # RCCL writes its version banner through C stdio: flush it out BEFORE the line, which must come last
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(compact_line(out, wrote), flush=True)
 
 
 # ----------------------------------------------------------------------------------------------- sub-steps
@@ -263,11 +407,14 @@ def make_step(module, batch, world, overlap=False):
     return step
 
 
-def build_partitioned_steps(args, rank, world, dev):
+def build_partitioned_steps(args, rank, world, dev, simulate=False):
     """The same pair of sub-steps over ONE graph whose nodes are partitioned over the ranks: GGD with its
     augmentation (coin, feature mask, dropout_edge -- the replicated draws come from a generator every rank seeds alike)
     through the fused side-by-side views, R-GCN + DistMult with each rank scoring its share of the positives and its
-    own negatives."""
+    own negatives.
+
+    ``simulate``: THIS process stands in for rank ``rank`` of ``world`` without a process group (scripts/simulate_ranks.py:
+    the rank's real structures and kernels, every exchange a local copy of the same byte count -- partition.Comm)."""
     from biomedkg_amd import ops, partition as P, sampling, synthetic
     from biomedkg_amd.distributed import GradBucket
     from biomedkg_amd.gcl_module import GGDModule
@@ -275,7 +422,7 @@ def build_partitioned_steps(args, rank, world, dev):
     g = synthetic.primekg_like(args.nodes, args.edges, args.relations, seed=42)     # the same graph on every rank
     n, e, r, h = g["num_nodes"], g["edge_index"].size(1), g["num_relations"], args.hidden
     ei, et = g["edge_index"].to(dev), g["edge_type"].to(dev)
-    part = P.NodePartition(ei, n, rank, world)
+    part = P.NodePartition(ei, n, rank, world, simulate=simulate)
     # refuse early, with a message, what would otherwise die inside a step: the gathered tables live in the padded slot
     # space [world * n_max, d] -- per conv layer a forward table and a gathered output gradient, two views wide for GGD,
     # plus the activations saved for the backward (a generous bound: fp32, every layer resident at once)
@@ -319,10 +466,17 @@ def build_partitioned_steps(args, rank, world, dev):
     # eager partitioned step: a rank whose share of the kernels is shorter than that -- P >= 4 -- is launch-bound).  What
     # makes it capturable: every extent is static (patterns, block-structured negatives), no host read inside a step, the
     # in-kernel random streams are re-keyed by the library's device replay counter, torch's device draws come from a
-    # generator registered with the graph.  Falls back to the eager step if the capture raises.
-    graph_mode = (os.environ.get("BKG_BENCH_PARTITION_GRAPH") == "1" and torch.distributed.is_initialized()
-                  and torch.distributed.get_backend() == "nccl")
+    # generator registered with the graph.  If a capture raises on any rank, all ranks leave (exit code 3) and the launcher restarts the job with the eager step.
+    graph_mode = (os.environ.get("BKG_BENCH_PARTITION_GRAPH") == "1"
+                  and (simulate or (torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl")))
     graph_stats = {"captured": 0, "replayed": 0, "eager": 0, "refused": None}
+
+    def capture_agreed(ok):
+        if simulate or not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(flag.item())
 
     def make(params, loss_fn, draw_key, defer_update=False):
         """``defer_update`` (graphed mode, the KGE sub-step): its 32.5 MB gradient bucket -- the one message of the step that
@@ -336,9 +490,9 @@ def build_partitioned_steps(args, rank, world, dev):
         if graph_mode:
             from biomedkg_amd.graphs import make_capturable
             opt = make_capturable(opt)
-        defer = bool(defer_update and graph_mode and os.environ.get("BKG_BENCH_DEFER_UPDATE", "1") != "0")
+        defer = bool(defer_update and graph_mode and not simulate and os.environ.get("BKG_BENCH_DEFER_UPDATE", "1") != "0")
         group = torch.distributed.new_group() if defer else None      # (every rank makes it: the same call order everywhere)
-        bucket = GradBucket(params, world, group=group)
+        bucket = GradBucket(params, world, group=group, simulate=simulate)
         defer = defer and bucket.live
         epoch = torch.zeros(1, dtype=torch.int32, device=dev)
         graphs, losses = {}, {}
@@ -423,18 +577,24 @@ def build_partitioned_steps(args, rank, world, dev):
                         time.sleep(0.5)
                         g = torch.cuda.CUDAGraph()
                         g.register_generator_state(shared)
+                        refused = None
                         try:
                             with as_captured(), torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                                 losses[key] = body(key, whole=not defer).detach()
                         except Exception as why:                    # noqa: BLE001
                             torch.cuda.synchronize()
-                            state["on"] = False
-                            graph_stats["refused"] = f"{type(why).__name__}: {why}"[:300]
-                            if defer:                               # the eager step just run stopped at the pack: finish it
-                                bucket.all_reduce_packed()
-                                update_body()
-                            opt.zero_grad(set_to_none=True)
-                            return loss
+                            refused = f"{type(why).__name__}: {why}"[:300]
+                        # the outcome is agreed on by ALL ranks before anyone goes on: a rank that dropped to
+                        # the eager step on its own would issue another sequence of collectives than the ranks replaying
+                        # their graphs, and the job would hang until the launcher's limit.  One eager MIN all-reduce of an
+                        # ok flag per capture (three per run); if any rank's capture failed every rank leaves with exit
+                        # code 3 and the launcher starts the job again with the eager step (launch_ranks).
+                        if not capture_agreed(refused is None):
+                            graph_stats["refused"] = refused or "another rank's capture failed"
+                            sys.stderr.write(f"bench.py rank {rank}: capture of a partitioned sub-step refused "
+                                             f"({graph_stats['refused']}); leaving so that the eager step can run\n")
+                            sys.stderr.flush()
+                            os._exit(3)
                         graphs[key] = g
                         graph_stats["captured"] += 1
                         if defer:
@@ -902,88 +1062,81 @@ def cpu_full_step(nodes, edges, relations, hidden, neg_ratio, threads, steps=1):
 
 def cpu_baseline(args):
     """CPU oracle (kind "port": the torch restatement of the reference's PyG/PyGCL path -- PyG itself cannot be installed
-    here) timed on this box's host cores.  ``value``: ONE full training step (GGD + R-GCN/DistMult, fwd + bwd + clip +
-    Adam) on the FULL bench graph with all cores, through the memory-lean form of the oracle (``cpu_full_step``).  A
-    bounded probe on a 1/cpu_scale graph runs first (the plain oracle; reported as ``scaled_sample``); when it says the
-    full step would take more than ~4 minutes the scaled figure is the value instead and says so.  ``threads1``: the
-    same full step on ONE thread, measured once per round by ``scripts/cpu_baseline_full.py`` on the GPU box (it takes
-    minutes: not part of the default run) and read from profiles/."""
+    here) timed on this box's host cores.
+
+    ``value`` is LIVE and BOUNDED: full training steps (GGD + R-GCN/DistMult, fwd + bwd + clip + Adam) of the memory-lean
+    oracle (``cpu_full_step`` / oracle/lean.py) on a 1/``--cpu-scale`` graph of the bench graph's shape with all cores --
+    one untimed step, then timed steps for ~15 s.  ``full_size``: the same step on the FULL bench graph, which takes 100-110 s
+    of all 64 cores per step (180 s on one thread) and is therefore measured once per round on a GPU box of this pool by
+    ``scripts/cpu_baseline_full.py`` and read from profiles/*cpu_baseline_full.json (the default run was two
+    thirds CPU leg).  ``BKG_BENCH_CPU_FULL=1`` runs the full-size step live as well (``full_size_live``)."""
     from biomedkg_amd import synthetic
-    from oracle import ref_modules as R
+    from oracle import lean, ref_modules as R
     # the cores this process may actually run on (a cgroup-limited box reports more in cpu_count())
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
+    scale = max(args.cpu_scale, 1)
+    torch.set_num_threads(cores)
+    n, e = args.nodes // scale, args.edges // scale
+    g = synthetic.primekg_like(n, e, args.relations, seed=7)
+    torch.manual_seed(0)
+    xk, xg = torch.randn(n, args.hidden), torch.randn(n, 768)
+    kge = R.make_kge_model("rgcn", "dismult", args.hidden, args.hidden, args.hidden, 2, g["num_relations"])
+    ggd = R.GGD(R.GCNEncoder(768, args.hidden, args.hidden, 2), args.hidden, 1, 0.5)
+    ok, og = torch.optim.Adam(kge.parameters(), lr=1e-3), torch.optim.Adam(ggd.parameters(), lr=1e-3)
 
-    def run(scale, threads, budget):
-        torch.set_num_threads(threads)
-        n, e = args.nodes // scale, args.edges // scale
-        g = synthetic.primekg_like(n, e, args.relations, seed=7)
-        torch.manual_seed(0)
-        xk, xg = torch.randn(n, args.hidden), torch.randn(n, 768)
-        kge = R.make_kge_model("rgcn", "dismult", args.hidden, args.hidden, args.hidden, 2, g["num_relations"])
-        ggd = R.GGD(R.GCNEncoder(768, args.hidden, args.hidden, 2), args.hidden, 1, 0.5)
-        ok, og = torch.optim.Adam(kge.parameters(), lr=1e-3), torch.optim.Adam(ggd.parameters(), lr=1e-3)
+    def step():
+        og.zero_grad(); lean.ggd_loss(ggd, xg, g["edge_index"]).backward()
+        torch.nn.utils.clip_grad_norm_(ggd.parameters(), 1.0); og.step()
+        ok.zero_grad(); lean.kge_step(kge, xk, g["edge_index"], g["edge_type"], args.neg_ratio)[0].backward()
+        torch.nn.utils.clip_grad_norm_(kge.parameters(), 1.0); ok.step()
 
-        def step():
-            og.zero_grad(); lg = R.ggd_loss(ggd, xg, g["edge_index"]); lg.backward()
-            torch.nn.utils.clip_grad_norm_(ggd.parameters(), 1.0); og.step()
-            ok.zero_grad(); lk = R.kge_step(kge, xk, g["edge_index"], g["edge_type"], args.neg_ratio)[0]; lk.backward()
-            torch.nn.utils.clip_grad_norm_(kge.parameters(), 1.0); ok.step()
-
-        t0 = time.perf_counter()
-        step()  # warm-up (also bounds the cost: a slow host gets a single timed step)
-        warm = time.perf_counter() - t0
-        t0, reps = time.perf_counter(), 0
-        while reps < 1 or (time.perf_counter() - t0 + warm < budget and reps < 10):
-            step(); reps += 1
-        dt = (time.perf_counter() - t0) / reps
-        return n, e, g["num_relations"], reps, dt
-
-    n, e, r, reps, dt = run(args.cpu_scale, cores, 8.0)
-    scaled = {"value": e / dt, "unit": "edges/s", "cores": cores,
-              "sample": f"plain oracle, 1/{args.cpu_scale}-scale graph (N={n}, E={e}, R={r}), {reps} steps, {dt:.2f} s/step"}
-    full = None
-    if dt * args.cpu_scale < 240.0:          # bounded: skipped on a host where the scaled-up step says it would take too long
-        try:
-            sec, sec_ggd = cpu_full_step(args.nodes, args.edges, args.relations, args.hidden, args.neg_ratio, cores)
-            full = {"seconds_per_step": sec, "seconds_ggd": sec_ggd, "seconds_kge": sec - sec_ggd}
-        except Exception as why:             # noqa: BLE001  (e.g. not enough host memory)
-            full = {"error": f"{type(why).__name__}: {why}"[:200]}
-    # the one-thread figure of the same full step (and the all-core one of that run): measured by scripts/cpu_baseline_full.py
-    offline = None
+    budget = float(os.environ.get("BKG_BENCH_CPU_BUDGET_S", "15"))
+    t0 = time.perf_counter()
+    step()                                   # untimed: the allocator's first touch
+    warm = time.perf_counter() - t0
+    times = []
+    while not times or (sum(times) + times[-1] < budget and len(times) < 10):
+        t0 = time.perf_counter(); step(); times.append(time.perf_counter() - t0)
+    dt = min(times)
+    out = {"value": e / dt, "unit": "edges/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+           "seconds_per_step": dt, "steps_timed": len(times), "seconds_first_step": warm,
+           "sample": f"live: CPU oracle (oracle/lean.py), full GGD + R-GCN/DistMult training steps (fwd+bwd+clip+Adam) on a "
+                     f"1/{scale}-scale graph of the bench shape (N={n}, E={e}, R={g['num_relations']}, "
+                     f"neg_ratio={args.neg_ratio}), {cores} threads, fastest of {len(times)} steps = {dt:.2f} s; full_size = the "
+                     f"same step on the whole bench graph, measured per round on this pool's box (profiles/)"}
+    # the full-size step (all cores and ONE thread): measured by scripts/cpu_baseline_full.py
     try:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_baseline_full.json")), reverse=True):
-            offline = dict(json.load(open(path)), source=os.path.basename(path))
+            off = json.load(open(path))
+            out["full_size"] = {"value": off.get("edges_per_s_all_cores"), "seconds_per_step": off.get("seconds_all_cores"),
+                                "cores": off.get("cores"), "nodes": off.get("nodes"), "edges": off.get("edges"),
+                                "cpu_model": off.get("cpu_model"), "source": os.path.basename(path)}
+            out["threads1"] = {"value": off.get("edges_per_s_1_thread"), "seconds_per_step": off.get("seconds_1_thread"),
+                               "cores": 1, "thread_scaling": off.get("thread_scaling"), "source": os.path.basename(path)}
             break
     except Exception:  # noqa: BLE001
-        offline = None
-    if full and "seconds_per_step" in full:
-        sec = full["seconds_per_step"]
-        out = {"value": args.edges / sec, "unit": "edges/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-               "seconds_per_step": sec, "seconds_ggd_step": full["seconds_ggd"], "seconds_kge_step": full["seconds_kge"],
-               "sample": f"CPU oracle (torch restatement of the reference's PyG path, memory-lean form: oracle/lean.py), ONE "
-                         f"full training step -- GGD + R-GCN/DistMult, fwd + bwd + clip + Adam -- on the FULL bench graph "
-                         f"(N={args.nodes}, E={args.edges}, R={args.relations}, neg_ratio={args.neg_ratio}), {cores} threads, "
-                         f"{sec:.1f} s"}
-    else:
-        out = {"value": e / dt, "unit": "edges/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-               "sample": f"CPU oracle on a 1/{args.cpu_scale}-scale graph (N={n}, E={e}, R={r}), {reps} steps, {dt:.2f} s/step, "
-                         f"{cores} threads -- the full-size step was not run here ({full})"}
-    out["scaled_sample"] = scaled
-    out["threads1"] = (None if not offline else
-                       {"value": offline.get("edges_per_s_1_thread"), "unit": "edges/s", "cores": 1,
-                        "seconds_per_step": offline.get("seconds_1_thread"),
-                        "same_run_all_cores_seconds": offline.get("seconds_all_cores"),
-                        "thread_scaling": offline.get("thread_scaling"), "source": offline.get("source"),
-                        "sample": "the same full-size step on ONE thread, measured by scripts/cpu_baseline_full.py on a GPU "
-                                  "box of this pool (minutes per step: not part of the default bench run)"})
+        pass
+    if os.environ.get("BKG_BENCH_CPU_FULL") == "1":
+        try:
+            sec, sec_ggd = cpu_full_step(args.nodes, args.edges, args.relations, args.hidden, args.neg_ratio, cores)
+            out["full_size_live"] = {"value": args.edges / sec, "seconds_per_step": sec, "seconds_ggd": sec_ggd,
+                                     "seconds_kge": sec - sec_ggd, "cores": cores}
+        except Exception as why:             # noqa: BLE001  (e.g. not enough host memory)
+            out["full_size_live"] = {"error": f"{type(why).__name__}: {why}"[:200]}
     return out
 
 
 # ----------------------------------------------------------------------------------------------- main
-def _run_ranks(args, extra_env, limit_s):
+STEPS_MARK = "bench.py: structures built, steps start"      # rank 0 writes this to stderr right before its warm-up steps
+
+
+def _run_ranks(args, extra_env, limit_s, setup_limit_s=None):
     """Start N fresh interpreters on this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and wait for them.
-    -> (rank 0's stdout, exit codes, text for stderr).  ``limit_s``: end every rank when the attempt takes longer."""
+    -> (rank 0's stdout, exit codes, text for stderr).  ``limit_s``: end every rank when the STEPS (warm-up, timed loop,
+    side measurements -- everything after rank 0's ``STEPS_MARK``) take longer; ``setup_limit_s``: the same for what comes
+    before the mark (the first ``import torch`` on a fresh box pages the image in for 1-2 minutes, the rendezvous, the
+    partition's structures), so that a short limit on the steps never ends a healthy run that was merely slow to start."""
     import socket
     import subprocess
     import tempfile
@@ -1001,20 +1154,28 @@ def _run_ranks(args, extra_env, limit_s):
         logs.append(tempfile.TemporaryFile(mode="w+b"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=logs[-1]))
-    out, first_dead, note = None, None, ""
+    out, first_dead, note, t_mark = None, None, "", None
     t0 = time.time()
     while out is None:                              # a rank that dies early leaves the others waiting in a collective:
         try:                                        # end them instead of waiting for the caller's own limit
             out, _ = procs[0].communicate(timeout=2)
         except subprocess.TimeoutExpired:
             dead = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
-            late = limit_s is not None and time.time() - t0 > limit_s
+            if t_mark is None and (limit_s is not None or setup_limit_s is not None):
+                logs[0].seek(0)
+                if STEPS_MARK.encode() in logs[0].read():
+                    t_mark = time.time()
+                logs[0].seek(0, 2)
+            late = ((t_mark is not None and limit_s is not None and time.time() - t_mark > limit_s)
+                    or (t_mark is None and setup_limit_s is not None and time.time() - t0 > setup_limit_s))
             if dead or late:
                 if dead:
                     first_dead = dead[0]
                     note += f"bench.py --gpus {n}: rank {dead[0][0]} exited with {dead[0][1]}; ending the others\n"
+                elif t_mark is not None:
+                    note += f"bench.py --gpus {n}: no result {limit_s:.0f} s after the steps started; ending the ranks\n"
                 else:
-                    note += f"bench.py --gpus {n}: no result after {limit_s:.0f} s; ending the ranks\n"
+                    note += f"bench.py --gpus {n}: the ranks were not ready after {setup_limit_s:.0f} s; ending them\n"
                 for p in procs:
                     if p.poll() is None:
                         p.kill()
@@ -1043,6 +1204,30 @@ def _run_ranks(args, extra_env, limit_s):
     return out.decode(), codes, note
 
 
+def graphed_line_refused(stdout):
+    """Why the graphed attempt's line must not stand, or None: it has to be there, parse strictly, say that replays
+    happened, and show that they TRAINED -- both fixed-draw check losses finite and lower after the run than before."""
+    import math
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    if not lines:
+        return "no line"
+    try:
+        line = json.loads(lines[-1])
+    except ValueError as why:
+        return f"unparsable line: {why}"
+    gs = (line.get("exchange") or {}).get("graphed_sub_steps") or {}
+    if not gs.get("replayed") or gs.get("refused"):
+        return f"no replays ({gs})"
+    before, after = line.get("check_loss") or {}, line.get("check_loss_after") or {}
+    for key in ("ggd", "kge"):
+        a, b = before.get(key), after.get(key)
+        if not (isinstance(a, (int, float)) and isinstance(b, (int, float)) and math.isfinite(a) and math.isfinite(b)):
+            return f"check loss {key} missing or not finite ({a} -> {b})"
+        if not b < a:
+            return f"check loss {key} did not fall over the run ({a} -> {b})"
+    return None
+
+
 def launch_ranks(args):
     """``python3 bench.py --gpus N`` with no launcher around it: this process becomes the launcher -- it never touches
     the GPU (nothing before this point does: ``import torch`` and ``torch.cuda.device_count()`` do not initialise HIP on
@@ -1052,9 +1237,13 @@ def launch_ranks(args):
 
     Node-partitioned runs over RCCL try the GRAPHED sub-steps first (BKG_BENCH_PARTITION_GRAPH=1: every sub-step one
     hipGraph replay -- an eager partitioned step costs the host 3.6-5 ms to enqueue, more than a rank's kernels take from
-    four ranks on); captured collectives have only ever run on a one-rank RCCL group here (no multi-GPU box), so if that
-    attempt fails or yields nothing within BKG_BENCH_GRAPH_ATTEMPT_S (default 300 s) the ranks are started again with
-    the eager step, and the line says which form ran (``exchange.graphed_sub_steps``)."""
+    four ranks on).  Captured collectives have only ever run on a one-rank RCCL group here (no multi-GPU box), so that
+    attempt is fenced three ways: (1) its steps get BKG_BENCH_GRAPH_ATTEMPT_S (default 75 s, counted from
+    rank 0's "steps start" mark, not from process start) -- a run stuck in a collective is ended; (2) a rank whose capture
+    fails takes every rank out with it (``capture_agreed``), never a mix of replaying and eager ranks; (3) the line is
+    ACCEPTED only if it shows that the replays trained: both fixed-draw check losses finite and lower after the run than
+    before it (a graph that replays wrongly -- stale buffers, a collective out of order -- does not pass that).  Otherwise
+    the ranks are started again with the eager step.  The line says which form ran (``exchange.form``)."""
     n = args.gpus
     one_device = os.environ.get("BKG_BENCH_ONE_DEVICE") == "1"
     have = torch.cuda.device_count()
@@ -1064,14 +1253,16 @@ def launch_ranks(args):
     backend = os.environ.get("BKG_BENCH_BACKEND", "nccl")
     try_graphs = ("BKG_BENCH_PARTITION_GRAPH" not in os.environ and backend == "nccl" and args.mode in ("auto", "partition"))
     if try_graphs:
-        limit = float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "300"))
-        out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "1"}, limit)
-        if all(c == 0 for c in codes) and any(l.startswith("{") for l in out.splitlines()):
+        limit = float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "75"))
+        setup = float(os.environ.get("BKG_BENCH_SETUP_LIMIT_S", "600"))
+        out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "1"}, limit, setup)
+        why = graphed_line_refused(out) if all(c == 0 for c in codes) else f"exit codes {codes}"
+        if why is None:
             sys.stderr.write(note)
             sys.stdout.write(out)
             sys.stdout.flush()
             raise SystemExit(0)
-        sys.stderr.write(note + f"bench.py --gpus {n}: the graphed attempt failed (exit codes {codes}); running the eager step\n")
+        sys.stderr.write(note + f"bench.py --gpus {n}: the graphed attempt is not used ({why}); running the eager step\n")
     out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "0"} if try_graphs else {}, None)
     sys.stderr.write(note)
     sys.stdout.write(out)
@@ -1178,6 +1369,8 @@ def main():
     # 1.0-1.3 ms long (10.9-11.2 against 9.75 ms, every run; scripts/dev_first_step_syncs.py takes the loop apart).  So:
     # collect what the set-up left, switch the collector off, THEN warm up -- the timed steps see the allocator the warm-up
     # steps left
+    if rank == 0 and world > 1:
+        sys.stderr.write(STEPS_MARK + "\n"); sys.stderr.flush()
     for _ in range(args.warmup):
         step_g(); step_k()
     step_k.finish()
@@ -1265,6 +1458,7 @@ def main():
                     "ms_per_step_overlapped": wall_o, "ms_per_step_serial": wall_s,
                     "host_enqueue_ms_per_step": host_o, "library_calls_per_step": launches[0],
                     "graphed_sub_steps": getattr(step_g, "graph_stats", None),
+                    "form": "graphed sub-steps (hipGraph replays)" if graphed else "eager step",
                     "host_enqueue_ms_per_step_graphed": host_graphed,
                     "host_note": "host_enqueue_ms_per_step: the host's time to enqueue one step (no synchronisation inside it); a "
                                  "rank whose share of the kernels is shorter than that is launch-bound, whatever the wire does",
@@ -1408,7 +1602,7 @@ def main():
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
             "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_shuffled_neg_types": ms_shuffled_types,
             "ms_per_step_fresh_structures": ms_fresh,
-            "roofline": roof, "kernels": others, "exchange": exchange,
+            "roofline": roof, "roofline_model": ROOFLINE_MODEL, "kernels": others, "exchange": exchange,
             "step_accounting": None,
             "check_loss": getattr(step_g, "check_loss", None), "check_loss_after": check_after,
             "cpu_baseline": None,
@@ -1444,12 +1638,7 @@ def main():
     if world > 1 or forced:
         torch.distributed.destroy_process_group()
     if rank == 0:
-        try:      # RCCL writes its version banner through C stdio: flush it out BEFORE the line, which must come last
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:      # noqa: BLE001
-            pass
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail)
 
 
 if __name__ == "__main__":

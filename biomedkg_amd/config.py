@@ -92,4 +92,8 @@ def instantiate(cfg, **extra):
     kwargs = {k: v for k, v in cfg.items() if k != "_target_"}
     kwargs.update(extra)
     module, _, name = cfg["_target_"].rpartition(".")
+    # the reference's configs name its own package (configs/data/primekg.yaml: ``biomedkg.data_module.PrimeKGModule``): this
+    # build is the drop-in for those classes, so the verbatim target resolves to the class of the same name here
+    if module == "biomedkg" or module.startswith("biomedkg."):
+        module = "biomedkg_amd" + module[len("biomedkg"):]
     return getattr(importlib.import_module(module), name)(**kwargs)

@@ -37,18 +37,28 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+class _Done:
+    @staticmethod
+    def wait():
+        return True
+
+
 class GradBucket:
     """Averages the gradients of ``params`` across ranks with one flat all-reduce per call."""
 
-    def __init__(self, params, world=None, group=None):
+    def __init__(self, params, world=None, group=None, simulate=False):
         """``group``: the process group the all-reduce runs on (a bucket reduced on a stream of its own while another
-        communicator's collectives are in flight -- bench.py's graphed partitioned steps -- needs a group of its own)."""
+        communicator's collectives are in flight -- bench.py's graphed partitioned steps -- needs a group of its own).
+        ``simulate``: one process standing in for a rank of ``world`` (partition.Comm(simulate=True)): pack, scale and
+        write-back as live, the all-reduce itself replaced by a local round trip of the bucket's bytes."""
+        self.simulate = bool(simulate)
         self.params = [p for p in params if p.requires_grad]
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.group = group
         self._flat = None
         # (BKG_PARTITION_FORCE_COLLECTIVES=1: a 1-rank group still issues its all-reduce -- functional check of the calls)
-        self.live = self.world > 1 or (os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
+        self.live = (self.world > 1 or (os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
+                     or self.simulate)
 
     def pack(self):
         """The gradients copied into the flat bucket (``views``: the bucket seen through each parameter's shape)."""
@@ -71,6 +81,10 @@ class GradBucket:
         if not self.live:
             return
         self.pack()
+        if self.simulate:
+            self._flat.copy_(self._flat.clone())
+            self._work = _Done
+            return
         self._work = dist.all_reduce(self._flat, async_op=True, group=self.group)
 
     def finish(self):
@@ -88,7 +102,9 @@ class GradBucket:
 
     def all_reduce_packed(self):
         """The all-reduce of a bucket that ``pack`` filled (synchronous on the current stream); ``views`` hold the sums."""
-        if self.live:
+        if self.simulate:
+            self._flat.copy_(self._flat.clone())
+        elif self.live:
             dist.all_reduce(self._flat, group=self.group)
 
 

@@ -102,15 +102,29 @@ HALO_THRESHOLD = float(os.environ.get("BKG_HALO_THRESHOLD", "0.75"))   # halo ex
 EXACT_GATHER_WASTE = float(os.environ.get("BKG_EXACT_GATHER_WASTE", "1.1"))   # padded / real rows above which "all" is exact
 
 
+class _Done:
+    """A collective that has already happened (``Comm(simulate=True)``)."""
+
+    @staticmethod
+    def wait():
+        return True
+
+
 class Comm:
     """The exchange of one partition: ``exchange_begin`` / ``exchange_end`` move the rank's shard of a node table to the
     ranks that read it (RCCL / gloo run the collective on their own stream; ``end`` makes the current stream wait for
     it) and return the ``[world * n_max, d]`` table in slot space.  ``stats`` counts what crossed the wire and, with
     ``timed``, how long the compute stream waited (``exposed``) -- bench.py's ``wire_bytes_per_step`` /
-    ``exchange_exposed_ms``."""
+    ``exchange_exposed_ms``.
 
-    def __init__(self, world, n_local, n_max, group=None, rank=0):
+    ``simulate=True`` (one process standing in for rank ``rank`` of ``world``; bench.py's simulated-rank measurement): no
+    process group -- every exchange packs and lands exactly as the live one does, but the rows that would arrive over the
+    wire are a LOCAL copy of the same byte count (own rows, repeated), so the rank's kernels, pack / unpack passes and
+    buffer sizes are those of the real rank and only the wire itself is missing."""
+
+    def __init__(self, world, n_local, n_max, group=None, rank=0, simulate=False):
         self.world, self.n_local, self.n_max, self.group, self.rank = int(world), int(n_local), int(n_max), group, int(rank)
+        self.simulate = bool(simulate)
         # one rank has nothing to exchange; BKG_PARTITION_FORCE_COLLECTIVES=1 issues the collectives anyway (a 1-rank
         # RCCL group: the way to run the exact collective calls of the N-rank path on a single-GPU box)
         self.live = self.world > 1 or os.environ.get("BKG_PARTITION_FORCE_COLLECTIVES") == "1"
@@ -171,7 +185,11 @@ class Comm:
         if pat is None:
             # every row travels: the plain all-gather (from a copy of the shard: it already sits at its offset of the
             # table, and an input that aliases the output is not something every backend promises to take)
-            work = dist.all_gather_into_tensor(table, own.clone(), group=self.group, async_op=True)
+            if self.simulate:
+                table.view(self.world, self.n_max, table.size(1)).copy_(own.clone().unsqueeze(0).expand(self.world, -1, -1))
+                work = _Done
+            else:
+                work = dist.all_gather_into_tensor(table, own.clone(), group=self.group, async_op=True)
             self._count(el * self.n_max * (self.world - 1), el * self.n_max * (self.world - 1))
             return self._issued((table, work, None, None))
         if chunk is None:
@@ -179,10 +197,21 @@ class Comm:
         else:
             send_rows, send_counts, recv_slots, recv_counts = pat.parts[chunk]
         packed = own.index_select(0, send_rows)
-        recv = torch.empty(sum(recv_counts), table.size(1), dtype=table.dtype, device=table.device)
-        work = dist.all_to_all_single(recv, packed, recv_counts, send_counts, group=self.group, async_op=True)
+        if self.simulate:
+            recv, work = own.index_select(0, self._stand_in_rows(sum(recv_counts), own.device)), _Done
+        else:
+            recv = torch.empty(sum(recv_counts), table.size(1), dtype=table.dtype, device=table.device)
+            work = dist.all_to_all_single(recv, packed, recv_counts, send_counts, group=self.group, async_op=True)
         self._count(el * recv.size(0), el * packed.size(0))
         return self._issued((table, work, recv, recv_slots))
+
+    def _stand_in_rows(self, count, device):
+        """(simulate) ``count`` row numbers of the rank's own shard, cycling: what stands in for the rows off the wire."""
+        hit = getattr(self, "_stand_in", None)
+        if hit is None or hit.numel() < count or hit.device != device:
+            hit = torch.arange(max(count, 1), device=device) % max(self.n_local, 1)
+            self._stand_in = hit
+        return hit[:count]
 
     def _issued(self, pending):
         if self.serial:                                    # (measurement: the whole collective shows as exposed time)
@@ -248,8 +277,11 @@ class Comm:
         buf[:, : v.size(1)] = v
         if not self.live:
             return buf
-        out = torch.empty(self.world * v.size(0), self.n_max, dtype=v.dtype, device=v.device)
-        dist.all_gather_into_tensor(out, buf, group=self.group)
+        if self.simulate:
+            out = buf.repeat(self.world, 1)
+        else:
+            out = torch.empty(self.world * v.size(0), self.n_max, dtype=v.dtype, device=v.device)
+            dist.all_gather_into_tensor(out, buf, group=self.group)
         return out.view(self.world, v.size(0), self.n_max).permute(1, 0, 2).reshape(v.size(0), self.world * self.n_max)
 
 
@@ -263,7 +295,7 @@ class NodePartition:
 
     NODE_WEIGHT = 16.0
 
-    def __init__(self, edge_index, num_nodes, rank, world, node_weight=None, halo=None):
+    def __init__(self, edge_index, num_nodes, rank, world, node_weight=None, halo=None, simulate=False):
         self.num_nodes, self.rank, self.world = int(num_nodes), int(rank), int(world)
         dev = edge_index.device
         self.node_weight = float(self.NODE_WEIGHT if node_weight is None else node_weight)
@@ -279,7 +311,7 @@ class NodePartition:
         self.n_local = self.hi - self.lo
         self.n_max = max(max(b - a for a, b in zip(bounds[:-1], bounds[1:])), 1)
         self._bounds_t = torch.tensor(bounds, device=dev, dtype=torch.int64)
-        self.comm = Comm(world, self.n_local, self.n_max, rank=rank)
+        self.comm = Comm(world, self.n_local, self.n_max, rank=rank, simulate=simulate)
         self._valid = None
         self.halo_fraction = {}
         self.padding_waste = 1.0
@@ -976,7 +1008,7 @@ def ntxent_partitioned(h1_local, h2_local, tau, part: NodePartition, kernels=Non
 
 def loss_value(loss_local, world):
     """The whole-graph loss from the ranks' scaled shares (reporting only: one scalar all-reduce)."""
-    if world == 1:
+    if world == 1 or not dist.is_initialized():      # (a simulated rank reports its own share)
         return loss_local.detach()
     t = loss_local.detach().clone()
     dist.all_reduce(t)

@@ -64,13 +64,23 @@ def build_graph(df, encoder):
                 num_edge_types=len(edge_stores), edge_map_index=edge_map_index, node_list=node_list)
 
 
-def to_undirected(edge_index, edge_type):
-    """PyG ``T.ToUndirected()`` as the reference's DPI module applies it (``data_module.py:178``): append the
-    reversed edges (with the same type) and coalesce duplicates (sorted by (row, col))."""
+def to_undirected(edge_index, edge_type, num_nodes=None, reduce="add"):
+    """PyG 2.5.3 ``T.ToUndirected()`` as the reference's DPI module applies it (``data_module.py:178``; defaults
+    ``reduce="add", merge=True``): append the reversed edges with their types, then ``coalesce`` -- sort by
+    ``row * N + col``, merge duplicate pairs.  ``reduce="add"`` is PyG's default and what the reference runs: the edge
+    attributes of merged entries are SUMMED, ``edge_type`` included (a pair listed twice under relation r comes out as
+    2 r).  In the reference's DPI graph that is harmless -- one relation, id 0 -- and it is kept here for parity;
+    ``reduce="first"`` keeps the type of the first listed entry instead (ids stay valid on multi-relation input)."""
     ei = torch.cat([edge_index, edge_index.flip(0)], dim=1)
     et = torch.cat([edge_type, edge_type])
-    n = int(ei.max()) + 1 if ei.numel() else 0
+    n = int(num_nodes) if num_nodes is not None else (int(ei.max()) + 1 if ei.numel() else 0)
     key = ei[0] * n + ei[1]
     uniq, inv = torch.unique(key, return_inverse=True)
-    first = torch.full((uniq.numel(),), key.numel(), dtype=torch.long).scatter_reduce_(0, inv, torch.arange(key.numel()), "amin")
-    return torch.stack([uniq // n, uniq % n]), et[first]
+    if reduce == "add":
+        merged = torch.zeros(uniq.numel(), dtype=et.dtype).index_add_(0, inv, et)
+    elif reduce == "first":
+        first = torch.full((uniq.numel(),), key.numel(), dtype=torch.long).scatter_reduce_(0, inv, torch.arange(key.numel()), "amin")
+        merged = et[first]
+    else:
+        raise ValueError(reduce)
+    return torch.stack([uniq // n, uniq % n]), merged

@@ -31,3 +31,10 @@ class LightningModule(torch.nn.Module):
 
     def log_dict(self, d, **kwargs):
         self.__dict__.setdefault("_logged", {}).update(d)
+
+
+class LightningDataModule:
+    """Shim: ``save_hyperparameters`` is all the reference's data modules call (``biomedkg/data_module.py:40-41``)."""
+
+    def save_hyperparameters(self, *args, **kwargs):
+        pass

@@ -354,6 +354,58 @@ def gen_triplets():
                           node_type=tb.data.node_type, edge_map_index=tb.edge_map_index, node_list=tb.node_list))
 
 
+# --------------------------------------------------------------------------- data modules
+def gen_data_modules():
+    """The reference's own ``PrimeKGModule`` / ``DPIModule`` (``biomedkg/data_module.py``, unmodified) set up over the toy
+    tables ``scripts/make_toy_kg.py`` writes: pandas and the reference's ``TripletBase`` / ``PrimeKG`` / ``DPI`` /
+    ``RandomEncode`` are the real thing; ``HeteroData.to_homogeneous``, ``RandomLinkSplit`` and ``ToUndirected`` come from
+    the shims (oracle/shims/torch_geometric: PyG restated).  Recorded: the graph, the features and the three splits under
+    a fixed seed.  The tables travel with the fixture as ``tests/golden/toy_kg.csv`` / ``toy_dpi.csv`` (data written by
+    the committed script, which the test re-runs and compares)."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import make_toy_kg
+    work = tempfile.mkdtemp(prefix="bkg_dm_")
+    cwd = os.getcwd()
+    try:
+        os.makedirs(os.path.join(work, "ckpt", "gcl"))          # (node.py's GCLEncode asserts on it at import time)
+        kg = os.path.join(work, "data", "primekg", "kg.csv")
+        dpi = os.path.join(work, "data", "dpi", "dpi_benchmark.csv")
+        make_toy_kg.write_kg_csv(kg)
+        make_toy_kg.write_dpi_csv(dpi)
+        shutil.copy(kg, os.path.join(HERE, "toy_kg.csv"))
+        shutil.copy(dpi, os.path.join(HERE, "toy_dpi.csv"))
+        os.chdir(work)
+        from biomedkg import data_module as ref_dm
+        out = {}
+        pick = lambda d: dict(x=d.x.clone(), edge_index=d.edge_index.clone(), edge_type=d.edge_type.clone())   # noqa: E731
+        for name, make in (
+            ("primekg", lambda: ref_dm.PrimeKGModule(data_dir="data/primekg", embed_dim=16, batch_size=8, val_ratio=0.2,
+                                                     test_ratio=0.1, node_type=["gene/protein", "drug", "disease"],
+                                                     node_init_method="random")),
+            ("primekg_gene", lambda: ref_dm.PrimeKGModule(data_dir="data/primekg", embed_dim=8, batch_size=8, val_ratio=0.25,
+                                                          test_ratio=0.25, node_type=["gene/protein"], node_init_method=None)),
+            ("dpi", lambda: ref_dm.DPIModule(data_dir="data/dpi/dpi_benchmark.csv", embed_dim=16, batch_size=8, val_ratio=0.2,
+                                             test_ratio=0.2, node_init_method="random")),
+        ):
+            seed_all(11)
+            dm = make()
+            dm.setup(stage="split")
+            ds = dm.primekg if name.startswith("primekg") else dm.dpi
+            rec = dict(data=pick(dm.data), node_type=dm.data.node_type.clone(), num_edge_types=dm.data.num_edge_types,
+                       edge_map_index=dict(dm.edge_map_index), node_list=list(ds.node_list), seed=11)
+            for split in ("train", "val", "test"):
+                d = getattr(dm, split + "_data")
+                rec[split] = dict(edge_index=d.edge_index.clone(), edge_type=d.edge_type.clone(),
+                                  edge_label=d.edge_label.clone(), edge_label_index=d.edge_label_index.clone())
+            out[name] = rec
+        save("data_modules", out)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         raise SystemExit("the reference is only mounted in the authoring container")
@@ -364,5 +416,6 @@ if __name__ == "__main__":
     gen_ckpt()
     gen_metric()
     gen_triplets()
+    gen_data_modules()
     # the reference tree must stay clean
     assert not any("__pycache__" in d for d, _, _ in os.walk(REF)), "left bytecode in /root/reference"

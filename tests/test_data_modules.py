@@ -1,0 +1,185 @@
+"""The data modules over real triplet tables (reference biomedkg/data_module.py:27-145, 148-259 and
+data/dataset/_base.py:23-89): ``PrimeKGModule`` / ``DPIModule`` built here against a fixture recorded from the reference's
+OWN classes (tests/golden/make_goldens.py gen_data_modules: unmodified data_module.py / TripletBase / RandomEncode over
+the toy tables of scripts/make_toy_kg.py; to_homogeneous / RandomLinkSplit / ToUndirected from the PyG shims) -- same
+seed, same graph, same features, same splits, bit for bit."""
+import os
+import pickle
+import shutil
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture()
+def tables(tmp_path):
+    os.makedirs(tmp_path / "primekg")
+    shutil.copy(os.path.join(GOLDEN, "toy_kg.csv"), tmp_path / "primekg" / "kg.csv")
+    shutil.copy(os.path.join(GOLDEN, "toy_dpi.csv"), tmp_path / "dpi.csv")
+    return tmp_path
+
+
+def test_the_committed_tables_are_what_the_committed_script_writes(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import make_toy_kg
+    make_toy_kg.write_kg_csv(str(tmp_path / "kg.csv"))
+    make_toy_kg.write_dpi_csv(str(tmp_path / "dpi.csv"))
+    assert (tmp_path / "kg.csv").read_bytes() == open(os.path.join(GOLDEN, "toy_kg.csv"), "rb").read()
+    assert (tmp_path / "dpi.csv").read_bytes() == open(os.path.join(GOLDEN, "toy_dpi.csv"), "rb").read()
+
+
+def _same(dm, ds, rec):
+    d = dm.data
+    assert torch.equal(d.x, rec["data"]["x"])                              # RandomEncode: the same draws in the same order
+    assert torch.equal(d.edge_index, rec["data"]["edge_index"]) and torch.equal(d.edge_type, rec["data"]["edge_type"])
+    assert torch.equal(d.node_type, rec["node_type"]) and d.num_edge_types == rec["num_edge_types"]
+    assert d.num_nodes == rec["data"]["x"].size(0)
+    assert dm.edge_map_index == rec["edge_map_index"] and ds.node_list == rec["node_list"]
+    for split in ("train", "val", "test"):
+        got, want = getattr(dm, split + "_data"), rec[split]
+        for key in ("edge_index", "edge_type", "edge_label", "edge_label_index"):
+            assert torch.equal(getattr(got, key), want[key]), (split, key)
+        assert got.x is d.x and got.num_edge_types == d.num_edge_types
+
+
+@pytest.mark.parametrize("case", ["primekg", "primekg_gene"])
+def test_primekg_module_matches_the_reference(golden, tables, case):
+    from biomedkg_amd.data_module import PrimeKGModule
+    rec = golden("data_modules")[case]
+    kw = (dict(embed_dim=16, val_ratio=0.2, test_ratio=0.1, node_type=["gene/protein", "drug", "disease"], node_init_method="random")
+          if case == "primekg" else dict(embed_dim=8, val_ratio=0.25, test_ratio=0.25, node_type=["gene/protein"], node_init_method=None))
+    torch.manual_seed(rec["seed"])
+    dm = PrimeKGModule(data_dir=str(tables / "primekg"), batch_size=8, **kw)
+    dm.setup(stage="split")
+    _same(dm, dm.primekg, rec)
+    if case == "primekg":
+        # one direction per relation survives, the two extra node types are filtered out
+        assert dm.data.edge_index.size(1) == 463 and dm.data.num_edge_types == 7 and dm.data.num_nodes == 119
+        e = dm.data.edge_index.size(1)
+        assert dm.train_data.edge_index.size(1) == e - int(0.2 * e) - int(0.1 * e)
+        assert dm.test_data.edge_index.size(1) == e - int(0.1 * e)
+    # stage != "split": the graph only
+    dm2 = PrimeKGModule(data_dir=str(tables / "primekg"), batch_size=8, **kw)
+    dm2.setup(stage="all")
+    assert not hasattr(dm2, "train_data") and dm2.data.num_nodes == dm.data.num_nodes
+
+
+def test_dpi_module_matches_the_reference(golden, tables):
+    from biomedkg_amd.data_module import DPIModule
+    rec = golden("data_modules")["dpi"]
+    torch.manual_seed(rec["seed"])
+    dm = DPIModule(data_dir=str(tables / "dpi.csv"), embed_dim=16, batch_size=8, val_ratio=0.2, test_ratio=0.2,
+                   node_init_method="random")
+    dm.setup(stage="split")
+    _same(dm, dm.dpi, rec)
+    ei = dm.data.edge_index
+    assert torch.equal(ei.flip(0)[:, torch.argsort(ei[1] * dm.data.num_nodes + ei[0])], ei)     # undirected, coalesced
+    assert int(dm.data.edge_type.max()) == 0                                                    # one relation: sums stay 0
+
+
+def test_missing_tables_are_errors_that_say_where_the_file_goes(tmp_path):
+    from biomedkg_amd.data_module import DPIModule, PrimeKGModule
+    with pytest.raises(FileNotFoundError, match="kg.csv"):
+        PrimeKGModule(data_dir=str(tmp_path), embed_dim=8, node_type=["drug"], batch_size=4, val_ratio=0.2, test_ratio=0.2).setup()
+    with pytest.raises(FileNotFoundError, match="DPI"):
+        DPIModule(data_dir=str(tmp_path / "nope.csv"), embed_dim=8, batch_size=4, val_ratio=0.2, test_ratio=0.2).setup()
+
+
+def test_the_reference_configs_instantiate_verbatim(tables):
+    """configs/data/primekg.yaml keeps the reference's ``_target_: biomedkg.data_module.PrimeKGModule``: it resolves to this
+    build's class (the default command line raised ModuleNotFoundError)."""
+    from biomedkg_amd import config
+    from biomedkg_amd.data_module import DPIModule, PrimeKGModule
+    cfg = config.compose(os.path.join(ROOT, "configs"), "kge", [f"data.data_dir={tables / 'primekg'}", "data.embed_dim=8"])
+    assert cfg.data["_target_"] == "biomedkg.data_module.PrimeKGModule"
+    dm = config.instantiate(cfg.data, gcl_model=cfg.gcl_model, gcl_fuse_method=cfg.gcl_fuse_method)
+    assert isinstance(dm, PrimeKGModule)
+    dm.setup(stage="split")
+    assert dm.data.num_edge_types == 7 and dm.train_data.edge_index.size(1) > 0
+    cfg = config.compose(os.path.join(ROOT, "configs"), "dpi", [f"data.data_dir={tables / 'dpi.csv'}"])
+    assert isinstance(config.instantiate(cfg.data, gcl_model=cfg.gcl_model, gcl_fuse_method=cfg.gcl_fuse_method), DPIModule)
+
+
+def test_pickled_node_features_lm_and_gcl(tables, monkeypatch):
+    """``lm`` / ``gcl`` node features come from the reference's pickles ({name: array}); a name that is not in the
+    dictionary gets a random block and counts into ``random_init_ratio``; a missing pickle is an error that names it."""
+    from biomedkg_amd.data_module import PrimeKGModule
+    monkeypatch.chdir(tables)
+    kw = dict(data_dir=str(tables / "primekg"), embed_dim=6, node_type=["drug"], batch_size=4, val_ratio=0.2, test_ratio=0.2)
+    with pytest.raises(FileNotFoundError, match="primekg_modality_lm.pickle"):
+        PrimeKGModule(node_init_method="lm", **kw)
+    import numpy as np
+    os.makedirs(tables / "data" / "embed")
+    table = {f"drug-{i:03d}": np.full((2, 6), float(i), dtype=np.float64) for i in range(1, 40, 2)}
+    pickle.dump(table, open(tables / "data" / "embed" / "primekg_modality_lm.pickle", "wb"))
+    dm = PrimeKGModule(node_init_method="lm", **kw)
+    dm.setup(stage="split")
+    x, names = dm.data.x, dm.primekg.node_list
+    assert x.shape == (len(names), 2, 6) and x.dtype == torch.float32
+    for i, name in enumerate(names):
+        if name in table:
+            assert torch.equal(x[i], torch.full((2, 6), float(int(name[-3:]))))
+    assert 0 < dm.encoder.random_init_ratio < 1
+    os.makedirs(tables / "data" / "gcl_embed")
+    pickle.dump({n: np.ones((1, 6), dtype=np.float32) for n in names[:5]}, open(tables / "data" / "gcl_embed" / "ggd_redaf.pickle", "wb"))
+    dm = PrimeKGModule(node_init_method="gcl", gcl_model="ggd", gcl_fuse_method="redaf", **kw)
+    dm.setup(stage="all")
+    assert dm.data.x.shape == (len(names), 1, 6) and torch.equal(dm.data.x[:5], torch.ones(5, 1, 6))
+
+
+def test_star_loader_is_the_one_hop_in_neighbourhood(tables):
+    from biomedkg_amd.data_module import PrimeKGModule
+    dm = PrimeKGModule(data_dir=str(tables / "primekg"), embed_dim=4, node_type=["gene/protein", "drug"], batch_size=4,
+                       val_ratio=0.2, test_ratio=0.2)
+    dm.setup(stage="all")
+    loader = dm.subgraph_dataloader()
+    assert len(loader) == dm.data.num_nodes
+    ei, et = dm.data.edge_index, dm.data.edge_type
+    for v, b in enumerate(loader):
+        into = torch.nonzero(ei[1] == v).squeeze(1)
+        assert b.batch_size == 1 and int(b.n_id[0]) == v and torch.equal(b.e_id, into)
+        assert torch.equal(b.n_id[b.edge_index[0]], ei[0, into]) and bool((b.edge_index[1] == 0).all())
+        assert torch.equal(b.edge_type, et[into]) and torch.equal(b.x, dm.data.x[b.n_id])
+        assert b.n_id.unique().numel() == b.n_id.numel()
+        if v > 25:
+            break
+
+
+@pytest.mark.gpu
+def test_entry_points_run_on_the_tables_with_the_reference_command_line(tables, monkeypatch):
+    """``python train_kge.py debug=true`` / ``train_gcl.py`` / ``train_dpi.py`` with the reference's own default data
+    configs (only ``data_dir`` pointed at the toy tables and the widths cut down): PrimeKGModule / DPIModule -> device
+    GraphSAINT / NeighborLoader batches -> the HIP training step."""
+    import train_gcl
+    import train_kge
+    small = ["data.embed_dim=32", "model.in_dim=32", "model.hidden_dim=16", "model.out_dim=16", "debug=true",
+             f"ckpt_dir={tables / 'ckpt'}", "devices=[0]"]
+    out = train_kge.main([f"data.data_dir={tables / 'primekg'}", "neg_ratio=2"] + small)
+    assert out and any(k.startswith("test_") for k in out[0])
+    out = train_gcl.main([f"data.data_dir={tables / 'primekg'}", "data.node_type=gene", "model.model_name=ggd"] + small)
+    assert "test_loss" in out[0]
+    out = train_kge.main([f"data.data_dir={tables / 'dpi.csv'}", "neg_ratio=3"] + small, config_name="dpi")
+    assert out and isinstance(out[0], dict)
+
+
+@pytest.mark.gpu
+def test_loaders_of_the_real_module_hand_out_device_batches(tables):
+    from biomedkg_amd.data_module import PrimeKGModule
+    torch.manual_seed(3)
+    dm = PrimeKGModule(data_dir=str(tables / "primekg"), embed_dim=8, node_type=["gene/protein", "drug", "disease"],
+                       batch_size=16, val_ratio=0.2, test_ratio=0.2)
+    dm.setup(stage="split")
+    loader = dm.train_dataloader(loader_type="neighbor")
+    assert len(loader) == (dm.data.num_nodes + 15) // 16
+    b = next(iter(loader))
+    assert b.x.is_cuda and b.batch_size == 16 and b.edge_index.dtype == torch.int64 and b.edge_type.numel() == b.edge_index.size(1)
+    tr = dm.train_data.edge_index.cuda()
+    assert torch.equal(b.n_id[b.edge_index], tr[:, b.e_id])               # every batch edge is a train edge, relabelled
+    saint = dm.train_dataloader(loader_type="saint")
+    assert len(saint) == 1000 and len(dm.val_dataloader(loader_type="saint")) == 100
+    b = next(iter(saint))
+    assert torch.equal(b.n_id[b.edge_index], tr[:, b.e_id]) and torch.equal(b.edge_type, dm.train_data.edge_type.cuda()[b.e_id])

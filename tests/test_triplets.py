@@ -24,5 +24,9 @@ def test_to_undirected():
     from biomedkg_amd.triplets import to_undirected
     ei = torch.tensor([[0, 1, 2, 1], [1, 0, 3, 0]])
     et = torch.tensor([5, 5, 7, 5])
+    # PyG's ToUndirected(reduce="add"), what the reference runs: merged duplicates SUM their attributes, edge_type included
+    # ((0, 1) is listed once forward and twice as a reversed (1, 0): 5 + 5 + 5)
     u, t = to_undirected(ei, et)
+    assert u.tolist() == [[0, 1, 2, 3], [1, 0, 3, 2]] and t.tolist() == [15, 15, 7, 7]
+    u, t = to_undirected(ei, et, reduce="first")
     assert u.tolist() == [[0, 1, 2, 3], [1, 0, 3, 2]] and t.tolist() == [5, 5, 7, 7]
