@@ -317,8 +317,8 @@ def compact_line(out, detail_path=None):
     if out.get("exchange"):
         ex = _pick(out["exchange"], _EXCHANGE_KEYS)
         gs = out["exchange"].get("graphed_sub_steps")
-        if isinstance(gs, dict):
-            ex["graphed_sub_steps"] = {k: (_short(v, 120) if isinstance(v, str) else v) for k, v in gs.items()}
+        ex["graphed_sub_steps"] = ({k: (_short(v, 120) if isinstance(v, str) else v) for k, v in gs.items()}
+                                   if isinstance(gs, dict) else None)
         line["exchange"] = ex
     for k in _SIDE_KEYS:
         if out.get(k) is not None:

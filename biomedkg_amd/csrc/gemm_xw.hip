@@ -602,6 +602,217 @@ __global__ __launch_bounds__(512) void gemm_xw8_grouped_kernel(XwArgs g, GemmEpi
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- K = 256 KC (KC = 2, 3), N a multiple of 256, bf16 rows: a 256-column WEIGHT SLAB in registers for the block's life ---
+// The K = 768 products (ReDAF, AttentionFusion's two products, the first GCN layer; reference biomedkg/utils/fusion.py:17-31,
+// 49-90, model/encoder.py:153-162) through gemm_xw_kernel re-read A once per 128-column slab -- six times at N = 768 -- in
+// MFMA-fragment shape (every 128-byte line asked for four times): 0.84 ms = 365 TF for ReDAF at 130k nodes.
+// Here the block is gemm_xw8_kernel's -- 8 waves, wave w owns columns [32 w, 32 w + 32) of the block's 256, A tiles by
+// LDS-DMA into a ring, one raw barrier per tile, counted vmcnt waits -- extended along K: the wave keeps its 32 weight rows
+// for ALL K as 16 KC MFMA operands (192 VGPRs at K = 768).  That leaves 64 registers, so a tile is 32 rows (ONE 32 x 32
+// accumulator, 16 registers; the 64-row form spilled -- and a spill is a scratch access on the vmcnt counter the ring is
+// waited by) x all K: KC planes of 32 rows x 512 B, gemm_xw8_kernel's swizzle inside a plane; three ring slots (48 KB each
+// at K = 768), two tiles in flight.  Per tile and CU: 48 KB through the DMA, 384 KB of LDS fragment reads (1536 clocks at
+// 256 B/clk) under 2 x 1536 MFMA clocks per SIMD: matrix-pipe bound, not LDS bound.
+//   A block's column group is FIXED (the weights are loaded once): N / 256 column groups x row-tile streams.  The blocks
+// that walk the same row tiles for the N / 256 column groups carry the same blockIdx.x % 8 -- one XCD under round-robin
+// placement (speed only) -- and run in step, so A comes from HBM once and from that XCD's L2 for the other groups.
+//   Nothing in the loop is an ordinary global load (hipcc would drain the DMA ring at its first use): bias and the ReDAF
+// scale rows of the block's columns are staged into LDS behind the ring (ONE __shared__ object) before the first DMA.
+//   vmcnt bookkeeping: tile i's DMAs are issued in iteration i - 2, behind its barrier; behind them this wave issues the
+// stores of tile i - 2, the DMAs of tile i + 1 and the stores of tile i - 1 (a partial tile -- fewer stores -- can only be
+// a block's last): the wait before tile i leaves exactly those in flight.
+constexpr int XK_BM = 32, XK_NS = 3;
+constexpr int XK_CONST_BYTES = 3 * 256 * 4;   // bias | ReDAF scale of modality 0 | of modality 1, this block's 256 columns
+#ifndef XK_PF
+#define XK_PF 3          // A fragments read ahead of their MFMA (4 registers each; 192 of the 256 are the weights)
+#endif
+
+template <int N> __device__ __forceinline__ void xk_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS reads of this kernel are hand-issued: (a) left to hipcc, the 16 KC fragment reads are either hoisted until the
+// kernel's state spills (a spill is a scratch access on the vmcnt counter the ring is waited by) or, with the order pinned
+// by sched_group_barrier, each read is waited for right in front of its MFMA; (b) hipcc puts s_waitcnt vmcnt(0) in front of
+// a read of the constants behind the ring (it cannot tell them from the slots the DMAs in flight are writing).
+typedef float xk_f4_t __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ xw_bf16x8_t xk_frag(uint32_t addr) {
+  xw_bf16x8_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void xk_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);      // (an MFMA touches no memory: the clobber alone does not keep it behind the wait)
+}
+template <int OFF> __device__ __forceinline__ float4 xk_const4(uint32_t addr) {
+  xk_f4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+// step S of a tile's 16 KC k-steps: the fragment of step S + XK_PF leaves, the wait leaves the younger reads in flight
+template <int S, int KC> __device__ __forceinline__ void xk_step(xw_acc_t& acc, const xw_bf16x8_t (&w)[KC][16],
+                                                                 xw_bf16x8_t (&a)[XK_PF + 1], uint32_t tile, int p16) {
+  constexpr int T = 16 * KC, NX = S + XK_PF;
+  if constexpr (NX < T)
+    a[NX % (XK_PF + 1)] = xk_frag<(NX / 16) * (XK_BM * 512)>(tile + (uint32_t)(((NX % 16) * 32) ^ p16));
+  xk_lgkm<(T - 1 - S) < XK_PF ? (T - 1 - S) : XK_PF>();
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[S / 16][S % 16], a[S % (XK_PF + 1)], acc, 0, 0, 0);
+  if constexpr (S + 1 < T) xk_step<S + 1, KC>(acc, w, a, tile, p16);
+}
+
+template <typename CT, int KC, bool REDAF>
+__global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue ep, int n_groups, int streams) {
+  constexpr int SLOT = XK_BM * KC * 512;
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[XK_NS * SLOT + XK_CONST_BYTES];
+  float* cst = reinterpret_cast<float*>(ring + XK_NS * SLOT);
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ring;
+  // 192 of the 256 registers hold weights: everything wave-uniform is kept in SGPRs (readfirstlane), and what depends on the
+  // lane is derived from the thread id again in every iteration (tid is laundered there, so hipcc cannot keep a dozen
+  // loop-invariant lane values in registers for the kernel's life -- it then spilled weights, into the loop)
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int cg = jb % n_groups, rs = jb / n_groups;
+  const int n0 = cg * 256 + wave * 32;
+  const __bf16* __restrict__ A = reinterpret_cast<const __bf16*>(g.A);
+  const int m_tiles = (g.M + XK_BM - 1) / XK_BM, stride = streams * 8, first = rs * 8 + xcd;
+  if (first >= m_tiles) return;   // block-uniform, before any barrier
+
+  // constants of the block's columns -> LDS (ordinary loads: BEFORE the first DMA)
+  if (threadIdx.x < 256) {
+    const int e = threadIdx.x;
+    cst[e] = ep.bias ? ep.bias[cg * 256 + e] : 0.f;
+    if constexpr (REDAF) {
+      cst[256 + e] = g.rd_scale[cg * 256 + e];
+      cst[512 + e] = g.rd_scale[(int64_t)g.N + cg * 256 + e];
+    }
+  }
+  uint32_t sid = 0;
+  if constexpr (REDAF) sid = __builtin_amdgcn_readfirstlane(with_epoch(g.rd_stream, g.rd_epoch));
+  // the weights: rows n0 + l31, all K
+  xw_bf16x8_t w[KC][16];
+  {
+    const int l31 = threadIdx.x & 31, lh = (threadIdx.x >> 5) & 1;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        w[kc][ks] = *reinterpret_cast<const xw_bf16x8_t*>(g.Wt + (int64_t)(n0 + l31) * g.ldw + kc * 256 + ks * 16 + lh * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                 // cst is visible; nothing is in flight
+
+  // DMA pieces of a lane: rows wave * 4 + 2 j + (lane >> 5) of a tile, every K plane, 16-byte chunk lane & 31 (swizzled source)
+  auto issue = [&](int slot, int tile, int l31, int lh) {
+    const uint32_t base = (uint32_t)(slot * SLOT + wave * (4 * 512));
+    const int m0 = tile * XK_BM;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = wave * 4 + 2 * j + lh;
+      const int r = max(0, min(m0 + rr, g.M - 1));   // past the end: valid memory, never stored
+      const __bf16* src = A + (int64_t)r * g.lda + ((l31 ^ rr) * 8);
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + kc * 256),
+                                         (__attribute__((address_space(3))) void*)(ring + base + kc * (XK_BM * 512) + j * 1024), 16, 0, 0);
+    }
+  };
+  issue(0, first, threadIdx.x & 31, (threadIdx.x >> 5) & 1);
+  issue(1, first + stride, threadIdx.x & 31, (threadIdx.x >> 5) & 1);
+
+  constexpr int D = 2 * KC;                                         // DMA instructions per wave and tile
+  constexpr int SPT = REDAF ? 4 : (sizeof(CT) == 2 ? 2 : 4);        // store instructions per wave and tile
+  int slot = 0, it = 0;
+  float keep_scale = 1.0f;
+  uint32_t thresh = 0u;
+  if constexpr (REDAF) {
+    if (g.rd_p > 0.f) keep_scale = 1.0f / (1.0f - g.rd_p);
+    keep_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, keep_scale)));
+    thresh = __builtin_amdgcn_readfirstlane((uint32_t)fminf(g.rd_p * 4294967296.0f, 4294967295.0f));
+  }
+  for (int t = first; t < m_tiles; t += stride) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int l31 = tid & 31, lh = (tid >> 5) & 1;
+    if (it >= 2) xk_wait<D + 2 * SPT>();
+    else if (it == 1) xk_wait<D + SPT>();
+    else xk_wait<D>();
+    ++it;
+    __builtin_amdgcn_s_barrier();      // ... every wave's pieces have landed, and every wave is done with the slot refilled next
+    issue(slot == 0 ? XK_NS - 1 : slot - 1, t + 2 * stride, l31, lh);
+    xw_acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+      const int p16 = (lh ^ l31) * 16;
+      const uint32_t tile = ring_lds + (uint32_t)(slot * SLOT + l31 * 512);
+      xw_bf16x8_t a[XK_PF + 1];
+#pragma unroll
+      for (int s0 = 0; s0 < XK_PF; ++s0) a[s0] = xk_frag<0>(tile + (uint32_t)((s0 * 32) ^ p16));   // (XK_PF <= 16: plane 0)
+      xk_step<0, KC>(acc, w, a, tile, p16);
+    }
+    slot = slot + 1 == XK_NS ? 0 : slot + 1;
+    // acc[4q..4q+3] = C[t * 32 + l31][n0 + 8 q + 4 lh + 0..3]
+    const uint32_t cb = ring_lds + (uint32_t)(XK_NS * SLOT + (wave * 32 + 4 * lh) * 4);
+    const int row = t * XK_BM + l31;
+    if constexpr (REDAF) {
+      // ReDAF.forward behind the product (reference biomedkg/utils/fusion.py:49-90), as gemm_xw_kernel<.., REDAF> runs it:
+      // the two modality rows of a node are the lanes l31 and l31 ^ 1; the Philox stream is indexed exactly as
+      // bkg_redaf_combine_f32 indexes it (the same masks, the same bits out)
+      const int mrow = l31 & 1;
+      const bool live = row < g.M;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int off = q * 8 + lh * 4, col = n0 + off;
+        float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        const float4 b = xk_const4<0>(cb + 32 * q);
+        v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f); v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+        const float4 sc = xk_const4<1024>(cb + 1024 * mrow + 32 * q);
+        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+        if (g.rd_p > 0.f) {
+          const uint4 r = philox_keep4(g.rd_seed, (uint64_t)(g.rd_row0 + row) * g.N + col, sid);
+          v.x = r.x >= thresh ? v.x * keep_scale : 0.f; v.y = r.y >= thresh ? v.y * keep_scale : 0.f;
+          v.z = r.z >= thresh ? v.z * keep_scale : 0.f; v.w = r.w >= thresh ? v.w * keep_scale : 0.f;
+        }
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        float4 o;
+        o.x = __shfl_xor(v.x, 1, 64); o.y = __shfl_xor(v.y, 1, 64); o.z = __shfl_xor(v.z, 1, 64); o.w = __shfl_xor(v.w, 1, 64);
+        if (live && mrow == 0)   // modality 0 first, as the two-kernel form adds them: bit-equal
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)(row >> 1) * g.ldc + col) =
+              make_float4((v.x + o.x) * 0.5f, (v.y + o.y) * 0.5f, (v.z + o.z) * 0.5f, (v.w + o.w) * 0.5f);
+      }
+    } else {
+      if (row < g.M) {
+        CT* __restrict__ drow_p = reinterpret_cast<CT*>(g.C) + (int64_t)row * g.ldc + n0;
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          float4 v[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int q = 2 * qp + h;
+            const float4 b = xk_const4<0>(cb + 32 * q);
+            v[h] = make_float4(ep.alpha * acc[4 * q] + b.x, ep.alpha * acc[4 * q + 1] + b.y,
+                               ep.alpha * acc[4 * q + 2] + b.z, ep.alpha * acc[4 * q + 3] + b.w);
+            if (ep.act == 1) {
+              v[h].x = fmaxf(v[h].x, 0.f); v[h].y = fmaxf(v[h].y, 0.f); v[h].z = fmaxf(v[h].z, 0.f); v[h].w = fmaxf(v[h].w, 0.f);
+            } else if (ep.act == 2) {
+              v[h].x = v[h].x > 0.f ? v[h].x : expm1f(v[h].x); v[h].y = v[h].y > 0.f ? v[h].y : expm1f(v[h].y);
+              v[h].z = v[h].z > 0.f ? v[h].z : expm1f(v[h].z); v[h].w = v[h].w > 0.f ? v[h].w : expm1f(v[h].w);
+            }
+          }
+          xw_store_pair(drow_p + 16 * qp, lh, v[0], v[1]);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile
+}
+
+// grid of gemm_xw8k_kernel: 8 (XCD classes) x column groups x row-tile streams, at most one block per CU
+static inline void xk_grid(int64_t M, int64_t N, int* n_groups, int* streams, unsigned* blocks) {
+  const int ng = (int)(N / 256);
+  int st = std::max(1, (256 / 8) / ng);
+  st = (int)std::min<int64_t>(st, ceil_div(ceil_div(M, XK_BM), 8));
+  *n_groups = ng; *streams = st; *blocks = (unsigned)(8 * ng * st);
+}
+
 // weights -> the [N][K] bf16 image the kernel above reads (a 64 x 64 patch per block through LDS)
 __global__ __launch_bounds__(256) void weight_to_bf16_kernel(const float* __restrict__ W, int64_t ldw, int64_t stride_w,
                                                              int rows, int cols, __bf16* __restrict__ out, int64_t ldo,
@@ -627,6 +838,12 @@ __global__ __launch_bounds__(256) void weight_to_bf16_kernel(const float* __rest
 }  // namespace bkg
 
 using namespace bkg;
+
+// BKG_XW_SLAB=0: the K = 256 KC products keep the streaming kernel (A / B measurements, scripts/bench_gemm.py)
+static bool xk_disabled() {
+  const char* v = getenv("BKG_XW_SLAB");      // (read per call: the tests switch between the two kernels in one process)
+  return v && v[0] == '0';
+}
 
 extern "C" int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w, int64_t rows, int64_t cols,
                                   int32_t batch, void* out, int64_t ldo, int64_t stride_o, void* out_t, int64_t ldt,
@@ -666,6 +883,17 @@ extern "C" int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const v
     if (c_is_bf16) hipLaunchKernelGGL(gemm_xw8_kernel<__bf16>, dim3(blocks), dim3(512), 0, s, g, ep);
     else hipLaunchKernelGGL(gemm_xw8_kernel<float>, dim3(blocks), dim3(512), 0, s, g, ep);
     return check_launch("bkg_gemm_xw(8 waves)");
+  }
+  if (a_is_bf16 && !group_ptr && !a_rows && !gate && beta == 0.f && (K == 512 || K == 768) && N % 256 == 0 && N <= 8 * 256 &&
+      !xk_disabled()) {
+    int ng, st; unsigned blocks;
+    xk_grid(M, N, &ng, &st, &blocks);
+#define BKG_XK(CT, KC) hipLaunchKernelGGL((gemm_xw8k_kernel<CT, KC, false>), dim3(blocks), dim3(512), 0, s, g, ep, ng, st)
+    const int kc = (int)(K / 256);
+    if (c_is_bf16) { if (kc == 2) BKG_XK(__bf16, 2); else BKG_XK(__bf16, 3); }
+    else { if (kc == 2) BKG_XK(float, 2); else BKG_XK(float, 3); }
+#undef BKG_XK
+    return check_launch("bkg_gemm_xw(weight slab in registers)");
   }
   if (a_is_bf16 && group_ptr && G <= 63 && !gate && beta == 0.f && K == X8_K && N == X8_N) {
     const unsigned blocks = (unsigned)std::min<int64_t>(256, ceil_div(M, X8_BM) + G);
@@ -713,12 +941,20 @@ extern "C" int bkg_redaf_fused_xw(int64_t rows, int64_t N, int64_t K, const void
   const int n_tiles = ceil_div(N, XW_BN);
   XwArgs g{A, lda, nullptr, reinterpret_cast<const __bf16*>(Wt), ldw, 0, out, ldo, nullptr, 0, (int)rows, (int)N, (int)K, 0,
            scale, keep, drop_p, seed, stream_id, 0, rng_epoch_ptr()};
+  hipStream_t s = (hipStream_t)stream;
+  if (a_is_bf16 && !keep && (K == 512 || K == 768) && N % 256 == 0 && N <= 8 * 256 && !xk_disabled()) {
+    int ng, st; unsigned blocks;
+    xk_grid(rows, N, &ng, &st, &blocks);
+    const int kc = (int)(K / 256);
+    if (kc == 2) hipLaunchKernelGGL((gemm_xw8k_kernel<float, 2, true>), dim3(blocks), dim3(512), 0, s, g, ep, ng, st);
+    else hipLaunchKernelGGL((gemm_xw8k_kernel<float, 3, true>), dim3(blocks), dim3(512), 0, s, g, ep, ng, st);
+    return check_launch("bkg_redaf_fused_xw(weight slab in registers)");
+  }
   const int64_t m_tiles = ceil_div(rows, XW_BM);
   int64_t lanes = std::max<int64_t>(BKG_XCDS, (2 * 256 / n_tiles) / BKG_XCDS * BKG_XCDS);
   lanes = std::min<int64_t>(lanes, (m_tiles + BKG_XCDS - 1) / BKG_XCDS * BKG_XCDS);
   g.persist = (int)lanes;
   const unsigned grid = (unsigned)(lanes * n_tiles);
-  hipStream_t s = (hipStream_t)stream;
   if (a_is_bf16) hipLaunchKernelGGL((gemm_xw_kernel<__bf16, float, false, true>), dim3(grid), dim3(256), 0, s, g, ep);
   else hipLaunchKernelGGL((gemm_xw_kernel<float, float, false, true>), dim3(grid), dim3(256), 0, s, g, ep);
   return check_launch("bkg_redaf_fused_xw");

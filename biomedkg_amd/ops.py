@@ -189,6 +189,10 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias
         L.call("bkg_gemm_tn_bf16", m, n, k, L.ptr(a), int(a.dtype == torch.bfloat16), a.stride(0), L.ptr(bb),
                int(bb.dtype == torch.bfloat16), bb.stride(0), L.ptr(out), out.stride(0), L.stream())
         return out
+    if trans_a and out_dtype == torch.float32 and (a.dtype == torch.bfloat16 or b.dtype == torch.bfloat16):
+        # a weight gradient over few rows (a node-partitioned rank that owns hub nodes holds ~4k rows or fewer: below the
+        # split-K kernel's floor): widen the bf16 tables once and take the general kernel
+        a, b = a.float(), b.float()
     if out_dtype != torch.float32 or a.dtype != torch.float32 or b.dtype != torch.float32:
         raise TypeError("bf16 activations are only taken / produced by the bf16-mode tall products")
     a = _f32c(a)

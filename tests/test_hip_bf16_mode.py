@@ -603,3 +603,66 @@ def test_projected_attention_fusion_tracks_the_exact_path(d):
     err_lit = float((literal - want).norm() / want.norm())
     assert err_proj < 1e-2, err_proj
     assert err_proj < 3.0 * err_lit + 1e-3, (err_proj, err_lit)     # no worse than bf16 operands make the literal form
+
+
+@pytest.mark.parametrize("m", [1, 31, 32, 33, 100, 4097, 70_001])
+@pytest.mark.parametrize("n,k", [(768, 768), (256, 768), (512, 512), (1024, 512)])
+@pytest.mark.parametrize("c_bf16", [False, True])
+def test_gemm_xw_weight_slab_kernel(m, n, k, c_bf16, monkeypatch):
+    """K = 512 / 768 products of bf16 rows (csrc/gemm_xw.hip gemm_xw8k_kernel: a 256-column weight slab in registers, 32-row
+    A tiles through an LDS-DMA ring): against fp64 on the bf16-rounded operands, and BIT-equal with the streaming kernel
+    it replaces (same operands, same fp32 accumulation order along K: k ascending inside one accumulator) -- every row
+    count around the 32-row tile, every column group, bias / ReLU / ELU / alpha epilogues, both result types."""
+    from biomedkg_amd import ops
+    prev = ops.get_matmul_precision()
+    ops.set_matmul_precision("bf16")
+    try:
+        torch.manual_seed(m + n + k)
+        a = torch.randn(m, k, device=DEV).bfloat16()
+        w = torch.randn(n, k, device=DEV) / k ** 0.5
+        bias = torch.randn(n, device=DEV)
+        cdt = torch.bfloat16 if c_bf16 else torch.float32
+        tol = dict(rtol=2 ** -7, atol=2e-2) if c_bf16 else dict(rtol=1e-4, atol=2e-3)
+        for kw in (dict(), dict(bias=bias, act=ops.ACT_RELU), dict(bias=bias, act=2, alpha=0.5)):
+            outs = {}
+            for slab in ("1", "0"):
+                monkeypatch.setenv("BKG_XW_SLAB", slab)
+                outs[slab] = ops.gemm(a, w, trans_b=True, out_dtype=cdt, **kw)
+            ref = kw.get("alpha", 1.0) * (a.double() @ w.bfloat16().double().t())
+            if "bias" in kw:
+                ref = ref + bias.double()
+                ref = torch.relu(ref) if kw["act"] == ops.ACT_RELU else torch.where(ref > 0, ref, torch.expm1(ref))
+            torch.testing.assert_close(outs["1"].double(), ref, **tol)
+            if k == 768:      # (the streaming kernel sums K in 256-slabs into the same accumulator: the same order)
+                assert torch.equal(outs["1"], outs["0"])
+    finally:
+        ops.set_matmul_precision(prev)
+
+
+@pytest.mark.parametrize("n_nodes", [1, 16, 17, 130, 5000, 33_333])
+@pytest.mark.parametrize("d", [512, 768])
+@pytest.mark.parametrize("how", ["eval", "philox"])
+def test_redaf_one_launch_on_bf16_rows_weight_slab_kernel(n_nodes, d, how, monkeypatch):
+    """ReDAF as the epilogue of the weight-slab kernel (the shape the training step runs: bf16 feature rows, d = 768):
+    bit-equal with the streaming kernel's epilogue -- same accumulators, same Philox masks -- which the goldens hold to
+    the reference's class."""
+    from biomedkg_amd import ops
+    prev = ops.get_matmul_precision()
+    ops.set_matmul_precision("bf16")
+    try:
+        g = torch.Generator(device=DEV).manual_seed(n_nodes + d)
+        x = torch.randn(n_nodes, 2, d, device=DEV, generator=g).bfloat16()
+        w = torch.randn(d, d, device=DEV, generator=g) / d ** 0.5
+        b = torch.randn(d, device=DEV, generator=g) * 0.1
+        scale = torch.rand(2, d, device=DEV, generator=g) + 0.25
+        drop = ops.Dropout(0.1, keep=None, seed=99, stream_id=3) if how == "philox" else None
+        outs = {}
+        for slab in ("1", "0"):
+            monkeypatch.setenv("BKG_XW_SLAB", slab)
+            outs[slab] = ops.redaf_fusion(x, w, b, scale, drop).clone()
+        assert torch.equal(outs["1"], outs["0"])
+        if how == "eval":
+            t = torch.relu(x.reshape(2 * n_nodes, d).double() @ w.bfloat16().double().t() + b.double()) * scale.repeat(n_nodes, 1).double()
+            torch.testing.assert_close(outs["1"].double(), torch.relu(t).view(n_nodes, 2, d).mean(1), rtol=2e-4, atol=2e-4)
+    finally:
+        ops.set_matmul_precision(prev)
