@@ -1154,7 +1154,7 @@ def _run_ranks(args, extra_env, limit_s, setup_limit_s=None):
         logs.append(tempfile.TemporaryFile(mode="w+b"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=logs[-1]))
-    out, first_dead, note, t_mark = None, None, "", None
+    out, first_dead, note, t_mark, killed = None, None, "", None, set()
     t0 = time.time()
     while out is None:                              # a rank that dies early leaves the others waiting in a collective:
         try:                                        # end them instead of waiting for the caller's own limit
@@ -1176,9 +1176,14 @@ def _run_ranks(args, extra_env, limit_s, setup_limit_s=None):
                     note += f"bench.py --gpus {n}: no result {limit_s:.0f} s after the steps started; ending the ranks\n"
                 else:
                     note += f"bench.py --gpus {n}: the ranks were not ready after {setup_limit_s:.0f} s; ending them\n"
-                for p in procs:
+                if dead:                            # a moment for ranks that are failing the same way to say so themselves
+                    t_grace = time.time() + 3.0
+                    while time.time() < t_grace and any(p.poll() is None for p in procs):
+                        time.sleep(0.1)
+                for r, p in enumerate(procs):
                     if p.poll() is None:
                         p.kill()
+                        killed.add(r)
                 out, _ = procs[0].communicate()
     codes = [procs[0].returncode]
     deadline = time.time() + 120
@@ -1196,7 +1201,7 @@ def _run_ranks(args, extra_env, limit_s, setup_limit_s=None):
         return "\n".join(text[-lines:])
     if bad:
         # the rank that failed FIRST (the others' errors are the collective timing out or the kill), else every bad one
-        show = [first_dead[0]] if first_dead else [r for r, c in enumerate(codes) if c != 0]
+        show = [r for r, c in enumerate(codes) if c != 0 and r not in killed] or ([first_dead[0]] if first_dead else [])
         for r in show:
             note += f"---- bench.py rank {r} (exit code {codes[r]}), last lines of its stderr ----\n{tail(r)}\n"
     else:
@@ -1264,6 +1269,12 @@ def launch_ranks(args):
             raise SystemExit(0)
         sys.stderr.write(note + f"bench.py --gpus {n}: the graphed attempt is not used ({why}); running the eager step\n")
     out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "0"} if try_graphs else {}, None)
+    if (any(c != 0 for c in codes) and try_graphs and "BKG_DIRECT_ALL_TO_ALL" not in os.environ):
+        # the in-place (list-form) all-to-all of the whole-table exchanges has only ever run in the simulated rank (it needs
+        # RCCL ranks with unequal shards: no multi-GPU box here): one more attempt with the packed all_to_all_single form
+        sys.stderr.write(note + f"bench.py --gpus {n}: the eager step failed (exit codes {codes}); once more with the packed "
+                         "all_to_all_single exchanges (BKG_DIRECT_ALL_TO_ALL=0)\n")
+        out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "0", "BKG_DIRECT_ALL_TO_ALL": "0"}, None)
     sys.stderr.write(note)
     sys.stdout.write(out)
     sys.stdout.flush()

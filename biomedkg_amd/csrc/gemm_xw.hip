@@ -623,6 +623,16 @@ __global__ __launch_bounds__(512) void gemm_xw8_grouped_kernel(XwArgs g, GemmEpi
 // a block's last): the wait before tile i leaves exactly those in flight.
 constexpr int XK_BM = 32, XK_NS = 3;
 constexpr int XK_CONST_BYTES = 3 * 256 * 4;   // bias | ReDAF scale of modality 0 | of modality 1, this block's 256 columns
+constexpr int XK_JUNK_BYTES = 8 * 256;        // where the L2 prefetch's dwords land (one 256-byte target per wave; never read)
+#ifndef XK_L2PF
+#define XK_L2PF 0        // tiles an L2 prefetch runs ahead of the DMA (0: none -- measured: 2 / 3 / 6 tiles ahead cost 3 / 6 / 7 %)
+#endif
+#ifndef XK_ABL
+#define XK_ABL 0         // ablations for timing only (wrong results): 1 no DMA, 2 no epilogue, 4 no fragment reads / MFMA
+#endif
+#ifndef XK_STAGGER
+#define XK_STAGGER 1     // waves 4-7 defer their epilogue by one tile (0: all eight waves in step)
+#endif
 #ifndef XK_PF
 #define XK_PF 3          // A fragments read ahead of their MFMA (4 registers each; 192 of the 256 are the weights)
 #endif
@@ -641,6 +651,9 @@ template <int OFF> __device__ __forceinline__ xw_bf16x8_t xk_frag(uint32_t addr)
 template <int N> __device__ __forceinline__ void xk_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);      // (an MFMA touches no memory: the clobber alone does not keep it behind the wait)
+}
+__device__ __forceinline__ float xk_swap1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 template <int OFF> __device__ __forceinline__ float4 xk_const4(uint32_t addr) {
   xk_f4_t v;
@@ -661,7 +674,7 @@ template <int S, int KC> __device__ __forceinline__ void xk_step(xw_acc_t& acc, 
 template <typename CT, int KC, bool REDAF>
 __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue ep, int n_groups, int streams) {
   constexpr int SLOT = XK_BM * KC * 512;
-  __shared__ __attribute__((aligned(1024))) unsigned char ring[XK_NS * SLOT + XK_CONST_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[XK_NS * SLOT + XK_CONST_BYTES + XK_JUNK_BYTES];
   float* cst = reinterpret_cast<float*>(ring + XK_NS * SLOT);
   const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ring;
   // 192 of the 256 registers hold weights: everything wave-uniform is kept in SGPRs (readfirstlane), and what depends on the
@@ -714,6 +727,24 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
                                          (__attribute__((address_space(3))) void*)(ring + base + kc * (XK_BM * 512) + j * 1024), 16, 0, 0);
     }
   };
+  // L2 prefetch.  The three blocks that read a row tile (one per column group) ask for it together and all wait for HBM: a CU
+  // with two tiles (96 KB) in flight streams from HBM at ~23 GB/s (MI355X_MICROARCH.md "Indexed rows"), 2.1 us per 48 KB tile
+  // against 1.3 us of matrix work.  LDS has no room for more tiles in flight, the L2 has: every wave touches each 128-byte
+  // line of ITS rows of the tile XK_L2PF tiles further on with one dword-per-lane LDS-DMA into a junk area -- one more
+  // instruction on the vmcnt counter per tile, no registers -- so that the tile's real DMA finds its lines in the L2.
+  constexpr int PFL = XK_L2PF > 0 ? 1 : 0;
+  auto prefetch = [&](int tile, int lane) {
+    constexpr int LPR = KC * 4;                       // 128-byte lines per row
+    const int rr = wave * 4 + lane / LPR;
+    const int r = max(0, min(tile * XK_BM + rr, g.M - 1));
+    if (lane < 4 * LPR)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)r * g.lda + (lane % LPR) * 64),
+                                       (__attribute__((address_space(3))) void*)(ring + XK_NS * SLOT + XK_CONST_BYTES + wave * 256), 4, 0, 0);
+  };
+  if constexpr (PFL) {
+#pragma unroll
+    for (int d = 0; d < XK_L2PF; ++d) prefetch(first + (2 + d) * stride, threadIdx.x & 63);
+  }
   issue(0, first, threadIdx.x & 31, (threadIdx.x >> 5) & 1);
   issue(1, first + stride, threadIdx.x & 31, (threadIdx.x >> 5) & 1);
 
@@ -727,29 +758,11 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
     keep_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, keep_scale)));
     thresh = __builtin_amdgcn_readfirstlane((uint32_t)fminf(g.rd_p * 4294967296.0f, 4294967295.0f));
   }
-  for (int t = first; t < m_tiles; t += stride) {
+  // the tile's epilogue: acc[4q..4q+3] = C[t * 32 + l31][n0 + 8 q + 4 lh + 0..3]
+  auto epilogue = [&](const xw_acc_t& acc, int t) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int l31 = tid & 31, lh = (tid >> 5) & 1;
-    if (it >= 2) xk_wait<D + 2 * SPT>();
-    else if (it == 1) xk_wait<D + SPT>();
-    else xk_wait<D>();
-    ++it;
-    __builtin_amdgcn_s_barrier();      // ... every wave's pieces have landed, and every wave is done with the slot refilled next
-    issue(slot == 0 ? XK_NS - 1 : slot - 1, t + 2 * stride, l31, lh);
-    xw_acc_t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    {
-      const int p16 = (lh ^ l31) * 16;
-      const uint32_t tile = ring_lds + (uint32_t)(slot * SLOT + l31 * 512);
-      xw_bf16x8_t a[XK_PF + 1];
-#pragma unroll
-      for (int s0 = 0; s0 < XK_PF; ++s0) a[s0] = xk_frag<0>(tile + (uint32_t)((s0 * 32) ^ p16));   // (XK_PF <= 16: plane 0)
-      xk_step<0, KC>(acc, w, a, tile, p16);
-    }
-    slot = slot + 1 == XK_NS ? 0 : slot + 1;
-    // acc[4q..4q+3] = C[t * 32 + l31][n0 + 8 q + 4 lh + 0..3]
     const uint32_t cb = ring_lds + (uint32_t)(XK_NS * SLOT + (wave * 32 + 4 * lh) * 4);
     const int row = t * XK_BM + l31;
     if constexpr (REDAF) {
@@ -772,8 +785,8 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
           v.z = r.z >= thresh ? v.z * keep_scale : 0.f; v.w = r.w >= thresh ? v.w * keep_scale : 0.f;
         }
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        float4 o;
-        o.x = __shfl_xor(v.x, 1, 64); o.y = __shfl_xor(v.y, 1, 64); o.z = __shfl_xor(v.z, 1, 64); o.w = __shfl_xor(v.w, 1, 64);
+        float4 o;   // the partner lane's values (lane ^ 1: quad_perm [1, 0, 3, 2] -- a DPP move, no LDS round trip)
+        o.x = xk_swap1(v.x); o.y = xk_swap1(v.y); o.z = xk_swap1(v.z); o.w = xk_swap1(v.w);
         if (live && mrow == 0)   // modality 0 first, as the two-kernel form adds them: bit-equal
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)(row >> 1) * g.ldc + col) =
               make_float4((v.x + o.x) * 0.5f, (v.y + o.y) * 0.5f, (v.z + o.z) * 0.5f, (v.w + o.w) * 0.5f);
@@ -801,7 +814,45 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
         }
       }
     }
+  };
+  // The two waves of a SIMD (w and w + 4) would run in lockstep -- matrix work together, epilogue (VALU, Philox, stores: no
+  // MFMA) together.  Waves 4-7 therefore DEFER each tile's epilogue behind the next tile's barrier (MI355X_MICROARCH.md
+  // "Two waves per SIMD", item 9): after every barrier waves 0-3 multiply while waves 4-7 finish their previous tile, then
+  // the roles swap.  Their stores come one iteration later, so their vmcnt ladder starts one step later.
+  const bool late = XK_STAGGER && wave >= 4;
+  xw_acc_t acc;
+  int t_prev = -1;
+  for (int t = first; t < m_tiles; t += stride) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int l31 = tid & 31, lh = (tid >> 5) & 1;
+    // behind this tile's DMAs: the next tile's (D), the prefetches of the iterations since (at most two) and the stores of
+    // the tiles finished since (at most two; one iteration later for the deferring waves)
+    const int stores_behind = min(late ? max(it - 1, 0) : it, 2), pf_behind = min(it, 2);
+    if (pf_behind == 0) xk_wait<D>();
+    else if (pf_behind == 1) { if (stores_behind == 1) xk_wait<D + PFL + SPT>(); else xk_wait<D + PFL>(); }
+    else { if (stores_behind == 2) xk_wait<D + 2 * PFL + 2 * SPT>(); else xk_wait<D + 2 * PFL + SPT>(); }
+    ++it;
+    __builtin_amdgcn_s_barrier();      // ... every wave's pieces have landed, and every wave is done with the slot refilled next
+    if constexpr (!(XK_ABL & 1)) issue(slot == 0 ? XK_NS - 1 : slot - 1, t + 2 * stride, l31, lh);
+    if constexpr (PFL) prefetch(t + (2 + XK_L2PF) * stride, tid & 63);
+    if (late && t_prev >= 0 && !(XK_ABL & 2)) epilogue(acc, t_prev);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (!(XK_ABL & 4)) {
+      const int p16 = (lh ^ l31) * 16;
+      const uint32_t tile = ring_lds + (uint32_t)(slot * SLOT + l31 * 512);
+      xw_bf16x8_t a[XK_PF + 1];
+#pragma unroll
+      for (int s0 = 0; s0 < XK_PF; ++s0) a[s0] = xk_frag<0>(tile + (uint32_t)((s0 * 32) ^ p16));   // (XK_PF <= 16: plane 0)
+      xk_step<0, KC>(acc, w, a, tile, p16);
+    }
+    slot = slot + 1 == XK_NS ? 0 : slot + 1;
+    if (!late && !(XK_ABL & 2)) epilogue(acc, t);
+    if constexpr ((XK_ABL & 2) != 0) asm volatile("" ::"v"(acc));
+    t_prev = t;
   }
+  if (late && t_prev >= 0) epilogue(acc, t_prev);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile
 }
 

@@ -1497,7 +1497,9 @@ class _FusedChunk:
 _FUSED_CHUNK_OF = _FusedChunk()
 
 
-_FEW_WAVES = 1 << 14     # below this the per-relation reduce of the waves' rows needs no long-row table
+_FEW_WAVES = 1 << 11     # below this the per-relation reduce of the waves' rows needs no long-row table (one wave then sums a
+                         # relation's rows in turn: ~70 at 30 relations; a node-partitioned rank's share -- 8k waves at 8 ranks --
+                         # took 0.34 ms per triplet set that way, r05 simulated-rank trace, and goes through the row split now)
 
 
 def _iota32(n, device):
@@ -1620,7 +1622,7 @@ class _KgeBceLoss(torch.autograd.Function):
                 if padded:
                     rel_ptr = rel_ptr[: r + 1]
                 drel_part = torch.empty(waves, d, dtype=torch.float32, device=dev)
-                if waves <= _FEW_WAVES:
+                if waves <= _FEW_WAVES or padded:      # (a padded mini-batch: fresh ids every batch, nothing to cache a table on)
                     wave_ptr, wave_iota, wave_split = _relation_waves_small(rel_ptr, r, waves)
                 else:
                     wave_ptr, wave_iota, wave_split = _relation_waves(et, rel_ptr, r, waves)
@@ -2010,6 +2012,10 @@ def _fusion_rows(x, n_out):
     mode, constant input features, a shape the streaming product takes -- a bf16 copy cached on the tensor (that product
     re-reads its A operand once per 128-column tile of the weight: 6 (ReDAF) or 18 (q|k|v) times 400 MB instead of 800)."""
     n, m, d = x.shape
+    if x.dtype == torch.bfloat16:       # rows that already are a bf16 table (bf16 mode takes them as they are)
+        if bf16_storage() and x.is_contiguous() and _bf16_operand_ok(max(n * m, _TALL_ROWS), n_out, d):
+            return x.view(n * m, d)
+        x = x.float()
     x2 = _f32c(x).view(n * m, d)
     chunk_rows = min(n, FUSION_CHUNK_NODES, REDAF_CHUNK_NODES) * m          # every chunk of it must be a tall operand too
     if (bf16_storage() and not x.requires_grad and n * m >= 4096 and x.is_contiguous()

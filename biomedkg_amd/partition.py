@@ -62,6 +62,11 @@ class HaloPattern:
         k = self.CHUNKS
         cut = lambda q, c: b[q] + ((b[q + 1] - b[q]) * c) // k                                     # noqa: E731
         self.chunk_rows = [(cut(rank, c) - b[rank], cut(rank, c + 1) - b[rank]) for c in range(k)]  # my local row ranges
+        # every rank reads every row ("all" of unequal shards): each peer's rows are one contiguous run of the table's slot
+        # space and mine one contiguous run of my shard -- the exchange can land them in place (Comm.exchange_begin)
+        self.whole = bool(needed_by.all())
+        self.peer_chunk_rows = [[(cut(q, c) - b[q], cut(q, c + 1) - b[q]) for q in range(world)] for c in range(k)]
+        self.peer_rows = [(0, b[q + 1] - b[q]) for q in range(world)]
         self.parts = []                      # per chunk: (send_rows, send_counts, recv_slots, recv_counts)
         for c in range(k):
             send, recv, sc, rc = [], [], [], []
@@ -192,6 +197,25 @@ class Comm:
                 work = dist.all_gather_into_tensor(table, own.clone(), group=self.group, async_op=True)
             self._count(el * self.n_max * (self.world - 1), el * self.n_max * (self.world - 1))
             return self._issued((table, work, None, None))
+        if pat.whole and self._lands_in_place():
+            # every row to every rank, unequal shards: my rows leave from where they are and each peer's rows arrive where
+            # they belong (RCCL runs the list form of all-to-all as grouped sends / receives on the given tensors) -- no
+            # (world - 1)-fold packed copy of the shard, no unpack pass over the other ranks' rows
+            lo, hi = (0, self.n_local) if chunk is None else pat.chunk_rows[chunk]
+            ranges = pat.peer_rows if chunk is None else pat.peer_chunk_rows[chunk]
+            send = own[lo:hi]
+            outs = [table[q * self.n_max + a:q * self.n_max + (b if q != self.rank else a)] for q, (a, b) in enumerate(ranges)]
+            rows_in = sum(o.size(0) for o in outs)
+            if self.simulate:
+                for o in outs:
+                    if o.size(0):
+                        o.copy_(own.index_select(0, self._stand_in_rows(o.size(0), own.device)))
+                work = _Done
+            else:
+                ins = [send if q != self.rank else send[:0] for q in range(self.world)]
+                work = dist.all_to_all(outs, ins, group=self.group, async_op=True)
+            self._count(el * rows_in, el * send.size(0) * (self.world - 1))
+            return self._issued((table, work, None, None))
         if chunk is None:
             send_rows, send_counts, recv_slots, recv_counts = pat.send_rows, pat.send_counts, pat.recv_slots, pat.recv_counts
         else:
@@ -204,6 +228,14 @@ class Comm:
             work = dist.all_to_all_single(recv, packed, recv_counts, send_counts, group=self.group, async_op=True)
         self._count(el * recv.size(0), el * packed.size(0))
         return self._issued((table, work, recv, recv_slots))
+
+    def _lands_in_place(self):
+        """The list form of all-to-all on the tensors themselves: RCCL (and the simulated rank).  gloo has no list form
+        (and its point-to-point calls take host pointers only): it keeps the packed all_to_all_single.
+        ``BKG_DIRECT_ALL_TO_ALL=0`` keeps the packed form everywhere."""
+        if os.environ.get("BKG_DIRECT_ALL_TO_ALL", "1") == "0":
+            return False
+        return self.simulate or (dist.is_initialized() and dist.get_backend(self.group) == "nccl")
 
     def _stand_in_rows(self, count, device):
         """(simulate) ``count`` row numbers of the rank's own shard, cycling: what stands in for the rows off the wire."""

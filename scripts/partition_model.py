@@ -6,8 +6,12 @@ R-GCN layer's constant input gathered once per graph), the time they take over x
 single-GPU kernel time, and an OVERLAP SCHEDULE: which exchange can hide under which kernels.
 
     python scripts/partition_model.py [single_gpu_ms_ggd=4.2] [single_gpu_ms_kge=6.3] [--json out.json]
+                                      [--measured profiles/r05_simulated_ranks.json]
 
-Compute per rank = the measured single-GPU sub-steps x the rank's load share, plus what both-owner scoring adds (a
+Compute per rank: with ``--measured``, the MEASURED ms per step of the slowest simulated rank (scripts/simulate_ranks.py on
+one MI355X: the rank's real structures and graphed sub-steps, every exchange a local copy of the same byte count) -- round
+4's linear term (single-GPU sub-steps x the rank's load share) had no per-kernel floor and no replicated work and was
+2.7x too low at 8 ranks.  Without it: that linear term, plus what both-owner scoring adds (a
 cross-rank triplet is scored by both owners: scorer forward x (2 - 1/P) of its 1/P share).  Wire time = bytes the busiest
 rank RECEIVES / (links x 153 GB/s); the full mesh has 7 links per GPU and every exchange here is a set of direct
 point-to-point transfers (all_to_all_single with per-peer counts, or the all-gather of equal shards), so the seven-link
@@ -24,6 +28,11 @@ from biomedkg_amd import partition as P, synthetic  # noqa: E402
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 GGD_MS, KGE_MS = (float(a) for a in (args[:2] + ["4.2", "6.3"][len(args[:2]):]))
 JSON_OUT = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+MEASURED = None
+if "--measured" in sys.argv:
+    _m = json.load(open(sys.argv[sys.argv.index("--measured") + 1]))
+    MEASURED = {w["world"]: w for w in _m["worlds"] if "compute_ms" in w and w["compute_ms"]}
+args = [a for a in args if not a.endswith(".json")]
 LINK_GBS, LINKS = 153.0, 7          # xGMI: 7 point-to-point links per GPU, ~153 GB/s each (MI355X_MICROARCH.md)
 N, E, R, H = 130_000, 4_000_000, 30, 256
 # measured single-GPU pieces of the sub-steps (scripts/dev_time_calls.py, v28): what an exchange can hide under
@@ -84,7 +93,13 @@ for world in (2, 4, 8):
     t1, t7 = worst / LINK_GBS, worst / (LINK_GBS * LINKS)
     share = max(load)
     extra = SCORER_FWD_MS * share * (1.0 - 1.0 / world)       # cross-rank triplets scored twice
-    comp = (GGD_MS + KGE_MS) * share + extra
+    comp_linear = (GGD_MS + KGE_MS) * share + extra
+    comp = comp_linear
+    measured = MEASURED.get(world) if MEASURED else None
+    if measured:
+        # the slowest simulated rank, sub-steps replayed as hipGraphs; its local stand-in copies of the exchanged rows are in
+        # it (a lower bound of what the rank's stream spends landing them)
+        comp = measured["compute_ms"]
     # ---- overlap schedule as coded (per sub-step the chain layer -> exchange -> layer): what runs under each exchange
     ggd, kge = parts_of_worst
     ms = lambda by: by / 1e6 / (LINK_GBS * LINKS)             # noqa: E731  (seven links)
@@ -105,7 +120,7 @@ for world in (2, 4, 8):
     ring = 2.0 * (world - 1) / world
     ar_kge_1, ar_kge_7 = ring * KGE_GRAD_MB / LINK_GBS, ring * KGE_GRAD_MB / (LINK_GBS * LINKS)
     ar_ggd_7 = ring * GGD_GRAD_MB / (LINK_GBS * LINKS)
-    ggd_compute = GGD_MS * share
+    ggd_compute = (measured["compute_ms_ggd"] if measured else GGD_MS * share)
     ar_exposed_7 = ar_ggd_7 + max(ar_kge_7 - ggd_compute, 0.0)
     ar_exposed_1 = ring * GGD_GRAD_MB / LINK_GBS + max(ar_kge_1 - ggd_compute, 0.0)
     ar_inline_7 = ar_ggd_7 + ar_kge_7                              # (both buckets inside their sub-steps' graphs: round 4 before)
@@ -121,6 +136,10 @@ for world in (2, 4, 8):
           f"{ar_kge_1:.2f} .. {ar_kge_7:.3f} ms (one ring .. seven) under a GGD sub-step of {ggd_compute:.2f} ms: exposed "
           f"{ar_exposed_1:.2f} .. {ar_exposed_7:.3f} ms (inline: {ar_inline_7:.3f} at seven)")
     rows_out.append({"world": world, "rows_min": min(rows), "rows_max": max(rows), "padded_over_real": waste,
+                     "compute_ms_linear_model_r04": comp_linear,
+                     "compute_ms_measured": (measured["compute_ms"] if measured else None),
+                     "compute_ms_measured_per_rank": ([round(r["ms_per_step"], 3) for r in measured["ranks"]] if measured else None),
+                     "compute_only_speedup_bound": (single / comp),
                      "halo_in": fr_in, "halo_out": fr_out, "wire_MB": worst, "wire_MB_round3": worst_old3,
                      "wire_MB_round2": old2, "wire_ms_one_link": t1, "wire_ms_seven_links": t7, "compute_ms": comp,
                      "exposed_ms_as_coded": exposed, "step_ms_as_coded": as_coded, "step_ms_interleaved": interleaved,
@@ -131,5 +150,15 @@ for world in (2, 4, 8):
                                         "ggd_substep_compute_ms": ggd_compute},
                      "bytes": {"ggd": {k: v / 1e6 for k, v in ggd.items()}, "kge": {k: v / 1e6 for k, v in kge.items()}}})
 if JSON_OUT:
-    json.dump({"single_gpu_ms": {"ggd": GGD_MS, "kge": KGE_MS}, "link_GBs": LINK_GBS, "links": LINKS, "ranks": rows_out},
+    json.dump({"single_gpu_ms": {"ggd": GGD_MS, "kge": KGE_MS}, "link_GBs": LINK_GBS, "links": LINKS,
+               "compute_term": ("measured: slowest simulated rank per world size (scripts/simulate_ranks.py, one MI355X, graphed "
+                                "sub-steps, exchanges = local copies of the same byte count)" if MEASURED else
+                                "linear: single-GPU sub-steps x the rank's load share"),
+               "measured_source": (sys.argv[sys.argv.index("--measured") + 1] if MEASURED else None),
+               "what_bounds_it": ("compute does not shrink with 1/P: ~350 launches per rank and step whose kernels fall to 5-20 us "
+                                  "each (per-kernel floors: launch ramp, tails, split-K reductions), work every rank repeats (the "
+                                  "dropout_edge view's weights over all E edges, the paired first-layer table over all N rows, "
+                                  "both-owner scoring x (2 - 1/P)), pack / unpack passes of the halo exchanges; the wire is the "
+                                  "smaller term" if MEASURED else None),
+               "ranks": rows_out},
               open(JSON_OUT, "w"), indent=1)
