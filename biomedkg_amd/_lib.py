@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+from ctypes import c_double, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 import torch
 
@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbiomedkg_hip.so")
 
 P = c_void_p
-I32, I64, U32, U64, F32 = c_int32, c_int64, c_uint32, c_uint64, c_float
+I32, I64, U32, U64, F32, F64 = c_int32, c_int64, c_uint32, c_uint64, c_float, c_double
 
 class RowSplitStruct(ctypes.Structure):
     """``bkg_rowsplit`` of include/biomedkg_hip.h (device pointers + upper-bound sizes)."""
@@ -74,7 +74,7 @@ SIGNATURES = {
     "bkg_kge_fused_bce_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
     "bkg_kge_fused_bce_dev_f32": (I32, [I32, P, I32, I64, I32, P, P, I64, F32, F32, P, P, I64, I32, P, P, P, P, P, P, P, I64, P]),
     "bkg_kge_loss_finish_scratch_bytes": (I64, []),
-    "bkg_kge_loss_finish_f32": (I32, [P, I32, F32, P, P, I64, I32, I32, P, I64, P, I64, I32, F32, P, P, P]),
+    "bkg_kge_loss_finish_f32": (I32, [P, I32, F32, P, P, I64, I32, I32, P, F64, P, I64, I32, F32, P, P, P]),
     "bkg_scale_add_rows_f32": (I32, [P, I64, P, I64, I32, I32, P, F32, P, P]),
     "bkg_scale_add_rows_out_f32": (I32, [P, I64, P, I64, I32, I32, P, F32, P, I64, P]),
     "bkg_relation_wave_ptr": (I32, [P, I32, I32, P, P]),

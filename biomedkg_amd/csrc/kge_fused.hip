@@ -220,7 +220,7 @@ constexpr int FIN_BLOCKS = 64, FIN_BLOCKS_MAX = 1024;
 __global__ __launch_bounds__(1024) void kge_loss_finish_kernel(const float* __restrict__ part, int n_part, float inv_total,
                                                                const float* __restrict__ inv_total_dev,
                                                                const float* __restrict__ z, int64_t ldz, int n_cap, int d,
-                                                               const int64_t* __restrict__ n_real_dev, int64_t mean_rows,
+                                                               const int64_t* __restrict__ n_real_dev, double mean_rows,
                                                                const float* __restrict__ rel, int64_t ldr, int n_rel,
                                                                float reg, double* __restrict__ scratch,
                                                                unsigned int* __restrict__ ticket, float* __restrict__ loss) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(1024) void kge_loss_finish_kernel(const float* __re
   if (t != 0) return;
   const double it = inv_total_dev ? (double)inv_total_dev[0] : (double)inv_total;
   double out = sa * it;
-  const double rows_of_mean = mean_rows > 0 ? (double)mean_rows : (double)max(n_rows, 1);
+  const double rows_of_mean = mean_rows > 0.0 ? mean_rows : (double)max(n_rows, 1);
   if (reg != 0.f) out += (double)reg * (sz / (rows_of_mean * d) + sr / ((double)n_rel * d));
   loss[0] = (float)out;
   *ticket = 0u;
@@ -333,9 +333,9 @@ extern "C" int64_t bkg_kge_loss_finish_scratch_bytes() { return 3 * FIN_BLOCKS_M
 
 extern "C" int bkg_kge_loss_finish_f32(const float* part, int32_t n_part, float inv_total, const float* inv_total_dev,
                                        const float* z, int64_t ldz, int32_t n_cap, int32_t d, const int64_t* n_real_dev,
-                                       int64_t mean_rows, const float* rel, int64_t ldr, int32_t n_rel, float reg,
+                                       double mean_rows, const float* rel, int64_t ldr, int32_t n_rel, float reg,
                                        void* scratch, float* loss, void* stream) {
-  BKG_ARG(n_part >= 0 && n_cap >= 0 && d > 0 && n_rel > 0 && mean_rows >= 0, "bkg_kge_loss_finish_f32: bad sizes");
+  BKG_ARG(n_part >= 0 && n_cap >= 0 && d > 0 && n_rel > 0 && mean_rows >= 0.0, "bkg_kge_loss_finish_f32: bad sizes");
   BKG_ARG(d % 4 == 0 && ldz % 4 == 0 && ldr % 4 == 0 && (uintptr_t)z % 16 == 0 && (uintptr_t)rel % 16 == 0 &&
               (uintptr_t)scratch % 8 == 0, "bkg_kge_loss_finish_f32: 16-byte aligned rows, d % 4 == 0");
   double* slots = reinterpret_cast<double*>(scratch);

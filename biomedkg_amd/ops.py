@@ -1029,7 +1029,7 @@ class _RgcnConv(torch.autograd.Function):
     reduce-scattered while the root / weight-gradient products run."""
 
     @staticmethod
-    def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop, hidden):
+    def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop, hidden, training_pass=True):
         n, n_table, comm = _dims(rg)
         d_in, d_out = weight.size(1), weight.size(2)
         x_given = x                        # (the caller's tensor object: what a remembered table is valid for)
@@ -1042,7 +1042,7 @@ class _RgcnConv(torch.autograd.Function):
         elif not ctx.needs_input_grad[0] and comm.constant_table(rg, x_given, ("in", _PRECISION)) is not None:
             table, pending = comm.constant_table(rg, x_given, ("in", _PRECISION)), None      # the node features: the same rows every step, gathered once
         else:
-            remember = not ctx.needs_input_grad[0]
+            remember = comm.is_constant_input(ctx.needs_input_grad, training_pass)
             pending = comm.exchange_begin(_table(x), "in")                           # crosses xGMI ...
         # ... under the [N, out] root term: a bf16 table where the layer's own output is one (a hidden layer of bf16 mode:
         # every value of the sum is rounded to bf16 right after it), fp32 for the encoder's output layer
@@ -1145,7 +1145,7 @@ class _RgcnConv(torch.autograd.Function):
                           out_dtype=torch.bfloat16 if x16 else torch.float32)
                 if dx.dtype != x.dtype:
                     dx = dx.to(x.dtype)
-            return dx, dweight, droot, db, None, None, None, None
+            return dx, dweight, droot, db, None, None, None, None, None
         # the input gradient: on a partitioned graph its table part goes out while the weight gradients run
         dx, pending, dx_root = None, None, None
         if ctx.needs_input_grad[0]:
@@ -1169,14 +1169,14 @@ class _RgcnConv(torch.autograd.Function):
             dweight, droot, db = weight_grads()
         if dx is not None and dx.dtype != x.dtype:
             dx = dx.to(x.dtype)
-        return dx, dweight, droot, db, None, None, None, None
+        return dx, dweight, droot, db, None, None, None, None, None
 
 
 def rgcn_conv(x, weight, root, bias, rg, relu=False, drop=None, hidden=False):
     L.require_cuda(x, weight, root, bias)
     if x.dtype != torch.bfloat16:
         x = _f32c(x)
-    return _RgcnConv.apply(x, weight, root, bias, rg, relu, drop, hidden)
+    return _RgcnConv.apply(x, weight, root, bias, rg, relu, drop, hidden, torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------- composable pieces
@@ -1677,7 +1677,7 @@ class _KgeBceLoss(torch.autograd.Function):
             # BCE mean + the L2 term in ONE launch (fp64 sums in a fixed order), as the padded mini-batch steps do
             out = torch.empty((), dtype=torch.float32, device=dev)
             L.call("bkg_kge_loss_finish_f32", L.ptr(part), n_counted, 1.0 / total, None, L.ptr(z), z.stride(0), z.size(0), d,
-                   None, 0 if reg_rows is None else int(reg_rows), L.ptr(rel_emb), rel_emb.stride(0), r, float(reg),
+                   None, 0.0 if reg_rows is None else float(reg_rows), L.ptr(rel_emb), rel_emb.stride(0), r, float(reg),
                    L.ptr(_finish_scratch(dev)), L.ptr(out), L.stream())
             return out, pos_scores, neg_scores
         loss = part[:n_counted].sum(dtype=torch.float64) / total

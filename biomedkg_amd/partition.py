@@ -270,16 +270,33 @@ class Comm:
 
     # ---- tables of constant inputs (the first R-GCN layer gathers the node features: the same rows every step)
     def constant_table(self, holder, shard, pattern="in"):
-        """The gathered table of ``shard`` remembered on ``holder`` (a graph structure), or None.  Valid for this tensor
-        object at this version; the holder keeps the shard alive, so its address cannot be handed to another tensor."""
-        hit = getattr(holder, "_bkg_const_table", None)
-        if (hit is not None and hit[0] is shard and hit[1] == shard._version and hit[2] == pattern
-                and hit[3].device == shard.device):
-            return hit[3]
+        """The gathered table of ``shard`` remembered on ``holder`` (a graph structure) under ``pattern``, or None.  Valid
+        for this tensor object at this version; the holder keeps the shard alive, so its address cannot be handed to
+        another tensor."""
+        hit = (getattr(holder, "_bkg_const_tables", None) or {}).get(pattern)
+        if hit is not None and hit[0] is shard and hit[1] == shard._version and hit[2].device == shard.device:
+            return hit[2]
         return None
 
+    @staticmethod
+    def is_constant_input(needs_input_grad, training_pass=True):
+        """May the layer input's gathered table be remembered?  Only in a TRAINING pass (``training_pass``: grad mode as
+        the layer's caller had it -- inside an autograd Function's forward it always reads off) whose input is a constant:
+        the input wants no gradient while some parameter does.  Under ``torch.no_grad()`` (an eval pass, bench.py's check
+        losses) EVERY hidden activation looks constant: remembering those pinned a ``[world * n_max, d]`` table per layer
+        on the graph and evicted the features' table on each layer.  (A table remembered by a training pass is
+        still USED by a later no-grad pass over the same tensor: identity and version decide that.)"""
+        return bool(training_pass) and (not needs_input_grad[0]) and any(needs_input_grad[1:])
+
     def remember_table(self, holder, shard, pattern, table):
-        holder._bkg_const_table = (shard, shard._version, pattern, table)
+        """One table per pattern key on the holder (the composable form and the fused layers use different keys: they do
+        not evict each other)."""
+        tables = getattr(holder, "_bkg_const_tables", None)
+        if tables is None:
+            tables = holder._bkg_const_tables = {}
+        tables[pattern] = (shard, shard._version, table)
+        while len(tables) > 4:                           # a handful of (pattern, precision) keys at most
+            tables.pop(next(iter(tables)))
 
     def _count(self, received, sent):
         self.stats["bytes_received"] += int(received)
@@ -563,12 +580,13 @@ class _PartRgcn(torch.autograd.Function):
     segment sums of it, products with ``W_r^T``, per-source sum + root part."""
 
     @staticmethod
-    def forward(ctx, x_local, weight, root, bias, prg, backend, relu, drop):
+    def forward(ctx, x_local, weight, root, bias, prg, backend, relu, drop, training_pass=True):
         comm, f = prg.part.comm, prg.fwd
+        constant = comm.is_constant_input(ctx.needs_input_grad, training_pass)    # the node features: the same rows every step, gathered once
         table = None if ctx.needs_input_grad[0] else comm.constant_table(prg, x_local)
         if table is None:
             table = comm.exchange(x_local, "in")
-            if not ctx.needs_input_grad[0]:                 # a constant input (the node features): gathered once
+            if constant:
                 comm.remember_table(prg, x_local, "in", table)
         h = backend.spmm_epilogue(f.seg, f.seg_w, table, f.num_segments, None, None, False, None)
         y = backend.grouped_linear(h, weight, f.rel_ptr)
@@ -594,12 +612,12 @@ class _PartRgcn(torch.autograd.Function):
             t = be.spmm_epilogue(b.seg, b.seg_w, dtable, b.num_segments, None, None, False, None)
             dxs = be.grouped_linear(t, weight.transpose(1, 2), b.rel_ptr)
             dx = be.spmm_epilogue(b.rows, None, dxs, x_local.size(0), be.matmul_nt(dout, root), None, False, None)
-        return dx, dweight, droot, db, None, None, None, None
+        return dx, dweight, droot, db, None, None, None, None, None
 
 
 def rgcn_conv_partitioned(x_local, weight, root, bias, prg: PartitionedRelGraph, backend, relu=False, drop=None):
     """RGCNConv over the rank's targets (composable form)."""
-    return _PartRgcn.apply(x_local, weight, root, bias, prg, backend, relu, drop)
+    return _PartRgcn.apply(x_local, weight, root, bias, prg, backend, relu, drop, torch.is_grad_enabled())
 
 
 # ----------------------------------------------------------------------------- encoders over shards

@@ -246,12 +246,13 @@ int64_t bkg_kge_fused_bce_waves(int64_t T, int32_t n_rel);
  * loss[0] = inv_total * sum(part[0..n_part)) + reg * (mean over rows < n_real of z^2 + mean of rel^2), the reference's
  * BCE mean + 1e-2 L2 (biomedkg/kge_module.py:127-129); inv_total_dev / n_real_dev (nullable) read the count / the real
  * row count from device memory; mean_rows > 0: the rows the mean of z^2 is taken over when z is a shard of them (a
- * node-partitioned step: N / world), 0 = the rows summed.  bkg_scale_add_rows_f32: dst = dst * g + src * (g * coef / rows) on the first `rows`
+ * node-partitioned step: N / world -- not an integer when world does not divide N, hence a double: the backward
+ * normalises by the same value), 0 = the rows summed.  bkg_scale_add_rows_f32: dst = dst * g + src * (g * coef / rows) on the first `rows`
  * rows (n_real_dev[0], or n), dst * g beyond; g = gloss[0] -- the backward of that L2 term folded into the scaling of
  * the scorer's gradient by the upstream gradient. */
 int64_t bkg_kge_loss_finish_scratch_bytes(void);   /* zero it once; the kernel leaves its ticket zero */
 int bkg_kge_loss_finish_f32(const float* part, int32_t n_part, float inv_total, const float* inv_total_dev, const float* z,
-                            int64_t ldz, int32_t n_cap, int32_t d, const int64_t* n_real_dev, int64_t mean_rows,
+                            int64_t ldz, int32_t n_cap, int32_t d, const int64_t* n_real_dev, double mean_rows,
                             const float* rel, int64_t ldr, int32_t n_rel, float reg, void* scratch, float* loss,
                             void* stream);
 int bkg_scale_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t n, int32_t d,

@@ -365,3 +365,57 @@ def test_deterministic_mode_every_gradient_repeats_bitwise(kg, precision):
         assert torch.equal(la, lc)                                   # the forward never had atomics
         for x, y in zip(ga, gc):
             assert float((x - y).norm() / y.norm().clamp_min(1e-20)) < 1e-5
+
+
+def test_kge_step_at_the_reference_default_neg_ratio_10_full_size():
+    """The reference's DEFAULT KGE workload (configs/kge.yaml:14 ``neg_ratio: 10``, kge_module.py:86-102) at the bench
+    size: N = 130,000, E = 4,000,000, T = 44 M triplets in one step, in the bf16 mode bench.py times -- the 40 M negatives
+    are distinct, loop-free non-edges with the positives' relation multiset, every score equals a chunked fp64 DistMult
+    on the same embeddings, and the loss equals the chunked fp64 BCE + L2 restatement."""
+    from types import SimpleNamespace
+    from biomedkg_amd import ops, rand as R, synthetic
+    from biomedkg_amd.kge_module import KGEModule
+    n, e, r, h = 130_000, 4_000_000, 30, 256
+    prev = ops.get_matmul_precision()
+    ops.set_matmul_precision("bf16")
+    try:
+        g = synthetic.primekg_like(n, e, r, seed=42)
+        ei, et = g["edge_index"].to(DEV), g["edge_type"].to(DEV)
+        e, r = ei.size(1), g["num_relations"]
+        torch.manual_seed(1234)
+        x = torch.randn(n, h, device=DEV)
+        m = KGEModule("rgcn", "dismult", h, h, h, 2, r, 2, "cosine", 1e-3, 0.2, "none", 10, "random").to(DEV).train()
+        drawn = {}
+        orig = m.sample_neg_edges
+
+        def spy(edge_index, edge_type):
+            drawn["neg"] = orig(edge_index, edge_type)
+            return drawn["neg"]
+        m.sample_neg_edges = spy
+        batch = SimpleNamespace(x=x, edge_index=ei, edge_type=et)
+        with R.use(R.DeviceRand(seed=6)):
+            loss = m.training_step(batch, 0)
+        loss.backward()
+        assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.model.parameters())
+        neg_ei, neg_et = drawn["neg"]
+        k = 10 * e
+        assert neg_ei.shape == (2, k) and neg_et.shape == (k,)
+        keys = neg_ei[0] * n + neg_ei[1]
+        assert not bool((neg_ei[0] == neg_ei[1]).any())
+        assert torch.unique(keys).numel() == k
+        assert not bool(torch.isin(keys, ei[0] * n + ei[1]).any())
+        assert torch.equal(torch.bincount(neg_et, minlength=r), 10 * torch.bincount(et, minlength=r))   # edge_type.repeat(10), permuted
+        z, pos_pred, neg_pred = m._last_scores
+        rel = m.model.decoder.rel_emb.detach().double()
+        zz = z.detach().bfloat16().double()          # bf16 mode: the scorer reads the embedding rows as a bf16 table (ops.py
+        total, acc = e + k, 0.0                      # _KgeLoss); products and sums in fp32, the L2 term on the fp32 rows
+        for tri, types, label, got in ((ei, et, 1.0, pos_pred), (neg_ei, neg_et, 0.0, neg_pred)):
+            for lo in range(0, tri.size(1), 2_000_000):
+                hh, tt, rr = tri[0, lo:lo + 2_000_000], tri[1, lo:lo + 2_000_000], types[lo:lo + 2_000_000]
+                s = (zz[hh] * rel[rr] * zz[tt]).sum(1)
+                torch.testing.assert_close(got[lo:lo + 2_000_000].double(), s, rtol=1e-4, atol=1e-4)
+                acc += float(torch.nn.functional.binary_cross_entropy_with_logits(s, torch.full_like(s, label), reduction="sum"))
+        ref = acc / total + 1e-2 * float(z.detach().double().pow(2).mean() + rel.pow(2).mean())
+        assert abs(float(loss) - ref) <= 1e-5 * max(1.0, abs(ref)), (float(loss), ref)
+    finally:
+        ops.set_matmul_precision(prev)

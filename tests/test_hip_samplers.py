@@ -71,7 +71,15 @@ def test_saint_random_walk_sampler_properties():
     assert (walks[0] == 13).all()                             # a sink stays put
     n_id, sub, e_id = samp.sample(start)
     n_id, sub, e_id = n_id.cpu(), sub.cpu(), e_id.cpu()
-    assert torch.equal(n_id, torch.unique(samp.walks(start).cpu())) or n_id.numel() > 0   # (walks re-drawn: new call id)
+    # the node set: sorted, distinct, contains every start node, and every node in it is reachable from a start node within
+    # the walk length (the walks themselves are re-drawn per call -- a new call id -- so they cannot be compared one to one;
+    # test_saint_random_walk_sampler_equals_the_oracle_on_the_same_tape below pins them against the oracle)
+    assert torch.equal(n_id, torch.unique(n_id)) and bool(torch.isin(start.cpu(), n_id).all())
+    reach = torch.zeros(n, dtype=torch.bool); reach[start.cpu()] = True
+    for _ in range(10):
+        step = torch.zeros(n, dtype=torch.bool); step[ei[1][reach[ei[0]]]] = True
+        reach |= step
+    assert bool(reach[n_id].all())
     inside = torch.zeros(n, dtype=torch.bool); inside[n_id] = True
     expect = torch.nonzero(inside[ei[0]] & inside[ei[1]]).squeeze(1)
     assert torch.equal(e_id, expect)                          # the induced subgraph: ALL edges among the nodes

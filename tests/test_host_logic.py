@@ -173,3 +173,41 @@ def test_gcl_edge_bucket_ladder():
     assert all(v % 1024 == 0 for v in b[:-1])
     assert all(hi <= 1.25 * lo + 1024 for lo, hi in zip(b, b[1:]))
     assert edge_buckets(1000) == (1000,) and edge_buckets(5000) == (4096, 5000)
+
+
+def test_constant_input_table_is_remembered_only_in_a_training_pass():
+    """partition.Comm remembers the gathered table of a CONSTANT layer input (the node features of the first R-GCN layer)
+    on the graph structure.  Under torch.no_grad() every hidden activation looks constant too: nothing may be remembered
+    then (it pinned a table per layer and evicted the features' one), while a table a training pass remembered
+    is still used; different pattern keys do not evict each other."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cpu_backend import TorchBackend as B
+    from biomedkg_amd import partition as P, synthetic
+    from oracle import ref_modules as R
+    g = synthetic.primekg_like(120, 900, 4, seed=2)
+    ei, et = g["edge_index"], g["edge_type"]
+    part = P.NodePartition(ei, 120, 0, 1)
+    prg = P.PartitionedRelGraph(part, ei, et, g["num_relations"], B)
+    torch.manual_seed(0)
+    enc = R.make_kge_model("rgcn", "dismult", 12, 8, 8, 1, g["num_relations"]).encoder.eval()      # three conv layers, no dropout
+    x = torch.randn(120, 12)
+    assert P.Comm.is_constant_input((False, True, True, True)) and not P.Comm.is_constant_input((True, True, True, True))
+    assert not P.Comm.is_constant_input((False, False, False, False))
+    with torch.no_grad():
+        P.rgcn_encoder_partitioned(enc, x, prg, B)
+    assert not getattr(prg, "_bkg_const_tables", None)                     # an eval pass remembers nothing
+    out = P.rgcn_encoder_partitioned(enc, x, prg, B)
+    tables = prg._bkg_const_tables
+    assert list(tables) == ["in"] and tables["in"][0] is x                 # the features' table, and only that
+    kept = tables["in"][2]
+    out.sum().backward()
+    with torch.no_grad():
+        out2 = P.rgcn_encoder_partitioned(enc, x, prg, B)                  # the eval pass USES it and adds nothing
+    assert list(prg._bkg_const_tables) == ["in"] and prg._bkg_const_tables["in"][2] is kept
+    torch.testing.assert_close(out2, out.detach())
+    part.comm.remember_table(prg, x, ("in", 1), kept)                      # the fused layers' key lives beside it
+    assert part.comm.constant_table(prg, x) is kept and part.comm.constant_table(prg, x, ("in", 1)) is kept
+    x.add_(1.0)                                                            # a new version of the tensor: stale
+    assert part.comm.constant_table(prg, x) is None
