@@ -25,7 +25,7 @@ constexpr float KN_EPS = 1e-12f;
 #define KS_L32 16     // lanes per row of a 32-piece table (d = 256 bf16) in the stream form (swept: 8 0.775, 16 0.662, 32 0.676 ms per tagged call)
 #endif
 #ifndef KS_U2
-#define KS_U2 4       // entries in flight per lane group at two pieces per lane (swept: DESIGN 9-5)
+#define KS_U2 4       // entries in flight per lane group at two pieces per lane (swept: docs/experiments.md 9-5)
 #endif
 #ifndef KS_ATTR
 #define KS_ATTR

@@ -24,7 +24,7 @@
 #define KF_CH 64     // triplets per wave (biomedkg_amd/ops.py _FUSED_CHUNK must agree: bkg_kge_fused_chunk)
 #endif
 #ifndef KF_L32
-#define KF_L32 8     // lanes per row of a 32-piece table (d = 256 bf16) in the fused scorer (swept: DESIGN 9-4)
+#define KF_L32 8     // lanes per row of a 32-piece table (d = 256 bf16) in the fused scorer (swept: docs/experiments.md 9-4)
 #endif
 
 namespace bkg {

@@ -57,7 +57,7 @@ constexpr int NX_BJ = 64;   // rows of a j-tile
 #ifndef NX_BWD16_PIPE
 #define NX_BWD16_PIPE 1        // bf16 backward at h > 128: the three-tile software pipeline (ntx2_bwd16p_kernel); 0: ntx2_kernel
 #endif
-#ifndef NX_PIPE_DS           // ntx2_bwd16p_kernel: instructions of each class issued behind every MFMA (sweep: DESIGN.md 9-3)
+#ifndef NX_PIPE_DS           // ntx2_bwd16p_kernel: instructions of each class issued behind every MFMA (sweep: docs/experiments.md 9-3)
 #define NX_PIPE_DS 4
 #endif
 #ifndef NX_PIPE_VALU

@@ -24,10 +24,10 @@
 #include "rowpiece.h"
 
 #ifndef SPMM_L32
-#define SPMM_L32 32   // lanes per row of a 32-piece row (512 bytes) in the item kernel (swept: DESIGN 9-5)
+#define SPMM_L32 32   // lanes per row of a 32-piece row (512 bytes) in the item kernel (swept: docs/experiments.md 9-5)
 #endif
 #ifndef SPMM_U1
-#define SPMM_U1 8    // entries in flight per lane group, one piece per lane (swept: see DESIGN 9-5)
+#define SPMM_U1 8    // entries in flight per lane group, one piece per lane (swept: see docs/experiments.md 9-5)
 #endif
 
 namespace bkg {

@@ -2054,10 +2054,16 @@ def _attention_fusion_projected(x2, w_qkv, b_qkv, n, d):
     The exact-fp32 mode keeps the reference's literal form (three projections, then the 2 x 2 attention)."""
     wq, wk, wv = w_qkv[:d], w_qkv[d:2 * d], w_qkv[2 * d:]
     bq, bk, bv = b_qkv[:d], b_qkv[d:2 * d], b_qkv[2 * d:]
-    mqk = _exact_gemm(wq, wk, trans_a=True)                               # Wq^T Wk  [D, D]
-    u = _exact_gemm(bq.view(1, d), wk).view(d)                            # Wk^T bq
-    w = _exact_gemm(bk.view(1, d), wq).view(d)                            # Wq^T bk
-    c0 = float((bq.double() * bk.double()).sum())
+
+    def constants():
+        # constants of the frozen fuser: three small exact products and one host read, once per weight version (they were
+        # recomputed -- and the host read stalled the launch queue -- on every call with new features: ~0.15 ms of 1.3)
+        return (_exact_gemm(wq, wk, trans_a=True),                        # Wq^T Wk  [D, D]
+                _exact_gemm(bq.view(1, d), wk).view(d),                   # Wk^T bq
+                _exact_gemm(bk.view(1, d), wq).view(d),                   # Wq^T bk
+                float((bq.double() * bk.double()).sum()))
+    from .graph import _cached
+    mqk, u, w, c0 = _cached(w_qkv, "attn_projected", (b_qkv.data_ptr(), b_qkv._version, d), constants)
     t = gemm(x2, mqk, out_dtype=torch.bfloat16)                           # [2n, D] bf16
     xc = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
     L.call("bkg_attn_scores_combine_bf16", L.ptr(t), t.stride(0), L.ptr(x2), x2.stride(0), n, d, L.ptr(u), L.ptr(w), c0,

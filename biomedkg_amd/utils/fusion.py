@@ -47,8 +47,13 @@ class AttentionFusion(torch.nn.Module):
         for hit in cache:
             if hit[2] is x and hit[0] == key:
                 return hit[1]
-        w = torch.cat(params[:3], dim=0)
-        b = torch.cat(params[3:], dim=0)
+        # the stacked q | k | v weights: one tensor pair per weight version (what ops caches on them -- the bf16 images, the
+        # projected form's constants -- then survives from one input table to the next)
+        stacked = self.__dict__.get("_qkv_stacked")
+        if stacked is None or stacked[0] != key[1]:
+            stacked = self.__dict__["_qkv_stacked"] = (key[1], torch.cat(params[:3], dim=0).detach(),
+                                                       torch.cat(params[3:], dim=0).detach())
+        w, b = stacked[1], stacked[2]
         with torch.no_grad():
             out = ops.attention_fusion(x, w, b)
         if not x.requires_grad:

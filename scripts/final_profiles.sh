@@ -8,26 +8,26 @@ out=gpurun_out
 export TMPDIR=/tmp
 mkdir -p $out
 # a first bench line: its tags' grids are what the counter rows are attributed by (the line that is KEPT is taken last, below)
-python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --detail $out/${tag}_bench_detail.json > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 for prec in bf16 fp32; do
   rm -rf /tmp/ks_$prec
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$prec -o k -- python3 bench.py --precision $prec --steps 5 --warmup 2 \
-      --no-cpu-baseline --no-extras > $out/${tag}_bench_under_rocprof_$prec.json 2>/dev/null
+      --no-cpu-baseline --no-extras --detail /tmp/ks_detail_$prec.json > $out/${tag}_bench_under_rocprof_$prec.json 2>/dev/null
   cp $(find /tmp/ks_$prec -name "*kernel_stats.csv" | head -1) $out/${tag}_${prec}_kernel_stats.csv
 done
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
   rm -rf /tmp/pmc_$name
   rocprofv3 --pmc $pass --output-format csv -d /tmp/pmc_$name -o p -- python3 bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline \
-      > /tmp/pmc_$name.json 2>/dev/null
+      --detail /tmp/pmc_detail_$name.json > /tmp/pmc_$name.json 2>/dev/null
 done
 # (the kernel trace of the bf16 --kernel-trace --stats run above gives the per-(kernel, grid) durations and the step object)
 python3 scripts/pmc_summary.py $(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv") $(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv") \
-    $out/${tag}_pmc_traffic.json bf16 $out/${tag}_bench.json $(find /tmp/pmc_TCC_HIT_sum -name "*counter_collection.csv") \
+    $out/${tag}_pmc_traffic.json bf16 $out/${tag}_bench_detail.json $(find /tmp/pmc_TCC_HIT_sum -name "*counter_collection.csv") \
     $(find /tmp/ks_bf16 -name "*kernel_trace.csv" | head -1) 2 5 > $out/${tag}_pmc_summary.txt 2>&1
 # the bench line of this build against ITS OWN counter passes (bench.py reads the newest profiles/*pmc_traffic.json)
 cp $out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail $out/${tag}_bench_detail.json > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 # the sampled GCL regime as replayed graphs: kernel stats and the busy fraction of the trace
 rm -rf /tmp/gclg
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gclg -o g -- python3 scripts/dev_gcl_graphed_loop.py fp32 100 1 > $out/${tag}_gcl_graphed.txt 2>/dev/null

@@ -35,7 +35,7 @@ if "--measured" in sys.argv:
 args = [a for a in args if not a.endswith(".json")]
 LINK_GBS, LINKS = 153.0, 7          # xGMI: 7 point-to-point links per GPU, ~153 GB/s each (MI355X_MICROARCH.md)
 N, E, R, H = 130_000, 4_000_000, 30, 256
-# measured single-GPU pieces of the sub-steps (scripts/dev_time_calls.py, v28): what an exchange can hide under
+# measured single-GPU pieces of the sub-steps (docs/experiments.md 9-7, scripts/attic/dev_time_calls.py, v28): what an exchange can hide under
 SCORER_FWD_MS = 1.14                 # kge_fused_bce over positives + negatives
 RGCN_PRODUCTS_MS = 1.35              # grouped / root / weight-gradient products of the 4 R-GCN layers
 GCN_PRODUCTS_MS = 0.8                # x W products + weight gradients of the 4 GCN layers (two views)

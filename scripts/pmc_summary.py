@@ -105,7 +105,10 @@ def main(fetch_csv, write_csv, out_json, precision="fp32", bench_json=None, tcc_
     miss = load(tcc_csv, "TCC_MISS_sum") if tcc_csv else {}
     tags = {}
     if bench_json:
-        b = json.loads([ln for ln in open(bench_json) if ln.startswith("{")][-1])
+        try:                                  # the full record (bench_detail.json, round 5) ...
+            b = json.load(open(bench_json))
+        except ValueError:                    # ... or a file holding bench.py's stdout (the line comes last)
+            b = json.loads([ln for ln in open(bench_json) if ln.startswith("{")][-1])
         for r in [b.get("roofline")] + list(b.get("kernels") or []):
             if r and r.get("grid_size"):
                 tags.setdefault(("spmm_items", int(r["grid_size"]), int(r["pieces"])), []).append(r["tag"])
