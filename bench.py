@@ -14,12 +14,16 @@ positive, BCE + L2 reg) over the same synthetic PrimeKG++-shaped graph (BASELINE
 Adam (clip + update fused: biomedkg_amd/optim.py), inputs resident in HBM.  ``value`` = input edges / step time (every input edge counted once
 although both sub-steps consume it), whole job.
 
-N = 1 runs the whole graph on the GPU.  N > 1 (``--mode auto`` -> ``partition``, BASELINE configs[3] / north_star):
-ONE graph, its nodes partitioned over the ranks (biomedkg_amd/partition.py): per conv layer a gather of the table rows a
-rank's in-edges read (forward) and of the output-gradient rows its out-edges point at (backward), every triplet scored by
-the owners of both its endpoints (no gradient rows cross the wire), flat-bucket gradient all-reduce; the total work is
-fixed, so ``"scaling": "strong"``.  ``--mode replicas`` is the reference's own regime (Lightning DDP:
-one graph per rank, gradient all-reduce only, weak scaling) and is opt-in.
+N = 1 runs the whole graph on the GPU.  N > 1, ``--mode auto`` -> ``replicas``: one PrimeKG++-shaped graph per rank, the
+ranks' gradients averaged by one flat RCCL all-reduce per sub-step (the KGE bucket under the next GGD sub-step) -- the
+reference's own multi-GPU regime (Lightning DDP: train_gcl.py:63-68, configs/gcl.yaml:11), per-GPU work fixed, ``"scaling":
+"weak"``, ``value`` = the edges of all ranks' graphs / step time.  ``--mode partition`` (BASELINE configs[3] / north_star's
+node sharding; strong scaling): ONE graph, its nodes partitioned over the ranks (biomedkg_amd/partition.py): per conv layer a
+gather of the table rows a rank's in-edges read (forward) and of the output-gradient rows its out-edges point at (backward),
+every triplet scored by the owners of both its endpoints (no gradient rows cross the wire), flat-bucket gradient all-reduce.
+Round 5 measured each rank's compute on one GPU (scripts/simulate_ranks.py): 7.6 / 5.7 / 4.8 ms per step at 2 / 4 / 8 ranks
+against 9.5 on one GPU -- at most 1.8-2.0x at 8 GPUs whatever the wire does -- which is why it is not the
+default way to use N GPUs on a graph that fits one.
 Default ``--precision bf16`` = BASELINE's "bf16 storage / fp32 accumulate" configuration; ``--precision fp32``
 is the exact parity mode (its step time is reported on the same line as ``ms_per_step_fp32``).
 
@@ -93,8 +97,10 @@ def parse():
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                     help="matrix-core operand precision (BASELINE configs[2] is the bf16 config; fp32 = exact mode)")
     ap.add_argument("--mode", choices=["auto", "replicas", "partition"], default="auto",
-                    help="auto: the whole graph on one GPU, node-partitioned over N > 1 GPUs (strong scaling); "
-                         "replicas: one graph per rank, gradient all-reduce only (weak scaling, the reference's DDP regime)")
+                    help="auto: the whole graph on one GPU; over N > 1 GPUs one graph per rank with a flat gradient "
+                         "all-reduce (replicas: weak scaling, the reference's DDP regime).  partition: ONE graph, its nodes "
+                         "partitioned over the N GPUs (strong scaling; for graphs that do not fit one GPU -- on the bench "
+                         "graph a rank's share of the 9.5 ms step is below the floor of the kernels that carry it: DESIGN.md 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 step / GRACE / NT-Xent / fusion figures")
     ap.add_argument("--cpu-scale", type=int, default=8, help="the live CPU baseline probe runs on a 1/scale graph")
@@ -248,8 +254,8 @@ _EXCHANGE_KEYS = ("wire_bytes_received_per_step", "wire_bytes_sent_per_step", "e
                   "exchange_serial_ms", "exposed_fraction", "ms_per_step_overlapped", "ms_per_step_serial",
                   "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_graphed", "library_calls_per_step",
                   "padded_over_real_rows", "rows", "form")
-_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "ranks", "backend", "steps", "warmup", "ms_per_step", "higher_is_better",
-             "scaling", "vs_baseline", "dtype", "data")
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "ranks", "backend", "mode", "steps", "warmup", "ms_per_step",
+             "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 _SIDE_KEYS = ("triplets_per_sec_kge_step", "edges_per_sec_gcl_step", "ms_per_step_median", "ms_per_step_max", "ms_gcl_step",
               "ms_kge_step", "ms_per_step_fp32", "ms_per_step_shuffled_neg_types", "ms_kge_step_neg10",
               "triplets_per_sec_kge_step_neg10")
@@ -393,7 +399,7 @@ def make_step(module, batch, world, overlap=False):
         opt.zero_grad(set_to_none=True)
         loss = module.training_step(batch)
         loss.backward()
-        if overlap and world > 1:
+        if overlap and bucket.live:
             bucket.begin()
             state["pending"] = True
         else:
@@ -1257,7 +1263,7 @@ def launch_ranks(args):
         raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s) (BKG_BENCH_ONE_DEVICE=1 + "
                          "BKG_BENCH_BACKEND=gloo is the functional single-device check)")
     backend = os.environ.get("BKG_BENCH_BACKEND", "nccl")
-    try_graphs = ("BKG_BENCH_PARTITION_GRAPH" not in os.environ and backend == "nccl" and args.mode in ("auto", "partition"))
+    try_graphs = ("BKG_BENCH_PARTITION_GRAPH" not in os.environ and backend == "nccl" and args.mode == "partition")
     if try_graphs:
         limit = float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "75"))
         setup = float(os.environ.get("BKG_BENCH_SETUP_LIMIT_S", "600"))
@@ -1313,7 +1319,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)                          # does not return
     if (args.gpus > 1 and os.environ.get("BKG_BENCH_SPAWNED") != "1" and os.environ.get("BKG_BENCH_OUTER_RANKS") != "1"
-            and args.mode in ("auto", "partition")):
+            and args.mode == "partition"):
         take_over_from_outer_launcher(args)         # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -1352,7 +1358,7 @@ def main():
             os._exit(7)
 
     from biomedkg_amd import ops
-    mode = args.mode if args.mode != "auto" else ("partition" if world > 1 else "single")
+    mode = args.mode if args.mode != "auto" else ("replicas" if world > 1 else "single")
     ops.set_matmul_precision(args.precision)
     if mode == "partition":
         step_g, step_k, n, e, r = build_partitioned_steps(args, rank, world, dev)
@@ -1610,7 +1616,7 @@ def main():
             "metric": "edges/sec, GCL (GGD) step + KGE (R-GCN+DistMult) step, PrimeKG++ scale",
             "value": total_edges / (ms * 1e-3), "unit": "edges/s", "n_gpus": world,
             "ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-            "backend": ("rccl" if backend == "nccl" else backend), "steps": args.steps,
+            "backend": ("rccl" if backend == "nccl" else backend), "mode": mode, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",

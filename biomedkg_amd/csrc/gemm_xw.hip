@@ -732,14 +732,18 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
   // against 1.3 us of matrix work.  LDS has no room for more tiles in flight, the L2 has: every wave touches each 128-byte
   // line of ITS rows of the tile XK_L2PF tiles further on with one dword-per-lane LDS-DMA into a junk area -- one more
   // instruction on the vmcnt counter per tile, no registers -- so that the tile's real DMA finds its lines in the L2.
-  constexpr int PFL = XK_L2PF > 0 ? 1 : 0;
+  constexpr int LPR64 = KC * 8;                        // 64-byte sectors per row (a 4-byte touch brings in ONE 64-byte sector)
+  constexpr int PFL = XK_L2PF > 0 ? (4 * LPR64 + 63) / 64 : 0;      // prefetch instructions per wave and tile
   auto prefetch = [&](int tile, int lane) {
-    constexpr int LPR = KC * 4;                       // 128-byte lines per row
-    const int rr = wave * 4 + lane / LPR;
-    const int r = max(0, min(tile * XK_BM + rr, g.M - 1));
-    if (lane < 4 * LPR)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)r * g.lda + (lane % LPR) * 64),
-                                       (__attribute__((address_space(3))) void*)(ring + XK_NS * SLOT + XK_CONST_BYTES + wave * 256), 4, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PFL; ++i) {
+      const int sct = i * 64 + lane;                   // sector of the wave's 4 rows
+      const int rr = wave * 4 + sct / LPR64;
+      const int r = max(0, min(tile * XK_BM + rr, g.M - 1));
+      if (sct < 4 * LPR64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)r * g.lda + (sct % LPR64) * 32),
+                                         (__attribute__((address_space(3))) void*)(ring + XK_NS * SLOT + XK_CONST_BYTES + wave * 256), 4, 0, 0);
+    }
   };
   if constexpr (PFL) {
 #pragma unroll

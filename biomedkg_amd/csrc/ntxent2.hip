@@ -51,6 +51,10 @@ constexpr int NX_BJ = 64;   // rows of a j-tile
 #ifndef NX_X2_RD
 #define NX_X2_RD 2           // fragment reads in flight ahead of their MFMAs in the x2 forward at h = 256 (2: 24 B of scratch)
 #endif
+#ifndef NX_X2_ASM
+#define NX_X2_ASM 0          // 1: x2 forward with hand-issued fragment reads (asm ds_read_b128 + counted lgkmcnt) and the NEXT tile's
+#endif                       // four LDS-DMAs issued BETWEEN the MFMAs of the matrix phase.  Round 5, N = 130k: 16.1 ms against 15.5 with
+                             // hipcc's own schedule (0) -- correct, slower: the pinned order costs more than the DMA issue it hides
 #ifndef NX_X2_ODD
 #define NX_X2_ODD 0          // the x2 forward's barrier between a tile's two half-steps: 0 none (15.8 ms at N = 130k), 1 raw s_barrier (16.5), 2 __syncthreads (16.3)
 #endif
@@ -657,6 +661,16 @@ __global__ __launch_bounds__(NW * 64) void ntx2_kernel(NxArgs a) {
   }
 }
 
+template <int OFF> __device__ __forceinline__ uint4 nx_frag_asm(uint32_t addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void nx_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);      // (an MFMA touches no memory: the clobber alone does not keep it behind the wait)
+}
+
 // ------------------------------------------------------------------------------------------------ bf16 forward, 64 anchors per wave
 // The forward kernel above reads one 1 KB A fragment from LDS per 32x32x16 MFMA (the B fragment is the wave's 32 anchor
 // rows in registers): 32 B per cycle and SIMD = 128 B per cycle and CU, exactly what the LDS delivers -- the Gram phase is
@@ -759,6 +773,56 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
 
   nx_acc_t s[AB][2];
   float rowsum[AB] = {0.f, 0.f};
+
+  // (NX_X2_ASM) one of the NG DMAs of a FULL tile, issued from inside the matrix phase: the issue costs 100-185 cycles of
+  // the wave's own chain when it stands in a block of its own (experiments 9-3); between two MFMAs the matrix pipe covers it
+  const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto stage_one = [&](int jt_, int buf_, int g) {
+    unsigned off = st_lane;
+    asm volatile("" : "+v"(off));
+    const int ws = __builtin_amdgcn_readfirstlane(wave);
+    const int q = ws * NG + g, slab = q >> 4;
+    const unsigned char* base = zn + (size_t)(jt_ * NX_BJ + 4 * (q & 15)) * ROW_BYTES + slab * 256;     // wave-uniform
+    unsigned char* dst = tile_at(buf_) + slab * (NX_BJ * 256) + (q & 15) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (off ^ (16u * (q & 3)))),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  // the matrix phase with hand-issued fragment reads: RD k-steps (two reads each) ahead, a counted wait in front of every
+  // k-step's four MFMAs; `jt_next >= 0`: the next tile's DMAs of this wave go out behind k-steps 1, 5, 9, 13
+  auto gram_asm = [&](int buf_, int jt_next) {
+    constexpr int RD = HP > 4 ? NX_X2_RD : 3, RING = RD + 1;
+    uint4 ring[RING][2];
+    uint32_t lc = (uint32_t)(row_lc + buf_ * TILE_BYTES);
+    asm volatile("" : "+v"(lc));
+    const nx_acc_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define NX_READ_K(K, DST)                                                                       \
+    do {                                                                                        \
+      const uint32_t at_ = smem_lds + (lc ^ (uint32_t)(32 * ((K) & 7)));                        \
+      (DST)[0] = nx_frag_asm<16384 * ((K) >> 3)>(at_);                                          \
+      (DST)[1] = nx_frag_asm<16384 * ((K) >> 3) + 8192>(at_);                                   \
+    } while (0)
+#define NX_STEP(K)                                                                              \
+    do {                                                                                        \
+      if constexpr ((K) + RD < KF) NX_READ_K((K) + RD, ring[((K) + RD) % RING]);                \
+      nx_lgkm<2 * ((KF - 1 - (K)) < RD ? (KF - 1 - (K)) : RD)>();                               \
+      _Pragma("unroll") for (int b = 0; b < AB; ++b)                                            \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                           \
+          s[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nx_bf16x8_t, ring[(K) % RING][t]), \
+                                                            __builtin_bit_cast(nx_bf16x8_t, zi[b][(K)]),           \
+                                                            (K) == 0 ? zero16 : s[b][t], 0, 0, 0);                 \
+      if constexpr (((K) & 3) == 1 && ((K) >> 2) < NG) { if (jt_next >= 0) stage_one(jt_next, buf_ ^ 1, (K) >> 2); } \
+    } while (0)
+    if constexpr (RD >= 1) NX_READ_K(0, ring[0]);
+    if constexpr (RD >= 2) NX_READ_K(1, ring[1 % RING]);
+    if constexpr (RD >= 3) NX_READ_K(2, ring[2 % RING]);
+    static_assert(RD <= 3 && KF <= 16 && NG <= 4, "gram_asm: unrolled by hand for h <= 256");
+    NX_STEP(0); NX_STEP(1); NX_STEP(2); NX_STEP(3);
+    if constexpr (KF > 4) { NX_STEP(4); NX_STEP(5); NX_STEP(6); NX_STEP(7); }
+    if constexpr (KF > 8) { NX_STEP(8); NX_STEP(9); NX_STEP(10); NX_STEP(11); }
+    if constexpr (KF > 12) { NX_STEP(12); NX_STEP(13); NX_STEP(14); NX_STEP(15); }
+#undef NX_STEP
+#undef NX_READ_K
+  };
 
   auto gram = [&](int buf_) {
     constexpr int RD = HP > 4 ? NX_X2_RD : 3, RING = RD + 1;      // (h = 256: the two anchor blocks leave little room for reads ahead)
@@ -878,7 +942,9 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
       if (k + 1 < n_it) {
         item_after(Pe, jte);
 #if !defined(NX_EXP_NODMA)
-        stage(jte, (int)((k + 1) & 1));
+        // (NX_X2_ASM: every wave sends ITS pieces of tile k + 1 from inside its own matrix phase of tile k -- the early
+        // waves in this half-step, the late ones in the next -- unless the tile is a partial one: the row-clamped form)
+        if (!NX_X2_ASM || (jte + 1) * NX_BJ > M) stage(jte, (int)((k + 1) & 1));
 #endif
       }
       slot_e = slot_e == 2 ? 0 : slot_e + 1;
@@ -889,7 +955,18 @@ __global__ __launch_bounds__(512) void ntx2_fwd16x2_kernel(NxArgs a) {
     if ((hh & 1) == 0) {
       if (NX_PRIO_GRAM >= 0) __builtin_amdgcn_s_setprio(NX_PRIO_GRAM);
 #if !defined(NX_EXP_NOGRAM)
-      gram(buf);
+      if constexpr (NX_X2_ASM != 0) {
+        int jt_n = -1;
+        if (kw + 1 < n_it) {
+          int P_n = P;
+          jt_n = jt;
+          item_after(P_n, jt_n);
+          if ((jt_n + 1) * NX_BJ > M) jt_n = -1;          // a partial tile: staged by the block's row-clamped form
+        }
+        gram_asm(buf, jt_n);
+      } else {
+        gram(buf);
+      }
 #endif
     } else {
       if (NX_PRIO_VP >= 0) __builtin_amdgcn_s_setprio(NX_PRIO_VP);

@@ -42,7 +42,7 @@ def test_world_size_must_match_gpus():
 
 
 def test_under_an_outer_launcher_rank_zero_takes_over_and_the_others_leave():
-    """``torch.distributed.run --nproc-per-node N bench.py --gpus N``: the outer launcher's workers other than rank 0 exit
+    """``torch.distributed.run --nproc-per-node N bench.py --gpus N --mode partition``: the outer launcher's workers other than rank 0 exit
     0 at once (no GPU touched, nothing printed); rank 0 becomes bench.py's own launcher with a clean rank environment --
     here, without GPUs, its children stop at "needs an MI355X" after reading THEIR rendezvous (two of them, ranks 0 and
     1 on a port of their own, not the outer launcher's)."""
@@ -52,11 +52,15 @@ def test_under_an_outer_launcher_rank_zero_takes_over_and_the_others_leave():
     outer = {"WORLD_SIZE": "2", "LOCAL_WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1",
              "TORCHELASTIC_USE_AGENT_STORE": "True", "TORCHELASTIC_RUN_ID": "x", "BKG_BENCH_ONE_DEVICE": "1",
              "BKG_BENCH_BACKEND": "gloo"}
-    other = _run(dict(outer, RANK="1", LOCAL_RANK="1"), "--gpus", "2", "--steps", "1", "--warmup", "0")
+    part = ("--gpus", "2", "--steps", "1", "--warmup", "0", "--mode", "partition")
+    other = _run(dict(outer, RANK="1", LOCAL_RANK="1"), *part)
     assert other.returncode == 0 and other.stdout.strip() == "" and other.stderr.strip() == ""
-    lead = _run(dict(outer, RANK="0", LOCAL_RANK="0"), "--gpus", "2", "--steps", "1", "--warmup", "0")
+    lead = _run(dict(outer, RANK="0", LOCAL_RANK="0"), *part)
     assert lead.returncode != 0
     assert lead.stderr.count("needs an MI355X") == 2, lead.stderr[-1500:]
     # kept as the ranks on request: this process IS rank 1 then (and stops at the missing GPU itself)
-    kept = _run(dict(outer, RANK="1", LOCAL_RANK="1", BKG_BENCH_OUTER_RANKS="1"), "--gpus", "2", "--steps", "1", "--warmup", "0")
+    kept = _run(dict(outer, RANK="1", LOCAL_RANK="1", BKG_BENCH_OUTER_RANKS="1"), *part)
     assert kept.returncode != 0 and kept.stderr.count("needs an MI355X") == 1
+    # the default mode over N GPUs (round 5: replicas -- nothing to fall back from) runs in the outer launcher's own processes
+    own = _run(dict(outer, RANK="1", LOCAL_RANK="1"), "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert own.returncode != 0 and own.stderr.count("needs an MI355X") == 1

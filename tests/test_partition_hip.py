@@ -297,29 +297,34 @@ def test_fused_partitioned_steps_two_ranks_on_one_gpu_match_one_rank(tmp_path):
             assert err < (3e-2 if key != "dpi_transe" else 6e-2), (key, err)   # TransE: a sum of signs (ties flip)
 
 
-def test_collectives_of_the_partitioned_step_over_a_one_rank_rccl_group():
-    """BKG_PARTITION_FORCE_COLLECTIVES=1: bench.py's node-partitioned step at ONE rank with every collective of the
-    N-rank path issued for real over RCCL (bf16 all-gather of the gather tables, fp32 reduce-scatter of their gradients,
-    the flat gradient all-reduce) -- the closest a single-GPU box gets to the N-rank RCCL path."""
+@pytest.mark.parametrize("mode", ["partition", "replicas"])
+def test_collectives_of_the_partitioned_step_over_a_one_rank_rccl_group(mode):
+    """BKG_PARTITION_FORCE_COLLECTIVES=1: bench.py's N-rank steps at ONE rank with every collective issued for real over
+    RCCL -- the node-partitioned step (bf16 gathers of the tables and output gradients, the flat gradient all-reduce) and
+    the replicas step (the default over N GPUs since round 5: the two flat gradient all-reduces, the KGE one started after
+    its backward and finished under the next GGD sub-step) -- the closest a single-GPU box gets to the N-rank RCCL path."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BKG_PARTITION_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "partition", "--steps", "2",
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--mode", mode, "--steps", "2",
                           "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["scaling"] == "strong" and line["value"] > 0 and line["n_gpus"] == 1
+    assert line["scaling"] == ("strong" if mode == "partition" else "weak") and line["value"] > 0 and line["n_gpus"] == 1
+    assert line["backend"] == "rccl" and line["mode"] == mode
 
 
-@pytest.mark.parametrize("keep_outer_ranks", [False, True])
-def test_bench_under_torch_distributed_run(keep_outer_ranks):
+@pytest.mark.parametrize("keep_outer_ranks,mode", [(False, "partition"), (True, "partition"), (False, "auto")])
+def test_bench_under_torch_distributed_run(keep_outer_ranks, mode):
     """The other form the driver may use: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
-    127.0.0.1 --master-port P bench.py --gpus 2 ...``.  By default the outer launcher's rank 0 becomes bench.py's own
-    launcher (graphed sub-steps first over RCCL, eager fallback; here: gloo on the one GPU) and the other worker leaves;
-    ``BKG_BENCH_OUTER_RANKS=1`` keeps the outer launcher's processes as the ranks.  Either way: exit code 0, ONE JSON line."""
+    127.0.0.1 --master-port P bench.py --gpus 2 ...``.  ``--mode auto`` (round 5: replicas, one graph per rank, weak
+    scaling) runs in the outer launcher's own processes.  ``--mode partition``: the outer launcher's rank 0 becomes
+    bench.py's own launcher (graphed sub-steps first over RCCL, eager fallback; here: gloo on the one GPU) and the other
+    worker leaves; ``BKG_BENCH_OUTER_RANKS=1`` keeps the outer launcher's processes as the ranks.  Every way: exit code 0,
+    ONE JSON line."""
     import json
     import socket
     import subprocess
@@ -334,14 +339,19 @@ def test_bench_under_torch_distributed_run(keep_outer_ranks):
         port = sk.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-                          "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"],
+                          "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000",
+                          "--mode", mode],
                          env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo" and line["scaling"] == "strong"
-    assert line["exchange"] is not None and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo" and line["value"] > 0
+    if mode == "partition":
+        assert line["scaling"] == "strong" and line["exchange"] is not None and line["mode"] == "partition"
+    else:
+        assert line["scaling"] == "weak" and line["mode"] == "replicas" and line["config"]["parallelism"] == "dp2"
+        assert not line.get("exchange")
 
 
 def test_bench_starts_its_own_ranks():
@@ -356,16 +366,21 @@ def test_bench_starts_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(BKG_BENCH_ONE_DEVICE="1", BKG_BENCH_BACKEND="gloo")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000"],
-                         env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo"
-    assert line["scaling"] == "strong" and line["value"] > 0
-    assert line["config"]["parallelism"] == "np2"
+    lines = {}
+    for mode in ("auto", "partition"):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                              "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000", "--mode", mode],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        got = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(got) == 1, out.stdout[-2000:]
+        lines[mode] = json.loads(got[0])
+        assert lines[mode]["n_gpus"] == 2 and lines[mode]["ranks"] == 2 and lines[mode]["backend"] == "gloo"
+        assert lines[mode]["value"] > 0
+    # the default over N GPUs (round 5): one graph per rank, gradient all-reduce only -- the reference's DDP regime
+    assert lines["auto"]["mode"] == "replicas" and lines["auto"]["scaling"] == "weak"
+    assert lines["auto"]["config"]["parallelism"] == "dp2"
+    assert lines["partition"]["scaling"] == "strong" and lines["partition"]["config"]["parallelism"] == "np2"
 
 
 def test_bench_ends_the_job_when_a_rank_dies():
