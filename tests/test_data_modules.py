@@ -183,3 +183,48 @@ def test_loaders_of_the_real_module_hand_out_device_batches(tables):
     assert len(saint) == 1000 and len(dm.val_dataloader(loader_type="saint")) == 100
     b = next(iter(saint))
     assert torch.equal(b.n_id[b.edge_index], tr[:, b.e_id]) and torch.equal(b.edge_type, dm.train_data.edge_type.cuda()[b.e_id])
+
+
+@pytest.mark.gpu
+def test_three_stage_pipeline_gcl_checkpoints_feed_the_kge_stage(tables, monkeypatch):
+    """The reference's pipeline B -> C on the toy tables with its own command lines: ``train_gcl.py`` once per node type
+    (lm features, GGD + attention fuser) writes ``ckpt/gcl/{gene,drug,disease}/ggd_attention_lm_*/epoch=*.ckpt``; ``train_kge.py
+    data.node_init_method=gcl gcl_model=ggd gcl_fuse_method=attention`` then finds no ``data/gcl_embed/ggd_attention.pickle``,
+    builds it from those checkpoints (data_module.GCLEncode -> export.node_embeddings: the reference's per-node
+    NeighborLoader([-1]) loop of data/node.py:196-241 in bulk) and trains on the ``[N, 1, D]`` embeddings."""
+    import numpy as np
+    import train_gcl
+    import train_kge
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import make_toy_kg
+    monkeypatch.chdir(tables)
+    os.makedirs("data/primekg", exist_ok=True)
+    shutil.copy(tables / "primekg" / "kg.csv", "data/primekg/kg.csv")
+    os.makedirs("data/embed", exist_ok=True)
+    rng = np.random.default_rng(0)
+    lm = {name: rng.standard_normal((2, 64)).astype(np.float32)
+          for kind in ("gene/protein", "drug", "disease") for name in make_toy_kg.node_names(kind, 40)}
+    pickle.dump(lm, open("data/embed/primekg_modality_lm.pickle", "wb"))
+    small = ["data.data_dir=data/primekg", "data.embed_dim=64", "model.in_dim=64", "model.hidden_dim=32", "model.out_dim=32",
+             "model.model_name=ggd", "model.fuse_method=attention", "data.node_init_method=lm", "data.batch_size=16",
+             "epochs=1", "val_every_epoch=1", "ckpt_dir=ckpt", "devices=[0]"]
+    for nt in ("gene", "drug", "disease"):
+        out = train_gcl.main([f"data.node_type={nt}"] + small)
+        assert "test_loss" in out[0]
+        assert [f for _, _, fs in os.walk(os.path.join("ckpt", "gcl", nt)) for f in fs if f.endswith(".ckpt")]
+    out = train_kge.main(["data.data_dir=data/primekg", "data.node_init_method=gcl", "gcl_model=ggd", "gcl_fuse_method=attention",
+                          "data.embed_dim=32", "model.in_dim=32", "model.hidden_dim=16", "model.out_dim=16", "neg_ratio=2",
+                          "debug=true", "ckpt_dir=ckpt", "devices=[0]"])
+    assert out and isinstance(out[0], dict)
+    table = pickle.load(open("data/gcl_embed/ggd_attention.pickle", "rb"))
+    from biomedkg_amd.data_module import PrimeKGModule
+    dm = PrimeKGModule(data_dir="data/primekg", embed_dim=32, node_type=["gene/protein", "drug", "disease"], batch_size=8,
+                       val_ratio=0.2, test_ratio=0.2, node_init_method="gcl", gcl_model="ggd", gcl_fuse_method="attention")
+    dm.setup(stage="all")
+    # (a node that has no edge inside its own type's graph is in no GCL stage: the reference gives it a random row too)
+    names = set(dm.primekg.node_list)
+    assert set(table) <= names and len(table) > 0.6 * len(names) and all(v.shape == (1, 32) for v in table.values())
+    genes = {n for n in names if n.startswith("GENE")}
+    assert len(genes & set(table)) >= len(genes) - 3                         # (nearly) every gene has a protein_protein edge here
+    assert dm.data.x.shape == (dm.data.num_nodes, 1, 32) and dm.encoder.random_init_ratio < 0.5
+    assert np.isfinite(np.stack(list(table.values()))).all()
