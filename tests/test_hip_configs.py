@@ -267,7 +267,26 @@ def test_c3_as_timed_bf16_path_against_fp64_with_the_same_rounding_points():
     e_kge = check("kge", loss64.detach(), {**W, **Rt, **bs, "decoder.rel_emb": rel})
     differing = [m / t for m, t in B.GATE_MISMATCHES]
     assert len(differing) == len(layers) - 1 and max(differing) < 1e-3, differing     # measured 2e-5, 9e-5, 2e-4
+    # ... and WITHOUT the HIP run's decisions (the aligned form above is mildly self-referential): the same
+    # restatement gating by its own float64 pre-activations.  The loss does not feel a few flipped gates in 10^5 (same
+    # 1e-4 bar); the weight / bias gradients -- sums of cancelling terms over 130,000 rows -- move by what one flipped
+    # element per 10^4 is worth, so their bar is the size of THAT effect (measured 1e-3 per layer, bar 2e-2), which still
+    # catches any shortcut of the size of a term.
+    del loss64
+    W2 = {k: B.leaf(v.detach().float()) for k, v in W.items()}
+    R2 = {k: B.leaf(v.detach().float()) for k, v in Rt.items()}
+    b2 = {k: B.leaf(v.detach().float()) for k, v in bs.items()}
+    rel2 = B.leaf(rel.detach().float())
+    loss_free, _ = B.kge_step(bk.x.double(), ei, et, drawn["neg"], drawn["neg_type"], list(W2.values()), list(R2.values()),
+                              list(b2.values()), rel2, r, gates=None)
+    loss_free.backward()
+    l16, g16 = got["kge"]
+    assert abs(l16 - float(loss_free)) <= 1e-4 * max(1.0, abs(float(loss_free))), (l16, float(loss_free))
+    free = {k: float((g16[k] - v.grad).norm() / v.grad.norm().clamp_min(1e-30))
+            for k, v in {**W2, **R2, **b2, "decoder.rel_emb": rel2}.items()}
+    assert max(free.values()) < 2e-2, free
     short = lambda e: ", ".join(f"{k.replace('encoder.graph_layers.', 'L')}={v:.1e}" for k, v in e.items())  # noqa: E731
+    print("KGE against the restatement gating by its OWN pre-activations: " + short(free))
     print("bf16 path vs fp64 restatement with bf16 rounding points, gradient errors: GGD " + short(e_ggd)
           + "; KGE " + short(e_kge) + "; ReLU decisions that differ per hidden layer: " + ", ".join(f"{v:.1e}" for v in differing))
 
