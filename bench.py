@@ -253,7 +253,8 @@ _CPU_KEYS = ("value", "unit", "cores", "kind", "cpu_model", "seconds_per_step", 
 _EXCHANGE_KEYS = ("wire_bytes_received_per_step", "wire_bytes_sent_per_step", "exchanges_per_step", "exchange_exposed_ms",
                   "exchange_serial_ms", "exposed_fraction", "ms_per_step_overlapped", "ms_per_step_serial",
                   "host_enqueue_ms_per_step", "host_enqueue_ms_per_step_graphed", "library_calls_per_step",
-                  "padded_over_real_rows", "rows", "form")
+                  "padded_over_real_rows", "rows", "form", "bucket_bytes_ggd", "bucket_bytes_kge", "allreduce_alone_ms_ggd",
+                  "allreduce_alone_ms_kge")
 _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "ranks", "backend", "mode", "steps", "warmup", "ms_per_step",
              "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 _SIDE_KEYS = ("triplets_per_sec_kge_step", "edges_per_sec_gcl_step", "ms_per_step_median", "ms_per_step_max", "ms_gcl_step",
@@ -410,6 +411,7 @@ def make_step(module, batch, world, overlap=False):
     step.finish = finish
     step.batch = batch
     step.params = params
+    step.bucket = bucket
     return step
 
 
@@ -1488,6 +1490,23 @@ def main():
                             "bf16 mode), the scorer's embedding table -- its gradient needs no exchange (both-owner scoring) -- "
                             "the first R-GCN layer's constant input gathered once per graph, not per step; the flat gradient "
                             "all-reduce is not counted here"}
+    if mode == "replicas" and getattr(step_g, "bucket", None) is not None and step_g.bucket.live:
+        # what crosses the wire per step in the replicas regime: the two flat gradient buckets, all-reduced (ring: 2 (P - 1) / P
+        # of the bucket per rank); timed alone on the buckets as they stand after the run (3 repetitions, every rank together)
+        def reduce_ms(bucket):
+            bucket.pack()
+            sync(); t = time.perf_counter()
+            for _ in range(3):
+                bucket.all_reduce_packed()
+            sync()
+            return (time.perf_counter() - t) / 3 * 1e3
+        by_g = sum(p.numel() for p in step_g.bucket.params) * 4
+        by_k = sum(p.numel() for p in step_k.bucket.params) * 4
+        ring = 2.0 * (world - 1) / max(world, 1)
+        exchange = {"form": "flat gradient all-reduce per sub-step (the KGE bucket under the next GGD sub-step)",
+                    "exchanges_per_step": 2, "bucket_bytes_ggd": by_g, "bucket_bytes_kge": by_k,
+                    "wire_bytes_sent_per_step": ring * (by_g + by_k), "wire_bytes_received_per_step": ring * (by_g + by_k),
+                    "allreduce_alone_ms_ggd": reduce_ms(step_g.bucket), "allreduce_alone_ms_kge": reduce_ms(step_k.bucket)}
     # the same two losses after the run's optimizer steps (every rank: collectives inside): training moved them
     check_after = step_g.check_fn() if mode == "partition" else None
     n_neg = args.neg_ratio * e

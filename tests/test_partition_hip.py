@@ -351,7 +351,9 @@ def test_bench_under_torch_distributed_run(keep_outer_ranks, mode):
         assert line["scaling"] == "strong" and line["exchange"] is not None and line["mode"] == "partition"
     else:
         assert line["scaling"] == "weak" and line["mode"] == "replicas" and line["config"]["parallelism"] == "dp2"
-        assert not line.get("exchange")
+        ex = line["exchange"]                # the regime's only wire traffic: the two flat gradient buckets
+        assert ex["exchanges_per_step"] == 2 and ex["bucket_bytes_kge"] > ex["bucket_bytes_ggd"] > 0
+        assert ex["allreduce_alone_ms_kge"] > 0 and ex["wire_bytes_sent_per_step"] == ex["bucket_bytes_ggd"] + ex["bucket_bytes_kge"]
 
 
 def test_bench_starts_its_own_ranks():
