@@ -1318,6 +1318,9 @@ def take_over_from_outer_launcher(args):
 
 def main():
     args = parse()
+    # dmabuf IPC: RCCL across processes needs it on this stack (the launcher sets it for the ranks it starts; ranks started
+    # by an outer torch.distributed.run get it here, before anything touches the GPU)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)                          # does not return
     if (args.gpus > 1 and os.environ.get("BKG_BENCH_SPAWNED") != "1" and os.environ.get("BKG_BENCH_OUTER_RANKS") != "1"
