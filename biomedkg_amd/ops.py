@@ -2061,9 +2061,10 @@ def _attention_fusion_projected(x2, w_qkv, b_qkv, n, d):
         return (_exact_gemm(wq, wk, trans_a=True),                        # Wq^T Wk  [D, D]
                 _exact_gemm(bq.view(1, d), wk).view(d),                   # Wk^T bq
                 _exact_gemm(bk.view(1, d), wq).view(d),                   # Wq^T bk
-                float((bq.double() * bk.double()).sum()))
+                float((bq.double() * bk.double()).sum()),
+                wv)                                                       # (the SAME view object every call: its bf16 image stays cached on it)
     from .graph import _cached
-    mqk, u, w, c0 = _cached(w_qkv, "attn_projected", (b_qkv.data_ptr(), b_qkv._version, d), constants)
+    mqk, u, w, c0, wv = _cached(w_qkv, "attn_projected", (b_qkv.data_ptr(), b_qkv._version, d), constants)
     t = gemm(x2, mqk, out_dtype=torch.bfloat16)                           # [2n, D] bf16
     xc = torch.empty(n, d, dtype=torch.bfloat16, device=x2.device)
     L.call("bkg_attn_scores_combine_bf16", L.ptr(t), t.stride(0), L.ptr(x2), x2.stride(0), n, d, L.ptr(u), L.ptr(w), c0,
