@@ -330,13 +330,13 @@ def compact_line(out, detail_path=None):
     for k in _SIDE_KEYS:
         if out.get(k) is not None:
             line[k] = out[k]
-    for key in ("check_loss", "check_loss_after"):
+    for key in ("check_loss", "check_loss_after", "partition_bound"):
         if out.get(key):
-            line[key] = {k: v for k, v in out[key].items() if not isinstance(v, str)}
+            line[key] = {k: v for k, v in out[key].items() if not isinstance(v, str) or k == "source"}
     line["detail"] = detail_path
     line = _strict(line)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
-    for drop in ("check_loss_after", "check_loss", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_shuffled_neg_types",
+    for drop in ("check_loss_after", "check_loss", "partition_bound", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_shuffled_neg_types",
                  "ms_per_step_fp32", "exchange.graphed_sub_steps", "cpu_baseline.threads1", "cpu_baseline.full_size"):
         if len(text) < LINE_LIMIT - 1024:
             break
@@ -1510,6 +1510,19 @@ def main():
                     "exchanges_per_step": 2, "bucket_bytes_ggd": by_g, "bucket_bytes_kge": by_k,
                     "wire_bytes_sent_per_step": ring * (by_g + by_k), "wire_bytes_received_per_step": ring * (by_g + by_k),
                     "allreduce_alone_ms_ggd": reduce_ms(step_g.bucket), "allreduce_alone_ms_kge": reduce_ms(step_k.bucket)}
+    partition_bound = None
+    if world > 1 and mode == "replicas":
+        # why this is not the node-partitioned step: its measured bound at this world size (profiles/*partition_model.json:
+        # each rank's compute measured on one GPU by scripts/simulate_ranks.py + the wire model)
+        try:
+            import glob
+            path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*partition_model.json")), reverse=True)[0]
+            row = next(r_ for r_ in json.load(open(path))["ranks"] if r_["world"] == world)
+            partition_bound = {"world": world, "compute_ms_slowest_rank_measured": row.get("compute_ms_measured"),
+                               "step_ms_as_coded": row.get("step_ms_as_coded"), "speedup_over_one_gpu": row.get("speedup_as_coded"),
+                               "wire_MB_per_step_per_rank": row.get("wire_MB"), "source": os.path.basename(path)}
+        except Exception:      # noqa: BLE001 - reporting only
+            partition_bound = None
     # the same two losses after the run's optimizer steps (every rank: collectives inside): training moved them
     check_after = step_g.check_fn() if mode == "partition" else None
     n_neg = args.neg_ratio * e
@@ -1679,6 +1692,7 @@ def main():
             "triplets_per_sec_kge_step_neg10": (neg10 or {}).get("triplets_per_sec_kge_step"),
             "roofline": roof, "roofline_model": ROOFLINE_MODEL, "kernels": others, "exchange": exchange,
             "step_accounting": None,
+            "partition_bound": partition_bound,
             "check_loss": getattr(step_g, "check_loss", None), "check_loss_after": check_after,
             "cpu_baseline": None,
         }
