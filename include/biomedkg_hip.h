@@ -181,7 +181,12 @@ int bkg_gemm_grouped_k_bf16(int64_t rows_total, int64_t M, int64_t N, const void
  * W + b*stride_w of shape [rows, cols]), C is fp32 or bf16 (c_is_bf16; beta needs fp32).  K % 256 == 0, N % 32 == 0,
  * 16-byte aligned rows.  group_ptr != NULL: rows of group g use Wt + g*stride_w (device group_ptr[G+1]).
  * bf16 rows with K = N = 256 and no gate / beta -- every hidden layer of the bench step -- run the 8-wave form that keeps
- * the weight in registers and streams A through LDS in full lines (plain; grouped with G <= 63; gathered). */
+ * the weight in registers and streams A through LDS in full lines (plain; grouped with G <= 63; gathered).  bf16 rows with
+ * K = 512 | 768 and N a multiple of 256 (<= 2048), no groups / gate / beta -- ReDAF, AttentionFusion's two products, the
+ * first GCN layer: reference biomedkg/utils/fusion.py:17-31,49-90, model/encoder.py:153-162 -- run the weight-slab form
+ * (round 5: a 256-column slab of the weight in registers for the block's life, 32-row A tiles through an LDS-DMA ring,
+ * the column groups of a row tile on one XCD; env BKG_XW_SLAB=0 keeps the streaming kernel).  Same results either way
+ * (bit-equal at K = 768: one accumulator, k ascending). */
 int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w, int64_t rows, int64_t cols, int32_t batch,
                        void* out /* [batch, rows, cols] bf16, nullable */, int64_t ldo, int64_t stride_o,
                        void* out_t /* [batch, cols, rows] bf16 (transposed), nullable */, int64_t ldt, int64_t stride_t,
