@@ -608,8 +608,8 @@ __global__ __launch_bounds__(512) void gemm_xw8_grouped_kernel(XwArgs g, GemmEpi
 // MFMA-fragment shape (every 128-byte line asked for four times): 0.84 ms = 365 TF for ReDAF at 130k nodes.
 // Here the block is gemm_xw8_kernel's -- 8 waves, wave w owns columns [32 w, 32 w + 32) of the block's 256, A tiles by
 // LDS-DMA into a ring, one raw barrier per tile, counted vmcnt waits -- extended along K: the wave keeps its 32 weight rows
-// for ALL K as 16 KC MFMA operands (192 VGPRs at K = 768).  That leaves 64 registers, so a tile is 32 rows (ONE 32 x 32
-// accumulator, 16 registers; the 64-row form spilled -- and a spill is a scratch access on the vmcnt counter the ring is
+// for ALL K as 16 KC MFMA operands (192 VGPRs at K = 768).  That leaves 64 registers, so a tile is 32 rows (four 16 x 16
+// accumulators, 16 registers; the 64-row form spilled -- and a spill is a scratch access on the vmcnt counter the ring is
 // waited by) x all K: KC planes of 32 rows x 512 B, gemm_xw8_kernel's swizzle inside a plane; three ring slots (48 KB each
 // at K = 768), two tiles in flight.  Per tile and CU: 48 KB through the DMA, 384 KB of LDS fragment reads (1536 clocks at
 // 256 B/clk) under 2 x 1536 MFMA clocks per SIMD: matrix-pipe bound, not LDS bound.
@@ -628,7 +628,7 @@ constexpr int XK_JUNK_BYTES = 8 * 256;        // where the L2 prefetch's dwords 
 #define XK_L2PF 0        // tiles an L2 prefetch runs ahead of the DMA (0: none -- measured: 2 / 3 / 6 tiles ahead cost 3 / 6 / 7 %)
 #endif
 #ifndef XK_ABL
-#define XK_ABL 0         // ablations for timing only (wrong results): 1 no DMA, 2 no epilogue, 4 no fragment reads / MFMA
+#define XK_ABL 0         // ablations for timing only (wrong results): 1 no DMA, 2 no epilogue, 4 no matrix phase, 8 no fragment reads in it
 #endif
 #ifndef XK_STAGGER
 #define XK_STAGGER 1     // waves 4-7 defer their epilogue by one tile (0: all eight waves in step)
@@ -648,6 +648,9 @@ template <int OFF> __device__ __forceinline__ xw_bf16x8_t xk_frag(uint32_t addr)
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
+__device__ __forceinline__ xw_bf16x8_t xk_frag_rt(uint32_t addr, int off) {      // (off: 0 or 8192, compile-time after unrolling)
+  return off ? xk_frag<8192>(addr) : xk_frag<0>(addr);
+}
 template <int N> __device__ __forceinline__ void xk_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);      // (an MFMA touches no memory: the clobber alone does not keep it behind the wait)
@@ -660,17 +663,27 @@ template <int OFF> __device__ __forceinline__ float4 xk_const4(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
   return make_float4(v[0], v[1], v[2], v[3]);
 }
-// step S of a tile's 16 KC k-steps: the fragment of step S + XK_PF leaves, the wait leaves the younger reads in flight
-template <int S, int KC> __device__ __forceinline__ void xk_step(xw_acc_t& acc, const xw_bf16x8_t (&w)[KC][16],
-                                                                 xw_bf16x8_t (&a)[XK_PF + 1], uint32_t tile, int p16) {
-  constexpr int T = 16 * KC, NX = S + XK_PF;
-  if constexpr (NX < T)
-    a[NX % (XK_PF + 1)] = xk_frag<(NX / 16) * (XK_BM * 512)>(tile + (uint32_t)(((NX % 16) * 32) ^ p16));
-  xk_lgkm<(T - 1 - S) < XK_PF ? (T - 1 - S) : XK_PF>();
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[S / 16][S % 16], a[S % (XK_PF + 1)], acc, 0, 0, 0);
-  if constexpr (S + 1 < T) xk_step<S + 1, KC>(acc, w, a, tile, p16);
+typedef float xk_acc4_t __attribute__((ext_vector_type(4)));
+// Half-step H of a tile's 16 KC: k-step k32 = H / 2 (32 deep), row group rg = H % 2 (16 rows).  The fragment of half-step
+// H + XK_PF leaves, the wait leaves the younger reads in flight, then the fragment meets the wave's two 16-column weight
+// fragments of this k-step: v_mfma_f32_16x16x32_bf16 into FOUR independent accumulators (rg, ch) -- the same accumulator
+// comes round every fourth MFMA.  (Round 5 first built this on v_mfma_f32_32x32x16_bf16 with ONE 32 x 32 accumulator; the
+// two forms run at the same speed and give the same bits -- the matrix phase alone, without DMA, epilogue or fragment
+// reads (XK_ABL = 11), takes 0.19 ms for 307 GFLOP = 1.6 PF: the matrix pipe is saturated at the clock the chip holds under
+// back-to-back bf16 MFMAs -- this form keeps ten more registers free of the 256.)
+template <int H, int KC> __device__ __forceinline__ void xk_step(xk_acc4_t (&acc)[2][2], const xw_bf16x8_t (&w)[2][8 * KC],
+                                                                 xw_bf16x8_t (&a)[XK_PF + 1], uint32_t tile, int q0) {
+  constexpr int T = 16 * KC, NX = H + XK_PF;
+  if constexpr (NX < T && !(XK_ABL & 8)) {      // (XK_ABL & 8: timing only -- no fragment reads in the loop)
+    constexpr int k32 = NX / 2, rg = NX % 2;
+    // row 16 rg + fr, 16-byte chunk 4 (k32 % 8) + fq of plane k32 / 8, at position chunk ^ row (the source swizzle)
+    a[NX % (XK_PF + 1)] = xk_frag<(k32 / 8) * (XK_BM * 512) + rg * 8192>(tile + (uint32_t)((64 * (k32 % 8)) ^ q0 ^ (256 * rg)));
+  }
+  xk_lgkm<(T - 1 - H) < XK_PF ? (T - 1 - H) : XK_PF>();
+  acc[H % 2][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][H / 2], a[H % (XK_PF + 1)], acc[H % 2][0], 0, 0, 0);
+  acc[H % 2][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1][H / 2], a[H % (XK_PF + 1)], acc[H % 2][1], 0, 0, 0);
+  if constexpr (H + 1 < T) xk_step<H + 1, KC>(acc, w, a, tile, q0);
 }
-
 template <typename CT, int KC, bool REDAF>
 __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue ep, int n_groups, int streams) {
   constexpr int SLOT = XK_BM * KC * 512;
@@ -699,15 +712,15 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
   }
   uint32_t sid = 0;
   if constexpr (REDAF) sid = __builtin_amdgcn_readfirstlane(with_epoch(g.rd_stream, g.rd_epoch));
-  // the weights: rows n0 + l31, all K
-  xw_bf16x8_t w[KC][16];
+  // the weights: the wave's two 16-column fragments (rows n0 + 16 ch + fr of Wt) of every 32-deep k-step
+  xw_bf16x8_t w[2][8 * KC];
   {
-    const int l31 = threadIdx.x & 31, lh = (threadIdx.x >> 5) & 1;
+    const int fr = threadIdx.x & 15, fq = (threadIdx.x >> 4) & 3;
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc)
+    for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks)
-        w[kc][ks] = *reinterpret_cast<const xw_bf16x8_t*>(g.Wt + (int64_t)(n0 + l31) * g.ldw + kc * 256 + ks * 16 + lh * 8);
+      for (int k32 = 0; k32 < 8 * KC; ++k32)
+        w[ch][k32] = *reinterpret_cast<const xw_bf16x8_t*>(g.Wt + (int64_t)(n0 + 16 * ch + fr) * g.ldw + k32 * 32 + fq * 8);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                 // cst is visible; nothing is in flight
@@ -762,59 +775,78 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
     keep_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, keep_scale)));
     thresh = __builtin_amdgcn_readfirstlane((uint32_t)fminf(g.rd_p * 4294967296.0f, 4294967295.0f));
   }
-  // the tile's epilogue: acc[4q..4q+3] = C[t * 32 + l31][n0 + 8 q + 4 lh + 0..3]
-  auto epilogue = [&](const xw_acc_t& acc, int t) {
+  // the tile's epilogue: acc[rg][ch][j] = C[t * 32 + 16 rg + fr][n0 + 16 ch + 4 fq + j]   (fr = lane & 15, fq = lane >> 4)
+  auto epilogue = [&](const xk_acc4_t (&acc)[2][2], int t) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int l31 = tid & 31, lh = (tid >> 5) & 1;
-    const uint32_t cb = ring_lds + (uint32_t)(XK_NS * SLOT + (wave * 32 + 4 * lh) * 4);
-    const int row = t * XK_BM + l31;
+    const int fr = tid & 15, fq = (tid >> 4) & 3;
+    const uint32_t cb = ring_lds + (uint32_t)(XK_NS * SLOT + (wave * 32 + 4 * fq) * 4);
     if constexpr (REDAF) {
       // ReDAF.forward behind the product (reference biomedkg/utils/fusion.py:49-90), as gemm_xw_kernel<.., REDAF> runs it:
-      // the two modality rows of a node are the lanes l31 and l31 ^ 1; the Philox stream is indexed exactly as
-      // bkg_redaf_combine_f32 indexes it (the same masks, the same bits out)
-      const int mrow = l31 & 1;
-      const bool live = row < g.M;
+      // the two modality rows of a node are the lanes fr and fr ^ 1; the Philox stream is indexed exactly as
+      // bkg_redaf_combine_f32 indexes it (the same masks)
+      const int mrow = fr & 1;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int off = q * 8 + lh * 4, col = n0 + off;
-        float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-        const float4 b = xk_const4<0>(cb + 32 * q);
-        v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f); v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
-        const float4 sc = xk_const4<1024>(cb + 1024 * mrow + 32 * q);
-        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-        if (g.rd_p > 0.f) {
-          const uint4 r = philox_keep4(g.rd_seed, (uint64_t)(g.rd_row0 + row) * g.N + col, sid);
-          v.x = r.x >= thresh ? v.x * keep_scale : 0.f; v.y = r.y >= thresh ? v.y * keep_scale : 0.f;
-          v.z = r.z >= thresh ? v.z * keep_scale : 0.f; v.w = r.w >= thresh ? v.w * keep_scale : 0.f;
+      for (int rg = 0; rg < 2; ++rg) {
+        const int row = t * XK_BM + 16 * rg + fr;
+        const bool live = row < g.M;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const int col = n0 + 16 * ch + 4 * fq;
+          float4 v = make_float4(acc[rg][ch][0], acc[rg][ch][1], acc[rg][ch][2], acc[rg][ch][3]);
+          const float4 b = ch ? xk_const4<64>(cb) : xk_const4<0>(cb);
+          v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f); v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+          const float4 sc = ch ? xk_const4<1024 + 64>(cb + 1024 * mrow) : xk_const4<1024>(cb + 1024 * mrow);
+          v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+          if (g.rd_p > 0.f) {
+            const uint4 r = philox_keep4(g.rd_seed, (uint64_t)(g.rd_row0 + row) * g.N + col, sid);
+            v.x = r.x >= thresh ? v.x * keep_scale : 0.f; v.y = r.y >= thresh ? v.y * keep_scale : 0.f;
+            v.z = r.z >= thresh ? v.z * keep_scale : 0.f; v.w = r.w >= thresh ? v.w * keep_scale : 0.f;
+          }
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          float4 o;   // the partner lane's values (lane ^ 1: quad_perm [1, 0, 3, 2] -- a DPP move, no LDS round trip)
+          o.x = xk_swap1(v.x); o.y = xk_swap1(v.y); o.z = xk_swap1(v.z); o.w = xk_swap1(v.w);
+          if (live && mrow == 0)   // modality 0 first, as the two-kernel form adds them
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)(row >> 1) * g.ldc + col) =
+                make_float4((v.x + o.x) * 0.5f, (v.y + o.y) * 0.5f, (v.z + o.z) * 0.5f, (v.w + o.w) * 0.5f);
         }
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        float4 o;   // the partner lane's values (lane ^ 1: quad_perm [1, 0, 3, 2] -- a DPP move, no LDS round trip)
-        o.x = xk_swap1(v.x); o.y = xk_swap1(v.y); o.z = xk_swap1(v.z); o.w = xk_swap1(v.w);
-        if (live && mrow == 0)   // modality 0 first, as the two-kernel form adds them: bit-equal
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)(row >> 1) * g.ldc + col) =
-              make_float4((v.x + o.x) * 0.5f, (v.y + o.y) * 0.5f, (v.z + o.z) * 0.5f, (v.w + o.w) * 0.5f);
       }
     } else {
-      if (row < g.M) {
-        CT* __restrict__ drow_p = reinterpret_cast<CT*>(g.C) + (int64_t)row * g.ldc + n0;
 #pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
-          float4 v[2];
+      for (int rg = 0; rg < 2; ++rg) {
+        const int row = t * XK_BM + 16 * rg + fr;
+        float4 v[2];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int q = 2 * qp + h;
-            const float4 b = xk_const4<0>(cb + 32 * q);
-            v[h] = make_float4(ep.alpha * acc[4 * q] + b.x, ep.alpha * acc[4 * q + 1] + b.y,
-                               ep.alpha * acc[4 * q + 2] + b.z, ep.alpha * acc[4 * q + 3] + b.w);
-            if (ep.act == 1) {
-              v[h].x = fmaxf(v[h].x, 0.f); v[h].y = fmaxf(v[h].y, 0.f); v[h].z = fmaxf(v[h].z, 0.f); v[h].w = fmaxf(v[h].w, 0.f);
-            } else if (ep.act == 2) {
-              v[h].x = v[h].x > 0.f ? v[h].x : expm1f(v[h].x); v[h].y = v[h].y > 0.f ? v[h].y : expm1f(v[h].y);
-              v[h].z = v[h].z > 0.f ? v[h].z : expm1f(v[h].z); v[h].w = v[h].w > 0.f ? v[h].w : expm1f(v[h].w);
-            }
+        for (int ch = 0; ch < 2; ++ch) {
+          const float4 b = ch ? xk_const4<64>(cb) : xk_const4<0>(cb);
+          v[ch] = make_float4(ep.alpha * acc[rg][ch][0] + b.x, ep.alpha * acc[rg][ch][1] + b.y,
+                              ep.alpha * acc[rg][ch][2] + b.z, ep.alpha * acc[rg][ch][3] + b.w);
+          if (ep.act == 1) {
+            v[ch].x = fmaxf(v[ch].x, 0.f); v[ch].y = fmaxf(v[ch].y, 0.f); v[ch].z = fmaxf(v[ch].z, 0.f); v[ch].w = fmaxf(v[ch].w, 0.f);
+          } else if (ep.act == 2) {
+            v[ch].x = v[ch].x > 0.f ? v[ch].x : expm1f(v[ch].x); v[ch].y = v[ch].y > 0.f ? v[ch].y : expm1f(v[ch].y);
+            v[ch].z = v[ch].z > 0.f ? v[ch].z : expm1f(v[ch].z); v[ch].w = v[ch].w > 0.f ? v[ch].w : expm1f(v[ch].w);
           }
-          xw_store_pair(drow_p + 16 * qp, lh, v[0], v[1]);
+        }
+        if constexpr (sizeof(CT) == 4) {
+          if (row < g.M) {
+            float* __restrict__ drow_p = reinterpret_cast<float*>(g.C) + (int64_t)row * g.ldc + n0 + 4 * fq;
+            *reinterpret_cast<float4*>(drow_p) = v[0];
+            *reinterpret_cast<float4*>(drow_p + 16) = v[1];
+          }
+        } else {
+          // bf16: the lane pair (fq, fq ^ 1: lanes 16 apart, the same row) trades one packed quad so that each lane owns 8
+          // CONSECUTIVE columns and writes one 16-byte piece: even fq the columns 4 fq .. + 7 of the first 16, odd fq the
+          // columns 4 (fq - 1) .. + 7 of the second 16
+          const uint2 p0 = xw_pack4(v[0]), p1 = xw_pack4(v[1]);
+          const bool odd = fq & 1;
+          const uint2 give = odd ? p0 : p1;
+          uint2 got;
+          got.x = __shfl_xor(give.x, 16, 64);
+          got.y = __shfl_xor(give.y, 16, 64);
+          const uint4 o = odd ? make_uint4(got.x, got.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, got.x, got.y);
+          if (row < g.M)
+            *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(g.C) + (int64_t)row * g.ldc + n0 + (odd ? 16 + 4 * (fq - 1) : 4 * fq)) = o;
         }
       }
     }
@@ -824,12 +856,12 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
   // "Two waves per SIMD", item 9): after every barrier waves 0-3 multiply while waves 4-7 finish their previous tile, then
   // the roles swap.  Their stores come one iteration later, so their vmcnt ladder starts one step later.
   const bool late = XK_STAGGER && wave >= 4;
-  xw_acc_t acc;
+  xk_acc4_t acc[2][2];
   int t_prev = -1;
   for (int t = first; t < m_tiles; t += stride) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    const int l31 = tid & 31, lh = (tid >> 5) & 1;
+    const int l31 = tid & 31, lh = (tid >> 5) & 1;      // (the DMA pieces' lane roles)
     // behind this tile's DMAs: the next tile's (D), the prefetches of the iterations since (at most two) and the stores of
     // the tiles finished since (at most two; one iteration later for the deferring waves)
     const int stores_behind = min(late ? max(it - 1, 0) : it, 2), pf_behind = min(it, 2);
@@ -842,18 +874,22 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
     if constexpr (PFL) prefetch(t + (2 + XK_L2PF) * stride, tid & 63);
     if (late && t_prev >= 0 && !(XK_ABL & 2)) epilogue(acc, t_prev);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) acc[rg][ch] = xk_acc4_t{0.f, 0.f, 0.f, 0.f};
     if constexpr (!(XK_ABL & 4)) {
-      const int p16 = (lh ^ l31) * 16;
-      const uint32_t tile = ring_lds + (uint32_t)(slot * SLOT + l31 * 512);
+      const int fr = tid & 15, fq = (tid >> 4) & 3;
+      const int q0 = 16 * (fq ^ fr);
+      const uint32_t tile = ring_lds + (uint32_t)(slot * SLOT + fr * 512);
       xw_bf16x8_t a[XK_PF + 1];
 #pragma unroll
-      for (int s0 = 0; s0 < XK_PF; ++s0) a[s0] = xk_frag<0>(tile + (uint32_t)((s0 * 32) ^ p16));   // (XK_PF <= 16: plane 0)
-      xk_step<0, KC>(acc, w, a, tile, p16);
+      for (int h0 = 0; h0 < XK_PF; ++h0)       // (XK_PF <= 16: plane 0) half-step h0: k-step h0 / 2, row group h0 % 2
+        a[h0] = xk_frag_rt(tile + (uint32_t)((64 * ((h0 / 2) % 8)) ^ q0 ^ (256 * (h0 % 2))), (h0 % 2) * 8192);
+      xk_step<0, KC>(acc, w, a, tile, q0);
     }
     slot = slot + 1 == XK_NS ? 0 : slot + 1;
     if (!late && !(XK_ABL & 2)) epilogue(acc, t);
-    if constexpr ((XK_ABL & 2) != 0) asm volatile("" ::"v"(acc));
+    if constexpr ((XK_ABL & 2) != 0) asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[1][0]), "v"(acc[1][1]));
     t_prev = t;
   }
   if (late && t_prev >= 0) epilogue(acc, t_prev);
