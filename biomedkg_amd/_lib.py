@@ -63,6 +63,8 @@ SIGNATURES = {
     # gemm_xw.hip
     "bkg_weight_to_bf16": (I32, [P, I64, I64, I64, I64, I32, P, I64, I64, P, I64, I64, P]),
     "bkg_gemm_xw": (I32, [I64, I64, I64, F32, P, I32, I64, P, P, I64, I64, P, I32, F32, P, I32, I64, P, I32, P, I64, F32, P]),
+    "bkg_gemm_xw8_gated_workspace_floats": (I64, [I64]),
+    "bkg_gemm_xw8_gated": (I32, [I64, P, I64, P, I64, P, I64, P, I64, F32, P, P, P]),
     # kge.hip
     "bkg_kge_score_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, P]),
     "bkg_row_l1norm_f32": (I32, [P, I64, I64, I32, P, P]),

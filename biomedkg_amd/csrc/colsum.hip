@@ -166,6 +166,11 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
+// (for launches of other translation units whose kernels leave per-block partial rows: gemm_xw.hip's gated product)
+void colsum_final_launch(const float* partial, int n_blocks, int d, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, s, partial, n_blocks, d, out);
+}
+
 // few rows (a mini-batch): ONE launch -- block = 32 row groups x 32 columns over ALL rows (4 rows in flight per
 // thread), groups added in group order
 template <typename T>

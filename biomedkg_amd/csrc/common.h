@@ -56,6 +56,9 @@ DetWorkspace det_workspace();
 void splitk_reduce(const float* ws, float* C, int64_t ldc, int64_t strideC, int M, int N, const int32_t* group_ptr, int G,
                    int kchunk, int n_chunks, hipStream_t s);
 
+// out[c] = sum over the n_blocks partial rows (in a fixed order) of partial[b * d + c]  (colsum.hip)
+void colsum_final_launch(const float* partial, int n_blocks, int d, float* out, hipStream_t s);
+
 // XCD-aware block -> work mapping.  MI355X dispatches workgroup b of a 1-D grid to XCD b % 8, and each of the 8
 // XCDs has a private L2.  Work is indexed (outer, inner) where the `n_inner` items of one outer index re-read the
 // same operand panel: they take consecutive slots of a single XCD, so the panel crosses the fabric once.  The grid

@@ -81,14 +81,46 @@ __device__ __forceinline__ uint2 xw_pack4(const float4& v) {
   h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
   return __builtin_bit_cast(uint2, h);
 }
-__device__ __forceinline__ void xw_store_pair(__bf16* base, int lh, const float4& v0, const float4& v1) {
+__device__ __forceinline__ uint4 xw_pair8(int lh, const float4& v0, const float4& v1) {
   const uint2 p0 = xw_pack4(v0), p1 = xw_pack4(v1);
   const uint2 give = lh ? p0 : p1;                       // lh 0 keeps columns 0..3, hands over 8..11; lh 1 the reverse
   uint2 got;
   got.x = __shfl_xor(give.x, 32, 64);
   got.y = __shfl_xor(give.y, 32, 64);
-  const uint4 o = lh ? make_uint4(got.x, got.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, got.x, got.y);
-  *reinterpret_cast<uint4*>(base + 8 * lh) = o;          // lh 0: columns 0..7, lh 1: columns 8..15
+  return lh ? make_uint4(got.x, got.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, got.x, got.y);
+}
+__device__ __forceinline__ void xw_store_pair(__bf16* base, int lh, const float4& v0, const float4& v1) {
+  *reinterpret_cast<uint4*>(base + 8 * lh) = xw_pair8(lh, v0, v1);   // lh 0: columns 0..7, lh 1: columns 8..15
+}
+
+// ---- the ReLU / dropout backward gate of the PREVIOUS layer and that layer's bias gradient in the epilogue of the
+// product that makes its output gradient (gemm_xw8_kernel<__bf16, true>): C = bf16(gate > 0 ? bf16(A W) * scale : 0),
+// partial[block][c] = sum over the block's rows of C[:, c].  The values are those of the two-pass form (product
+// rounded to bf16, gate_cast_colsum over it); the column sums add the same values in another order.
+struct XwGate {
+  const __bf16* gate;    // [M, ldg] bf16: the saved activation the gradient flows back through
+  int64_t ldg;
+  float scale;           // 1 / (1 - p) of the dropout behind the ReLU (1: none)
+  float* partial;        // [gridDim.x][256]
+};
+typedef unsigned xw_u32x4_t __attribute__((ext_vector_type(4)));
+// hand-issued: a load hipcc knows about makes it drain the LDS-DMA ring (vmcnt(0)) before the first use
+__device__ __forceinline__ xw_u32x4_t xw_gload16(const void* p) {
+  xw_u32x4_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// one packed pair of bf16 values through the gate; adds the two results (as stored) to lo / hi
+__device__ __forceinline__ unsigned xw_gate2(unsigned x, unsigned gt, float scale, float& lo, float& hi) {
+  const float x0 = __uint_as_float(x << 16), x1 = __uint_as_float(x & 0xffff0000u);
+  const float g0 = __uint_as_float(gt << 16), g1 = __uint_as_float(gt & 0xffff0000u);
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 o;
+  o[0] = (__bf16)(g0 > 0.f ? x0 * scale : 0.f);
+  o[1] = (__bf16)(g1 > 0.f ? x1 * scale : 0.f);
+  lo += (float)o[0];
+  hi += (float)o[1];
+  return __builtin_bit_cast(unsigned, o);
 }
 
 // one 16-deep step: 4 weight fragments from LDS x 2 row fragments -> 8 MFMAs
@@ -338,8 +370,9 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
 constexpr int X8_BM = 64, X8_NS = 4, X8_K = 256, X8_N = 256;
 constexpr int X8_STAGE = X8_BM * X8_K * 2;
 
-template <typename CT>
-__global__ __launch_bounds__(512) void gemm_xw8_kernel(XwArgs g, GemmEpilogue ep) {
+template <typename CT, bool GATED = false>
+__global__ __launch_bounds__(512) void gemm_xw8_kernel(XwArgs g, GemmEpilogue ep, XwGate gt) {
+  static_assert(!GATED || sizeof(CT) == 2, "the gated product writes a bf16 table");
   __shared__ __attribute__((aligned(1024))) unsigned char ring[X8_NS * X8_STAGE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
   const int n0 = wave * 32;
@@ -384,18 +417,35 @@ __global__ __launch_bounds__(512) void gemm_xw8_kernel(XwArgs g, GemmEpilogue ep
 
   const int p16 = (lh ^ l31) * 16;
   int slot = 0, it = 0;
+  float cs[2][8];       // gated: column sums of the lane's 2 x 8 columns over its rows
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cs[p][c] = 0.f;
   for (int t = blockIdx.x; t < m_tiles; t += stride) {
     // This wave's DMAs of tile t have landed.  vmcnt retires in issue order and counts the result stores too: behind
     // tile t's DMAs this wave has issued the DMAs of two more tiles and the stores of up to three finished ones (a
     // partial tile -- fewer stores -- can only be a block's last).  Counting the stores keeps both younger tiles in
     // flight; a wait for "at most 8" would retire the older of them as well.
     constexpr int SPT = sizeof(CT) == 2 ? 4 : 8;   // 16-byte stores per wave and tile
-    if (it >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 3 * SPT) : "memory");
-    else if (it == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * SPT) : "memory");
-    else if (it == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + SPT) : "memory");
+    // (gated: every iteration also issues GL gate loads, BEFORE its DMAs -- two iterations' worth sit behind tile t's)
+    constexpr int GL = GATED ? 4 : 0;
+    if (it >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 3 * SPT + 2 * GL) : "memory");
+    else if (it == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + 2 * SPT + 2 * GL) : "memory");
+    else if (it == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + SPT + GL) : "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     ++it;
     __builtin_amdgcn_s_barrier();   // ... everyone else's too, and every wave is done with the slot refilled next
+    // this tile's gate pieces: the 16 bytes beside each 16-byte piece of C this lane stores (rows past the end: row M - 1)
+    xw_u32x4_t gq[2][2];
+    if constexpr (GATED) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t row = min(t * X8_BM + j * 32 + l31, g.M - 1);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) gq[j][p] = xw_gload16(gt.gate + row * gt.ldg + n0 + 16 * p + 8 * lh);
+      }
+    }
     issue(slot == 0 ? X8_NS - 1 : slot - 1);
     const unsigned char* tile = ring + slot * X8_STAGE + l31 * 512;
     xw_acc_t acc[2];
@@ -412,6 +462,9 @@ __global__ __launch_bounds__(512) void gemm_xw8_kernel(XwArgs g, GemmEpilogue ep
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], a, acc[j], 0, 0, 0);
       }
     }
+    // behind the gate loads this wave has issued one tile's DMAs, nothing else
+    if constexpr (GATED)
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(gq[0][0]), "+v"(gq[0][1]), "+v"(gq[1][0]), "+v"(gq[1][1])::"memory");
     // acc[j][4q..4q+3] = C[t * 64 + 32 j + l31][n0 + 8 q + 4 lh + 0..3]
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -421,6 +474,10 @@ __global__ __launch_bounds__(512) void gemm_xw8_kernel(XwArgs g, GemmEpilogue ep
         float4 v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if constexpr (GATED) {      // a plain product under the gate
+            v[q] = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+            continue;
+          }
           v[q] = make_float4(ep.alpha * acc[j][4 * q] + bias[q].x, ep.alpha * acc[j][4 * q + 1] + bias[q].y,
                              ep.alpha * acc[j][4 * q + 2] + bias[q].z, ep.alpha * acc[j][4 * q + 3] + bias[q].w);
           if (ep.act == 1) {
@@ -430,13 +487,46 @@ __global__ __launch_bounds__(512) void gemm_xw8_kernel(XwArgs g, GemmEpilogue ep
             v[q].z = v[q].z > 0.f ? v[q].z : expm1f(v[q].z); v[q].w = v[q].w > 0.f ? v[q].w : expm1f(v[q].w);
           }
         }
-        xw_store_pair(drow_p, lh, v[0], v[1]);
-        xw_store_pair(drow_p + 16, lh, v[2], v[3]);
+        if constexpr (GATED) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const uint4 x = xw_pair8(lh, v[2 * p], v[2 * p + 1]);
+            uint4 o;
+            o.x = xw_gate2(x.x, gq[j][p][0], gt.scale, cs[p][0], cs[p][1]);
+            o.y = xw_gate2(x.y, gq[j][p][1], gt.scale, cs[p][2], cs[p][3]);
+            o.z = xw_gate2(x.z, gq[j][p][2], gt.scale, cs[p][4], cs[p][5]);
+            o.w = xw_gate2(x.w, gq[j][p][3], gt.scale, cs[p][6], cs[p][7]);
+            *reinterpret_cast<uint4*>(drow_p + 16 * p + 8 * lh) = o;
+          }
+        } else {
+          xw_store_pair(drow_p, lh, v[0], v[1]);
+          xw_store_pair(drow_p + 16, lh, v[2], v[3]);
+        }
       }
     }
     slot = slot + 1 == X8_NS ? 0 : slot + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead DMAs past the last tile
+  if constexpr (GATED) {
+    // this block's column sums: lanes of one half hold the same 16 columns over different rows
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float v = cs[p][c];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+        cs[p][c] = v;
+      }
+    if (l31 == 0) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float* dst = gt.partial + (int64_t)blockIdx.x * X8_N + n0 + 16 * p + 8 * lh;
+        *reinterpret_cast<float4*>(dst) = make_float4(cs[p][0], cs[p][1], cs[p][2], cs[p][3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(cs[p][4], cs[p][5], cs[p][6], cs[p][7]);
+      }
+    }
+  }
 }
 
 // The same block for ROW GROUPS (RGCNConv: rows of relation g use Wt + g * stride_w) and gathered rows (a_rows).  Tiles
@@ -948,6 +1038,31 @@ extern "C" int bkg_weight_to_bf16(const float* W, int64_t ldw, int64_t stride_w,
   return check_launch("bkg_weight_to_bf16");
 }
 
+// dX = gate(dXW W) of a 256 -> 256 layer as a bf16 table, and the bias gradient of the layer BELOW (the column sums of
+// that table), in one launch pair: bkg_gemm_xw's 8-wave kernel with the gate in its epilogue + colsum.hip's final add.
+// `workspace`: bkg_gemm_xw8_gated_workspace_floats(M) floats.
+extern "C" int64_t bkg_gemm_xw8_gated_workspace_floats(int64_t M) {
+  return std::min<int64_t>(256, ceil_div(std::max<int64_t>(M, 1), X8_BM)) * X8_N;
+}
+extern "C" int bkg_gemm_xw8_gated(int64_t M, const void* A, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc,
+                                  const void* gate, int64_t ldg, float gate_scale, float* workspace, float* colsum,
+                                  void* stream) {
+  BKG_ARG(M > 0 && M < (1ll << 31), "bkg_gemm_xw8_gated: bad row count");
+  BKG_ARG(A && Wt && C && gate && workspace && colsum, "bkg_gemm_xw8_gated: null argument");
+  BKG_ARG((uintptr_t)A % 16 == 0 && (lda * 2) % 16 == 0 && (uintptr_t)Wt % 16 == 0 && (ldw * 2) % 16 == 0 &&
+              (uintptr_t)C % 16 == 0 && (ldc * 2) % 16 == 0 && (uintptr_t)gate % 16 == 0 && (ldg * 2) % 16 == 0 &&
+              (uintptr_t)workspace % 16 == 0,
+          "bkg_gemm_xw8_gated: 16-byte aligned rows");
+  GemmEpilogue ep{1.0f, 0.0f, nullptr, 0, nullptr, 0, 1.0f, 0};
+  XwArgs g{A, lda, nullptr, reinterpret_cast<const __bf16*>(Wt), ldw, 0, C, ldc, nullptr, 0, (int)M, X8_N, X8_K, 0};
+  const unsigned blocks = (unsigned)std::min<int64_t>(256, ceil_div(M, X8_BM));
+  XwGate gt{reinterpret_cast<const __bf16*>(gate), ldg, gate_scale, workspace};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((gemm_xw8_kernel<__bf16, true>), dim3(blocks), dim3(512), 0, s, g, ep, gt);
+  colsum_final_launch(workspace, (int)blocks, X8_N, colsum, s);
+  return check_launch("bkg_gemm_xw8_gated");
+}
+
 extern "C" int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const void* A, int32_t a_is_bf16, int64_t lda,
                            const int32_t* a_rows, const void* Wt, int64_t ldw, int64_t stride_w, const int32_t* group_ptr, int32_t G,
                            float beta, void* C, int32_t c_is_bf16, int64_t ldc, const float* bias, int32_t act,
@@ -971,8 +1086,8 @@ extern "C" int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const v
   hipStream_t s = (hipStream_t)stream;
   if (a_is_bf16 && !group_ptr && !a_rows && !gate && beta == 0.f && K == X8_K && N == X8_N) {
     const unsigned blocks = (unsigned)std::min<int64_t>(256, ceil_div(M, X8_BM));
-    if (c_is_bf16) hipLaunchKernelGGL(gemm_xw8_kernel<__bf16>, dim3(blocks), dim3(512), 0, s, g, ep);
-    else hipLaunchKernelGGL(gemm_xw8_kernel<float>, dim3(blocks), dim3(512), 0, s, g, ep);
+    if (c_is_bf16) hipLaunchKernelGGL(gemm_xw8_kernel<__bf16>, dim3(blocks), dim3(512), 0, s, g, ep, XwGate{});
+    else hipLaunchKernelGGL(gemm_xw8_kernel<float>, dim3(blocks), dim3(512), 0, s, g, ep, XwGate{});
     return check_launch("bkg_gemm_xw(8 waves)");
   }
   if (a_is_bf16 && !group_ptr && !a_rows && !gate && beta == 0.f && (K == 512 || K == 768) && N % 256 == 0 && N <= 8 * 256 &&

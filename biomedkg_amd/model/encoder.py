@@ -117,12 +117,16 @@ class GCNEncoder(_Stack):
         gw = g.gcn_weights(edge_keep)
         last = len(self.graph_layers) - 1
         h = xw2
+        below = None                 # ops.GateLink with the layer below: whose backward applies that layer's gate
         for i, layer in enumerate(self.graph_layers):
             drop = None
             if i != last and self.drop_out and self.training:
                 drop = _rand.current().dropout((h.size(0), views * layer.out_channels), 0.2, h.device)
+            above = ops.GateLink() if i != last else None
             h = ops.gcn_conv_views(h, None if i == 0 else layer.lin.weight, layer.bias, g, gw, views, relu=(i != last),
-                                   drop=drop, hidden=(i != last) or out_bf16, is_table=(i == 0))
+                                   drop=drop, hidden=(i != last) or out_bf16, is_table=(i == 0), link_in=below,
+                                   link_out=above)
+            below = above
         return h
 
     def forward(self, x, edge_index, edge_keep=None):

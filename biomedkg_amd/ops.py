@@ -204,6 +204,47 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, bias
     return out
 
 
+class GateLink:
+    """Hand-over between two consecutive conv layers of a stack (bf16 mode).  The layer ABOVE, whose backward makes the
+    gradient of the activation between them, may apply the ReLU / dropout backward gate of the layer BELOW in the
+    epilogue of the product that makes that gradient (``gemm_gated``) and leave the lower layer's bias gradient here;
+    the lower layer's backward then finds ``applied`` set and skips its own gate pass over the table.  The lower
+    layer's forward fills ``relu`` / ``scale``; a fresh link per forward pass; the activation must have no other
+    reader than the layer above (the stacks of ``model/encoder.py`` hand it to nothing else)."""
+    __slots__ = ("relu", "scale", "applied", "db")
+
+    def __init__(self):
+        self.relu, self.scale, self.applied, self.db = False, 1.0, False, None
+
+
+GATE_IN_PRODUCT = __import__("os").environ.get("BKG_GATE_IN_PRODUCT", "1") != "0"
+
+
+def gemm_gated_ok(a, b, gate):
+    """Shapes ``gemm_gated`` takes: tall contiguous bf16 ``a [m, 256]`` and ``gate [m, 256]``, fp32 ``b [256, 256]``."""
+    return (GATE_IN_PRODUCT and bf16_storage() and a.dtype == torch.bfloat16 and gate.dtype == torch.bfloat16
+            and a.dim() == 2 and gate.dim() == 2 and a.size(0) >= _TALL_ROWS and a.size(1) == 256 and tuple(b.shape) == (256, 256)
+            and gate.shape == a.shape and a.is_contiguous() and gate.is_contiguous()
+            and a.data_ptr() % 16 == 0 and gate.data_ptr() % 16 == 0)
+
+
+def gemm_gated(a, b, gate, gate_scale):
+    """``(dx, colsum(dx))`` with ``dx = bf16(gate > 0 ? bf16(a @ b) * gate_scale : 0)`` (csrc/gemm_xw.hip
+    ``bkg_gemm_xw8_gated``): the values of ``to_bf16_colsum(gemm(a, b, out_dtype=bf16), gate, gate_scale)`` without the
+    pass over the table in between (the column sums add the same numbers in another order)."""
+    L.require_cuda(a, b, gate)
+    if not gemm_gated_ok(a, b, gate):
+        raise ValueError("gemm_gated: tall contiguous bf16 [m, 256] operands and a [256, 256] weight (gemm_gated_ok)")
+    m = a.size(0)
+    wt = _weight_bf16(_f32c(b) if b.dtype != torch.bfloat16 else b, True)      # [n, k] image of b [k, n]
+    out = torch.empty(m, 256, dtype=torch.bfloat16, device=a.device)
+    ws = torch.empty(L.lib().bkg_gemm_xw8_gated_workspace_floats(m), dtype=torch.float32, device=a.device)
+    cs = torch.empty(256, dtype=torch.float32, device=a.device)
+    L.call("bkg_gemm_xw8_gated", m, L.ptr(a), a.stride(0), L.ptr(wt), wt.stride(0), L.ptr(out), out.stride(0), L.ptr(gate),
+           gate.stride(0), float(gate_scale), L.ptr(ws), L.ptr(cs), L.stream())
+    return out, cs
+
+
 def gemm_grouped_rows(a, b, group_ptr, trans_b=False, out_dtype=torch.float32, a_rows=None):
     """``out[rows of g] = a[rows of g] @ op(b[g])``; ``b`` is ``[G, k, n]`` (or ``[G, n, k]`` if trans_b).
     ``a_rows`` (int32, bf16 mode's streaming kernel only): output row ``m`` reads ``a[a_rows[m]]``."""
@@ -937,8 +978,10 @@ class _GcnConvViews(torch.autograd.Function):
     bf16 mode only (``views_ok``).  Node-partitioned graphs exchange the table as ``_GcnConv`` does."""
 
     @staticmethod
-    def forward(ctx, x2, weight, bias, graph: Graph, gw: GcnWeights, relu, drop, hidden, views, is_table):
+    def forward(ctx, x2, weight, bias, graph: Graph, gw: GcnWeights, relu, drop, hidden, views, is_table, link_in=None,
+                link_out=None):
         n, n_table, comm = _dims(graph)
+        ctx.link_in, ctx.link_out = link_in, link_out
         if is_table:
             table = x2 if x2.is_contiguous() else x2.contiguous()
         else:
@@ -961,6 +1004,8 @@ class _GcnConvViews(torch.autograd.Function):
         ctx.gated = relu or ctx.scale != 1.0
         ctx.keep = _plain_dropout_keep(relu, drop)
         ctx.table_dtype = x2.dtype
+        if link_out is not None:
+            link_out.relu, link_out.scale = bool(relu), ctx.scale
         ctx.save_for_backward(None if is_table else x2, weight, out if ctx.gated else None)
         return out
 
@@ -971,7 +1016,10 @@ class _GcnConvViews(torch.autograd.Function):
         n, n_table, comm = _dims(g)
         dout = dout if dout.is_contiguous() else dout.contiguous()
         cs = None
-        if ctx.relu or not ctx.gated:
+        lo = ctx.link_out
+        if lo is not None and lo.applied and dout.dtype == torch.bfloat16:
+            cs, lo.db = lo.db, None            # the layer above gated its product's result and summed its columns
+        elif ctx.relu or not ctx.gated:
             if ctx.needs_input_grad[2]:
                 dout, cs = to_bf16_colsum(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
             else:
@@ -982,31 +1030,46 @@ class _GcnConvViews(torch.autograd.Function):
         d_out = dout.size(1) // v
         db = None
         if ctx.needs_input_grad[2]:        # the views share the bias: their column sums added
-            db = cs.view(v, d_out).sum(0) if cs is not None else colsum(dout.view(v * n, d_out))
+            if cs is not None and cs.numel() == d_out:
+                db = cs                    # (summed over the rows of all views already)
+            else:
+                db = cs.view(v, d_out).sum(0) if cs is not None else colsum(dout.view(v * n, d_out))
         if comm is not None:               # gather dOut, sum the table gradient of the rank's own rows (see _GcnConv)
             dxw = spmm(c.rowptr, c.col, gw.w_src, comm.exchange(dout, "out"), n, self_w=gw.self_w, split=c.split,
                        out_dtype=torch.bfloat16)
             if ctx.is_table:               # a gathered input table: only the rank's own slots carry a gradient
                 full = torch.zeros(n_table, dxw.size(1), dtype=ctx.table_dtype, device=dxw.device)
                 comm.own_rows(full)[:n] = dxw
-                return full, None, db, None, None, None, None, None, None, None
+                return full, None, db, None, None, None, None, None, None, None, None, None
         else:
             dxw = spmm(c.rowptr, c.col, gw.w_src, dout, n_table, self_w=gw.self_w, split=c.split, out_dtype=torch.bfloat16,
                        tag=_view_tag("gcn_propagate_views_bwd", c), live=getattr(c, "count", None))
             if ctx.is_table:
-                return dxw.to(ctx.table_dtype), None, db, None, None, None, None, None, None, None
+                return dxw.to(ctx.table_dtype), None, db, None, None, None, None, None, None, None, None, None
         d_in = weight.size(1)
         dxw_rows = dxw.view(v * n, d_out)
-        dx = (gemm(dxw_rows, weight, out_dtype=x2.dtype).view(n, v * d_in) if ctx.needs_input_grad[0] else None)
+        dx, li = None, ctx.link_in
+        if ctx.needs_input_grad[0]:
+            x_rows = x2.view(v * n, d_in)
+            if (li is not None and li.relu and comm is None and d_in == d_out
+                    and gemm_gated_ok(dxw_rows, weight, x_rows)):
+                # x2 is the layer below's dropout(relu(.)) output: its sign is that layer's backward gate
+                dx, li.db = gemm_gated(dxw_rows, weight, x_rows, li.scale)
+                li.applied = True
+                dx = dx.view(n, v * d_in)
+            else:
+                dx = gemm(dxw_rows, weight, out_dtype=x2.dtype).view(n, v * d_in)
         dw = gemm(dxw_rows, x2.view(v * n, d_in), trans_a=True) if ctx.needs_input_grad[1] else None
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
-def gcn_conv_views(x2, weight, bias, graph, gw, views, relu=False, drop=None, hidden=False, is_table=False):
+def gcn_conv_views(x2, weight, bias, graph, gw, views, relu=False, drop=None, hidden=False, is_table=False, link_in=None,
+                   link_out=None):
+    """``link_in`` / ``link_out`` (``GateLink``, bf16 mode): the hand-over with the layer below / above in a stack."""
     L.require_cuda(x2, weight, bias)
     if not bf16_storage():          # exact mode: fp32 tables throughout (``hidden`` asks for bf16 results: not here)
         return _GcnConvViewsF32.apply(x2, weight, bias, graph, gw, relu, drop, views, is_table)
-    return _GcnConvViews.apply(x2, weight, bias, graph, gw, relu, drop, hidden, views, is_table)
+    return _GcnConvViews.apply(x2, weight, bias, graph, gw, relu, drop, hidden, views, is_table, link_in, link_out)
 
 
 # ----------------------------------------------------------------------------- RGCNConv

@@ -196,6 +196,14 @@ int bkg_gemm_xw(int64_t M, int64_t N, int64_t K, float alpha, const void* A, int
                 const void* Wt, int64_t ldw, int64_t stride_w, const int32_t* group_ptr, int32_t G, float beta, void* C,
                 int32_t c_is_bf16, int64_t ldc, const float* bias, int32_t act, const float* gate, int64_t ldg,
                 float gate_scale, void* stream);
+/* C = bf16(gate > 0 ? bf16(A Wt^T) * gate_scale : 0) for a 256 -> 256 product over bf16 tables, and colsum[c] = sum_m C[m, c]:
+ * the input gradient of a GCNConv layer (reference biomedkg/model/encoder.py:153-162, autograd of `x = conv(x)`) already
+ * through the ReLU / dropout backward of the layer below, with that layer's bias gradient -- no separate gate pass.
+ * workspace: bkg_gemm_xw8_gated_workspace_floats(M) floats. */
+int64_t bkg_gemm_xw8_gated_workspace_floats(int64_t M);
+int bkg_gemm_xw8_gated(int64_t M, const void* A /* bf16 [M, 256] */, int64_t lda, const void* Wt /* bf16 [256, 256] */,
+                       int64_t ldw, void* C /* bf16 [M, 256] */, int64_t ldc, const void* gate /* bf16 [M, 256] */,
+                       int64_t ldg, float gate_scale, float* workspace, float* colsum /* [256] */, void* stream);
 /* RGCNConv per-relation products: rows grouped by device-side group_ptr[G+1]; group g uses B + g*strideB */
 int bkg_gemm_grouped_rows_f32(int32_t trans_b, int64_t M_total, int64_t N, int64_t K, const float* A, int64_t lda,
                               const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,

@@ -666,3 +666,64 @@ def test_redaf_one_launch_on_bf16_rows_weight_slab_kernel(n_nodes, d, how, monke
             torch.testing.assert_close(outs["1"].double(), torch.relu(t).view(n_nodes, 2, d).mean(1), rtol=2e-4, atol=2e-4)
     finally:
         ops.set_matmul_precision(prev)
+
+
+@pytest.mark.parametrize("m", [4096, 4161, 70_001, 260_000])
+@pytest.mark.parametrize("scale", [1.0, 1.25])
+def test_gate_and_bias_gradient_in_the_product(m, scale):
+    """``ops.gemm_gated``: the input-gradient product of a 256 -> 256 layer with the gate of the layer below and that
+    layer's bias gradient in its epilogue == the product, then ``to_bf16_colsum`` over its bf16 result: the table bit for
+    bit (both round the product to bf16, multiply, round again), the column sums to fp32 summation order."""
+    from biomedkg_amd import ops
+    g = torch.Generator().manual_seed(m)
+    a = torch.randn(m, 256, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(256, 256, generator=g) / 16).to(DEV)
+    act = torch.relu(torch.randn(m, 256, generator=g)).to(DEV).bfloat16()      # ~half of it zero, like dropout(relu(.))
+    assert ops.gemm_gated_ok(a, w, act)
+    dx, cs = ops.gemm_gated(a, w, act, scale)
+    ref, cs_ref = ops.to_bf16_colsum(ops.gemm(a, w, out_dtype=torch.bfloat16), gate=act, gate_scale=scale)
+    assert dx.dtype == torch.bfloat16 and torch.equal(dx.view(torch.int16), ref.view(torch.int16))
+    mag = ref.float().abs().sum(0)
+    assert float(((cs - cs_ref).abs() / mag.clamp_min(1e-6)).max()) < 1e-5
+    torch.testing.assert_close(cs.double(), ref.double().sum(0), rtol=1e-4, atol=1e-5 * float(mag.max()))
+
+
+@pytest.mark.parametrize("drop_out", [False, True])
+def test_ggd_gate_in_the_product_equals_the_gate_pass(drop_out, monkeypatch):
+    """The GGD step with the hidden layers' backward gates inside the products above them (``ops.GateLink``) against the
+    same step with a gate pass per layer: the same loss and weight gradients bit for bit, bias gradients to fp32 order."""
+    from biomedkg_amd import ops, rand as R
+    from biomedkg_amd.gcl_module import GGDModule
+    n, e = 6000, 100_000
+    g = torch.Generator().manual_seed(13)
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    x = torch.randn(n, 768, generator=g).to(DEV)
+    torch.manual_seed(0)
+    m = GGDModule(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="none").to(DEV).train()
+    m.model.encoder.drop_out = drop_out
+    m.model.p = 0.0
+    calls = {"n": 0}
+    real = ops.gemm_gated
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(ops, "gemm_gated", counted)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, "GATE_IN_PRODUCT", on)
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(99)
+        with R.use(R.DeviceRand(seed=1)):
+            loss = m.calculate_loss(x, ei)
+        loss.backward()
+        res.append((float(loss.detach()), {k: p.grad.clone() for k, p in m.model.named_parameters()}))
+    assert calls["n"] == 3                        # the three hidden activations of the four-layer stack
+    (la, ga), (lb, gb) = res
+    assert la == lb
+    for k in ga:
+        if k.endswith("bias"):
+            torch.testing.assert_close(ga[k], gb[k], rtol=1e-4, atol=1e-6 * float(gb[k].abs().max()) + 1e-9)
+        else:
+            assert torch.equal(ga[k], gb[k]), k
