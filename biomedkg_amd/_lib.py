@@ -52,7 +52,8 @@ SIGNATURES = {
     "bkg_cast_f32_bf16": (I32, [P, P, F32, P, I64, P]),
     "bkg_mask_cast_bf16": (I32, [P, I32, F32, U64, U32, P, I64, P]),
     "bkg_gate_cast_bf16": (I32, [P, I32, P, I32, F32, P, I64, P]),
-    "bkg_spmm_csr_f32": (I32, [P, P, P, P, I32, I64, P, I32, I64, I64, I32, P, P, I32, I64, P, I32, P, F32, U64, U32, P, P, I32, P]),
+    "bkg_spmm_csr_f32": (I32, [P, P, P, P, I32, I64, P, I32, I64, I64, I32, P, P, I32, I64, P, I32, P, F32, U64, U32, P, I64, F32,
+                                 P, P, I32, P]),
     # gemm_f32.hip
     "bkg_gemm_f32": (I32, [I32, I32, I64, I64, I64, F32, P, I64, P, I64, F32, P, I64, P, I32, P, I64, F32, I32, P]),
     "bkg_gemm_grouped_rows_f32": (I32, [I32, I64, I64, I64, P, I64, P, I64, I64, P, I64, P, I32, P, I64, F32, I32, P]),

@@ -52,6 +52,12 @@ struct SpmmEpilogue {
   // (0: the kernel's own d); part_stride: floats between the two halves' partial-slot buffers
   int halves, col0, d_full;
   int64_t part_stride;
+  // a bf16 result through ANOTHER layer's ReLU / dropout backward gate (the result is the gradient of that layer's
+  // output `out_gate`): out = bf16(out_gate > 0 ? bf16(v) * out_gate_scale : 0) -- the values of a gate pass over the
+  // finished bf16 table (bkg_gate_cast_bf16), without the pass
+  const __bf16* out_gate;   // [n_rows, ld_gate] or null
+  int64_t ld_gate;
+  float out_gate_scale;
 };
 
 // block id inside its half; `half` (0 / 1) tells the kernel which columns and which partial-slot buffer are its own
@@ -219,6 +225,15 @@ __device__ __forceinline__ void spmm_finish(float4* acc, int row, int lig, const
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         bf16x4 h;
         h[0] = (__bf16)a.x; h[1] = (__bf16)a.y; h[2] = (__bf16)a.z; h[3] = (__bf16)a.w;
+        if (ep.out_gate) {
+          const uint2 t = *reinterpret_cast<const uint2*>(ep.out_gate + (int64_t)row * ep.ld_gate + c);
+          const float g0 = __uint_as_float(t.x << 16), g1 = __uint_as_float(t.x & 0xffff0000u);
+          const float g2 = __uint_as_float(t.y << 16), g3 = __uint_as_float(t.y & 0xffff0000u);
+          h[0] = (__bf16)(g0 > 0.f ? (float)h[0] * ep.out_gate_scale : 0.f);
+          h[1] = (__bf16)(g1 > 0.f ? (float)h[1] * ep.out_gate_scale : 0.f);
+          h[2] = (__bf16)(g2 > 0.f ? (float)h[2] * ep.out_gate_scale : 0.f);
+          h[3] = (__bf16)(g3 > 0.f ? (float)h[3] * ep.out_gate_scale : 0.f);
+        }
         if constexpr (Q == 2) {     // the two quads of a 16-byte piece leave as ONE 16-byte store (8 columns)
           if (q == 0) { lo = __builtin_bit_cast(uint2, h); continue; }
           const uint2 hi = __builtin_bit_cast(uint2, h);
@@ -486,9 +501,11 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
                                 int64_t n_rows, int32_t d, const float* self_w, const void* addend, int32_t addend_is_bf16,
                                 int64_t ld_add, const float* bias,
                                 int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
-                                uint32_t stream_id, const bkg_rowsplit* split, float* partials, int32_t col_halves,
-                                void* stream) {
+                                uint32_t stream_id, const void* out_gate, int64_t ld_gate, float out_gate_scale,
+                                const bkg_rowsplit* split, float* partials, int32_t col_halves, void* stream) {
   using namespace bkg;
+  BKG_ARG(!out_gate || (out_is_bf16 && (uintptr_t)out_gate % 8 == 0 && ld_gate % 4 == 0),
+          "bkg_spmm_csr_f32: an output gate goes with a bf16 result; 8-byte aligned bf16 rows");
   BKG_ARG(n_rows >= 0 && d > 0, "bkg_spmm_csr_f32: bad shape");
   BKG_ARG(col_halves == 1 || ((col_halves == 2 || col_halves == 4) && split && d % (8 * col_halves) == 0),
           "bkg_spmm_csr_f32: col_halves = 2 | 4 needs a row table and d % (8 col_halves) == 0");
@@ -497,7 +514,8 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   if (n_rows == 0) return 0;
   float* out = reinterpret_cast<float*>(out_);
   SpmmEpilogue ep{self_w, bias, reinterpret_cast<const float*>(addend), ld_add, addend_is_bf16 ? 1 : 0, relu, keep, drop_p, seed,
-                  stream_id, out_is_bf16 ? 1 : 0, rng_epoch_ptr(), 1, 0, 0, 0};
+                  stream_id, out_is_bf16 ? 1 : 0, rng_epoch_ptr(), 1, 0, 0, 0,
+                  reinterpret_cast<const __bf16*>(out_gate), ld_gate, out_gate_scale};
   if (col_halves > 1) {            // the kernels run at a part's width; the mask keeps the whole row's indexing
     ep.halves = col_halves;
     ep.d_full = d;
@@ -519,7 +537,7 @@ extern "C" int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const
   } else {
     SpmmArgs<float> a{rowptr, col, w, (const float*)x, ldx, out, ldo, (int)n_rows, split, partials, ep, s};
     if (vec_ok) done = dispatch_spmm<float>(d, a);
-    BKG_ARG(done || !out_is_bf16, "bkg_spmm_csr_f32: a bf16 result needs a vector-width d and aligned rows");
+    BKG_ARG(done || !out_is_bf16, "bkg_spmm_csr_f32: a bf16 result needs a vector-width d and aligned rows");   // (=> no gate either)
     if (!done)
       hipLaunchKernelGGL(spmm_csr_f32_generic_kernel, dim3(ceil_div(n_rows, 4)), dim3(256), 0, s, rowptr, col, w,
                          (const float*)x, ldx, out, ldo, (int)n_rows, d, ep);

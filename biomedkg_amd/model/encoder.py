@@ -58,9 +58,12 @@ class RGCNConv(torch.nn.Module):
         _glorot(self.root)
         torch.nn.init.zeros_(self.bias)
 
-    def forward(self, x, edge_index, edge_type, relu=False, drop=None, hidden=False):
+    links = True      # takes ops.GateLink hand-overs from _Stack._run
+
+    def forward(self, x, edge_index, edge_type, relu=False, drop=None, hidden=False, link_in=None, link_out=None):
         rg = rel_graph_of(edge_index, edge_type, x.size(0), self.num_relations)
-        return ops.rgcn_conv(x, self.weight, self.root, self.bias, rg, relu=relu, drop=drop, hidden=hidden)
+        return ops.rgcn_conv(x, self.weight, self.root, self.bias, rg, relu=relu, drop=drop, hidden=hidden,
+                             link_in=link_in, link_out=link_out)
 
 
 class _Stack(torch.nn.Module):
@@ -82,15 +85,21 @@ class _Stack(torch.nn.Module):
         if ops.features_bf16_ok(x) and x.is_cuda:
             x = ops.cached_bf16(x)      # constant input features: one bf16 table per tensor, not one cast per step
         last = len(self.graph_layers) - 1
+        below = None      # ops.GateLink with the layer below: the layer above may apply that layer's backward gate itself
         for i, layer in enumerate(self.graph_layers):
+            lk = {}
+            if getattr(layer, "links", False) and ops.bf16_storage():
+                above = ops.GateLink() if i != last else None
+                lk = {"link_in": below, "link_out": above}
+                below = above
             if i == last:
-                x = layer(x, *graph, **kw)
+                x = layer(x, *graph, **lk, **kw)
             else:
                 drop = None
                 if self.drop_out and self.training:
                     drop = _rand.current().dropout((x.size(0), layer.out_channels), 0.2, x.device)
                 # hidden=True: in bf16 mode the activation between two conv layers is kept as a bf16 table (ops.py)
-                x = layer(x, *graph, relu=True, drop=drop, hidden=True, **kw)
+                x = layer(x, *graph, relu=True, drop=drop, hidden=True, **lk, **kw)
         return x
 
 

@@ -453,11 +453,16 @@ def bf16_storage() -> bool:
 
 
 def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=False, drop: Dropout = None, tag=None,
-         split=None, out_dtype=torch.float32, live=None):
+         split=None, out_dtype=torch.float32, live=None, out_gate=None, out_gate_scale=1.0):
     """``out[i] = epi(sum_k w[k] x[col[k]] (+ self_w[i] x[i]) (+ addend[i]))`` (csrc/spmm.hip).
     ``x`` is an fp32 or a bf16 table; the result is fp32.  ``live``: device int32 count of the entries ``rowptr`` spans
-    when ``col`` / ``w`` are longer than that (graph.KeptCSR) -- only the byte accounting of a tagged call reads it."""
-    L.require_cuda(rowptr, col, w, x, self_w, addend, bias)
+    when ``col`` / ``w`` are longer than that (graph.KeptCSR) -- only the byte accounting of a tagged call reads it.
+    ``out_gate`` (bf16 ``[n_rows, d]``, bf16 result only): the result leaves through the ReLU / dropout backward gate of
+    the layer whose output ``out_gate`` is -- ``to_bf16(result, gate=out_gate, gate_scale=out_gate_scale)`` without the pass."""
+    L.require_cuda(rowptr, col, w, x, self_w, addend, bias, out_gate)
+    if out_gate is not None and (out_dtype != torch.bfloat16 or out_gate.dtype != torch.bfloat16 or not out_gate.is_contiguous()
+                                 or out_gate.shape != (n_rows, x.size(1))):
+        raise ValueError("spmm: out_gate is a contiguous bf16 [n_rows, d] table and goes with a bf16 result")
     if x.dtype == torch.bfloat16:
         x = x if x.is_contiguous() else x.contiguous()
     else:
@@ -498,8 +503,8 @@ def spmm(rowptr, col, w, x, n_rows, self_w=None, addend=None, bias=None, relu=Fa
     L.call("bkg_spmm_csr_f32", L.ptr(rowptr), L.ptr(col), L.ptr(w), L.ptr(x), is_bf16, x.stride(0), L.ptr(out),
            int(out_dtype == torch.bfloat16), out.stride(0), n_rows, d, L.ptr(self_w), L.ptr(addend),
            int(addend is not None and addend.dtype == torch.bfloat16), addend.stride(0) if addend is not None else 0,
-           L.ptr(bias), int(relu), L.ptr(keep), p, seed, sid, L.sref(split.c if split is not None else None),
-           L.ptr(partials), halves, L.stream())
+           L.ptr(bias), int(relu), L.ptr(keep), p, seed, sid, L.ptr(out_gate), out_gate.stride(0) if out_gate is not None else 0,
+           float(out_gate_scale), L.sref(split.c if split is not None else None), L.ptr(partials), halves, L.stream())
     if timing:
         ev1.record()
         rec = KERNEL_TIMERS.setdefault(tag, {"events": [], "bytes": _spmm_bytes(col.numel(), n_rows, d, w is not None,
@@ -1092,9 +1097,10 @@ class _RgcnConv(torch.autograd.Function):
     reduce-scattered while the root / weight-gradient products run."""
 
     @staticmethod
-    def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop, hidden, training_pass=True):
+    def forward(ctx, x, weight, root, bias, rg: RelGraph, relu, drop, hidden, training_pass=True, link_in=None, link_out=None):
         n, n_table, comm = _dims(rg)
         d_in, d_out = weight.size(1), weight.size(2)
+        ctx.link_in, ctx.link_out = link_in, link_out
         x_given = x                        # (the caller's tensor object: what a remembered table is valid for)
         if x.dtype == torch.bfloat16 and not _xw_ok(x, n, d_out, d_in):
             x = x.float()
@@ -1129,6 +1135,8 @@ class _RgcnConv(torch.autograd.Function):
         ctx.scale = 1.0 / (1.0 - drop.p) if (drop is not None and drop.p > 0) else 1.0
         ctx.gated = relu or ctx.scale != 1.0
         ctx.keep = _plain_dropout_keep(relu, drop)
+        if link_out is not None:
+            link_out.relu, link_out.scale = bool(relu), ctx.scale
         ctx.save_for_backward(x, weight, root, h, out if ctx.gated else None)
         return out
 
@@ -1140,7 +1148,12 @@ class _RgcnConv(torch.autograd.Function):
         d_in, d_out = weight.size(1), weight.size(2)
         dout = dout if dout.is_contiguous() else dout.contiguous()
         db0 = None
-        if (bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(d_out) and n >= 4096
+        lo = ctx.link_out
+        if lo is not None and lo.applied:
+            # the layer above wrote dOut through this layer's gate (the epilogue of its last aggregation): a bf16 table
+            if not (bf16_storage() and _bf16_ok(d_out) and n >= 4096 and _bf16_operand_ok(n, d_in, d_out)):
+                dout = _as_f32(dout)
+        elif (bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(d_out) and n >= 4096
                 and _bf16_operand_ok(n, d_in, d_out)):
             # gated dOut as one bf16 table: gather table of dY, operand of the root products, source of db
             if ctx.needs_input_grad[3]:
@@ -1208,7 +1221,7 @@ class _RgcnConv(torch.autograd.Function):
                           out_dtype=torch.bfloat16 if x16 else torch.float32)
                 if dx.dtype != x.dtype:
                     dx = dx.to(x.dtype)
-            return dx, dweight, droot, db, None, None, None, None, None
+            return dx, dweight, droot, db, None, None, None, None, None, None, None
         # the input gradient: on a partitioned graph its table part goes out while the weight gradients run
         dx, pending, dx_root = None, None, None
         if ctx.needs_input_grad[0]:
@@ -1224,22 +1237,30 @@ class _RgcnConv(torch.autograd.Function):
             # [N, in]; bf16 where dx itself leaves as a bf16 table
             root16 = x16 and dout.dtype == torch.bfloat16 and _xw_ok(dout, n, d_in, d_out)
             dx_root = gemm(dout, root, trans_b=True, out_dtype=torch.bfloat16 if root16 else torch.float32)
+            # x is the layer below's dropout(relu(.)) output: dx leaves through that layer's backward gate (GateLink)
+            li = ctx.link_in
+            gate_here = (GATE_IN_PRODUCT and li is not None and li.relu and x16 and x.is_contiguous()
+                         and x.size(0) == n_table and n_table >= 4096)
             dx = spmm(c.rowptr, c.col, rg.src_w, _table(dh), n_table, addend=dx_root, split=c.split,
-                      out_dtype=torch.bfloat16 if x16 else torch.float32)
+                      out_dtype=torch.bfloat16 if x16 else torch.float32, out_gate=x if gate_here else None,
+                      out_gate_scale=li.scale if gate_here else 1.0)
+            if gate_here:
+                li.applied, li.db = True, None
         if branch:
             main.wait_stream(side)
         else:
             dweight, droot, db = weight_grads()
         if dx is not None and dx.dtype != x.dtype:
             dx = dx.to(x.dtype)
-        return dx, dweight, droot, db, None, None, None, None, None
+        return dx, dweight, droot, db, None, None, None, None, None, None, None
 
 
-def rgcn_conv(x, weight, root, bias, rg, relu=False, drop=None, hidden=False):
+def rgcn_conv(x, weight, root, bias, rg, relu=False, drop=None, hidden=False, link_in=None, link_out=None):
+    """``link_in`` / ``link_out`` (``GateLink``): the hand-over with the layer below / above in a stack."""
     L.require_cuda(x, weight, root, bias)
     if x.dtype != torch.bfloat16:
         x = _f32c(x)
-    return _RgcnConv.apply(x, weight, root, bias, rg, relu, drop, hidden, torch.is_grad_enabled())
+    return _RgcnConv.apply(x, weight, root, bias, rg, relu, drop, hidden, torch.is_grad_enabled(), link_in, link_out)
 
 
 # ----------------------------------------------------------------------------- composable pieces

@@ -148,7 +148,12 @@ int bkg_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* w, 
                      int32_t out_is_bf16, int64_t ldo, int64_t n_rows, int32_t d, const float* self_w,
                      const void* addend /* fp32, or bf16 when addend_is_bf16: RGCNConv's root term */, int32_t addend_is_bf16,
                      int64_t ld_add, const float* bias, int32_t relu, const uint8_t* keep, float drop_p, uint64_t seed,
-                     uint32_t stream_id, const bkg_rowsplit* split, float* partials,
+                     uint32_t stream_id,
+                     const void* out_gate /* nullable bf16 [n_rows, ld_gate], with a bf16 out only: out = bf16(out_gate > 0 ?
+                                             bf16(epi) * out_gate_scale : 0) -- the result is the gradient of ANOTHER layer's
+                                             dropout(relu(.)) output `out_gate`, and leaves through that layer's backward gate
+                                             (what bkg_gate_cast_bf16 over the finished table would give) */,
+                     int64_t ld_gate, float out_gate_scale, const bkg_rowsplit* split, float* partials,
                      int32_t col_halves /* 1; 2 (bf16 table, split given, d % 16 == 0): the launch runs the two d / 2-column
                                            halves as two problems, each on four of the eight XCDs (an L2 then caches pieces
                                            of half the table's bytes); same sums per column, same dropout mask */,

@@ -683,6 +683,8 @@ def test_gate_and_bias_gradient_in_the_product(m, scale):
     dx, cs = ops.gemm_gated(a, w, act, scale)
     ref, cs_ref = ops.to_bf16_colsum(ops.gemm(a, w, out_dtype=torch.bfloat16), gate=act, gate_scale=scale)
     assert dx.dtype == torch.bfloat16 and torch.equal(dx.view(torch.int16), ref.view(torch.int16))
+    if cs_ref is None:          # (<= 4096 rows: the one-pass form leaves the sums to the caller)
+        cs_ref = ops.colsum(ref)
     mag = ref.float().abs().sum(0)
     assert float(((cs - cs_ref).abs() / mag.clamp_min(1e-6)).max()) < 1e-5
     torch.testing.assert_close(cs.double(), ref.double().sum(0), rtol=1e-4, atol=1e-5 * float(mag.max()))
@@ -723,4 +725,71 @@ def test_ggd_gate_in_the_product_equals_the_gate_pass(drop_out, monkeypatch):
     (la, ga), (lb, gb) = res
     assert la == lb
     for k in ga:       # (the weight-gradient products add their K chunks with float atomics: order, not values, differs)
+        torch.testing.assert_close(ga[k], gb[k], rtol=1e-4, atol=1e-5 * float(gb[k].abs().max()) + 1e-9)
+
+
+@pytest.mark.parametrize("d", [256, 512])
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_spmm_result_through_another_layers_gate(d, with_addend):
+    """``ops.spmm(out_gate=...)``: a bf16 aggregation result written through the ReLU / dropout backward gate of the layer
+    below == the gate pass (``to_bf16(gate=...)``) over the ungated bf16 result, bit for bit (split long rows, short rows
+    and column halves included: the graph is skewed)."""
+    from biomedkg_amd import graph as G, ops
+    n, e = 9000, 300_000
+    g = torch.Generator().manual_seed(d)
+    dst = (torch.rand(e, generator=g) ** 3 * n).long().clamp_(max=n - 1)      # a few hub rows, many short ones
+    src = torch.randint(0, n, (e,), generator=g)
+    gr = G.Graph(torch.stack([src, dst]).to(DEV), n)
+    c = gr.by_dst
+    w = torch.rand(e, generator=g).to(DEV)
+    table = torch.randn(n, d, generator=g).to(DEV).bfloat16()
+    addend = torch.randn(n, d, generator=g).to(DEV).bfloat16() if with_addend else None
+    act = torch.relu(torch.randn(n, d, generator=g)).to(DEV).bfloat16()
+    ref = ops.to_bf16(ops.spmm(c.rowptr, c.col, w, table, n, addend=addend, split=c.split, out_dtype=torch.bfloat16),
+                      gate=act, gate_scale=1.25)
+    out = ops.spmm(c.rowptr, c.col, w, table, n, addend=addend, split=c.split, out_dtype=torch.bfloat16, out_gate=act,
+                   out_gate_scale=1.25)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    with pytest.raises(ValueError):
+        ops.spmm(c.rowptr, c.col, w, table, n, split=c.split, out_gate=act)          # an fp32 result takes no gate
+
+
+@pytest.mark.parametrize("drop_out", [False, True])
+def test_rgcn_gate_in_the_aggregation_equals_the_gate_pass(drop_out, monkeypatch):
+    """The R-GCN + DistMult step with the hidden layers' backward gates inside the aggregation that makes their output
+    gradient (``ops.GateLink``) against the same step with a gate pass per layer: same loss, gradients to fp32 order."""
+    from biomedkg_amd import ops, rand as R
+    from biomedkg_amd.kge_module import KGEModule
+    n, e, r = 6000, 120_000, 7
+    g = torch.Generator().manual_seed(14)
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    et = torch.randint(0, r, (e,), generator=g).to(DEV)
+    x = torch.randn(n, 256, generator=g).to(DEV)
+    torch.manual_seed(0)
+    m = KGEModule(encoder_name="rgcn", decoder_name="dismult", in_dim=256, hidden_dim=256, out_dim=256, num_hidden_layers=2,
+                  num_relation=r, num_heads=1, scheduler_type="cosine", learning_rate=1e-3, warm_up_ratio=0.03,
+                  fuse_method="none", neg_ratio=1, node_init_method="random").to(DEV).train()
+    m.model.encoder.drop_out = drop_out
+    seen = {"gated": 0}
+    real = ops.spmm
+
+    def counted(*a, **k):
+        seen["gated"] += k.get("out_gate") is not None
+        return real(*a, **k)
+
+    monkeypatch.setattr(ops, "spmm", counted)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, "GATE_IN_PRODUCT", on)
+        m.zero_grad(set_to_none=True)
+        z_loss = None
+        with R.use(R.DeviceRand(seed=5)):
+            z = m(x, ei, et)
+            z_loss = (z.float() ** 2).mean() + z.float().sum() * 1e-3
+        z_loss.backward()
+        res.append((float(z_loss.detach()), {k: p.grad.clone() for k, p in m.model.encoder.named_parameters()}))
+    assert seen["gated"] == 3
+    (la, ga), (lb, gb) = res
+    assert la == lb
+    for k in ga:
         torch.testing.assert_close(ga[k], gb[k], rtol=1e-4, atol=1e-5 * float(gb[k].abs().max()) + 1e-9)
