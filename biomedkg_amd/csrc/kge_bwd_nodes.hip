@@ -50,6 +50,26 @@ __device__ __forceinline__ float kn_group_sum(float v) {
   return v;
 }
 
+// What the LAST launch over a dz buffer may do on its way out (the whole-graph training step: the loss's upstream gradient
+// and the L2 term of reference kge_module.py:128-129, otherwise one more pass over [N, d] -- bkg_scale_add_rows_f32):
+// dz = dz * gloss[0] + zreg * (gloss[0] * coef).  gloss == nullptr: off.
+struct KnTail {
+  const float* gloss;
+  const float* zreg;      // nullable: scale only
+  int64_t ldzr;
+  float coef;
+};
+__device__ __forceinline__ void kn_tail(float4& v, const KnTail& tl, int node, int col) {
+  if (!tl.gloss) return;
+  const float g = tl.gloss[0];
+  v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+  if (tl.zreg) {
+    const float c = g * tl.coef;
+    const float4 s = *reinterpret_cast<const float4*>(tl.zreg + (int64_t)node * tl.ldzr + col);
+    v.x = fmaf(s.x, c, v.x); v.y = fmaf(s.y, c, v.y); v.z = fmaf(s.z, c, v.z); v.w = fmaf(s.w, c, v.w);
+  }
+}
+
 struct KnTriplets {
   const int64_t* head;
   const int64_t* tail;
@@ -79,7 +99,8 @@ __device__ __forceinline__ void kn_load_self(const T* __restrict__ z, int64_t ld
 // TransE normalisation backward (needs every lane of the group), then store / accumulate
 template <typename T, int KIND, int LPR, int VPL>
 __device__ __forceinline__ void kn_finish(float4* acc, const float4* self, float inv_self, bool above_eps, int node,
-                                          int lig, float* __restrict__ dz, int64_t lddz, int accumulate, bool store) {
+                                          int lig, float* __restrict__ dz, int64_t lddz, int accumulate, bool store,
+                                          const KnTail& tl = KnTail{nullptr, nullptr, 0, 0.f}) {
   constexpr int VQ = VPL * Piece<T>::Q;
   if (KIND == KN_TRANSE) {
     float dot = 0.f;
@@ -102,6 +123,7 @@ __device__ __forceinline__ void kn_finish(float4* acc, const float4* self, float
       const float4 o = *dst;
       acc[q].x += o.x; acc[q].y += o.y; acc[q].z += o.z; acc[q].w += o.w;
     }
+    kn_tail(acc[q], tl, node, piece_col<T, LPR>(lig, q));
     *dst = acc[q];
   }
 }
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_fixup_kernel(bkg_rowsplit r
                                                                   int64_t ldz, const float* __restrict__ l1 /* of the self rows */,
                                                                   const float* __restrict__ partials,
                                                                   float* __restrict__ dz, int64_t lddz,
-                                                                  int accumulate) {
+                                                                  int accumulate, KnTail tl) {
   constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, d = EPL * LPR * VPL;
   const int lane = threadIdx.x & 63;
   const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G + lane / LPR;
@@ -301,7 +323,7 @@ __global__ __launch_bounds__(256) void kge_bwd_nodes_fixup_kernel(bkg_rowsplit r
         }
       }
   }
-  kn_finish<T, KIND, LPR, VPL>(acc, self, inv_self, above, node, lig, dz, lddz, accumulate, live);
+  kn_finish<T, KIND, LPR, VPL>(acc, self, inv_self, above, node, lig, dz, lddz, accumulate, live, tl);
 }
 
 // ------------------------------------------------------------------------------------------------ DistMult, stream form
@@ -411,7 +433,7 @@ __global__ __launch_bounds__(256) KS_ATTR void kge_bwd_stream_kernel(const T* __
                                                              const int32_t* __restrict__ other,
                                                              const int32_t* __restrict__ relid, const float* __restrict__ g,
                                                              float* __restrict__ dz, int64_t lddz, bkg_rowsplit rs,
-                                                             float* __restrict__ partials, int accumulate) {
+                                                             float* __restrict__ partials, int accumulate, KnTail tl) {
   constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, D = EPL * LPR * VPL;
   constexpr int U = (VPL == 1) ? 8 : KS_U2, NB = U * G;
   extern __shared__ __attribute__((aligned(16))) float rel_lds[];
@@ -477,6 +499,7 @@ __global__ __launch_bounds__(256) KS_ATTR void kge_bwd_stream_kernel(const T* __
         const float4 o = *dst;
         acc[q].x += o.x; acc[q].y += o.y; acc[q].z += o.z; acc[q].w += o.w;
       }
+      kn_tail(acc[q], tl, node, piece_col<T, LPR>(lig, q));
       *dst = acc[q];
     }
   }
@@ -526,7 +549,8 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_b
     }                                                                                                                  \
     if (split->n_long_max > 0)   /* (bounds cut to the table's actual counts may be zero) */                          \
     hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, K, LPR, VPL>), dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), \
-                       block, 0, s, *split, (const TT*)z + self_row0 * ldz, ldz, l1_self, partials, dz, lddz, accumulate); \
+                       block, 0, s, *split, (const TT*)z + self_row0 * ldz, ldz, l1_self, partials, dz, lddz, accumulate, \
+                       KnTail{nullptr, nullptr, 0, 0.f});                                                              \
   } else {                                                                                                             \
     if (rel_lds) KN_LAUNCH2(TT, K, false, true, n_nodes, none);                                                        \
     else KN_LAUNCH2(TT, K, false, false, n_nodes, none);                                                               \
@@ -560,8 +584,12 @@ extern "C" int bkg_kge_incidence_streams(const int32_t* perm, int64_t n_inc, int
 extern "C" int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes, int32_t d,
                                       const float* rel_emb, int64_t ldr, int64_t n_rel, const int32_t* other,
                                       const int32_t* relid, const float* g, float* dz, int64_t lddz,
-                                      const bkg_rowsplit* split, float* partials, int32_t accumulate, void* stream) {
+                                      const bkg_rowsplit* split, float* partials, int32_t accumulate, const float* tail_gloss,
+                                      const float* tail_z, int64_t ld_tail_z, float tail_coef, void* stream) {
   const int epl = z_is_bf16 ? 8 : 4;
+  BKG_ARG(!tail_z || (tail_gloss && (uintptr_t)tail_z % 16 == 0 && ld_tail_z % 4 == 0),
+          "bkg_kge_bwd_stream_f32: the tail's rows need its scale and 16-byte aligned rows");
+  const KnTail tl{tail_gloss, tail_z, ld_tail_z, tail_coef};
   BKG_ARG(split && partials && other && relid && g && n_rel > 0, "bkg_kge_bwd_stream_f32: needs the row table, its partials and the streams");
   BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) && (ldr % 4 == 0) &&
               ((uintptr_t)dz % 16 == 0) && (lddz % 4 == 0) && ((uintptr_t)partials % 16 == 0), "bkg_kge_bwd_stream_f32: alignment");
@@ -575,11 +603,11 @@ extern "C" int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t 
     hipLaunchKernelGGL((kge_bwd_stream_kernel<TT, LPR, VPL>),                                                          \
                        dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(split->n_items_max, 4), KN_PERSIST_BLOCKS))), \
                        block, smem, s, (const TT*)z, ldz, rel_emb, ldr, (int)n_rel, other, relid, g, dz, lddz, *split,  \
-                       partials, accumulate);                                                                          \
+                       partials, accumulate, tl);                                                                      \
   if (split->n_long_max > 0)                                                                                           \
     hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, KN_DISTMULT, LPR, VPL>),                                        \
                        dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), block, 0, s, *split, (const TT*)z, ldz,      \
-                       (const float*)nullptr, partials, dz, lddz, accumulate);
+                       (const float*)nullptr, partials, dz, lddz, accumulate, tl);
   BKG_PIECE_DISPATCH_(d / epl, KS_L32, 64, {
     if (z_is_bf16) { KS_LAUNCH(__bf16) } else { KS_LAUNCH(float) }
   })

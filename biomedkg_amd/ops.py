@@ -1327,6 +1327,7 @@ def grouped_linear(h, weight, group_ptr):
 KGE_DISTMULT, KGE_TRANSE = 0, 1
 KGE_BWD_STREAMS = __import__("os").environ.get("BKG_KGE_BWD_STREAMS", "1") != "0"
 KGE_LOSS_FINISH = __import__("os").environ.get("BKG_KGE_LOSS_FINISH", "1") != "0"     # 0: the loss tail as torch expressions
+KGE_BWD_TAIL = __import__("os").environ.get("BKG_KGE_BWD_TAIL", "1") != "0"           # 0: dz * gloss + the L2 term as a pass of its own
 
 
 class Incidence:
@@ -1799,7 +1800,18 @@ class _KgeBceLoss(torch.autograd.Function):
             n_rows = groups[0][6]
             dz = torch.empty(n_rows, d, dtype=torch.float32, device=z.device)
             first = True
-            for ei, et, g, rec, inc, t, _, row0 in groups:
+            live = [gi for gi, gr in enumerate(groups)
+                    if gr[5] and gr[4] is not None and (2 * gr[5] if owned is None else gr[4].n_inc)]
+            # the last launch over dz applies the upstream gradient and the L2 term on its way out (the stream form's tail)
+            tail = None
+            if (KGE_BWD_TAIL and live and not ctx.padded and gloss.numel() == 1 and dz.stride(0) % 4 == 0
+                    and (not ctx.reg or (z_reg is not None and z_reg.dtype == torch.float32 and z_reg.shape == dz.shape
+                                         and z_reg.stride(1) == 1 and z_reg.stride(0) % 4 == 0 and z_reg.data_ptr() % 16 == 0))):
+                ratio = 1.0 if ctx.reg_rows is None else dz.size(0) / ctx.reg_rows
+                tail = (gloss.reshape(1).float().contiguous(), z_reg if ctx.reg else None,
+                        2.0 * ctx.reg / d * ratio / max(dz.size(0), 1))
+            tailed = False
+            for gi, (ei, et, g, rec, inc, t, _, row0) in enumerate(groups):
                 if t == 0 or inc is None:
                     continue
                 n_inc = 2 * t if owned is None else inc.n_inc
@@ -1831,9 +1843,13 @@ class _KgeBceLoss(torch.autograd.Function):
                         L.call("bkg_kge_incidence_streams", L.ptr(inc.perm), n_inc, t, None, None, None, L.ptr(rec),
                                None, L.ptr(inc.other) if fresh else None, L.ptr(inc.relid) if fresh else None, L.ptr(gs),
                                L.stream())
+                        tl = tail if (tail is not None and gi == live[-1]) else None
                         L.call("bkg_kge_bwd_stream_f32", L.ptr(zt), zt_bf16, zt.stride(0), n_rows, d, L.ptr(rel_emb),
                                rel_emb.stride(0), rel_emb.size(0), L.ptr(inc.other), L.ptr(inc.relid), L.ptr(gs), L.ptr(dz),
-                               dz.stride(0), L.sref(sp.c), L.ptr(partials), 0 if first else 1, L.stream())
+                               dz.stride(0), L.sref(sp.c), L.ptr(partials), 0 if first else 1,
+                               L.ptr(tl[0]) if tl else None, L.ptr(tl[1]) if tl else None,
+                               tl[1].stride(0) if (tl and tl[1] is not None) else 0, tl[2] if tl else 0.0, L.stream())
+                        tailed = tl is not None
                     first = False
                     continue
                 with _Timed("kge_bwd_nodes" if not ctx.padded else None, by, d=d):
@@ -1846,7 +1862,9 @@ class _KgeBceLoss(torch.autograd.Function):
                 first = False
             if first:
                 dz.zero_()
-            if ctx.padded:       # dz * gloss + the L2 term's 2 reg z / (real rows * d) on the real rows: one launch
+            if tailed:
+                pass             # (scaled, L2 term added: the last stream launch's tail)
+            elif ctx.padded:     # dz * gloss + the L2 term's 2 reg z / (real rows * d) on the real rows: one launch
                 gl = gloss.reshape(1).contiguous()
                 L.call("bkg_scale_add_rows_f32", L.ptr(dz), dz.stride(0), L.ptr(z_reg), z_reg.stride(0), n, d, L.ptr(gl),
                        2.0 * ctx.reg / d, L.ptr(ctx.n_real), L.stream())

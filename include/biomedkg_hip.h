@@ -252,7 +252,12 @@ int bkg_kge_incidence_streams(const int32_t* perm, int64_t n_inc, int64_t T, con
                               float* g, void* stream);
 int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes, int32_t d, const float* rel_emb,
                            int64_t ldr, int64_t n_rel, const int32_t* other, const int32_t* relid, const float* g, float* dz,
-                           int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate, void* stream);
+                           int64_t lddz, const bkg_rowsplit* split, float* partials, int32_t accumulate,
+                           const float* tail_gloss /* nullable device scalar: the LAST launch over dz leaves
+                                                      dz * tail_gloss[0] + tail_z * (tail_gloss[0] * tail_coef) -- the loss's upstream
+                                                      gradient and the L2 term of kge_module.py:128-129 without another pass */,
+                           const float* tail_z /* nullable [n_nodes, ld_tail_z] fp32 */, int64_t ld_tail_z, float tail_coef,
+                           void* stream);
 /* Fused training pass for one label (1 = positives, 0 = negatives): score[T], g[T] = (sigmoid(s) - label) *
  * inv_total, per-wave BCE-with-logits partial sums loss_part[W] and per-wave partial rows drel[W, lddr] of the
  * relation-side gradient (W = bkg_kge_fused_bce_waves(T, n_rel); relation r owns ceil(cnt_r / 64) consecutive waves;

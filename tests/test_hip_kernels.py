@@ -247,7 +247,22 @@ def test_kge_bwd_stream_form_matches_one_pass_form(prec, n, d, r, hubs):
         rows[ne.flatten()] = True
         reg_only = 2e-2 * z0 / (n * d)                                # rows without triplets carry the L2 term alone
         assert torch.allclose(gz1[~rows], reg_only[~rows], rtol=1e-6, atol=0)
+        # the upstream gradient and the L2 term as the last stream launch's tail (default) against a pass of their own,
+        # under a non-unit upstream gradient and without the L2 term
+        for reg, up in ((1e-2, 3.0), (0.0, 0.5)):
+            tails = []
+            for tail in (True, False):
+                ops.KGE_BWD_TAIL = tail
+                del launches[:]
+                z, rel = z0.clone().requires_grad_(), rel0.clone().requires_grad_()
+                loss = ops.kge_bce_loss(z, rel, pe.clone(), pt.clone(), ne.clone(), nt.clone(), ops.KGE_DISTMULT, reg=reg)[0]
+                (loss * up).backward()
+                tails.append((z.grad.clone(), launches.count("bkg_scale_add_rows_f32")))
+            (ga, na), (gb, nb) = tails
+            assert na == 0 and (nb == 1 or reg == 0.0)
+            torch.testing.assert_close(ga, gb, rtol=2e-6, atol=1e-12)
     finally:
         ops.L.call = call
         ops.KGE_BWD_STREAMS = old_streams
+        ops.KGE_BWD_TAIL = True
         ops.set_matmul_precision(old_prec)
