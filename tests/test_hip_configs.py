@@ -128,9 +128,9 @@ def test_c3_as_timed_bf16_fast_paths_against_exact_fp32():
     assert fast.get("bkg_kge_fused_bce_dev_f32", 0) == 2
     # GGD's head as a dot product per row (forward + both gradient pieces), gate / cast / bias gradient in one pass
     assert fast.get("bkg_rowdot_f32", 0) == 1 and fast.get("bkg_scaled_rows", 0) == 1
-    # (the six hidden layers' gates ride in the kernels that make their output gradients: only the two output layers'
+    # (the six hidden layers' gates ride in the kernels that make their output gradients: only the output layers'
     # casts are passes of their own)
-    assert fast.get("bkg_colsum_weighted_f32", 0) == 1 and fast.get("bkg_gate_cast_colsum_bf16", 0) >= 2
+    assert fast.get("bkg_colsum_weighted_f32", 0) == 1 and fast.get("bkg_gate_cast_colsum_bf16", 0) >= 1
     exact = res["fp32"][1]
     # (the exact mode runs the two views side by side too -- fp32 tables, the shared first product bit-identical: round 4 --
     # but none of the bf16 forms: no streaming bf16 product, the reference's head)
