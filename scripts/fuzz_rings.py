@@ -27,7 +27,7 @@ def group_ptr(total, g):
 
 noise = torch.randn(1 << 22, device=dev)
 for it in range(iters):
-    kind = random.choice(["plain", "grouped", "gathered", "tn", "tn_grouped", "tn_gathered"])
+    kind = random.choice(["plain", "gated", "grouped", "gathered", "tn", "tn_grouped", "tn_gathered"])
     m = random.choice([256, 257, 320, 1000, 4095, 4160, 20_000, 33_333, 70_001, 150_000])
     c16 = random.random() < 0.5
     cdt = torch.bfloat16 if c16 else torch.float32
@@ -53,6 +53,23 @@ for it in range(iters):
                 ref = torch.where(ref > 0, ref, torch.expm1(ref))
             torch.testing.assert_close(outs[0].double(), ref, **tol)
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "run-to-run difference"
+        elif kind == "gated":
+            # the gated product (hand-issued gate loads counted into the ring's vmcnt ladder): the table bit for bit against
+            # the product + gate pass, and run-to-run (its column sums have a fixed order too)
+            mg = max(m, 4096)
+            a = torch.randn(mg, 256, device=dev).bfloat16()
+            w = torch.randn(256, 256, device=dev) * 0.1
+            act = torch.relu(torch.randn(mg, 256, device=dev)).bfloat16()
+            scale = random.choice([1.0, 1.25])
+            outs = []
+            for rep in range(3):
+                outs.append(ops.gemm_gated(a, w, act, scale))
+                noise.mul_(1.0001)
+            ref = ops.to_bf16(ops.gemm(a, w, out_dtype=torch.bfloat16), gate=act, gate_scale=scale)
+            assert torch.equal(outs[0][0].view(torch.int16), ref.view(torch.int16)), "gated table differs from the gate pass"
+            torch.testing.assert_close(outs[0][1].double(), ref.double().sum(0), rtol=1e-4, atol=1e-5 * float(ref.float().abs().sum(0).max()))
+            for o in outs[1:]:
+                assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]), "run-to-run difference"
         elif kind in ("grouped", "gathered"):
             g = random.choice([1, 2, 7, 30, 63, 64, 100])
             gp = group_ptr(m, g)
