@@ -1022,8 +1022,10 @@ class _GcnConvViews(torch.autograd.Function):
         dout = dout if dout.is_contiguous() else dout.contiguous()
         cs = None
         lo = ctx.link_out
-        if lo is not None and lo.applied and dout.dtype == torch.bfloat16:
-            cs, lo.db = lo.db, None            # the layer above gated its product's result and summed its columns
+        if lo is not None and lo.applied:      # the layer above gated its product's result and summed its columns
+            cs, lo.db = lo.db, None
+            if dout.dtype != torch.bfloat16:   # (never gated twice, whatever autograd did to the tensor on its way here)
+                dout = to_bf16(dout)
         elif ctx.relu or not ctx.gated:
             if ctx.needs_input_grad[2]:
                 dout, cs = to_bf16_colsum(dout, gate=out if ctx.gated else None, gate_scale=ctx.scale)
