@@ -258,8 +258,8 @@ _EXCHANGE_KEYS = ("wire_bytes_received_per_step", "wire_bytes_sent_per_step", "e
 _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "ranks", "backend", "mode", "steps", "warmup", "ms_per_step",
              "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 _SIDE_KEYS = ("triplets_per_sec_kge_step", "edges_per_sec_gcl_step", "ms_per_step_median", "ms_per_step_max", "ms_gcl_step",
-              "ms_kge_step", "ms_per_step_fp32", "ms_per_step_shuffled_neg_types", "ms_kge_step_neg10",
-              "triplets_per_sec_kge_step_neg10")
+              "ms_kge_step", "ms_per_step_fp32", "ms_per_step_literal_ggd_last_layer", "ms_per_step_shuffled_neg_types",
+              "ms_kge_step_neg10", "triplets_per_sec_kge_step_neg10")
 
 
 def _strict(o, digits=6):
@@ -336,7 +336,7 @@ def compact_line(out, detail_path=None):
     line["detail"] = detail_path
     line = _strict(line)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
-    for drop in ("check_loss_after", "check_loss", "partition_bound", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_shuffled_neg_types",
+    for drop in ("check_loss_after", "check_loss", "partition_bound", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_shuffled_neg_types", "ms_per_step_literal_ggd_last_layer",
                  "ms_per_step_fp32", "exchange.graphed_sub_steps", "cpu_baseline.threads1", "cpu_baseline.full_size"):
         if len(text) < LINE_LIMIT - 1024:
             break
@@ -1557,21 +1557,31 @@ def main():
         except Exception:                      # noqa: BLE001  (a side figure: never costs the headline line)
             torch.cuda.synchronize()
 
-    ms_linear_head = None
+    ms_linear_head = ms_literal_last = None
     if world == 1 and not args.no_extras and args.precision == "bf16":
-        # the same bf16 step with GGD's head in the reference's own form (the [2N, 256] Linear, then the row sum)
-        ok_fn = ops.rowsum_linear_ok
-        ops.rowsum_linear_ok = lambda *a, **k: False
-        try:
+        def timed5():
             for _ in range(2):
                 step_g(); step_k()
             sync(); t1 = time.perf_counter()
             for _ in range(5):
                 step_g(); step_k()
             sync()
-            ms_linear_head = (time.perf_counter() - t1) / 5 * 1e3
+            return (time.perf_counter() - t1) / 5 * 1e3
+        # the same bf16 step with GGD's LAST CONV LAYER as a layer (its [2N, 256] product and [N, 512] aggregation, forward
+        # and backward) instead of folded into the linear head behind it (model/gcl.py GGD._forward_views) ...
+        was_fold = ops.GGD_FOLD_LAST
+        ops.GGD_FOLD_LAST = False
+        try:
+            ms_literal_last = timed5()
+            # ... and, on top, with the head in the reference's own form (the [2N, 256] Linear, then the row sum)
+            ok_fn = ops.rowsum_linear_ok
+            ops.rowsum_linear_ok = lambda *a, **k: False
+            try:
+                ms_linear_head = timed5()
+            finally:
+                ops.rowsum_linear_ok = ok_fn
         finally:
-            ops.rowsum_linear_ok = ok_fn
+            ops.GGD_FOLD_LAST = was_fold
 
     ms_shuffled_types = None
     if world == 1 and mode == "single" and not args.no_extras:
@@ -1685,6 +1695,7 @@ def main():
             "ms_per_step_each": [round(v, 3) for v in per_step_raw],
             "ms_per_step_slowest_index": per_step_raw.index(per_step[-1]),
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
+            "ms_per_step_literal_ggd_last_layer": ms_literal_last,
             "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_shuffled_neg_types": ms_shuffled_types,
             "ms_per_step_fresh_structures": ms_fresh,
             "kge_step_neg10": neg10,

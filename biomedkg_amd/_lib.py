@@ -120,6 +120,7 @@ SIGNATURES = {
     "bkg_colsum_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),
     "bkg_colsum_weighted_f32": (I32, [P, I32, I64, I64, I32, P, P, P, P]),
     "bkg_gate_cast_colsum_bf16": (I32, [P, I32, P, I32, F32, P, I64, I32, P, P, P]),
+    "bkg_outer_gate_colsum_bf16": (I32, [P, P, P, F32, P, I64, I32, P, P, P]),
     "bkg_rowdot_f32": (I32, [P, I32, I64, I64, I32, P, P, P]),
     "bkg_scaled_rows": (I32, [P, P, I64, I32, P, I32, I64, P]),
     # negsample.hip

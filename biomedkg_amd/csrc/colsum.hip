@@ -138,6 +138,71 @@ __global__ __launch_bounds__(256) void gate_cast_colsum_kernel(const ST* __restr
   }
 }
 
+// The gradient of a row dot product s[r] = x[r, :] . w -- dx[r, :] = g[r] w, an outer product -- written straight through the
+// ReLU / dropout backward gate of the layer whose output x is, with that layer's bias gradient:
+// dst[r, c] = bf16(x[r, c] > 0 ? bf16(g[r] w[c]) * scale : 0), partial[block][c] = sum of the block's rows of dst.  The values
+// of bkg_scaled_rows (bf16 out) followed by bkg_gate_cast_colsum_bf16, same blocking and addition order as that kernel:
+// two passes over [n, d] less (GGD's head behind its folded last conv layer: model/gcl.py).
+__global__ __launch_bounds__(256) void outer_gate_colsum_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                                const __bf16* __restrict__ gate, float scale,
+                                                                __bf16* __restrict__ dst, int64_t n, int d,
+                                                                int64_t rows_per_block, float* __restrict__ partial) {
+  __shared__ float4 red[256 * 2];
+  const int ppr = d / 8, rpb = 256 / ppr;
+  const int piece = threadIdx.x % ppr, slot = threadIdx.x / ppr;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, n);
+  float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  if (slot < rpb) {
+    float wv[8];
+    Load8<float>::get(w + piece * 8, wv);
+    constexpr int U = 4;
+    auto one = [&](float gr, const float (&gt)[8], int64_t r) {
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      bf16x8 o;
+      float back[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = (float)(__bf16)(gr * wv[e]);
+        o[e] = (__bf16)(gt[e] > 0.f ? x * scale : 0.f);
+        back[e] = (float)o[e];
+      }
+      *reinterpret_cast<bf16x8*>(dst + r * d + piece * 8) = o;
+      acc[0].x += back[0]; acc[0].y += back[1]; acc[0].z += back[2]; acc[0].w += back[3];
+      acc[1].x += back[4]; acc[1].y += back[5]; acc[1].z += back[6]; acc[1].w += back[7];
+    };
+    int64_t r = r0 + slot;
+    for (; r + (U - 1) * rpb < r1; r += U * rpb) {
+      float gt[U][8], gr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        Load8<__bf16>::get(gate + (r + (int64_t)u * rpb) * d + piece * 8, gt[u]);
+        gr[u] = g[r + (int64_t)u * rpb];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) one(gr[u], gt[u], r + (int64_t)u * rpb);
+    }
+    for (; r < r1; r += rpb) {
+      float gt[8];
+      Load8<__bf16>::get(gate + r * d + piece * 8, gt);
+      one(g[r], gt, r);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) red[threadIdx.x * 2 + q] = acc[q];
+  __syncthreads();
+  if (slot == 0) {
+    for (int s = 1; s < rpb; ++s)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 v = red[(s * ppr + piece) * 2 + q];
+        acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w;
+      }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * d + piece * 8 + 4 * q) = acc[q];
+  }
+}
+
 // block = 8 row groups x 32 columns; group g adds partial rows g, g + 8, ... (8 loads in flight), then the groups are
 // added in group order through LDS
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int n_blocks, int d,
@@ -289,4 +354,22 @@ extern "C" int bkg_gate_cast_colsum_bf16(const void* src, int32_t src_is_bf16, c
 #undef BKG_GCC
   hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, s, workspace, n_blocks, d, out);
   return check_launch("bkg_gate_cast_colsum_bf16");
+}
+
+
+// dst = bf16(gate > 0 ? bf16(g[r] w[c]) * gate_scale : 0) over a contiguous [n, d] bf16 gate table, out[c] = sum_r dst[r, c]:
+// bkg_scaled_rows + bkg_gate_cast_colsum_bf16 in one pass (same values, same sums).  n > 4096, d % 8 == 0, d <= 2048.
+extern "C" int bkg_outer_gate_colsum_bf16(const float* g, const float* w, const void* gate, float gate_scale, void* dst,
+                                          int64_t n, int32_t d, float* workspace, float* out, void* stream) {
+  BKG_ARG(n > 4096 && d > 0 && d % 8 == 0 && d / 8 <= 256, "bkg_outer_gate_colsum_bf16: n > 4096 rows, d a multiple of 8, <= 2048");
+  BKG_ARG(g && w && gate && dst && workspace && out && ((uintptr_t)w % 16 == 0) && ((uintptr_t)dst % 16 == 0) &&
+              ((uintptr_t)gate % 16 == 0) && (uintptr_t)workspace % 16 == 0,
+          "bkg_outer_gate_colsum_bf16: arguments / 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_blocks = (int)(bkg_colsum_workspace_floats(n, d) / d);
+  const int64_t rpb = (n + n_blocks - 1) / n_blocks;
+  hipLaunchKernelGGL(outer_gate_colsum_kernel, dim3(n_blocks), dim3(256), 0, s, g, w, (const __bf16*)gate, gate_scale, (__bf16*)dst,
+                     n, d, rpb, workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(d, 32)), dim3(256), 0, s, workspace, n_blocks, d, out);
+  return check_launch("bkg_outer_gate_colsum_bf16");
 }

@@ -117,17 +117,21 @@ class GCNEncoder(_Stack):
                     and ops.views_ok(n_rows, 256, layers[0].out_channels, views))
         return all(ops.views_ok_f32(n_rows, l.in_channels, l.out_channels, views) for l in layers)     # (exact mode)
 
-    def forward_views(self, xw2, edge_index, views, edge_keep=None, out_bf16=False):
+    def forward_views(self, xw2, edge_index, views, edge_keep=None, out_bf16=False, before_last=False):
         """The stack over ``views`` inputs of the SAME graph at once (bf16 mode; GGD's positive + corrupted pass).
         ``xw2 [N, views * h]``: the first layer's products ``x_v W_0^T`` side by side (``ops.xw_table``); returns the
         last layer's outputs ``[N, views * out]`` (fp32; bf16 with ``out_bf16`` when only products consume them), view v
-        in columns ``[v * out, (v + 1) * out)``."""
+        in columns ``[v * out, (v + 1) * out)``.  ``before_last``: stop in front of the last layer and return its INPUT
+        (the bf16 hidden activations) and the ``ops.GateLink`` to the layer that made it -- for a caller that folds the last
+        layer into what follows (``GGD._forward_views``)."""
         g = graph_of(edge_index, xw2.size(0))
         gw = g.gcn_weights(edge_keep)
         last = len(self.graph_layers) - 1
         h = xw2
         below = None                 # ops.GateLink with the layer below: whose backward applies that layer's gate
         for i, layer in enumerate(self.graph_layers):
+            if before_last and i == last:
+                return h, below
             drop = None
             if i != last and self.drop_out and self.training:
                 drop = _rand.current().dropout((h.size(0), views * layer.out_channels), 0.2, h.device)

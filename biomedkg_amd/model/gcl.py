@@ -129,8 +129,28 @@ class GGD(torch.nn.Module):
         xw = ops.xw_table(x, layer0.lin.weight)                                  # [N, h] bf16, shared by both views
         perm = r.perm(n, x.device)
         xw2 = ops.pair_rows(xw, perm)                                            # node i: [pos_i | neg_i]
+        enc, last = self.encoder, self.mlp[-1]
+        conv = enc.graph_layers[-1]
+        if (ops.GGD_FOLD_LAST and ops.bf16_storage() and len(self.mlp) == 1 and len(enc.graph_layers) >= 2
+                and ops.row_dot_ok(conv.in_channels, torch.bfloat16)):
+            # The last conv layer has no activation behind it and the head sums a Linear's outputs, so the scores are
+            # LINEAR in that layer's input H:  sum_j (W_m (A_hat (H W_L^T) + b_L) + b_m)_j = A_hat (H w') + b_L . v + sum b_m
+            # with v = W_m^T 1 and w' = W_L^T v -- a dot product per row and an aggregation of ONE column per view instead of
+            # the layer's [2 N, out] product and [N, 2 out] aggregation (and their backward passes).  Same function of the same
+            # parameters, every one of which gets its gradient through autograd of the small products below; the exact-fp32
+            # parity mode keeps the layer (reference biomedkg/model/gcl.py:79-90, encoder.py:153-162).
+            from ..graph import graph_of
+            h2, link = enc.forward_views(xw2, edge_index, 2, edge_keep=edge_keep, before_last=True)   # [N, 2 * hid] bf16
+            hid = conv.in_channels
+            v = last.weight.sum(0)                                                  # [out]
+            w_fold = conv.lin.weight.t() @ v                                        # [hid]
+            const = conv.bias @ v + last.bias.sum()
+            u = ops.row_dot(h2.view(2 * n, hid), w_fold, link_in=link).view(n, 2)
+            g = graph_of(edge_index, n)
+            s = ops.gcn_propagate_narrow(u, g, g.gcn_weights(edge_keep)) + const
+            return ops.columns_of_pair(s)
         # [N, 2 * out]; bf16: the embeddings feed the head's product only
-        h2 = self.encoder.forward_views(xw2, edge_index, 2, edge_keep=edge_keep, out_bf16=True)
+        h2 = enc.forward_views(xw2, edge_index, 2, edge_keep=edge_keep, out_bf16=True)
         h = h2.view(2 * n, h2.size(1) // 2)
         for layer in self.mlp[:-1]:
             h = ops.linear(h, layer.weight, layer.bias, act=ops.ACT_RELU)

@@ -621,11 +621,12 @@ class _RowDot(torch.autograd.Function):
     x's type, ``dw = sum_i g[i] x[i, :]`` (column sums with row weights, csrc/colsum.hip)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, link_in=None):
         out = torch.empty(x.size(0), dtype=torch.float32, device=x.device)
         L.call("bkg_rowdot_f32", L.ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), x.size(0), x.size(1), L.ptr(w),
                L.ptr(out), L.stream())
         ctx.save_for_backward(x, w)
+        ctx.link_in = link_in
         return out
 
     @staticmethod
@@ -634,7 +635,19 @@ class _RowDot(torch.autograd.Function):
         n, d = x.shape
         g = _f32c(g)
         dx = dw = None
-        if ctx.needs_input_grad[0]:
+        li = ctx.link_in
+        if (ctx.needs_input_grad[0] and GATE_IN_PRODUCT and li is not None and li.relu and x.dtype == torch.bfloat16
+                and n > 4096 and d % 8 == 0 and d // 8 <= 256 and x.is_contiguous() and x.data_ptr() % 16 == 0
+                and w.data_ptr() % 16 == 0):
+            # x is the layer below's dropout(relu(.)) output: dx = g (x) w leaves through that layer's backward gate, with its
+            # bias gradient (GateLink) -- neither the outer product nor its gated copy is a pass of its own
+            dx = torch.empty(n, d, dtype=torch.bfloat16, device=x.device)
+            ws = torch.empty(L.lib().bkg_colsum_workspace_floats(n, d), dtype=torch.float32, device=x.device)
+            cs = torch.empty(d, dtype=torch.float32, device=x.device)
+            L.call("bkg_outer_gate_colsum_bf16", L.ptr(g), L.ptr(w), L.ptr(x), float(li.scale), L.ptr(dx), n, d, L.ptr(ws),
+                   L.ptr(cs), L.stream())
+            li.applied, li.db = True, cs
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty(n, d, dtype=x.dtype, device=x.device)
             L.call("bkg_scaled_rows", L.ptr(g), L.ptr(w), n, d, L.ptr(dx), int(x.dtype == torch.bfloat16), dx.stride(0),
                    L.stream())
@@ -643,7 +656,7 @@ class _RowDot(torch.autograd.Function):
             dw = torch.empty(d, dtype=torch.float32, device=x.device)
             L.call("bkg_colsum_weighted_f32", L.ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), n, d, L.ptr(g), L.ptr(ws),
                    L.ptr(dw), L.stream())
-        return dx, dw
+        return dx, dw, None
 
 
 class _ColumnsOfPair(torch.autograd.Function):
@@ -690,6 +703,21 @@ def rowsum_linear_ok(x, weight):
     return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.stride(1) == 1 and d % epl == 0
             and d // epl <= 256 and (d // epl) in _KGE_PIECES and x.stride(0) % epl == 0 and x.data_ptr() % 16 == 0
             and weight.dtype == torch.float32)
+
+
+def row_dot_ok(d, dtype=torch.float32):
+    """Row widths ``row_dot`` takes for a contiguous table of ``dtype``."""
+    epl = 8 if dtype == torch.bfloat16 else 4
+    return d % epl == 0 and d // epl <= 256 and (d // epl) in _KGE_PIECES
+
+
+def row_dot(x, w, link_in=None):
+    """``s[i] = x[i, :] . w`` over a tall contiguous fp32 / bf16 table (csrc/rowdot.hip), differentiable in both.
+    ``link_in`` (``GateLink``): ``x`` is the output of the conv layer that holds the other end of the link."""
+    L.require_cuda(x, w)
+    if x.dim() != 2 or not row_dot_ok(x.size(1), x.dtype) or x.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("row_dot: a contiguous fp32 / bf16 [rows, d] table of a supported width (row_dot_ok)")
+    return _RowDot.apply(x if x.is_contiguous() else x.contiguous(), _f32c(w), link_in)
 
 
 def linear_rowsum(x, weight, bias=None):
@@ -1077,6 +1105,44 @@ def gcn_conv_views(x2, weight, bias, graph, gw, views, relu=False, drop=None, hi
     if not bf16_storage():          # exact mode: fp32 tables throughout (``hidden`` asks for bf16 results: not here)
         return _GcnConvViewsF32.apply(x2, weight, bias, graph, gw, relu, drop, views, is_table)
     return _GcnConvViews.apply(x2, weight, bias, graph, gw, relu, drop, hidden, views, is_table, link_in, link_out)
+
+
+class _GcnPropagateNarrow(torch.autograd.Function):
+    """``A_hat u`` for a FEW columns (``u [N, c]``, c <= 16, fp32): the aggregation of a conv layer whose product has been
+    folded into what follows it (``gcn_propagate_narrow``).  The columns ride in a 64-byte-row fp32 table (8 MB at the
+    bench size: it lives in the caches); the backward is the same aggregation over the out-edge CSR."""
+
+    @staticmethod
+    def forward(ctx, u, graph: Graph, gw: GcnWeights):
+        n, c = u.shape
+        t = torch.zeros(n, 16, dtype=torch.float32, device=u.device)
+        t[:, :c] = u
+        cf = _view_csr(gw, "dst") or graph.by_dst
+        out = spmm(cf.rowptr, cf.col, gw.w_dst, t, n, self_w=gw.self_w, split=cf.split)
+        ctx.graph, ctx.gw, ctx.c = graph, gw, c
+        return out[:, :c].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c = g.shape
+        t = torch.zeros(n, 16, dtype=torch.float32, device=g.device)
+        t[:, :c] = g
+        cb = _view_csr(ctx.gw, "src") or ctx.graph.by_src
+        d = spmm(cb.rowptr, cb.col, ctx.gw.w_src, t, n, self_w=ctx.gw.self_w, split=cb.split)
+        return d[:, :c].contiguous(), None, None
+
+
+def gcn_propagate_narrow(u, graph, gw):
+    """``A_hat u`` (GCNConv's normalised aggregation) of ``u [N, c]``, ``c <= 16`` fp32 columns, differentiable
+    in ``u``.  Whole graphs on one GPU."""
+    L.require_cuda(u)
+    if u.dim() != 2 or u.size(1) > 16 or u.dtype != torch.float32 or _dims(graph)[2] is not None:
+        raise ValueError("gcn_propagate_narrow: an fp32 [N, c <= 16] table over a whole graph")
+    return _GcnPropagateNarrow.apply(u.contiguous(), graph, gw)
+
+
+# GGD's last conv layer folded into its head (model/gcl.py GGD._forward_views): 0 keeps the layer's [N, out] aggregation
+GGD_FOLD_LAST = __import__("os").environ.get("BKG_GGD_FOLD_LAST", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- RGCNConv

@@ -435,6 +435,11 @@ int bkg_colsum_f32(const void* x, int32_t x_is_bf16, int64_t ldx, int64_t n, int
  * (the bias gradient of the layer whose output gradient it is): one pass, same sums as bkg_colsum_f32 over the result */
 int bkg_gate_cast_colsum_bf16(const void* src, int32_t src_is_bf16, const void* gate, int32_t gate_is_bf16, float gate_scale,
                               void* dst, int64_t n, int32_t d, float* workspace, float* out, void* stream);
+/* The gradient of a row dot product through the gate of the layer below: dst[r, c] = bf16(gate[r, c] > 0 ? bf16(g[r] w[c]) *
+ * gate_scale : 0) and out[c] = sum_r dst[r, c] -- bkg_scaled_rows (bf16) + bkg_gate_cast_colsum_bf16 in one pass (GGD's linear
+ * head behind its last hidden layer, reference biomedkg/model/gcl.py:86-90 through autograd).  Workspace as bkg_colsum_f32. */
+int bkg_outer_gate_colsum_bf16(const float* g, const float* w, const void* gate /* bf16 [n, d] */, float gate_scale,
+                               void* dst /* bf16 [n, d] */, int64_t n, int32_t d, float* workspace, float* out, void* stream);
 /* ---- a Linear whose outputs are summed over the features (GGD's head, biomedkg/model/gcl.py:86-90:
  *      `mlp[-1](h).sum(1)` = h . (sum_j W[j, :]) + sum_j b_j): out[i] = sum_c x[i, c] * w[c]; its backward pieces
  *      d h = g (x) w (bkg_scaled_rows, fp32 or bf16 table out) and d w = sum_i g[i] * x[i, :] (column sums with row

@@ -92,9 +92,12 @@ def leaf(p):
     return p.detach().double().requires_grad_()
 
 
-def ggd_step(x, edge_index, perm, conv_w, conv_b, head_w, head_b):
+def ggd_step(x, edge_index, perm, conv_w, conv_b, head_w, head_b, fold=True):
     """GGD's loss (reference gcl.py:73-93 without the augmentation branch, gcl_module.py:229-234) through the side-by-side
-    bf16 path of model/gcl.py ``GGD._forward_views``.  ``conv_w[i] [out, in]`` / ``conv_b[i]``: float64 leaves."""
+    bf16 path of model/gcl.py ``GGD._forward_views``.  ``conv_w[i] [out, in]`` / ``conv_b[i]``: float64 leaves.
+    ``fold`` (the product's default since round 5): the last conv layer folded into the linear head -- the hidden
+    activations H (bf16, their gradient a bf16 table) meet ``w' = W_L^T (W_m^T 1)`` in a dot product per row and ONE column
+    per view goes through the aggregation, in fp32: no bf16 rounding of that layer's product, output or gradient tables."""
     n = x.size(0)
     src, dst, w, self_w = gcn_norm(edge_index, n)
     x16 = bf(x)                                                     # cached bf16 copy of the constant input features
@@ -103,13 +106,21 @@ def ggd_step(x, edge_index, perm, conv_w, conv_b, head_w, head_b):
     last = len(conv_w) - 1
     h = None
     for i in range(len(conv_w)):
+        if fold and i == last and last >= 1:
+            break
         if i > 0:
             d_in, d_out = conv_w[i].size(1), conv_w[i].size(0)
             table = rb(rf(h.view(2 * n, d_in) @ rf(conv_w[i]).t())).view(n, 2 * d_out)
         pre = rb(aggregate(table, src, dst, w, self_w, n) + conv_b[i].repeat(2))   # gated dOut is cast to bf16 in the backward
         h = rb(rf(torch.relu(pre) if i != last else pre))           # hidden activations and the head's operand: bf16
-    hh = h.view(2 * n, h.size(1) // 2)
-    s = (hh @ head_w.sum(0) + head_b.sum()).view(n, 2)              # (W h + b).sum(1) = h . W.sum(0) + b.sum()
+    if fold and last >= 1:
+        v = head_w.sum(0)
+        w_fold = conv_w[last].t() @ v
+        u = (h.view(2 * n, conv_w[last].size(1)) @ w_fold).view(n, 2)
+        s = aggregate(u, src, dst, w, self_w, n) + (conv_b[last] @ v + head_b.sum())
+    else:
+        hh = h.view(2 * n, h.size(1) // 2)
+        s = (hh @ head_w.sum(0) + head_b.sum()).view(n, 2)          # (W h + b).sum(1) = h . W.sum(0) + b.sum()
     pred = torch.cat([s[:, 0], s[:, 1]])
     gt = torch.cat([torch.ones(n, dtype=torch.float64, device=x.device), torch.zeros(n, dtype=torch.float64, device=x.device)])
     return torch.nn.functional.binary_cross_entropy_with_logits(pred, gt)

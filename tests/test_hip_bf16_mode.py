@@ -704,6 +704,7 @@ def test_ggd_gate_in_the_product_equals_the_gate_pass(drop_out, monkeypatch):
     m = GGDModule(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="none").to(DEV).train()
     m.model.encoder.drop_out = drop_out
     m.model.p = 0.0
+    monkeypatch.setattr(ops, "GGD_FOLD_LAST", False)      # (all four conv layers as layers: three hand-overs)
     calls = {"n": 0}
     real = ops.gemm_gated
 
@@ -793,3 +794,74 @@ def test_rgcn_gate_in_the_aggregation_equals_the_gate_pass(drop_out, monkeypatch
     assert la == lb
     for k in ga:
         torch.testing.assert_close(ga[k], gb[k], rtol=1e-4, atol=1e-5 * float(gb[k].abs().max()) + 1e-9)
+
+
+@pytest.mark.parametrize("aug", [False, True])
+def test_ggd_last_layer_folded_into_the_head_equals_the_layer(aug, monkeypatch):
+    """GGD's scores are linear in the last conv layer's input (no activation behind that layer, a summed Linear as the
+    head): ``A_hat (H w') + const`` with ``w' = W_L^T W_m^T 1`` (``GGD._forward_views``, one column per view through the
+    aggregation) against the layer computed as a layer -- the same loss and the same gradient for EVERY parameter (the folded
+    layer's and the head's included) to bf16 rounding, and both as close to the exact fp32 step."""
+    from biomedkg_amd import ops, rand as R
+    from biomedkg_amd.gcl_module import GGDModule
+    n, e = 6000, 100_000
+    g = torch.Generator().manual_seed(21)
+    ei = torch.randint(0, n, (2, e), generator=g).to(DEV)
+    x = torch.randn(n, 768, generator=g).to(DEV)
+    torch.manual_seed(0)
+    m = GGDModule(in_dim=768, hidden_dim=256, out_dim=256, num_hidden_layers=2, fuse_method="none").to(DEV).train()
+    m.model.encoder.drop_out = aug
+    m.model.p = 1.0 if aug else 0.0                     # with: feature masking + dropout_edge view + layer dropout
+    narrow = {"n": 0}
+    real = ops.gcn_propagate_narrow
+    monkeypatch.setattr(ops, "gcn_propagate_narrow", lambda *a, **k: (narrow.__setitem__("n", narrow["n"] + 1), real(*a, **k))[1])
+
+    def step(fold, mode="bf16"):
+        ops.set_matmul_precision(mode)
+        monkeypatch.setattr(ops, "GGD_FOLD_LAST", fold)
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(99)
+        with R.use(R.DeviceRand(seed=4)):
+            loss = m.calculate_loss(x, ei)
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in m.model.named_parameters()}
+    launches = []
+    call = ops.L.call
+    monkeypatch.setattr(ops.L, "call", lambda name, *a: (launches.append(name), call(name, *a))[1])
+    (la, ga), (lb, gb) = step(True), step(False)
+    assert narrow["n"] == 1
+    # the head's gradient leaves through the last hidden layer's gate: one fused launch, once (the folded step)
+    assert launches.count("bkg_outer_gate_colsum_bf16") == 1
+    lx, gx = step(False, "fp32")
+    ops.set_matmul_precision("bf16")
+    # (bf16 mode against the exact step: 0.5 % with the augmentations on -- the folded form no further away than the layer form)
+    assert abs(la - lb) <= 2e-3 * abs(lb) and abs(la - lx) <= max(5e-3 * abs(lx), 1.5 * abs(lb - lx)), (la, lb, lx)
+    for k in ga:
+        assert ga[k] is not None and torch.isfinite(ga[k]).all()
+        rel_ab = float((ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-12))
+        rel_ax = float((ga[k] - gx[k]).norm() / gx[k].norm().clamp_min(1e-12))
+        rel_bx = float((gb[k] - gx[k]).norm() / gx[k].norm().clamp_min(1e-12))
+        assert rel_ab < 3e-2, (k, rel_ab)
+        assert rel_ax < max(3e-2, 1.5 * rel_bx), (k, rel_ax, rel_bx)        # no further from the exact step than the layer form
+
+
+@pytest.mark.parametrize("n,d", [(4097, 256), (70_001, 256), (9_000, 768)])
+def test_row_dot_gradient_through_the_gate_of_the_layer_below(n, d):
+    """``ops.row_dot(x, w, link_in=...)``: the backward writes ``g (x) w`` through the gate of the layer whose output ``x``
+    is and leaves that layer's bias gradient on the link (csrc/colsum.hip ``bkg_outer_gate_colsum_bf16``) == the outer
+    product as a bf16 table, then ``to_bf16_colsum`` over it -- table and sums bit for bit (same blocking, same order)."""
+    from biomedkg_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = torch.relu(torch.randn(n, d, generator=g)).to(DEV).bfloat16().requires_grad_()
+    w = torch.randn(d, generator=g).to(DEV).requires_grad_()
+    up = torch.randn(n, generator=g).to(DEV)
+    link = ops.GateLink()
+    link.relu, link.scale = True, 1.25
+    s = ops.row_dot(x, w, link_in=link)
+    torch.testing.assert_close(s.double(), x.double() @ w.double(), rtol=1e-5, atol=1e-4)
+    dx, dw = torch.autograd.grad(s, (x, w), up)
+    assert link.applied and link.db is not None
+    plain_dx, plain_dw = torch.autograd.grad(ops.row_dot(x, w), (x, w), up)      # no link: the ungated outer product
+    ref, cs = ops.to_bf16_colsum(plain_dx, gate=x.detach(), gate_scale=1.25)
+    assert torch.equal(dx.view(torch.int16), ref.view(torch.int16)) and torch.equal(link.db, cs)
+    assert torch.equal(dw, plain_dw)

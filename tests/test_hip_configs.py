@@ -123,14 +123,16 @@ def test_c3_as_timed_bf16_fast_paths_against_exact_fp32():
     fast = res["bf16"][1]
     assert fast.get("forward_views", 0) == 1                      # GGD's two views side by side
     # streaming activation-x-weight products; three of them carry the gate of the layer below (ops.GateLink, round 5)
-    assert fast.get("_gemm_xw", 0) + fast.get("bkg_gemm_xw8_gated", 0) >= 20 and fast.get("bkg_gemm_xw8_gated", 0) == 3
+    # (GGD's last conv layer is folded into its linear head -- no product of its own: two hand-overs in GGD's stack)
+    assert fast.get("_gemm_xw", 0) + fast.get("bkg_gemm_xw8_gated", 0) >= 18 and fast.get("bkg_gemm_xw8_gated", 0) == 2
     assert fast.get("bkg_gemm_tn_bf16", 0) >= 4 and fast.get("bkg_gemm_grouped_k_bf16", 0) >= 4   # bf16 weight gradients
     assert fast.get("bkg_kge_fused_bce_dev_f32", 0) == 2
     # GGD's head as a dot product per row (forward + both gradient pieces), gate / cast / bias gradient in one pass
-    assert fast.get("bkg_rowdot_f32", 0) == 1 and fast.get("bkg_scaled_rows", 0) == 1
+    # (the head's gradient -- an outer product -- leaves through the last hidden layer's gate in one launch)
+    assert fast.get("bkg_rowdot_f32", 0) == 1 and fast.get("bkg_outer_gate_colsum_bf16", 0) == 1
     # (the six hidden layers' gates ride in the kernels that make their output gradients: only the output layers'
     # casts are passes of their own)
-    assert fast.get("bkg_colsum_weighted_f32", 0) == 1 and fast.get("bkg_gate_cast_colsum_bf16", 0) >= 1
+    assert fast.get("bkg_colsum_weighted_f32", 0) == 1
     exact = res["fp32"][1]
     # (the exact mode runs the two views side by side too -- fp32 tables, the shared first product bit-identical: round 4 --
     # but none of the bf16 forms: no streaming bf16 product, the reference's head)
