@@ -258,7 +258,8 @@ _EXCHANGE_KEYS = ("wire_bytes_received_per_step", "wire_bytes_sent_per_step", "e
 _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "ranks", "backend", "mode", "steps", "warmup", "ms_per_step",
              "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 _SIDE_KEYS = ("triplets_per_sec_kge_step", "edges_per_sec_gcl_step", "ms_per_step_median", "ms_per_step_max", "ms_gcl_step",
-              "ms_kge_step", "ms_per_step_fp32", "ms_per_step_literal_ggd_last_layer", "ms_per_step_shuffled_neg_types",
+              "ms_kge_step", "ms_per_step_fp32", "ms_per_step_literal_ggd_last_layer", "ms_per_step_fresh_first_layer_means",
+              "ms_per_step_shuffled_neg_types",
               "ms_kge_step_neg10", "triplets_per_sec_kge_step_neg10")
 
 
@@ -336,7 +337,7 @@ def compact_line(out, detail_path=None):
     line["detail"] = detail_path
     line = _strict(line)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
-    for drop in ("check_loss_after", "check_loss", "partition_bound", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_shuffled_neg_types", "ms_per_step_literal_ggd_last_layer",
+    for drop in ("check_loss_after", "check_loss", "partition_bound", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_shuffled_neg_types", "ms_per_step_literal_ggd_last_layer", "ms_per_step_fresh_first_layer_means",
                  "ms_per_step_fp32", "exchange.graphed_sub_steps", "cpu_baseline.threads1", "cpu_baseline.full_size"):
         if len(text) < LINE_LIMIT - 1024:
             break
@@ -1557,7 +1558,7 @@ def main():
         except Exception:                      # noqa: BLE001  (a side figure: never costs the headline line)
             torch.cuda.synchronize()
 
-    ms_linear_head = ms_literal_last = None
+    ms_linear_head = ms_literal_last = ms_fresh_means = None
     if world == 1 and not args.no_extras and args.precision == "bf16":
         def timed5():
             for _ in range(2):
@@ -1569,6 +1570,13 @@ def main():
             return (time.perf_counter() - t1) / 5 * 1e3
         # the same bf16 step with GGD's LAST CONV LAYER as a layer (its [2N, 256] product and [N, 512] aggregation, forward
         # and backward) instead of folded into the linear head behind it (model/gcl.py GGD._forward_views) ...
+        # the same step with the first R-GCN layer's segment means of the CONSTANT node features aggregated every step
+        # instead of kept on the graph (ops._RgcnConv)
+        ops.RGCN_KEEP_SEGMENT_MEANS = False
+        try:
+            ms_fresh_means = timed5()
+        finally:
+            ops.RGCN_KEEP_SEGMENT_MEANS = True
         was_fold = ops.GGD_FOLD_LAST
         ops.GGD_FOLD_LAST = False
         try:
@@ -1695,7 +1703,7 @@ def main():
             "ms_per_step_each": [round(v, 3) for v in per_step_raw],
             "ms_per_step_slowest_index": per_step_raw.index(per_step[-1]),
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
-            "ms_per_step_literal_ggd_last_layer": ms_literal_last,
+            "ms_per_step_literal_ggd_last_layer": ms_literal_last, "ms_per_step_fresh_first_layer_means": ms_fresh_means,
             "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_shuffled_neg_types": ms_shuffled_types,
             "ms_per_step_fresh_structures": ms_fresh,
             "kge_step_neg10": neg10,
