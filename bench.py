@@ -1568,8 +1568,6 @@ def main():
                 step_g(); step_k()
             sync()
             return (time.perf_counter() - t1) / 5 * 1e3
-        # the same bf16 step with GGD's LAST CONV LAYER as a layer (its [2N, 256] product and [N, 512] aggregation, forward
-        # and backward) instead of folded into the linear head behind it (model/gcl.py GGD._forward_views, DESIGN 4) ...
         # the same step with the first R-GCN layer's segment means of the CONSTANT node features aggregated every step
         # instead of kept on the graph (ops._RgcnConv)
         ops.RGCN_KEEP_SEGMENT_MEANS = False
@@ -1577,6 +1575,8 @@ def main():
             ms_fresh_means = timed5()
         finally:
             ops.RGCN_KEEP_SEGMENT_MEANS = True
+        # the same bf16 step with GGD's LAST CONV LAYER as a layer (its [2N, 256] product and [N, 512] aggregation, forward
+        # and backward) instead of folded into the linear head behind it (model/gcl.py GGD._forward_views, DESIGN 4) ...
         was_fold = ops.GGD_FOLD_LAST
         ops.GGD_FOLD_LAST = False
         try:
