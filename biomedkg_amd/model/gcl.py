@@ -142,9 +142,9 @@ class GGD(torch.nn.Module):
             from ..graph import graph_of
             h2, link = enc.forward_views(xw2, edge_index, 2, edge_keep=edge_keep, before_last=True)   # [N, 2 * hid] bf16
             hid = conv.in_channels
-            v = last.weight.sum(0)                                                  # [out]
-            w_fold = conv.lin.weight.t() @ v                                        # [hid]
-            const = conv.bias @ v + last.bias.sum()
+            v = ops.weight_colsum(last.weight)                                      # [out] = W_m^T 1
+            w_fold = ops.weight_colsum(conv.lin.weight * v.unsqueeze(1))            # [hid] = W_L^T v  (no BLAS call for 64 k products)
+            const = (conv.bias * v).sum() + last.bias.sum()
             u = ops.row_dot(h2.view(2 * n, hid), w_fold, link_in=link).view(n, 2)
             g = graph_of(edge_index, n)
             s = ops.gcn_propagate_narrow(u, g, g.gcn_weights(edge_keep)) + const

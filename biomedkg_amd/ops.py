@@ -696,6 +696,13 @@ class _ColSumOfWeight(torch.autograd.Function):
         return g.unsqueeze(0).expand(ctx.rows, g.numel())
 
 
+def weight_colsum(weight):
+    """``weight.sum(0)`` of a small 2-D parameter (or an expression of parameters) through the library's column sum,
+    differentiable."""
+    L.require_cuda(weight)
+    return _ColSumOfWeight.apply(_f32c(weight))
+
+
 def rowsum_linear_ok(x, weight):
     """Can ``linear(x, weight, bias).sum(-1)`` run as one dot product per row (:func:`linear_rowsum`)?"""
     epl = 8 if x.dtype == torch.bfloat16 else 4
