@@ -833,14 +833,18 @@ def fusion_figures(dev, edge_index=None, n=130_000):
             x.add_(0.0)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             f(x)
-            torch.cuda.synchronize(); first = (time.perf_counter() - t0) * 1e3
+            torch.cuda.synchronize(); first = (time.perf_counter() - t0) * 1e3      # wall clock of ONE cold call (host included)
+            x.add_(0.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(x); e1.record()
+            torch.cuda.synchronize(); first_dev = e0.elapsed_time(e1)               # the same call on the device's clock
             steady = _event_ms(lambda: f(x), 5)
             # nominal flops = the reference's literal form (q, k and v projections of all 2N token rows); the bf16 mode
             # evaluates it in projected form (ops._attention_fusion_projected: X (Wq^T Wk) over 2N rows + Wv over the N
             # combined rows = half the multiply-adds) -- both rates are given
             executed = (2.0 * 2 * n * 768 * 768 + 2.0 * n * 768 * 768) if (mode == "bf16" and ops.PROJECTED_ATTENTION) \
                 else 2.0 * 2 * n * 768 * 2304
-            out[mode] = {"first_call_ms": first, "steady_ms": steady, "first_call_TFLOPs": 2.0 * 2 * n * 768 * 2304 / first / 1e9,
+            out[mode] = {"first_call_ms": first, "first_call_device_ms": first_dev, "steady_ms": steady, "first_call_TFLOPs": 2.0 * 2 * n * 768 * 2304 / first / 1e9,
                          "first_call_executed_TFLOPs": executed / first / 1e9,
                          "form": "projected (two identities of the reference's arithmetic, DESIGN 4)"
                                  if (mode == "bf16" and ops.PROJECTED_ATTENTION) else "literal (q | k | v product, 2 x 2 attention)"}

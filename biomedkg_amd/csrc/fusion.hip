@@ -122,77 +122,128 @@ __device__ __forceinline__ void bf16x8_to_f32(const uint4 v, float (&f)[8]) {
   f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
 
+// Eight partial sums per lane -> the eight wave totals in every lane: a reduce-scatter over the lane bits 5, 4, 3 (each step
+// sends the half of the values the partner keeps: 4 + 2 + 1 shuffles), three more steps over bits 2, 1, 0 on the one value
+// left, then eight readlanes -- 10 shuffles where eight separate wave sums take 48.  Value k ends in lanes with
+// (lane >> 3) == k.
+__device__ __forceinline__ void attn_reduce8(float (&v)[8], float (&tot)[8]) {
+  const int lane = threadIdx.x & 63;
+  const bool hi5 = (lane & 32) != 0, hi4 = (lane & 16) != 0, hi3 = (lane & 8) != 0;
+  float a[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {      // keep values [0, 4) in the low half of the wave, [4, 8) in the high half
+    const float send = hi5 ? v[i] : v[4 + i];
+    a[i] = (hi5 ? v[4 + i] : v[i]) + __shfl_xor(send, 32, 64);
+  }
+  float b[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float send = hi4 ? a[i] : a[2 + i];
+    b[i] = (hi4 ? a[2 + i] : a[i]) + __shfl_xor(send, 16, 64);
+  }
+  float c = (hi3 ? b[1] : b[0]) + __shfl_xor(hi3 ? b[0] : b[1], 8, 64);
+  c += __shfl_xor(c, 4, 64);
+  c += __shfl_xor(c, 2, 64);
+  c += __shfl_xor(c, 1, 64);
+  // lane l now holds the total of value 4 * bit5 + 2 * bit4 + bit3 = l >> 3
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tot[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 8 * k));
+}
+
 template <int PASSES>      // D = PASSES * 512 at most (64 lanes x 8 elements per pass)
 __global__ __launch_bounds__(256) void attn_scores_combine_kernel(const __bf16* __restrict__ t, int64_t ldt,
                                                                   const __bf16* __restrict__ x, int64_t ldx, int n, int D,
                                                                   const float* __restrict__ u /* Wk^T bq */,
                                                                   const float* __restrict__ w /* Wq^T bk */, float c0,
                                                                   __bf16* __restrict__ out, int64_t ldo) {
+  // A wave walks nodes wave, wave + stride, ...: the two bias vectors stay in its registers (read per node they were as
+  // many L1 bytes as the node's four rows), and the eight reductions of a node are one joint butterfly (attn_reduce8).
   const int lane = threadIdx.x & 63;
-  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (node >= n) return;
-  const __bf16* t0 = t + (int64_t)(2 * node) * ldt;
-  const __bf16* x0 = x + (int64_t)(2 * node) * ldx;
-  uint4 xr[PASSES][2];
-  float s[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, lin_u[2] = {0.f, 0.f}, lin_w[2] = {0.f, 0.f};
+  float fu[PASSES][8], fw[PASSES][8];
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
     const int c = (p * 64 + lane) * 8;
-    const bool ok = c < D;
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    xr[p][0] = ok ? *reinterpret_cast<const uint4*>(x0 + c) : z;
-    xr[p][1] = ok ? *reinterpret_cast<const uint4*>(x0 + ldx + c) : z;
-    const uint4 ta = ok ? *reinterpret_cast<const uint4*>(t0 + c) : z;
-    const uint4 tb = ok ? *reinterpret_cast<const uint4*>(t0 + ldt + c) : z;
-    float fx[2][8], ft[2][8], fu[8], fw[8];
-    bf16x8_to_f32(xr[p][0], fx[0]); bf16x8_to_f32(xr[p][1], fx[1]);
-    bf16x8_to_f32(ta, ft[0]); bf16x8_to_f32(tb, ft[1]);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const float4 a = ok ? *reinterpret_cast<const float4*>(u + c + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 b = ok ? *reinterpret_cast<const float4*>(w + c + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-      fu[4 * h] = a.x; fu[4 * h + 1] = a.y; fu[4 * h + 2] = a.z; fu[4 * h + 3] = a.w;
-      fw[4 * h] = b.x; fw[4 * h + 1] = b.y; fw[4 * h + 2] = b.z; fw[4 * h + 3] = b.w;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) s[a][b] = fmaf(ft[a][e], fx[b][e], s[a][b]);
-        lin_u[a] = fmaf(fu[e], fx[a][e], lin_u[a]);
-        lin_w[a] = fmaf(fw[e], fx[a][e], lin_w[a]);
-      }
+      const int cc = c < D ? c : 0;
+      float4 a = *reinterpret_cast<const float4*>(u + cc + 4 * h), b = *reinterpret_cast<const float4*>(w + cc + 4 * h);
+      if (c >= D) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+      fu[p][4 * h] = a.x; fu[p][4 * h + 1] = a.y; fu[p][4 * h + 2] = a.z; fu[p][4 * h + 3] = a.w;
+      fw[p][4 * h] = b.x; fw[p][4 * h + 1] = b.y; fw[p][4 * h + 2] = b.z; fw[p][4 * h + 3] = b.w;
     }
   }
   const float scale = 1.0f / sqrtf((float)D);
-  float coef[2] = {0.f, 0.f};
+  const int stride = gridDim.x * 4;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  auto fetch = [&](int node_, uint4 (&xr_)[PASSES][2], uint4 (&tr_)[PASSES][2]) {
+    const int nd = min(node_, n - 1);                 // (past the end: a valid node, never used)
+    const __bf16* t0 = t + (int64_t)(2 * nd) * ldt;
+    const __bf16* x0 = x + (int64_t)(2 * nd) * ldx;
+    // (every load unconditional -- lanes past D read column 0 and drop it: a load under a lane condition becomes a branch
+    // of its own with its own wait, and the eight loads of a node went out one at a time)
 #pragma unroll
-  for (int a = 0; a < 2; ++a) lin_w[a] = wave_sum(lin_w[a]);
+    for (int p = 0; p < PASSES; ++p) {
+      const int c = (p * 64 + lane) * 8;
+      const bool ok = c < D;
+      const int cc = ok ? c : 0;
+      const uint4 a0 = *reinterpret_cast<const uint4*>(x0 + cc), a1 = *reinterpret_cast<const uint4*>(x0 + ldx + cc);
+      const uint4 b0 = *reinterpret_cast<const uint4*>(t0 + cc), b1 = *reinterpret_cast<const uint4*>(t0 + ldt + cc);
+      xr_[p][0] = ok ? a0 : z; xr_[p][1] = ok ? a1 : z;
+      tr_[p][0] = ok ? b0 : z; tr_[p][1] = ok ? b1 : z;
+    }
+  };
+  uint4 xn[PASSES][2], tn[PASSES][2];
+  int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node < n) fetch(node, xn, tn);
+  for (; node < n; node += stride) {
+    uint4 xr[PASSES][2], tr[PASSES][2];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) lin_u[b] = wave_sum(lin_u[b]);
+    for (int p = 0; p < PASSES; ++p) { xr[p][0] = xn[p][0]; xr[p][1] = xn[p][1]; tr[p][0] = tn[p][0]; tr[p][1] = tn[p][1]; }
+    fetch(node + stride, xn, tn);                     // the next node's rows travel under this node's arithmetic
+    // v: s[0][0], s[0][1], s[1][0], s[1][1], lin_u[0], lin_u[1], lin_w[0], lin_w[1]
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    float sc[2];
+    for (int p = 0; p < PASSES; ++p) {
+      float fx[2][8], ft[2][8];
+      bf16x8_to_f32(xr[p][0], fx[0]); bf16x8_to_f32(xr[p][1], fx[1]);
+      bf16x8_to_f32(tr[p][0], ft[0]); bf16x8_to_f32(tr[p][1], ft[1]);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) sc[b] = (wave_sum(s[a][b]) + lin_w[a] + lin_u[b] + c0) * scale;
-    const float mx = fmaxf(sc[0], sc[1]);
-    const float e0 = expf(sc[0] - mx), e1 = expf(sc[1] - mx);
-    const float inv = 0.5f / (e0 + e1);
-    coef[0] += e0 * inv;
-    coef[1] += e1 * inv;
-  }
-  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      for (int e = 0; e < 8; ++e) {
 #pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
-    const int c = (p * 64 + lane) * 8;
-    if (c >= D) continue;
-    float f0[8], f1[8];
-    bf16x8_to_f32(xr[p][0], f0); bf16x8_to_f32(xr[p][1], f1);
-    bf16x8 o;
+        for (int a = 0; a < 2; ++a) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaf(coef[1], f1[e], coef[0] * f0[e]);
-    *reinterpret_cast<bf16x8*>(out + (int64_t)node * ldo + c) = o;
+          for (int b = 0; b < 2; ++b) v[2 * a + b] = fmaf(ft[a][e], fx[b][e], v[2 * a + b]);
+          v[4 + a] = fmaf(fu[p][e], fx[a][e], v[4 + a]);
+          v[6 + a] = fmaf(fw[p][e], fx[a][e], v[6 + a]);
+        }
+      }
+    }
+    float tot[8];
+    attn_reduce8(v, tot);
+    float coef[2] = {0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float sc[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) sc[b] = (tot[2 * a + b] + tot[6 + a] + tot[4 + b] + c0) * scale;
+      const float mx = fmaxf(sc[0], sc[1]);
+      const float e0 = expf(sc[0] - mx), e1 = expf(sc[1] - mx);
+      const float inv = 0.5f / (e0 + e1);
+      coef[0] += e0 * inv;
+      coef[1] += e1 * inv;
+    }
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int c = (p * 64 + lane) * 8;
+      if (c >= D) continue;
+      float f0[8], f1[8];
+      bf16x8_to_f32(xr[p][0], f0); bf16x8_to_f32(xr[p][1], f1);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaf(coef[1], f1[e], coef[0] * f0[e]);
+      *reinterpret_cast<bf16x8*>(out + (int64_t)node * ldo + c) = o;
+    }
   }
 }
 
@@ -226,7 +277,8 @@ extern "C" int bkg_attn_scores_combine_bf16(const void* t, int64_t ldt, const vo
               ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)u % 16 == 0) && ((uintptr_t)w % 16 == 0),
           "bkg_attn_scores_combine_bf16: D a multiple of 8 up to 2048, 16-byte aligned rows");
   if (n == 0) return 0;
-  dim3 grid(ceil_div(n, 4)), block(256);
+  // waves walk the nodes, six blocks per CU (swept at 130k nodes: 768 blocks 200 us, 1536 185, one node per wave 188)
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div(n, 4), 256 * 6)), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define BKG_ASC(P) hipLaunchKernelGGL(attn_scores_combine_kernel<P>, grid, block, 0, s, (const __bf16*)t, ldt, (const __bf16*)x, \
                                       ldx, (int)n, D, u, w, c0, (__bf16*)out, ldo)
