@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void outer_gate_colsum_kernel(const float* __r
   if (slot < rpb) {
     float wv[8];
     Load8<float>::get(w + piece * 8, wv);
-    constexpr int U = 4;
+    constexpr int U = 8;      // one input stream: twice the rows in flight of gate_cast_colsum_kernel
     auto one = [&](float gr, const float (&gt)[8], int64_t r) {
       typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
       bf16x8 o;
