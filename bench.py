@@ -1691,9 +1691,15 @@ def main():
                        "cached_structures": "the step re-uses one graph: CSRs, (relation, target) segments, incidence lists, "
                                             "the positive-edge hash set and the bf16 copy of the constant input features are "
                                             "built once (the reference's per-batch loaders rebuild PyG's COO bookkeeping)",
-                       "identities": "bf16 mode evaluates two expressions of the reference in an algebraically equal form, "
+                       "identities": "bf16 mode evaluates three expressions of the reference in an algebraically equal form, "
                                      "nothing is skipped: the corrupted view's first product x[perm] W^T as (x W^T)[perm], "
-                                     "and GGD's head (W h + b).sum(1) as h . W.sum(0) + b.sum() (every gradient included; "
+                                     "GGD's head (W h + b).sum(1) as h . W.sum(0) + b.sum(), and (round 5) -- no activation "
+                                     "follows the last conv layer, so the scores are linear in its INPUT H -- that layer "
+                                     "folded into the head: A_hat (H W_L^T) . v = A_hat (H w'), w' = W_L^T W_m^T 1, one column "
+                                     "per view through the aggregation (ms_per_step_literal_ggd_last_layer times the layer as a "
+                                     "layer; every parameter keeps its exact gradient).  Constants of a run are computed once: "
+                                     "the features' bf16 copy and the first R-GCN layer's segment means of the constant node "
+                                     "features (ms_per_step_fresh_first_layer_means recomputes them) (every gradient included; "
                                      "the exact-fp32 mode shares the first product too -- there the identity holds bit for "
                                      "bit, rows of a product do not depend on their position -- and keeps the reference's "
                                      "head).  Both modes: the negatives' relation "
