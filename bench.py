@@ -175,6 +175,8 @@ KERNEL_NAMES = {
     "kge_fused_bce": "kge_fused_bce_kernel<{t}>: DistMult scores + BCE terms + d score + d rel_emb partials, one triplet set, d={d}",
     "kge_bwd_nodes": "kge_incidence_streams_kernel + kge_bwd_stream_kernel<{t}> + fixup: dz by per-node segment reduce over the "
                      "triplet incidences (their other-endpoint / relation / g streams in list order), d={d}",
+    "kge_onepass": "kge_onepass_kernel<{t}> + fixup: the whole DistMult training pass of the POSITIVES in one walk over their "
+                   "(node, role, relation)-sorted incidence lists (scores, BCE terms, dz, one d rel_emb record row per run), d={d}",
 }
 
 

@@ -58,6 +58,10 @@ struct KnTail {
   const float* zreg;      // nullable: scale only
   int64_t ldzr;
   float coef;
+  // an accumulating launch adds to THESE rows instead of to dz's own (nullable): the positives' part of dz computed by
+  // the forward's one-pass walk stays intact for a second backward
+  const float* acc_src;
+  int64_t ld_src;
 };
 __device__ __forceinline__ void kn_tail(float4& v, const KnTail& tl, int node, int col) {
   if (!tl.gloss) return;
@@ -100,7 +104,7 @@ __device__ __forceinline__ void kn_load_self(const T* __restrict__ z, int64_t ld
 template <typename T, int KIND, int LPR, int VPL>
 __device__ __forceinline__ void kn_finish(float4* acc, const float4* self, float inv_self, bool above_eps, int node,
                                           int lig, float* __restrict__ dz, int64_t lddz, int accumulate, bool store,
-                                          const KnTail& tl = KnTail{nullptr, nullptr, 0, 0.f}) {
+                                          const KnTail& tl = KnTail{nullptr, nullptr, 0, 0.f, nullptr, 0}) {
   constexpr int VQ = VPL * Piece<T>::Q;
   if (KIND == KN_TRANSE) {
     float dot = 0.f;
@@ -120,7 +124,8 @@ __device__ __forceinline__ void kn_finish(float4* acc, const float4* self, float
   for (int q = 0; q < VQ; ++q) {
     float4* dst = reinterpret_cast<float4*>(dz + (int64_t)node * lddz + piece_col<T, LPR>(lig, q));
     if (accumulate) {
-      const float4 o = *dst;
+      const float4 o = tl.acc_src ? *reinterpret_cast<const float4*>(tl.acc_src + (int64_t)node * tl.ld_src + piece_col<T, LPR>(lig, q))
+                                  : *dst;
       acc[q].x += o.x; acc[q].y += o.y; acc[q].z += o.z; acc[q].w += o.w;
     }
     kn_tail(acc[q], tl, node, piece_col<T, LPR>(lig, q));
@@ -496,13 +501,230 @@ __global__ __launch_bounds__(256) KS_ATTR void kge_bwd_stream_kernel(const T* __
     for (int q = 0; q < VQ; ++q) {
       float4* dst = reinterpret_cast<float4*>(dz + (int64_t)node * lddz + piece_col<T, LPR>(lig, q));
       if (accumulate) {
-        const float4 o = *dst;
+        const float4 o = tl.acc_src ? *reinterpret_cast<const float4*>(tl.acc_src + (int64_t)node * tl.ld_src + piece_col<T, LPR>(lig, q))
+                                    : *dst;
         acc[q].x += o.x; acc[q].y += o.y; acc[q].z += o.z; acc[q].w += o.w;
       }
       kn_tail(acc[q], tl, node, piece_col<T, LPR>(lig, q));
       *dst = acc[q];
     }
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------ DistMult, ONE pass (positives)
+// A graph's positive triplets are the same every step, and on a knowledge graph a node's edges of one relation come in
+// RUNS (the bench graph: 19 entries per (head, relation) run): with a node's incidence list sorted by (role, relation) the
+// list walk can do the scorer's work too.  z_n stays in registers; per run zr = z_n (*) rel_r; per entry the OTHER
+// endpoint's row o gives s = zr . o (DistMult is symmetric: the same score from either end), g = (sigmoid(s) - y) / total
+// and M += g o; at the end of a run dz_n += rel_r (*) M -- and, where n is the head, one ROW z_n (*) M of d rel_emb's sum
+// leaves for a record buffer (207 k rows on the bench graph, added per relation by the caller in a fixed order: no atomics
+// anywhere, bitwise repeatable).  Every triplet's rows are read once per incidence -- 2 T row reads where the two-pass
+// form (relation-ordered scorer + node-ordered gradient) reads 4 T -- and g never travels.  The lists, their runs and
+// the batches the kernel walks (<= NB entries of ONE run each, so that the role / relation of a batch is wave-uniform) are
+// built once per graph (biomedkg_amd/ops.py OnePassLists).  Negatives are fresh every step and uniformly random -- their
+// runs are single entries -- and keep the two-pass form.
+#ifndef KO_U
+#define KO_U 2          // entries in flight per lane group (the batch table is cut for NB = KO_U * 64 / lanes-per-row)
+#endif
+#ifndef KO_L32
+#define KO_L32 16       // lanes per row of a 32-piece table (d = 256 bf16)
+#endif
+
+// The sum over a lane group of 2..16 lanes, in every lane of it, by DPP partners inside the 16-lane row (row_ror:8,
+// row_half_mirror, quad_perm) -- VALU instructions, no LDS crossbar round trip (the __shfl_xor butterfly is four
+// ds_bpermute + lgkmcnt waits per score); wider groups finish with the shuffles.
+template <int CTRL>
+__device__ __forceinline__ float ko_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int LPR>
+__device__ __forceinline__ float ko_group_sum(float v) {
+  if constexpr (LPR > 16) {
+#pragma unroll
+    for (int o = LPR / 2; o >= 16; o >>= 1) v += __shfl_xor(v, o, 64);
+  }
+  if constexpr (LPR >= 16) v += ko_dpp<0x128>(v);      // row_ror:8        i <-> i ^ 8
+  if constexpr (LPR >= 8) v += ko_dpp<0x141>(v);       // row_half_mirror  i <-> i ^ 7 (the other quad of the eight)
+  if constexpr (LPR >= 4) v += ko_dpp<0x4E>(v);        // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 2) v += ko_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
+  return v;
+}
+
+template <typename T, int LPR, int VPL>
+__global__ __launch_bounds__(256) void kge_onepass_kernel(const T* __restrict__ z, int64_t ldz,
+                                                          const float* __restrict__ rel_emb, int64_t ldr, int n_rel,
+                                                          const int32_t* __restrict__ other, const int32_t* __restrict__ tid,
+                                                          const int4* __restrict__ batches, const int4* __restrict__ items,
+                                                          int n_items, float label, float inv_t, float* __restrict__ score,
+                                                          float* __restrict__ loss_part, float* __restrict__ records,
+                                                          float* __restrict__ dz, int64_t lddz, float* __restrict__ partials) {
+  constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, D = EPL * LPR * VPL, U = KO_U;
+  extern __shared__ __attribute__((aligned(16))) float ko_rel[];
+  const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
+  float* scratch = ko_rel + n_rel * D + (threadIdx.x >> 6) * ((G > 1 ? G - 1 : 1) * D);      // this wave's (G - 1) rows
+  for (int i = threadIdx.x; i < n_rel * (D / 4); i += 256) {
+    const int r = i / (D / 4), c = i % (D / 4);
+    reinterpret_cast<float4*>(ko_rel)[i] = kn_ld4(rel_emb + (int64_t)r * ldr + 4 * c);
+  }
+  __syncthreads();
+  float loss_acc = 0.f;
+  for (int work = blockIdx.x * 4 + (threadIdx.x >> 6); work < n_items; work += gridDim.x * 4) {
+    const int item = __builtin_amdgcn_readfirstlane(work);
+    const int4 it = items[item];                      // {node, first batch, end batch, partial slot or -1}
+    const int node = __builtin_amdgcn_readfirstlane(it.x), b0 = __builtin_amdgcn_readfirstlane(it.y);
+    const int b1 = __builtin_amdgcn_readfirstlane(it.z), slot = __builtin_amdgcn_readfirstlane(it.w);
+    float4 acc[VQ], zn[VQ], zr[VQ], M[VQ];
+    zero4(acc);
+    zero4(M);
+    zero4(zr);
+    {
+      const T* src = z + (int64_t)node * ldz + EPL * lig;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        Piece<T> pc;
+        pc.load(src + EPL * v * LPR);
+        pc.expand(zn + v * Q);
+      }
+    }
+    // Software pipeline over the item's batches: the rows of batch b + 1, the indices of batch b + 2 and the record of
+    // batch b + 3 are in flight while batch b is computed (the chain record -> indices -> rows would otherwise cost three
+    // memory latencies per batch: 1.2 ms per launch on the bench graph).  Past the item's last batch the last one is
+    // re-read (cache hits, never used).
+    auto rec_at = [&](int bb) { return batches[min(bb, b1 - 1)]; };
+    auto idx_of = [&](const int4& br_, int (&oi_)[U], int (&ti_)[U]) {
+      const int e0_ = __builtin_amdgcn_readfirstlane(br_.x), cnt_ = __builtin_amdgcn_readfirstlane(br_.y) & 0xff;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0_ + min(u * G + grp, cnt_ - 1);
+        oi_[u] = other[e];
+        ti_[u] = tid[e];
+      }
+    };
+    auto rows_of = [&](const int (&oi_)[U], Piece<T> (&val_)[U][VPL]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const T* src = z + (int64_t)oi_[u] * ldz + EPL * lig;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) val_[u][v].load(src + EPL * v * LPR);
+      }
+    };
+    int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    int oi0[U], ti0[U], oi1[U], ti1[U];
+    Piece<T> val[U][VPL], valn[U][VPL];
+    if (b0 < b1) {
+      r0 = rec_at(b0); r1 = rec_at(b0 + 1); r2 = rec_at(b0 + 2);
+      idx_of(r0, oi0, ti0);
+      idx_of(r1, oi1, ti1);
+      rows_of(oi0, val);
+    }
+    for (int b = b0; b < b1; ++b) {
+      const int4 br = r0;                             // {first entry, count | flags << 8, relation + n_rel * role, record row}
+      int ti[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) ti[u] = ti0[u];
+      rows_of(oi1, valn);                             // batch b + 1
+      int oi2[U], ti2[U];
+      idx_of(r2, oi2, ti2);                           // batch b + 2
+      const int4 r3 = rec_at(b + 3);
+      const int cf = __builtin_amdgcn_readfirstlane(br.y);
+      const int relrole = __builtin_amdgcn_readfirstlane(br.z), rec = __builtin_amdgcn_readfirstlane(br.w);
+      const int cnt = cf & 0xff;
+      const bool first = (cf & 0x100) != 0, last = (cf & 0x200) != 0, head = relrole < n_rel;
+      const float* rrow = ko_rel + (head ? relrole : relrole - n_rel) * D;
+      if (first) {
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) {
+          const float4 r = *reinterpret_cast<const float4*>(rrow + piece_col<T, LPR>(lig, q));
+          zr[q] = make_float4(zn[q].x * r.x, zn[q].y * r.y, zn[q].z * r.z, zn[q].w * r.w);
+          M[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool live = u * G + grp < cnt;
+        float4 o[VQ];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) val[u][v].expand(o + v * Q);
+        float sp = 0.f;
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) {
+          sp = fmaf(zr[q].x, o[q].x, sp); sp = fmaf(zr[q].y, o[q].y, sp);
+          sp = fmaf(zr[q].z, o[q].z, sp); sp = fmaf(zr[q].w, o[q].w, sp);
+        }
+        const float sc = ko_group_sum<LPR>(sp);
+        // BCE with logits (torch formula): max(s,0) - s*y + log1p(exp(-|s|));  d/ds = sigmoid(s) - y.  Every triplet is
+        // scored from both of its ends here: the hardware exp2 / rcp / log2 (1 ulp) instead of the library forms
+        const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sc));
+        const float rc = __builtin_amdgcn_rcpf(1.0f + ex);
+        const float sig = sc >= 0.f ? rc : ex * rc;
+        const float g = live ? (sig - label) * inv_t : 0.f;
+        if (head && live && lig == 0) {               // (head: wave-uniform)
+          if (score) score[ti[u]] = sc;
+          loss_acc += fmaxf(sc, 0.f) - sc * label + 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + ex);
+        }
+#pragma unroll
+        for (int q = 0; q < VQ; ++q) {
+          M[q].x = fmaf(g, o[q].x, M[q].x); M[q].y = fmaf(g, o[q].y, M[q].y);
+          M[q].z = fmaf(g, o[q].z, M[q].z); M[q].w = fmaf(g, o[q].w, M[q].w);
+        }
+      }
+      if (last) {
+        // the groups' sums of the run meet in group 0 through this wave's LDS scratch (G - 1 rows written, read back by
+        // group 0: 16-byte LDS accesses, no cross-lane instruction; a wave's LDS operations complete in order)
+        if (G > 1) {
+          float* mine = scratch + (grp > 0 ? grp - 1 : 0) * D;
+          if (grp > 0) {
+#pragma unroll
+            for (int q = 0; q < VQ; ++q) *reinterpret_cast<float4*>(mine + piece_col<T, LPR>(lig, q)) = M[q];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (grp == 0) {
+#pragma unroll
+            for (int o = 0; o < G - 1; ++o)
+#pragma unroll
+              for (int q = 0; q < VQ; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(scratch + o * D + piece_col<T, LPR>(lig, q));
+                M[q].x += v.x; M[q].y += v.y; M[q].z += v.z; M[q].w += v.w;
+              }
+          }
+        }
+        if (grp == 0) {
+#pragma unroll
+          for (int q = 0; q < VQ; ++q) {
+            const float4 r = *reinterpret_cast<const float4*>(rrow + piece_col<T, LPR>(lig, q));
+            acc[q].x = fmaf(r.x, M[q].x, acc[q].x); acc[q].y = fmaf(r.y, M[q].y, acc[q].y);
+            acc[q].z = fmaf(r.z, M[q].z, acc[q].z); acc[q].w = fmaf(r.w, M[q].w, acc[q].w);
+            if (head)
+              *reinterpret_cast<float4*>(records + (int64_t)rec * D + piece_col<T, LPR>(lig, q)) =
+                  make_float4(zn[q].x * M[q].x, zn[q].y * M[q].y, zn[q].z * M[q].z, zn[q].w * M[q].w);
+          }
+        }
+      }
+      r0 = r1; r1 = r2; r2 = r3;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        oi0[u] = oi1[u]; ti0[u] = ti1[u]; oi1[u] = oi2[u]; ti1[u] = ti2[u];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) val[u][v] = valn[u][v];
+      }
+    }
+    if (grp != 0) continue;
+    if (slot >= 0) {
+#pragma unroll
+      for (int q = 0; q < VQ; ++q)
+        *reinterpret_cast<float4*>(partials + (int64_t)slot * D + piece_col<T, LPR>(lig, q)) = acc[q];
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < VQ; ++q)
+      *reinterpret_cast<float4*>(dz + (int64_t)node * lddz + piece_col<T, LPR>(lig, q)) = acc[q];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) loss_acc += __shfl_xor(loss_acc, o, 64);
+  if (lane == 0) loss_part[blockIdx.x * 4 + (threadIdx.x >> 6)] = loss_acc;
 }
 
 }  // namespace bkg
@@ -550,7 +772,7 @@ extern "C" int bkg_kge_bwd_nodes_f32(int32_t kind, const void* z, int32_t z_is_b
     if (split->n_long_max > 0)   /* (bounds cut to the table's actual counts may be zero) */                          \
     hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, K, LPR, VPL>), dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), \
                        block, 0, s, *split, (const TT*)z + self_row0 * ldz, ldz, l1_self, partials, dz, lddz, accumulate, \
-                       KnTail{nullptr, nullptr, 0, 0.f});                                                              \
+                       KnTail{nullptr, nullptr, 0, 0.f, nullptr, 0});                                                              \
   } else {                                                                                                             \
     if (rel_lds) KN_LAUNCH2(TT, K, false, true, n_nodes, none);                                                        \
     else KN_LAUNCH2(TT, K, false, false, n_nodes, none);                                                               \
@@ -585,11 +807,14 @@ extern "C" int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t 
                                       const float* rel_emb, int64_t ldr, int64_t n_rel, const int32_t* other,
                                       const int32_t* relid, const float* g, float* dz, int64_t lddz,
                                       const bkg_rowsplit* split, float* partials, int32_t accumulate, const float* tail_gloss,
-                                      const float* tail_z, int64_t ld_tail_z, float tail_coef, void* stream) {
+                                      const float* tail_z, int64_t ld_tail_z, float tail_coef, const float* acc_src,
+                                      int64_t ld_acc_src, void* stream) {
   const int epl = z_is_bf16 ? 8 : 4;
   BKG_ARG(!tail_z || (tail_gloss && (uintptr_t)tail_z % 16 == 0 && ld_tail_z % 4 == 0),
           "bkg_kge_bwd_stream_f32: the tail's rows need its scale and 16-byte aligned rows");
-  const KnTail tl{tail_gloss, tail_z, ld_tail_z, tail_coef};
+  BKG_ARG(!acc_src || (accumulate && (uintptr_t)acc_src % 16 == 0 && ld_acc_src % 4 == 0),
+          "bkg_kge_bwd_stream_f32: acc_src goes with accumulate, 16-byte aligned rows");
+  const KnTail tl{tail_gloss, tail_z, ld_tail_z, tail_coef, acc_src, ld_acc_src};
   BKG_ARG(split && partials && other && relid && g && n_rel > 0, "bkg_kge_bwd_stream_f32: needs the row table, its partials and the streams");
   BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) && (ldr % 4 == 0) &&
               ((uintptr_t)dz % 16 == 0) && (lddz % 4 == 0) && ((uintptr_t)partials % 16 == 0), "bkg_kge_bwd_stream_f32: alignment");
@@ -613,4 +838,54 @@ extern "C" int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t 
   })
 #undef KS_LAUNCH
   return check_launch("bkg_kge_bwd_stream_f32");
+}
+
+// The whole DistMult TRAINING pass of a graph's positive triplets in ONE walk over (role, relation)-sorted incidence lists
+// (kge_onepass_kernel): scores, BCE terms, dz, and one record row z_n (*) M per (head, relation) run -- the caller adds the
+// records of each relation (a fixed-order segment reduce) into d rel_emb.  items [n_items] = {node, first batch, end batch,
+// partial slot}; batches = {first entry, count | first << 8 | last << 9, relation + n_rel * role, record row}; the batches
+// of an item hold <= bkg_kge_onepass_batch(d, z_is_bf16) entries of one run each.  split: the row table the items were
+// cut by (its long rows' partial slots are added by the fix-up launch); dz is written, not added to.
+extern "C" int32_t bkg_kge_onepass_batch(int32_t d, int32_t z_is_bf16) {
+  const int epl = z_is_bf16 ? 8 : 4, pieces = d / epl;
+  int lpr = pieces;                                   // lanes per row as BKG_PIECE_DISPATCH_(.., KS_L32, 64) picks them
+  switch (pieces) { case 6: lpr = 2; break; case 12: lpr = 4; break; case 24: lpr = 8; break; case 32: lpr = KO_L32; break;
+                    case 64: lpr = 64; break; case 96: lpr = 32; break; case 128: case 192: lpr = 64; break; default: break; }
+  return KO_U * (64 / lpr);
+}
+extern "C" int32_t bkg_kge_onepass_blocks(int64_t n_items) {
+  return (int32_t)std::max<int64_t>(1, std::min<int64_t>(ceil_div(std::max<int64_t>(n_items, 1), 4), KN_PERSIST_BLOCKS));
+}
+extern "C" int bkg_kge_onepass_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes, int32_t d, const float* rel_emb,
+                                   int64_t ldr, int64_t n_rel, const int32_t* other, const int32_t* tid, const void* batches,
+                                   const void* items, int64_t n_items, float label, float inv_total, float* score,
+                                   float* loss_part, float* records, float* dz, int64_t lddz, const bkg_rowsplit* split,
+                                   float* partials, void* stream) {
+  const int epl = z_is_bf16 ? 8 : 4;
+  BKG_ARG(other && tid && batches && items && loss_part && records && dz && split && partials && n_rel > 0 && n_items >= 0,
+          "bkg_kge_onepass_f32: needs the lists, their batch / item tables, the row table and the output buffers");
+  BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) && (ldr % 4 == 0) &&
+              ((uintptr_t)dz % 16 == 0) && (lddz % 4 == 0) && ((uintptr_t)partials % 16 == 0) && ((uintptr_t)records % 16 == 0) &&
+              ((uintptr_t)batches % 16 == 0) && ((uintptr_t)items % 16 == 0), "bkg_kge_onepass_f32: alignment");
+  BKG_ARG(n_rel * (int64_t)d * 4 <= 65536, "bkg_kge_onepass_f32: the relation table must fit 64 KB of LDS");
+  if (n_nodes == 0 || n_items == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)bkg_kge_onepass_blocks(n_items);
+#define KO_LAUNCH(TT)                                                                                                  \
+  {                                                                                                                    \
+    /* the relation table + every wave's scratch: (lane groups - 1) rows of d floats */                                \
+    const size_t smem = ((size_t)n_rel + 4 * (size_t)std::max(64 / LPR - 1, 1)) * d * 4;                               \
+    hipLaunchKernelGGL((kge_onepass_kernel<TT, LPR, VPL>), dim3(blocks), dim3(256), smem, s, (const TT*)z, ldz, rel_emb, ldr, \
+                       (int)n_rel, other, tid, (const int4*)batches, (const int4*)items, (int)n_items, label, inv_total, score, \
+                       loss_part, records, dz, lddz, partials);                                                        \
+    if (split->n_long_max > 0)                                                                                         \
+      hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, KN_DISTMULT, LPR, VPL>),                                      \
+                         dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), dim3(256), 0, s, *split, (const TT*)z, ldz, \
+                         (const float*)nullptr, partials, dz, lddz, 0, KnTail{nullptr, nullptr, 0, 0.f, nullptr, 0});              \
+  }
+  BKG_PIECE_DISPATCH_(d / epl, KO_L32, 64, {
+    if (z_is_bf16) KO_LAUNCH(__bf16) else KO_LAUNCH(float)
+  })
+#undef KO_LAUNCH
+  return check_launch("bkg_kge_onepass_f32");
 }

@@ -1416,6 +1416,7 @@ def grouped_linear(h, weight, group_ptr):
 KGE_DISTMULT, KGE_TRANSE = 0, 1
 KGE_BWD_STREAMS = __import__("os").environ.get("BKG_KGE_BWD_STREAMS", "1") != "0"
 KGE_LOSS_FINISH = __import__("os").environ.get("BKG_KGE_LOSS_FINISH", "1") != "0"     # 0: the loss tail as torch expressions
+KGE_ONEPASS = __import__("os").environ.get("BKG_KGE_ONEPASS", "1") != "0"            # 0: the positives through scorer + list walk too
 KGE_BWD_TAIL = __import__("os").environ.get("BKG_KGE_BWD_TAIL", "1") != "0"
 RGCN_KEEP_SEGMENT_MEANS = __import__("os").environ.get("BKG_RGCN_KEEP_SEGMENT_MEANS", "1") != "0"   # 0: recomputed every step           # 0: dz * gloss + the L2 term as a pass of its own
 
@@ -1488,6 +1489,70 @@ class OwnedTriplets:
             self._inc = LocalIncidence(both, self.row0, self.n_local, self._entries)
             self._both = None
         return self._inc
+
+
+class OnePassLists:
+    """What ``bkg_kge_onepass_f32`` walks for a graph's POSITIVE triplets, built once per (edge_index, edge_type): the 2 T
+    incidences ``cat(head, tail)`` sorted by (node, role, relation) -- role 0: the node is the triplet's head --, their
+    streams in list order (``other``: the row to gather, ``tid``: the triplet), the work items (a node's list, hubs cut into
+    slices: ``RowSplit``), the runs of equal (role, relation) inside every item cut into batches of at most ``nb`` entries,
+    and the record rows: one per (head-role) run, with the static order that groups them by relation for the caller's
+    segment reduce into ``d rel_emb``.  ``nb`` = ``bkg_kge_onepass_batch(d, bf16)``."""
+
+    def __init__(self, edge_index, edge_type, num_nodes, num_relations, nb):
+        from .graph import RowSplit, _Sorter
+        ei = edge_index.contiguous()
+        dev, t, r, n = ei.device, ei.size(1), int(num_relations), int(num_nodes)
+        et = edge_type.contiguous()
+        node = ei.view(-1)                                               # cat(head, tail)
+        lo = torch.cat([et, et + r])                                     # role * R + relation
+        keys, perm, rowptr = _Sorter.sort_rowptr(lo, node, 2 * r, n, n + 1, 2 * r)
+        perm64 = perm.long()
+        hd = perm64 < t
+        trip = torch.where(hd, perm64, perm64 - t)
+        self.other = torch.where(hd, ei[1][trip], ei[0][trip]).to(torch.int32).contiguous()
+        self.tid = trip.to(torch.int32).contiguous()
+        relrole = (keys.long() % (2 * r))                                # per entry, list order
+        self.split = RowSplit(rowptr, n, 2 * t)
+        self.split.tighten()                                             # (one host read per graph: the item count)
+        n_items = self.split.n_items_max
+        item_row, item_beg, item_end, item_slot = (b[:n_items].long() for b in self.split.bufs[:4])
+        # runs: a new one where an item starts or the (role, relation) key changes
+        start = torch.zeros(2 * t + 1, dtype=torch.bool, device=dev)
+        start[item_beg[item_end > item_beg]] = True
+        if t:
+            start[1:2 * t] |= relrole[1:] != relrole[:-1]
+        run_first = torch.nonzero(start[:2 * t]).squeeze(1)
+        n_runs = run_first.numel()
+        run_len = torch.diff(run_first, append=torch.tensor([2 * t], device=dev))
+        run_key = relrole[run_first]
+        nbr = (run_len + nb - 1) // nb                                   # batches per run
+        n_b = int(nbr.sum())
+        b_run = torch.repeat_interleave(torch.arange(n_runs, device=dev), nbr)
+        b_k = torch.arange(n_b, device=dev) - (torch.cumsum(nbr, 0) - nbr)[b_run]
+        b_e0 = run_first[b_run] + b_k * nb
+        b_cnt = torch.minimum(torch.full_like(b_k, nb), run_len[b_run] - b_k * nb)
+        head_run = run_key < r
+        rec_of_run = torch.cumsum(head_run.long(), 0) - 1
+        self.n_records = int(head_run.sum())
+        flags = (b_k == 0).long() * 0x100 + (b_k == nbr[b_run] - 1).long() * 0x200
+        b_rec = torch.where(head_run[b_run], rec_of_run[b_run], torch.full_like(b_run, -1))
+        self.batches = torch.stack([b_e0, b_cnt + flags, run_key[b_run], b_rec], dim=1).to(torch.int32).contiguous()
+        i_b0 = torch.searchsorted(b_e0, item_beg)
+        i_b1 = torch.searchsorted(b_e0, item_end)
+        self.items = torch.stack([item_row, i_b0, i_b1, item_slot], dim=1).to(torch.int32).contiguous()
+        self.n_items, self.n_batches, self.nb = n_items, n_b, nb
+        # the records grouped by relation (stable): rows of the segment reduce that sums them into d rel_emb
+        rec_rel = run_key[head_run]
+        _, self.rec_order, self.rec_ptr = _Sorter.sort_rowptr(rec_rel.contiguous(), None, r, 1, r + 1)
+        from .graph import rowsplit_for
+        self.rec_split = rowsplit_for(self.rec_ptr, r, self.n_records)
+
+
+def onepass_lists_of(edge_index, edge_type, num_nodes, num_relations, nb) -> OnePassLists:
+    from .graph import _cached
+    key = (int(num_nodes), int(num_relations), int(nb), edge_type.data_ptr(), edge_type._version)
+    return _cached(edge_index, "onepass", key, lambda: OnePassLists(edge_index, edge_type, num_nodes, num_relations, nb))
 
 
 def incidence_of(edge_index, num_nodes) -> Incidence:
@@ -1753,19 +1818,29 @@ class _KgeBceLoss(torch.autograd.Function):
         zt_bf16 = int(zt.dtype == torch.bfloat16)
         # triplet sets (index, type, label, counted) in groups: one group = one incidence structure of the backward
         resort = None
+        # A whole graph's POSITIVES in a DistMult training pass: ONE walk over their (node, role, relation)-sorted lists does
+        # scorer and gradient (csrc/kge_bwd_nodes.hip kge_onepass_kernel; lists built once per graph) -- dz's positive part
+        # is ready when the forward returns, the backward adds the negatives' part to it
+        onepass = (KGE_ONEPASS and owned is None and not padded and comm is None and kind == KGE_DISTMULT
+                   and bool(ctx.needs_input_grad[0]) and pos_ei.size(1) >= _SORTED_MIN_TRIPLETS and 2 * pos_ei.size(1) < (1 << 31)
+                   and n < (1 << 31) and (r + 12) * d * 4 <= 65536 and zt.stride(0) % (8 if zt_bf16 else 4) == 0
+                   and rel_emb.stride(0) % 4 == 0 and rel_emb.data_ptr() % 16 == 0)
+        pos_one = None
         if owned is None:
-            if not padded and comm is None:
+            if not padded and comm is None and not onepass:
                 resort = sorted_positives_of(pos_ei, pos_et, r)
                 if resort is not None:             # the positives of a graph that stays: walked in (relation, target) order
                     pos_ei, pos_et = resort.index, resort.types
             sets = ((pos_ei, pos_et, 1.0, True, 0), (neg_ei, neg_et, 0.0, True, 1))
+            if onepass:
+                sets = sets[1:]
         else:
             po, ne = owned
             sets = ((po.own_index, po.own_type, 1.0, True, 0), (po.foreign_index, po.foreign_type, 1.0, False, 0),
                     (ne.own_index, ne.own_type, 0.0, True, 1), (ne.foreign_index, ne.foreign_type, 0.0, False, 1))
         t_all = sum(ei.size(1) for ei, _, _, _, _ in sets)
         if total is None:
-            total = sum(ei.size(1) for ei, _, _, counted, _ in sets if counted)
+            total = sum(ei.size(1) for ei, _, _, counted, _ in sets if counted) + (pos_ei.size(1) if onepass else 0)
         # packed {head, tail, rel, g} per triplet for the node-side backward (ids fit int32; one gather instead of four)
         pack = bool(ctx.needs_input_grad[0]) and n < (1 << 31) and r < (1 << 31)
         if padded and not pack:
@@ -1773,10 +1848,14 @@ class _KgeBceLoss(torch.autograd.Function):
         if owned is not None and ctx.needs_input_grad[0] and not pack:
             raise ValueError("both-owner scoring needs the packed gradient records (table rows and relations < 2^31)")
         n_waves = [L.lib().bkg_kge_fused_bce_waves(ei.size(1), r) if ei.size(1) else 0 for ei, _, _, _, _ in sets]
-        part = torch.empty(sum(n_waves), dtype=torch.float32, device=dev)      # every wave of a launch writes its slot
+        lists, one_parts = None, 0
+        if onepass:
+            lists = onepass_lists_of(pos_ei, pos_et, n, r, L.lib().bkg_kge_onepass_batch(d, zt_bf16))
+            one_parts = 4 * L.lib().bkg_kge_onepass_blocks(lists.n_items)
+        part = torch.empty(one_parts + sum(n_waves), dtype=torch.float32, device=dev)      # every wave of a launch writes its slot
         # the sets the loss counts take the first slots: ONE contiguous sum (the others' slots follow)
-        n_counted = sum(w for w, st in zip(n_waves, sets) if st[3])
-        slot_c, slot_u, slot0 = 0, n_counted, []
+        n_counted = one_parts + sum(w for w, st in zip(n_waves, sets) if st[3])
+        slot_c, slot_u, slot0 = one_parts, n_counted, []
         for w, st in zip(n_waves, sets):
             slot0.append(slot_c if st[3] else slot_u)
             if st[3]:
@@ -1787,6 +1866,23 @@ class _KgeBceLoss(torch.autograd.Function):
         rec_all = new(t_all, 4, dtype=torch.int32, device=dev) if pack else None
         scores, grads, drel = [], [], None
         t0 = 0
+        if onepass:
+            t_pos = pos_ei.size(1)
+            s_pos = torch.empty(t_pos, dtype=torch.float32, device=dev)
+            dz_pos = torch.empty(n, d, dtype=torch.float32, device=dev)
+            records = torch.empty(lists.n_records, d, dtype=torch.float32, device=dev)
+            sp = lists.split.use()
+            # algorithmic bytes: per incidence the other endpoint's row + its index and triplet id; per node its own row, the
+            # gradient row and its item; per run a record row written and read
+            with _Timed("kge_onepass", 2 * t_pos * (d * zt.element_size() + 8) + n * (d * zt.element_size() + 4 * d + 16)
+                        + 2 * lists.n_records * 4 * d + lists.n_batches * 16, d=d, launches_per_call=1):
+                L.call("bkg_kge_onepass_f32", L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(rel_emb), rel_emb.stride(0), r,
+                       L.ptr(lists.other), L.ptr(lists.tid), L.ptr(lists.batches), L.ptr(lists.items), lists.n_items, 1.0,
+                       1.0 / total, L.ptr(s_pos), L.ptr(part[:one_parts]), L.ptr(records), L.ptr(dz_pos), dz_pos.stride(0),
+                       L.sref(sp.c), L.ptr(sp.partials(d, dev)), L.stream())
+            # the runs' record rows added per relation (fixed order: the records are grouped once per graph)
+            drel = spmm(lists.rec_ptr, lists.rec_order, None, records, r, split=lists.rec_split)
+            pos_one = (s_pos, dz_pos)
         for (ei, et, label, counted, _), waves, w0 in zip(sets, n_waves, slot0):
             t = ei.size(1)
             s = torch.empty(t, dtype=torch.float32, device=dev)
@@ -1822,12 +1918,19 @@ class _KgeBceLoss(torch.autograd.Function):
         ctx.owned = owned
         ctx.n_real = rows
         ctx.padded = padded
-        if owned is None:
+        ctx.onepass = onepass
+        if owned is None and onepass:
+            ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
+            ctx.save_for_backward(zt, rel_emb, None, grads[0], drel, None, rec_all if (pack and neg_ei.size(1)) else None,
+                                  z if (reg or padded) else None, pos_one[1])
+            pos_scores, neg_scores = pos_one[0], scores[0]
+            _FRAME["inverse"] = None
+        elif owned is None:
             ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
             ctx.save_for_backward(zt, rel_emb, grads[0], grads[1], drel,
                                   rec_all[:pos_ei.size(1)] if (pack and pos_ei.size(1)) else None,
                                   rec_all[pos_ei.size(1):] if (pack and neg_ei.size(1)) else None,
-                                  z if (reg or padded) else None)
+                                  z if (reg or padded) else None, None)
             pos_scores, neg_scores = scores[0], scores[1]
             _FRAME["inverse"] = None
             if resort is not None and _FRAME["lazy"]:
@@ -1838,7 +1941,7 @@ class _KgeBceLoss(torch.autograd.Function):
             t_pos = owned[0].n_own + owned[0].n_foreign
             ctx.graphs = None
             ctx.save_for_backward(zt, rel_emb, None, None, drel, rec_all[:t_pos] if (pack and t_pos) else None,
-                                  rec_all[t_pos:] if (pack and t_all > t_pos) else None, z if reg else None)
+                                  rec_all[t_pos:] if (pack and t_all > t_pos) else None, z if reg else None, None)
             pos_scores, neg_scores = scores[0], scores[2]           # (the sets the rank counts)
         ctx.mark_non_differentiable(pos_scores, neg_scores)
         if padded:   # BCE mean + L2 over the real rows in ONE launch (a captured mini-batch step is bound by its launch count)
@@ -1864,7 +1967,7 @@ class _KgeBceLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss, _gp, _gn):
-        zt, rel_emb, g_pos, g_neg, drel, rec_pos, rec_neg, z_reg = ctx.saved_tensors
+        zt, rel_emb, g_pos, g_neg, drel, rec_pos, rec_neg, z_reg, dz_pos = ctx.saved_tensors
         kind, owned = ctx.kind, ctx.owned
         n, d = zt.size(0), zt.size(1)
         zt_bf16 = int(zt.dtype == torch.bfloat16)
@@ -1881,8 +1984,9 @@ class _KgeBceLoss(torch.autograd.Function):
             # the incidence structures: (edge_index, edge_type, g, rec, incidence, triplets, rows of dz, first table row)
             if owned is None:
                 pos_ei, pos_et, neg_ei, neg_et = ctx.graphs
+                both = ((pos_ei, pos_et, g_pos, rec_pos), (neg_ei, neg_et, g_neg, rec_neg))
                 groups = [(ei, et, g, rec, (incidence_of(ei, n) if ei.size(1) else None), ei.size(1), n, 0)
-                          for ei, et, g, rec in ((pos_ei, pos_et, g_pos, rec_pos), (neg_ei, neg_et, g_neg, rec_neg))]
+                          for ei, et, g, rec in (both[1:] if ctx.onepass else both)]    # (one-pass: dz_pos holds the positives' part)
             else:
                 groups = [(None, ts.own_type, None, rec, (ts.incidence if ts.n_own + ts.n_foreign else None),
                            ts.n_own + ts.n_foreign, ts.n_local, ts.row0)
@@ -1890,6 +1994,7 @@ class _KgeBceLoss(torch.autograd.Function):
             n_rows = groups[0][6]
             dz = torch.empty(n_rows, d, dtype=torch.float32, device=z.device)
             first = True
+            base = dz_pos if ctx.onepass else None      # what the first launch over dz adds to (it stays intact)
             live = [gi for gi, gr in enumerate(groups)
                     if gr[5] and gr[4] is not None and (2 * gr[5] if owned is None else gr[4].n_inc)]
             # the last launch over dz applies the upstream gradient and the L2 term on its way out (the stream form's tail)
@@ -1934,14 +2039,20 @@ class _KgeBceLoss(torch.autograd.Function):
                                None, L.ptr(inc.other) if fresh else None, L.ptr(inc.relid) if fresh else None, L.ptr(gs),
                                L.stream())
                         tl = tail if (tail is not None and gi == live[-1]) else None
+                        src = base if first else None
                         L.call("bkg_kge_bwd_stream_f32", L.ptr(zt), zt_bf16, zt.stride(0), n_rows, d, L.ptr(rel_emb),
                                rel_emb.stride(0), rel_emb.size(0), L.ptr(inc.other), L.ptr(inc.relid), L.ptr(gs), L.ptr(dz),
-                               dz.stride(0), L.sref(sp.c), L.ptr(partials), 0 if first else 1,
+                               dz.stride(0), L.sref(sp.c), L.ptr(partials), 0 if (first and src is None) else 1,
                                L.ptr(tl[0]) if tl else None, L.ptr(tl[1]) if tl else None,
-                               tl[1].stride(0) if (tl and tl[1] is not None) else 0, tl[2] if tl else 0.0, L.stream())
+                               tl[1].stride(0) if (tl and tl[1] is not None) else 0, tl[2] if tl else 0.0,
+                               L.ptr(src), src.stride(0) if src is not None else 0, L.stream())
                         tailed = tl is not None
+                        base = None
                     first = False
                     continue
+                if base is not None:          # (the one-pass form's positives + a group on the older path: start from a copy)
+                    dz.copy_(base)
+                    base, first = None, False
                 with _Timed("kge_bwd_nodes" if not ctx.padded else None, by, d=d):
                     L.call("bkg_kge_bwd_nodes_f32", kind, L.ptr(zt), zt_bf16, zt.stride(0), n_rows, d,
                            L.ptr(ei[0]) if ei is not None else None, L.ptr(ei[1]) if ei is not None else None,
@@ -1950,7 +2061,9 @@ class _KgeBceLoss(torch.autograd.Function):
                            L.ptr(inc.perm), L.ptr(dz), dz.stride(0), L.sref(sp.c if sp is not None else None),
                            L.ptr(partials), 0 if first else 1, row0, L.stream())
                 first = False
-            if first:
+            if base is not None:              # no other group ran: dz is the positives' part
+                dz.copy_(base)
+            elif first:
                 dz.zero_()
             if tailed:
                 pass             # (scaled, L2 term added: the last stream launch's tail)

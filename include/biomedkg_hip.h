@@ -257,7 +257,24 @@ int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_
                                                       dz * tail_gloss[0] + tail_z * (tail_gloss[0] * tail_coef) -- the loss's upstream
                                                       gradient and the L2 term of kge_module.py:128-129 without another pass */,
                            const float* tail_z /* nullable [n_nodes, ld_tail_z] fp32 */, int64_t ld_tail_z, float tail_coef,
-                           void* stream);
+                           const float* acc_src /* nullable: an accumulating launch adds to THESE rows (dz is only written) */,
+                           int64_t ld_acc_src, void* stream);
+/* The whole DistMult TRAINING pass of a graph's POSITIVE triplets -- scores, BCE-with-logits terms, dz and d rel_emb -- in ONE
+ * walk over incidence lists sorted by (node, role, relation) (reference biomedkg/kge_module.py:121-128 +
+ * biomedkg/model/decoder.py:45-49 and their autograd): z_n stays in registers, every run of equal (role, relation) adds
+ * rel (*) sum g z_other to dz_n, and each (head, relation) run leaves ONE record row z_n (*) sum g z_other that the caller adds
+ * per relation into d rel_emb (fixed order: no atomics).  2 T row reads instead of the 4 T of scorer + node-side gradient.
+ * items [n_items] int32x4 {node, first batch, end batch, partial slot or -1}; batches int32x4 {first entry, count | first_of_run
+ * << 8 | last_of_run << 9, relation + n_rel * role (0: the node is the head), record row}; a batch holds at most
+ * bkg_kge_onepass_batch(d, z_is_bf16) entries of ONE run.  loss_part: 4 * bkg_kge_onepass_blocks(n_items) unscaled partial sums;
+ * dz is written (not added to); split: the row table the items were cut by. */
+int32_t bkg_kge_onepass_batch(int32_t d, int32_t z_is_bf16);
+int32_t bkg_kge_onepass_blocks(int64_t n_items);
+int bkg_kge_onepass_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes, int32_t d, const float* rel_emb,
+                        int64_t ldr, int64_t n_rel, const int32_t* other, const int32_t* tid, const void* batches,
+                        const void* items, int64_t n_items, float label, float inv_total, float* score /* nullable */,
+                        float* loss_part, float* records, float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials,
+                        void* stream);
 /* Fused training pass for one label (1 = positives, 0 = negatives): score[T], g[T] = (sigmoid(s) - label) *
  * inv_total, per-wave BCE-with-logits partial sums loss_part[W] and per-wave partial rows drel[W, lddr] of the
  * relation-side gradient (W = bkg_kge_fused_bce_waves(T, n_rel); relation r owns ceil(cnt_r / 64) consecutive waves;

@@ -266,3 +266,60 @@ def test_kge_bwd_stream_form_matches_one_pass_form(prec, n, d, r, hubs):
         ops.KGE_BWD_STREAMS = old_streams
         ops.KGE_BWD_TAIL = True
         ops.set_matmul_precision(old_prec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,n,d,r,hubs", [("bf16", 9000, 256, 30, 3), ("fp32", 5000, 128, 7, 1), ("bf16", 40000, 64, 2, 0)])
+def test_kge_positives_in_one_pass_match_the_two_pass_form(prec, n, d, r, hubs, monkeypatch):
+    """The DistMult training pass of a graph's positives as ONE walk over (node, role, relation)-sorted incidence lists
+    (``bkg_kge_onepass_f32``: scores, BCE terms, dz, d rel_emb records per run; reference kge_module.py:121-128 +
+    decoder.py:45-49 through autograd) against scorer + node-side list walk: the same loss, scores, dz and d rel_emb --
+    hub nodes (lists cut into slices + fix-up), nodes without triplets, runs longer than a batch, both table types, a
+    non-unit upstream gradient, and a second backward over the kept graph."""
+    from biomedkg_amd import ops
+    dev, t = "cuda", 1_100_000
+    old_prec = ops.get_matmul_precision()
+    monkeypatch.setattr(ops, "_SORTED_MIN_TRIPLETS", 1 << 20)
+    launches = []
+    call = ops.L.call
+    try:
+        ops.set_matmul_precision(prec)
+        ops.L.call = lambda name, *a: (launches.append(name), call(name, *a))[1]
+        g = torch.Generator(device=dev).manual_seed(n)
+        pe = torch.randint(0, n // 2, (2, t), device=dev, generator=g)          # nodes n // 2 .. n carry no positive triplet
+        if hubs:
+            m = torch.rand(t, device=dev, generator=g) < 0.3
+            pe[0][m] = torch.randint(0, hubs, (int(m.sum()),), device=dev, generator=g)
+        # relation ids skewed like a knowledge graph's: long (node, relation) runs
+        pt = (torch.rand(t, device=dev, generator=g) ** 3 * r).long().clamp_(max=r - 1)
+        ne = torch.randint(0, n, (2, t), device=dev, generator=g)
+        nt = torch.randint(0, r, (t,), device=dev, generator=g).sort().values
+        z0, rel0 = torch.randn(n, d, device=dev) * 0.3, torch.randn(r, d, device=dev) * 0.3
+        got = []
+        for one in (True, False):
+            monkeypatch.setattr(ops, "KGE_ONEPASS", one)
+            del launches[:]
+            z, rel = z0.clone().requires_grad_(), rel0.clone().requires_grad_()
+            loss, pp, npred = ops.kge_bce_loss(z, rel, pe, pt, ne, nt, ops.KGE_DISTMULT, reg=1e-2)
+            (loss * 1.5).backward(retain_graph=True)
+            gz1 = z.grad.clone()
+            z.grad = rel.grad = None
+            (loss * 1.5).backward()                                              # the positives' part must have stayed intact
+            assert torch.equal(z.grad, gz1)
+            got.append((float(loss.detach()), pp.clone(), npred.clone(), z.grad.clone(), rel.grad.clone(),
+                        launches.count("bkg_kge_onepass_f32"), launches.count("bkg_kge_fused_bce_dev_f32")))
+        (la, pa, na, za, ra, oa, fa), (lb, pb, nb_, zb, rb, ob, fb) = got
+        assert oa == 1 and fa == 1 and ob == 0 and fb == 2
+        assert abs(la - lb) <= 1e-6 * abs(lb)
+        tol = 2e-5 if prec == "fp32" else 1e-4
+        torch.testing.assert_close(pa, pb, rtol=tol, atol=tol)
+        assert torch.equal(na, nb_)
+        assert float((za - zb).norm() / zb.norm()) < 5e-6 and float((ra - rb).norm() / rb.norm()) < 5e-6
+        rows = torch.zeros(n, dtype=torch.bool, device=dev)
+        rows[pe.flatten()] = True
+        rows[ne.flatten()] = True
+        if (~rows).any():
+            assert torch.allclose(za[~rows], 1.5 * 2e-2 * z0[~rows] / (n * d), rtol=1e-5, atol=0)
+    finally:
+        ops.L.call = call
+        ops.set_matmul_precision(old_prec)
