@@ -218,11 +218,14 @@ def test_kge_loss_full_size(kg, kind):
         assert err < (1e-5 if kind == 0 else 2e-3), (name, err)   # TransE: sign(0) ties of |.|' differ at fp32 roundoff
 
 
-def test_kge_loss_full_size_in_the_sorted_frame(kg):
+def test_kge_loss_full_size_in_the_sorted_frame(kg, monkeypatch):
     """The positives of a graph that stays are scored in their (relation, target) frame from the step after the R-GCN
     structure's planted order is used up (ops._SortedTriplets; 4 M triplets: above the product's floor, as shipped): the
     same loss, scores and gradients as the first call's plain form, against the fp64 restatement."""
     from biomedkg_amd import graph as G, ops, sampling
+    # (the two-pass form of the positives: a DistMult training pass takes the one-pass walk by default since round 5 --
+    # test_kge_loss_full_size_positives_in_one_pass below; TransE and gradient-free calls still go through the frame)
+    monkeypatch.setattr(ops, "KGE_ONEPASS", False)
     ei0, et0 = kg
     ei, et = ei0.clone(), et0.clone()                          # (structures are cached on the tensors)
     G.rel_graph_of(ei, et, N, R)                               # what the encoder builds: plants the relation order
@@ -246,6 +249,43 @@ def test_kge_loss_full_size_in_the_sorted_frame(kg):
         torch.testing.assert_close(pos_s.double(), ref_s[:E], rtol=1e-4, atol=1e-4)      # the caller's order
         assert float((dz.double() - zd.grad).norm() / zd.grad.norm()) < 1e-5
         assert float((drel.double() - rd.grad).norm() / rd.grad.norm()) < 1e-5
+
+
+def test_kge_loss_full_size_positives_in_one_pass(kg):
+    """The shipped DistMult training pass at full size (4 M positives in ONE walk over their sorted incidence lists,
+    4 M fresh negatives through scorer + list walk) against the fp64 restatement: loss, the positives' scores in the
+    caller's order, dz and d rel_emb; twice (the second call finds the lists cached on the graph's tensors)."""
+    from biomedkg_amd import ops, sampling
+    ei0, et0 = kg
+    ei, et = ei0.clone(), et0.clone()
+    torch.manual_seed(7)
+    neg = sampling.negative_sampling(ei, N, E)
+    nt = et[torch.randperm(E, device=DEV)]
+    z0, rel0 = _x(8) * 0.3, torch.randn(R, D, device=DEV) * 0.3
+    launches = []
+    call = ops.L.call
+    ops.L.call = lambda name, *a: (launches.append(name), call(name, *a))[1]
+    try:
+        res = []
+        for _ in range(2):
+            z, rel = z0.clone().requires_grad_(), rel0.clone().requires_grad_()
+            loss, pos_s, neg_s = ops.kge_bce_loss(z, rel, ei, et, neg, nt, 0)
+            loss.backward()
+            res.append((float(loss.detach()), pos_s.clone(), neg_s.clone(), z.grad.clone(), rel.grad.clone()))
+    finally:
+        ops.L.call = call
+    assert launches.count("bkg_kge_onepass_f32") == 2 and "onepass" in ei._bkg_cache
+    zd, rd = z0.double().requires_grad_(), rel0.double().requires_grad_()
+    all_ei, all_et = torch.cat([ei, neg], 1), torch.cat([et, nt])
+    label = torch.cat([torch.ones(E, dtype=torch.float64, device=DEV), torch.zeros(E, dtype=torch.float64, device=DEV)])
+    ref_loss, ref_s = _kge_ref(0, zd, rd, all_ei, all_et, label)
+    for loss, pos_s, neg_s, dz, drel in res:
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+        torch.testing.assert_close(pos_s.double(), ref_s[:E], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(neg_s.double(), ref_s[E:], rtol=1e-4, atol=1e-4)
+        assert float((dz.double() - zd.grad).norm() / zd.grad.norm()) < 1e-5
+        assert float((drel.double() - rd.grad).norm() / rd.grad.norm()) < 1e-5
+    assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])      # no atomics anywhere: repeatable
 
 
 def _ntxent_ref(h1, h2, tau, chunk=4096):

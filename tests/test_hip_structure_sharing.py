@@ -96,6 +96,7 @@ def test_positives_of_a_graph_that_stays_are_scored_in_their_sorted_frame(monkey
     target) order: same loss, same gradients, scores handed back in the caller's order."""
     from biomedkg_amd import graph as G, ops
     monkeypatch.setattr(ops, "_SORTED_MIN_TRIPLETS", 1000)
+    monkeypatch.setattr(ops, "KGE_ONEPASS", False)      # (the two-pass form: DistMult training passes walk the positives once by default)
     n, e, r, d = 3000, 60_000, 7, 128
     ei, et = _graph(n, e, r, 5)
     g = torch.Generator().manual_seed(6)
