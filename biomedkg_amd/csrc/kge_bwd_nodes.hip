@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256) void kge_onepass_kernel(const T* __restrict__ 
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
+        if (u > 0 && u * G >= cnt) break;             // (wave-uniform: a short batch's empty rounds cost nothing)
         const bool live = u * G + grp < cnt;
         float4 o[VQ];
 #pragma unroll
