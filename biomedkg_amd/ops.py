@@ -1550,9 +1550,33 @@ class OnePassLists:
 
 
 def onepass_lists_of(edge_index, edge_type, num_nodes, num_relations, nb) -> OnePassLists:
+    """Cached on ``edge_index`` for THIS ``edge_type`` object at this version (an id tensor re-allocated at the same
+    address -- ``fix_edge_id``'s ``full_like`` every step -- is another object: ``onepass_stable`` keeps such flows off
+    this path, and a stale entry is rebuilt here)."""
     from .graph import _cached
     key = (int(num_nodes), int(num_relations), int(nb), edge_type.data_ptr(), edge_type._version)
-    return _cached(edge_index, "onepass", key, lambda: OnePassLists(edge_index, edge_type, num_nodes, num_relations, nb))
+
+    def build():
+        lists = OnePassLists(edge_index, edge_type, num_nodes, num_relations, nb)
+        lists.types_ref = weakref.ref(edge_type)
+        return lists
+    lists = _cached(edge_index, "onepass", key, build)
+    if lists.types_ref() is not edge_type:
+        edge_index._bkg_cache.pop("onepass", None)
+        lists = _cached(edge_index, "onepass", key, build)
+    return lists
+
+
+def onepass_stable(edge_index, edge_type):
+    """Has this very (``edge_index``, ``edge_type``) pair of tensor objects, at these versions, been asked about before?
+    The lists of the one-pass walk take ~20 launches over 8 M entries to build: they pay from the second step of a graph
+    that stays, never for triplets that are new objects every step (mini-batches, ``fix_edge_id``)."""
+    seen = getattr(edge_index, "_bkg_onepass_seen", None)
+    now = (edge_index._version, edge_type._version)
+    same = seen is not None and seen[0]() is edge_type and seen[1] == now
+    if not same:
+        edge_index._bkg_onepass_seen = (weakref.ref(edge_type), now)
+    return same
 
 
 def incidence_of(edge_index, num_nodes) -> Incidence:
@@ -1824,7 +1848,8 @@ class _KgeBceLoss(torch.autograd.Function):
         onepass = (KGE_ONEPASS and owned is None and not padded and comm is None and kind == KGE_DISTMULT
                    and bool(ctx.needs_input_grad[0]) and pos_ei.size(1) >= _SORTED_MIN_TRIPLETS and 2 * pos_ei.size(1) < (1 << 31)
                    and n < (1 << 31) and (r + 12) * d * 4 <= 65536 and zt.stride(0) % (8 if zt_bf16 else 4) == 0
-                   and rel_emb.stride(0) % 4 == 0 and rel_emb.data_ptr() % 16 == 0)
+                   and rel_emb.stride(0) % 4 == 0 and rel_emb.data_ptr() % 16 == 0 and not torch.cuda.is_current_stream_capturing()
+                   and onepass_stable(pos_ei, pos_et))
         pos_one = None
         if owned is None:
             if not padded and comm is None and not onepass:

@@ -131,6 +131,8 @@ def main(fetch_csv, write_csv, out_json, precision="fp32", bench_json=None, tcc_
             tag = "kge_bwd_nodes"
         if "kge_fused_bce_kernel" in key[0]:
             tag = "kge_fused_bce"
+        if "kge_onepass_kernel" in key[0]:
+            tag = "kge_onepass"
         rec = {"kernel": key[0], "grid_size": key[1], "precision": precision, "launches": len(fv), "tag": tag, "tags": also,
                "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write}
         if key in durations:

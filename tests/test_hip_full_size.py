@@ -262,6 +262,7 @@ def test_kge_loss_full_size_positives_in_one_pass(kg):
     neg = sampling.negative_sampling(ei, N, E)
     nt = et[torch.randperm(E, device=DEV)]
     z0, rel0 = _x(8) * 0.3, torch.randn(R, D, device=DEV) * 0.3
+    assert not ops.onepass_stable(ei, et)          # (first sighting of the pair; the calls below are its 2nd and 3rd)
     launches = []
     call = ops.L.call
     ops.L.call = lambda name, *a: (launches.append(name), call(name, *a))[1]

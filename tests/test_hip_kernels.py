@@ -296,6 +296,10 @@ def test_kge_positives_in_one_pass_match_the_two_pass_form(prec, n, d, r, hubs, 
         nt = torch.randint(0, r, (t,), device=dev, generator=g).sort().values
         z0, rel0 = torch.randn(n, d, device=dev) * 0.3, torch.randn(r, d, device=dev) * 0.3
         got = []
+        # a pair of tensors seen for the FIRST time goes the two-pass way (the lists pay from a graph's second step on)
+        zf, rf = z0.clone().requires_grad_(), rel0.clone().requires_grad_()
+        first = ops.kge_bce_loss(zf, rf, pe, pt, ne, nt, ops.KGE_DISTMULT, reg=1e-2)[0]
+        assert launches.count("bkg_kge_onepass_f32") == 0 and launches.count("bkg_kge_fused_bce_dev_f32") == 2
         for one in (True, False):
             monkeypatch.setattr(ops, "KGE_ONEPASS", one)
             del launches[:]
@@ -310,7 +314,7 @@ def test_kge_positives_in_one_pass_match_the_two_pass_form(prec, n, d, r, hubs, 
                         launches.count("bkg_kge_onepass_f32"), launches.count("bkg_kge_fused_bce_dev_f32")))
         (la, pa, na, za, ra, oa, fa), (lb, pb, nb_, zb, rb, ob, fb) = got
         assert oa == 1 and fa == 1 and ob == 0 and fb == 2
-        assert abs(la - lb) <= 1e-6 * abs(lb)
+        assert abs(la - lb) <= 1e-6 * abs(lb) and abs(float(first.detach()) - lb) <= 1e-6 * abs(lb)
         tol = 2e-5 if prec == "fp32" else 1e-4
         torch.testing.assert_close(pa, pb, rtol=tol, atol=tol)
         assert torch.equal(na, nb_)
