@@ -125,8 +125,11 @@ def pmc_traffic(tag, precision):
             if hits:
                 # a call = one launch of its main kernel (+ its second kernel); a tag may cover several shapes of the same
                 # call (the positive and the negative triplet set): bytes over all launches / number of calls
+                # (a fix-up kernel may also run behind ANOTHER call -- the one-pass walk's long rows end in the node-side
+                # backward's fix-up kernel --: calls are counted on the main kernels)
+                main = [k for k in hits if "fixup" not in k["kernel"]] or hits
                 per_kernel = {}
-                for k in hits:
+                for k in main:
                     per_kernel[k["kernel"]] = per_kernel.get(k["kernel"], 0) + k["launches"]
                 calls = max(per_kernel.values())      # (a group shared by several tags -- "tags" -- averages over their calls)
                 total = sum(k["traffic_bytes_per_launch"] * k["launches"] for k in hits) / calls
@@ -137,7 +140,7 @@ def pmc_traffic(tag, precision):
                 traced = None
                 if all("avg_duration_us" in k for k in hits):
                     per = {}
-                    for k in hits:
+                    for k in main:
                         per[k["kernel"]] = per.get(k["kernel"], 0) + k["launches_traced"]
                     traced = sum(k["avg_duration_us"] * k["launches_traced"] for k in hits) / max(per.values()) / 1e3
                 return total, (h / (h + m) if (h + m) else None), os.path.basename(path), traced
