@@ -854,8 +854,11 @@ extern "C" int32_t bkg_kge_onepass_batch(int32_t d, int32_t z_is_bf16) {
                     case 64: lpr = 64; break; case 96: lpr = 32; break; case 128: case 192: lpr = 64; break; default: break; }
   return KO_U * (64 / lpr);
 }
+#ifndef KO_BLOCKS
+#define KO_BLOCKS KN_PERSIST_BLOCKS
+#endif
 extern "C" int32_t bkg_kge_onepass_blocks(int64_t n_items) {
-  return (int32_t)std::max<int64_t>(1, std::min<int64_t>(ceil_div(std::max<int64_t>(n_items, 1), 4), KN_PERSIST_BLOCKS));
+  return (int32_t)std::max<int64_t>(1, std::min<int64_t>(ceil_div(std::max<int64_t>(n_items, 1), 4), KO_BLOCKS));
 }
 extern "C" int bkg_kge_onepass_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes, int32_t d, const float* rel_emb,
                                    int64_t ldr, int64_t n_rel, const int32_t* other, const int32_t* tid, const void* batches,
