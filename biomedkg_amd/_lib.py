@@ -11,7 +11,8 @@ from ctypes import c_double, c_float, c_int32, c_int64, c_uint32, c_uint64, c_vo
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbiomedkg_hip.so")
+# (BKG_HIP_LIB: another build of the same library -- tuning variants compiled with other -D flags, scripts/dev_*)
+LIB_PATH = os.environ.get("BKG_HIP_LIB") or os.path.join(_HERE, "csrc", "libbiomedkg_hip.so")
 
 P = c_void_p
 I32, I64, U32, U64, F32, F64 = c_int32, c_int64, c_uint32, c_uint64, c_float, c_double

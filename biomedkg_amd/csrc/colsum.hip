@@ -7,7 +7,10 @@
 
 namespace bkg {
 
-constexpr int CS_MAX_BLOCKS = 512;
+#ifndef CS_MAX_BLOCKS_
+#define CS_MAX_BLOCKS_ 512
+#endif
+constexpr int CS_MAX_BLOCKS = CS_MAX_BLOCKS_;
 
 // block = 256 threads = RPB row slots x PPR pieces per row; thread (slot, piece) walks rows slot, slot + RPB, ...
 template <typename T>
