@@ -14,16 +14,21 @@ positive, BCE + L2 reg) over the same synthetic PrimeKG++-shaped graph (BASELINE
 Adam (clip + update fused: biomedkg_amd/optim.py), inputs resident in HBM.  ``value`` = input edges / step time (every input edge counted once
 although both sub-steps consume it), whole job.
 
-N = 1 runs the whole graph on the GPU.  N > 1, ``--mode auto`` -> ``replicas``: one PrimeKG++-shaped graph per rank, the
-ranks' gradients averaged by one flat RCCL all-reduce per sub-step (the KGE bucket under the next GGD sub-step) -- the
-reference's own multi-GPU regime (Lightning DDP: train_gcl.py:63-68, configs/gcl.yaml:11), per-GPU work fixed, ``"scaling":
-"weak"``, ``value`` = the edges of all ranks' graphs / step time.  ``--mode partition`` (BASELINE configs[3] / north_star's
-node sharding; strong scaling): ONE graph, its nodes partitioned over the ranks (biomedkg_amd/partition.py): per conv layer a
-gather of the table rows a rank's in-edges read (forward) and of the output-gradient rows its out-edges point at (backward),
-every triplet scored by the owners of both its endpoints (no gradient rows cross the wire), flat-bucket gradient all-reduce.
-Round 5 measured each rank's compute on one GPU (scripts/simulate_ranks.py): 7.6 / 5.7 / 4.8 ms per step at 2 / 4 / 8 ranks
-against 9.5 on one GPU -- at most 1.8-2.0x at 8 GPUs whatever the wire does -- which is why it is not the
-default way to use N GPUs on a graph that fits one.
+N = 1 runs the whole graph on the GPU.  N > 1, ``--mode auto`` runs BOTH multi-GPU regimes one after the other, each on N
+fresh ranks, and prints ONE line (``launch_ranks``):
+* the headline -- ``value``, ``ms_per_step``, ``"scaling": "strong"``, ``"mode": "partition"`` -- is BASELINE configs[3] /
+  north_star's node sharding: ONE graph, its nodes partitioned over the ranks (biomedkg_amd/partition.py): per conv layer a
+  gather of the table rows a rank's in-edges read (forward) and of the output-gradient rows its out-edges point at
+  (backward), every triplet scored by the owners of both its endpoints (no gradient rows cross the wire), flat-bucket
+  gradient all-reduce.  Round 5 measured each rank's compute on one GPU (scripts/simulate_ranks.py): at most 1.8-2.0x at 8
+  GPUs whatever the wire does -- a rank's share of a step that takes one GPU 8-9 ms is below the floor of
+  the ~350 kernels that carry it;
+* ``replicas`` on the same line -- its own ``value`` / ``ms_per_step`` / ``"scaling": "weak"`` -- is the reference's own
+  multi-GPU regime (Lightning DDP: train_gcl.py:63-68, configs/gcl.yaml:11): one PrimeKG++-shaped graph per rank, the ranks'
+  gradients averaged by one flat RCCL all-reduce per sub-step (the KGE bucket under the next GGD sub-step), per-GPU work
+  fixed, value = the edges of all ranks' graphs / step time.
+``--mode partition`` / ``--mode replicas`` run one of them.  (Rounds 1-4 reported the partition as the N-GPU figure, round 5
+the replicas: the two are different workloads, hence both, each labelled.)
 Default ``--precision bf16`` = BASELINE's "bf16 storage / fp32 accumulate" configuration; ``--precision fp32``
 is the exact parity mode (its step time is reported on the same line as ``ms_per_step_fp32``).
 
@@ -97,10 +102,10 @@ def parse():
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
                     help="matrix-core operand precision (BASELINE configs[2] is the bf16 config; fp32 = exact mode)")
     ap.add_argument("--mode", choices=["auto", "replicas", "partition"], default="auto",
-                    help="auto: the whole graph on one GPU; over N > 1 GPUs one graph per rank with a flat gradient "
-                         "all-reduce (replicas: weak scaling, the reference's DDP regime).  partition: ONE graph, its nodes "
-                         "partitioned over the N GPUs (strong scaling; for graphs that do not fit one GPU -- on the bench "
-                         "graph a rank's share of the 9.5 ms step is below the floor of the kernels that carry it: DESIGN.md 6)")
+                    help="auto: the whole graph on one GPU; over N > 1 GPUs BOTH regimes on one line -- headline: partition "
+                         "(ONE graph, its nodes partitioned over the N GPUs: BASELINE configs[3], strong scaling), beside it: "
+                         "replicas (one graph per rank with a flat gradient all-reduce: the reference's DDP regime, weak "
+                         "scaling).  partition / replicas: that regime alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 step / GRACE / NT-Xent / fusion figures")
     ap.add_argument("--cpu-scale", type=int, default=8, help="the live CPU baseline probe runs on a 1/scale graph")
@@ -1150,9 +1155,10 @@ def cpu_baseline(args):
 STEPS_MARK = "bench.py: structures built, steps start"      # rank 0 writes this to stderr right before its warm-up steps
 
 
-def _run_ranks(args, extra_env, limit_s, setup_limit_s=None):
+def _run_ranks(args, extra_env, limit_s, setup_limit_s=None, argv=()):
     """Start N fresh interpreters on this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and wait for them.
-    -> (rank 0's stdout, exit codes, text for stderr).  ``limit_s``: end every rank when the STEPS (warm-up, timed loop,
+    -> (rank 0's stdout, exit codes, text for stderr).  ``argv``: arguments appended to this process's own (a later
+    ``--mode`` / ``--detail`` wins: the two legs of the default N-GPU run).  ``limit_s``: end every rank when the STEPS (warm-up, timed loop,
     side measurements -- everything after rank 0's ``STEPS_MARK``) take longer; ``setup_limit_s``: the same for what comes
     before the mark (the first ``import torch`` on a fresh box pages the image in for 1-2 minutes, the rendezvous, the
     partition's structures), so that a short limit on the steps never ends a healthy run that was merely slow to start."""
@@ -1171,7 +1177,7 @@ def _run_ranks(args, extra_env, limit_s, setup_limit_s=None):
         # every rank's stderr goes to a file of its own: when one fails, ITS last lines are shown under its rank number
         # (eight interleaved tracebacks of ranks that were merely killed in a collective say nothing)
         logs.append(tempfile.TemporaryFile(mode="w+b"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=logs[-1]))
     out, first_dead, note, t_mark, killed = None, None, "", None, set()
     t0 = time.time()
@@ -1252,6 +1258,100 @@ def graphed_line_refused(stdout):
     return None
 
 
+def _last_line(stdout):
+    """The last JSON line of a leg's stdout as a dict, or None."""
+    for l in reversed((stdout or "").splitlines()):
+        if l.startswith("{"):
+            try:
+                return json.loads(l)
+            except ValueError:
+                return None
+    return None
+
+
+def run_partition_ladder(args, argv=()):
+    """The node-partitioned step over N fresh ranks -> (rank 0's stdout, exit codes, text for stderr, attempts).
+
+    Over RCCL the GRAPHED sub-steps go first (BKG_BENCH_PARTITION_GRAPH=1: every sub-step one hipGraph replay -- an eager
+    partitioned step costs the host 3.6-5 ms to enqueue, more than a rank's kernels take from four ranks on).  Captured
+    collectives have only ever run on a one-rank RCCL group here (no multi-GPU box), so that attempt is fenced three ways
+    (ADVICE r04): (1) its steps get BKG_BENCH_GRAPH_ATTEMPT_S (default 75 s, counted from rank 0's "steps start" mark, not
+    from process start) -- a run stuck in a collective is ended; (2) a rank whose capture fails takes every rank out with it
+    (``capture_agreed``), never a mix of replaying and eager ranks; (3) the line is ACCEPTED only if it shows that the
+    replays trained: both fixed-draw check losses finite and lower after the run than before it (a graph that replays
+    wrongly -- stale buffers, a collective out of order -- does not pass that).  Otherwise the ranks are started again with
+    the eager step, which is fenced as well (BKG_BENCH_EAGER_ATTEMPT_S, default 300 s from the same mark).
+
+    Whole-table exchanges of unequal shards: the library's default is the packed ``all_to_all_single`` (the form the gloo
+    worlds 2 / 3 / 4 / 8 of tests/test_partition_gloo.py run).  The in-place list form (``BKG_DIRECT_ALL_TO_ALL=1``: no
+    (world - 1)-fold packed copy, no unpack pass) has only ever run in the simulated rank, so bench.py asks for it in its
+    first two attempts -- both fenced -- and the last attempt is the packed form.  ``exchange.form`` / ``attempts`` on the
+    line say which ran."""
+    n = args.gpus
+    backend = os.environ.get("BKG_BENCH_BACKEND", "nccl")
+    setup = float(os.environ.get("BKG_BENCH_SETUP_LIMIT_S", "600"))
+    eager_limit = float(os.environ.get("BKG_BENCH_EAGER_ATTEMPT_S", "300"))
+    direct = ({} if "BKG_DIRECT_ALL_TO_ALL" in os.environ else {"BKG_DIRECT_ALL_TO_ALL": "1"}) if backend == "nccl" else {}
+    try_graphs = "BKG_BENCH_PARTITION_GRAPH" not in os.environ and backend == "nccl"
+    attempts, notes = [], ""
+    if try_graphs:
+        limit = float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "75"))
+        out, codes, note = _run_ranks(args, dict(direct, BKG_BENCH_PARTITION_GRAPH="1"), limit, setup, argv)
+        why = graphed_line_refused(out) if all(c == 0 for c in codes) else f"exit codes {codes}"
+        attempts.append({"form": "graphed sub-steps" + (", in-place all-to-all" if direct else ""), "ok": why is None,
+                         "why_not": why})
+        if why is None:
+            return out, codes, note, attempts
+        notes += note + f"bench.py --gpus {n}: the graphed attempt is not used ({why}); running the eager step\n"
+    eager_env = {"BKG_BENCH_PARTITION_GRAPH": "0"} if try_graphs else {}
+    out, codes, note = _run_ranks(args, dict(direct, **eager_env), eager_limit, setup, argv)
+    ok = all(c == 0 for c in codes) and _last_line(out) is not None
+    attempts.append({"form": "eager step" + (", in-place all-to-all" if direct else ""), "ok": ok,
+                     "why_not": None if ok else f"exit codes {codes}"})
+    if not ok and direct:
+        notes += note + (f"bench.py --gpus {n}: the eager step failed (exit codes {codes}); once more with the packed "
+                         "all_to_all_single exchanges (the library's default)\n")
+        out, codes, note = _run_ranks(args, dict(eager_env, BKG_DIRECT_ALL_TO_ALL="0"), eager_limit, setup, argv)
+        ok = all(c == 0 for c in codes) and _last_line(out) is not None
+        attempts.append({"form": "eager step, packed all_to_all_single", "ok": ok,
+                         "why_not": None if ok else f"exit codes {codes}"})
+    return out, codes, notes + note, attempts
+
+
+_LEG_KEYS = ("mode", "value", "unit", "ms_per_step", "ms_per_step_median", "scaling", "ranks", "backend", "steps", "warmup",
+             "ms_gcl_step", "ms_kge_step", "triplets_per_sec_kge_step", "edges_per_sec_gcl_step")
+
+
+def merge_legs(primary, secondary, key, attempts=None):
+    """The ONE line of the default N-GPU run: ``primary`` (a leg's parsed line) with the other leg's headline figures under
+    ``key`` -- both regimes explicitly, each with its own ``scaling``.  -> strict JSON text < LINE_LIMIT."""
+    line = dict(primary)
+    if isinstance(secondary, dict) and "error" not in secondary:
+        leg = {k: secondary.get(k) for k in _LEG_KEYS if secondary.get(k) is not None}
+        leg["parallelism"] = (secondary.get("config") or {}).get("parallelism")
+        ex = secondary.get("exchange") or {}
+        leg["exchange"] = {k: ex[k] for k in ("form", "exchanges_per_step", "wire_bytes_sent_per_step", "bucket_bytes_ggd",
+                                              "bucket_bytes_kge", "allreduce_alone_ms_ggd", "allreduce_alone_ms_kge",
+                                              "exposed_fraction", "host_enqueue_ms_per_step") if k in ex}
+        leg["detail"] = secondary.get("detail")
+    else:
+        leg = secondary
+    line[key] = leg
+    if attempts is not None:
+        line["attempts"] = attempts
+    line = _strict(line)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    for drop in ("attempts", "check_loss_after", "check_loss", "partition_bound"):
+        if len(text) < LINE_LIMIT - 512:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT and isinstance(line.get(key), dict):
+        line[key].pop("exchange", None)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    return text
+
+
 def launch_ranks(args):
     """``python3 bench.py --gpus N`` with no launcher around it: this process becomes the launcher -- it never touches
     the GPU (nothing before this point does: ``import torch`` and ``torch.cuda.device_count()`` do not initialise HIP on
@@ -1259,46 +1359,61 @@ def launch_ranks(args):
     way Lightning starts the reference's ranks from one ``python train_gcl.py`` (reference train_gcl.py:63-68,
     configs/gcl.yaml:11).  Rank 0's stdout (the single JSON line) is relayed; the exit code is the worst child's.
 
-    Node-partitioned runs over RCCL try the GRAPHED sub-steps first (BKG_BENCH_PARTITION_GRAPH=1: every sub-step one
-    hipGraph replay -- an eager partitioned step costs the host 3.6-5 ms to enqueue, more than a rank's kernels take from
-    four ranks on).  Captured collectives have only ever run on a one-rank RCCL group here (no multi-GPU box), so that
-    attempt is fenced three ways: (1) its steps get BKG_BENCH_GRAPH_ATTEMPT_S (default 75 s, counted from
-    rank 0's "steps start" mark, not from process start) -- a run stuck in a collective is ended; (2) a rank whose capture
-    fails takes every rank out with it (``capture_agreed``), never a mix of replaying and eager ranks; (3) the line is
-    ACCEPTED only if it shows that the replays trained: both fixed-draw check losses finite and lower after the run than
-    before it (a graph that replays wrongly -- stale buffers, a collective out of order -- does not pass that).  Otherwise
-    the ranks are started again with the eager step.  The line says which form ran (``exchange.form``)."""
+    ``--mode auto`` over N > 1 GPUs runs BOTH regimes, one after the other, each on N fresh ranks, and prints ONE line
+    (rounds 1-4 reported the node partition, round 5 the replicas; the two figures are not comparable and the
+    line must say which is which): the headline is the NODE-PARTITIONED step (BASELINE configs[3] / north_star: one graph,
+    ``"scaling": "strong"``, ``run_partition_ladder``) and ``replicas`` carries the reference's own DDP regime (one graph
+    per rank, flat gradient all-reduce, ``"scaling": "weak"``) with its own value / ms_per_step.  If every partition attempt
+    fails the replicas leg becomes the headline and ``partition`` holds the attempts' outcomes -- a number the driver can
+    read either way.  ``--mode partition`` / ``--mode replicas`` run one leg."""
     n = args.gpus
     one_device = os.environ.get("BKG_BENCH_ONE_DEVICE") == "1"
     have = torch.cuda.device_count()
     if have < n and not one_device:
         raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s) (BKG_BENCH_ONE_DEVICE=1 + "
                          "BKG_BENCH_BACKEND=gloo is the functional single-device check)")
-    backend = os.environ.get("BKG_BENCH_BACKEND", "nccl")
-    try_graphs = ("BKG_BENCH_PARTITION_GRAPH" not in os.environ and backend == "nccl" and args.mode == "partition")
-    if try_graphs:
-        limit = float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "75"))
-        setup = float(os.environ.get("BKG_BENCH_SETUP_LIMIT_S", "600"))
-        out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "1"}, limit, setup)
-        why = graphed_line_refused(out) if all(c == 0 for c in codes) else f"exit codes {codes}"
-        if why is None:
-            sys.stderr.write(note)
-            sys.stdout.write(out)
-            sys.stdout.flush()
-            raise SystemExit(0)
-        sys.stderr.write(note + f"bench.py --gpus {n}: the graphed attempt is not used ({why}); running the eager step\n")
-    out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "0"} if try_graphs else {}, None)
-    if (any(c != 0 for c in codes) and try_graphs and "BKG_DIRECT_ALL_TO_ALL" not in os.environ):
-        # the in-place (list-form) all-to-all of the whole-table exchanges has only ever run in the simulated rank (it needs
-        # RCCL ranks with unequal shards: no multi-GPU box here): one more attempt with the packed all_to_all_single form
-        sys.stderr.write(note + f"bench.py --gpus {n}: the eager step failed (exit codes {codes}); once more with the packed "
-                         "all_to_all_single exchanges (BKG_DIRECT_ALL_TO_ALL=0)\n")
-        out, codes, note = _run_ranks(args, {"BKG_BENCH_PARTITION_GRAPH": "0", "BKG_DIRECT_ALL_TO_ALL": "0"}, None)
-    sys.stderr.write(note)
-    sys.stdout.write(out)
-    sys.stdout.flush()
-    bad = [c for c in codes if c != 0]
-    raise SystemExit(max(abs(c) for c in bad) if bad else 0)
+    setup = float(os.environ.get("BKG_BENCH_SETUP_LIMIT_S", "600"))
+
+    def finish(out, codes, note):
+        sys.stderr.write(note)
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        bad = [c for c in codes if c != 0]
+        raise SystemExit(max(abs(c) for c in bad) if bad else 0)
+
+    if args.mode == "partition":
+        out, codes, note, _ = run_partition_ladder(args)
+        finish(out, codes, note)
+    replicas_limit = float(os.environ.get("BKG_BENCH_REPLICAS_LIMIT_S", "600"))
+    if args.mode == "replicas":
+        finish(*_run_ranks(args, {}, replicas_limit, setup))
+    # auto: both legs, one line
+    base, ext = os.path.splitext(args.detail)
+    out_r, codes_r, note_r = _run_ranks(args, {}, replicas_limit, setup,
+                                        ["--mode", "replicas", "--detail", base + "_replicas" + ext])
+    line_r = _last_line(out_r) if all(c == 0 for c in codes_r) else None
+    sys.stderr.write(note_r)
+    if line_r is None:
+        sys.stderr.write(f"bench.py --gpus {n}: the replicas leg gave no line (exit codes {codes_r})\n")
+    out_p, codes_p, note_p, attempts = run_partition_ladder(args, ["--mode", "partition"])
+    line_p = _last_line(out_p) if all(c == 0 for c in codes_p) else None
+    sys.stderr.write(note_p)
+    try:      # (RCCL's banner etc. went through the children; nothing of ours is buffered in C stdio here)
+        sys.stderr.flush()
+    except Exception:      # noqa: BLE001
+        pass
+    if line_p is not None:
+        other = line_r if line_r is not None else {"error": f"the replicas leg gave no line (exit codes {codes_r})"}
+        print(merge_legs(line_p, other, "replicas", attempts), flush=True)
+        raise SystemExit(0)
+    if line_r is not None:
+        sys.stderr.write(f"bench.py --gpus {n}: no partition attempt gave a line (exit codes {codes_p}); the replicas leg is "
+                         "the headline\n")
+        print(merge_legs(line_r, {"error": f"no attempt of the node-partitioned step gave a line (exit codes {codes_p})",
+                                  "attempts": attempts}, "partition"), flush=True)
+        raise SystemExit(0)
+    bad = [c for c in list(codes_r) + list(codes_p) if c != 0]
+    raise SystemExit(max(abs(c) for c in bad) if bad else 1)
 
 
 # what an outer launcher (torch.distributed.run) puts into its workers' environment
@@ -1334,7 +1449,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)                          # does not return
     if (args.gpus > 1 and os.environ.get("BKG_BENCH_SPAWNED") != "1" and os.environ.get("BKG_BENCH_OUTER_RANKS") != "1"
-            and args.mode == "partition"):
+            and args.mode in ("partition", "auto")):
         take_over_from_outer_launcher(args)         # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

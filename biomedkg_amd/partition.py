@@ -230,10 +230,13 @@ class Comm:
         return self._issued((table, work, recv, recv_slots))
 
     def _lands_in_place(self):
-        """The list form of all-to-all on the tensors themselves: RCCL (and the simulated rank).  gloo has no list form
-        (and its point-to-point calls take host pointers only): it keeps the packed all_to_all_single.
-        ``BKG_DIRECT_ALL_TO_ALL=0`` keeps the packed form everywhere."""
-        if os.environ.get("BKG_DIRECT_ALL_TO_ALL", "1") == "0":
+        """The list form of all-to-all on the tensors themselves -- my rows leave from their slice of the table, each peer's
+        rows arrive in theirs (disjoint row ranges of one allocation) -- is OPT-IN: ``BKG_DIRECT_ALL_TO_ALL=1``.
+        It has only ever run in the simulated rank (it needs RCCL ranks with unequal shards; no multi-GPU box was available
+        to this build), so library users under torchrun get the packed ``all_to_all_single`` -- the form every gloo world of
+        tests/test_partition_gloo.py runs -- unless they ask.  bench.py asks for it in its first, time-fenced attempts and
+        falls back to the packed form (``run_partition_ladder``).  gloo has no list form at all."""
+        if os.environ.get("BKG_DIRECT_ALL_TO_ALL", "0") != "1":
             return False
         return self.simulate or (dist.is_initialized() and dist.get_backend(self.group) == "nccl")
 

@@ -114,6 +114,9 @@ def in_process(args):
         raise SystemExit("simulate_ranks.py needs an MI355X: the HIP path has no CPU fallback")
     if not args.eager:
         os.environ["BKG_BENCH_PARTITION_GRAPH"] = "1"
+    # the form bench.py's first attempts ask for (in-place list-form all-to-all of whole-table exchanges; the library's
+    # default is the packed all_to_all_single): BKG_DIRECT_ALL_TO_ALL=0 measures the packed form
+    os.environ.setdefault("BKG_DIRECT_ALL_TO_ALL", "1")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     ops.set_matmul_precision(args.precision)
@@ -129,6 +132,8 @@ def in_process(args):
                          f"host {rec['host_ms_per_step']:.3f}, eager {rec['ms_per_step_eager']:.3f} ms, rows {rec['rows']}\n")
     slow = max(rows, key=lambda x: x["ms_per_step"])
     return {"world": world, "ranks": rows, "slowest_rank": slow["rank"], "compute_ms": slow["ms_per_step"],
+            "whole_table_exchange": ("in-place list form" if os.environ.get("BKG_DIRECT_ALL_TO_ALL") == "1"
+                                     else "packed all_to_all_single"),
             "compute_ms_ggd": max(x["ms_ggd"] for x in rows), "compute_ms_kge": max(x["ms_kge"] for x in rows),
             "compute_ms_eager": max(x["ms_per_step_eager"] for x in rows),
             "mean_ms": sum(x["ms_per_step"] for x in rows) / len(rows)}

@@ -135,3 +135,105 @@ def test_a_graphed_attempt_must_show_that_it_trained():
     assert "no replays" in bench.graphed_line_refused(json.dumps(bad))
     bad = json.loads(json.dumps(ok)); bad["exchange"]["graphed_sub_steps"]["refused"] = "RuntimeError: x"
     assert "no replays" in bench.graphed_line_refused(json.dumps(bad))
+
+
+# ---------------------------------------------------------------------------------- the default N-GPU run: both regimes, one line
+def _leg_line(mode, n_gpus, graphed=True):
+    """What a leg's rank 0 prints: the compact line of a canned record in that mode."""
+    import bench
+    full = _canned(n_gpus)
+    full.update(mode=mode, scaling="strong" if mode == "partition" else "weak",
+                value=9.0e8 if mode == "partition" else 3.6e9, ms_per_step=4.4 if mode == "partition" else 8.9)
+    full["config"]["parallelism"] = (f"np{n_gpus}" if mode == "partition" else f"dp{n_gpus}")
+    if mode == "replicas":
+        full["exchange"] = {"form": "flat gradient all-reduce per sub-step", "exchanges_per_step": 2, "bucket_bytes_ggd": 1.8e6,
+                            "bucket_bytes_kge": 3.25e7, "wire_bytes_sent_per_step": 6.0e7, "allreduce_alone_ms_ggd": 0.05,
+                            "allreduce_alone_ms_kge": 0.4}
+    else:
+        full["exchange"]["form"] = "graphed sub-steps (hipGraph replays)" if graphed else "eager step"
+        if not graphed:
+            full["exchange"]["graphed_sub_steps"] = None
+    return bench.compact_line(full, "bench_detail.json")
+
+
+class _Args:
+    gpus, mode, detail = 8, "auto", "/tmp/bench_detail.json"
+
+
+def _launch(monkeypatch, capsys, script):
+    """bench.launch_ranks with ``_run_ranks`` replaced by ``script(extra_env, argv) -> (stdout, codes)``; -> (exit code,
+    the calls made, stdout lines)."""
+    import bench
+    calls = []
+
+    def fake(args, extra_env, limit_s, setup_limit_s=None, argv=()):
+        calls.append({"env": dict(extra_env), "argv": list(argv), "limit": limit_s})
+        out, codes = script(dict(extra_env), list(argv))
+        return out, codes, ""
+    monkeypatch.setattr(bench, "_run_ranks", fake)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    for key in ("BKG_BENCH_BACKEND", "BKG_BENCH_PARTITION_GRAPH", "BKG_DIRECT_ALL_TO_ALL", "BKG_BENCH_ONE_DEVICE"):
+        monkeypatch.delenv(key, raising=False)
+    with pytest.raises(SystemExit) as stop:
+        bench.launch_ranks(_Args())
+    return stop.value.code, calls, [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+
+
+def test_the_default_n_gpu_run_reports_both_regimes_on_one_line(monkeypatch, capsys):
+    """``--mode auto`` over N GPUs = the replicas leg, then the node-partitioned leg, ONE line: headline the
+    partition (BASELINE configs[3], strong scaling), ``replicas`` beside it with its own value / scaling."""
+    def script(env, argv):
+        mode = argv[argv.index("--mode") + 1]
+        return "RCCL banner\n" + _leg_line(mode, 8) + "\n", [0] * 8
+    code, calls, lines = _launch(monkeypatch, capsys, script)
+    assert code == 0 and len(lines) == 1
+    line = _check(lines[0], 8)
+    assert line["mode"] == "partition" and line["scaling"] == "strong" and line["config"]["parallelism"] == "np8"
+    rep = line["replicas"]
+    assert rep["mode"] == "replicas" and rep["scaling"] == "weak" and rep["value"] == pytest.approx(3.6e9)
+    assert rep["ms_per_step"] == pytest.approx(8.9) and rep["parallelism"] == "dp8" and rep["exchange"]["bucket_bytes_kge"] > 0
+    assert [a["ok"] for a in line["attempts"]] == [True]
+    # the replicas leg first (a detail file of its own), then the graphed partition attempt with the in-place exchanges
+    assert calls[0]["argv"][:2] == ["--mode", "replicas"] and calls[0]["argv"][3].endswith("bench_detail_replicas.json")
+    assert calls[1]["env"] == {"BKG_DIRECT_ALL_TO_ALL": "1", "BKG_BENCH_PARTITION_GRAPH": "1"} and calls[1]["limit"] == 75.0
+    assert all(c["limit"] is not None for c in calls)                 # every attempt is time-fenced
+
+
+def test_the_partition_ladder_ends_on_the_packed_exchanges(monkeypatch, capsys):
+    """Graphed attempt refused (its check losses did not fall), eager attempt with the in-place all-to-all dies, the packed
+    ``all_to_all_single`` form (the library's default) runs: its line is the headline and ``attempts`` says what happened."""
+    def script(env, argv):
+        mode = argv[argv.index("--mode") + 1]
+        if mode == "replicas":
+            return _leg_line(mode, 8) + "\n", [0] * 8
+        if env.get("BKG_BENCH_PARTITION_GRAPH") == "1":
+            bad = json.loads(_leg_line(mode, 8))
+            bad["check_loss_after"] = bad["check_loss"]
+            return json.dumps(bad) + "\n", [0] * 8
+        if env.get("BKG_DIRECT_ALL_TO_ALL") == "1":
+            return "", [-9] * 8
+        return _leg_line(mode, 8, graphed=False) + "\n", [0] * 8
+    code, calls, lines = _launch(monkeypatch, capsys, script)
+    assert code == 0 and len(lines) == 1
+    line = _check(lines[0], 8)
+    assert line["mode"] == "partition" and line["exchange"]["form"] == "eager step"
+    assert [a["ok"] for a in line["attempts"]] == [False, False, True]
+    assert "did not fall" in line["attempts"][0]["why_not"] and "packed" in line["attempts"][2]["form"]
+    assert calls[-1]["env"] == {"BKG_BENCH_PARTITION_GRAPH": "0", "BKG_DIRECT_ALL_TO_ALL": "0"}
+
+
+def test_without_a_partition_line_the_replicas_leg_is_the_headline(monkeypatch, capsys):
+    def script(env, argv):
+        mode = argv[argv.index("--mode") + 1]
+        return (_leg_line(mode, 8) + "\n", [0] * 8) if mode == "replicas" else ("", [1] + [-9] * 7)
+    code, calls, lines = _launch(monkeypatch, capsys, script)
+    assert code == 0 and len(lines) == 1
+    line = _check(lines[0], 8)
+    assert line["mode"] == "replicas" and line["scaling"] == "weak"
+    assert "error" in line["partition"] and len(line["partition"]["attempts"]) == 3
+    assert not any(a["ok"] for a in line["partition"]["attempts"])
+
+
+def test_no_leg_at_all_is_a_failure(monkeypatch, capsys):
+    code, calls, lines = _launch(monkeypatch, capsys, lambda env, argv: ("", [1] * 8))
+    assert code != 0 and not lines

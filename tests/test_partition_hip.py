@@ -323,11 +323,11 @@ def test_collectives_of_the_partitioned_step_over_a_one_rank_rccl_group(mode):
 @pytest.mark.parametrize("keep_outer_ranks,mode", [(False, "partition"), (True, "partition"), (False, "auto")])
 def test_bench_under_torch_distributed_run(keep_outer_ranks, mode):
     """The other form the driver may use: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
-    127.0.0.1 --master-port P bench.py --gpus 2 ...``.  ``--mode auto`` (round 5: replicas, one graph per rank, weak
-    scaling) runs in the outer launcher's own processes.  ``--mode partition``: the outer launcher's rank 0 becomes
-    bench.py's own launcher (graphed sub-steps first over RCCL, eager fallback; here: gloo on the one GPU) and the other
-    worker leaves; ``BKG_BENCH_OUTER_RANKS=1`` keeps the outer launcher's processes as the ranks.  Every way: exit code 0,
-    ONE JSON line."""
+    127.0.0.1 --master-port P bench.py --gpus 2 ...``.  The outer launcher's rank 0 becomes bench.py's own launcher and the
+    other worker leaves: ``--mode partition`` = the node-partitioned step (graphed sub-steps first over RCCL, eager
+    fallback; here: gloo on the one GPU); ``--mode auto`` (round 6) = BOTH regimes on fresh ranks, one line: headline the
+    partition, ``replicas`` (one graph per rank, weak scaling) beside it.  ``BKG_BENCH_OUTER_RANKS=1`` keeps the outer
+    launcher's processes as the ranks.  Every way: exit code 0, ONE JSON line."""
     import json
     import socket
     import subprocess
@@ -350,13 +350,14 @@ def test_bench_under_torch_distributed_run(keep_outer_ranks, mode):
     assert len(lines) == 1, out.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo" and line["value"] > 0
-    if mode == "partition":
-        assert line["scaling"] == "strong" and line["exchange"] is not None and line["mode"] == "partition"
-    else:
-        assert line["scaling"] == "weak" and line["mode"] == "replicas" and line["config"]["parallelism"] == "dp2"
-        ex = line["exchange"]                # the regime's only wire traffic: the two flat gradient buckets
+    assert line["scaling"] == "strong" and line["exchange"] is not None and line["mode"] == "partition"
+    if mode == "auto":
+        rep = line["replicas"]
+        assert rep["scaling"] == "weak" and rep["mode"] == "replicas" and rep["parallelism"] == "dp2" and rep["value"] > 0
+        ex = rep["exchange"]                 # the regime's only wire traffic: the two flat gradient buckets
         assert ex["exchanges_per_step"] == 2 and ex["bucket_bytes_kge"] > ex["bucket_bytes_ggd"] > 0
         assert ex["allreduce_alone_ms_kge"] > 0 and ex["wire_bytes_sent_per_step"] == ex["bucket_bytes_ggd"] + ex["bucket_bytes_kge"]
+        assert [a["ok"] for a in line["attempts"]] == [True]
 
 
 def test_bench_starts_its_own_ranks():
@@ -372,7 +373,7 @@ def test_bench_starts_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(BKG_BENCH_ONE_DEVICE="1", BKG_BENCH_BACKEND="gloo")
     lines = {}
-    for mode in ("auto", "partition"):
+    for mode in ("auto", "partition", "replicas"):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                               "--no-extras", "--no-cpu-baseline", "--nodes", "20000", "--edges", "300000", "--mode", mode],
                              env=env, capture_output=True, text=True, timeout=900)
@@ -382,10 +383,15 @@ def test_bench_starts_its_own_ranks():
         lines[mode] = json.loads(got[0])
         assert lines[mode]["n_gpus"] == 2 and lines[mode]["ranks"] == 2 and lines[mode]["backend"] == "gloo"
         assert lines[mode]["value"] > 0
-    # the default over N GPUs (round 5): one graph per rank, gradient all-reduce only -- the reference's DDP regime
-    assert lines["auto"]["mode"] == "replicas" and lines["auto"]["scaling"] == "weak"
-    assert lines["auto"]["config"]["parallelism"] == "dp2"
+    # the default over N GPUs (round 6): both regimes on one line -- headline the node partition (BASELINE configs[3], strong
+    # scaling), beside it the replicas (one graph per rank, gradient all-reduce only: the reference's DDP regime, weak)
+    assert lines["auto"]["mode"] == "partition" and lines["auto"]["scaling"] == "strong"
+    assert lines["auto"]["config"]["parallelism"] == "np2"
+    rep = lines["auto"]["replicas"]
+    assert rep["mode"] == "replicas" and rep["scaling"] == "weak" and rep["parallelism"] == "dp2" and rep["value"] > 0
     assert lines["partition"]["scaling"] == "strong" and lines["partition"]["config"]["parallelism"] == "np2"
+    assert lines["replicas"]["scaling"] == "weak" and lines["replicas"]["config"]["parallelism"] == "dp2"
+    assert "replicas" not in lines["partition"] and "replicas" not in lines["replicas"]
 
 
 def test_bench_ends_the_job_when_a_rank_dies():
