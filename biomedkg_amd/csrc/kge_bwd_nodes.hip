@@ -847,12 +847,28 @@ extern "C" int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t 
 // partial slot}; batches = {first entry, count | first << 8 | last << 9, relation + n_rel * role, record row}; the batches
 // of an item hold <= bkg_kge_onepass_batch(d, z_is_bf16) entries of one run each.  split: the row table the items were
 // cut by (its long rows' partial slots are added by the fix-up launch); dz is written, not added to.
+// lanes per row as BKG_PIECE_DISPATCH_(d / epl, KO_L32, 64) picks them; 0: a width the walk has no instance for
+static int onepass_lanes_per_row(int32_t d, int32_t z_is_bf16) {
+  const int epl = z_is_bf16 ? 8 : 4;
+  if (d <= 0 || d % epl) return 0;
+  switch (d / epl) {
+    case 2: return 2;   case 4: return 4;   case 6: return 2;   case 8: return 8;    case 12: return 4;   case 16: return 16;
+    case 24: return 8;  case 32: return KO_L32;                 case 64: return 64;  case 96: return 32;
+    case 128: case 192: return 64;
+    default: return 0;
+  }
+}
 extern "C" int32_t bkg_kge_onepass_batch(int32_t d, int32_t z_is_bf16) {
-  const int epl = z_is_bf16 ? 8 : 4, pieces = d / epl;
-  int lpr = pieces;                                   // lanes per row as BKG_PIECE_DISPATCH_(.., KS_L32, 64) picks them
-  switch (pieces) { case 6: lpr = 2; break; case 12: lpr = 4; break; case 24: lpr = 8; break; case 32: lpr = KO_L32; break;
-                    case 64: lpr = 64; break; case 96: lpr = 32; break; case 128: case 192: lpr = 64; break; default: break; }
-  return KO_U * (64 / lpr);
+  const int lpr = onepass_lanes_per_row(d, z_is_bf16);
+  return lpr ? KO_U * (64 / lpr) : 0;                 // 0: unsupported width (the caller keeps the two-pass form)
+}
+// Dynamic LDS of one workgroup of the walk: the relation table + every wave's scratch ((lane groups - 1) rows of d floats,
+// four waves); 0 for a width without an instance.  The caller takes the one-pass form only when this fits 64 KB (ADVICE
+// r05: narrow tables have many lane groups -- d = 64 bf16: 28 scratch rows -- so n_rel * d * 4 alone does not decide).
+extern "C" int64_t bkg_kge_onepass_smem_bytes(int32_t d, int32_t z_is_bf16, int64_t n_rel) {
+  const int lpr = onepass_lanes_per_row(d, z_is_bf16);
+  if (!lpr || n_rel <= 0) return 0;
+  return ((int64_t)n_rel + 4 * (int64_t)std::max(64 / lpr - 1, 1)) * d * 4;
 }
 #ifndef KO_BLOCKS
 #define KO_BLOCKS KN_PERSIST_BLOCKS
@@ -871,14 +887,18 @@ extern "C" int bkg_kge_onepass_f32(const void* z, int32_t z_is_bf16, int64_t ldz
   BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) && (ldr % 4 == 0) &&
               ((uintptr_t)dz % 16 == 0) && (lddz % 4 == 0) && ((uintptr_t)partials % 16 == 0) && ((uintptr_t)records % 16 == 0) &&
               ((uintptr_t)batches % 16 == 0) && ((uintptr_t)items % 16 == 0), "bkg_kge_onepass_f32: alignment");
-  BKG_ARG(n_rel * (int64_t)d * 4 <= 65536, "bkg_kge_onepass_f32: the relation table must fit 64 KB of LDS");
+  {
+    const int64_t smem_need = bkg_kge_onepass_smem_bytes(d, z_is_bf16, n_rel);
+    BKG_ARG(smem_need > 0 && smem_need <= 65536,
+            "bkg_kge_onepass_f32: the relation table + the waves' scratch rows must fit 64 KB of LDS (bkg_kge_onepass_smem_bytes)");
+  }
   if (n_nodes == 0 || n_items == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const unsigned blocks = (unsigned)bkg_kge_onepass_blocks(n_items);
 #define KO_LAUNCH(TT)                                                                                                  \
   {                                                                                                                    \
     /* the relation table + every wave's scratch: (lane groups - 1) rows of d floats */                                \
-    const size_t smem = ((size_t)n_rel + 4 * (size_t)std::max(64 / LPR - 1, 1)) * d * 4;                               \
+    const size_t smem = ((size_t)n_rel + 4 * (size_t)std::max(64 / LPR - 1, 1)) * d * 4; /* = bkg_kge_onepass_smem_bytes */ \
     hipLaunchKernelGGL((kge_onepass_kernel<TT, LPR, VPL>), dim3(blocks), dim3(256), smem, s, (const TT*)z, ldz, rel_emb, ldr, \
                        (int)n_rel, other, tid, (const int4*)batches, (const int4*)items, (int)n_items, label, inv_total, score, \
                        loss_part, records, dz, lddz, partials);                                                        \

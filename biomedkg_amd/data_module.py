@@ -434,5 +434,13 @@ class DPIModule(_TripletModule):
         self.edge_map_index = self.dpi.edge_map_index
         d = self.dpi.data
         ei, et = to_undirected(d.edge_index, d.edge_type, num_nodes=d.num_nodes)
+        # PyG's ToUndirected SUMS the edge_type of merged duplicate pairs (reduce="add", what the reference runs): on the
+        # reference's one-relation DPI table every id stays 0, but a multi-relation table could come out with ids >=
+        # num_edge_types, which PyG's RGCNConv / the decoder's rel_emb lookup answer with an IndexError -- and the device
+        # kernels, which index rel_emb / rel_ptr unchecked, with an out-of-bounds read.  Same contract, raised here.
+        if et.numel() and int(et.max()) >= int(d.num_edge_types):
+            raise IndexError(f"DPIModule: ToUndirected(reduce='add') merged duplicate pairs into relation id {int(et.max())} "
+                             f">= num_edge_types = {int(d.num_edge_types)} (a pair listed under several relations; "
+                             "triplets.to_undirected(..., reduce='first') keeps valid ids)")
         self.data = GraphData(d.x, ei, et, d.node_type, d.num_edge_types)
         self._split(stage)

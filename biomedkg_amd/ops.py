@@ -210,7 +210,11 @@ class GateLink:
     epilogue of the product that makes that gradient (``gemm_gated``) and leave the lower layer's bias gradient here;
     the lower layer's backward then finds ``applied`` set and skips its own gate pass over the table.  The lower
     layer's forward fills ``relu`` / ``scale``; a fresh link per forward pass; the activation must have no other
-    reader than the layer above (the stacks of ``model/encoder.py`` hand it to nothing else)."""
+    reader than the layer above: the links are made and held by ``_Stack._run`` / ``forward_views`` only, which hand a
+    hidden activation to nothing but the next layer (a second reader's gradient contribution would arrive un-gated).
+    ``applied`` is per backward pass: the upper layer sets it in the backward in which it gated, the lower layer clears it
+    when it consumes the hand-over -- a later backward over the same graph in which the upper layer takes its plain
+    branch finds it clear and the lower layer gates for itself."""
     __slots__ = ("relu", "scale", "applied", "db")
 
     def __init__(self):
@@ -1058,7 +1062,7 @@ class _GcnConvViews(torch.autograd.Function):
         cs = None
         lo = ctx.link_out
         if lo is not None and lo.applied:      # the layer above gated its product's result and summed its columns
-            cs, lo.db = lo.db, None
+            cs, lo.db, lo.applied = lo.db, None, False     # consumed: valid for THIS backward only
             if dout.dtype != torch.bfloat16:   # (never gated twice, whatever autograd did to the tensor on its way here)
                 dout = to_bf16(dout)
         elif ctx.relu or not ctx.gated:
@@ -1240,6 +1244,7 @@ class _RgcnConv(torch.autograd.Function):
         lo = ctx.link_out
         if lo is not None and lo.applied:
             # the layer above wrote dOut through this layer's gate (the epilogue of its last aggregation): a bf16 table
+            lo.applied = False                 # consumed: valid for THIS backward only
             if not (bf16_storage() and _bf16_ok(d_out) and n >= 4096 and _bf16_operand_ok(n, d_in, d_out)):
                 dout = _as_f32(dout)
         elif (bf16_storage() and (ctx.relu or not ctx.gated) and _bf16_ok(d_out) and n >= 4096
@@ -1847,7 +1852,8 @@ class _KgeBceLoss(torch.autograd.Function):
         # is ready when the forward returns, the backward adds the negatives' part to it
         onepass = (KGE_ONEPASS and owned is None and not padded and comm is None and kind == KGE_DISTMULT
                    and bool(ctx.needs_input_grad[0]) and pos_ei.size(1) >= _SORTED_MIN_TRIPLETS and 2 * pos_ei.size(1) < (1 << 31)
-                   and n < (1 << 31) and (r + 12) * d * 4 <= 65536 and zt.stride(0) % (8 if zt_bf16 else 4) == 0
+                   and n < (1 << 31) and 0 < L.lib().bkg_kge_onepass_smem_bytes(d, zt_bf16, r) <= 65536
+                   and zt.stride(0) % (8 if zt_bf16 else 4) == 0
                    and rel_emb.stride(0) % 4 == 0 and rel_emb.data_ptr() % 16 == 0 and not torch.cuda.is_current_stream_capturing()
                    and onepass_stable(pos_ei, pos_et))
         pos_one = None

@@ -267,9 +267,13 @@ int bkg_kge_bwd_stream_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_
  * items [n_items] int32x4 {node, first batch, end batch, partial slot or -1}; batches int32x4 {first entry, count | first_of_run
  * << 8 | last_of_run << 9, relation + n_rel * role (0: the node is the head), record row}; a batch holds at most
  * bkg_kge_onepass_batch(d, z_is_bf16) entries of ONE run.  loss_part: 4 * bkg_kge_onepass_blocks(n_items) unscaled partial sums;
- * dz is written (not added to); split: the row table the items were cut by. */
+ * dz is written (not added to); split: the row table the items were cut by.
+ * bkg_kge_onepass_batch returns 0 for a width the walk has no instance for; bkg_kge_onepass_smem_bytes = the dynamic LDS one
+ * workgroup asks for (the relation table + every wave's scratch rows; 0: unsupported width) -- the walk is taken only when it
+ * fits 64 KB, else the caller keeps the two-pass form (scorer + node-side gradient). */
 int32_t bkg_kge_onepass_batch(int32_t d, int32_t z_is_bf16);
 int32_t bkg_kge_onepass_blocks(int64_t n_items);
+int64_t bkg_kge_onepass_smem_bytes(int32_t d, int32_t z_is_bf16, int64_t n_rel);
 int bkg_kge_onepass_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n_nodes, int32_t d, const float* rel_emb,
                         int64_t ldr, int64_t n_rel, const int32_t* other, const int32_t* tid, const void* batches,
                         const void* items, int64_t n_items, float label, float inv_total, float* score /* nullable */,

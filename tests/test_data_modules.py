@@ -81,6 +81,23 @@ def test_dpi_module_matches_the_reference(golden, tables):
     assert int(dm.data.edge_type.max()) == 0                                                    # one relation: sums stay 0
 
 
+def test_dpi_module_refuses_relation_ids_the_merge_pushed_out_of_range(tmp_path):
+    """ToUndirected(reduce="add") sums ``edge_type`` over merged duplicate pairs.  On a table with TWO relations
+    in which a pair is listed TWICE under relation 1 (TripletBase keeps duplicate rows) the merged id is 2 = num_edge_types:
+    PyG's layers would raise an IndexError on it; the device kernels index their relation tables unchecked, so the module
+    raises up front."""
+    import pandas as pd
+    from biomedkg_amd.data_module import DPIModule
+    rows = [("drug", f"d{i}", "binds", "gene/protein", f"p{i % 5}") for i in range(12)]
+    rows += [("drug", "d0", "inhibits", "gene/protein", "p1"), ("drug", "d0", "inhibits", "gene/protein", "p1")]
+    path = tmp_path / "dpi2.csv"
+    pd.DataFrame(rows, columns=["x_type", "x_name", "relation", "y_type", "y_name"]).to_csv(path, index=False)
+    torch.manual_seed(0)
+    dm = DPIModule(data_dir=str(path), embed_dim=8, batch_size=4, val_ratio=0.2, test_ratio=0.2, node_init_method="random")
+    with pytest.raises(IndexError, match="num_edge_types"):
+        dm.setup(stage="split")
+
+
 def test_missing_tables_are_errors_that_say_where_the_file_goes(tmp_path):
     from biomedkg_amd.data_module import DPIModule, PrimeKGModule
     with pytest.raises(FileNotFoundError, match="kg.csv"):

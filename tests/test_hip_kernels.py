@@ -327,3 +327,48 @@ def test_kge_positives_in_one_pass_match_the_two_pass_form(prec, n, d, r, hubs, 
     finally:
         ops.L.call = call
         ops.set_matmul_precision(old_prec)
+
+
+@pytest.mark.gpu
+def test_one_pass_walk_gives_way_when_its_lds_does_not_fit():
+    """the walk's dynamic LDS is the relation table PLUS every wave's scratch rows (narrow tables have many lane
+    groups: d = 64 bf16 -> 28 scratch rows).  240 relations x 64 columns pass the old ``n_rel * d * 4 <= 64 KB`` check and
+    ask for 68.6 KB: ``bkg_kge_onepass_smem_bytes`` says so, ops keeps the two-pass form (same loss / gradients as with the
+    walk switched off), and the C entry refuses the call with a message instead of a failed launch."""
+    from biomedkg_amd import ops, _lib as L
+    lib = L.lib()
+    assert lib.bkg_kge_onepass_smem_bytes(64, 1, 240) == (240 + 4 * 7) * 64 * 4 > 65536 >= 240 * 64 * 4
+    assert lib.bkg_kge_onepass_smem_bytes(256, 1, 30) == (30 + 4 * 3) * 256 * 4         # the bench width: 16 lanes per row
+    assert lib.bkg_kge_onepass_smem_bytes(40, 1, 30) == 0 and lib.bkg_kge_onepass_batch(40, 1) == 0   # no instance: 5 pieces
+    dev, n, d, r, t = "cuda", 30000, 64, 240, 1_100_000
+    old_prec = ops.get_matmul_precision()
+    launches, call = [], ops.L.call
+    try:
+        ops.set_matmul_precision("bf16")
+        ops.L.call = lambda name, *a: (launches.append(name), call(name, *a))[1]
+        g = torch.Generator(device=dev).manual_seed(5)
+        pe = torch.randint(0, n, (2, t), device=dev, generator=g)
+        pt = torch.randint(0, r, (t,), device=dev, generator=g)
+        ne = torch.randint(0, n, (2, t), device=dev, generator=g)
+        nt = torch.randint(0, r, (t,), device=dev, generator=g).sort().values
+        z0, rel0 = torch.randn(n, d, device=dev) * 0.3, torch.randn(r, d, device=dev) * 0.3
+        got = []
+        for _ in range(3):                     # (the pair of tensors is "stable" from its second sighting on)
+            z, rel = z0.clone().requires_grad_(), rel0.clone().requires_grad_()
+            loss = ops.kge_bce_loss(z, rel, pe, pt, ne, nt, ops.KGE_DISTMULT, reg=1e-2)[0]
+            loss.backward()
+            got.append((float(loss.detach()), z.grad.clone(), rel.grad.clone()))
+        assert launches.count("bkg_kge_onepass_f32") == 0
+        assert got[0][0] == got[2][0] and torch.equal(got[0][1], got[2][1])
+        # the entry point itself: an argument error with a message, not a launch failure
+        zt = ops.to_bf16(z0)
+        with pytest.raises(L.HipLibraryError, match="64 KB of LDS"):
+            one = torch.zeros(16, dtype=torch.int32, device=dev)
+            f = torch.zeros(4 * 64 * d, device=dev)
+            L.call("bkg_kge_onepass_f32", L.ptr(zt), 1, zt.stride(0), n, d, L.ptr(rel0), rel0.stride(0), r, L.ptr(one),
+                   L.ptr(one), L.ptr(one), L.ptr(one), 1, 1.0, 1.0, None, L.ptr(f), L.ptr(f), L.ptr(f), d,
+                   L.ptr(one), L.ptr(f), L.stream())
+    finally:
+        ops.L.call = call
+        ops.set_matmul_precision(old_prec)
+
