@@ -269,7 +269,7 @@ _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "ranks", "backend", "mode", "s
              "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 _SIDE_KEYS = ("triplets_per_sec_kge_step", "edges_per_sec_gcl_step", "ms_per_step_median", "ms_per_step_max", "ms_gcl_step",
               "ms_kge_step", "ms_per_step_fp32", "ms_per_step_literal_ggd_last_layer", "ms_per_step_fresh_first_layer_means",
-              "ms_per_step_shuffled_neg_types",
+              "ms_per_step_shuffled_neg_types", "ms_per_step_all_literal",
               "ms_kge_step_neg10", "triplets_per_sec_kge_step_neg10")
 
 
@@ -348,7 +348,7 @@ def compact_line(out, detail_path=None):
     line = _strict(line)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     for drop in ("check_loss_after", "check_loss", "partition_bound", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_shuffled_neg_types", "ms_per_step_literal_ggd_last_layer", "ms_per_step_fresh_first_layer_means",
-                 "ms_per_step_fp32", "exchange.graphed_sub_steps", "cpu_baseline.threads1", "cpu_baseline.full_size"):
+                 "ms_per_step_all_literal", "ms_per_step_fp32", "exchange.graphed_sub_steps", "cpu_baseline.threads1", "cpu_baseline.full_size"):
         if len(text) < LINE_LIMIT - 1024:
             break
         head, _, leaf = drop.partition(".")
@@ -1682,7 +1682,7 @@ def main():
         except Exception:                      # noqa: BLE001  (a side figure: never costs the headline line)
             torch.cuda.synchronize()
 
-    ms_linear_head = ms_literal_last = ms_fresh_means = None
+    ms_linear_head = ms_literal_last = ms_fresh_means = ms_all_literal = None
     if world == 1 and not args.no_extras and args.precision == "bf16":
         def timed5():           # (GGD's augmentation coin makes the steps of a short run differ: as many steps as the headline)
             for _ in range(3):
@@ -1710,6 +1710,18 @@ def main():
             ops.rowsum_linear_ok = lambda *a, **k: False
             try:
                 ms_linear_head = timed5()
+                # ... and with EVERY switchable identity / kept constant of the bf16 mode off at once: the layer as a layer, the
+                # head as a Linear + row sum, the first R-GCN layer's segment means recomputed every step, the negatives'
+                # relation ids as repeat(k)[randperm] -- the reference's expressions literally, on the same kernels (what stays
+                # is the graph's own bookkeeping: CSRs, segments, incidence lists, built once for a graph that stays)
+                from biomedkg_amd import kge_module as _km
+                was_grouped, _km.GROUPED_NEG_TYPES = _km.GROUPED_NEG_TYPES, False
+                ops.RGCN_KEEP_SEGMENT_MEANS = False
+                try:
+                    ms_all_literal = timed5()
+                finally:
+                    _km.GROUPED_NEG_TYPES = was_grouped
+                    ops.RGCN_KEEP_SEGMENT_MEANS = True
             finally:
                 ops.rowsum_linear_ok = ok_fn
         finally:
@@ -1826,7 +1838,7 @@ def main():
                                      "ids -- the reference's edge_type.repeat(k)[randperm] -- are delivered grouped by relation; "
                                      "the negatives they are paired with come out of the sampler in exchangeable order, so the "
                                      "typed negatives have the same distribution (ms_per_step_shuffled_neg_types times the "
-                                     "literal form)"},
+                                     "literal form).  ms_per_step_all_literal: every one of these switched off at once"},
             "triplets_per_sec_kge_step": (total_edges + (n_neg if strong or world == 1 else world * n_neg)) / (ms_k * 1e-3),
             "edges_per_sec_gcl_step": total_edges / (ms_g * 1e-3),
             "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_max": per_step[-1],
@@ -1835,6 +1847,7 @@ def main():
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
             "ms_per_step_literal_ggd_last_layer": ms_literal_last, "ms_per_step_fresh_first_layer_means": ms_fresh_means,
             "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_shuffled_neg_types": ms_shuffled_types,
+            "ms_per_step_all_literal": ms_all_literal,
             "ms_per_step_fresh_structures": ms_fresh,
             "kge_step_neg10": neg10,
             "ms_kge_step_neg10": (neg10 or {}).get("ms_kge_step"),

@@ -184,6 +184,29 @@ def test_entry_points_run_on_the_tables_with_the_reference_command_line(tables, 
 
 
 @pytest.mark.gpu
+def test_evaluation_entry_points_load_the_checkpoints_the_training_ones_write(tables):
+    """The reference's ``test_kge.py`` / ``test_dpi.py`` (evaluation entry points, not unit tests; test_kge.py:9-44): a
+    checkpoint written by ``train_kge.py`` / ``train_dpi.py`` is loaded with ``KGEModule.load_from_checkpoint`` (no
+    arguments: the hyper-parameters travel in the file), ``neg_ratio`` and the relation names are set, and ``trainer.test``
+    over the GraphSAINT test loader returns the bootstrapped AUROC / AP / F1 and the per-relation precision."""
+    import test_dpi  # noqa: F401  (importable: it only forwards to test_kge.main)
+    import test_kge
+    import train_kge
+    small = ["data.embed_dim=32", "model.in_dim=32", "model.hidden_dim=16", "model.out_dim=16", "epochs=1", "val_every_epoch=1",
+             f"ckpt_dir={tables / 'ckpt'}", "devices=[0]"]
+    for name, data_dir in (("kge", tables / "primekg"), ("dpi", tables / "dpi.csv")):
+        train_kge.main([f"data.data_dir={data_dir}", "neg_ratio=2"] + small, config_name=name)
+        ckpts = sorted(os.path.join(d, f) for d, _, fs in os.walk(tables / "ckpt" / name) for f in fs if f.endswith(".ckpt"))
+        assert ckpts
+        out = test_kge.main([f"data.data_dir={data_dir}", "neg_ratio=3", f"pretrained_path={ckpts[-1]}",
+                             "data.embed_dim=32", "devices=[0]"], config_name=name)
+        assert out and any(k.startswith("test_") for k in out[0]), out
+        assert all(v == v for v in out[0].values())                      # no NaN
+    with pytest.raises(FileNotFoundError, match="pretrained_path"):
+        test_kge.main([f"data.data_dir={tables / 'primekg'}", "pretrained_path=nope.ckpt", "data.embed_dim=32"])
+
+
+@pytest.mark.gpu
 def test_loaders_of_the_real_module_hand_out_device_batches(tables):
     from biomedkg_amd.data_module import PrimeKGModule
     torch.manual_seed(3)
