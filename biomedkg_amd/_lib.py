@@ -75,7 +75,11 @@ SIGNATURES = {
     "bkg_kge_onepass_batch": (I32, [I32, I32]),
     "bkg_kge_onepass_blocks": (I32, [I64]),
     "bkg_kge_onepass_smem_bytes": (I64, [I32, I32, I64]),
-    "bkg_kge_onepass_f32": (I32, [P, I32, I64, I64, I32, P, I64, I64, P, P, P, P, I64, F32, F32, P, P, P, P, I64, P, P, P]),
+    "bkg_kge_role_incidence": (I32, [P, P, P, I64, I64, P, P, P, P, P, P, I64, P]),
+    "bkg_kge_onepass_mx_ok": (I32, [I32, I32, I64]),
+    "bkg_kge_onepass_mx_blocks": (I32, [I64]),
+    "bkg_kge_onepass_mx_f32": (I32, [P, I64, I64, P, I64, I64, P, P, P, I64, F32, F32, P, P, P, I64, P, I32, P]),
+    "bkg_kge_onepass_f32": (I32, [P, I32, I64, I64, I32, P, I64, I64, P, P, P, P, I64, F32, F32, P, P, P, P, I64, P, P, P, I64, P]),
     "bkg_kge_bwd_nodes_f32": (I32, [I32, P, I32, I64, I64, I32, P, P, P, I64, P, I64, I64, P, P, P, P, P, P, I64, P, P, I32, I64, P]),
     "bkg_kge_fused_chunk": (I32, []),
     "bkg_kge_fused_bce_waves": (I64, [I64, I32]),

@@ -99,6 +99,21 @@ __global__ __launch_bounds__(1024) void small_sort_kernel(const int64_t* __restr
 constexpr int SMALL_SORT_MAX = 8192;
 
 // out[s] = first position p in sorted[0..n) with sorted[p] >= s * stride   (s in [0, n_q))
+// The 2 T incidences cat(head, tail) of a triplet set as (key, payload) pairs for the (node, role)-sorted one-pass walk
+// (csrc/kge_onepass_mx.hip): key = 2 * node + role (role 0: the node is the head), payload = other endpoint | relation << 24.
+__global__ void role_incidence_keys_kernel(const int64_t* __restrict__ head, const int64_t* __restrict__ tail,
+                                           const int64_t* __restrict__ rel, int64_t T, uint32_t* __restrict__ keys,
+                                           uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * T) return;
+  const int role = i >= T;
+  const int64_t t = role ? i - T : i;
+  const int64_t h = head[t], tl = tail[t];
+  const uint32_t node = (uint32_t)(role ? tl : h), oth = (uint32_t)(role ? h : tl);
+  keys[i] = 2u * node + (uint32_t)role;
+  vals[i] = oth | ((uint32_t)rel[t] << 24);
+}
+
 __global__ void lower_bound_kernel(const uint32_t* __restrict__ sorted, int64_t n, int64_t n_q, uint32_t stride,
                                    int32_t* __restrict__ out) {
   int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,6 +449,33 @@ extern "C" int bkg_sort_edges_rowptr(const int64_t* lo, const int64_t* hi, int64
   BKG_ARG(n_queries >= 0 && rowptr, "bkg_sort_edges_rowptr: bad arguments");
   return sort_edges_impl(lo, hi, n_lo, n_hi, n, keys_tmp, iota_tmp, sorted_keys, perm, workspace, workspace_bytes, n_queries,
                          stride, rowptr, stream);
+}
+
+// (node, role)-sorted incidence lists of a triplet set for bkg_kge_onepass_mx_f32 (reference biomedkg/kge_module.py:121-128
+// through its autograd: the node-side sums run over these lists): packed [2 T] = the entries' (other endpoint | relation
+// << 24) in list order, rowptr2 [2 n_nodes + 1] = first entry of key 2 * node + role.  keys_tmp / vals_tmp / sorted_keys:
+// uint32 [2 T] scratch; workspace of bkg_sort_workspace_bytes(2 T).  Node ids < 2^24, relation ids < 256.  No host read.
+extern "C" int bkg_kge_role_incidence(const int64_t* head, const int64_t* tail, const int64_t* rel, int64_t T, int64_t n_nodes,
+                                      uint32_t* keys_tmp, uint32_t* vals_tmp, uint32_t* sorted_keys, int32_t* packed,
+                                      int32_t* rowptr2, void* workspace, int64_t workspace_bytes, void* stream) {
+  BKG_ARG(T >= 0 && n_nodes > 0 && n_nodes <= (1ll << 24) && 2 * T < (1ll << 31) && rowptr2,
+          "bkg_kge_role_incidence: node ids below 2^24, 2 T below 2^31");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = 2 * T, n_q = 2 * n_nodes + 1;
+  if (n == 0) {
+    fill_u32(rowptr2, 0u, n_q, s);
+    return check_launch("bkg_kge_role_incidence");
+  }
+  BKG_ARG(head && tail && rel && keys_tmp && vals_tmp && sorted_keys && packed && workspace, "bkg_kge_role_incidence: null buffer");
+  hipLaunchKernelGGL(role_incidence_keys_kernel, grid1(n), dim3(256), 0, s, head, tail, rel, T, keys_tmp, vals_tmp);
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < 2ull * (uint64_t)n_nodes) ++bits;
+  size_t bytes = (size_t)workspace_bytes;
+  hipError_t e = rocprim::radix_sort_pairs<SortConfig>(workspace, bytes, keys_tmp, sorted_keys, vals_tmp,
+                                                       reinterpret_cast<uint32_t*>(packed), (size_t)n, 0, bits, s);
+  if (e != hipSuccess) { set_error("bkg_kge_role_incidence: sort", e); return (int)e; }
+  hipLaunchKernelGGL(lower_bound_kernel, grid1(n_q), dim3(256), 0, s, sorted_keys, n, n_q, 1u, rowptr2);
+  return check_launch("bkg_kge_role_incidence");
 }
 
 extern "C" int bkg_lower_bound_u32(const uint32_t* sorted, int64_t n, int64_t n_queries, uint32_t stride,

@@ -124,8 +124,11 @@ class KGEModule(LightningModule):
         if last is None:
             return None                              # no fused training step has run yet
         z, pos_pred, neg_pred, inverse = last
-        if inverse is not None:
-            pos_pred = ops.scores_in_order(pos_pred, inverse)
+        if inverse is not None or isinstance(neg_pred, ops.LazyScores):
+            if inverse is not None:
+                pos_pred = ops.scores_in_order(pos_pred, inverse)
+            if isinstance(neg_pred, ops.LazyScores):      # (the negatives' one-pass walk writes no scores: computed on demand)
+                neg_pred = neg_pred()
             self._scores_of_last_step = (z, pos_pred, neg_pred, None)
         return z, pos_pred, neg_pred
 

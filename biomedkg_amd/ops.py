@@ -1423,6 +1423,9 @@ KGE_BWD_STREAMS = __import__("os").environ.get("BKG_KGE_BWD_STREAMS", "1") != "0
 KGE_LOSS_FINISH = __import__("os").environ.get("BKG_KGE_LOSS_FINISH", "1") != "0"     # 0: the loss tail as torch expressions
 KGE_ONEPASS = __import__("os").environ.get("BKG_KGE_ONEPASS", "1") != "0"            # 0: the positives through scorer + list walk too
 KGE_BWD_TAIL = __import__("os").environ.get("BKG_KGE_BWD_TAIL", "1") != "0"
+# the fresh NEGATIVES of a whole-graph DistMult step in ONE walk over (node, role)-sorted lists, d rel_emb on the matrix cores
+# (csrc/kge_onepass_mx.hip); 0: scorer + node-side list walk (the two-pass form)
+KGE_ONEPASS_MX = __import__("os").environ.get("BKG_KGE_ONEPASS_MX", "1") != "0"
 RGCN_KEEP_SEGMENT_MEANS = __import__("os").environ.get("BKG_RGCN_KEEP_SEGMENT_MEANS", "1") != "0"   # 0: recomputed every step           # 0: dz * gloss + the L2 term as a pass of its own
 
 
@@ -1625,7 +1628,7 @@ _SORTED_MIN_TRIPLETS = 1 << 20
 # how the positives' scores leave a call that ran in the sorted frame: put back in the caller's order by the op (default), or
 # left in frame order with the inverse permutation handed over beside them ("lazy": a training step stores the scores for
 # whoever may ask -- metrics, tests -- and pays the 4 M-float gather only then)
-_FRAME = {"lazy": False, "inverse": None}
+_FRAME = {"lazy": False, "inverse": None, "lazy_neg": None}
 
 
 def scores_in_order(scores, inverse):
@@ -1807,6 +1810,38 @@ def kge_prepare_structures(pos_edge_index, pos_edge_type, neg_edge_index, neg_ed
             incidence_of(ei, num_nodes)
 
 
+def role_incidence(edge_index, edge_type, num_nodes):
+    """-> (rowptr2 int32 [2 N + 1], packed int32 [2 T]): the incidences cat(head, tail) of a triplet set sorted by
+    (node, role) -- role 0: the node is the head -- each as (other endpoint | relation << 24): what the one-pass walk of the
+    negatives reads (csrc/graph.hip bkg_kge_role_incidence: one key-making launch, one radix sort of pairs, one lower bound;
+    no host read)."""
+    t, dev = edge_index.size(1), edge_index.device
+    ws_bytes = L.lib().bkg_sort_workspace_bytes(max(2 * t, 1))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    keys, vals, skeys, packed = (torch.empty(2 * t, dtype=torch.int32, device=dev) for _ in range(4))
+    rowptr2 = torch.empty(2 * num_nodes + 1, dtype=torch.int32, device=dev)
+    L.call("bkg_kge_role_incidence", L.ptr(edge_index[0]), L.ptr(edge_index[1]), L.ptr(edge_type), t, num_nodes, L.ptr(keys),
+           L.ptr(vals), L.ptr(skeys), L.ptr(packed), L.ptr(rowptr2), L.ptr(ws), ws_bytes, L.stream())
+    return rowptr2, packed
+
+
+class LazyScores:
+    """The negatives' scores of a training step whose one-pass walk did not write them: computed by the plain scorer from
+    the step's own table when somebody asks (``KGEModule._last_scores``)."""
+
+    def __init__(self, table, rel_emb, edge_index, edge_type, kind):
+        self.args = (table, rel_emb.detach(), edge_index, edge_type, kind)
+        self.value = None
+
+    def __call__(self):
+        if self.value is None:
+            table, rel_emb, ei, et, kind = self.args
+            with torch.no_grad():
+                self.value = kge_score(table.float() if table.dtype != torch.float32 else table, rel_emb, ei, et, kind)
+            self.args = None
+        return self.value
+
+
 _FINISH_SCRATCH = {}
 
 
@@ -1856,6 +1891,12 @@ class _KgeBceLoss(torch.autograd.Function):
                    and zt.stride(0) % (8 if zt_bf16 else 4) == 0
                    and rel_emb.stride(0) % 4 == 0 and rel_emb.data_ptr() % 16 == 0 and not torch.cuda.is_current_stream_capturing()
                    and onepass_stable(pos_ei, pos_et))
+        # ... and then the step's NEGATIVES too, in a walk of their own over (node, role)-sorted lists built this step (2 T row
+        # reads instead of the scorer's 2 T + the list walk's 2 T; d rel_emb as a one-hot product on the matrix cores).  Their
+        # scores are not written (a training step never reads them): ``LazyScores`` computes them if somebody asks
+        mx = (KGE_ONEPASS_MX and onepass and _FRAME["lazy"] and zt_bf16 and neg_ei.size(1) >= _SORTED_MIN_TRIPLETS
+              and 2 * neg_ei.size(1) < (1 << 31) and n <= (1 << 24) and r < 256 and zt.stride(0) % 8 == 0
+              and bool(L.lib().bkg_kge_onepass_mx_ok(d, 1, r)))
         pos_one = None
         if owned is None:
             if not padded and comm is None and not onepass:
@@ -1864,14 +1905,15 @@ class _KgeBceLoss(torch.autograd.Function):
                     pos_ei, pos_et = resort.index, resort.types
             sets = ((pos_ei, pos_et, 1.0, True, 0), (neg_ei, neg_et, 0.0, True, 1))
             if onepass:
-                sets = sets[1:]
+                sets = () if mx else sets[1:]
         else:
             po, ne = owned
             sets = ((po.own_index, po.own_type, 1.0, True, 0), (po.foreign_index, po.foreign_type, 1.0, False, 0),
                     (ne.own_index, ne.own_type, 0.0, True, 1), (ne.foreign_index, ne.foreign_type, 0.0, False, 1))
         t_all = sum(ei.size(1) for ei, _, _, _, _ in sets)
         if total is None:
-            total = sum(ei.size(1) for ei, _, _, counted, _ in sets if counted) + (pos_ei.size(1) if onepass else 0)
+            total = (sum(ei.size(1) for ei, _, _, counted, _ in sets if counted) + (pos_ei.size(1) if onepass else 0)
+                     + (neg_ei.size(1) if mx else 0))
         # packed {head, tail, rel, g} per triplet for the node-side backward (ids fit int32; one gather instead of four)
         pack = bool(ctx.needs_input_grad[0]) and n < (1 << 31) and r < (1 << 31)
         if padded and not pack:
@@ -1879,10 +1921,14 @@ class _KgeBceLoss(torch.autograd.Function):
         if owned is not None and ctx.needs_input_grad[0] and not pack:
             raise ValueError("both-owner scoring needs the packed gradient records (table rows and relations < 2^31)")
         n_waves = [L.lib().bkg_kge_fused_bce_waves(ei.size(1), r) if ei.size(1) else 0 for ei, _, _, _, _ in sets]
-        lists, one_parts = None, 0
+        lists, one_parts, mx_parts, mx_blocks = None, 0, 0, 0
         if onepass:
             lists = onepass_lists_of(pos_ei, pos_et, n, r, L.lib().bkg_kge_onepass_batch(d, zt_bf16))
             one_parts = 4 * L.lib().bkg_kge_onepass_blocks(lists.n_items)
+            if mx:
+                mx_blocks = L.lib().bkg_kge_onepass_mx_blocks(n)
+                mx_parts = 4 * mx_blocks
+                one_parts += mx_parts                    # (the negatives' walk takes the slots behind the positives')
         part = torch.empty(one_parts + sum(n_waves), dtype=torch.float32, device=dev)      # every wave of a launch writes its slot
         # the sets the loss counts take the first slots: ONE contiguous sum (the others' slots follow)
         n_counted = one_parts + sum(w for w, st in zip(n_waves, sets) if st[3])
@@ -1897,6 +1943,21 @@ class _KgeBceLoss(torch.autograd.Function):
         rec_all = new(t_all, 4, dtype=torch.int32, device=dev) if pack else None
         scores, grads, drel = [], [], None
         t0 = 0
+        dz_neg = None
+        if mx:
+            t_neg = neg_ei.size(1)
+            rowptr2, packed = role_incidence(neg_ei, neg_et, n)
+            dz_neg = torch.empty(n, d, dtype=torch.float32, device=dev)
+            drel_mx = torch.empty(mx_blocks, 32 * d, dtype=torch.float32, device=dev)
+            # algorithmic bytes: per incidence the other endpoint's row + its packed index; per node its own row, the
+            # gradient row and its two list bounds; the workgroups' partial sums of d rel_emb
+            with _Timed("kge_onepass_mx", 2 * t_neg * (d * zt.element_size() + 4) + n * (d * zt.element_size() + 4 * d + 8)
+                        + mx_blocks * 32 * d * 4, d=d, launches_per_call=1):
+                L.call("bkg_kge_onepass_mx_f32", L.ptr(zt), zt.stride(0), n, L.ptr(rel_emb), rel_emb.stride(0), r,
+                       L.ptr(rowptr2), L.ptr(packed), None, 2 * t_neg, 0.0, 1.0 / total, None,
+                       L.ptr(part[one_parts - mx_parts:one_parts]), L.ptr(dz_neg), dz_neg.stride(0), L.ptr(drel_mx),
+                       mx_blocks, L.stream())
+            drel = (drel_mx.sum(0).view(32, d)[:r] * (1.0 / total)).contiguous()
         if onepass:
             t_pos = pos_ei.size(1)
             s_pos = torch.empty(t_pos, dtype=torch.float32, device=dev)
@@ -1909,10 +1970,12 @@ class _KgeBceLoss(torch.autograd.Function):
                         + 2 * lists.n_records * 4 * d + lists.n_batches * 16, d=d, launches_per_call=1):
                 L.call("bkg_kge_onepass_f32", L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(rel_emb), rel_emb.stride(0), r,
                        L.ptr(lists.other), L.ptr(lists.tid), L.ptr(lists.batches), L.ptr(lists.items), lists.n_items, 1.0,
-                       1.0 / total, L.ptr(s_pos), L.ptr(part[:one_parts]), L.ptr(records), L.ptr(dz_pos), dz_pos.stride(0),
-                       L.sref(sp.c), L.ptr(sp.partials(d, dev)), L.stream())
+                       1.0 / total, L.ptr(s_pos), L.ptr(part[:one_parts - mx_parts]), L.ptr(records), L.ptr(dz_pos),
+                       dz_pos.stride(0), L.sref(sp.c), L.ptr(sp.partials(d, dev)), L.ptr(dz_neg),
+                       dz_neg.stride(0) if dz_neg is not None else 0, L.stream())     # (dz_pos = both walks' sums when mx)
             # the runs' record rows added per relation (fixed order: the records are grouped once per graph)
-            drel = spmm(lists.rec_ptr, lists.rec_order, None, records, r, split=lists.rec_split)
+            dr = spmm(lists.rec_ptr, lists.rec_order, None, records, r, split=lists.rec_split)
+            drel = dr if drel is None else drel + dr
             pos_one = (s_pos, dz_pos)
         for (ei, et, label, counted, _), waves, w0 in zip(sets, n_waves, slot0):
             t = ei.size(1)
@@ -1950,7 +2013,15 @@ class _KgeBceLoss(torch.autograd.Function):
         ctx.n_real = rows
         ctx.padded = padded
         ctx.onepass = onepass
-        if owned is None and onepass:
+        ctx.mx = mx
+        if owned is None and onepass and mx:
+            ctx.graphs = None
+            ctx.save_for_backward(zt, rel_emb, None, None, drel, None, None, z if reg else None, pos_one[1])
+            pos_scores = pos_one[0]
+            neg_scores = torch.empty(0, dtype=torch.float32, device=dev)      # (a placeholder: see _FRAME["lazy_neg"])
+            _FRAME["inverse"] = None
+            _FRAME["lazy_neg"] = LazyScores(zt, rel_emb, neg_ei, neg_et, kind)
+        elif owned is None and onepass:
             ctx.graphs = (pos_ei, pos_et, neg_ei, neg_et)
             ctx.save_for_backward(zt, rel_emb, None, grads[0], drel, None, rec_all if (pack and neg_ei.size(1)) else None,
                                   z if (reg or padded) else None, pos_one[1])
@@ -2004,7 +2075,20 @@ class _KgeBceLoss(torch.autograd.Function):
         zt_bf16 = int(zt.dtype == torch.bfloat16)
         z = zt
         dz = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and getattr(ctx, "mx", False):
+            # both walks ran in the forward: dz_pos holds the sums of the positives' AND the negatives' lists.  What is left is
+            # the upstream gradient and the L2 term, out of place (the buffer stays intact for a second backward)
+            if (ctx.reg and gloss.numel() == 1 and z_reg is not None and z_reg.dtype == torch.float32 and z_reg.shape == dz_pos.shape
+                    and z_reg.stride(1) == 1 and z_reg.stride(0) % 4 == 0 and z_reg.data_ptr() % 16 == 0):
+                dz = torch.empty_like(dz_pos)
+                gl = gloss.reshape(1).float().contiguous()
+                L.call("bkg_scale_add_rows_out_f32", L.ptr(dz_pos), dz_pos.stride(0), L.ptr(z_reg), z_reg.stride(0), n, d,
+                       L.ptr(gl), 2.0 * ctx.reg / d, L.ptr(dz), dz.stride(0), L.stream())
+            else:
+                dz = dz_pos * gloss
+                if ctx.reg:
+                    dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / (z_reg.size(0) * z_reg.size(1))))
+        elif ctx.needs_input_grad[0]:
             l1 = None
             if kind == KGE_TRANSE:
                 if zt_bf16:   # norms of the rows as the kernels read them
@@ -2176,6 +2260,9 @@ def kge_bce_loss(z, rel_emb, pos_edge_index, pos_edge_type, neg_edge_index, neg_
         _FRAME["lazy"] = False
     if lazy_scores:        # (loss, positives' scores possibly in frame order, negatives' scores, the inverse permutation or None)
         inverse, _FRAME["inverse"] = _FRAME["inverse"], None
+        lazy_neg, _FRAME["lazy_neg"] = _FRAME.get("lazy_neg"), None
+        if lazy_neg is not None:       # the negatives' one-pass walk wrote no scores: a LazyScores in their place
+            out = (out[0], out[1], lazy_neg)
         return out + (inverse,)
     return out
 

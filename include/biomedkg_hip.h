@@ -278,7 +278,31 @@ int bkg_kge_onepass_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n
                         int64_t ldr, int64_t n_rel, const int32_t* other, const int32_t* tid, const void* batches,
                         const void* items, int64_t n_items, float label, float inv_total, float* score /* nullable */,
                         float* loss_part, float* records, float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials,
-                        void* stream);
+                        const float* acc_src /* nullable: rows added to dz on the way out */, int64_t ld_src, void* stream);
+/* The DistMult TRAINING pass of ONE label's triplets -- the step's fresh NEGATIVES -- in one walk over their 2 T incidences
+ * sorted by (node, role): scores, BCE-with-logits terms, dz and d rel_emb (reference biomedkg/kge_module.py:121-128 +
+ * biomedkg/model/decoder.py:45-49 and their autograd; csrc/kge_onepass_mx.hip).  The node's row stays in registers, every
+ * entry's OTHER row is read once (2 T row reads where scorer + node-side gradient read 4 T); d rel_emb -- a segmented sum
+ * over a random relation id per entry -- goes to the matrix cores as a product with a one-hot matrix (the 16 entries of a
+ * chunk staged in LDS as bf16 rows g z_n (*) o, read back k-major by the hardware transpose read): no atomics, no
+ * relation order, no records.  bf16 tables of width 256 and <= 32 relations only (bkg_kge_onepass_mx_ok); everything else
+ * keeps the two-pass form.  rowptr2 [2 n_nodes + 1]: first entry of key 2 * node + role (role 0: the node is the head);
+ * packed / perm [n_inc]: the entries' (other endpoint | relation id << 24) and position in cat(head, tail) in list order
+ * (perm only with score; bkg_kge_role_incidence builds rowptr2 and packed).  loss_part [4 * blocks] unscaled BCE sums; dz rows = the lists' sums (written);
+ * drel_part [blocks][32][256] unscaled (the caller sums over the workgroups and multiplies by inv_total);
+ * blocks = bkg_kge_onepass_mx_blocks(n_nodes). */
+/* The lists that walk takes (csrc/graph.hip): the 2 T incidences cat(head, tail) sorted by key 2 * node + role (one key-making
+ * launch, one radix sort of (key, payload) pairs, one lower bound; no host read).  keys_tmp / vals_tmp / sorted_keys: uint32
+ * [2 T] scratch; workspace of bkg_sort_workspace_bytes(2 T).  Node ids < 2^24, relation ids < 256. */
+int bkg_kge_role_incidence(const int64_t* head, const int64_t* tail, const int64_t* rel, int64_t T, int64_t n_nodes,
+                           uint32_t* keys_tmp, uint32_t* vals_tmp, uint32_t* sorted_keys, int32_t* packed, int32_t* rowptr2,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int32_t bkg_kge_onepass_mx_ok(int32_t d, int32_t z_is_bf16, int64_t n_rel);
+int32_t bkg_kge_onepass_mx_blocks(int64_t n_nodes);
+int bkg_kge_onepass_mx_f32(const void* z, int64_t ldz, int64_t n_nodes, const float* rel_emb, int64_t ldr, int64_t n_rel,
+                           const int32_t* rowptr2, const int32_t* packed, const int32_t* perm, int64_t n_inc, float label,
+                           float inv_total, float* score /* nullable */, float* loss_part,
+                           float* dz, int64_t lddz, float* drel_part, int32_t blocks, void* stream);
 /* Fused training pass for one label (1 = positives, 0 = negatives): score[T], g[T] = (sigmoid(s) - label) *
  * inv_total, per-wave BCE-with-logits partial sums loss_part[W] and per-wave partial rows drel[W, lddr] of the
  * relation-side gradient (W = bkg_kge_fused_bce_waves(T, n_rel); relation r owns ceil(cnt_r / 64) consecutive waves;

@@ -127,8 +127,10 @@ def test_c3_as_timed_bf16_fast_paths_against_exact_fp32():
     # (GGD's last conv layer is folded into its linear head -- no product of its own: two hand-overs in GGD's stack)
     assert fast.get("_gemm_xw", 0) + fast.get("bkg_gemm_xw8_gated", 0) >= 18 and fast.get("bkg_gemm_xw8_gated", 0) == 2
     assert fast.get("bkg_gemm_tn_bf16", 0) >= 4 and fast.get("bkg_gemm_grouped_k_bf16", 0) >= 4   # bf16 weight gradients
-    # the positives in one walk over their sorted incidence lists, the (fresh) negatives through scorer + list walk
-    assert fast.get("bkg_kge_onepass_f32", 0) == 1 and fast.get("bkg_kge_fused_bce_dev_f32", 0) == 1
+    # the positives in one walk over their (node, role, relation)-sorted incidence lists (built once per graph), the
+    # (fresh) negatives in one walk over (node, role)-sorted lists built this step, d rel_emb on the matrix cores (round 6)
+    assert fast.get("bkg_kge_onepass_f32", 0) == 1 and fast.get("bkg_kge_onepass_mx_f32", 0) == 1
+    assert fast.get("bkg_kge_fused_bce_dev_f32", 0) == 0 and fast.get("bkg_kge_role_incidence", 0) == 1
     # GGD's head as a dot product per row (forward + both gradient pieces), gate / cast / bias gradient in one pass
     # (the head's gradient -- an outer product -- leaves through the last hidden layer's gate in one launch)
     assert fast.get("bkg_rowdot_f32", 0) == 1 and fast.get("bkg_outer_gate_colsum_bf16", 0) == 1

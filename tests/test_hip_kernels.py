@@ -367,8 +367,148 @@ def test_one_pass_walk_gives_way_when_its_lds_does_not_fit():
             f = torch.zeros(4 * 64 * d, device=dev)
             L.call("bkg_kge_onepass_f32", L.ptr(zt), 1, zt.stride(0), n, d, L.ptr(rel0), rel0.stride(0), r, L.ptr(one),
                    L.ptr(one), L.ptr(one), L.ptr(one), 1, 1.0, 1.0, None, L.ptr(f), L.ptr(f), L.ptr(f), d,
-                   L.ptr(one), L.ptr(f), L.stream())
+                   L.ptr(one), L.ptr(f), None, 0, L.stream())
     finally:
         ops.L.call = call
         ops.set_matmul_precision(old_prec)
+
+
+def _mx_reference(zt, rel, ei, et, label, inv_t):
+    """fp64 restatement of one label's DistMult training pass on the bf16 table (reference kge_module.py:121-128 +
+    decoder.py:45-49 through autograd): scores, the unscaled BCE sum, dz, d rel_emb."""
+    n, d = zt.shape
+    z64, rel64 = zt.double(), rel.double()
+    t = ei.size(1)
+    s_ref = torch.empty(t, dtype=torch.float64, device=zt.device)
+    dz = torch.zeros(n, d, dtype=torch.float64, device=zt.device)
+    drel = torch.zeros(rel.size(0), d, dtype=torch.float64, device=zt.device)
+    loss = torch.zeros((), dtype=torch.float64, device=zt.device)
+    for lo in range(0, t, 1 << 18):
+        h, tl, rr = ei[0, lo:lo + (1 << 18)], ei[1, lo:lo + (1 << 18)], et[lo:lo + (1 << 18)]
+        zh, ztl, rw = z64[h], z64[tl], rel64[rr]
+        s = (zh * rw * ztl).sum(1)
+        s_ref[lo:lo + s.numel()] = s
+        g = (torch.sigmoid(s) - label) * inv_t
+        loss += (torch.clamp(s, min=0) - s * label + torch.log1p(torch.exp(-s.abs()))).sum()
+        dz.index_add_(0, h, g[:, None] * rw * ztl)
+        dz.index_add_(0, tl, g[:, None] * rw * zh)
+        drel.index_add_(0, rr, g[:, None] * zh * ztl)
+    return s_ref, loss, dz, drel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,t,r,hub", [(130, 5000, 30, False), (4001, 60_000, 32, True), (7, 300, 1, False), (2002, 1500, 5, False)])
+def test_negatives_one_pass_walk_on_the_matrix_cores_against_fp64(n, t, r, hub):
+    """csrc/kge_onepass_mx.hip called directly (bkg_kge_role_incidence + bkg_kge_onepass_mx_f32) on small and odd shapes: node
+    counts that are not a multiple of four, nodes without any triplet (their dz rows are zeros), a hub whose list is thousands
+    of entries long, self pairs, one relation and all 32, more nodes than triplets -- the BCE sum and dz against an fp64
+    restatement on the same bf16 table to fp32 accuracy; d rel_emb (its terms g z_h (*) z_t are bf16 MFMA operands: 2^-9 per
+    term, unbiased) to 1 % of the largest entry."""
+    from biomedkg_amd import _lib as L, ops
+    dev, d, label = "cuda", 256, 0.0
+    g = torch.Generator(device=dev).manual_seed(n + t)
+    old = ops.get_matmul_precision()
+    try:
+        ops.set_matmul_precision("bf16")
+        z = torch.randn(n, d, device=dev, generator=g) * 0.3
+        zt = ops.to_bf16(z)
+        rel = (torch.randn(r, d, device=dev, generator=g) * 0.3).contiguous()
+        ei = torch.randint(0, max(n - 3, 1), (2, t), device=dev, generator=g)     # (the last nodes carry no triplet)
+        if hub:
+            m = torch.rand(t, device=dev, generator=g) < 0.2
+            ei[0][m] = 5
+            ei[1][torch.rand(t, device=dev, generator=g) < 0.1] = 5               # (and self pairs of the hub)
+        et = torch.randint(0, r, (t,), device=dev, generator=g)
+        inv_t = 1.0 / (3 * t)
+        rowptr2, packed = ops.role_incidence(ei, et, n)
+        # the lists themselves: bounds are the sorted keys' counts, an entry = other endpoint | relation << 24
+        cnt = (rowptr2[1:] - rowptr2[:-1]).long()
+        assert int(rowptr2[0]) == 0 and int(rowptr2[-1]) == 2 * t
+        assert torch.equal(cnt[0::2], torch.bincount(ei[0], minlength=n)) and torch.equal(cnt[1::2], torch.bincount(ei[1], minlength=n))
+        key = torch.repeat_interleave(torch.arange(2 * n, device=dev), cnt)
+        want = torch.cat([2 * ei[0] << 32 | (ei[1] | et << 24), (2 * ei[1] + 1) << 32 | (ei[0] | et << 24)]).sort().values
+        assert torch.equal(((key << 32) | packed.long()).sort().values, want)
+        blocks = L.lib().bkg_kge_onepass_mx_blocks(n)
+        loss_part = torch.empty(4 * blocks, device=dev)
+        dz = torch.full((n, d), float("nan"), device=dev)
+        drel_part = torch.empty(blocks, 32, d, device=dev)
+        L.call("bkg_kge_onepass_mx_f32", L.ptr(zt), zt.stride(0), n, L.ptr(rel), rel.stride(0), r, L.ptr(rowptr2), L.ptr(packed),
+               None, 2 * t, label, inv_t, None, L.ptr(loss_part), L.ptr(dz), dz.stride(0), L.ptr(drel_part), blocks, L.stream())
+        s_ref, loss_ref, dz_ref, drel_ref = _mx_reference(zt, rel, ei, et, label, inv_t)
+        assert abs(float(loss_part.double().sum()) - float(loss_ref)) <= 5e-6 * float(loss_ref)     # (a lane's fp32 sum: the hub's 12 k terms)
+        assert torch.isfinite(dz).all() and float((dz.double() - dz_ref).abs().max()) <= 2e-6 * float(dz_ref.abs().max())
+        if n > 3:
+            assert float(dz[n - 3:].abs().max()) == 0.0
+        drel = drel_part.sum(0)[:r].double() * inv_t
+        assert float((drel - drel_ref).abs().max()) <= 1e-2 * float(drel_ref.abs().max())
+        if r < 32:
+            assert float(drel_part.sum(0)[r:].abs().max()) == 0.0
+        # with scores: written from the head end by the entries' positions (the generic sort keeps them)
+        from biomedkg_amd.graph import _Sorter
+        role = torch.cat([torch.zeros(t, dtype=torch.int64, device=dev), torch.ones(t, dtype=torch.int64, device=dev)])
+        _, perm, rp2 = _Sorter.sort_rowptr(role, ei.view(-1), 2, n, 2 * n + 1, 1)
+        assert torch.equal(rp2, rowptr2)
+        p64 = perm.long()
+        tid = torch.where(p64 < t, p64, p64 - t)
+        packed2 = (torch.where(p64 < t, ei[1][tid], ei[0][tid]) | (et[tid] << 24)).to(torch.int32)
+        score = torch.empty(t, device=dev)
+        dz2 = torch.empty(n, d, device=dev)
+        L.call("bkg_kge_onepass_mx_f32", L.ptr(zt), zt.stride(0), n, L.ptr(rel), rel.stride(0), r, L.ptr(rp2), L.ptr(packed2),
+               L.ptr(perm), 2 * t, label, inv_t, L.ptr(score), L.ptr(loss_part), L.ptr(dz2), dz2.stride(0), L.ptr(drel_part),
+               blocks, L.stream())
+        assert float((score.double() - s_ref).abs().max()) <= 2e-6 * max(float(s_ref.abs().max()), 1.0)
+        assert float((dz2 - dz).abs().max()) <= 1e-6 * float(dz.abs().max())          # (another order inside a list)
+        # the entry refuses what it has no instance for
+        assert not L.lib().bkg_kge_onepass_mx_ok(128, 1, r) and not L.lib().bkg_kge_onepass_mx_ok(256, 0, r)
+        assert not L.lib().bkg_kge_onepass_mx_ok(256, 1, 33)
+    finally:
+        ops.set_matmul_precision(old)
+
+
+@pytest.mark.gpu
+def test_training_pass_with_both_walks_matches_the_two_pass_negatives(monkeypatch):
+    """``ops.kge_bce_loss(lazy_scores=True)`` on a graph that stays: from the second step on the positives AND the fresh
+    negatives go through their one-pass walks (``bkg_kge_onepass_mx_f32`` first, then ``bkg_kge_onepass_f32``, which adds
+    the negatives' sums on its way out), the backward is one scale + L2 launch.  Against the same op with the negatives
+    through scorer + list walk: the same loss, dz to fp32 accuracy, d rel_emb to the bf16 operand's accuracy, the negatives'
+    scores (computed on demand: ``LazyScores``) equal -- also for a non-unit upstream gradient and a second backward."""
+    from biomedkg_amd import ops
+    dev, n, d, r, t = "cuda", 20000, 256, 30, 1_100_000
+    old = ops.get_matmul_precision()
+    launches, call = [], ops.L.call
+    try:
+        ops.set_matmul_precision("bf16")
+        ops.L.call = lambda name, *a: (launches.append(name), call(name, *a))[1]
+        g = torch.Generator(device=dev).manual_seed(11)
+        pe = torch.randint(0, n, (2, t), device=dev, generator=g)
+        pt = (torch.rand(t, device=dev, generator=g) ** 3 * r).long().clamp_(max=r - 1)
+        ne = torch.randint(0, n, (2, t), device=dev, generator=g)
+        nt = torch.randint(0, r, (t,), device=dev, generator=g).sort().values
+        z0, rel0 = torch.randn(n, d, device=dev) * 0.3, torch.randn(r, d, device=dev) * 0.3
+        ops.onepass_stable(pe, pt)                      # (this pair of tensors has been seen: the lists pay)
+        got = []
+        for mx in (True, False):
+            monkeypatch.setattr(ops, "KGE_ONEPASS_MX", mx)
+            del launches[:]
+            z, rel = z0.clone().requires_grad_(), rel0.clone().requires_grad_()
+            loss, pp, npred, _ = ops.kge_bce_loss(z, rel, pe, pt, ne, nt, ops.KGE_DISTMULT, reg=1e-2, lazy_scores=True)
+            (loss * 1.5).backward(retain_graph=True)
+            gz1 = z.grad.clone()
+            z.grad = rel.grad = None
+            (loss * 1.5).backward()
+            assert torch.equal(z.grad, gz1)
+            n_mx, n_fused = launches.count("bkg_kge_onepass_mx_f32"), launches.count("bkg_kge_fused_bce_dev_f32")
+            if isinstance(npred, ops.LazyScores):
+                npred = npred()
+            got.append((float(loss.detach()), pp.clone(), npred.clone(), z.grad.clone(), rel.grad.clone(), n_mx, n_fused))
+        (la, pa, na, za, ra, mxa, fa), (lb, pb, nb_, zb, rb, mxb, fb) = got
+        assert mxa == 1 and fa == 0 and mxb == 0 and fb == 1
+        assert abs(la - lb) <= 1e-6 * abs(lb)
+        torch.testing.assert_close(pa, pb, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(na, nb_, rtol=1e-4, atol=1e-4)
+        assert float((za - zb).norm() / zb.norm()) < 5e-6
+        assert float((ra - rb).norm() / rb.norm()) < 2e-3                    # (bf16 MFMA operands in the one-hot product)
+    finally:
+        ops.L.call = call
+        ops.set_matmul_precision(old)
 
