@@ -49,7 +49,7 @@ constexpr int KM_NR = 32;                    // relation rows of the one-hot pro
 constexpr int KM_STEP = 8;                   // rounds per step (= slots of a group's row ring: 32 rows in flight per wave)
 constexpr int KM_ROW = 576;                  // bytes of a staged row: 512 + 64 pad (the transposed reads of a 32-lane half
                                              // then fall on 32 distinct bank pairs: rows 16 banks apart, 16-column blocks 8)
-constexpr int KM_STAGE = 16 * KM_ROW + 64;   // a wave's staging area: 16 rows + relk[16] (padded)
+constexpr int KM_STAGE = 16 * KM_ROW + 64 + 1024;   // a wave's staging area: 16 rows + relk[16] (padded) + its one-hot operand
 constexpr int KM_FLAGS = 64;                 // the waves' "my stream goes on" words of a step (two sets)
 constexpr int KM_LDS = KM_NR * KM_D * 4 + 4 * KM_STAGE + KM_FLAGS;
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void kge_onepass_mx_kernel(const KmArgs a) 
   auto issue = [&](int u, int nv, int np) {
     rid_s[u] = (int)((unsigned)nv >> 24);
     if (SCORES) pm_s[u] = np;
-    const __bf16* p = a.z + (int64_t)(nv & 0xffffff) * a.ldz + 8 * lig;
+    const __bf16* p = a.z + (unsigned)(nv & 0xffffff) * (unsigned)a.ldz + 8 * lig;      // (< 2^31 elements: checked)
     val[u][0].load(p);
     val[u][1].load(p + 128);
   };
@@ -215,7 +215,11 @@ __global__ __launch_bounds__(256, 2) void kge_onepass_mx_kernel(const KmArgs a) 
     const bool r_on = km_uniform(R.valid) != 0;
     if (r_on && km_uniform(R.first)) fetch_zn(R);
     // does any group still have head entries in this step?  (wave-uniform: the one-hot product runs only then)
+#ifdef KM_ABL
+    const bool step_heads = (KM_ABL & 1) ? false : __builtin_amdgcn_ballot_w64(C.e0 < min(C.mid, C.end)) != 0;
+#else
     const bool step_heads = __builtin_amdgcn_ballot_w64(C.e0 < min(C.mid, C.end)) != 0;
+#endif
 #pragma unroll
     for (int u = 0; u < KM_STEP; ++u) {
       unsigned char* stage = stage0 + wave * KM_STAGE;
@@ -281,22 +285,32 @@ __global__ __launch_bounds__(256, 2) void kge_onepass_mx_kernel(const KmArgs a) 
       }
       issue(u, nv, np);   // this slot's next tenant: round u of the step behind (unconditional: past the stream's end entry 0 again)
       if ((u & 3) == 0 && !step_heads && lane < 16) relk[lane] = 255;   // (no head entry left: a zero one-hot over stale rows)
+#if defined(KM_ABL) && (KM_ABL & 4)
+      if (false) {
+#else
       if ((u & 3) == 3) {
+#endif
         // d rel_emb of the 4 x 16 entries the workgroup just staged: C[rel, col] += onehot[rel, k] * B[k, col], this wave
         // its 64 columns of all four chunks (unconditional: a product under a branch made hipcc keep two copies of the
         // accumulators and move them back after every chunk)
-        __syncthreads();
-        const unsigned me = lane & 31;
-#pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
-          const unsigned char* st = stage0 + w2 * KM_STAGE;
-          const uint2 rk = *reinterpret_cast<const uint2*>(st + 16 * KM_ROW + 8 * (lane >> 5));
+        {   // this wave's one-hot operand A[rel = lane % 32][k = 8 (lane / 32) + j] = (rel_k == rel), built ONCE and left in
+            // LDS for the four consumers (each of them building all four cost 90 vector instructions per chunk)
+          const unsigned me = lane & 31;
+          const uint2 rk = *reinterpret_cast<const uint2*>(relk + 8 * (lane >> 5));
           uint4 aw;
           aw.x = (((rk.x) & 255u) == me ? 0x3F80u : 0u) | (((rk.x >> 8) & 255u) == me ? 0x3F800000u : 0u);
           aw.y = (((rk.x >> 16) & 255u) == me ? 0x3F80u : 0u) | ((rk.x >> 24) == me ? 0x3F800000u : 0u);
           aw.z = (((rk.y) & 255u) == me ? 0x3F80u : 0u) | (((rk.y >> 8) & 255u) == me ? 0x3F800000u : 0u);
           aw.w = (((rk.y >> 16) & 255u) == me ? 0x3F80u : 0u) | ((rk.y >> 24) == me ? 0x3F800000u : 0u);
-          const km_bf16x8_t af = __builtin_bit_cast(km_bf16x8_t, aw);
+          *reinterpret_cast<uint4*>(stage + 16 * KM_ROW + 64 + 16 * lane) = aw;
+        }
+#if !defined(KM_ABL) || !(KM_ABL & 2)
+        __syncthreads();
+#endif
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+          const unsigned char* st = stage0 + w2 * KM_STAGE;
+          const km_bf16x8_t af = __builtin_bit_cast(km_bf16x8_t, *reinterpret_cast<const uint4*>(st + 16 * KM_ROW + 64 + 16 * lane));
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             const unsigned char* src = st + tr_off + 64 * b;
@@ -307,7 +321,9 @@ __global__ __launch_bounds__(256, 2) void kge_onepass_mx_kernel(const KmArgs a) 
             cacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(km_bf16x8_t, bb), cacc[b], 0, 0, 0);
           }
         }
+#if !defined(KM_ABL) || !(KM_ABL & 2)
         __syncthreads();                               // (one staging area: nobody stages the next chunk before all have read)
+#endif
       }
     }
     if (c_on && km_uniform(C.last)) {
@@ -377,7 +393,8 @@ extern "C" int bkg_kge_onepass_mx_f32(const void* z, int64_t ldz, int64_t n_node
   BKG_ARG(z && rel_emb && rowptr2 && loss_part && dz && drel_part && n_rel > 0 && n_rel <= KM_NR && n_nodes >= 0 && n_inc >= 0,
           "bkg_kge_onepass_mx_f32: needs the table, the relation rows (<= 32), the list bounds and the output buffers");
   BKG_ARG(n_inc > 0 && packed && (!score || perm), "bkg_kge_onepass_mx_f32: needs the entries' streams (n_inc > 0)");
-  BKG_ARG(n_inc < (1ll << 31) && n_nodes <= (1ll << 24), "bkg_kge_onepass_mx_f32: 32-bit entry positions, 24-bit node ids");
+  BKG_ARG(n_inc < (1ll << 31) && n_nodes <= (1ll << 24) && n_nodes * ldz < (1ll << 31),
+          "bkg_kge_onepass_mx_f32: 32-bit entry positions, 24-bit node ids, a table below 2^31 elements");
   BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % 8 == 0) && ((uintptr_t)rel_emb % 16 == 0) && (ldr % 4 == 0) &&
               ((uintptr_t)dz % 16 == 0) && (lddz % 4 == 0) && ((uintptr_t)drel_part % 16 == 0),
           "bkg_kge_onepass_mx_f32: alignment");

@@ -436,7 +436,7 @@ def test_negatives_one_pass_walk_on_the_matrix_cores_against_fp64(n, t, r, hub):
                None, 2 * t, label, inv_t, None, L.ptr(loss_part), L.ptr(dz), dz.stride(0), L.ptr(drel_part), blocks, L.stream())
         s_ref, loss_ref, dz_ref, drel_ref = _mx_reference(zt, rel, ei, et, label, inv_t)
         assert abs(float(loss_part.double().sum()) - float(loss_ref)) <= 5e-6 * float(loss_ref)     # (a lane's fp32 sum: the hub's 12 k terms)
-        assert torch.isfinite(dz).all() and float((dz.double() - dz_ref).abs().max()) <= 2e-6 * float(dz_ref.abs().max())
+        assert torch.isfinite(dz).all() and float((dz.double() - dz_ref).abs().max()) <= 1e-5 * float(dz_ref.abs().max())   # (fp32 sums; the hub's: 12 k terms)
         if n > 3:
             assert float(dz[n - 3:].abs().max()) == 0.0
         drel = drel_part.sum(0)[:r].double() * inv_t
