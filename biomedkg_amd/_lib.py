@@ -79,7 +79,7 @@ SIGNATURES = {
     "bkg_kge_onepass_mx_ok": (I32, [I32, I32, I64]),
     "bkg_kge_onepass_mx_blocks": (I32, [I64]),
     "bkg_kge_onepass_mx_f32": (I32, [P, I64, I64, P, I64, I64, P, P, P, I64, F32, F32, P, P, P, I64, P, I32, P]),
-    "bkg_kge_onepass_f32": (I32, [P, I32, I64, I64, I32, P, I64, I64, P, P, P, P, I64, F32, F32, P, P, P, P, I64, P, P, P, I64, P]),
+    "bkg_kge_onepass_f32": (I32, [P, I32, I64, I64, I32, P, I64, I64, P, P, P, P, I64, F32, F32, P, P, P, P, I64, P, P, P]),
     "bkg_kge_bwd_nodes_f32": (I32, [I32, P, I32, I64, I64, I32, P, P, P, I64, P, I64, I64, P, P, P, P, P, P, I64, P, P, I32, I64, P]),
     "bkg_kge_fused_chunk": (I32, []),
     "bkg_kge_fused_bce_waves": (I64, [I64, I32]),
@@ -89,6 +89,7 @@ SIGNATURES = {
     "bkg_kge_loss_finish_f32": (I32, [P, I32, F32, P, P, I64, I32, I32, P, F64, P, I64, I32, F32, P, P, P]),
     "bkg_scale_add_rows_f32": (I32, [P, I64, P, I64, I32, I32, P, F32, P, P]),
     "bkg_scale_add_rows_out_f32": (I32, [P, I64, P, I64, I32, I32, P, F32, P, I64, P]),
+    "bkg_kge_dz_finish_f32": (I32, [P, I64, P, I64, P, I64, I64, I32, P, F32, P, I64, P]),
     "bkg_relation_wave_ptr": (I32, [P, I32, I32, P, P]),
     "bkg_kge_bwd_rel_f32": (I32, [I32, P, I64, I32, P, P, P, I64, P, I64, P, I32, P, I64, P, P, P]),
     # ntxent.hip

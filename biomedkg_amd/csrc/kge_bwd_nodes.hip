@@ -558,8 +558,7 @@ __global__ __launch_bounds__(256) void kge_onepass_kernel(const T* __restrict__ 
                                                           const int4* __restrict__ batches, const int4* __restrict__ items,
                                                           int n_items, float label, float inv_t, float* __restrict__ score,
                                                           float* __restrict__ loss_part, float* __restrict__ records,
-                                                          float* __restrict__ dz, int64_t lddz, float* __restrict__ partials,
-                                                          const float* __restrict__ acc_src, int64_t ld_src) {
+                                                          float* __restrict__ dz, int64_t lddz, float* __restrict__ partials) {
   constexpr int G = 64 / LPR, Q = Piece<T>::Q, EPL = Piece<T>::EPL, VQ = VPL * Q, D = EPL * LPR * VPL, U = KO_U;
   extern __shared__ __attribute__((aligned(16))) float ko_rel[];
   const int lane = threadIdx.x & 63, grp = lane / LPR, lig = lane % LPR;
@@ -721,13 +720,8 @@ __global__ __launch_bounds__(256) void kge_onepass_kernel(const T* __restrict__ 
       continue;
     }
 #pragma unroll
-    for (int q = 0; q < VQ; ++q) {
-      if (acc_src) {      // (rows added on the way out: the negatives' part of dz when their walk ran first)
-        const float4 o = *reinterpret_cast<const float4*>(acc_src + (int64_t)node * ld_src + piece_col<T, LPR>(lig, q));
-        acc[q].x += o.x; acc[q].y += o.y; acc[q].z += o.z; acc[q].w += o.w;
-      }
+    for (int q = 0; q < VQ; ++q)
       *reinterpret_cast<float4*>(dz + (int64_t)node * lddz + piece_col<T, LPR>(lig, q)) = acc[q];
-    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) loss_acc += __shfl_xor(loss_acc, o, 64);
@@ -886,14 +880,13 @@ extern "C" int bkg_kge_onepass_f32(const void* z, int32_t z_is_bf16, int64_t ldz
                                    int64_t ldr, int64_t n_rel, const int32_t* other, const int32_t* tid, const void* batches,
                                    const void* items, int64_t n_items, float label, float inv_total, float* score,
                                    float* loss_part, float* records, float* dz, int64_t lddz, const bkg_rowsplit* split,
-                                   float* partials, const float* acc_src, int64_t ld_src, void* stream) {
+                                   float* partials, void* stream) {
   const int epl = z_is_bf16 ? 8 : 4;
   BKG_ARG(other && tid && batches && items && loss_part && records && dz && split && partials && n_rel > 0 && n_items >= 0,
           "bkg_kge_onepass_f32: needs the lists, their batch / item tables, the row table and the output buffers");
   BKG_ARG(((uintptr_t)z % 16 == 0) && (ldz % epl == 0) && (d % epl == 0) && ((uintptr_t)rel_emb % 16 == 0) && (ldr % 4 == 0) &&
               ((uintptr_t)dz % 16 == 0) && (lddz % 4 == 0) && ((uintptr_t)partials % 16 == 0) && ((uintptr_t)records % 16 == 0) &&
-              ((uintptr_t)batches % 16 == 0) && ((uintptr_t)items % 16 == 0) &&
-              (!acc_src || ((uintptr_t)acc_src % 16 == 0 && ld_src % 4 == 0)), "bkg_kge_onepass_f32: alignment");
+              ((uintptr_t)batches % 16 == 0) && ((uintptr_t)items % 16 == 0), "bkg_kge_onepass_f32: alignment");
   {
     const int64_t smem_need = bkg_kge_onepass_smem_bytes(d, z_is_bf16, n_rel);
     BKG_ARG(smem_need > 0 && smem_need <= 65536,
@@ -908,12 +901,11 @@ extern "C" int bkg_kge_onepass_f32(const void* z, int32_t z_is_bf16, int64_t ldz
     const size_t smem = ((size_t)n_rel + 4 * (size_t)std::max(64 / LPR - 1, 1)) * d * 4; /* = bkg_kge_onepass_smem_bytes */ \
     hipLaunchKernelGGL((kge_onepass_kernel<TT, LPR, VPL>), dim3(blocks), dim3(256), smem, s, (const TT*)z, ldz, rel_emb, ldr, \
                        (int)n_rel, other, tid, (const int4*)batches, (const int4*)items, (int)n_items, label, inv_total, score, \
-                       loss_part, records, dz, lddz, partials, acc_src, ld_src);                                       \
+                       loss_part, records, dz, lddz, partials);                                                        \
     if (split->n_long_max > 0)                                                                                         \
       hipLaunchKernelGGL((kge_bwd_nodes_fixup_kernel<TT, KN_DISTMULT, LPR, VPL>),                                      \
                          dim3(ceil_div(split->n_long_max, 4 * (64 / LPR))), dim3(256), 0, s, *split, (const TT*)z, ldz, \
-                         (const float*)nullptr, partials, dz, lddz, acc_src ? 1 : 0,                                   \
-                         KnTail{nullptr, nullptr, 0, 0.f, acc_src, ld_src});                                           \
+                         (const float*)nullptr, partials, dz, lddz, 0, KnTail{nullptr, nullptr, 0, 0.f, nullptr, 0});              \
   }
   BKG_PIECE_DISPATCH_(d / epl, KO_L32, 64, {
     if (z_is_bf16) KO_LAUNCH(__bf16) else KO_LAUNCH(float)

@@ -325,9 +325,48 @@ __global__ __launch_bounds__(256) void scale_add_rows_out_kernel(const float* __
   out[(int64_t)row * ldo + col] = fmaf(src[(int64_t)row * lds + col], g * (coef / (float)max(n, 1)), base[(int64_t)row * ldb + col] * g);
 }
 
+// out = (a + b) * g + z * (g * coef / n): the two walks' node-side sums, the upstream gradient, the L2 term (float4 per lane)
+__global__ __launch_bounds__(256) void kge_dz_finish_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                                            int64_t ldb, const float* __restrict__ z, int64_t ldz, int64_t n, int d4,
+                                                            const float* __restrict__ gloss, float coef,
+                                                            float* __restrict__ out, int64_t ldo) {
+  const float g = gloss[0], c = g * (coef / (float)(n > 0 ? n : 1));
+  const int64_t total = n * d4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t row = e / d4;
+    const int col = 4 * (int)(e - row * d4);
+    float4 v = *reinterpret_cast<const float4*>(a + row * lda + col);
+    if (b) {
+      const float4 w = *reinterpret_cast<const float4*>(b + row * ldb + col);
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+    if (z) {
+      const float4 s = *reinterpret_cast<const float4*>(z + row * ldz + col);
+      v.x = fmaf(s.x, c, v.x); v.y = fmaf(s.y, c, v.y); v.z = fmaf(s.z, c, v.z); v.w = fmaf(s.w, c, v.w);
+    }
+    *reinterpret_cast<float4*>(out + row * ldo + col) = v;
+  }
+}
+
 }  // namespace bkg
 
 using namespace bkg;
+
+extern "C" int bkg_kge_dz_finish_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* z, int64_t ldz,
+                                     int64_t n, int32_t d, const float* gloss, float coef, float* out, int64_t ldo,
+                                     void* stream) {
+  BKG_ARG(a && gloss && out && n >= 0 && d > 0 && d % 4 == 0, "bkg_kge_dz_finish_f32: bad arguments");
+  BKG_ARG((uintptr_t)a % 16 == 0 && lda % 4 == 0 && (!b || ((uintptr_t)b % 16 == 0 && ldb % 4 == 0)) &&
+              (!z || ((uintptr_t)z % 16 == 0 && ldz % 4 == 0)) && (uintptr_t)out % 16 == 0 && ldo % 4 == 0,
+          "bkg_kge_dz_finish_f32: 16-byte aligned rows");
+  if (n == 0) return 0;
+  const int64_t total = n * (d / 4);
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(kge_dz_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, z, ldz, n, d / 4,
+                     gloss, coef, out, ldo);
+  return check_launch("bkg_kge_dz_finish_f32");
+}
 
 extern "C" int64_t bkg_kge_loss_finish_scratch_bytes() { return 3 * FIN_BLOCKS_MAX * sizeof(double) + 16; }
 

@@ -1971,8 +1971,7 @@ class _KgeBceLoss(torch.autograd.Function):
                 L.call("bkg_kge_onepass_f32", L.ptr(zt), zt_bf16, zt.stride(0), n, d, L.ptr(rel_emb), rel_emb.stride(0), r,
                        L.ptr(lists.other), L.ptr(lists.tid), L.ptr(lists.batches), L.ptr(lists.items), lists.n_items, 1.0,
                        1.0 / total, L.ptr(s_pos), L.ptr(part[:one_parts - mx_parts]), L.ptr(records), L.ptr(dz_pos),
-                       dz_pos.stride(0), L.sref(sp.c), L.ptr(sp.partials(d, dev)), L.ptr(dz_neg),
-                       dz_neg.stride(0) if dz_neg is not None else 0, L.stream())     # (dz_pos = both walks' sums when mx)
+                       dz_pos.stride(0), L.sref(sp.c), L.ptr(sp.partials(d, dev)), L.stream())
             # the runs' record rows added per relation (fixed order: the records are grouped once per graph)
             dr = spmm(lists.rec_ptr, lists.rec_order, None, records, r, split=lists.rec_split)
             drel = dr if drel is None else drel + dr
@@ -2016,7 +2015,7 @@ class _KgeBceLoss(torch.autograd.Function):
         ctx.mx = mx
         if owned is None and onepass and mx:
             ctx.graphs = None
-            ctx.save_for_backward(zt, rel_emb, None, None, drel, None, None, z if reg else None, pos_one[1])
+            ctx.save_for_backward(zt, rel_emb, None, dz_neg, drel, None, None, z if reg else None, pos_one[1])
             pos_scores = pos_one[0]
             neg_scores = torch.empty(0, dtype=torch.float32, device=dev)      # (a placeholder: see _FRAME["lazy_neg"])
             _FRAME["inverse"] = None
@@ -2076,16 +2075,22 @@ class _KgeBceLoss(torch.autograd.Function):
         z = zt
         dz = None
         if ctx.needs_input_grad[0] and getattr(ctx, "mx", False):
-            # both walks ran in the forward: dz_pos holds the sums of the positives' AND the negatives' lists.  What is left is
-            # the upstream gradient and the L2 term, out of place (the buffer stays intact for a second backward)
-            if (ctx.reg and gloss.numel() == 1 and z_reg is not None and z_reg.dtype == torch.float32 and z_reg.shape == dz_pos.shape
-                    and z_reg.stride(1) == 1 and z_reg.stride(0) % 4 == 0 and z_reg.data_ptr() % 16 == 0):
+            # both walks ran in the forward: dz_pos holds the sums of the positives' lists, g_neg (the slot of the negatives'
+            # d score, which this form never materialises) those of the negatives'.  What is left is their sum, the upstream
+            # gradient and the L2 term: one pass, out of place (the buffers stay intact for a second backward)
+            dz_neg = g_neg
+            ok = (gloss.numel() == 1 and d % 4 == 0 and dz_pos.stride(0) % 4 == 0 and dz_neg.stride(0) % 4 == 0
+                  and (not ctx.reg or (z_reg is not None and z_reg.dtype == torch.float32 and z_reg.shape == dz_pos.shape
+                                       and z_reg.stride(1) == 1 and z_reg.stride(0) % 4 == 0 and z_reg.data_ptr() % 16 == 0)))
+            if ok:
                 dz = torch.empty_like(dz_pos)
                 gl = gloss.reshape(1).float().contiguous()
-                L.call("bkg_scale_add_rows_out_f32", L.ptr(dz_pos), dz_pos.stride(0), L.ptr(z_reg), z_reg.stride(0), n, d,
-                       L.ptr(gl), 2.0 * ctx.reg / d, L.ptr(dz), dz.stride(0), L.stream())
+                zr = z_reg if ctx.reg else None
+                L.call("bkg_kge_dz_finish_f32", L.ptr(dz_pos), dz_pos.stride(0), L.ptr(dz_neg), dz_neg.stride(0), L.ptr(zr),
+                       zr.stride(0) if zr is not None else 0, n, d, L.ptr(gl), 2.0 * ctx.reg / d, L.ptr(dz), dz.stride(0),
+                       L.stream())
             else:
-                dz = dz_pos * gloss
+                dz = (dz_pos + dz_neg) * gloss
                 if ctx.reg:
                     dz = torch.addcmul(dz, z_reg, gloss * (2.0 * ctx.reg / (z_reg.size(0) * z_reg.size(1))))
         elif ctx.needs_input_grad[0]:

@@ -278,7 +278,7 @@ int bkg_kge_onepass_f32(const void* z, int32_t z_is_bf16, int64_t ldz, int64_t n
                         int64_t ldr, int64_t n_rel, const int32_t* other, const int32_t* tid, const void* batches,
                         const void* items, int64_t n_items, float label, float inv_total, float* score /* nullable */,
                         float* loss_part, float* records, float* dz, int64_t lddz, const bkg_rowsplit* split, float* partials,
-                        const float* acc_src /* nullable: rows added to dz on the way out */, int64_t ld_src, void* stream);
+                        void* stream);
 /* The DistMult TRAINING pass of ONE label's triplets -- the step's fresh NEGATIVES -- in one walk over their 2 T incidences
  * sorted by (node, role): scores, BCE-with-logits terms, dz and d rel_emb (reference biomedkg/kge_module.py:121-128 +
  * biomedkg/model/decoder.py:45-49 and their autograd; csrc/kge_onepass_mx.hip).  The node's row stays in registers, every
@@ -328,6 +328,12 @@ int bkg_scale_add_rows_f32(float* dst, int64_t ldd, const float* src, int64_t ld
 /* out = base * g + src * (g * coef / n), out of place (base: a tensor the autograd graph saved) */
 int bkg_scale_add_rows_out_f32(const float* base, int64_t ldb, const float* src, int64_t lds, int32_t n, int32_t d,
                                const float* gloss, float coef, float* out, int64_t ldo, void* stream);
+/* The node-side gradient of a step whose two one-pass walks ran in the forward (reference kge_module.py:127-129 through
+ * autograd): out = (a + b) * gloss[0] + z * (gloss[0] * coef / n) -- the positives' sums, the negatives' sums (b nullable),
+ * the upstream gradient and the L2 term in ONE pass (16 bytes per lane; d % 4 == 0, 16-byte aligned rows). */
+int bkg_kge_dz_finish_f32(const float* a, int64_t lda, const float* b /* nullable */, int64_t ldb, const float* z /* nullable */,
+                          int64_t ldz, int64_t n, int32_t d, const float* gloss, float coef, float* out, int64_t ldo,
+                          void* stream);
 /* wave_ptr[n_rel + 1]: first wave of each relation in that pass (chunk = 64 triplets per wave) */
 int bkg_relation_wave_ptr(const int32_t* rel_ptr, int32_t n_rel, int32_t chunk, int32_t* wave_ptr, void* stream);
 int bkg_kge_fused_bce_f32(int32_t kind, const void* z /* fp32 or bf16 table */, int32_t z_is_bf16, int64_t ldz,

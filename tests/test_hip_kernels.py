@@ -367,7 +367,7 @@ def test_one_pass_walk_gives_way_when_its_lds_does_not_fit():
             f = torch.zeros(4 * 64 * d, device=dev)
             L.call("bkg_kge_onepass_f32", L.ptr(zt), 1, zt.stride(0), n, d, L.ptr(rel0), rel0.stride(0), r, L.ptr(one),
                    L.ptr(one), L.ptr(one), L.ptr(one), 1, 1.0, 1.0, None, L.ptr(f), L.ptr(f), L.ptr(f), d,
-                   L.ptr(one), L.ptr(f), None, 0, L.stream())
+                   L.ptr(one), L.ptr(f), L.stream())
     finally:
         ops.L.call = call
         ops.set_matmul_precision(old_prec)
@@ -468,8 +468,8 @@ def test_negatives_one_pass_walk_on_the_matrix_cores_against_fp64(n, t, r, hub):
 @pytest.mark.gpu
 def test_training_pass_with_both_walks_matches_the_two_pass_negatives(monkeypatch):
     """``ops.kge_bce_loss(lazy_scores=True)`` on a graph that stays: from the second step on the positives AND the fresh
-    negatives go through their one-pass walks (``bkg_kge_onepass_mx_f32`` first, then ``bkg_kge_onepass_f32``, which adds
-    the negatives' sums on its way out), the backward is one scale + L2 launch.  Against the same op with the negatives
+    negatives go through their one-pass walks (``bkg_kge_onepass_mx_f32``, ``bkg_kge_onepass_f32``), the backward is ONE
+    launch (``bkg_kge_dz_finish_f32``: both walks' sums, the upstream gradient, the L2 term).  Against the same op with the negatives
     through scorer + list walk: the same loss, dz to fp32 accuracy, d rel_emb to the bf16 operand's accuracy, the negatives'
     scores (computed on demand: ``LazyScores``) equal -- also for a non-unit upstream gradient and a second backward."""
     from biomedkg_amd import ops
