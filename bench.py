@@ -185,6 +185,9 @@ KERNEL_NAMES = {
                      "triplet incidences (their other-endpoint / relation / g streams in list order), d={d}",
     "kge_onepass": "kge_onepass_kernel<{t}> + fixup: the whole DistMult training pass of the POSITIVES in one walk over their "
                    "(node, role, relation)-sorted incidence lists (scores, BCE terms, dz, one d rel_emb record row per run), d={d}",
+    "kge_onepass_mx": "kge_onepass_mx_kernel: the whole DistMult training pass of the step's fresh NEGATIVES in one walk over "
+                      "their (node, role)-sorted incidence lists (BCE terms, dz; d rel_emb as a one-hot product on the matrix "
+                      "cores), d={d}",
 }
 
 

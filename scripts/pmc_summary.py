@@ -44,6 +44,7 @@ FAMILIES = (("spmm", "gather / aggregate (spmm_items, spmm_fixup)"), ("kge_", "K
             ("scaled_rows", "casts / gates / column sums / row dots"), ("pair", "casts / gates / column sums / row dots"),
             ("negative_", "negative sampler + structures"), ("hashset", "negative sampler + structures"),
             ("rowsplit", "negative sampler + structures"), ("sort", "negative sampler + structures"),
+            ("role_incidence", "negative sampler + structures"),
             ("ggd_bce", "losses"), ("bkg", "other library kernels"), ("at::", "ATen (fills, norms, glue)"),
             ("6native", "ATen (fills, norms, glue)"), ("fillBuffer", "ATen (fills, norms, glue)"))
 
@@ -133,6 +134,8 @@ def main(fetch_csv, write_csv, out_json, precision="fp32", bench_json=None, tcc_
             tag = "kge_fused_bce"
         if "kge_onepass_kernel" in key[0]:
             tag = "kge_onepass"
+        if "kge_onepass_mx_kernel" in key[0]:
+            tag = "kge_onepass_mx"
         rec = {"kernel": key[0], "grid_size": key[1], "precision": precision, "launches": len(fv), "tag": tag, "tags": also,
                "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write}
         if key in durations:

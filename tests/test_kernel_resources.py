@@ -40,7 +40,10 @@ def test_gated_product_and_one_pass_walk_do_not_spill(tmp_path):
     """``gemm_xw8_kernel<bf16, GATED>`` issues its gate loads by hand and counts them into the ring's ``vmcnt`` ladder -- a
     spill would be one more memory operation on that counter; ``kge_onepass_kernel`` at the bench width (bf16, 16 lanes per
     row) keeps four 16-register vectors and two batches of rows in flight: it must fit three waves per SIMD without scratch."""
-    for src, want in (("gemm_xw.hip", ("gemm_xw8_kernelIDF16bLb1E",)), ("kge_bwd_nodes.hip", ("kge_onepass_kernelIDF16bLi16ELi2E",))):
+    # (round 6) ``kge_onepass_mx_kernel``: 256 registers and 74 KB of LDS are what puts two of its workgroups on a CU -- two
+    # waves per SIMD hide each other's LDS and transcendental latencies; a spill would also sit on the row ring's vmcnt count
+    for src, want in (("gemm_xw.hip", ("gemm_xw8_kernelIDF16bLb1E",)), ("kge_bwd_nodes.hip", ("kge_onepass_kernelIDF16bLi16ELi2E",)),
+                      ("kge_onepass_mx.hip", ("kge_onepass_mx_kernelILb0E", "kge_onepass_mx_kernelILb1E"))):
         out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + CSRC, "-I" + os.path.join(ROOT, "include"),
                               "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", str(tmp_path / "x.o")],
                              capture_output=True, text=True, timeout=900)
