@@ -272,7 +272,7 @@ _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "ranks", "backend", "mode", "s
              "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 _SIDE_KEYS = ("triplets_per_sec_kge_step", "edges_per_sec_gcl_step", "ms_per_step_median", "ms_per_step_max", "ms_gcl_step",
               "ms_kge_step", "ms_per_step_fp32", "ms_per_step_literal_ggd_last_layer", "ms_per_step_fresh_first_layer_means",
-              "ms_per_step_shuffled_neg_types", "ms_per_step_all_literal",
+              "ms_per_step_grouped_neg_types", "ms_per_step_all_literal",
               "ms_kge_step_neg10", "triplets_per_sec_kge_step_neg10")
 
 
@@ -350,7 +350,7 @@ def compact_line(out, detail_path=None):
     line["detail"] = detail_path
     line = _strict(line)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
-    for drop in ("check_loss_after", "check_loss", "partition_bound", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_shuffled_neg_types", "ms_per_step_literal_ggd_last_layer", "ms_per_step_fresh_first_layer_means",
+    for drop in ("check_loss_after", "check_loss", "partition_bound", "exchange.rows", "detail", "triplets_per_sec_kge_step_neg10", "ms_kge_step_neg10", "ms_per_step_grouped_neg_types", "ms_per_step_literal_ggd_last_layer", "ms_per_step_fresh_first_layer_means",
                  "ms_per_step_all_literal", "ms_per_step_fp32", "exchange.graphed_sub_steps", "cpu_baseline.threads1", "cpu_baseline.full_size"):
         if len(text) < LINE_LIMIT - 1024:
             break
@@ -1714,39 +1714,30 @@ def main():
             try:
                 ms_linear_head = timed5()
                 # ... and with EVERY switchable identity / kept constant of the bf16 mode off at once: the layer as a layer, the
-                # head as a Linear + row sum, the first R-GCN layer's segment means recomputed every step, the negatives'
-                # relation ids as repeat(k)[randperm] -- the reference's expressions literally, on the same kernels (what stays
-                # is the graph's own bookkeeping: CSRs, segments, incidence lists, built once for a graph that stays)
-                from biomedkg_amd import kge_module as _km
-                was_grouped, _km.GROUPED_NEG_TYPES = _km.GROUPED_NEG_TYPES, False
+                # head as a Linear + row sum, the first R-GCN layer's segment means recomputed every step (the negatives'
+                # relation ids are the literal repeat(k)[randperm] by default) -- the reference's expressions literally, on the
+                # same kernels (what stays is the graph's own bookkeeping: CSRs, segments, incidence lists, built once for a
+                # graph that stays)
                 ops.RGCN_KEEP_SEGMENT_MEANS = False
                 try:
                     ms_all_literal = timed5()
                 finally:
-                    _km.GROUPED_NEG_TYPES = was_grouped
                     ops.RGCN_KEEP_SEGMENT_MEANS = True
             finally:
                 ops.rowsum_linear_ok = ok_fn
         finally:
             ops.GGD_FOLD_LAST = was_fold
 
-    ms_shuffled_types = None
-    if world == 1 and mode == "single" and not args.no_extras:
-        # the same step with the negatives' relation ids in the reference's literal form, repeat(..)[randperm(..)], instead
-        # of grouped by relation (biomedkg_amd/ops.py grouped_types: the same distribution of typed negatives)
+    ms_grouped_types = None
+    if world == 1 and mode == "single" and not args.no_extras and args.precision == "bf16":
+        # the same step with the negatives' relation ids GROUPED BY RELATION (BKG_GROUPED_NEG_TYPES=1, biomedkg_amd/ops.py
+        # grouped_types: the same distribution of typed negatives, the default of rounds 3-5) instead of the reference's literal
+        # repeat(..)[randperm(..)], which the headline draws since round 6
         from biomedkg_amd import kge_module as _km
         was = _km.GROUPED_NEG_TYPES
-        _km.GROUPED_NEG_TYPES = False
+        _km.GROUPED_NEG_TYPES = True
         try:
-            for _ in range(3):
-                step_g(); step_k()
-            per = []                                    # median of individually timed steps (this form allocates new
-            for _ in range(7):                          # tensors every step: a first-time hipMalloc must not set the figure)
-                sync(); t1 = time.perf_counter()
-                step_g(); step_k()
-                sync()
-                per.append((time.perf_counter() - t1) * 1e3)
-            ms_shuffled_types = sorted(per)[len(per) // 2]
+            ms_grouped_types = timed5()
         finally:
             _km.GROUPED_NEG_TYPES = was
 
@@ -1837,11 +1828,11 @@ def main():
                                      "features (ms_per_step_fresh_first_layer_means recomputes them) (every gradient included; "
                                      "the exact-fp32 mode shares the first product too -- there the identity holds bit for "
                                      "bit, rows of a product do not depend on their position -- and keeps the reference's "
-                                     "head).  Both modes: the negatives' relation "
-                                     "ids -- the reference's edge_type.repeat(k)[randperm] -- are delivered grouped by relation; "
-                                     "the negatives they are paired with come out of the sampler in exchangeable order, so the "
-                                     "typed negatives have the same distribution (ms_per_step_shuffled_neg_types times the "
-                                     "literal form).  ms_per_step_all_literal: every one of these switched off at once"},
+                                     "head).  The negatives' relation ids are the reference's literal "
+                                     "edge_type.repeat(k)[randperm] (round 6; ms_per_step_grouped_neg_types times the opt-in form "
+                                     "of rounds 3-5: the ids grouped by relation, the same distribution of typed negatives since "
+                                     "the sampler's order is exchangeable).  ms_per_step_all_literal: every one of these "
+                                     "switched off at once"},
             "triplets_per_sec_kge_step": (total_edges + (n_neg if strong or world == 1 else world * n_neg)) / (ms_k * 1e-3),
             "edges_per_sec_gcl_step": total_edges / (ms_g * 1e-3),
             "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_max": per_step[-1],
@@ -1849,7 +1840,7 @@ def main():
             "ms_per_step_slowest_index": per_step_raw.index(per_step[-1]),
             "ms_gcl_step": ms_g, "ms_kge_step": ms_k, "ms_per_step_fp32": ms_fp32, "ms_per_step_deterministic": ms_det,
             "ms_per_step_literal_ggd_last_layer": ms_literal_last, "ms_per_step_fresh_first_layer_means": ms_fresh_means,
-            "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_shuffled_neg_types": ms_shuffled_types,
+            "ms_per_step_linear_ggd_head": ms_linear_head, "ms_per_step_grouped_neg_types": ms_grouped_types,
             "ms_per_step_all_literal": ms_all_literal,
             "ms_per_step_fresh_structures": ms_fresh,
             "kge_step_neg10": neg10,

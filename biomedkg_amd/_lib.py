@@ -140,6 +140,9 @@ SIGNATURES = {
     "bkg_negative_blocks_struct_bytes": (I64, []),
     "bkg_negative_sample_blocks": (I32, [P, I32, I64, I64, U64, I64, P, I64, P, I64, P, P, P, P, P, P, P, P, I64, P]),
     "bkg_permute_gather_i64": (I32, [P, I64, U64, P, P]),
+    "bkg_permute_gather_repeat_i64": (I32, [P, I64, I64, U64, P, P]),
+    "bkg_narrow_i64_u8": (I32, [P, I64, P, P]),
+    "bkg_permute_gather_repeat_u8": (I32, [P, I64, I64, U64, P, P]),
     "bkg_randperm_dev": (I32, [P, I64, U64, P, P, P]),
     "bkg_negative_sample_dev_candidates": (I64, [I64]),
     "bkg_negative_sample_dev": (I32, [P, I64, P, P, P, I64, U64, P, P, I64, P, P, P, I64, I64, P, P, P, P, P, I64, P]),

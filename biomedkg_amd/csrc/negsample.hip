@@ -83,6 +83,45 @@ __host__ __device__ static inline Feistel make_feistel(uint64_t n, uint64_t seed
   return f;
 }
 
+// The same network with a 32-bit round function (murmur3's finaliser under a 32-bit round key: two v_mul_lo_u32 per round
+// where the splitmix64 finaliser costs two 64-BIT multiplies, eight quarter-rate 32-bit ones) for the id shuffles
+// (round 6: ``edge_type.repeat(10)[randperm]`` -- 40 M evaluations -- took 0.85 ms, now 0.37).  The halves have at most 32
+// bits.  The samplers and the corruption permutation keep the network above (their streams are what the tests' training
+// trajectories were recorded with).
+__device__ __host__ __forceinline__ uint32_t fs_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu;
+  x ^= x >> 13; x *= 0xc2b2ae35u;
+  x ^= x >> 16;
+  return x;
+}
+struct Feistel32 {
+  uint64_t n;
+  uint32_t key[6];
+  int half;
+  __device__ __forceinline__ uint64_t operator()(uint64_t x) const {
+    const uint32_t m = half >= 32 ? 0xffffffffu : ((1u << half) - 1u);
+    do {
+      uint32_t l = (uint32_t)(x >> half), r = (uint32_t)x & m;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const uint32_t t = l ^ (fs_mix32(r ^ key[i]) & m);
+        l = r; r = t;
+      }
+      x = ((uint64_t)l << half) | r;
+    } while (x >= n);
+    return x;
+  }
+};
+__host__ __device__ static inline Feistel32 make_feistel32(uint64_t n, uint64_t seed) {
+  Feistel32 f;
+  f.n = n;
+  int bits = 2;
+  while (bits < 64 && (1ull << bits) < n) bits += 2;
+  f.half = bits / 2;
+  for (int i = 0; i < 6; ++i) f.key[i] = (uint32_t)(hs_mix(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1)) >> 29);
+  return f;
+}
+
 // PyG edge_index_to_vector (non-bipartite, directed): self loops are not positives of the off-diagonal population;
 // cell (r, c), r != c, has the code r*(N-1) + c - (r < c).
 __global__ __launch_bounds__(256) void hashset_insert_kernel(const int64_t* __restrict__ head, const int64_t* __restrict__ tail,
@@ -128,10 +167,23 @@ __global__ __launch_bounds__(256) void negative_scatter_kernel(const uint64_t* _
   if (i == n_cand - 1) *count = (int32_t)total;
 }
 
-__global__ __launch_bounds__(256) void permute_gather_kernel(const int64_t* __restrict__ src, int64_t n, Feistel pi,
+__global__ __launch_bounds__(256) void permute_gather_kernel(const int64_t* __restrict__ src, int64_t n, Feistel32 pi,
                                                              int64_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = src[pi((uint64_t)i)];
+}
+
+// out[i] = src[pi(i) % n_src] over i < n_src * repeat: ``src.repeat(repeat)[randperm(n_src * repeat)]`` -- the negatives'
+// relation ids of reference kge_module.py:97-100 -- without the repeated copy
+template <typename S>
+__global__ __launch_bounds__(256) void permute_gather_repeat_kernel(const S* __restrict__ src, int64_t n_src, int64_t n,
+                                                                    Feistel32 pi, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (int64_t)src[(int64_t)(pi((uint64_t)i) % (uint64_t)n_src)];
+}
+__global__ __launch_bounds__(256) void narrow_i64_u8_kernel(const int64_t* __restrict__ src, int64_t n, uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)src[i];
 }
 
 // ---- the same sampler with every extent in DEVICE memory (captured training steps over padded mini-batches,
@@ -476,8 +528,35 @@ extern "C" int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t se
   BKG_ARG(n >= 0, "bkg_permute_gather_i64: bad n");
   if (n == 0) return 0;
   hipLaunchKernelGGL(permute_gather_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, n,
-                     make_feistel((uint64_t)n, seed), out);
+                     make_feistel32((uint64_t)n, seed), out);
   return check_launch("bkg_permute_gather_i64");
+}
+
+extern "C" int bkg_permute_gather_repeat_i64(const int64_t* src, int64_t n_src, int64_t repeat, uint64_t seed, int64_t* out,
+                                             void* stream) {
+  BKG_ARG(n_src >= 0 && repeat >= 0, "bkg_permute_gather_repeat_i64: bad sizes");
+  const int64_t n = n_src * repeat;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(permute_gather_repeat_kernel<int64_t>, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, n_src,
+                     n, make_feistel32((uint64_t)n, seed), out);
+  return check_launch("bkg_permute_gather_repeat_i64");
+}
+// The same from a one-byte image of the ids (values < 256; bkg_narrow_i64_u8 makes it, once per id tensor): the random reads
+// of a 4 M-entry source then stay in the L2 (4 MB instead of 32), which is what k = 10 repeats spend their time on.
+extern "C" int bkg_narrow_i64_u8(const int64_t* src, int64_t n, uint8_t* out, void* stream) {
+  BKG_ARG(n >= 0, "bkg_narrow_i64_u8: bad n");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(narrow_i64_u8_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, n, out);
+  return check_launch("bkg_narrow_i64_u8");
+}
+extern "C" int bkg_permute_gather_repeat_u8(const uint8_t* src, int64_t n_src, int64_t repeat, uint64_t seed, int64_t* out,
+                                            void* stream) {
+  BKG_ARG(n_src >= 0 && repeat >= 0, "bkg_permute_gather_repeat_u8: bad sizes");
+  const int64_t n = n_src * repeat;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(permute_gather_repeat_kernel<uint8_t>, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, n_src,
+                     n, make_feistel32((uint64_t)n, seed), out);
+  return check_launch("bkg_permute_gather_repeat_u8");
 }
 
 extern "C" int bkg_randperm_dev(const int64_t* n_dev, int64_t cap, uint64_t seed, const uint32_t* epoch, int64_t* out,

@@ -22,6 +22,11 @@ from .ops import Dropout
 _PERM_SIZES = {}     # (n, device) -> the device scalar bkg_randperm_dev reads its extent from
 
 
+def max_below(ids, bound):
+    """Are all ids in [0, bound)?  (One host read, once per id tensor: the caller keeps the answer on the tensor.)"""
+    return ids.numel() == 0 or (int(ids.max()) < bound and int(ids.min()) >= 0)
+
+
 class DeviceRand:
     device_draws = True     # draws are made on the device in whatever order / shape the fast path needs (no tape)
 
@@ -79,6 +84,30 @@ class DeviceRand:
             return src[torch.randperm(src.size(0), device=src.device)]
         out = torch.empty_like(src)
         L.call("bkg_permute_gather_i64", L.ptr(src), src.numel(), self._draw_seed(), L.ptr(out), L.stream())
+        return out
+
+    def shuffle_repeat(self, src, repeat):
+        """``src.repeat(repeat)[randperm(repeat * len(src))]`` (the negatives' relation ids, reference kge_module.py:97-100)
+        in one launch, without the repeated copy; takes the draw ``shuffle`` would have taken."""
+        from . import _lib as L
+        src = src.contiguous()
+        if src.dtype != torch.int64 or src.dim() != 1 or not src.is_cuda or repeat < 1:
+            return self.shuffle(src.repeat(repeat))
+        out = torch.empty(src.numel() * int(repeat), dtype=torch.int64, device=src.device)
+        small = getattr(src, "_bkg_u8", None)            # a one-byte image of ids < 256, kept on the tensor at this version
+        if small is None or small[0] != src._version:
+            small = None
+            if src.numel() >= (1 << 16) and not torch.cuda.is_current_stream_capturing() and max_below(src, 256):
+                img = torch.empty(src.numel(), dtype=torch.uint8, device=src.device)
+                L.call("bkg_narrow_i64_u8", L.ptr(src), src.numel(), L.ptr(img), L.stream())
+                small = src._bkg_u8 = (src._version, img)
+            elif not torch.cuda.is_current_stream_capturing():
+                src._bkg_u8 = (src._version, None)
+        seed = self._draw_seed()
+        if small is not None and small[1] is not None:
+            L.call("bkg_permute_gather_repeat_u8", L.ptr(small[1]), src.numel(), int(repeat), seed, L.ptr(out), L.stream())
+        else:
+            L.call("bkg_permute_gather_repeat_i64", L.ptr(src), src.numel(), int(repeat), seed, L.ptr(out), L.stream())
         return out
 
     def grouped_types(self, edge_type, repeat, num_relations):

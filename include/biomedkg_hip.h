@@ -540,6 +540,13 @@ int bkg_negative_sample_blocks(const void* blocks, int32_t n_blocks, int64_t n_c
                                int64_t* out_tail, int64_t* out_type, int32_t* count, void* workspace,
                                int64_t workspace_bytes, void* stream);
 int bkg_permute_gather_i64(const int64_t* src, int64_t n, uint64_t seed, int64_t* out, void* stream);
+/* out[i] = src[pi(i) % n_src], i < n_src * repeat, pi a keyed bijection of that range: edge_type.repeat(k)[randperm(k E)] of
+ * reference biomedkg/kge_module.py:97-100 in one launch, without the repeated copy. */
+int bkg_permute_gather_repeat_i64(const int64_t* src, int64_t n_src, int64_t repeat, uint64_t seed, int64_t* out, void* stream);
+/* ... from a one-byte image of the ids (values < 256; bkg_narrow_i64_u8 makes it once per id tensor): the same outputs for
+ * the same seed, the random reads stay in the L2. */
+int bkg_narrow_i64_u8(const int64_t* src, int64_t n, uint8_t* out, void* stream);
+int bkg_permute_gather_repeat_u8(const uint8_t* src, int64_t n_src, int64_t repeat, uint64_t seed, int64_t* out, void* stream);
 /* torch.randperm over the REAL rows of a padded mini-batch (GGD's corruption, reference biomedkg/model/gcl.py:70-71, inside
  * a captured step): out[i] = pi(i) for i < n_dev[0] (device scalar), pi a bijection of [0, n_dev[0]) keyed by seed and the
  * device replay counter `epoch` (NULL: the library-wide counter of bkg_set_rng_epoch, if one is set); out[i] = i for

@@ -201,7 +201,11 @@ def test_c3_as_timed_bf16_path_against_fp64_with_the_same_rounding_points():
             drawn["neg_type"] = super().shuffle(src)
             return drawn["neg_type"]
 
-        def grouped_types(self, edge_type, repeat, num_relations):     # (the form the timed step takes)
+        def shuffle_repeat(self, src, repeat):                         # (the form the timed step takes: the literal ids)
+            drawn["neg_type"] = super().shuffle_repeat(src, repeat)
+            return drawn["neg_type"]
+
+        def grouped_types(self, edge_type, repeat, num_relations):     # (BKG_GROUPED_NEG_TYPES=1)
             drawn["neg_type"] = super().grouped_types(edge_type, repeat, num_relations)
             return drawn["neg_type"]
 

@@ -114,6 +114,23 @@ def test_uniform_over_the_free_cells():
     assert chi2 < 255 + 6 * (2 * 255) ** 0.5, chi2          # mean 255, sd ~22.6 for 255 dof
 
 
+@pytest.mark.parametrize("n,k", [(1, 1), (3, 4), (1000, 1), (4097, 3), (100_003, 10)])
+def test_shuffled_repeat_is_repeat_then_randperm(n, k):
+    """``DeviceRand.shuffle_repeat(src, k)`` (bkg_permute_gather_repeat_i64) = ``src.repeat(k)[randperm(k n)]`` of reference
+    kge_module.py:97-100 without the repeated copy: every value exactly k times, another arrangement per draw, no trace of
+    the source order."""
+    from biomedkg_amd import rand as R
+    r = R.DeviceRand(seed=9)
+    src = torch.arange(n, dtype=torch.int64, device=DEV) * 5 + 2
+    a, b = r.shuffle_repeat(src, k), r.shuffle_repeat(src, k)
+    want = torch.sort(src.repeat(k)).values
+    assert a.numel() == n * k and torch.equal(torch.sort(a).values, want) and torch.equal(torch.sort(b).values, want)
+    if n >= 1000:
+        assert not torch.equal(a, b)
+        pos = ((a - 2) // 5).double()                                        # the source index each output came from
+        assert float((pos[1:] - pos[:-1]).abs().mean()) > 0.2 * n            # neighbours come from far apart
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 1000, 4096, 100_003])
 def test_permute_gather_is_a_bijection(n):
     from biomedkg_amd import rand as R
@@ -147,7 +164,7 @@ def test_kge_module_uses_device_sampler():
     assert torch.isfinite(loss)
 
 
-def test_grouped_negative_types_are_the_same_typed_negatives():
+def test_grouped_negative_types_are_the_same_typed_negatives(monkeypatch):
     """The negatives' relation ids grouped by relation (ops.grouped_types) instead of ``repeat(k)[randperm]`` (reference
     kge_module.py:97-100): the same multiset of ids; its own relation order is the identity with the positives' counts
     times k; the fused step over it equals the unfused decode + BCE route over the SAME tensors; the pairing with the
@@ -155,6 +172,7 @@ def test_grouped_negative_types_are_the_same_typed_negatives():
     with the frequency the independent shuffle gives it; and the literal form is still there behind the flag."""
     from types import SimpleNamespace
     from biomedkg_amd import kge_module as KM, ops, rand as R, synthetic
+    monkeypatch.setattr(KM, "GROUPED_NEG_TYPES", True)          # (opt-in since round 6: BKG_GROUPED_NEG_TYPES=1)
     g = synthetic.primekg_like(3000, 40_000, 8, seed=1)
     ei, et = g["edge_index"].to(DEV), g["edge_type"].to(DEV)
     m = KM.KGEModule("rgcn", "dismult", 32, 32, 32, 2, 8, 1, "cosine", 1e-3, 0.1, "none", 3, "random").to(DEV)
@@ -177,15 +195,14 @@ def test_grouped_negative_types_are_the_same_typed_negatives():
     ref = torch.nn.functional.binary_cross_entropy_with_logits(torch.cat([sp, sn]), torch.cat([torch.ones_like(sp), torch.zeros_like(sn)]))
     assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
     assert torch.allclose(npred, sn, rtol=1e-4, atol=1e-5)
-    # the literal form behind the flag
-    was = KM.GROUPED_NEG_TYPES
-    KM.GROUPED_NEG_TYPES = False
-    try:
-        with R.use(R.DeviceRand(seed=2)):
-            _, net3 = m.sample_neg_edges(ei, et)
-    finally:
-        KM.GROUPED_NEG_TYPES = was
+    # the literal form (the default): repeat(k)[randperm] in one launch, a fresh arrangement every draw
+    monkeypatch.setattr(KM, "GROUPED_NEG_TYPES", False)
+    with R.use(R.DeviceRand(seed=2)):
+        _, net3 = m.sample_neg_edges(ei, et)
+        _, net4 = m.sample_neg_edges(ei, et)
+    monkeypatch.setattr(KM, "GROUPED_NEG_TYPES", True)
     assert not torch.equal(net3, net) and torch.equal(torch.sort(net3).values, net)
+    assert not torch.equal(net4, net3) and torch.equal(torch.sort(net4).values, net)
     # uniform pairing: ids 0..9, two relations with 3 + 6 positives; negatives of relation 0 must be spread over the free
     # cells like those of relation 1 (a position-dependent sampler would put relation 0 -- always first -- on fixed cells)
     n = 12
@@ -206,7 +223,7 @@ def test_grouped_negative_types_are_the_same_typed_negatives():
         assert float((p - want).abs().max()) < 6 * (want / (draws * cnt)) ** 0.5 + 1e-9
 
 
-def test_dense_batches_shuffle_their_negative_types():
+def test_dense_batches_shuffle_their_negative_types(monkeypatch):
     """on a tiny dense batch PyG's sample size exceeds the population and the sampler enumerates the cells in
     (head, tail) order -- NOT an exchangeable order, so relation-grouped ids would pair relation id with head id
     monotonically.  There the ids are shuffled (reference kge_module.py:97-100), whatever GROUPED_NEG_TYPES says."""
@@ -214,7 +231,7 @@ def test_dense_batches_shuffle_their_negative_types():
     pe = torch.tensor([[0, 1, 2, 3], [1, 2, 3, 0]], device=DEV)      # 4 nodes: 12 off-diagonal cells, 4 positives, 8 free
     pt = torch.tensor([0, 0, 1, 1], device=DEV)
     m = KM.KGEModule("rgcn", "dismult", 8, 8, 8, 2, 2, 1, "cosine", 1e-3, 0.1, "none", 2, "random").to(DEV)
-    assert KM.GROUPED_NEG_TYPES
+    monkeypatch.setattr(KM, "GROUPED_NEG_TYPES", True)
     monotone = 0
     heads_of_rel0 = torch.zeros(4, device=DEV)
     with R.use(R.DeviceRand(seed=3)):

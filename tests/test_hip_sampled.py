@@ -123,6 +123,9 @@ def test_padded_step_is_the_reference_step_on_the_real_part(decoder):
                     def shuffle(self, src):
                         return neg_type[:k].contiguous()
 
+                    def shuffle_repeat(self, src, repeat):
+                        return neg_type[:k].contiguous()
+
                     def grouped_types(self, *a):             # (the padded step's own ids, not a grouped list of its own)
                         return None
                 same = Same(sg.rand.seed)
