@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256, 2) void kge_onepass_mx_kernel(const KmArgs a) 
   auto issue = [&](int u, int nv, int np) {
     rid_s[u] = (int)((unsigned)nv >> 24);
     if (SCORES) pm_s[u] = np;
-    const __bf16* p = a.z + (unsigned)(nv & 0xffffff) * (unsigned)a.ldz + 8 * lig;      // (< 2^31 elements: checked)
+    // (a slot past the end of this group's list -- padding: the quad's four lists run to the longest, rounded up to 8 --
+    // loads row 0, a cache hit, instead of whatever entry the clamped position holds: 0.6 GB less off the fabric per launch)
+    const unsigned row = (R.e0 + u < R.end) ? (unsigned)(nv & 0xffffff) : 0u;
+    const __bf16* p = a.z + row * (unsigned)a.ldz + 8 * lig;                              // (< 2^31 elements: checked)
     val[u][0].load(p);
     val[u][1].load(p + 128);
   };
