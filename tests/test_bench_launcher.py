@@ -28,10 +28,12 @@ def test_children_get_the_rendezvous_environment_and_their_exit_code_comes_back(
     if torch.cuda.is_available():
         return                      # on a GPU box the real thing runs (tests/test_partition_hip.py)
     # no GPU here: each child must stop at "bench.py needs an MI355X" -- AFTER it has read its rank environment
-    out = _run({"BKG_BENCH_ONE_DEVICE": "1", "BKG_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
-    assert out.returncode != 0
-    assert out.stderr.count("needs an MI355X") == 2, out.stderr[-1500:]
-    assert out.stdout.strip() == ""
+    for mode, legs in (("replicas", 1), ("partition", 1), ("auto", 2)):      # auto (round 6): both regimes, one after the other
+        out = _run({"BKG_BENCH_ONE_DEVICE": "1", "BKG_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "1", "--warmup", "0",
+                   "--mode", mode)
+        assert out.returncode != 0
+        assert out.stderr.count("needs an MI355X") == 2 * legs, (mode, out.stderr[-1500:])
+        assert out.stdout.strip() == ""
 
 
 def test_world_size_must_match_gpus():
@@ -61,6 +63,11 @@ def test_under_an_outer_launcher_rank_zero_takes_over_and_the_others_leave():
     # kept as the ranks on request: this process IS rank 1 then (and stops at the missing GPU itself)
     kept = _run(dict(outer, RANK="1", LOCAL_RANK="1", BKG_BENCH_OUTER_RANKS="1"), *part)
     assert kept.returncode != 0 and kept.stderr.count("needs an MI355X") == 1
-    # the default mode over N GPUs (round 5: replicas -- nothing to fall back from) runs in the outer launcher's own processes
+    # the default mode over N GPUs (round 6: both regimes on fresh ranks): rank 0 takes over there too, the others leave
     own = _run(dict(outer, RANK="1", LOCAL_RANK="1"), "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert own.returncode == 0 and own.stdout.strip() == "" and own.stderr.strip() == ""
+    lead = _run(dict(outer, RANK="0", LOCAL_RANK="0"), "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert lead.returncode != 0 and lead.stderr.count("needs an MI355X") == 4, lead.stderr[-1500:]
+    # --mode replicas alone runs in the outer launcher's own processes (nothing to fall back from)
+    own = _run(dict(outer, RANK="1", LOCAL_RANK="1"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--mode", "replicas")
     assert own.returncode != 0 and own.stderr.count("needs an MI355X") == 1
