@@ -1895,7 +1895,8 @@ class _KgeBceLoss(torch.autograd.Function):
         # reads instead of the scorer's 2 T + the list walk's 2 T; d rel_emb as a one-hot product on the matrix cores).  Their
         # scores are not written (a training step never reads them): ``LazyScores`` computes them if somebody asks
         mx = (KGE_ONEPASS_MX and onepass and _FRAME["lazy"] and zt_bf16 and neg_ei.size(1) >= _SORTED_MIN_TRIPLETS
-              and 2 * neg_ei.size(1) < (1 << 31) and n <= (1 << 24) and r < 256 and zt.stride(0) % 8 == 0
+              and 2 * neg_ei.size(1) < (1 << 31) and n <= (1 << 24) and n * zt.stride(0) < (1 << 31) and r < 256
+              and zt.stride(0) % 8 == 0
               and bool(L.lib().bkg_kge_onepass_mx_ok(d, 1, r)))
         pos_one = None
         if owned is None:
