@@ -1894,7 +1894,11 @@ class _KgeBceLoss(torch.autograd.Function):
         # ... and then the step's NEGATIVES too, in a walk of their own over (node, role)-sorted lists built this step (2 T row
         # reads instead of the scorer's 2 T + the list walk's 2 T; d rel_emb as a one-hot product on the matrix cores).  Their
         # scores are not written (a training step never reads them): ``LazyScores`` computes them if somebody asks
+        # Only for negatives that come out of the library's uniform sampler (it marks its output ``_bkg_exchangeable``: a
+        # uniform subset of the free cells): the walk gives a node's whole list to ONE lane group -- lists of Poisson length
+        # -- where the two-pass form cuts a hub's list into slices
         mx = (KGE_ONEPASS_MX and onepass and _FRAME["lazy"] and zt_bf16 and neg_ei.size(1) >= _SORTED_MIN_TRIPLETS
+              and getattr(neg_ei, "_bkg_exchangeable", False)
               and 2 * neg_ei.size(1) < (1 << 31) and n <= (1 << 24) and n * zt.stride(0) < (1 << 31) and r < 256
               and zt.stride(0) % 8 == 0
               and bool(L.lib().bkg_kge_onepass_mx_ok(d, 1, r)))

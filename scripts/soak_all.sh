@@ -13,5 +13,6 @@ run fuzz_sampled_gcl python3 scripts/fuzz_sampled_gcl.py
 run fuzz_steps python3 scripts/fuzz_steps.py
 run fuzz_tiny python3 scripts/fuzz_tiny.py
 run fuzz_views_frames python3 scripts/fuzz_views_frames.py
+run fuzz_kge_mx python3 scripts/fuzz_kge_mx.py
 run soak_rings python3 scripts/soak_rings.py 60
 cat $out

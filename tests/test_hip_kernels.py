@@ -483,6 +483,7 @@ def test_training_pass_with_both_walks_matches_the_two_pass_negatives(monkeypatc
         pe = torch.randint(0, n, (2, t), device=dev, generator=g)
         pt = (torch.rand(t, device=dev, generator=g) ** 3 * r).long().clamp_(max=r - 1)
         ne = torch.randint(0, n, (2, t), device=dev, generator=g)
+        ne._bkg_exchangeable = True                     # (uniform pairs, as the library's sampler marks its own: no hubs)
         nt = torch.randint(0, r, (t,), device=dev, generator=g).sort().values
         z0, rel0 = torch.randn(n, d, device=dev) * 0.3, torch.randn(r, d, device=dev) * 0.3
         ops.onepass_stable(pe, pt)                      # (this pair of tensors has been seen: the lists pay)
@@ -503,6 +504,13 @@ def test_training_pass_with_both_walks_matches_the_two_pass_negatives(monkeypatc
             got.append((float(loss.detach()), pp.clone(), npred.clone(), z.grad.clone(), rel.grad.clone(), n_mx, n_fused))
         (la, pa, na, za, ra, mxa, fa), (lb, pb, nb_, zb, rb, mxb, fb) = got
         assert mxa == 1 and fa == 0 and mxb == 0 and fb == 1
+        # negatives that do not carry the sampler's mark (hand-made pairs may hold hubs) keep the two-pass form
+        monkeypatch.setattr(ops, "KGE_ONEPASS_MX", True)
+        del launches[:]
+        plain = ne.clone()
+        z, rel = z0.clone().requires_grad_(), rel0.clone().requires_grad_()
+        ops.kge_bce_loss(z, rel, pe, pt, plain, nt, ops.KGE_DISTMULT, reg=1e-2, lazy_scores=True)[0].backward()
+        assert launches.count("bkg_kge_onepass_mx_f32") == 0 and launches.count("bkg_kge_fused_bce_dev_f32") == 1
         assert abs(la - lb) <= 1e-6 * abs(lb)
         torch.testing.assert_close(pa, pb, rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(na, nb_, rtol=1e-4, atol=1e-4)
