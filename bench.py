@@ -1272,8 +1272,9 @@ def _last_line(stdout):
     return None
 
 
-def run_partition_ladder(args, argv=()):
+def run_partition_ladder(args, argv=(), deadline=None):
     """The node-partitioned step over N fresh ranks -> (rank 0's stdout, exit codes, text for stderr, attempts).
+    ``deadline`` (time.time() value): the whole run's budget -- an attempt gets what is left of it, or is not started.
 
     Over RCCL the GRAPHED sub-steps go first (BKG_BENCH_PARTITION_GRAPH=1: every sub-step one hipGraph replay -- an eager
     partitioned step costs the host 3.6-5 ms to enqueue, more than a rank's kernels take from four ranks on).  Captured
@@ -1297,28 +1298,43 @@ def run_partition_ladder(args, argv=()):
     direct = ({} if "BKG_DIRECT_ALL_TO_ALL" in os.environ else {"BKG_DIRECT_ALL_TO_ALL": "1"}) if backend == "nccl" else {}
     try_graphs = "BKG_BENCH_PARTITION_GRAPH" not in os.environ and backend == "nccl"
     attempts, notes = [], ""
+
+    def attempt(form, env, limit):
+        """One fenced attempt inside what is left of the whole run's budget (``deadline``): -> (stdout, codes, note) or None
+        when there is no time left for it (recorded in ``attempts``)."""
+        left = (deadline - time.time()) if deadline is not None else float("inf")
+        if left < 150:
+            attempts.append({"form": form, "ok": False, "why_not": f"not started: {left:.0f} s of the run's budget left"})
+            return None
+        return _run_ranks(args, env, min(limit, left - 60), min(setup, left - 90), argv)
+
+    out, codes = "", [1]
     if try_graphs:
-        limit = float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "75"))
-        out, codes, note = _run_ranks(args, dict(direct, BKG_BENCH_PARTITION_GRAPH="1"), limit, setup, argv)
-        why = graphed_line_refused(out) if all(c == 0 for c in codes) else f"exit codes {codes}"
-        attempts.append({"form": "graphed sub-steps" + (", in-place all-to-all" if direct else ""), "ok": why is None,
-                         "why_not": why})
-        if why is None:
-            return out, codes, note, attempts
-        notes += note + f"bench.py --gpus {n}: the graphed attempt is not used ({why}); running the eager step\n"
+        form = "graphed sub-steps" + (", in-place all-to-all" if direct else "")
+        got = attempt(form, dict(direct, BKG_BENCH_PARTITION_GRAPH="1"), float(os.environ.get("BKG_BENCH_GRAPH_ATTEMPT_S", "75")))
+        if got is not None:
+            out, codes, note = got
+            why = graphed_line_refused(out) if all(c == 0 for c in codes) else f"exit codes {codes}"
+            attempts.append({"form": form, "ok": why is None, "why_not": why})
+            if why is None:
+                return out, codes, note, attempts
+            notes += note + f"bench.py --gpus {n}: the graphed attempt is not used ({why}); running the eager step\n"
     eager_env = {"BKG_BENCH_PARTITION_GRAPH": "0"} if try_graphs else {}
-    out, codes, note = _run_ranks(args, dict(direct, **eager_env), eager_limit, setup, argv)
-    ok = all(c == 0 for c in codes) and _last_line(out) is not None
-    attempts.append({"form": "eager step" + (", in-place all-to-all" if direct else ""), "ok": ok,
-                     "why_not": None if ok else f"exit codes {codes}"})
-    if not ok and direct:
-        notes += note + (f"bench.py --gpus {n}: the eager step failed (exit codes {codes}); once more with the packed "
-                         "all_to_all_single exchanges (the library's default)\n")
-        out, codes, note = _run_ranks(args, dict(eager_env, BKG_DIRECT_ALL_TO_ALL="0"), eager_limit, setup, argv)
+    forms = [("eager step" + (", in-place all-to-all" if direct else ""), dict(direct, **eager_env))]
+    if direct:
+        forms.append(("eager step, packed all_to_all_single", dict(eager_env, BKG_DIRECT_ALL_TO_ALL="0")))
+    for form, env in forms:
+        got = attempt(form, env, eager_limit)
+        if got is None:
+            break
+        out, codes, note = got
         ok = all(c == 0 for c in codes) and _last_line(out) is not None
-        attempts.append({"form": "eager step, packed all_to_all_single", "ok": ok,
-                         "why_not": None if ok else f"exit codes {codes}"})
-    return out, codes, notes + note, attempts
+        attempts.append({"form": form, "ok": ok, "why_not": None if ok else f"exit codes {codes}"})
+        notes += note
+        if ok:
+            break
+        notes += f"bench.py --gpus {n}: {form} failed (exit codes {codes})\n"
+    return out, codes, notes, attempts
 
 
 _LEG_KEYS = ("mode", "value", "unit", "ms_per_step", "ms_per_step_median", "scaling", "ranks", "backend", "steps", "warmup",
@@ -1384,10 +1400,12 @@ def launch_ranks(args):
         bad = [c for c in codes if c != 0]
         raise SystemExit(max(abs(c) for c in bad) if bad else 0)
 
+    # the whole run's budget (the driver's own limit on a bench run is 30 minutes): every attempt is cut to what is left
+    deadline = time.time() + float(os.environ.get("BKG_BENCH_TOTAL_S", "1400"))
     if args.mode == "partition":
-        out, codes, note, _ = run_partition_ladder(args)
+        out, codes, note, _ = run_partition_ladder(args, deadline=deadline)
         finish(out, codes, note)
-    replicas_limit = float(os.environ.get("BKG_BENCH_REPLICAS_LIMIT_S", "600"))
+    replicas_limit = float(os.environ.get("BKG_BENCH_REPLICAS_LIMIT_S", "400"))
     if args.mode == "replicas":
         finish(*_run_ranks(args, {}, replicas_limit, setup))
     # auto: both legs, one line
@@ -1398,7 +1416,7 @@ def launch_ranks(args):
     sys.stderr.write(note_r)
     if line_r is None:
         sys.stderr.write(f"bench.py --gpus {n}: the replicas leg gave no line (exit codes {codes_r})\n")
-    out_p, codes_p, note_p, attempts = run_partition_ladder(args, ["--mode", "partition"])
+    out_p, codes_p, note_p, attempts = run_partition_ladder(args, ["--mode", "partition"], deadline=deadline)
     line_p = _last_line(out_p) if all(c == 0 for c in codes_p) else None
     sys.stderr.write(note_p)
     try:      # (RCCL's banner etc. went through the children; nothing of ours is buffered in C stdio here)

@@ -234,6 +234,29 @@ def test_without_a_partition_line_the_replicas_leg_is_the_headline(monkeypatch, 
     assert not any(a["ok"] for a in line["partition"]["attempts"])
 
 
+def test_attempts_stay_inside_the_runs_budget(monkeypatch, capsys):
+    """BKG_BENCH_TOTAL_S: what is left of the whole run's budget caps every attempt's limits, and an attempt that could not
+    get two and a half minutes is not started (the driver ends a bench run after 30 minutes: a line must be out before)."""
+    import time as _time
+    clock = {"t": 1000.0}
+    monkeypatch.setattr(_time, "time", lambda: clock["t"])
+    monkeypatch.setenv("BKG_BENCH_TOTAL_S", "1000")
+
+    def script(env, argv):
+        mode = argv[argv.index("--mode") + 1]
+        clock["t"] += 300.0 if mode == "replicas" else 350.0            # every leg / attempt takes this long
+        if mode == "replicas":
+            return _leg_line(mode, 8) + "\n", [0] * 8
+        return "", [-9] * 8                                              # every partition attempt fails
+    code, calls, lines = _launch(monkeypatch, capsys, script)
+    line = _check(lines[0], 8)
+    assert code == 0 and line["mode"] == "replicas"
+    att = line["partition"]["attempts"]
+    assert [a["ok"] for a in att] == [False, False, False] and "not started" in att[2]["why_not"]
+    assert len(calls) == 3                                               # replicas, graphed, eager; the packed retry had no time left
+    assert calls[1]["limit"] == 75.0 and calls[2]["limit"] <= 350.0 - 60.0 + 1e-9     # (1000 - 650 s left, minus the margin)
+
+
 def test_no_leg_at_all_is_a_failure(monkeypatch, capsys):
     code, calls, lines = _launch(monkeypatch, capsys, lambda env, argv: ("", [1] * 8))
     assert code != 0 and not lines
