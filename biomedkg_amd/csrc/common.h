@@ -97,6 +97,27 @@ __device__ __forceinline__ uint4 philox_keep4(uint64_t seed, uint64_t e, uint32_
   return philox4x32((uint32_t)q, (uint32_t)(q >> 32), stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// The same kind of keep decisions at a fifth of the cost, for ReDAF's dropout behind a K = 768 product (reference
+// biomedkg/utils/fusion.py:84; round 6): Philox4x32-7 is 28 quarter-rate 32-bit multiplies per four decisions, six here --
+// 0.49 -> 0.46 ms for the training call at the bench size; with no mixing at all it is 0.435 (docs/experiments.md).  Three rounds of
+// murmur3's 32-bit finaliser over (element group, seed, stream) give two words = four 16-bit fields, returned in the TOP
+// halves of four 32-bit values so that the callers' ``r >= p * 2^32`` comparisons stand (drop probability ceil(p * 2^16) /
+// 2^16: 0.100006 for p = 0.1).  Counter-based like the Philox stream: every kernel that asks about an element gets the same
+// answer.
+__device__ __forceinline__ uint32_t keep_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu;
+  x ^= x >> 13; x *= 0xc2b2ae35u;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint4 hash_keep4(uint64_t seed, uint64_t e, uint32_t stream_id) {
+  const uint32_t q = (uint32_t)(e >> 2), qh = (uint32_t)(e >> 34);
+  const uint32_t k0 = (uint32_t)seed ^ (stream_id * 0x9E3779B1u), k1 = (uint32_t)(seed >> 32) + qh * 0x85ebca6bu;
+  const uint32_t a = keep_mix32(keep_mix32(q ^ k0) + k1);
+  const uint32_t b = keep_mix32(a ^ ((q << 13) | (q >> 19)) ^ 0x68E31DA4u);
+  return make_uint4(a << 16, a & 0xffff0000u, b << 16, b & 0xffff0000u);
+}
+
 // Device fills WITHOUT the runtime's memset: a hipMemsetAsync recorded into a hipGraph re-executes wrongly on this
 // stack (ROCm 7.2: a 20 KB or 520 KB memset node leaves stale / non-zero words from the second replay on; 4 MB ones
 // behave) -- every fill of the library is a kernel of its own, so that every entry point can be captured.

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void redaf_combine_kernel(const float* __restr
       uchar4 k = *reinterpret_cast<const uchar4*>(keep + row * D + c);
       v.x = k.x ? v.x * ks : 0.f; v.y = k.y ? v.y * ks : 0.f; v.z = k.z ? v.z * ks : 0.f; v.w = k.w ? v.w * ks : 0.f;
     } else if (drop_p > 0.f) {
-      uint4 r = philox_keep4(seed, (uint64_t)(row0 + row) * D + c, stream_id);   // row0: this call's first row of the whole input
+      uint4 r = hash_keep4(seed, (uint64_t)(row0 + row) * D + c, stream_id);   // row0: this call's first row of the whole input
       v.x = r.x >= thresh ? v.x * ks : 0.f; v.y = r.y >= thresh ? v.y * ks : 0.f;
       v.z = r.z >= thresh ? v.z * ks : 0.f; v.w = r.w >= thresh ? v.w * ks : 0.f;
     }

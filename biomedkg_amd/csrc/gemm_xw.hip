@@ -64,7 +64,7 @@ struct XwArgs {
   // ReDAF epilogue (gemm_xw_kernel<..., REDAF>): C is the fp32 [M / 2, N] fused output, rows 2n / 2n + 1 of the product are
   // node n's two modality tokens
   const float* rd_scale;       // [2][N]  modal_weights * zeta
-  const uint8_t* rd_keep;      // nullable [M][N] dropout keep mask (replayed draws); else the in-kernel Philox stream
+  const uint8_t* rd_keep;      // nullable [M][N] dropout keep mask (replayed draws); else the in-kernel keep hash (hash_keep4)
   float rd_p; uint64_t rd_seed; uint32_t rd_stream; int64_t rd_row0;
   const uint32_t* rd_epoch;
 };
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
       // ReDAF.forward behind the product (reference biomedkg/utils/fusion.py:49-90): t = relu(x W^T + b) is this lane's
       // accumulator row; out[n] = mean_m relu(dropout(t[2n + m] * scale[m])) -- the two modality rows of a node are the
       // lanes l31 and l31 ^ 1 (lane = row in this kernel), so the [2n, D] transform never leaves the registers.  The
-      // Philox stream is indexed exactly as bkg_redaf_combine_f32 indexes it: the same masks, the same bits out.
+      // keep hash (common.h hash_keep4) is indexed exactly as bkg_redaf_combine_f32 indexes it: the same masks, the same bits out.
       const int mrow = l31 & 1;
       const float ks = (g.rd_keep || g.rd_p > 0.f) ? 1.0f / (1.0f - g.rd_p) : 1.0f;
       const uint32_t thresh = (uint32_t)fminf(g.rd_p * 4294967296.0f, 4294967295.0f);
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xw_kernel(XwArgs g, GemmEpilogue 
                 if (live) k = *reinterpret_cast<const uchar4*>(g.rd_keep + (int64_t)row * g.N + col);
                 v.x = k.x ? v.x * ks : 0.f; v.y = k.y ? v.y * ks : 0.f; v.z = k.z ? v.z * ks : 0.f; v.w = k.w ? v.w * ks : 0.f;
               } else if (g.rd_p > 0.f) {
-                const uint4 r = philox_keep4(g.rd_seed, (uint64_t)(g.rd_row0 + row) * g.N + col, sid);
+                const uint4 r = hash_keep4(g.rd_seed, (uint64_t)(g.rd_row0 + row) * g.N + col, sid);
                 v.x = r.x >= thresh ? v.x * ks : 0.f; v.y = r.y >= thresh ? v.y * ks : 0.f;
                 v.z = r.z >= thresh ? v.z * ks : 0.f; v.w = r.w >= thresh ? v.w * ks : 0.f;
               }
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
     const uint32_t cb = ring_lds + (uint32_t)(XK_NS * SLOT + (wave * 32 + 4 * fq) * 4);
     if constexpr (REDAF) {
       // ReDAF.forward behind the product (reference biomedkg/utils/fusion.py:49-90), as gemm_xw_kernel<.., REDAF> runs it:
-      // the two modality rows of a node are the lanes fr and fr ^ 1; the Philox stream is indexed exactly as
+      // the two modality rows of a node are the lanes fr and fr ^ 1; the keep hash (hash_keep4) is indexed exactly as
       // bkg_redaf_combine_f32 indexes it (the same masks)
       const int mrow = fr & 1;
 #pragma unroll
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
           const float4 sc = ch ? xk_const4<1024 + 64>(cb + 1024 * mrow) : xk_const4<1024>(cb + 1024 * mrow);
           v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
           if (g.rd_p > 0.f) {
-            const uint4 r = philox_keep4(g.rd_seed, (uint64_t)(g.rd_row0 + row) * g.N + col, sid);
+            const uint4 r = hash_keep4(g.rd_seed, (uint64_t)(g.rd_row0 + row) * g.N + col, sid);
             v.x = r.x >= thresh ? v.x * keep_scale : 0.f; v.y = r.y >= thresh ? v.y * keep_scale : 0.f;
             v.z = r.z >= thresh ? v.z * keep_scale : 0.f; v.w = r.w >= thresh ? v.w * keep_scale : 0.f;
           }
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(512) void gemm_xw8k_kernel(XwArgs g, GemmEpilogue e
       }
     }
   };
-  // The two waves of a SIMD (w and w + 4) would run in lockstep -- matrix work together, epilogue (VALU, Philox, stores: no
+  // The two waves of a SIMD (w and w + 4) would run in lockstep -- matrix work together, epilogue (VALU, keep hash, stores: no
   // MFMA) together.  Waves 4-7 therefore DEFER each tile's epilogue behind the next tile's barrier (MI355X_MICROARCH.md
   // "Two waves per SIMD", item 9): after every barrier waves 0-3 multiply while waves 4-7 finish their previous tile, then
   // the roles swap.  Their stores come one iteration later, so their vmcnt ladder starts one step later.

@@ -2539,7 +2539,7 @@ def redaf_fusion(x, w_t, b_t, scale, drop: Dropout = None):
     every training step (nothing to cache, unlike AttentionFusion), so the ``[M n, D]`` transform must not make an HBM
     round trip per step: like ``attention_fusion`` it runs in node chunks -- 4,096 nodes = 8,192 x 768 fp32 = 25 MB --
     and the combine kernel reads each chunk's ``t`` out of the Infinity Cache right behind the product (at n = 130,000:
-    one 25 MB scratch instead of an 800 MB intermediate; the Philox stream is indexed by the GLOBAL row, so the masks
+    one 25 MB scratch instead of an 800 MB intermediate; the keep hash is indexed by the GLOBAL row, so the masks
     do not depend on the chunking)."""
     L.require_cuda(x, w_t, b_t, scale)
     n, m, d = x.shape

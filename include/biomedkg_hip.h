@@ -32,7 +32,7 @@ const char* bkg_last_error(void); /* (host) thread-local text of the last failur
 int bkg_set_deterministic_workspace(float* workspace, int64_t floats);
 
 /* hipGraph replay of a captured training step (biomedkg_amd/graphs.py): kernel arguments are frozen at capture, so
- * the in-kernel Philox streams (layer dropout of bkg_spmm_csr_f32, bkg_mask_cast_bf16, bkg_redaf_combine_f32) add
+ * the in-kernel Philox streams (layer dropout of bkg_spmm_csr_f32, bkg_mask_cast_bf16) and ReDAF's keep hash (bkg_redaf_combine_f32, bkg_redaf_fused_xw) add
  * `*epoch << 16` to their stream id -- a DEVICE counter the captured step increments once per replay.  NULL = off. */
 int bkg_set_rng_epoch(const uint32_t* epoch);
 
@@ -589,18 +589,19 @@ int bkg_attn_fuse_f32(const float* qkv, int64_t ld, int64_t n, int32_t M, int32_
  * combined row out[i] = c_0 x_{i,0} + c_1 x_{i,1} (bf16), over which the V projection then runs. */
 int bkg_attn_scores_combine_bf16(const void* t, int64_t ldt, const void* x, int64_t ldx, int64_t n, int32_t D,
                                  const float* u, const float* w, float c0, void* out, int64_t ldo, void* stream);
-/* ReDAF dropout: `keep` (explicit mask, [n*M, D] bytes) or, when NULL and drop_p > 0, an in-kernel Philox stream keyed by
+/* ReDAF dropout: `keep` (explicit mask, [n*M, D] bytes) or, when NULL and drop_p > 0, an in-kernel counter-based keep hash
+ * (three rounds of a 32-bit mixer per four elements, 16-bit thresholds: drop probability ceil(drop_p * 2^16) / 2^16) keyed by
  * (seed, stream_id) -- the caller advances stream_id on every call, as nn.Dropout draws a fresh mask per forward. */
 int bkg_redaf_combine_f32(const float* t, int64_t ld, int64_t n, int32_t M, int32_t D, const float* scale,
                           const uint8_t* keep, float drop_p, uint64_t seed, uint32_t stream_id,
-                          int64_t row0 /* index of t's first row in the whole [n_total * M, D] input: the Philox stream is
+                          int64_t row0 /* index of t's first row in the whole [n_total * M, D] input: the keep hash is
                                           keyed by the global element, so a chunked call draws the same mask */,
                           float* out, int64_t ldo, void* stream);
 /* ReDAF.forward (biomedkg/utils/fusion.py:49-90, two modalities) as ONE launch: the scale / dropout / ReLU / modality mean run
  * in the epilogue of the product x W^T (the two token rows of a node are adjacent lanes of an accumulator tile), so the
  * [2n, D] transform is never written.  A [rows, K] fp32 or bf16 (rows = 2 n, node-major), Wt the [N, K] bf16 weight image of
- * bkg_weight_to_bf16, bias [N], scale [2, N]; dropout as in bkg_redaf_combine_f32 (keep mask [rows, N], or drop_p + the Philox
- * stream (seed, stream_id) indexed by row * N + column: the same masks, bit-equal results); out fp32 [n, N]. */
+ * bkg_weight_to_bf16, bias [N], scale [2, N]; dropout as in bkg_redaf_combine_f32 (keep mask [rows, N], or drop_p + the keep
+ * hash of (seed, stream_id) indexed by row * N + column: the same masks, bit-equal results); out fp32 [n, N]. */
 int bkg_redaf_fused_xw(int64_t rows, int64_t N, int64_t K, const void* A, int32_t a_is_bf16, int64_t lda, const void* Wt,
                        int64_t ldw, const float* bias, const float* scale, const uint8_t* keep, float drop_p, uint64_t seed,
                        uint32_t stream_id, float* out, int64_t ldo, void* stream);

@@ -64,3 +64,50 @@ def test_shapes_outside_the_streaming_product_keep_the_two_kernel_form():
             torch.testing.assert_close(out, ref, rtol=2e-2 if mode == "bf16" else 1e-4, atol=2e-2 if mode == "bf16" else 1e-4)
     finally:
         ops.set_matmul_precision(prev)
+
+
+def _keep_mask(rows, d, p, seed, stream_id, row0=0):
+    """The keep decisions of the in-kernel hash (csrc/common.h hash_keep4) for a [rows, d] input: bkg_redaf_combine_f32 with
+    one modality over ones."""
+    from biomedkg_amd import _lib as L
+    t = torch.ones(rows, d, device=DEV)
+    scale = torch.ones(1, d, device=DEV)
+    out = torch.empty(rows, d, device=DEV)
+    L.call("bkg_redaf_combine_f32", L.ptr(t), d, rows, 1, d, L.ptr(scale), None, p, seed, stream_id, row0, L.ptr(out), d,
+           L.stream())
+    kept = out > 0
+    torch.testing.assert_close(out[kept], torch.full_like(out[kept], 1.0 / (1.0 - p)), rtol=1e-6, atol=0)      # kept values are scaled
+    return kept
+
+
+def test_keep_hash_statistics():
+    """Round 6: ReDAF's masks come from a 32-bit mixer with 16-bit thresholds (Philox4x32-7 before).  Drop rate as asked;
+    neighbours along a row (inside and across the 4-element groups one hash serves), down a column, between consecutive
+    calls (stream ids) and between seeds are uncorrelated; a chunked call (row0) continues the whole input's mask."""
+    rows, d, p = 4096, 768, 0.1
+    k = _keep_mask(rows, d, p, 1234, 7)
+    n = k.numel()
+    rate = 1.0 - float(k.float().mean())
+    assert abs(rate - p) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-5, rate
+    kf = k.float() - (1 - p)
+    var = p * (1 - p)
+
+    def corr(a, b):
+        return float((a * b).mean()) / var
+
+    tol = 5.0 / n ** 0.5
+    for shift in (1, 2, 3, 4, 5, 8, 16):                       # along a row
+        assert abs(corr(kf[:, :-shift], kf[:, shift:])) < tol, shift
+    for shift in (1, 2, 3, 7):                                 # down a column (rows 2i / 2i + 1: the two modalities of a node)
+        assert abs(corr(kf[:-shift], kf[shift:])) < tol, shift
+    for other in (_keep_mask(rows, d, p, 1234, 8), _keep_mask(rows, d, p, 1235, 7), _keep_mask(rows, d, p, 1234 + (1 << 32), 7)):
+        assert abs(corr(kf, other.float() - (1 - p))) < tol
+    # per-column and per-row rates: no column or row is favoured (768 / 4096 binomials, 6 sigma)
+    assert float((k.float().mean(0) - (1 - p)).abs().max()) < 6 * (var / rows) ** 0.5
+    assert float((k.float().mean(1) - (1 - p)).abs().max()) < 6 * (var / d) ** 0.5
+    # other probabilities, including the ends of the threshold's range
+    for q in (0.5, 0.9, 1e-3):
+        r = 1.0 - float(_keep_mask(rows, d, q, 99, 1).float().mean())
+        assert abs(r - q) < 5 * (q * (1 - q) / n) ** 0.5 + 2e-5, (q, r)
+    # a call over rows [1000, 1512) of the input draws that part of the whole input's mask
+    assert torch.equal(_keep_mask(512, d, p, 1234, 7, row0=1000), k[1000:1512])
