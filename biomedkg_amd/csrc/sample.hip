@@ -52,6 +52,30 @@ __global__ void random_walk_kernel(const int32_t* __restrict__ rowptr, const int
 // For every frontier node f: up to `fanout` DISTINCT in-edges chosen uniformly (all of them when deg <= fanout),
 // over the DESTINATION-sorted CSR.  out_pos[f, j] = CSR position of the j-th pick, or -1.
 // One thread per frontier node; Floyd's algorithm (exactly `fanout` draws, no rejection loop).
+// Floyd's draw of `fanout` distinct positions out of a row of `deg` > fanout entries: step s takes t uniform in [0, j],
+// j = deg - fanout + s, or j itself if t was taken before (pyg-lib's neighbor_sample; oracle/samplers.py).  The picks live
+// in REGISTERS: both loops are fully unrolled (a dynamically indexed array went to scratch -- 272 bytes per lane, up to 450
+// dependent scratch reads per thread: the launch took 61 us for 25 k frontier rows, round 6: 8 us).  `fanout` is a kernel
+// argument, so the guards are scalar branches.
+template <int MAXF, typename Draw>
+__device__ __forceinline__ void floyd_positions(int beg, int deg, int fanout, Draw draw, int32_t* __restrict__ out) {
+  int picked[MAXF];
+#pragma unroll
+  for (int step = 0; step < MAXF; ++step) {
+    if (step < fanout) {
+      const int j = deg - fanout + step;
+      const int t = draw(step, (uint32_t)(j + 1));
+      bool taken = false;
+#pragma unroll
+      for (int q = 0; q < step; ++q) taken |= picked[q] == t;
+      picked[step] = taken ? j : t;
+    }
+  }
+#pragma unroll
+  for (int step = 0; step < MAXF; ++step)
+    if (step < fanout) out[step] = beg + picked[step];
+}
+
 template <int MAXF>
 __global__ void sample_neighbors_kernel(const int32_t* __restrict__ rowptr, const int64_t* __restrict__ frontier,
                                         int64_t n_frontier, int fanout, uint64_t seed, uint32_t hop,
@@ -65,17 +89,9 @@ __global__ void sample_neighbors_kernel(const int32_t* __restrict__ rowptr, cons
     for (int j = 0; j < fanout; ++j) out[j] = j < deg ? beg + j : -1;
     return;
   }
-  int picked[MAXF];
-  int n = 0;
-  for (int j = deg - fanout; j < deg; ++j) {   // Floyd: t uniform in [0, j]; take t, or j if t was taken
-    const int step = j - (deg - fanout);
-    int t = (int)(tape ? below(tape[v * TAPE_STRIDE + step], (uint32_t)(j + 1))
-                       : rng_below(seed, (uint64_t)f * 64 + (uint64_t)step, hop, (uint32_t)(j + 1)));
-    bool seen = false;
-    for (int q = 0; q < n; ++q) seen |= picked[q] == t;
-    picked[n++] = seen ? j : t;
-  }
-  for (int j = 0; j < fanout; ++j) out[j] = beg + picked[j];
+  floyd_positions<MAXF>(beg, deg, fanout, [&](int step, uint32_t bound) {
+    return (int)(tape ? below(tape[v * TAPE_STRIDE + step], bound) : rng_below(seed, (uint64_t)f * 64 + (uint64_t)step, hop, bound));
+  }, out);
 }
 
 // ---- GraphSAINT batch = distinct walk nodes (ascending) + ALL edges among them, with no host round trip: every
@@ -149,8 +165,10 @@ __global__ void nb_begin_kernel(const int64_t* __restrict__ seeds, int64_t n_see
 template <int MAXF>
 __global__ void nb_sample_kernel(const int32_t* __restrict__ rowptr, const int64_t* __restrict__ n_id,
                                  const int64_t* __restrict__ ctr, int fanout, uint64_t seed, uint32_t hop,
-                                 const uint32_t* __restrict__ tape, int32_t* __restrict__ out_pos) {
+                                 const uint32_t* __restrict__ tape, int32_t* __restrict__ out_pos,
+                                 int32_t* __restrict__ new_flag, int64_t n_nodes) {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n_nodes) new_flag[f] = 0;      // (the launch covers n_nodes threads: the hop's "new node" marks start clear)
   const int64_t lo = ctr[0], cnt = ctr[1] - ctr[0];
   if (f >= cnt) return;
   const int64_t v = n_id[lo + f];
@@ -160,17 +178,9 @@ __global__ void nb_sample_kernel(const int32_t* __restrict__ rowptr, const int64
     for (int j = 0; j < fanout; ++j) out[j] = j < deg ? beg + j : -1;
     return;
   }
-  int picked[MAXF];
-  int n = 0;
-  for (int j = deg - fanout; j < deg; ++j) {   // Floyd, as sample_neighbors_kernel
-    const int step = j - (deg - fanout);
-    int t = (int)(tape ? below(tape[v * TAPE_STRIDE + step], (uint32_t)(j + 1))
-                       : rng_below(seed, (uint64_t)f * 64 + (uint64_t)step, hop, (uint32_t)(j + 1)));
-    bool taken = false;
-    for (int q = 0; q < n; ++q) taken |= picked[q] == t;
-    picked[n++] = taken ? j : t;
-  }
-  for (int j = 0; j < fanout; ++j) out[j] = beg + picked[j];
+  floyd_positions<MAXF>(beg, deg, fanout, [&](int step, uint32_t bound) {      // (as sample_neighbors_kernel)
+    return (int)(tape ? below(tape[v * TAPE_STRIDE + step], bound) : rng_below(seed, (uint64_t)f * 64 + (uint64_t)step, hop, bound));
+  }, out);
 }
 
 // per candidate slot: valid pick?  (and mark the not-yet-seen sources)
@@ -207,10 +217,10 @@ __global__ void nb_append_edges_kernel(const int32_t* __restrict__ pos, const in
                                        const int32_t* __restrict__ perm, const int64_t* __restrict__ n_id,
                                        const int64_t* __restrict__ ctr, int fanout, int64_t slots, int64_t edge_cap,
                                        int64_t* __restrict__ e_src, int64_t* __restrict__ e_dst,
-                                       int64_t* __restrict__ e_id) {
+                                       int64_t* __restrict__ e_id, const int32_t* __restrict__ bias) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= slots || !eflag[k]) return;
-  const int64_t o = ctr[2] + offs[k];
+  const int64_t o = ctr[2] + offs[k] - (bias ? bias[0] : 0);      // (bias: the hop's new nodes, when ONE scan ran over both flag arrays)
   if (o >= edge_cap) return;
   const int32_t p = pos[k];
   e_src[o] = col[p];
@@ -221,10 +231,10 @@ __global__ void nb_append_edges_kernel(const int32_t* __restrict__ pos, const in
 // after both appends: the new nodes become the frontier
 __global__ void nb_advance_kernel(const int32_t* __restrict__ new_flag, const int32_t* __restrict__ node_offs,
                                   int64_t n_nodes, const int32_t* __restrict__ eflag, const int32_t* __restrict__ edge_offs,
-                                  int64_t slots, int64_t* __restrict__ ctr) {
+                                  int64_t slots, int64_t* __restrict__ ctr, const int32_t* __restrict__ bias) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const int64_t new_nodes = node_offs[n_nodes - 1] + new_flag[n_nodes - 1];
-  const int64_t new_edges = edge_offs[slots - 1] + eflag[slots - 1];
+  const int64_t new_edges = edge_offs[slots - 1] + eflag[slots - 1] - (bias ? bias[0] : 0);
   ctr[0] = ctr[1];
   ctr[1] += new_nodes;
   ctr[2] += new_edges;
@@ -305,8 +315,12 @@ extern "C" int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* fronti
                                     uint64_t seed, uint32_t hop, const uint32_t* tape, int32_t* out_pos, void* stream) {
   BKG_ARG(n_frontier >= 0 && fanout > 0 && fanout <= 64, "bkg_sample_neighbors: 1 <= fanout <= 64");
   if (n_frontier == 0) return 0;
-  hipLaunchKernelGGL(sample_neighbors_kernel<64>, dim3(ceil_div(n_frontier, 256)), dim3(256), 0, (hipStream_t)stream,
-                     rowptr, frontier, n_frontier, fanout, seed, hop, tape, out_pos);
+  if (fanout <= 32)
+    hipLaunchKernelGGL(sample_neighbors_kernel<32>, dim3(ceil_div(n_frontier, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rowptr, frontier, n_frontier, fanout, seed, hop, tape, out_pos);
+  else
+    hipLaunchKernelGGL(sample_neighbors_kernel<64>, dim3(ceil_div(n_frontier, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rowptr, frontier, n_frontier, fanout, seed, hop, tape, out_pos);
   return check_launch("bkg_sample_neighbors");
 }
 
@@ -316,8 +330,8 @@ extern "C" int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* fronti
 // n_nodes * max fanout always suffices).
 extern "C" int64_t bkg_neighbor_workspace_bytes(int64_t n_nodes, int32_t max_fanout) {
   size_t a = 0;
-  rocprim::exclusive_scan(nullptr, a, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)(n_nodes * max_fanout),
-                          rocprim::plus<int32_t>());
+  rocprim::exclusive_scan(nullptr, a, (int32_t*)nullptr, (int32_t*)nullptr, 0, (size_t)(n_nodes * (max_fanout + 1)),
+                          rocprim::plus<int32_t>());      // (+ 1: the node flags in front of the slots' when one scan takes both)
   return (int64_t)a + 256;
 }
 
@@ -339,23 +353,35 @@ extern "C" int bkg_neighbor_hop(const int32_t* rowptr, const int32_t* col, const
   BKG_ARG(n_nodes > 0 && fanout > 0 && fanout <= 64 && n_nodes * fanout < (1ll << 31), "bkg_neighbor_hop: bad sizes");
   hipStream_t s = (hipStream_t)stream;
   const int64_t slots = n_nodes * fanout;
-  hipLaunchKernelGGL(nb_sample_kernel<64>, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, rowptr, n_id, ctr, fanout, seed,
-                     hop, tape, pos);
-  fill_u32(new_flag, 0u, n_nodes, s);
+  if (fanout <= 32)
+    hipLaunchKernelGGL(nb_sample_kernel<32>, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, rowptr, n_id, ctr, fanout, seed,
+                       hop, tape, pos, new_flag, n_nodes);
+  else
+    hipLaunchKernelGGL(nb_sample_kernel<64>, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, rowptr, n_id, ctr, fanout, seed,
+                       hop, tape, pos, new_flag, n_nodes);
   hipError_t e = hipSuccess;
   hipLaunchKernelGGL(nb_flags_kernel, dim3(ceil_div(slots, 256)), dim3(256), 0, s, pos, col, ctr, fanout, slots, seen,
                      new_flag, eflag);
+  // the slots' flags right behind the nodes' (and the offsets alike): ONE scan over both -- the slots' offsets then start at
+  // the hop's number of new nodes, edge_offs[0], which the consumers take off (two launches less per hop, round 6)
+  const bool merged = eflag == new_flag + n_nodes && edge_offs == node_offs + n_nodes && n_nodes + slots < (1ll << 31);
   size_t bytes = (size_t)workspace_bytes;
-  e = rocprim::exclusive_scan(workspace, bytes, new_flag, node_offs, 0, (size_t)n_nodes, rocprim::plus<int32_t>(), s);
-  if (e != hipSuccess) { set_error("bkg_neighbor_hop: node scan", e); return (int)e; }
-  bytes = (size_t)workspace_bytes;
-  e = rocprim::exclusive_scan(workspace, bytes, eflag, edge_offs, 0, (size_t)slots, rocprim::plus<int32_t>(), s);
-  if (e != hipSuccess) { set_error("bkg_neighbor_hop: edge scan", e); return (int)e; }
+  if (merged) {
+    e = rocprim::exclusive_scan(workspace, bytes, new_flag, node_offs, 0, (size_t)(n_nodes + slots), rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) { set_error("bkg_neighbor_hop: scan", e); return (int)e; }
+  } else {
+    e = rocprim::exclusive_scan(workspace, bytes, new_flag, node_offs, 0, (size_t)n_nodes, rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) { set_error("bkg_neighbor_hop: node scan", e); return (int)e; }
+    bytes = (size_t)workspace_bytes;
+    e = rocprim::exclusive_scan(workspace, bytes, eflag, edge_offs, 0, (size_t)slots, rocprim::plus<int32_t>(), s);
+    if (e != hipSuccess) { set_error("bkg_neighbor_hop: edge scan", e); return (int)e; }
+  }
+  const int32_t* bias = merged ? edge_offs : nullptr;
   hipLaunchKernelGGL(nb_append_edges_kernel, dim3(ceil_div(slots, 256)), dim3(256), 0, s, pos, eflag, edge_offs, col, perm,
-                     n_id, ctr, fanout, slots, edge_cap, e_src, e_dst, e_id);
+                     n_id, ctr, fanout, slots, edge_cap, e_src, e_dst, e_id, bias);
   hipLaunchKernelGGL(nb_append_nodes_kernel, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, new_flag, node_offs, n_nodes,
                      ctr, seen, n_id);
-  hipLaunchKernelGGL(nb_advance_kernel, dim3(1), dim3(64), 0, s, new_flag, node_offs, n_nodes, eflag, edge_offs, slots, ctr);
+  hipLaunchKernelGGL(nb_advance_kernel, dim3(1), dim3(64), 0, s, new_flag, node_offs, n_nodes, eflag, edge_offs, slots, ctr, bias);
   return check_launch("bkg_neighbor_hop");
 }
 

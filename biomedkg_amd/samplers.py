@@ -66,8 +66,9 @@ class NeighborSampler:
             i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)      # noqa: E731
             i64 = lambda k: torch.empty(k, dtype=torch.int64, device=dev)      # noqa: E731
             cap = n * fan
-            st = self._st = dict(fan=fan, cap=cap, seen=i32(n), n_id=i64(n), ctr=i64(3), pos=i32(cap), new_flag=i32(n),
-                                 node_offs=i32(n), eflag=i32(cap), edge_offs=i32(cap), lut=i32(n), e_src=i64(cap),
+            flags, offs = i32(n + cap), i32(n + cap)     # the slots' flags right behind the nodes': one scan per hop takes both
+            st = self._st = dict(fan=fan, cap=cap, seen=i32(n), n_id=i64(n), ctr=i64(3), pos=i32(cap), new_flag=flags[:n],
+                                 node_offs=offs[:n], eflag=flags[n:], edge_offs=offs[n:], lut=i32(n), e_src=i64(cap),
                                  e_dst=i64(cap), e_id=i64(cap),
                                  ws=torch.empty(L.lib().bkg_neighbor_workspace_bytes(n, fan), dtype=torch.uint8, device=dev))
         return st

@@ -417,7 +417,9 @@ int bkg_sample_neighbors(const int32_t* rowptr, const int64_t* frontier, int64_t
  * original edge id) in (frontier row, pick) order), finish (global -> local ids).  Same draws and orders as
  * bkg_sample_neighbors driven hop by hop from the host.  Capacities: seen / n_id / lut / new_flag / node_offs: n_nodes;
  * pos / eflag / edge_offs: n_nodes * fanout; e_src / e_dst / e_id: edge_cap (n_nodes * the largest fan-out always
- * suffices: every node is expanded once); workspace of bkg_neighbor_workspace_bytes. */
+ * suffices: every node is expanded once); workspace of bkg_neighbor_workspace_bytes.  When eflag = new_flag + n_nodes and
+ * edge_offs = node_offs + n_nodes (one array each, the slots' part behind the nodes'), a hop runs ONE scan over both (the
+ * edge offsets as written then start at the hop's number of new nodes). */
 int64_t bkg_neighbor_workspace_bytes(int64_t n_nodes, int32_t max_fanout);
 int bkg_neighbor_begin(const int64_t* seeds, int64_t n_seeds, int64_t n_nodes, int32_t* seen, int64_t* n_id, int64_t* ctr,
                        void* stream);
