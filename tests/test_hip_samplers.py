@@ -196,7 +196,7 @@ def _oracle_graphs():
 
 
 @pytest.mark.parametrize("case", range(3))
-@pytest.mark.parametrize("fanouts", [(30, 30, 30), (5, 3)])
+@pytest.mark.parametrize("fanouts", [(30, 30, 30), (5, 3), (40, 33)])      # (40, 33: the 64-pick instance of the draw)
 def test_neighbor_sampler_equals_the_oracle_on_the_same_tape(case, fanouts):
     """NeighborLoader(num_neighbors=[30] * 3) (reference data_module.py:93-99): the device sampler and oracle/samplers.py
     (pyg-lib's neighbor_sample restated) fed the SAME tape of raw draws give the same batch: seeds first, the same nodes
