@@ -142,3 +142,37 @@ class use:
         global _current
         _current = self.prev
         return False
+
+
+# ---- the library's in-kernel keep decisions of ReDAF's dropout, restated (test infrastructure: pins the mask definition)
+def redaf_keep_mask(rows: int, d: int, p: float, seed: int, stream_id: int, row0: int = 0) -> torch.Tensor:
+    """``biomedkg_amd/csrc/common.h hash_keep4`` for the ``[rows, d]`` slice starting at global row ``row0`` of a ReDAF input
+    (reference ``biomedkg/utils/fusion.py:84``: ``nn.Dropout`` on the scaled transform -- WHICH elements are dropped is the
+    library's own counter-based choice; this restates it).  Element ``e = (row0 + row) * d + col``: the four elements of a
+    group ``q = e >> 2`` take the 16-bit fields of ``a = mix(mix(q ^ k0) + k1)`` and ``b = mix(a ^ rotl(q, 13) ^ c)`` (mix =
+    murmur3's 32-bit finaliser), kept iff ``field << 16 >= uint32(p * 2^32)``."""
+    import numpy as np
+    assert d % 4 == 0
+    m32 = np.uint64(0xFFFFFFFF)
+
+    def mix(x):
+        x = x & m32
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x85EBCA6B)) & m32
+        x ^= x >> np.uint64(13); x = (x * np.uint64(0xC2B2AE35)) & m32
+        x ^= x >> np.uint64(16)
+        return x
+
+    e = (np.uint64(row0) + np.arange(rows, dtype=np.uint64)[:, None]) * np.uint64(d) + np.arange(0, d, 4, dtype=np.uint64)[None, :]
+    q, qh = (e >> np.uint64(2)) & m32, (e >> np.uint64(34)) & m32
+    k0 = np.uint64((seed & 0xFFFFFFFF) ^ ((stream_id * 0x9E3779B1) & 0xFFFFFFFF))
+    k1 = (np.uint64((seed >> 32) & 0xFFFFFFFF) + ((qh * np.uint64(0x85EBCA6B)) & m32)) & m32
+    a = mix((mix(q ^ k0) + k1) & m32)
+    rot = ((q << np.uint64(13)) | (q >> np.uint64(19))) & m32
+    b = mix(a ^ rot ^ np.uint64(0x68E31DA4))
+    thresh = np.uint64(min(int(np.float32(p) * np.float32(4294967296.0)), 4294967295))
+    keep = np.empty((rows, d), dtype=bool)
+    keep[:, 0::4] = ((a << np.uint64(16)) & m32) >= thresh
+    keep[:, 1::4] = (a & np.uint64(0xFFFF0000)) >= thresh
+    keep[:, 2::4] = ((b << np.uint64(16)) & m32) >= thresh
+    keep[:, 3::4] = (b & np.uint64(0xFFFF0000)) >= thresh
+    return torch.from_numpy(keep)

@@ -111,3 +111,15 @@ def test_keep_hash_statistics():
         assert abs(r - q) < 5 * (q * (1 - q) / n) ** 0.5 + 2e-5, (q, r)
     # a call over rows [1000, 1512) of the input draws that part of the whole input's mask
     assert torch.equal(_keep_mask(512, d, p, 1234, 7, row0=1000), k[1000:1512])
+
+
+@pytest.mark.parametrize("rows,d,p,seed,stream_id,row0", [
+    (2048, 768, 0.1, 1234, 7, 0), (513, 256, 0.5, (5 << 32) + 99, 0xFFFF0003, 1000), (64, 512, 0.25, 2 ** 63 + 5, 1, 30_000_000),
+    (300, 64, 0.9, 0, 0, 2 ** 31)])
+def test_keep_hash_is_the_restated_one(rows, d, p, seed, stream_id, row0):
+    """The mask definition is pinned: ``oracle/rand.py redaf_keep_mask`` restates ``hash_keep4`` (64-bit seeds, stream ids
+    with the replay counter's high bits set, global rows past 2^34 / d -- the element index's high word) and the kernel's
+    decisions equal it bit for bit."""
+    from oracle.rand import redaf_keep_mask
+    got = _keep_mask(rows, d, p, seed, stream_id, row0=row0)
+    assert torch.equal(got.cpu(), redaf_keep_mask(rows, d, p, seed, stream_id, row0))
