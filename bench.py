@@ -20,8 +20,8 @@ fresh ranks, and prints ONE line (``launch_ranks``):
   north_star's node sharding: ONE graph, its nodes partitioned over the ranks (biomedkg_amd/partition.py): per conv layer a
   gather of the table rows a rank's in-edges read (forward) and of the output-gradient rows its out-edges point at
   (backward), every triplet scored by the owners of both its endpoints (no gradient rows cross the wire), flat-bucket
-  gradient all-reduce.  Round 5 measured each rank's compute on one GPU (scripts/simulate_ranks.py): at most 1.8-2.0x at 8
-  GPUs whatever the wire does -- a rank's share of a step that takes one GPU 8-9 ms is below the floor of
+  gradient all-reduce.  Rounds 5 and 6 measured each rank's compute on one GPU (scripts/simulate_ranks.py): at most
+  1.5-1.7x at 8 GPUs whatever the wire does -- a rank's share of a step that takes one GPU 8-9 ms is below the floor of
   the ~350 kernels that carry it;
 * ``replicas`` on the same line -- its own ``value`` / ``ms_per_step`` / ``"scaling": "weak"`` -- is the reference's own
   multi-GPU regime (Lightning DDP: train_gcl.py:63-68, configs/gcl.yaml:11): one PrimeKG++-shaped graph per rank, the ranks'

@@ -25,14 +25,13 @@ import torch
 sys.path.insert(0, ".")
 from biomedkg_amd import partition as P, synthetic  # noqa: E402
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for a in sys.argv[1:] if not a.startswith("--") and not a.endswith(".json")]
 GGD_MS, KGE_MS = (float(a) for a in (args[:2] + ["4.2", "6.3"][len(args[:2]):]))
 JSON_OUT = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
 MEASURED = None
 if "--measured" in sys.argv:
     _m = json.load(open(sys.argv[sys.argv.index("--measured") + 1]))
     MEASURED = {w["world"]: w for w in _m["worlds"] if "compute_ms" in w and w["compute_ms"]}
-args = [a for a in args if not a.endswith(".json")]
 LINK_GBS, LINKS = 153.0, 7          # xGMI: 7 point-to-point links per GPU, ~153 GB/s each (MI355X_MICROARCH.md)
 N, E, R, H = 130_000, 4_000_000, 30, 256
 # measured single-GPU pieces of the sub-steps (docs/experiments.md 9-7, scripts/attic/dev_time_calls.py, v28): what an exchange can hide under
